@@ -1,0 +1,117 @@
+"""ctypes binding of include/hermez_witness.h (no torch types cross this boundary)."""
+import ctypes
+import os
+
+R_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libhermez_witness.so")
+
+
+class HzError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("hz status %d: %s" % (status, msg))
+        self.status = status
+
+
+class ConstraintError(HzError):
+    """A `===` of the circuit failed; message mirrors circom_runtime's text."""
+
+    def __init__(self, instance, unit, cid, name, lhs, rhs):
+        RuntimeError.__init__(self, "Constraint doesn't match %d != %d (%s, instance %d unit %d)" % (lhs, rhs, name, instance, unit))
+        self.status = 3
+        self.instance, self.unit, self.constraint_id, self.name, self.lhs, self.rhs = instance, unit, cid, name, lhs, rhs
+
+
+def fr_to_bytes(vals):
+    return b"".join(int(v % R_MODULUS).to_bytes(32, "little") for v in vals)
+
+
+def fr_from_bytes(buf):
+    buf = bytes(buf)
+    return [int.from_bytes(buf[i:i + 32], "little") for i in range(0, len(buf), 32)]
+
+
+class hz_params(ctypes.Structure):
+    _fields_ = [("template_id", ctypes.c_int32), ("nTx", ctypes.c_int32), ("nLevels", ctypes.c_int32),
+                ("maxL1Tx", ctypes.c_int32), ("maxFeeTx", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("n_instances", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class hz_error(ctypes.Structure):
+    _fields_ = [("instance", ctypes.c_int32), ("unit", ctypes.c_int32), ("constraint_id", ctypes.c_int32),
+                ("lhs", ctypes.c_uint8 * 32), ("rhs", ctypes.c_uint8 * 32)]
+
+
+class hz_symbol(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("index", ctypes.c_uint64)]
+
+
+TEMPLATES = {"rollup-main": 0, "rollup-tx": 1, "decode-tx": 2, "fee-tx": 3, "hash-state": 4, "withdraw": 5, "hash-inputs": 6}
+
+# every symbol include/hermez_witness.h declares; tests check the .so exports all of them
+EXPORTS = [
+    "hz_version", "hz_last_error", "hz_device_count", "hz_ctx_create", "hz_ctx_destroy", "hz_witness_len",
+    "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_clear_inputs", "hz_input_count", "hz_input_name",
+    "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
+    "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
+    "hz_poseidon_batch_dev", "hz_shard_range",
+]
+
+
+class Lib:
+    """Loaded libhermez_witness.so. Raises if the HIP library has not been built."""
+
+    def __init__(self, path=None):
+        path = path or lib_path()
+        if not os.path.exists(path):
+            raise HzError(-1, "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        self.c = ctypes.CDLL(path)
+        c = self.c
+        c.hz_version.restype = ctypes.c_char_p
+        c.hz_last_error.restype = ctypes.c_char_p
+        c.hz_device_count.restype = ctypes.c_int32
+        c.hz_poseidon_batch.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+        c.hz_poseidon_batch_dev.argtypes = [ctypes.c_int32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        c.hz_shard_range.argtypes = [ctypes.c_int32] * 3 + [ctypes.POINTER(ctypes.c_int32)] * 2
+        c.hz_shard_range.restype = None
+
+    def _check(self, st):
+        if st != 0:
+            raise HzError(st, self.c.hz_last_error().decode())
+
+    def version(self):
+        return self.c.hz_version().decode()
+
+    def device_count(self):
+        return self.c.hz_device_count()
+
+    def poseidon_batch(self, t, inputs, witness=False, device=0):
+        """inputs: list of n lists of t-1 ints -> (digests, sbox_witness or None)."""
+        n = len(inputs)
+        flat = fr_to_bytes([x for row in inputs for x in row])
+        out = ctypes.create_string_buffer(32 * max(n, 1))
+        nsbox = 8 * t + [56, 57, 56, 60, 60, 63][t - 2]
+        wit = ctypes.create_string_buffer(96 * nsbox * max(n, 1)) if witness else None
+        self._check(self.c.hz_poseidon_batch(device, t, n, flat, out, wit))
+        return fr_from_bytes(out.raw[:32 * n]), (wit.raw if witness else None)
+
+    def poseidon_batch_dev(self, t, n, d_in, d_out, d_wit=None, stream=None):
+        self._check(self.c.hz_poseidon_batch_dev(t, n, d_in, d_out, d_wit, stream))
+
+    def shard_range(self, n_tx, world, rank):
+        f, c = ctypes.c_int32(), ctypes.c_int32()
+        self.c.hz_shard_range(n_tx, world, rank, ctypes.byref(f), ctypes.byref(c))
+        return f.value, c.value
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = Lib()
+    return _lib

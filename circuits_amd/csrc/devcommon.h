@@ -1,0 +1,123 @@
+// Device-side helpers shared by all kernels: constant staging into LDS, 32-byte element
+// loads/stores, the witness writer and the constraint-failure record.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fr.h"
+#include "poseidon.h"
+
+namespace hz {
+
+// ---- constant tables in device memory (Montgomery form); one private copy per translation unit,
+// unused widths are dropped by the compiler -----------------------------------------------------
+#define HZ_CONST_ARR static __device__ const
+#include "gen/poseidon_consts.inc"
+#include "gen/fee_table.inc"
+#undef HZ_CONST_ARR
+
+template <int T> __device__ __forceinline__ const uint32_t* poseidon_c_global();
+template <int T> __device__ __forceinline__ const uint32_t* poseidon_m_global();
+#define HZ_PC(T)                                                                                          \
+    template <> __device__ __forceinline__ const uint32_t* poseidon_c_global<T>() { return &HZ_POSEIDON_C_T##T[0][0]; } \
+    template <> __device__ __forceinline__ const uint32_t* poseidon_m_global<T>() { return &HZ_POSEIDON_M_T##T[0][0]; }
+HZ_PC(2) HZ_PC(3) HZ_PC(4) HZ_PC(5) HZ_PC(6) HZ_PC(7)
+#undef HZ_PC
+
+// Stage the width-T constants (C then M) into LDS at `dst` (Fr-aligned). Whole block cooperates
+// with 16-byte coalesced loads; caller must __syncthreads() afterwards.
+template <int T>
+__device__ __forceinline__ void stage_poseidon_consts(Fr* dst) {
+    constexpr int NC4 = poseidon_nconst<T>() * 2;  // uint4 count
+    constexpr int NM4 = T * T * 2;
+    const uint4* gc = reinterpret_cast<const uint4*>(poseidon_c_global<T>());
+    const uint4* gm = reinterpret_cast<const uint4*>(poseidon_m_global<T>());
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    for (int i = threadIdx.x; i < NC4; i += blockDim.x) d[i] = gc[i];
+    for (int i = threadIdx.x; i < NM4; i += blockDim.x) d[NC4 + i] = gm[i];
+}
+
+// ---- 32-byte element I/O --------------------------------------------------------------------
+__device__ __forceinline__ Fr load_fr(const void* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void store_fr(void* p, const Fr& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// ---- witness writer ---------------------------------------------------------------------------
+// Signals of a section are stored signal-major: element (sig, unit) of instance `inst` lives at
+// base + ((sig * n_units) + unit) * 32, so the 64 lanes of a wavefront (consecutive units) write
+// 2 KiB of contiguous HBM per signal.
+struct WitOut {
+    uint8_t* base;     // first byte of this section for this instance
+    uint32_t n_units;  // units (transactions, fee txs, witnesses) in the section
+    uint32_t unit;     // this lane's unit
+    __device__ __forceinline__ uint8_t* addr(uint32_t sig) const {
+        return base + ((size_t)sig * n_units + unit) * 32;
+    }
+    __device__ __forceinline__ void put_mont(uint32_t sig, const Fr& m) const { store_fr(addr(sig), fr_to_canon(m)); }
+    __device__ __forceinline__ void put_canon(uint32_t sig, const Fr& c) const { store_fr(addr(sig), c); }
+    __device__ __forceinline__ void put_u64(uint32_t sig, uint64_t x) const {
+        uint4* q = reinterpret_cast<uint4*>(addr(sig));
+        q[0] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), 0u, 0u);
+        q[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __device__ __forceinline__ void put_bit(uint32_t sig, uint32_t b) const { put_u64(sig, b & 1u); }
+};
+
+// Poseidon S-box sink that stores the three product signals of S-box k at sig0 + 3k + {0,1,2}.
+struct WitSboxSink {
+    WitOut w;
+    uint32_t sig0;
+    __device__ __forceinline__ void operator()(int k, const Fr& x2, const Fr& x4, const Fr& x5) const {
+        w.put_mont(sig0 + 3 * k + 0, x2);
+        w.put_mont(sig0 + 3 * k + 1, x4);
+        w.put_mont(sig0 + 3 * k + 2, x5);
+    }
+};
+
+// ---- constraint failure record ------------------------------------------------------------------
+// The reference stops at the first violated `===` (circom_runtime throws "Constraint doesn't
+// match lhs != rhs"). Lanes evaluate everything; a failing lane (1) lowers `minkey`
+// with atomicMin -- key = (instance, unit, constraint id), so the minimum is the first failure in
+// evaluation order -- and (2) appends its operands to a bounded list. If the list overflowed and
+// lost the minimum, the host re-enqueues with `filter` = minkey so only that lane appends.
+#define HZ_ERR_CAP 1024
+struct ErrRec {
+    unsigned long long key;
+    uint32_t lhs[8];
+    uint32_t rhs[8];
+};
+struct ErrBuf {
+    unsigned long long minkey;  // ~0ull = no failure
+    unsigned long long filter;  // ~0ull = record everything
+    unsigned int count;
+    unsigned int pad;
+    ErrRec rec[HZ_ERR_CAP];
+};
+
+__device__ __forceinline__ unsigned long long err_key(uint32_t inst, uint32_t unit, uint32_t cid) {
+    return ((unsigned long long)inst << 40) | ((unsigned long long)unit << 16) | cid;
+}
+
+__device__ __noinline__ void report_fail(ErrBuf* e, uint32_t inst, uint32_t unit, uint32_t cid, const Fr& lhs_m, const Fr& rhs_m) {
+    const unsigned long long key = err_key(inst, unit, cid);
+    atomicMin(&e->minkey, key);
+    if (e->filter != ~0ull && e->filter != key) return;
+    const unsigned int slot = atomicAdd(&e->count, 1u);
+    if (slot >= HZ_ERR_CAP) return;
+    const Fr l = fr_to_canon(lhs_m), r = fr_to_canon(rhs_m);
+    e->rec[slot].key = key;
+    for (int i = 0; i < 8; i++) {
+        e->rec[slot].lhs[i] = l.v[i];
+        e->rec[slot].rhs[i] = r.v[i];
+    }
+}
+
+}  // namespace hz

@@ -1,0 +1,146 @@
+/* hermez_witness.h -- C ABI of the MI355X-native witness generator for the Hermez rollup circuits.
+ *
+ * This is the drop-in boundary for the one hot path this repository accelerates: witness
+ * calculation for the circuits of hermeznetwork/circuits. What each entry point replaces:
+ *
+ *   reference call site                                         replaced by
+ *   ----------------------------------------------------------  --------------------------------
+ *   circuit = await tester(path)          test/rollup-main.test.js:52,  test/rollup-tx.test.js:43
+ *        (circom compile + WitnessCalculator instantiate)       hz_ctx_create / hz_ctx_destroy
+ *   WitnessCalculator setSignal(name, idx, value) loop inside
+ *        circuit.calculateWitness(input)  test/helpers/helpers.js:142,149    hz_set_input
+ *   calculateWitness body (component code of DecodeTx/RollupTx/FeeTx/HashInputs,
+ *        src/rollup-main.circom:201-475)                        hz_witness_run
+ *   returned witness array w[]            test/helpers/helpers.js:149        hz_witness_read
+ *   circuit.assertOut / getSignal via .sym                      hz_symbol_count / hz_symbol_get /
+ *                                         test/helpers/helpers.js:143,154,170    hz_symbol_lookup
+ *   native witness binary `./circuit input.json witness.json`   the same five calls
+ *                                         tools/helpers/actions.js:132-146
+ *   Poseidon(n) gadget (circomlib 0.5.2 poseidon.circom; call sites src/lib/hash-state.circom:32,
+ *        src/decode-tx.circom:275)                              hz_poseidon_batch(_dev)
+ *
+ * All field elements cross this boundary as 32-byte little-endian canonical integers (< r), the
+ * element format of snarkjs .wtns files. Plain C types only; caller-allocated buffers; no
+ * exceptions cross the ABI. A context is used by one thread at a time.
+ * There is NO CPU fallback: every entry point that computes returns HZ_ERR_NODEVICE when no
+ * gfx950 device is usable.
+ */
+#ifndef HERMEZ_WITNESS_H
+#define HERMEZ_WITNESS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HZ_FR_BYTES 32
+
+typedef enum {
+    HZ_OK = 0,
+    HZ_ERR_ARG = 1,        /* bad parameter */
+    HZ_ERR_HIP = 2,        /* HIP runtime failure, see hz_last_error() */
+    HZ_ERR_CONSTRAINT = 3, /* a `===` of the circuit does not hold; details in hz_error */
+    HZ_ERR_INPUT = 4,      /* unknown / mis-shaped / missing input signal */
+    HZ_ERR_NODEVICE = 5    /* no usable gfx950 device */
+} hz_status;
+
+/* main component selector: the templates the reference's suites instantiate as `component main` */
+typedef enum {
+    HZ_T_ROLLUP_MAIN = 0, /* RollupMain(nTx,nLevels,maxL1Tx,maxFeeTx)  src/rollup-main.circom:82   */
+    HZ_T_ROLLUP_TX = 1,   /* RollupTx(nLevels,maxFeeTx)                src/rollup-tx.circom:78     */
+    HZ_T_DECODE_TX = 2,   /* DecodeTx(nLevels)                         src/decode-tx.circom:44     */
+    HZ_T_FEE_TX = 3,      /* FeeTx(nLevels)                            src/fee-tx.circom:26        */
+    HZ_T_HASH_STATE = 4,  /* HashState()                               src/lib/hash-state.circom:18*/
+    HZ_T_WITHDRAW = 5,    /* Withdraw(nLevels)                         src/withdraw.circom:21      */
+    HZ_T_HASH_INPUTS = 6, /* HashInputs(nLevels,nTx,maxL1Tx,maxFeeTx)  src/hash-inputs.circom:23   */
+    HZ_T_COUNT
+} hz_template;
+
+typedef struct {
+    int32_t template_id; /* hz_template */
+    int32_t nTx;         /* RollupMain / HashInputs only */
+    int32_t nLevels;
+    int32_t maxL1Tx;
+    int32_t maxFeeTx;
+    int32_t device;      /* HIP device ordinal */
+    /* Number of independent instances of the main component evaluated by one hz_witness_run
+     * (e.g. 2^20 Withdraw witnesses, or several RollupMain batches in flight). Inputs and the
+     * witness carry the instance as the outermost index. 0 means 1. */
+    int32_t n_instances;
+    int32_t flags;       /* reserved, 0 */
+} hz_params;
+
+typedef struct {
+    int32_t instance;      /* which instance failed */
+    int32_t unit;          /* transaction / fee-tx index inside the instance, -1 if global */
+    int32_t constraint_id; /* stable id, see hz_constraint_name() */
+    uint8_t lhs[HZ_FR_BYTES];
+    uint8_t rhs[HZ_FR_BYTES];
+} hz_error;
+
+typedef struct {
+    const char* name; /* circom-style dotted name, e.g. main.rollupTx[3].processor1.newRoot */
+    uint64_t index;   /* position in the flat witness of instance 0 */
+} hz_symbol;
+
+typedef struct hz_ctx hz_ctx;
+
+/* library / device ----------------------------------------------------------------------- */
+const char* hz_version(void);
+const char* hz_last_error(void);          /* thread-local text of the last failure */
+int32_t hz_device_count(void);            /* 0 when no gfx950 device is usable */
+
+/* context: one compiled "circuit" ---------------------------------------------------------- */
+hz_status hz_ctx_create(const hz_params* params, hz_ctx** out);
+void hz_ctx_destroy(hz_ctx* ctx);
+/* number of field elements in the witness of ONE instance (w[0] == 1 included) */
+uint64_t hz_witness_len(const hz_ctx* ctx);
+/* closed-form constraint count of the template (reference tools/circuit-constraints.js:31-75) */
+uint64_t hz_constraint_estimate(const hz_ctx* ctx);
+
+/* inputs: `name` is a main-component input signal (e.g. "siblings1"); `vals` holds `count`
+ * canonical 32-byte LE integers in circom's row-major flattening of the signal's dimensions,
+ * for instance `instance`. Values >= r are rejected. */
+hz_status hz_set_input(hz_ctx* ctx, int32_t instance, const char* name, const uint8_t* vals, size_t count);
+/* same, but `vals` already lives in device memory of ctx's device */
+hz_status hz_set_input_dev(hz_ctx* ctx, int32_t instance, const char* name, const void* dvals, size_t count, void* stream);
+/* forget which inputs were set (values are kept; calculateWitness semantics need a fresh set) */
+void hz_clear_inputs(hz_ctx* ctx);
+/* enumerate the input signals the template expects */
+int32_t hz_input_count(const hz_ctx* ctx);
+const char* hz_input_name(const hz_ctx* ctx, int32_t i, uint64_t* flat_len);
+
+/* run: all instances, inputs resident in HBM. Asynchronous variant enqueues on `stream` and
+ * returns; hz_witness_check then synchronises and reports the first violated constraint
+ * (lowest instance, lowest unit, lowest constraint id). hz_witness_run = enqueue + check. */
+hz_status hz_witness_enqueue(hz_ctx* ctx, void* stream);
+hz_status hz_witness_check(hz_ctx* ctx, hz_error* err);
+hz_status hz_witness_run(hz_ctx* ctx, hz_error* err);
+
+/* output: copy `count` elements starting at flat index `first` of instance `instance` to host */
+hz_status hz_witness_read(hz_ctx* ctx, int32_t instance, uint64_t first, uint64_t count, uint8_t* out);
+/* device view of the whole witness buffer ([instance][hz_witness_len] x 32 B) */
+const void* hz_witness_dev_ptr(const hz_ctx* ctx);
+
+/* symbols ------------------------------------------------------------------------------------ */
+uint64_t hz_symbol_count(const hz_ctx* ctx);
+hz_status hz_symbol_get(const hz_ctx* ctx, uint64_t i, hz_symbol* out);
+/* returns 1 and the index if `name` (with or without the "main." prefix) is a witness signal */
+int32_t hz_symbol_lookup(const hz_ctx* ctx, const char* name, uint64_t* index);
+const char* hz_constraint_name(int32_t constraint_id);
+
+/* Poseidon batch: n independent permutations of width t = n_inputs + 1 (2..7). ----------------
+ * `in`  : [n][t-1] canonical elements; `out`: [n] digests (state[0] after the last round).
+ * If `sbox_witness` is non-NULL it receives the S-box signals (in2,in4,out per S-box, the
+ * non-linear signals of circomlib's Poseidon template) as [3*(8t+R_P)][n] elements. */
+hz_status hz_poseidon_batch(int32_t device, int32_t t, size_t n, const uint8_t* in, uint8_t* out, uint8_t* sbox_witness);
+hz_status hz_poseidon_batch_dev(int32_t t, size_t n, const void* d_in, void* d_out, void* d_sbox_witness, void* stream);
+
+/* multi-GPU helper (one process per GPU): the per-rank slice of transactions a rank owns when a
+ * RollupMain batch is sharded by transaction index. */
+void hz_shard_range(int32_t nTx, int32_t world, int32_t rank, int32_t* first, int32_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
