@@ -1,0 +1,566 @@
+"""Batch builder: builds circuit INPUTS for RollupMain / RollupTx / Withdraw from a sequence of
+transactions -- the role `@hermeznetwork/commonjs` (RollupDB.buildBatch / BatchBuilder.addTx /
+build / getInput / getHashInputs, called by the reference at test/helpers/helpers.js:46,148 and
+tools/generate-input.js:70-107) plays for the reference. That package is not on disk; this is a
+from-scratch restatement of the protocol rules the circuits themselves enforce (src/*.circom),
+plus the sparse-Merkle-tree update rules of circomlib's SMT (Poseidon hashes, key bits LSB first).
+
+Caller-side code: it never computes a witness. Field/curve arithmetic comes from
+circuits_amd/libhz_host.so (the product's own headers compiled for the host).
+"""
+import ctypes
+import hashlib
+import json
+import os
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+SUBORDER = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+BASE8 = (5299619240641551281634865583518297030282874472190772894086521144482721001553,
+         16950150798460657717958625567821834550301663161624707787222815936182638968203)
+CONST_SIG = 3322668559
+EXIT_IDX = 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Host:
+    """ctypes view of libhz_host.so."""
+
+    def __init__(self):
+        path = os.path.join(_HERE, "libhz_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError("%s missing: run __graft_entry__.build()" % path)
+        self.c = ctypes.CDLL(path)
+        self._o = ctypes.create_string_buffer(32)
+        self._ox = ctypes.create_string_buffer(32)
+        self._oy = ctypes.create_string_buffer(32)
+
+    def poseidon(self, xs):
+        buf = b"".join(int(x % P).to_bytes(32, "little") for x in xs)
+        self.c.hzb_poseidon(len(xs), buf, self._o)
+        return int.from_bytes(self._o.raw, "little")
+
+    def bjj_mul(self, pt, k):
+        b = lambda v: int(v).to_bytes(32, "little")  # noqa: E731
+        self.c.hzb_bjj_mul(b(pt[0]), b(pt[1]), b(k % (1 << 256)), self._ox, self._oy)
+        return int.from_bytes(self._ox.raw, "little"), int.from_bytes(self._oy.raw, "little")
+
+
+_host = None
+
+
+def host():
+    global _host
+    if _host is None:
+        _host = Host()
+    return _host
+
+
+# ---- fee table / float40 (reference src/compute-fee.circom:105-109, src/lib/decode-float.circom) ----
+_FEE = None
+
+
+def fee_table():
+    global _FEE
+    if _FEE is None:
+        _FEE = [int(x) for x in json.load(open(os.path.join(_HERE, "fee_table.json")))["table"]]
+    return _FEE
+
+
+def compute_fee(amount, sel):
+    t = fee_table()[sel]
+    return (amount * t) >> 60 if sel < 192 else amount * t
+
+
+def float2fix(f):
+    return (f & ((1 << 35) - 1)) * 10 ** (f >> 35)
+
+
+def floor_fix2float(v):
+    """largest float40 not above v"""
+    if v == 0:
+        return 0
+    best = 0
+    for e in range(32):
+        m = v // 10 ** e
+        if m < (1 << 35):
+            cand = m + (e << 35)
+            if float2fix(cand) > float2fix(best):
+                best = cand
+            break
+    return best
+
+
+def fix2float(v):
+    f = floor_fix2float(v)
+    if float2fix(f) != v:
+        raise ValueError("amount %d is not float40-representable" % v)
+    return f
+
+
+# ---- circomlib-compatible sparse Merkle tree ---------------------------------------------------
+class SMT:
+    def __init__(self):
+        self.h = host()
+        self.root = 0
+        self.nodes = {}  # hash -> ("leaf", key, value) | ("mid", left, right)
+
+    def _hash1(self, k, v):
+        return self.h.poseidon([k, v, 1])
+
+    def _hash0(self, l, r):
+        return self.h.poseidon([l, r])
+
+    def find(self, key):
+        node, sib, lvl = self.root, [], 0
+        while True:
+            if node == 0:
+                return {"found": False, "siblings": sib, "notFoundKey": key, "notFoundValue": 0, "isOld0": True}
+            n = self.nodes[node]
+            if n[0] == "leaf":
+                if n[1] == key:
+                    return {"found": True, "siblings": sib, "foundValue": n[2], "isOld0": False}
+                return {"found": False, "siblings": sib, "notFoundKey": n[1], "notFoundValue": n[2], "isOld0": False}
+            if (key >> lvl) & 1:
+                sib.append(n[1])
+                node = n[2]
+            else:
+                sib.append(n[2])
+                node = n[1]
+            lvl += 1
+
+    def _up(self, key, leaf_hash, sib):
+        rt = leaf_hash
+        for i in range(len(sib) - 1, -1, -1):
+            l, r = (sib[i], rt) if (key >> i) & 1 else (rt, sib[i])
+            rt = self._hash0(l, r)
+            self.nodes[rt] = ("mid", l, r)
+        return rt
+
+    def insert(self, key, value):
+        f = self.find(key)
+        if f["found"]:
+            raise KeyError("key exists")
+        res = {"oldRoot": self.root, "isOld0": f["isOld0"], "oldKey": f["notFoundKey"], "oldValue": f["notFoundValue"]}
+        sib = list(f["siblings"])
+        full = list(sib)
+        if not f["isOld0"]:
+            ok = f["notFoundKey"]
+            i = len(full)
+            while ((ok >> i) & 1) == ((key >> i) & 1):
+                full.append(0)
+                i += 1
+            full.append(self._hash1(ok, f["notFoundValue"]))
+        lh = self._hash1(key, value)
+        self.nodes[lh] = ("leaf", key, value)
+        self.root = self._up(key, lh, full)
+        if not f["isOld0"]:
+            full.pop()
+        while full and full[-1] == 0:
+            full.pop()
+        res["siblings"] = full
+        res["newRoot"] = self.root
+        return res
+
+    def update(self, key, value):
+        f = self.find(key)
+        if not f["found"]:
+            raise KeyError("key not found")
+        res = {"oldRoot": self.root, "oldKey": key, "oldValue": f["foundValue"], "siblings": list(f["siblings"])}
+        lh = self._hash1(key, value)
+        self.nodes[lh] = ("leaf", key, value)
+        self.root = self._up(key, lh, f["siblings"])
+        res["newRoot"] = self.root
+        return res
+
+
+# ---- accounts / signatures ------------------------------------------------------------------------
+class Account:
+    """Synthetic Hermez account: BabyJubjub key k (A = k*Base8), 160-bit address."""
+
+    def __init__(self, seed):
+        d = hashlib.sha512(b"hz-account-%d" % seed).digest()
+        self.k = int.from_bytes(d[:32], "little") % SUBORDER or 1
+        self.eth_addr = int.from_bytes(d[32:52], "little")
+        self.ax, self.ay = host().bjj_mul(BASE8, self.k)
+        self.sign = 1 if self.ax > (P - 1) // 2 else 0
+        self.bjj_compressed = self.ay | (self.sign << 255)
+
+    def sign_msg(self, msg):
+        """EdDSA-Poseidon: S*B8 == R8 + 8*H(R8,A,M)*A (circomlib eddsaposeidon.circom)."""
+        d = hashlib.sha512(self.k.to_bytes(32, "little") + int(msg).to_bytes(32, "little")).digest()
+        r = int.from_bytes(d, "little") % SUBORDER or 1
+        r8 = host().bjj_mul(BASE8, r)
+        hm = host().poseidon([r8[0], r8[1], self.ax, self.ay, msg])
+        s = (r + 8 * hm * self.k) % SUBORDER
+        return {"r8x": r8[0], "r8y": r8[1], "s": s}
+
+
+def hash_state(st):
+    e0 = st["tokenID"] + (st["nonce"] << 32) + (st["sign"] << 72)
+    return host().poseidon([e0, st["balance"], st["ay"], st["ethAddr"]])
+
+
+def build_tx_compressed_data(tx, chain_id):
+    return (CONST_SIG | (chain_id << 32) | (tx.get("fromIdx", 0) << 48) | (tx.get("toIdx", 0) << 96) | (tx.get("tokenID", 0) << 144) |
+            (tx.get("nonce", 0) << 176) | (tx.get("userFee", 0) << 216) | (tx.get("toBjjSign", 0) << 224))
+
+
+def build_tx_compressed_data_v2(tx):
+    return (tx.get("fromIdx", 0) | (tx.get("toIdx", 0) << 48) | (tx.get("amountF", 0) << 96) | (tx.get("tokenID", 0) << 136) |
+            (tx.get("nonce", 0) << 168) | (tx.get("userFee", 0) << 208) | (tx.get("toBjjSign", 0) << 216))
+
+
+def build_hash_sig(tx, chain_id):
+    e1 = tx.get("toEthAddr", 0) | (tx.get("amountF", 0) << 160) | (tx.get("maxNumBatch", 0) << 200)
+    return host().poseidon([build_tx_compressed_data(tx, chain_id), e1, tx.get("toBjjAy", 0), tx.get("rqTxCompressedDataV2", 0),
+                            tx.get("rqToEthAddr", 0), tx.get("rqToBjjAy", 0)])
+
+
+class RollupDB:
+    def __init__(self, chain_id=1):
+        self.chain_id = chain_id
+        self.state = SMT()
+        self.leaves = {}  # idx -> state dict
+        self.last_idx = 255
+        self.num_batch = 0
+        self.exit_trees = {}
+
+    def build_batch(self, n_tx, n_levels, max_l1, max_fee):
+        return BatchBuilder(self, n_tx, n_levels, max_l1, max_fee)
+
+
+class BatchBuilder:
+    def __init__(self, db, n_tx, n_levels, max_l1, max_fee):
+        self.db, self.nTx, self.L, self.maxL1, self.F = db, n_tx, n_levels, max_l1, max_fee
+        self.txs, self.fee_tokens, self.fee_idxs = [], [], []
+        self.current_num_batch = db.num_batch + 1
+        self.built = False
+
+    def add_tx(self, tx):
+        if len(self.txs) >= self.nTx:
+            raise ValueError("batch full")
+        self.txs.append(dict(tx))
+
+    def add_token(self, token_id):
+        self.fee_tokens.append(token_id)
+
+    def add_fee_idx(self, idx):
+        self.fee_idxs.append(idx)
+
+    # -- helpers
+    def _pad(self, sib):
+        return list(sib) + [0] * (self.L + 1 - len(sib))
+
+    def build(self):
+        db, L, F, nTx = self.db, self.L, self.F, self.nTx
+        if any(not t.get("onChain") for t in self.txs[:0]):
+            pass
+        n_l1 = sum(1 for t in self.txs if t.get("onChain"))
+        if n_l1 > self.maxL1:
+            raise ValueError("too many L1 txs")
+        inp = {k: [] for k in (
+            "txCompressedData amountF txCompressedDataV2 fromIdx auxFromIdx toIdx auxToIdx toBjjAy toEthAddr maxNumBatch onChain newAccount "
+            "rqOffset rqTxCompressedDataV2 rqToEthAddr rqToBjjAy s r8x r8y loadAmountF fromEthAddr fromBjjCompressed tokenID1 nonce1 sign1 "
+            "balance1 ay1 ethAddr1 siblings1 isOld0_1 oldKey1 oldValue1 tokenID2 nonce2 sign2 balance2 ay2 ethAddr2 siblings2 newExit isOld0_2 "
+            "oldKey2 oldValue2 imOnChain imOutIdx imStateRoot imExitRoot imAccFeeOut").split()}
+        inp["oldLastIdx"] = db.last_idx
+        inp["oldStateRoot"] = db.state.root
+        inp["globalChainID"] = db.chain_id
+        inp["currentNumBatch"] = self.current_num_batch
+        plan = list(self.fee_tokens) + [0] * (F - len(self.fee_tokens))
+        inp["feePlanTokens"] = plan
+        acc_fee = [0] * F
+        exit_tree = SMT()
+        exit_leaves = {}
+        self.tx_meta = []  # per-tx facts used by get_single_tx_input
+        ordered = [t for t in self.txs if t.get("onChain")] + [t for t in self.txs if not t.get("onChain")]
+        self.txs = ordered
+        for i in range(nTx):
+            tx = ordered[i] if i < len(ordered) else {"onChain": 0, "nop": True}
+            on = 1 if tx.get("onChain") else 0
+            from_idx, to_idx = tx.get("fromIdx", 0), tx.get("toIdx", 0)
+            amount = tx.get("amount", 0)
+            amount_f = fix2float(amount)
+            tx["amountF"] = amount_f
+            load_f = tx.get("loadAmountF", 0)
+            load_amount = float2fix(load_f)
+            token = tx.get("tokenID", 0)
+            user_fee = tx.get("userFee", 0)
+            new_account = 1 if (on and from_idx == 0) else 0
+            aux_from = 0
+            zero_state = {"tokenID": 0, "nonce": 0, "sign": 0, "balance": 0, "ay": 0, "ethAddr": 0}
+            st1, st2 = dict(zero_state), dict(zero_state)
+            sib1, sib2 = [], []
+            isold1 = isold2 = oldk1 = oldk2 = oldv1 = oldv2 = 0
+            new_exit = 0
+            is_nullified = 0
+            sig = {"r8x": 0, "r8y": 0, "s": 0}
+            bjj = tx.get("fromBjjCompressed", 0)
+            from_eth = tx.get("fromEthAddr", 0)
+            final_from = from_idx
+            if on:
+                if new_account:
+                    db.last_idx += 1
+                    aux_from = db.last_idx
+                    final_from = aux_from
+                    ay = bjj & ((1 << 254) - 1)
+                    sg = (bjj >> 255) & 1
+                    new_st = {"tokenID": token, "nonce": 0, "sign": sg, "balance": load_amount, "ay": ay, "ethAddr": from_eth}
+                    res = db.state.insert(aux_from, hash_state(new_st))
+                    db.leaves[aux_from] = new_st
+                    # coordinator-chosen leaf data for an INSERT: tokenID1/ethAddr1 are forced equal to the tx
+                    st1 = {"tokenID": token, "nonce": 0, "sign": sg, "balance": 0, "ay": ay, "ethAddr": from_eth}
+                    sib1 = res["siblings"]
+                    isold1 = 1 if res["isOld0"] else 0
+                    oldk1 = 0 if res["isOld0"] else res["oldKey"]
+                    oldv1 = 0 if res["isOld0"] else res["oldValue"]
+                    if amount:
+                        raise NotImplementedError("createAccountDepositTransfer")
+                elif from_idx:
+                    cur = db.leaves[from_idx]
+                    st1 = dict(cur)
+                    eff_load = load_amount if token == cur["tokenID"] else 0
+                    new_st = dict(cur)
+                    new_st["balance"] += eff_load
+                    res = db.state.update(from_idx, hash_state(new_st))
+                    db.leaves[from_idx] = new_st
+                    sib1 = res["siblings"]
+                    if amount:
+                        raise NotImplementedError("L1 transfers / force exit")
+            elif from_idx:
+                # L2 transfer or exit
+                cur = db.leaves[from_idx]
+                st1 = dict(cur)
+                tx.setdefault("nonce", cur["nonce"])
+                fee = compute_fee(amount, user_fee)
+                if cur["balance"] < amount + fee:
+                    raise ValueError("L2 underflow (the circuit rejects this tx)")
+                new_st = dict(cur)
+                new_st["nonce"] += 1
+                new_st["balance"] -= amount + fee
+                res = db.state.update(from_idx, hash_state(new_st))
+                db.leaves[from_idx] = new_st
+                sib1 = res["siblings"]
+                if token in plan:
+                    acc_fee[plan.index(token)] += fee
+                if amount:
+                    if to_idx == EXIT_IDX:
+                        if from_idx in exit_leaves:
+                            ecur = exit_leaves[from_idx]
+                            st2 = dict(ecur)
+                            enew = dict(ecur)
+                            enew["balance"] += amount
+                            r2 = exit_tree.update(from_idx, hash_state(enew))
+                            exit_leaves[from_idx] = enew
+                            sib2 = r2["siblings"]
+                        else:
+                            new_exit = 1
+                            enew = {"tokenID": cur["tokenID"], "nonce": 0, "sign": cur["sign"], "balance": amount, "ay": cur["ay"], "ethAddr": cur["ethAddr"]}
+                            r2 = exit_tree.insert(from_idx, hash_state(enew))
+                            exit_leaves[from_idx] = enew
+                            sib2 = r2["siblings"]
+                            isold2 = 1 if r2["isOld0"] else 0
+                            oldk2 = 0 if r2["isOld0"] else r2["oldKey"]
+                            oldv2 = 0 if r2["isOld0"] else r2["oldValue"]
+                    else:
+                        rcur = db.leaves[to_idx]
+                        st2 = dict(rcur)
+                        rnew = dict(rcur)
+                        rnew["balance"] += amount
+                        r2 = db.state.update(to_idx, hash_state(rnew))
+                        db.leaves[to_idx] = rnew
+                        sib2 = r2["siblings"]
+                if "signer" in tx:
+                    sig = tx["signer"].sign_msg(build_hash_sig(tx, db.chain_id))
+                else:
+                    sig = {k: tx.get(k, 0) for k in ("r8x", "r8y", "s")}
+            txc = build_tx_compressed_data(tx, db.chain_id) if not on else (
+                CONST_SIG | (db.chain_id << 32) | (from_idx << 48) | (to_idx << 96) | (token << 144))
+            inp["txCompressedData"].append(txc)
+            inp["amountF"].append(amount_f)
+            inp["txCompressedDataV2"].append(0 if on else build_tx_compressed_data_v2(tx))
+            inp["fromIdx"].append(from_idx); inp["auxFromIdx"].append(aux_from)
+            inp["toIdx"].append(to_idx); inp["auxToIdx"].append(tx.get("auxToIdx", 0))
+            inp["toBjjAy"].append(tx.get("toBjjAy", 0)); inp["toEthAddr"].append(tx.get("toEthAddr", 0))
+            inp["maxNumBatch"].append(tx.get("maxNumBatch", 0)); inp["onChain"].append(on); inp["newAccount"].append(new_account)
+            inp["rqOffset"].append(0); inp["rqTxCompressedDataV2"].append(0); inp["rqToEthAddr"].append(0); inp["rqToBjjAy"].append(0)
+            inp["s"].append(sig["s"]); inp["r8x"].append(sig["r8x"]); inp["r8y"].append(sig["r8y"])
+            inp["loadAmountF"].append(load_f); inp["fromEthAddr"].append(from_eth)
+            inp["fromBjjCompressed"].append([(bjj >> k) & 1 for k in range(256)])
+            for nm, st in (("1", st1), ("2", st2)):
+                for f in ("tokenID", "nonce", "sign", "balance", "ay", "ethAddr"):
+                    inp[f + nm].append(st[f])
+            inp["siblings1"].append(self._pad(sib1)); inp["siblings2"].append(self._pad(sib2))
+            inp["isOld0_1"].append(isold1); inp["oldKey1"].append(oldk1); inp["oldValue1"].append(oldv1)
+            inp["isOld0_2"].append(isold2); inp["oldKey2"].append(oldk2); inp["oldValue2"].append(oldv2)
+            inp["newExit"].append(new_exit)
+            self.tx_meta.append({"isAmountNullified": is_nullified, "sigL2Hash": 0 if on else build_hash_sig(tx, db.chain_id),
+                                 "stateRoot": db.state.root, "exitRoot": exit_tree.root, "accFee": list(acc_fee)})
+            if i < nTx - 1:
+                inp["imOnChain"].append(on); inp["imOutIdx"].append(db.last_idx)
+                inp["imStateRoot"].append(db.state.root); inp["imExitRoot"].append(exit_tree.root)
+                inp["imAccFeeOut"].append(list(acc_fee))
+        # fee transactions (src/fee-tx.circom, src/rollup-main.circom:393-431)
+        inp["imInitStateRootFee"] = db.state.root
+        inp["imFinalAccFee"] = list(acc_fee)
+        idxs = list(self.fee_idxs) + [0] * (F - len(self.fee_idxs))
+        inp["feeIdxs"] = idxs
+        for k in ("tokenID3", "nonce3", "sign3", "balance3", "ay3", "ethAddr3", "siblings3", "imStateRootFee"):
+            inp[k] = []
+        for j in range(F):
+            st3, sib3 = {"tokenID": 0, "nonce": 0, "sign": 0, "balance": 0, "ay": 0, "ethAddr": 0}, []
+            if idxs[j]:
+                cur = db.leaves[idxs[j]]
+                if cur["tokenID"] != plan[j]:
+                    raise ValueError("fee idx token mismatch")
+                st3 = dict(cur)
+                new = dict(cur)
+                new["balance"] += acc_fee[j]
+                r3 = db.state.update(idxs[j], hash_state(new))
+                db.leaves[idxs[j]] = new
+                sib3 = r3["siblings"]
+            for f, nm in (("tokenID", "tokenID3"), ("nonce", "nonce3"), ("sign", "sign3"), ("balance", "balance3"), ("ay", "ay3"), ("ethAddr", "ethAddr3")):
+                inp[nm].append(st3[f])
+            inp["siblings3"].append(self._pad(sib3))
+            if j < F - 1:
+                inp["imStateRootFee"].append(db.state.root)
+        self.input = inp
+        self.new_state_root = db.state.root
+        self.new_exit_root = exit_tree.root
+        self.exit_tree, self.exit_leaves = exit_tree, exit_leaves
+        db.exit_trees[self.current_num_batch] = (exit_tree, exit_leaves)
+        db.num_batch = self.current_num_batch
+        self.built = True
+        return self
+
+    def get_input(self):
+        return self.input
+
+    # data-availability strings and the global hash (src/hash-inputs.circom:117-184)
+    def get_hash_inputs(self):
+        L, F, nTx = self.L, self.F, self.nTx
+        inp = self.input
+        bits = []
+
+        def be(v, n):
+            bits.extend((v >> (n - 1 - k)) & 1 for k in range(n))
+        be(inp["oldLastIdx"], 48); be(self.db.last_idx, 48); be(inp["oldStateRoot"], 256); be(self.new_state_root, 256); be(self.new_exit_root, 256)
+        for i in range(self.maxL1):
+            on = inp["onChain"][i] if i < nTx else 0
+            if on:
+                bjj = sum(b << k for k, b in enumerate(inp["fromBjjCompressed"][i]))
+                txc = inp["txCompressedData"][i]
+                be(inp["fromEthAddr"][i], 160); be(bjj, 256); be((txc >> 48) & ((1 << 48) - 1), 48); be(inp["loadAmountF"][i], 40)
+                be(inp["amountF"][i], 40); be((txc >> 144) & 0xFFFFFFFF, 32); be((txc >> 96) & ((1 << 48) - 1), 48)
+            else:
+                bits.extend([0] * 624)
+        for i in range(nTx):
+            txc = inp["txCompressedData"][i]
+            on = inp["onChain"][i]
+            frm = (txc >> 48) & ((1 << 48) - 1)
+            to = (txc >> 96) & ((1 << 48) - 1)
+            final_to = inp["auxToIdx"][i] if (not on and to == 0) else to
+            be(frm, L); be(final_to, L)
+            be(0 if self.tx_meta[i]["isAmountNullified"] else inp["amountF"][i], 40)
+            be(0 if on else (txc >> 216) & 0xFF, 8)
+        for j in range(F):
+            be(inp["feeIdxs"][j], L)
+        be(inp["globalChainID"], 16); be(inp["currentNumBatch"], 32)
+        assert len(bits) % 8 == 0
+        by = bytes(sum(bits[8 * i + k] << (7 - k) for k in range(8)) for i in range(len(bits) // 8))
+        return int.from_bytes(hashlib.sha256(by).digest(), "big") % P
+
+    # reference test/helpers/helpers.js:45-137 getSingleTxInput
+    def get_single_tx_input(self, i):
+        inp, F = self.input, self.F
+        txc = inp["txCompressedData"][i]
+        r = {
+            "feePlanTokens": inp["feePlanTokens"], "accFeeIn": [0] * F,
+            "futureTxCompressedDataV2": [0] * 3, "pastTxCompressedDataV2": [0] * 4, "futureToEthAddr": [0] * 3, "pastToEthAddr": [0] * 4,
+            "futureToBjjAy": [0] * 3, "pastToBjjAy": [0] * 4,
+            "fromIdx": (txc >> 48) & ((1 << 48) - 1), "auxFromIdx": inp["auxFromIdx"][i], "toIdx": (txc >> 96) & ((1 << 48) - 1),
+            "auxToIdx": inp["auxToIdx"][i], "toBjjAy": inp["toBjjAy"][i], "toBjjSign": (txc >> 224) & 1, "toEthAddr": inp["toEthAddr"][i],
+            "amount": float2fix(inp["amountF"][i]), "tokenID": (txc >> 144) & 0xFFFFFFFF, "nonce": (txc >> 176) & ((1 << 40) - 1),
+            "userFee": (txc >> 216) & 0xFF, "rqOffset": inp["rqOffset"][i], "onChain": inp["onChain"][i], "newAccount": inp["newAccount"][i],
+            "rqTxCompressedDataV2": 0, "rqToEthAddr": 0, "rqToBjjAy": 0, "sigL2Hash": self.tx_meta[i]["sigL2Hash"],
+            "s": inp["s"][i], "r8x": inp["r8x"][i], "r8y": inp["r8y"][i], "fromEthAddr": inp["fromEthAddr"][i],
+            "fromBjjCompressed": inp["fromBjjCompressed"][i], "loadAmountF": inp["loadAmountF"][i],
+            "oldStateRoot": inp["imStateRoot"][i - 1] if i > 0 else inp["oldStateRoot"],
+            "oldExitRoot": inp["imExitRoot"][i - 1] if i > 0 else 0,
+        }
+        for k in ("tokenID1", "nonce1", "sign1", "balance1", "ay1", "ethAddr1", "siblings1", "isOld0_1", "oldKey1", "oldValue1", "tokenID2",
+                  "nonce2", "sign2", "balance2", "newExit", "ay2", "ethAddr2", "siblings2", "isOld0_2", "oldKey2", "oldValue2"):
+            r[k] = inp[k][i]
+        prev = self.tx_meta[i - 1]["accFee"] if i > 0 else [0] * F
+        out = {"accFeeOut": [a - b for a, b in zip(self.tx_meta[i]["accFee"], prev)],
+               "newStateRoot": self.tx_meta[i]["stateRoot"], "newExitRoot": self.tx_meta[i]["exitRoot"],
+               "isAmountNullified": self.tx_meta[i]["isAmountNullified"]}
+        return r, out
+
+
+def withdraw_input(batch, idx, n_levels):
+    """Inputs of Withdraw(nLevels) for an exit leaf of a built batch (reference test/withdraw.test.js:39-157)."""
+    tree, leaves = batch.exit_tree, batch.exit_leaves
+    st = leaves[idx]
+    f = tree.find(idx)
+    assert f["found"]
+    sib = list(f["siblings"]) + [0] * (n_levels + 1 - len(f["siblings"]))
+    inp = {"rootExit": tree.root, "ethAddr": st["ethAddr"], "tokenID": st["tokenID"], "balance": st["balance"], "idx": idx, "sign": st["sign"],
+           "ay": st["ay"], "siblingsState": sib}
+    bits = []
+
+    def be(v, n):
+        bits.extend((v >> (n - 1 - k)) & 1 for k in range(n))
+    be(tree.root, 256); be(st["ethAddr"], 160); be(st["tokenID"], 32); be(st["balance"], 192); be(idx, 48)
+    by = bytes(sum(bits[8 * i + k] << (7 - k) for k in range(8)) for i in range(len(bits) // 8))
+    return inp, int.from_bytes(hashlib.sha256(by).digest(), "big") % P
+
+
+def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0):
+    """Seeded synthetic batch following reference tools/generate-input.js:61-109 and
+    tools/helpers/gen-inputs-utils.js: pre-populated accounts (token 1), then one batch of `max_l1` L1
+    createAccountDeposit txs followed by signed L2 transfers of 20 % of the sender balance with
+    userFee 176 (plus `exits` L2 exits), one fee token and one fee receiver."""
+    import random
+    rng = random.Random(seed)
+    db = RollupDB(chain_id=1)
+    keys = [Account(seed * 1000 + i) for i in range(n_keys)]
+    n_accounts = n_accounts if n_accounts is not None else max(2, min(4 * n_tx, 4096))
+    owner = {}
+    # pre-population (direct state construction, equivalent to earlier deposit batches)
+    for _ in range(n_accounts):
+        db.last_idx += 1
+        a = keys[rng.randrange(n_keys)]
+        bal = float2fix(floor_fix2float(rng.randrange(1 << 96)))
+        st = {"tokenID": 1, "nonce": 0, "sign": a.sign, "balance": bal, "ay": a.ay, "ethAddr": a.eth_addr}
+        db.state.insert(db.last_idx, hash_state(st))
+        db.leaves[db.last_idx] = st
+        owner[db.last_idx] = a
+    bb = db.build_batch(n_tx, n_levels, max_l1, max_fee)
+    n_l1 = min(max_l1, n_tx)
+    for _ in range(n_l1):
+        a = keys[rng.randrange(n_keys)]
+        bb.add_tx({"fromIdx": 0, "loadAmountF": floor_fix2float(rng.randrange(1 << 96)), "tokenID": 1, "fromBjjCompressed": a.bjj_compressed,
+                   "fromEthAddr": a.eth_addr, "toIdx": 0, "onChain": 1})
+    tmp = {}
+    idxs = sorted(owner)
+    for t in range(n_tx - n_l1):
+        frm = idxs[rng.randrange(len(idxs))]
+        to = idxs[rng.randrange(len(idxs))]
+        bal, nonce = tmp.get(frm, (db.leaves[frm]["balance"], db.leaves[frm]["nonce"]))
+        amount = float2fix(floor_fix2float(bal * 20 // 100))
+        is_exit = t < exits
+        tx = {"fromIdx": frm, "toIdx": EXIT_IDX if is_exit else to, "amount": amount, "tokenID": 1, "userFee": 176, "nonce": nonce, "onChain": 0,
+              "signer": owner[frm]}
+        bb.add_tx(tx)
+        nb = bal - amount - compute_fee(amount, 176)
+        tmp[frm] = (nb, nonce + 1)
+        if not is_exit and to != frm:
+            tb, tn = tmp.get(to, (db.leaves[to]["balance"], db.leaves[to]["nonce"]))
+            tmp[to] = (tb + amount, tn)
+        elif not is_exit and to == frm:
+            tmp[frm] = (nb + amount, nonce + 1)
+    bb.add_token(1)
+    bb.add_fee_idx(idxs[rng.randrange(len(idxs))])
+    bb.build()
+    return bb

@@ -18,7 +18,7 @@ def fr_from_bytes(buf):
 
 class Oracle:
     def __init__(self):
-        so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+        so = os.environ.get("ORACLE_SO") or os.path.join(ROOT, "oracle", "_build", "liboracle.so")
         if not os.path.exists(so):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         self.c = ctypes.CDLL(so)
@@ -33,3 +33,99 @@ class Oracle:
         rc = self.c.orc_poseidon_batch(t, n, flat, out, wit)
         assert rc == 0
         return fr_from_bytes(out.raw[:32 * n]), (wit.raw if witness else None)
+
+
+TEMPLATES = {"rollup-main": 0, "rollup-tx": 1, "decode-tx": 2, "fee-tx": 3, "hash-state": 4, "withdraw": 5, "hash-inputs": 6}
+
+
+def flatten(v):
+    if isinstance(v, (list, tuple)):
+        out = []
+        for x in v:
+            out.extend(flatten(x))
+        return out
+    return [int(v)]
+
+
+class OracleCtx:
+    """One oracle "circuit": mirrors the product's hz_ctx API (oracle/oracle_api.h)."""
+
+    def __init__(self, template, nTx=0, nLevels=0, maxL1Tx=0, maxFeeTx=0, n_instances=1):
+        self.o = Oracle()
+        c = self.o.c
+        c.orc_ctx_create.restype = ctypes.c_void_p
+        c.orc_ctx_destroy.argtypes = [ctypes.c_void_p]
+        c.orc_witness_len.restype = ctypes.c_uint64
+        c.orc_witness_len.argtypes = [ctypes.c_void_p]
+        c.orc_witness_total.restype = ctypes.c_uint64
+        c.orc_witness_total.argtypes = [ctypes.c_void_p]
+        c.orc_set_input.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+        c.orc_run.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3 + [ctypes.c_void_p, ctypes.c_void_p]
+        c.orc_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        c.orc_read_raw.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        c.orc_unwritten.restype = ctypes.c_uint64
+        c.orc_unwritten.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        c.orc_symbol_lookup.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
+        c.orc_symbol_count.restype = ctypes.c_uint64
+        c.orc_symbol_count.argtypes = [ctypes.c_void_p]
+        c.orc_constraint_name.restype = ctypes.c_char_p
+        self.h = c.orc_ctx_create(TEMPLATES[template], nTx, nLevels, maxL1Tx, maxFeeTx, n_instances)
+        self.n_instances = n_instances
+
+    def __del__(self):
+        try:
+            self.o.c.orc_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+    def witness_len(self):
+        return self.o.c.orc_witness_len(self.h)
+
+    def total(self):
+        return self.o.c.orc_witness_total(self.h)
+
+    def set_input(self, name, value, instance=0):
+        flat = flatten(value)
+        rc = self.o.c.orc_set_input(self.h, instance, name.encode(), fr_to_bytes(flat), len(flat))
+        if rc:
+            raise ValueError("oracle rejected input %s (rc %d, %d values)" % (name, rc, len(flat)))
+
+    def set_inputs(self, d, instance=0):
+        for k, v in d.items():
+            self.set_input(k, v, instance)
+
+    def run(self):
+        """returns None or (instance, unit, cid, name, lhs, rhs)"""
+        a, b, cc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        l, r = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        rc = self.o.c.orc_run(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(cc), l, r)
+        if rc == 0:
+            return None
+        if rc == 3:
+            return (a.value, b.value, cc.value, self.o.c.orc_constraint_name(cc.value).decode(), int.from_bytes(l.raw, "little"), int.from_bytes(r.raw, "little"))
+        raise RuntimeError("oracle run rc=%d (missing input?)" % rc)
+
+    def read(self, first, count, instance=0):
+        buf = ctypes.create_string_buffer(32 * count)
+        assert self.o.c.orc_read(self.h, instance, first, count, buf) == 0
+        return fr_from_bytes(buf.raw)
+
+    def read_raw_bytes(self, first=0, count=None):
+        count = self.total() - first if count is None else count
+        buf = ctypes.create_string_buffer(32 * count)
+        assert self.o.c.orc_read_raw(self.h, first, count, buf) == 0
+        return buf.raw
+
+    def lookup(self, name):
+        idx = ctypes.c_uint64()
+        if not self.o.c.orc_symbol_lookup(self.h, name.encode(), ctypes.byref(idx)):
+            raise KeyError(name)
+        return idx.value
+
+    def get(self, name, instance=0):
+        return self.read(self.lookup(name), 1, instance)[0]
+
+    def unwritten(self):
+        nm = ctypes.create_string_buffer(256)
+        n = self.o.c.orc_unwritten(self.h, nm, 256)
+        return n, nm.value.decode()
