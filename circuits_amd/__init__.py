@@ -10,6 +10,7 @@ from .capi import (  # noqa: F401
     HzError,
     ConstraintError,
     Lib,
+    Ctx,
     lib,
     lib_path,
     fr_to_bytes,

@@ -56,6 +56,7 @@ EXPORTS = [
     "hz_version", "hz_last_error", "hz_device_count", "hz_ctx_create", "hz_ctx_destroy", "hz_witness_len",
     "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_clear_inputs", "hz_input_count", "hz_input_name",
     "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
+    "hz_witness_total", "hz_witness_read_raw",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
     "hz_poseidon_batch_dev", "hz_shard_range",
 ]
@@ -77,6 +78,30 @@ class Lib:
         c.hz_poseidon_batch_dev.argtypes = [ctypes.c_int32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         c.hz_shard_range.argtypes = [ctypes.c_int32] * 3 + [ctypes.POINTER(ctypes.c_int32)] * 2
         c.hz_shard_range.restype = None
+        vp, u64 = ctypes.c_void_p, ctypes.c_uint64
+        c.hz_ctx_create.argtypes = [ctypes.POINTER(hz_params), ctypes.POINTER(vp)]
+        c.hz_ctx_destroy.argtypes = [vp]
+        c.hz_ctx_destroy.restype = None
+        for f in ("hz_witness_len", "hz_constraint_estimate", "hz_witness_total", "hz_symbol_count"):
+            getattr(c, f).argtypes = [vp]
+            getattr(c, f).restype = u64
+        c.hz_set_input.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+        c.hz_set_input_dev.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p, vp, ctypes.c_size_t, vp]
+        c.hz_clear_inputs.argtypes = [vp]
+        c.hz_clear_inputs.restype = None
+        c.hz_input_count.argtypes = [vp]
+        c.hz_input_name.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(u64)]
+        c.hz_input_name.restype = ctypes.c_char_p
+        c.hz_witness_enqueue.argtypes = [vp, vp]
+        c.hz_witness_check.argtypes = [vp, ctypes.POINTER(hz_error)]
+        c.hz_witness_run.argtypes = [vp, ctypes.POINTER(hz_error)]
+        c.hz_witness_read.argtypes = [vp, ctypes.c_int32, u64, u64, vp]
+        c.hz_witness_read_raw.argtypes = [vp, u64, u64, vp]
+        c.hz_witness_dev_ptr.argtypes = [vp]
+        c.hz_witness_dev_ptr.restype = vp
+        c.hz_symbol_get.argtypes = [vp, u64, ctypes.POINTER(hz_symbol)]
+        c.hz_symbol_lookup.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(u64)]
+        c.hz_constraint_name.restype = ctypes.c_char_p
 
     def _check(self, st):
         if st != 0:
@@ -101,10 +126,120 @@ class Lib:
     def poseidon_batch_dev(self, t, n, d_in, d_out, d_wit=None, stream=None):
         self._check(self.c.hz_poseidon_batch_dev(t, n, d_in, d_out, d_wit, stream))
 
+    def ctx(self, template, **kw):
+        return Ctx(self, template, **kw)
+
     def shard_range(self, n_tx, world, rank):
         f, c = ctypes.c_int32(), ctypes.c_int32()
         self.c.hz_shard_range(n_tx, world, rank, ctypes.byref(f), ctypes.byref(c))
         return f.value, c.value
+
+
+def _flatten(v):
+    if isinstance(v, (list, tuple)):
+        out = []
+        for x in v:
+            out.extend(_flatten(x))
+        return out
+    return [int(v)]
+
+
+class Ctx:
+    """One circuit context (hz_ctx): the object the reference's `tester()` returns."""
+
+    def __init__(self, L, template, nTx=0, nLevels=0, maxL1Tx=0, maxFeeTx=0, n_instances=1, device=0):
+        self.L = L
+        self.h = ctypes.c_void_p()
+        p = hz_params(TEMPLATES[template], nTx, nLevels, maxL1Tx, maxFeeTx, device, n_instances, 0)
+        L._check(L.c.hz_ctx_create(ctypes.byref(p), ctypes.byref(self.h)))
+        self.n_instances = n_instances
+
+    def close(self):
+        if self.h:
+            self.L.c.hz_ctx_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def witness_len(self):
+        return self.L.c.hz_witness_len(self.h)
+
+    def total(self):
+        return self.L.c.hz_witness_total(self.h)
+
+    def constraint_estimate(self):
+        return self.L.c.hz_constraint_estimate(self.h)
+
+    def input_names(self):
+        n = self.L.c.hz_input_count(self.h)
+        out = []
+        for i in range(n):
+            ln = ctypes.c_uint64()
+            out.append((self.L.c.hz_input_name(self.h, i, ctypes.byref(ln)).decode(), ln.value))
+        return out
+
+    def set_input(self, name, value, instance=0):
+        flat = _flatten(value)
+        self.L._check(self.L.c.hz_set_input(self.h, instance, name.encode(), fr_to_bytes(flat), len(flat)))
+
+    def set_inputs(self, d, instance=0):
+        for k, v in d.items():
+            self.set_input(k, v, instance)
+
+    def clear_inputs(self):
+        self.L.c.hz_clear_inputs(self.h)
+
+    def _raise(self, st, err):
+        if st == 3:
+            raise ConstraintError(err.instance, err.unit, err.constraint_id, self.L.c.hz_constraint_name(err.constraint_id).decode(),
+                                  int.from_bytes(bytes(err.lhs), "little"), int.from_bytes(bytes(err.rhs), "little"))
+        self.L._check(st)
+
+    def run(self):
+        err = hz_error()
+        self._raise(self.L.c.hz_witness_run(self.h, ctypes.byref(err)), err)
+
+    def enqueue(self, stream=None):
+        self.L._check(self.L.c.hz_witness_enqueue(self.h, stream))
+
+    def check(self):
+        err = hz_error()
+        self._raise(self.L.c.hz_witness_check(self.h, ctypes.byref(err)), err)
+
+    def read(self, first, count, instance=0):
+        buf = ctypes.create_string_buffer(32 * max(count, 1))
+        self.L._check(self.L.c.hz_witness_read(self.h, instance, first, count, buf))
+        return fr_from_bytes(buf.raw[:32 * count])
+
+    def read_raw_bytes(self, first=0, count=None):
+        count = self.total() - first if count is None else count
+        buf = ctypes.create_string_buffer(32 * max(count, 1))
+        self.L._check(self.L.c.hz_witness_read_raw(self.h, first, count, buf))
+        return buf.raw[:32 * count]
+
+    def dev_ptr(self):
+        return self.L.c.hz_witness_dev_ptr(self.h)
+
+    def lookup(self, name):
+        idx = ctypes.c_uint64()
+        if not self.L.c.hz_symbol_lookup(self.h, name.encode(), ctypes.byref(idx)):
+            raise KeyError(name)
+        return idx.value
+
+    def get(self, name, instance=0):
+        return self.read(self.lookup(name), 1, instance)[0]
+
+    def symbol_count(self):
+        return self.L.c.hz_symbol_count(self.h)
+
+    def symbol(self, i):
+        s = hz_symbol()
+        self.L._check(self.L.c.hz_symbol_get(self.h, i, ctypes.byref(s)))
+        return s.name.decode(), s.index
 
 
 _lib = None

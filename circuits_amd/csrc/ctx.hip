@@ -1,0 +1,484 @@
+// hz_ctx: one "compiled circuit" -- layout, HBM-resident witness buffer, input upload, kernel
+// schedule, constraint-failure reporting, symbol table. Implements the context part of
+// include/hermez_witness.h (the calls that replace circom's tester()/calculateWitness()/assertOut(),
+// reference test/helpers/helpers.js:139-155).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "hostutil.h"
+#include "kernels.h"
+#include "tx_dev.h"
+
+using namespace hz;
+using namespace hzl;
+
+struct hz_ctx {
+    Layout lo;
+    int device = 0;
+    DevBuf wit, sc_tx, sc_fee, err, msg, chain, stage;
+    std::vector<uint8_t> input_set;
+    std::vector<uint8_t> host_stage;
+    hipStream_t last_stream = nullptr;
+    unsigned long long filter_stage = ~0ull;
+    bool enqueued = false;
+    // symbol enumeration index: cumulative symbol counts per (section, block)
+    struct BlkRef { int sec, blk; uint64_t first; uint32_t units; };
+    std::vector<BlkRef> sym_index;
+    uint64_t sym_total = 0;
+    std::string sym_name;
+};
+
+static uint8_t* sec_ptr(hz_ctx* c, int sec) { return (uint8_t*)c->wit.p + c->lo.sections[sec].base * 32; }
+
+static uint32_t block_units(const Layout& lo, const Section& s, const Block& b) {
+    const uint32_t nu = lo.instanced ? 1u : s.n_units;
+    return (b.max_units >= 0 && !lo.instanced) ? (uint32_t)b.max_units : nu;
+}
+
+extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
+    if (!p || !out) return set_err(HZ_ERR_ARG, "hz_ctx_create: null argument");
+    if (p->template_id < 0 || p->template_id >= T_COUNT) return set_err(HZ_ERR_ARG, "hz_ctx_create: unknown template %d", p->template_id);
+    Params lp;
+    lp.tmpl = p->template_id; lp.nTx = p->nTx; lp.L = p->nLevels; lp.maxL1 = p->maxL1Tx; lp.F = p->maxFeeTx;
+    lp.n_inst = p->n_instances > 0 ? p->n_instances : 1;
+    const bool needs_L = lp.tmpl != T_HASH_STATE;
+    if (needs_L && (lp.L < 2 || lp.L > 48)) return set_err(HZ_ERR_ARG, "nLevels must be in [2,48]");
+    if ((lp.tmpl == T_ROLLUP_MAIN || lp.tmpl == T_HASH_INPUTS) && (lp.nTx < 1 || lp.F < 1 || lp.maxL1 < 0))
+        return set_err(HZ_ERR_ARG, "RollupMain/HashInputs need nTx >= 1, maxFeeTx >= 1");
+    if (lp.tmpl == T_ROLLUP_TX && lp.F < 1) return set_err(HZ_ERR_ARG, "RollupTx needs maxFeeTx >= 1");
+    if ((lp.tmpl == T_ROLLUP_MAIN || lp.tmpl == T_HASH_INPUTS) && lp.n_inst != 1)
+        return set_err(HZ_ERR_ARG, "RollupMain/HashInputs contexts hold one instance; use one context per batch in flight");
+    if (hz_device_count() <= 0) return set_err(HZ_ERR_NODEVICE, "no usable gfx950 device");
+    if (p->device < 0 || p->device >= hz_device_count()) return set_err(HZ_ERR_ARG, "bad device ordinal %d", p->device);
+    hz_ctx* c = new hz_ctx();
+    build_layout(lp, c->lo);
+    c->device = p->device;
+    hipError_t e = hipSetDevice(c->device);
+    const Layout& lo = c->lo;
+    if (e == hipSuccess) e = c->wit.alloc(lo.total * 32);
+    if (e == hipSuccess) e = hipMemset(c->wit.p, 0, lo.total * 32);
+    if (e == hipSuccess) e = c->err.alloc(sizeof(ErrBuf));
+    if (e == hipSuccess && lo.sec_tx >= 0) e = c->sc_tx.alloc((size_t)SC_COUNT * lo.sections[lo.sec_tx].n_units * sizeof(Fr));
+    if (e == hipSuccess && lo.sec_fee >= 0) e = c->sc_fee.alloc((size_t)SC_COUNT * lo.sections[lo.sec_fee].n_units * sizeof(Fr));
+    if (e == hipSuccess && lo.sec_hi >= 0) {
+        e = c->msg.alloc((size_t)lo.hi.sha.nblocks * 64);
+        if (e == hipSuccess) e = c->chain.alloc((size_t)(lo.hi.sha.nblocks + 1) * 32);
+    }
+    if (e != hipSuccess) {
+        delete c;
+        return set_err(HZ_ERR_HIP, "hz_ctx_create: %s (witness buffer %.1f MiB)", hipGetErrorString(e), lo.total * 32.0 / 1048576.0);
+    }
+    c->input_set.assign(lo.inputs.size(), 0);
+    for (size_t si = 0; si < lo.sections.size(); si++)
+        for (size_t bi = 0; bi < lo.sections[si].blocks.size(); bi++) {
+            const Block& b = lo.sections[si].blocks[bi];
+            const uint32_t units = block_units(lo, lo.sections[si], b);
+            c->sym_index.push_back({(int)si, (int)bi, c->sym_total, units});
+            c->sym_total += (uint64_t)units * b.count;
+        }
+    *out = c;
+    return HZ_OK;
+}
+
+extern "C" void hz_ctx_destroy(hz_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    delete c;
+}
+extern "C" uint64_t hz_witness_len(const hz_ctx* c) { return c ? c->lo.per_instance : 0; }
+extern "C" uint64_t hz_constraint_estimate(const hz_ctx* c) { return c ? constraint_estimate(c->lo.p) : 0; }
+extern "C" const void* hz_witness_dev_ptr(const hz_ctx* c) { return c ? c->wit.p : nullptr; }
+extern "C" int32_t hz_input_count(const hz_ctx* c) { return c ? (int32_t)c->lo.inputs.size() : 0; }
+extern "C" const char* hz_input_name(const hz_ctx* c, int32_t i, uint64_t* flat_len) {
+    if (!c || i < 0 || (size_t)i >= c->lo.inputs.size()) return nullptr;
+    const InputDesc& d = c->lo.inputs[i];
+    if (flat_len) *flat_len = d.per_instance ? d.inner : (uint64_t)d.inner * d.outer;
+    return d.name.c_str();
+}
+extern "C" void hz_clear_inputs(hz_ctx* c) {
+    if (c) std::fill(c->input_set.begin(), c->input_set.end(), 0);
+}
+extern "C" const char* hz_constraint_name(int32_t id) { return constraint_name(id); }
+
+// transpose [outer][inner] -> [inner][outer] on the device (hz_set_input_dev)
+__global__ void k_transpose32(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t outer, uint32_t inner, uint32_t dst_pitch_elems) {
+    const size_t n = (size_t)outer * inner;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)(t / outer), u = (uint32_t)(t % outer);   // consecutive lanes -> consecutive units (coalesced stores)
+        const size_t s = ((size_t)u * inner + k) * 2, d = ((size_t)k * dst_pitch_elems + u) * 2;
+        dst[d] = src[s];
+        dst[d + 1] = src[s + 1];
+    }
+}
+
+static hz_status set_input_common(hz_ctx* c, int32_t instance, const char* name, const uint8_t* host, const void* dev, size_t count, hipStream_t stream) {
+    if (!c || !name || (!host && !dev)) return set_err(HZ_ERR_ARG, "hz_set_input: null argument");
+    const Layout& lo = c->lo;
+    const InputDesc* d = lo.find_input(name);
+    if (!d) return set_err(HZ_ERR_INPUT, "Signal not found: %s", name);
+    const Section& s = lo.sections[d->section];
+    HZ_HIP(hipSetDevice(c->device));
+    if (host)
+        for (size_t i = 0; i < count; i++)
+            if (!canon_lt_p(host + 32 * i)) return set_err(HZ_ERR_INPUT, "input %s[%zu] is not a canonical field element (>= r)", name, i);
+    uint8_t* dst0 = sec_ptr(c, d->section) + (size_t)d->off * s.n_units * 32;   // element (off, unit 0)
+    const size_t pitch = (size_t)s.n_units * 32;
+    uint32_t outer, u0 = 0;
+    if (d->per_instance) {
+        if (instance >= 0) {
+            if ((uint32_t)instance >= s.n_units || count != d->inner)
+                return set_err(HZ_ERR_INPUT, "input %s: expected %u values for instance %d, got %zu", name, d->inner, instance, count);
+            outer = 1;
+            u0 = (uint32_t)instance;
+        } else {
+            if (count != (size_t)d->inner * s.n_units)
+                return set_err(HZ_ERR_INPUT, "input %s: expected %zu values for all instances, got %zu", name, (size_t)d->inner * s.n_units, count);
+            outer = s.n_units;
+        }
+    } else {
+        if (instance != 0) return set_err(HZ_ERR_INPUT, "input %s: instance must be 0", name);
+        if (count != (size_t)d->inner * d->outer)
+            return set_err(HZ_ERR_INPUT, "input %s: expected %zu values, got %zu", name, (size_t)d->inner * d->outer, count);
+        outer = d->outer;
+    }
+    if (host) {
+        // host transpose [outer][inner] -> [inner][outer], then one (2-D) copy
+        c->host_stage.resize(count * 32);
+        uint8_t* st = c->host_stage.data();
+        if (d->inner == 1 || outer == 1) memcpy(st, host, count * 32);
+        else
+            for (uint32_t u = 0; u < outer; u++)
+                for (uint32_t k = 0; k < d->inner; k++) memcpy(st + ((size_t)k * outer + u) * 32, host + ((size_t)u * d->inner + k) * 32, 32);
+        HZ_HIP(hipMemcpy2D(dst0 + (size_t)u0 * 32, pitch, st, (size_t)outer * 32, (size_t)outer * 32, d->inner, hipMemcpyHostToDevice));
+    } else {
+        if (d->inner == 1 || outer == 1) {
+            HZ_HIP(hipMemcpy2DAsync(dst0 + (size_t)u0 * 32, pitch, dev, (size_t)outer * 32, (size_t)outer * 32, d->inner, hipMemcpyDeviceToDevice, stream));
+        } else {
+            const size_t n = (size_t)outer * d->inner;
+            const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+            hipLaunchKernelGGL(k_transpose32, dim3(blocks), dim3(256), 0, stream, (const uint4*)dev, (uint4*)(dst0 + (size_t)u0 * 32), outer, d->inner, s.n_units);
+            HZ_HIP(hipGetLastError());
+        }
+    }
+    c->input_set[d - &lo.inputs[0]] = 1;
+    return HZ_OK;
+}
+
+extern "C" hz_status hz_set_input(hz_ctx* c, int32_t instance, const char* name, const uint8_t* vals, size_t count) {
+    return set_input_common(c, instance, name, vals, nullptr, count, nullptr);
+}
+extern "C" hz_status hz_set_input_dev(hz_ctx* c, int32_t instance, const char* name, const void* dvals, size_t count, void* stream) {
+    return set_input_common(c, instance, name, nullptr, dvals, count, (hipStream_t)stream);
+}
+
+// ---- kernel schedule ---------------------------------------------------------------------------------
+static SmtProcDesc make_proc(const SmtProcOff& o, uint32_t siblings, int which /*0: p1, 1: p2, 2: fee*/) {
+    SmtProcDesc d;
+    d.o = o;
+    d.siblings = siblings;
+    if (which == 1) {
+        d.sc_oldkey = SC_KEY_S2OLD; d.sc_newkey = SC_KEY_2; d.sc_fnc0 = SC_P2_FNC0; d.sc_fnc1 = SC_P2_FNC1; d.sc_isold0 = SC_ISOLD0_2;
+        d.sc_leaf_old = SC_LEAF_P2OLD; d.sc_leaf_new = SC_LEAF_P2NEW; d.sc_root_old = SC_ROOT_P2OLD; d.sc_root_new = SC_ROOT_P2NEW;
+        d.cid_alias_old = C_RTX_P2_ALIAS_OLD; d.cid_alias_new = C_RTX_P2_ALIAS_NEW; d.cid_levins = C_RTX_P2_LEVINS; d.cid_sm_final = C_RTX_P2_SM_FINAL;
+    } else {
+        d.sc_oldkey = SC_KEY_S1OLD; d.sc_newkey = SC_KEY_1; d.sc_fnc0 = SC_P1_FNC0; d.sc_fnc1 = SC_P1_FNC1; d.sc_isold0 = SC_ISOLD0_1;
+        d.sc_leaf_old = SC_LEAF_P1OLD; d.sc_leaf_new = SC_LEAF_P1NEW; d.sc_root_old = SC_ROOT_P1OLD; d.sc_root_new = SC_ROOT_P1NEW;
+        if (which == 0) {
+            d.cid_alias_old = C_RTX_P1_ALIAS_OLD; d.cid_alias_new = C_RTX_P1_ALIAS_NEW; d.cid_levins = C_RTX_P1_LEVINS; d.cid_sm_final = C_RTX_P1_SM_FINAL;
+        } else {
+            d.cid_alias_old = C_FEE_P_ALIAS_OLD; d.cid_alias_new = C_FEE_P_ALIAS_NEW; d.cid_levins = C_FEE_P_LEVINS; d.cid_sm_final = C_FEE_P_SM_FINAL;
+        }
+    }
+    return d;
+}
+
+static Hash4Args make_hash4_rtx(uint8_t* base, Fr* sc, uint32_t n_units, const RtxOff& r) {
+    Hash4Args h;
+    memset(&h, 0, sizeof h);
+    h.base = base; h.scratch = sc; h.n_units = n_units; h.n_jobs = 4;
+    const PoseidonOff hs[4] = {r.oldSt1Hash, r.oldSt2Hash, r.newSt1Hash, r.newSt2Hash};
+    const PoseidonOff h1[4] = {r.p1.hash1Old, r.p2.hash1Old, r.p1.hash1New, r.p2.hash1New};
+    const uint32_t key[4] = {SC_KEY_S1OLD, SC_KEY_S2OLD, SC_KEY_1, SC_KEY_2};
+    const uint32_t leaf[4] = {SC_LEAF_P1OLD, SC_LEAF_P2OLD, SC_LEAF_P1NEW, SC_LEAF_P2NEW};
+    for (int j = 0; j < 4; j++) {
+        HashJob& J = h.job[j];
+        J.hs = hs[j]; J.h1 = h1[j]; J.sc_in = SC_HS_IN + 4 * j; J.sc_key = key[j]; J.sc_leaf = leaf[j];
+        J.mux_off = ~0u; J.sc_ins = 0; J.sc_oldvalue = 0; J.out_sig = ~0u;
+    }
+    h.job[0].mux_off = r.mux16 + MX_S1OLDVALUE; h.job[0].sc_ins = SC_ISP1INSERT; h.job[0].sc_oldvalue = SC_OLDVALUE1;
+    h.job[1].mux_off = r.mux16 + MX_S2OLDVALUE; h.job[1].sc_ins = SC_ISP2INSERT; h.job[1].sc_oldvalue = SC_OLDVALUE2;
+    return h;
+}
+
+static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, uint32_t sib1, uint32_t sib2, hipStream_t s) {
+    const Layout& lo = c->lo;
+    Fr* sc = (Fr*)c->sc_tx.p;
+    ErrBuf* err = (ErrBuf*)c->err.p;
+    HZ_HIP(launch_hash4(make_hash4_rtx(base, sc, n_units, lo.rtx), s));
+    SmtArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 2; sa.inst_is_unit = is_main ? 0 : 1;
+    sa.p[0] = make_proc(lo.rtx.p1, sib1, 0);
+    sa.p[1] = make_proc(lo.rtx.p2, sib2, 1);
+    HZ_HIP(launch_smt(sa, s));
+    EddsaArgs ea;
+    memset(&ea, 0, sizeof ea);
+    ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.inst_is_unit = is_main ? 0 : 1; ea.ed = lo.rtx.ed;
+    HZ_HIP(launch_eddsa(ea, s));
+    RtxBackArgs ba;
+    memset(&ba, 0, sizeof ba);
+    ba.base = base; ba.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; ba.scratch = sc; ba.err = err; ba.n_units = n_units; ba.L = (uint32_t)lo.p.L;
+    ba.is_main = is_main ? 1 : 0;
+    ba.p[0] = sa.p[0]; ba.p[1] = sa.p[1];
+    ba.s3 = lo.rtx.s3; ba.s4 = lo.rtx.s4; ba.s5 = lo.rtx.s5;
+    if (is_main) {
+        ba.im_stateroot = lo.mi.imStateRoot; ba.im_exitroot = lo.mi.imExitRoot; ba.g_initfeeroot = lo.g.imInitStateRootFee;
+        ba.main_l1l2amt = lo.rtx.main_l1l2amt; ba.n2bAmount = lo.dec.n2bAmount;
+    } else {
+        ba.o_newStateRoot = lo.rtxi.o_newStateRoot; ba.o_newExitRoot = lo.rtxi.o_newExitRoot;
+    }
+    HZ_HIP(launch_rtx_back(ba, s));
+    return HZ_OK;
+}
+
+static hz_status enqueue_fee(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, hipStream_t s) {
+    const Layout& lo = c->lo;
+    Fr* sc = (Fr*)c->sc_fee.p;
+    ErrBuf* err = (ErrBuf*)c->err.p;
+    FeeFrontArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.base = base; fa.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; fa.scratch = sc; fa.err = err; fa.n_units = n_units; fa.is_main = is_main;
+    fa.fee = lo.fee;
+    uint32_t sib;
+    if (is_main) {
+        const MainFeeInOff& f = lo.fi;
+        fa.in_feePlanToken = f.feePlanTokens; fa.in_feeIdx = f.feeIdxs; fa.in_accFee = f.imFinalAccFee; fa.in_tokenID = f.tokenID3; fa.in_nonce = f.nonce3;
+        fa.in_sign = f.sign3; fa.in_balance = f.balance3; fa.in_ay = f.ay3; fa.in_ethAddr = f.ethAddr3; fa.im_stateRootFee = f.imStateRootFee;
+        fa.g_initfeeroot = lo.g.imInitStateRootFee;
+        sib = f.siblings3;
+    } else {
+        const FeeTxInOff& f = lo.feei;
+        fa.in_feePlanToken = f.feePlanToken; fa.in_feeIdx = f.feeIdx; fa.in_accFee = f.accFee; fa.in_tokenID = f.tokenID; fa.in_nonce = f.nonce;
+        fa.in_sign = f.sign; fa.in_balance = f.balance; fa.in_ay = f.ay; fa.in_ethAddr = f.ethAddr; fa.in_oldStateRoot = f.oldStateRoot;
+        sib = f.siblings;
+    }
+    HZ_HIP(launch_fee_front(fa, s));
+    Hash4Args h;
+    memset(&h, 0, sizeof h);
+    h.base = base; h.scratch = sc; h.n_units = n_units; h.n_jobs = 2;
+    h.job[0] = HashJob{lo.fee.oldHash, lo.fee.p.hash1Old, SC_HS_IN + 0, SC_KEY_S1OLD, SC_LEAF_P1OLD, ~0u, 0, 0, ~0u};
+    h.job[1] = HashJob{lo.fee.newHash, lo.fee.p.hash1New, SC_HS_IN + 8, SC_KEY_1, SC_LEAF_P1NEW, ~0u, 0, 0, ~0u};
+    HZ_HIP(launch_hash4(h, s));
+    SmtArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 1; sa.inst_is_unit = is_main ? 0 : 1;
+    sa.p[0] = make_proc(lo.fee.p, sib, 2);
+    HZ_HIP(launch_smt(sa, s));
+    FeeBackArgs fb;
+    memset(&fb, 0, sizeof fb);
+    fb.base = base; fb.scratch = sc; fb.err = err; fb.n_units = n_units; fb.is_main = is_main; fb.p = sa.p[0];
+    fb.im_stateRootFee = is_main ? lo.fi.imStateRootFee : 0; fb.o_newStateRoot = lo.fee.o_newStateRoot;
+    HZ_HIP(launch_fee_back(fb, s));
+    return HZ_OK;
+}
+
+static HashInputsArgs make_hi(hz_ctx* c, bool is_main) {
+    const Layout& lo = c->lo;
+    HashInputsArgs a;
+    memset(&a, 0, sizeof a);
+    a.hi_base = sec_ptr(c, lo.sec_hi);
+    a.err = (ErrBuf*)c->err.p;
+    a.nTx = (uint32_t)lo.p.nTx; a.L = (uint32_t)lo.p.L; a.maxL1 = (uint32_t)lo.p.maxL1; a.F = (uint32_t)lo.p.F; a.is_main = is_main;
+    a.hi = lo.hi;
+    a.msg = (uint8_t*)c->msg.p; a.chain = (uint32_t*)c->chain.p;
+    if (is_main) {
+        a.glob_base = sec_ptr(c, lo.sec_glob); a.tx_base = sec_ptr(c, lo.sec_tx); a.fee_base = sec_ptr(c, lo.sec_fee);
+        a.tx_scratch = (Fr*)c->sc_tx.p; a.fee_scratch = (Fr*)c->sc_fee.p;
+        a.g = lo.g; a.mi_onChain = lo.mi.onChain; a.fi_feeIdxs = lo.fi.feeIdxs; a.dec = lo.dec; a.rtx_s5 = lo.rtx.s5; a.rtx_main_l1l2amt = lo.rtx.main_l1l2amt;
+    }
+    return a;
+}
+
+static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter) {
+    if (!c) return set_err(HZ_ERR_ARG, "hz_witness_enqueue: null context");
+    const Layout& lo = c->lo;
+    for (size_t i = 0; i < c->input_set.size(); i++)
+        if (!c->input_set[i]) return set_err(HZ_ERR_INPUT, "Not all inputs have been set: %s", lo.inputs[i].name.c_str());
+    HZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // error buffer header: minkey = ~0, filter (= ~0 unless hz_witness_check re-runs after an overflow), count = 0
+    HZ_HIP(hipMemsetAsync(c->err.p, 0xFF, 16, s));
+    HZ_HIP(hipMemsetAsync((uint8_t*)c->err.p + 16, 0, 8, s));
+    if (filter != ~0ull) {
+        c->filter_stage = filter;
+        HZ_HIP(hipMemcpyAsync((uint8_t*)c->err.p + 8, &c->filter_stage, 8, hipMemcpyHostToDevice, s));
+    }
+    ErrBuf* err = (ErrBuf*)c->err.p;
+    switch (lo.p.tmpl) {
+        case T_ROLLUP_MAIN: {
+            MainFrontArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.tx_base = sec_ptr(c, lo.sec_tx); fa.fee_base = sec_ptr(c, lo.sec_fee); fa.glob_base = sec_ptr(c, lo.sec_glob);
+            fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.nTx = (uint32_t)lo.p.nTx; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F;
+            fa.g = lo.g; fa.mi = lo.mi; fa.fi = lo.fi; fa.dec = lo.dec; fa.rtx = lo.rtx;
+            HZ_HIP(launch_main_front(fa, s));
+            hz_status st = enqueue_rtx_tail(c, fa.tx_base, fa.nTx, true, lo.mi.siblings1, lo.mi.siblings2, s);
+            if (st != HZ_OK) return st;
+            st = enqueue_fee(c, fa.fee_base, (uint32_t)lo.p.F, true, s);
+            if (st != HZ_OK) return st;
+            HZ_HIP(launch_hash_inputs(make_hi(c, true), s));
+            break;
+        }
+        case T_ROLLUP_TX: {
+            RtxFrontArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.base = sec_ptr(c, 0); fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.N = lo.sections[0].n_units; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F;
+            fa.in = lo.rtxi; fa.rtx = lo.rtx;
+            HZ_HIP(launch_rtx_front(fa, s));
+            hz_status st = enqueue_rtx_tail(c, fa.base, fa.N, false, lo.rtxi.siblings1, lo.rtxi.siblings2, s);
+            if (st != HZ_OK) return st;
+            break;
+        }
+        case T_DECODE_TX: {
+            DecMainArgs da;
+            memset(&da, 0, sizeof da);
+            da.base = sec_ptr(c, 0); da.err = err; da.N = lo.sections[0].n_units; da.L = (uint32_t)lo.p.L; da.in = lo.deci; da.dec = lo.dec;
+            HZ_HIP(launch_dec_main(da, s));
+            break;
+        }
+        case T_FEE_TX: {
+            hz_status st = enqueue_fee(c, sec_ptr(c, 0), lo.sections[0].n_units, false, s);
+            if (st != HZ_OK) return st;
+            break;
+        }
+        case T_HASH_STATE:
+            HZ_HIP(launch_hash_state_main(sec_ptr(c, 0), lo.sections[0].n_units, lo.hs, s));
+            break;
+        case T_WITHDRAW: {
+            WithdrawArgs wa;
+            memset(&wa, 0, sizeof wa);
+            wa.base = sec_ptr(c, 0); wa.err = err; wa.N = lo.sections[0].n_units; wa.L = (uint32_t)lo.p.L; wa.wd = lo.wd;
+            HZ_HIP(launch_withdraw(wa, s));
+            break;
+        }
+        case T_HASH_INPUTS:
+            HZ_HIP(launch_hash_inputs(make_hi(c, false), s));
+            break;
+    }
+    c->last_stream = s;
+    c->enqueued = true;
+    return HZ_OK;
+}
+
+extern "C" hz_status hz_witness_enqueue(hz_ctx* c, void* stream) { return enqueue_impl(c, stream, ~0ull); }
+
+static void fill_error(hz_error* out, unsigned long long key, const ErrRec* r) {
+    if (!out) return;
+    memset(out, 0, sizeof *out);
+    out->instance = (int32_t)(key >> 40);
+    out->unit = (int32_t)((key >> 16) & 0xFFFFFF);
+    out->constraint_id = (int32_t)(key & 0xFFFF);
+    if (r) {
+        memcpy(out->lhs, r->lhs, 32);
+        memcpy(out->rhs, r->rhs, 32);
+    }
+}
+
+extern "C" hz_status hz_witness_check(hz_ctx* c, hz_error* out) {
+    if (!c || !c->enqueued) return set_err(HZ_ERR_ARG, "hz_witness_check: nothing enqueued");
+    HZ_HIP(hipSetDevice(c->device));
+    struct { unsigned long long minkey, filter; unsigned int count, pad; } hd;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HZ_HIP(hipStreamSynchronize(c->last_stream));
+        c->enqueued = false;
+        HZ_HIP(hipMemcpy(&hd, c->err.p, sizeof hd, hipMemcpyDeviceToHost));
+        if (hd.minkey == ~0ull) return HZ_OK;
+        const unsigned int n = std::min<unsigned int>(hd.count, HZ_ERR_CAP);
+        std::vector<ErrRec> recs(n);
+        if (n) HZ_HIP(hipMemcpy(recs.data(), (uint8_t*)c->err.p + offsetof(ErrBuf, rec), n * sizeof(ErrRec), hipMemcpyDeviceToHost));
+        for (const ErrRec& r : recs)
+            if (r.key == hd.minkey) {
+                fill_error(out, hd.minkey, &r);
+                return set_err(HZ_ERR_CONSTRAINT, "Constraint doesn't match (%s, instance %d unit %d)", constraint_name((int)(hd.minkey & 0xFFFF)),
+                               (int)(hd.minkey >> 40), (int)((hd.minkey >> 16) & 0xFFFFFF));
+            }
+        if (attempt == 1) break;
+        // the record list overflowed before the first failure was appended: run again, recording only it
+        hz_status st = enqueue_impl(c, c->last_stream, hd.minkey);
+        if (st != HZ_OK) return st;
+    }
+    fill_error(out, hd.minkey, nullptr);
+    return set_err(HZ_ERR_CONSTRAINT, "Constraint doesn't match (%s, instance %d unit %d; operands not captured)", constraint_name((int)(hd.minkey & 0xFFFF)),
+                   (int)(hd.minkey >> 40), (int)((hd.minkey >> 16) & 0xFFFFFF));
+}
+
+extern "C" hz_status hz_witness_run(hz_ctx* c, hz_error* err) {
+    hz_status st = hz_witness_enqueue(c, nullptr);
+    if (st != HZ_OK) return st;
+    return hz_witness_check(c, err);
+}
+
+extern "C" hz_status hz_witness_read(hz_ctx* c, int32_t instance, uint64_t first, uint64_t count, uint8_t* out) {
+    if (!c || !out) return set_err(HZ_ERR_ARG, "hz_witness_read: null argument");
+    const Layout& lo = c->lo;
+    if (first + count > lo.per_instance) return set_err(HZ_ERR_ARG, "hz_witness_read: range beyond the witness");
+    HZ_HIP(hipSetDevice(c->device));
+    if (count == 0) return HZ_OK;
+    if (lo.instanced) {
+        const uint32_t N = lo.sections[0].n_units;
+        if (instance < 0 || (uint32_t)instance >= N) return set_err(HZ_ERR_ARG, "hz_witness_read: bad instance");
+        const uint8_t* src = (const uint8_t*)c->wit.p + ((size_t)first * N + (uint32_t)instance) * 32;
+        HZ_HIP(hipMemcpy2D(out, 32, src, (size_t)N * 32, 32, count, hipMemcpyDeviceToHost));
+    } else {
+        if (instance != 0) return set_err(HZ_ERR_ARG, "hz_witness_read: bad instance");
+        HZ_HIP(hipMemcpy(out, (const uint8_t*)c->wit.p + first * 32, count * 32, hipMemcpyDeviceToHost));
+    }
+    return HZ_OK;
+}
+
+// raw physical view (signal-major), for bulk consumers and tests
+extern "C" hz_status hz_witness_read_raw(hz_ctx* c, uint64_t first, uint64_t count, uint8_t* out) {
+    if (!c || !out) return set_err(HZ_ERR_ARG, "hz_witness_read_raw: null argument");
+    if (first + count > c->lo.total) return set_err(HZ_ERR_ARG, "hz_witness_read_raw: range beyond the buffer");
+    HZ_HIP(hipSetDevice(c->device));
+    if (count) HZ_HIP(hipMemcpy(out, (const uint8_t*)c->wit.p + first * 32, count * 32, hipMemcpyDeviceToHost));
+    return HZ_OK;
+}
+extern "C" uint64_t hz_witness_total(const hz_ctx* c) { return c ? c->lo.total : 0; }
+
+// ---- symbols ---------------------------------------------------------------------------------------------
+extern "C" uint64_t hz_symbol_count(const hz_ctx* c) { return c ? c->sym_total : 0; }
+
+extern "C" hz_status hz_symbol_get(const hz_ctx* cc, uint64_t i, hz_symbol* out) {
+    hz_ctx* c = const_cast<hz_ctx*>(cc);
+    if (!c || !out || i >= c->sym_total) return set_err(HZ_ERR_ARG, "hz_symbol_get: bad index");
+    // binary search the block
+    size_t lo_i = 0, hi_i = c->sym_index.size() - 1;
+    while (lo_i < hi_i) {
+        const size_t mid = (lo_i + hi_i + 1) / 2;
+        if (c->sym_index[mid].first <= i) lo_i = mid;
+        else hi_i = mid - 1;
+    }
+    const hz_ctx::BlkRef& r = c->sym_index[lo_i];
+    const Section& s = c->lo.sections[r.sec];
+    const Block& b = s.blocks[r.blk];
+    const uint64_t rel = i - r.first;
+    const uint32_t u = (uint32_t)(rel / b.count), k = (uint32_t)(rel % b.count);
+    std::string nm = ssub(b.name, "{u}", istr(u));
+    if (b.kind == BK_POSEIDON) nm += poseidon_signame(b.t, (int)k);
+    else if (b.count > 1 || b.scalar_array) nm += "[" + istr(k) + "]";
+    c->sym_name = nm;
+    out->name = c->sym_name.c_str();
+    out->index = c->lo.virt(r.sec, b.off + k, u);
+    return HZ_OK;
+}
+
+extern "C" int32_t hz_symbol_lookup(const hz_ctx* c, const char* name, uint64_t* index) {
+    if (!c || !name) return 0;
+    uint64_t idx = 0;
+    if (!c->lo.lookup(name, &idx)) return 0;
+    if (index) *index = idx;
+    return 1;
+}

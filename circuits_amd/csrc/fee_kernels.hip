@@ -1,0 +1,365 @@
+// FeeTx (reference src/fee-tx.circom:26-112), HashState as main (src/lib/hash-state.circom:18-40),
+// HashInputs (src/hash-inputs.circom:23-185) and Withdraw (src/withdraw.circom:21-176).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "sha_dev.h"
+#include "smt_dev.h"
+
+namespace hz {
+
+// ---- FeeTx front: lane = fee tx ---------------------------------------------------------------
+__global__ __launch_bounds__(HZ_BLOCK) void k_fee_front(const FeeFrontArgs a) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n_units) return;
+    const UnitIO io{a.base, a.n_units, j, a.is_main ? 0u : j, a.is_main ? j : 0u, a.err};
+    const Scratch sc{a.scratch, a.n_units, j};
+    const Fr one = fr_one(), zero = fr_zero();
+    if (!a.is_main) io.put_u64(0, 1);
+    const Fr feeIdx = io.in_m(a.in_feeIdx), feePlanToken = io.in_m(a.in_feePlanToken), tokenID = io.in_m(a.in_tokenID);
+    Fr z[2] = {feeIdx, fr_sub(tokenID, feePlanToken)};   // tokenIDChecker: in[0] = feePlanToken, in[1] = tokenID
+    Fr zi[2] = {z[0], z[1]};
+    batch_inv<2>(zi, 2);
+    const Fr fz = is_zero_dev(io, a.fee.feeIdxIsZero, z[0], zi[0]);
+    const Fr e = is_zero_dev(io, a.fee.tokenIDChecker, z[1], zi[1]);
+    io.chk_zero(C_FEE_TOKENID, fr_mul(fr_sub(one, e), fr_sub(one, fz)));
+    const Fr nonce = io.in_m(a.in_nonce), sign = io.in_m(a.in_sign), balance = io.in_m(a.in_balance), ay = io.in_m(a.in_ay),
+             ethAddr = io.in_m(a.in_ethAddr), accFee = io.in_m(a.in_accFee);
+    const Fr e0 = fr_add(fr_add(tokenID, fr_mul(nonce, m_pow2(32))), fr_mul(sign, m_pow2(72)));
+    sc.set(SC_HS_IN + 0, e0); sc.set(SC_HS_IN + 1, balance); sc.set(SC_HS_IN + 2, ay); sc.set(SC_HS_IN + 3, ethAddr);
+    sc.set(SC_HS_IN + 8, e0); sc.set(SC_HS_IN + 9, fr_add(accFee, balance)); sc.set(SC_HS_IN + 10, ay); sc.set(SC_HS_IN + 11, ethAddr);
+    sc.set(SC_KEY_S1OLD, feeIdx); sc.set(SC_KEY_1, feeIdx);
+    sc.set(SC_P1_FNC0, zero); sc.set(SC_P1_FNC1, fr_sub(one, fz)); sc.set(SC_ISOLD0_1, zero);
+    Fr oldRoot;
+    if (a.is_main) {
+        oldRoot = j == 0 ? fr_from_canon(load_fr(a.glob_base + (size_t)a.g_initfeeroot * 32)) : io.in_m_u(a.im_stateRootFee, j - 1);
+    } else {
+        oldRoot = io.in_m(a.in_oldStateRoot);
+    }
+    sc.set(SC_OLDSTATEROOT, oldRoot);
+}
+
+__global__ __launch_bounds__(HZ_BLOCK) void k_fee_back(const FeeBackArgs a) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n_units) return;
+    const UnitIO io{a.base, a.n_units, j, a.is_main ? 0u : j, a.is_main ? j : 0u, a.err};
+    const Scratch sc{a.scratch, a.n_units, j};
+    const Fr root = smt_top_dev(io, sc, a.p, sc.get(SC_OLDSTATEROOT), C_FEE_P_OLDROOT, C_FEE_P_KEYS);
+    sc.set(SC_ROOT_P2NEW, root);  // feeTx.newStateRoot for HashInputs
+    if (a.is_main) {
+        if (j + 1 < a.n_units) io.chk(C_MAIN_IM_FEEROOT, root, io.in_m(a.im_stateRootFee));
+    } else {
+        io.put_m(a.o_newStateRoot, root);
+    }
+}
+
+// ---- HashState as main component ------------------------------------------------------------------
+struct HsMainArgs { uint8_t* base; uint32_t N; HashStateOff hs; };
+__global__ __launch_bounds__(HZ_BLOCK) void k_hash_state_main(const HsMainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    Fr* C5 = reinterpret_cast<Fr*>(lds_raw);
+    Fr* M5 = C5 + poseidon_nconst<5>();
+    stage_poseidon_consts<5>(C5);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    const UnitIO io{a.base, a.N, i, i, 0, nullptr};
+    const HashStateOff& h = a.hs;
+    io.put_u64(h.one, 1);
+    Fr hin[4];
+    hin[0] = fr_add(fr_add(io.in_m(h.tokenID), fr_mul(io.in_m(h.nonce), m_pow2(32))), fr_mul(io.in_m(h.sign), m_pow2(72)));
+    hin[1] = io.in_m(h.balance); hin[2] = io.in_m(h.ay); hin[3] = io.in_m(h.ethAddr);
+    WitSboxSink s5 = io.sbox_sink(h.hash);
+    io.put_m(h.out, poseidon_hash<5>(hin, C5, M5, s5));
+}
+
+// ---- HashInputs --------------------------------------------------------------------------------------
+// k_hi_prep: lane 0 = header/tail fields (+ their Num2Bits signals), then one lane per L1 slot,
+// per transaction and per fee transaction; every lane ORs its bits into the zeroed message buffer.
+__device__ __forceinline__ void msg_put_be(uint32_t* msgw, uint64_t pos, const Fr& canon, int n) {
+    for (int k = 0; k < n; k++) msg_set_bit(msgw, pos + k, c_bit(canon, n - 1 - k));
+}
+
+__global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t L = a.L, nTx = a.nTx, maxL1 = a.maxL1, Fn = a.F;
+    const uint32_t n_items = 1 + maxL1 + nTx + Fn;
+    if (t >= n_items) return;
+    uint32_t* msgw = reinterpret_cast<uint32_t*>(a.msg);
+    const HashInputsOff& o = a.hi;
+    const uint64_t offL1 = 2 * 48 + 3 * 256, offL2 = offL1 + (uint64_t)maxL1 * L1FULL_BITS, offFee = offL2 + (uint64_t)nTx * (2 * L + 48);
+    const uint64_t offTail = offFee + (uint64_t)Fn * L;
+    const UnitIO hio{a.hi_base, 1, 0, 0, 0, a.err};
+    if (t == 0) {
+        Fr oldLastIdx, newLastIdx, oldStateRoot, newStateRoot, newExitRoot, chainID, batch;
+        if (a.is_main) {
+            auto glob = [&](uint32_t sig) { return load_fr(a.glob_base + (size_t)sig * 32); };
+            oldLastIdx = glob(a.g.oldLastIdx); oldStateRoot = glob(a.g.oldStateRoot); chainID = glob(a.g.globalChainID); batch = glob(a.g.currentNumBatch);
+            newLastIdx = fr_to_canon(a.tx_scratch[(size_t)SC_OUTIDX * nTx + (nTx - 1)]);
+            newStateRoot = fr_to_canon(a.fee_scratch[(size_t)SC_ROOT_P2NEW * Fn + (Fn - 1)]);
+            newExitRoot = load_fr(a.tx_base + ((size_t)a.rtx_s5 * nTx + (nTx - 1)) * 32);
+        } else {
+            hio.put_u64(o.one, 1);
+            oldLastIdx = hio.in_c(o.i_oldLastIdx); newLastIdx = hio.in_c(o.i_newLastIdx); oldStateRoot = hio.in_c(o.i_oldStateRoot);
+            newStateRoot = hio.in_c(o.i_newStateRoot); newExitRoot = hio.in_c(o.i_newExitRoot); chainID = hio.in_c(o.i_globalChainID);
+            batch = hio.in_c(o.i_currentNumBatch);
+        }
+        auto idx48 = [&](uint32_t off, const Fr& v) {
+            num2bits_dev(hio, off, v, 48, C_HI_N2B);
+            uint32_t pad = 0;
+            for (uint32_t i = L; i < 48; i++) pad += c_bit(v, i);
+            if (pad) report_fail(hio.err, 0, 0, C_HI_PAD, fr_from_u64(pad), fr_zero());
+        };
+        idx48(o.n2bOldLastIdx, oldLastIdx);
+        idx48(o.n2bNewLastIdx, newLastIdx);
+        // Num2Bits(256) of a field element never fails (value < r < 2^254)
+        for (int k = 0; k < 256; k++) { hio.put_bit(o.n2bOldStateRoot + k, c_bit(oldStateRoot, k)); hio.put_bit(o.n2bNewStateRoot + k, c_bit(newStateRoot, k));
+                                        hio.put_bit(o.n2bNewExitRoot + k, c_bit(newExitRoot, k)); }
+        num2bits_dev(hio, o.n2bChainID, chainID, 16, C_HI_N2B);
+        num2bits_dev(hio, o.n2bCurrentNumBatch, batch, 32, C_HI_N2B);
+        msg_put_be(msgw, 0, oldLastIdx, 48); msg_put_be(msgw, 48, newLastIdx, 48); msg_put_be(msgw, 96, oldStateRoot, 256);
+        msg_put_be(msgw, 352, newStateRoot, 256); msg_put_be(msgw, 608, newExitRoot, 256);
+        msg_put_be(msgw, offTail, chainID, 16); msg_put_be(msgw, offTail + 16, batch, 32);
+        // padding: 1 bit, zeros, 64-bit length
+        const uint64_t nbits = o.totalBits;
+        msg_set_bit(msgw, nbits, 1);
+        const uint64_t total = (uint64_t)o.sha.nblocks * 512;
+        for (int k = 0; k < 64; k++) msg_set_bit(msgw, total - 1 - k, (uint32_t)((nbits >> k) & 1));
+        return;
+    }
+    uint32_t u = t - 1;
+    if (u < maxL1) {   // L1TxsFullData slot u: the stored products are bit*onChain
+        for (uint32_t k = 0; k < L1FULL_BITS; k++) {
+            uint32_t bit;
+            if (a.is_main) bit = (u < nTx) ? (load_fr(a.tx_base + ((size_t)(a.dec.l1full + k) * nTx + u) * 32).v[0] & 1u) : 0u;
+            else bit = hio.in_c(o.i_L1TxsFullData + u * L1FULL_BITS + k).v[0] & 1u;
+            msg_set_bit(msgw, offL1 + (uint64_t)u * L1FULL_BITS + k, bit);
+        }
+        return;
+    }
+    u -= maxL1;
+    if (u < nTx) {
+        const uint64_t pos = offL2 + (uint64_t)u * (2 * L + 48);
+        if (a.is_main) {
+            auto txs = [&](uint32_t sig) { return load_fr(a.tx_base + ((size_t)sig * nTx + u) * 32).v[0] & 1u; };
+            for (uint32_t k = 0; k < L; k++) msg_set_bit(msgw, pos + (L - 1 - k), txs(a.dec.n2bData + 48 + k));
+            for (uint32_t k = 0; k < L; k++) msg_set_bit(msgw, pos + (2 * L - 1 - k), txs(a.dec.n2bFinalToIdx + k));
+            for (uint32_t k = 0; k < 40; k++) msg_set_bit(msgw, pos + 2 * L + k, txs(a.rtx_main_l1l2amt + k));
+            for (uint32_t k = 0; k < 8; k++) msg_set_bit(msgw, pos + 2 * L + 40 + k, txs(a.dec.l1l2Fee + k));
+        } else {
+            for (uint32_t k = 0; k < 2 * L + 48; k++) msg_set_bit(msgw, pos + k, hio.in_c(o.i_L1L2TxsData + u * (2 * L + 48) + k).v[0] & 1u);
+        }
+        return;
+    }
+    u -= nTx;
+    {
+        const Fr v = a.is_main ? load_fr(a.fee_base + ((size_t)a.fi_feeIdxs * Fn + u) * 32) : hio.in_c(o.i_feeTxsData + u);
+        num2bits_dev(hio, o.n2bFee + 48 * u, v, 48, C_HI_N2B);
+        uint32_t pad = 0;
+        for (uint32_t i = L; i < 48; i++) pad += c_bit(v, i);
+        if (pad) report_fail(hio.err, 0, 0, C_HI_PAD, fr_from_u64(pad), fr_zero());
+        msg_put_be(msgw, offFee + (uint64_t)u * L, v, (int)L);
+    }
+}
+
+// sequential chaining values: chain[b] = state before block b; then the digest -> output signal
+__global__ void k_sha_chain(const HashInputsArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg);
+    uint32_t hv[8];
+    for (int i = 0; i < 8; i++) hv[i] = SHA_H0[i];
+    const int nb = a.hi.sha.nblocks;
+    for (int b = 0; b < nb; b++) {
+        for (int i = 0; i < 8; i++) a.chain[8 * b + i] = hv[i];
+        uint32_t w16[16];
+        for (int i = 0; i < 16; i++) w16[i] = msgw[16 * b + i];
+        sha256_compress(hv, w16);
+    }
+    const Fr out = sha_digest_to_fr(hv);
+    if (a.is_main) store_fr(a.glob_base + (size_t)a.g.hashGlobalInputs * 32, out);
+    else store_fr(a.hi_base + (size_t)a.hi.out * 32, out);
+    if (a.is_main) {
+        uint4* q = reinterpret_cast<uint4*>(a.glob_base + (size_t)a.g.one * 32);
+        q[0] = make_uint4(1u, 0u, 0u, 0u);
+        q[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// per-block bit-level witness: one lane per block
+__global__ __launch_bounds__(HZ_BLOCK) void k_sha_expand(const HashInputsArgs a) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (uint32_t)a.hi.sha.nblocks) return;
+    const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg);
+    const UnitIO hio{a.hi_base, 1, 0, 0, 0, a.err};
+    uint32_t hv[8], w16[16];
+    for (int i = 0; i < 8; i++) hv[i] = a.chain[8 * b + i];
+    for (int i = 0; i < 16; i++) w16[i] = msgw[16 * b + i];
+    sha256_block_witness(hio, a.hi.sha.blocks + b * a.hi.sha.block_size, hv, w16);
+}
+
+// ---- Withdraw: lane = instance -----------------------------------------------------------------------
+__global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    Fr* C5 = reinterpret_cast<Fr*>(lds_raw);
+    Fr* M5 = C5 + poseidon_nconst<5>();
+    Fr* C4 = M5 + 25;
+    Fr* M4 = C4 + poseidon_nconst<4>();
+    Fr* C3 = M4 + 16;
+    Fr* M3 = C3 + poseidon_nconst<3>();
+    stage_poseidon_consts<5>(C5);
+    stage_poseidon_consts<4>(C4);
+    stage_poseidon_consts<3>(C3);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    const UnitIO io{a.base, a.N, i, i, 0, a.err};
+    const WithdrawOff& o = a.wd;
+    const int n = (int)a.L + 1;
+    const Fr one = fr_one(), zero = fr_zero();
+    io.put_u64(o.one, 1);
+    const Fr rootExit_c = io.in_c(o.rootExit), ethAddr_c = io.in_c(o.ethAddr), tokenID_c = io.in_c(o.tokenID), balance_c = io.in_c(o.balance),
+             idx_c = io.in_c(o.idx);
+    const Fr rootExit = fr_from_canon(rootExit_c), idx = fr_from_canon(idx_c);
+    // accountState = HashState(tokenID, nonce 0, sign, balance, ay, ethAddr)
+    Fr hin[4];
+    hin[0] = fr_add(fr_from_canon(tokenID_c), fr_mul(io.in_m(o.sign), m_pow2(72)));
+    hin[1] = fr_from_canon(balance_c); hin[2] = io.in_m(o.ay); hin[3] = fr_from_canon(ethAddr_c);
+    WitSboxSink s5 = io.sbox_sink(o.accountState);
+    const Fr st = poseidon_hash<5>(hin, C5, M5, s5);
+    // SMTVerifier(n): enabled = 1, fnc = 0, oldKey = oldValue = isOld0 = 0
+    const SmtVerOff& v = o.ver;
+    Fr h1in[3] = {zero, zero, one};
+    WitSboxSink so = io.sbox_sink(v.hash1Old);
+    const Fr h1old = poseidon_hash<4>(h1in, C4, M4, so);
+    (void)h1old;
+    h1in[0] = idx; h1in[1] = st;
+    WitSboxSink sn = io.sbox_sink(v.hash1New);
+    const Fr h1new = poseidon_hash<4>(h1in, C4, M4, sn);
+    num2bits_strict_dev(io, v.n2bOld, zero, C_WD_N2B_OLD);
+    num2bits_strict_dev(io, v.n2bNew, idx_c, C_WD_ALIAS_NEW);
+    // SMTLevIns
+    uint64_t zmask = 0;
+    for (int base = 0; base < n; base += 16) {
+        const int cnt = (n - base) < 16 ? (n - base) : 16;
+        Fr z[16], zi[16];
+        for (int k = 0; k < cnt; k++) { z[k] = io.in_m(o.siblingsState + base + k); zi[k] = z[k]; if (fr_is_zero(z[k])) zmask |= 1ull << (base + k); }
+        batch_inv<16>(zi, cnt);
+        for (int k = 0; k < cnt; k++) is_zero_dev(io, v.isz + 2 * (base + k), z[k], zi[k]);
+    }
+    if (!((zmask >> (n - 1)) & 1)) io.chk_zero(C_WD_LEVINS, fr_neg(one));
+    uint64_t levmask = 0;
+    {
+        uint32_t done = 0;
+        uint32_t li = 1u - (uint32_t)((zmask >> (n - 2)) & 1);
+        if (li) levmask |= 1ull << (n - 1);
+        done = li;
+        for (int k = n - 2; k > 0; k--) {
+            li = (1u - done) * (1u - (uint32_t)((zmask >> (k - 1)) & 1));
+            if (li) levmask |= 1ull << k;
+            done += li;
+        }
+        if (!done) levmask |= 1ull;
+    }
+    for (int k = 1; k <= n - 2; k++) io.put_bit(v.levIns + (k - 1), (uint32_t)((levmask >> k) & 1));
+    // SMTVerifierSM with enabled = 1, fnc = 0, is0 = 0: st_top stays 1 until the insertion level,
+    // where st_inew becomes 1; afterwards st_na. All values are bits.
+    uint64_t topmask = 0, inewmask = 0;
+    {
+        uint32_t p_top = 1, p_inew = 0, p_na = 0;
+        uint32_t last = 0;
+        for (int k = 0; k < n; k++) {
+            const uint32_t lev = (uint32_t)((levmask >> k) & 1);
+            const uint32_t ptli = p_top & lev;
+            const uint32_t t_top = p_top - ptli, t_inew = ptli, t_na = p_na + p_inew;
+            io.put_bit(v.sm + VSM_N * k + VSM_PTLI, ptli); io.put_bit(v.sm + VSM_N * k + VSM_PTLIF, 0);
+            io.put_bit(v.sm + VSM_N * k + VSM_IOLD, 0); io.put_bit(v.sm + VSM_N * k + VSM_I0, 0);
+            if (t_top) topmask |= 1ull << k;
+            if (t_inew) inewmask |= 1ull << k;
+            if (k == n - 1) last = t_na + t_inew;
+            p_top = t_top; p_inew = t_inew; p_na = t_na;
+        }
+        if (last != 1) io.chk(C_WD_SM_FINAL, fr_from_u64(last), one);
+    }
+    Fr child = zero;
+    for (int k = n - 1; k >= 0; k--) {
+        const uint32_t lv = v.levels + VL_SIZE * k;
+        const uint32_t sel = c_bit(idx_c, k);
+        const Fr sib = io.in_m(o.siblingsState + k);
+        io.put_m(lv + VL_SW_AUX, sel ? fr_sub(sib, child) : zero);
+        Fr h2[2];
+        h2[0] = sel ? sib : child;
+        h2[1] = sel ? child : sib;
+        WitSboxSink sk = io.sbox_sink(lv + VL_HASH);
+        const Fr ph = poseidon_hash<3>(h2, C3, M3, sk);
+        const Fr a0 = ((topmask >> k) & 1) ? ph : zero;
+        const Fr root = ((inewmask >> k) & 1) ? fr_add(a0, h1new) : a0;
+        io.put_m(lv + VL_AUX0, a0); io.put_u64(lv + VL_AUX1, 0); io.put_m(lv + VL_ROOT, root);
+        child = root;
+    }
+    {
+        // areKeyEquals(oldKey = 0, key); keysOk = MultiAND(4)(fnc=0, 1-isOld0=1, keq, enabled=1)
+        Fr z[2] = {idx, fr_sub(rootExit, child)};   // checkRoot: in[0] = levels[0].root, in[1] = root
+        Fr zi[2] = {z[0], z[1]};
+        batch_inv<2>(zi, 2);
+        const Fr keq = is_zero_dev(io, v.keyEq, z[0], zi[0]);
+        io.put_u64(v.and_a, 0); io.put_m(v.and_b, keq); io.put_u64(v.and_c, 0);
+        const Fr e = is_zero_dev(io, v.checkRoot, z[1], zi[1]);
+        io.chk_zero(C_WD_ROOT, fr_sub(one, e));
+    }
+    // HashInputsWithdrawal
+    for (int k = 0; k < 256; k++) io.put_bit(o.n2bRootExit + k, c_bit(rootExit_c, k));
+    num2bits_dev(io, o.n2bEthAddr, ethAddr_c, 160, C_WD_HI_N2B);
+    num2bits_dev(io, o.n2bTokenID, tokenID_c, 32, C_WD_HI_N2B);
+    num2bits_dev(io, o.n2bBalance, balance_c, 192, C_WD_HI_N2B);
+    num2bits_dev(io, o.n2bIdx, idx_c, 48, C_WD_HI_N2B);
+    {
+        uint32_t pad = 0;
+        for (int j = (int)a.L; j < 48; j++) pad += c_bit(idx_c, j);
+        if (pad) report_fail(io.err, io.inst, 0, C_WD_HI_PAD, fr_from_u64(pad), zero);
+    }
+    uint32_t msg[32];
+    for (int k = 0; k < 32; k++) msg[k] = 0;
+    auto put_be = [&](int pos, const Fr& c, int nb) {
+        for (int k = 0; k < nb; k++)
+            if (c_bit(c, nb - 1 - k)) msg[(pos + k) >> 5] |= 1u << (31 - ((pos + k) & 31));
+    };
+    put_be(0, rootExit_c, 256); put_be(256, ethAddr_c, 160); put_be(416, tokenID_c, 32); put_be(448, balance_c, 192); put_be(640, idx_c, 48);
+    msg[688 >> 5] |= 1u << (31 - (688 & 31));
+    msg[31] = 688;
+    uint32_t hv[8];
+    for (int k = 0; k < 8; k++) hv[k] = SHA_H0[k];
+    sha256_block_witness(io, o.sha.blocks, hv, msg);
+    sha256_block_witness(io, o.sha.blocks + o.sha.block_size, hv, msg + 16);
+    io.put_c(o.hashGlobalInputs, sha_digest_to_fr(hv));
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
+hipError_t launch_fee_front(const FeeFrontArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_fee_front, grid1(a.n_units), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_fee_back, grid1(a.n_units), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff& hs, hipStream_t s) {
+    HsMainArgs a{base, N, hs};
+    hipLaunchKernelGGL(k_hash_state_main, grid1(N), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<5>() * 32, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s) {
+    const size_t msg_bytes = (size_t)a.hi.sha.nblocks * 64;
+    hipError_t e = hipMemsetAsync(a.msg, 0, msg_bytes, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_hi_prep, grid1(1 + a.maxL1 + a.nTx + a.F), dim3(HZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_sha_chain, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_sha_expand, grid1((uint32_t)a.hi.sha.nblocks), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_withdraw, grid1(a.N), dim3(HZ_BLOCK),
+                       (size_t)(poseidon_const_frs<5>() + poseidon_const_frs<4>() + poseidon_const_frs<3>()) * 32, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace hz

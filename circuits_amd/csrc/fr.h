@@ -132,7 +132,14 @@ HZ_HD Fr fr_dbl(const Fr& a) { return fr_add(a, a); }
 
 // Montgomery product a*b/R mod p. CIOS, interleaved, using the "no final carry" shortcut that
 // holds because the top limb of p is < 2^31.
+// Out of line on the device unless HZ_FR_MUL_INLINE is defined: the product is ~700 instructions and
+// the witness kernels call it from hundreds of sites; one shared body keeps them inside the
+// instruction cache (and compiles in seconds instead of minutes).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_FR_MUL_INLINE)
+static __device__ __attribute__((noinline)) Fr fr_mul(const Fr a, const Fr b) {
+#else
 HZ_HD Fr fr_mul(const Fr& a, const Fr& b) {
+#endif
     uint32_t t[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) t[i] = 0;
@@ -170,7 +177,11 @@ HZ_HD Fr fr_from_canon(const Fr& a) {
     for (int i = 0; i < 8; i++) r2.v[i] = fr_r2(i);
     return fr_mul(a, r2);
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_FR_MUL_INLINE)
+static __device__ __attribute__((noinline)) Fr fr_to_canon(const Fr a) {
+#else
 HZ_HD Fr fr_to_canon(const Fr& a) {
+#endif
     // Montgomery reduction of a (multiply by 1): 8 rounds of m*p accumulation only
     uint32_t t[8];
 #pragma unroll

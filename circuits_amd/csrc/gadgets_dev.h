@@ -1,0 +1,197 @@
+// Device-side circuit gadgets: one lane evaluates the gadget for its unit and writes the gadget's
+// stored signals (see include/hz_layout.h for which signals are stored and where).
+// Restates circomlib 0.5.2 bitify / comparators / compconstant / mux (absent from
+// /root/reference) for CDNA4 lanes.
+#pragma once
+#include "../../include/hz_layout.h"
+#include "devcommon.h"
+
+namespace hz {
+using namespace hzl;
+
+// One lane's view of a witness section: loads inputs, stores signals, reports failed constraints.
+struct UnitIO {
+    uint8_t* base;      // section base (bytes)
+    uint32_t n_units;
+    uint32_t unit;
+    uint32_t inst;      // instance id for the failure key
+    uint32_t err_unit;  // unit id for the failure key
+    ErrBuf* err;
+
+    __device__ __forceinline__ uint8_t* addr(uint32_t sig) const { return base + ((size_t)sig * n_units + unit) * 32; }
+    __device__ __forceinline__ uint8_t* addr_u(uint32_t sig, uint32_t u) const { return base + ((size_t)sig * n_units + u) * 32; }
+    __device__ __forceinline__ Fr in_c(uint32_t sig) const { return load_fr(addr(sig)); }                    // canonical
+    __device__ __forceinline__ Fr in_m(uint32_t sig) const { return fr_from_canon(load_fr(addr(sig))); }      // Montgomery
+    __device__ __forceinline__ Fr in_c_u(uint32_t sig, uint32_t u) const { return load_fr(addr_u(sig, u)); }
+    __device__ __forceinline__ Fr in_m_u(uint32_t sig, uint32_t u) const { return fr_from_canon(load_fr(addr_u(sig, u))); }
+    __device__ __forceinline__ void put_m(uint32_t sig, const Fr& m) const { store_fr(addr(sig), fr_to_canon(m)); }
+    __device__ __forceinline__ void put_c(uint32_t sig, const Fr& c) const { store_fr(addr(sig), c); }
+    __device__ __forceinline__ void put_u64(uint32_t sig, uint64_t x) const {
+        uint4* q = reinterpret_cast<uint4*>(addr(sig));
+        q[0] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), 0u, 0u);
+        q[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __device__ __forceinline__ void put_bit(uint32_t sig, uint32_t b) const { put_u64(sig, b & 1u); }
+    // `lhs === rhs` (Montgomery operands)
+    __device__ __forceinline__ void chk(int cid, const Fr& lhs, const Fr& rhs) const {
+        if (!fr_eq(lhs, rhs)) report_fail(err, inst, err_unit, (uint32_t)cid, lhs, rhs);
+    }
+    __device__ __forceinline__ void chk_zero(int cid, const Fr& lhs) const {
+        if (!fr_is_zero(lhs)) report_fail(err, inst, err_unit, (uint32_t)cid, lhs, fr_zero());
+    }
+    __device__ __forceinline__ WitSboxSink sbox_sink(uint32_t sig0) const { return WitSboxSink{WitOut{base, n_units, unit}, sig0}; }
+};
+
+// inter-kernel scratch: Montgomery elements, field-major [field][unit]
+struct Scratch {
+    Fr* p;
+    uint32_t n_units;
+    uint32_t unit;
+    __device__ __forceinline__ Fr get(uint32_t f) const { return p[(size_t)f * n_units + unit]; }
+    __device__ __forceinline__ void set(uint32_t f, const Fr& v) const { p[(size_t)f * n_units + unit] = v; }
+};
+
+// ---- canonical-integer helpers ---------------------------------------------------------------------
+__device__ __forceinline__ uint32_t c_bit(const Fr& c, int i) { return (c.v[i >> 5] >> (i & 31)) & 1u; }
+// bits [from, from+n) of a canonical integer as u64 (n <= 64)
+__device__ __forceinline__ uint64_t c_bits64(const Fr& c, int from, int n) {
+    uint64_t r = 0;
+    for (int i = 0; i < n; i++) r |= (uint64_t)c_bit(c, from + i) << i;
+    return r;
+}
+// canonical integer with bits [from, from+n) of c moved to position 0 (n <= 256)
+__device__ __forceinline__ Fr c_extract(const Fr& c, int from, int n) {
+    Fr r = fr_zero();
+    for (int i = 0; i < n; i++) r.v[i >> 5] |= c_bit(c, from + i) << (i & 31);
+    return r;
+}
+// is the canonical integer < 2^n ?
+__device__ __forceinline__ bool c_fits(const Fr& c, int n) {
+    for (int i = n; i < 256; i++)
+        if (c_bit(c, i)) return false;
+    return true;
+}
+__device__ __forceinline__ Fr c_pow2(int k) {  // canonical 2^k, k < 254... (k < 256 as plain integer)
+    Fr r = fr_zero();
+    r.v[k >> 5] = 1u << (k & 31);
+    return r;
+}
+// Montgomery 2^k for k < 253
+__device__ __forceinline__ Fr m_pow2(int k) { return fr_from_canon(c_pow2(k)); }
+
+// Num2Bits(n): stores out[0..n) from the canonical value; reports `sum === in` when it cannot hold
+__device__ __forceinline__ void num2bits_dev(const UnitIO& io, uint32_t off, const Fr& canon, int n, int cid) {
+    for (int i = 0; i < n; i++) io.put_bit(off + i, c_bit(canon, i));
+    if (n < 254 && !c_fits(canon, n)) {
+        // lc1 = value mod 2^n
+        Fr lc = c_extract(canon, 0, n);
+        report_fail(io.err, io.inst, io.err_unit, (uint32_t)cid, fr_from_canon(lc), fr_from_canon(canon));
+    }
+}
+
+// IsZero with a precomputed inverse: stores inv,out; returns out (Montgomery 0/1)
+__device__ __forceinline__ Fr is_zero_dev(const UnitIO& io, IsZOff off, const Fr& in_m, const Fr& inv_m) {
+    const bool z = fr_is_zero(in_m);
+    io.put_m(off, inv_m);
+    io.put_bit(off + 1, z ? 1u : 0u);
+    return fr_from_bit(z ? 1u : 0u);
+}
+
+// Montgomery batch inversion of n values in place (zeros stay zero). 3(n-1) products + 1 inversion.
+template <int N>
+__device__ __forceinline__ void batch_inv(Fr (&x)[N], int n) {
+    Fr pre[N];
+    Fr acc = fr_one();
+    for (int i = 0; i < n; i++) {
+        pre[i] = acc;
+        if (!fr_is_zero(x[i])) acc = fr_mul(acc, x[i]);
+    }
+    Fr inv = fr_inv(acc);
+    for (int i = n - 1; i >= 0; i--) {
+        if (fr_is_zero(x[i])) continue;
+        const Fr xi = x[i];
+        x[i] = fr_mul(inv, pre[i]);
+        inv = fr_mul(inv, xi);
+    }
+}
+
+__device__ __forceinline__ Fr mux1_dev(const Fr& c0, const Fr& c1, const Fr& s) { return fr_add(fr_mul(fr_sub(c1, c0), s), c0); }
+
+// CompConstant(ct) over 254 bits given as canonical integer `bits` (bit i = in[i]); `nbits_valid`
+// lets the caller force upper inputs to 0 (EdDSA passes 253 bits + a zero). Stores parts[127] and
+// num2bits.out[135]; returns out (1 if in > ct).
+// parts are small: each is  +-b_i, +-a_i, ... with a_i = 2^i, b_i = 2^128 - 2^i, so the sum fits
+// in 135 bits of a plain integer; evaluated with 192-bit integer arithmetic, no field products.
+__device__ __forceinline__ uint32_t comp_constant_dev(const UnitIO& io, const CompConstOff& off, const Fr& bits, const uint32_t* ct /*8 LE limbs*/) {
+    // sum accumulates in 5 x 32-bit limbs (160 bits)
+    uint32_t sum[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 127; i++) {
+        const uint32_t clsb = (ct[(2 * i) >> 5] >> ((2 * i) & 31)) & 1u, cmsb = (ct[(2 * i + 1) >> 5] >> ((2 * i + 1) & 31)) & 1u;
+        const uint32_t slsb = c_bit(bits, 2 * i), smsb = c_bit(bits, 2 * i + 1);
+        // a = 2^i, b = 2^128 - 2^i. part in {0, a, b}:
+        //  c=00: -b*m*l + b*m + b*l  -> b if (m|l) else 0
+        //  c=01: a*m*l - a*l + b*m - a*m + a -> m ? (l ? b : b... ) evaluate by cases below
+        //  c=10: b*m*l - a*m + a -> m ? (l ? b : 0) : a
+        //  c=11: -a*m*l + a -> (m&l) ? 0 : a
+        int sel;  // 0: zero, 1: a, 2: b
+        if (!cmsb && !clsb) sel = (smsb | slsb) ? 2 : 0;
+        else if (!cmsb && clsb) sel = smsb ? 2 : (slsb ? 0 : 1);   // m=1: l=1 -> a - a + b - a + a = b ; l=0 -> b - a + a = b. m=0: l=1 -> -a + a = 0 ; l=0 -> a
+        else if (cmsb && !clsb) sel = smsb ? (slsb ? 2 : 0) : 1;   // m=1,l=1: b - a + a = b ; m=1,l=0: -a + a = 0 ; m=0: a
+        else sel = (smsb & slsb) ? 0 : 1;
+        // store part
+        Fr part = fr_zero();
+        if (sel == 1) part.v[i >> 5] = 1u << (i & 31);
+        else if (sel == 2) {
+            // 2^128 - 2^i
+            Fr t = fr_zero();
+            t.v[4] = 1u;
+            // subtract 2^i
+            uint32_t sub[5] = {0, 0, 0, 0, 0};
+            sub[i >> 5] = 1u << (i & 31);
+            uint64_t br = 0;
+            for (int k = 0; k < 5; k++) {
+                const uint64_t d = (uint64_t)t.v[k] - sub[k] - br;
+                t.v[k] = (uint32_t)d;
+                br = (d >> 63) & 1;
+            }
+            part = t;
+        }
+        io.put_c(off.parts + i, part);
+        uint64_t c = 0;
+        for (int k = 0; k < 5; k++) {
+            c += (uint64_t)sum[k] + part.v[k];
+            sum[k] = (uint32_t)c;
+            c >>= 32;
+        }
+    }
+    for (int i = 0; i < 135; i++) io.put_bit(off.bits + i, (sum[i >> 5] >> (i & 31)) & 1u);
+    return (sum[127 >> 5] >> (127 & 31)) & 1u;
+}
+
+__constant__ const uint32_t CT_MINUS1_D[8] = {0xf0000000u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+__constant__ const uint32_t CT_HALF_D[8] = {0xf8000000u, 0xa1f0fac9u, 0x3cdcb848u, 0x9419f424u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};
+__constant__ const uint32_t CT_SUBORDER_M1_D[8] = {0x392126f0u, 0x677297dcu, 0x3920ee0au, 0xab3eedb8u, 0xd0302b0bu, 0x370a08b6u, 0x5c263405u, 0x060c89ceu};
+
+// Num2Bits_strict: bits + AliasCheck
+__device__ __forceinline__ void num2bits_strict_dev(const UnitIO& io, const N2BStrictOff& off, const Fr& canon, int cid_alias) {
+    for (int i = 0; i < 254; i++) io.put_bit(off.bits + i, c_bit(canon, i));
+    const uint32_t o = comp_constant_dev(io, off.cc, canon, CT_MINUS1_D);
+    if (o) report_fail(io.err, io.inst, io.err_unit, (uint32_t)cid_alias, fr_one(), fr_zero());
+}
+
+// DecodeFloatBin (reference src/lib/decode-float.circom:12-44) on 40 bits given as u64
+__device__ __forceinline__ Fr decode_float_dev(const UnitIO& io, const DecodeFloatOff& o, uint64_t f40) {
+    // pe[0] = 9*e0 + 1 ; pe[i] = (pe[i-1]*10^(2^i) - pe[i-1])*e[i] + pe[i-1]
+    Fr pe = fr_from_u64(((f40 >> 35) & 1) ? 10 : 1);
+    Fr p10 = fr_from_u64(10);
+    for (int i = 1; i < 5; i++) {
+        p10 = fr_sqr(p10);
+        if ((f40 >> (35 + i)) & 1) pe = fr_mul(pe, p10);
+        io.put_m(o.pe + (i - 1), pe);
+    }
+    const Fr out = fr_mul(fr_from_u64(f40 & ((1ull << 35) - 1)), pe);
+    io.put_m(o.out, out);
+    return out;
+}
+
+}  // namespace hz

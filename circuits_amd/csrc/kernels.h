@@ -1,0 +1,166 @@
+// Kernel argument blocks and host launchers of the witness kernels (tx_kernels.hip,
+// eddsa_kernels.hip, fee_kernels.hip, sha_kernels.hip). Argument blocks are passed by value.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/hz_layout.h"
+#include "devcommon.h"
+
+namespace hz {
+using namespace hzl;
+
+// One wavefront per workgroup: at nTx = 2048 a batch is only 32 wavefronts per lane mapping, so
+// small workgroups spread them over as many CUs (and all 8 XCDs) as possible.
+#define HZ_BLOCK 64
+#define HZ_MAX_SMT_LEVELS 49
+
+struct MainFrontArgs {
+    uint8_t* tx_base;
+    uint8_t* fee_base;
+    uint8_t* glob_base;
+    Fr* scratch;
+    ErrBuf* err;
+    uint32_t nTx, L, F;
+    MainGlobOff g;
+    MainTxInOff mi;
+    MainFeeInOff fi;
+    DecOff dec;
+    RtxOff rtx;
+};
+
+struct RtxFrontArgs {
+    uint8_t* base;
+    Fr* scratch;
+    ErrBuf* err;
+    uint32_t N, L, F;
+    RtxInOff in;
+    RtxOff rtx;
+};
+
+struct DecMainArgs {
+    uint8_t* base;
+    ErrBuf* err;
+    uint32_t N, L;
+    DecInOff in;
+    DecOff dec;
+};
+
+// one hash-state job of k_hash4 (blockIdx.y selects the job)
+struct HashJob {
+    PoseidonOff hs;        // HashState Poseidon (t = 5) signals
+    PoseidonOff h1;        // SMTHash1 (t = 4) signals, ~0u = none
+    uint32_t sc_in;        // scratch: 4 Poseidon inputs
+    uint32_t sc_key;       // scratch: key for SMTHash1
+    uint32_t sc_leaf;      // scratch: destination of the leaf hash
+    uint32_t mux_off;      // s1OldValue/s2OldValue signal or ~0u
+    uint32_t sc_ins, sc_oldvalue;
+    uint32_t out_sig;      // signal receiving the hash-state output (~0u = none)
+};
+struct Hash4Args {
+    uint8_t* base;
+    Fr* scratch;
+    uint32_t n_units, n_jobs;
+    HashJob job[4];
+};
+
+struct SmtProcDesc {
+    SmtProcOff o;
+    uint32_t siblings;            // input offset of siblings[0]
+    int sc_oldkey, sc_newkey, sc_fnc0, sc_fnc1, sc_isold0, sc_leaf_old, sc_leaf_new, sc_root_old, sc_root_new;
+    int cid_alias_old, cid_alias_new, cid_levins, cid_sm_final;
+};
+
+struct SmtArgs {
+    uint8_t* base;
+    Fr* scratch;
+    ErrBuf* err;
+    uint32_t n_units, n_levels;   // n_levels = L + 1
+    uint32_t n_proc;
+    uint32_t inst_is_unit;
+    SmtProcDesc p[2];
+};
+
+struct RtxBackArgs {
+    uint8_t* base;
+    uint8_t* glob_base;
+    Fr* scratch;
+    ErrBuf* err;
+    uint32_t n_units, L, is_main;
+    SmtProcDesc p[2];
+    uint32_t s3, s4, s5;
+    // main: integrity checks + data-availability masking
+    uint32_t im_stateroot, im_exitroot, g_initfeeroot, main_l1l2amt, n2bAmount;
+    // standalone: outputs
+    uint32_t o_newStateRoot, o_newExitRoot;
+};
+
+struct EddsaArgs {
+    uint8_t* base;
+    Fr* scratch;
+    ErrBuf* err;
+    uint32_t n_units, inst_is_unit;
+    EddsaOff ed;
+};
+
+// FeeTx (reference src/fee-tx.circom:26-112): front = IsZero/checker + hash-state inputs,
+// back = processor top + newStateRoot (+ RollupMain phase G check)
+struct FeeFrontArgs {
+    uint8_t* base;
+    uint8_t* glob_base;
+    Fr* scratch;
+    ErrBuf* err;
+    uint32_t n_units, is_main;
+    FeeTxOff fee;
+    // input offsets (MainFeeInOff names for main, FeeTxInOff for standalone)
+    uint32_t in_feePlanToken, in_feeIdx, in_accFee, in_tokenID, in_nonce, in_sign, in_balance, in_ay, in_ethAddr, in_oldStateRoot;
+    uint32_t im_stateRootFee, g_initfeeroot;
+};
+struct FeeBackArgs {
+    uint8_t* base;
+    Fr* scratch;
+    ErrBuf* err;
+    uint32_t n_units, is_main;
+    SmtProcDesc p;
+    uint32_t im_stateRootFee, o_newStateRoot;
+};
+
+struct HashInputsArgs {
+    uint8_t* hi_base;    // hash-inputs section (1 unit)
+    uint8_t* glob_base;
+    uint8_t* tx_base;
+    uint8_t* fee_base;
+    Fr* tx_scratch;
+    Fr* fee_scratch;
+    ErrBuf* err;
+    uint32_t nTx, L, maxL1, F, is_main;
+    HashInputsOff hi;
+    MainGlobOff g;
+    uint32_t mi_onChain, fi_feeIdxs;
+    DecOff dec;
+    uint32_t rtx_s5, rtx_main_l1l2amt;
+    uint32_t fee_newRoot_sc;   // scratch field holding feeTx newStateRoot
+    uint8_t* msg;              // device byte buffer for the padded message (nblocks * 64)
+    uint32_t* chain;           // device buffer: (nblocks + 1) * 8 chaining words
+};
+
+struct WithdrawArgs {
+    uint8_t* base;
+    Fr* scratch;
+    ErrBuf* err;
+    uint32_t N, L;
+    WithdrawOff wd;
+};
+
+hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s);
+hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s);
+hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s);
+hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
+hipError_t launch_smt(const SmtArgs& a, hipStream_t s);
+hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
+hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s);
+hipError_t launch_fee_front(const FeeFrontArgs& a, hipStream_t s);
+hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s);
+hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s);
+hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff& hs, hipStream_t s);
+hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s);
+
+}  // namespace hz

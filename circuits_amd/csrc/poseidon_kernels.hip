@@ -5,6 +5,7 @@
 // HBM traffic per permutation: 32*(t-1) B in + 32 B out (digest mode), plus 96*(8t+R_P) B when the
 // S-box witness is requested. Digest mode is integer-VALU bound; witness mode is the HBM-write
 // bound regime of the rollup witness.
+#define HZ_FR_MUL_INLINE 1  // throughput kernel: keep the product inline (register-allocated operands)
 #include <hip/hip_runtime.h>
 #include "../../include/hermez_witness.h"
 #include "devcommon.h"

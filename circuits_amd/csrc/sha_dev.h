@@ -1,0 +1,109 @@
+// Bit-level SHA-256 compression witness (circomlib 0.5.2 sha256/*.circom: sha256compression,
+// sigmaplus, sigma, t1, t2, ch, maj, xor3, binsum; absent from /root/reference -- standard
+// FIPS 180-4 arithmetic, so values are checkable against any SHA-256). Used by HashInputs
+// (reference src/hash-inputs.circom:112-184) and HashInputsWithdrawal (src/withdraw.circom:84-176).
+// Per-block signal order: see include/hz_layout.h (SHA_SCHED_W / SHA_ROUND_W).
+#pragma once
+#include "gadgets_dev.h"
+
+namespace hz {
+
+__constant__ const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+__constant__ const uint32_t SHA_H0[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int r) { return (x >> r) | (x << (32 - r)); }
+
+// plain compression (chaining value only)
+__device__ __forceinline__ void sha256_compress(uint32_t* hv, const uint32_t* w16) {
+    uint32_t w[64];
+    for (int t = 0; t < 16; t++) w[t] = w16[t];
+    for (int t = 16; t < 64; t++) {
+        const uint32_t s0 = rotr32(w[t - 15], 7) ^ rotr32(w[t - 15], 18) ^ (w[t - 15] >> 3);
+        const uint32_t s1 = rotr32(w[t - 2], 17) ^ rotr32(w[t - 2], 19) ^ (w[t - 2] >> 10);
+        w[t] = s1 + w[t - 7] + s0 + w[t - 16];
+    }
+    uint32_t a = hv[0], b = hv[1], c = hv[2], d = hv[3], e = hv[4], f = hv[5], g = hv[6], h = hv[7];
+    for (int t = 0; t < 64; t++) {
+        const uint32_t t1 = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[t] + w[t];
+        const uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    hv[0] += a; hv[1] += b; hv[2] += c; hv[3] += d; hv[4] += e; hv[5] += f; hv[6] += g; hv[7] += h;
+}
+
+__device__ __forceinline__ void put_word_bits(const UnitIO& io, uint32_t off, uint64_t v, int n) {
+    for (int k = 0; k < n; k++) io.put_bit(off + k, (uint32_t)((v >> k) & 1));
+}
+// Xor3: mid = b & c, out = a ^ b ^ c  (64 signals)
+__device__ __forceinline__ uint32_t xor3_dev(const UnitIO& io, uint32_t off, uint32_t a, uint32_t b, uint32_t c) {
+    put_word_bits(io, off, b & c, 32);
+    const uint32_t o = a ^ b ^ c;
+    put_word_bits(io, off + 32, o, 32);
+    return o;
+}
+
+// compression with the full bit-level witness written at signal offset `base`
+__device__ void sha256_block_witness(const UnitIO& io, uint32_t base, uint32_t* hv, const uint32_t* w16) {
+    uint32_t w[64];
+    for (int t = 0; t < 16; t++) w[t] = w16[t];
+#pragma unroll 1
+    for (int t = 16; t < 64; t++) {
+        const uint32_t o = base + (uint32_t)(t - 16) * SHA_SCHED_W;
+        const uint32_t x15 = w[t - 15], x2 = w[t - 2];
+        const uint32_t s0 = xor3_dev(io, o, rotr32(x15, 7), rotr32(x15, 18), x15 >> 3);
+        const uint32_t s1 = xor3_dev(io, o + 64, rotr32(x2, 17), rotr32(x2, 19), x2 >> 10);
+        const uint64_t sum = (uint64_t)s1 + w[t - 7] + s0 + w[t - 16];
+        put_word_bits(io, o + 128, sum, 34);
+        w[t] = (uint32_t)sum;
+    }
+    uint32_t a = hv[0], b = hv[1], c = hv[2], d = hv[3], e = hv[4], f = hv[5], g = hv[6], h = hv[7];
+    const uint32_t rbase = base + 48 * SHA_SCHED_W;
+#pragma unroll 1
+    for (int t = 0; t < 64; t++) {
+        const uint32_t o = rbase + (uint32_t)t * SHA_ROUND_W;
+        const uint32_t S1 = xor3_dev(io, o, rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+        const uint32_t ch = (e & f) ^ (~e & g);
+        put_word_bits(io, o + 64, ch, 32);
+        const uint64_t t1 = (uint64_t)h + S1 + ch + SHA_K[t] + w[t];
+        put_word_bits(io, o + 96, t1, 35);
+        const uint32_t S0 = xor3_dev(io, o + 131, rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+        const uint32_t mid = b & c, maj = (a & b) ^ (a & c) ^ (b & c);
+        put_word_bits(io, o + 195, mid, 32);
+        put_word_bits(io, o + 227, maj, 32);
+        const uint64_t t2 = (uint64_t)S0 + maj;
+        put_word_bits(io, o + 259, t2, 33);
+        const uint64_t se = (uint64_t)d + (uint32_t)t1, sa = (uint64_t)(uint32_t)t1 + (uint32_t)t2;
+        put_word_bits(io, o + 292, se, 33);
+        put_word_bits(io, o + 325, sa, 33);
+        h = g; g = f; f = e; e = (uint32_t)se; d = c; c = b; b = a; a = (uint32_t)sa;
+    }
+    const uint32_t fbase = rbase + 64 * SHA_ROUND_W;
+    const uint32_t st[8] = {a, b, c, d, e, f, g, h};
+    for (int i = 0; i < 8; i++) {
+        const uint64_t s = (uint64_t)hv[i] + st[i];
+        put_word_bits(io, fbase + 33 * i, s, 33);
+        hv[i] = (uint32_t)s;
+    }
+}
+
+// digest (8 big-endian words) as a 256-bit integer reduced mod r -> canonical Fr
+__device__ __forceinline__ Fr sha_digest_to_fr(const uint32_t* hv) {
+    Fr r;
+    for (int i = 0; i < 8; i++) r.v[i] = hv[7 - i];
+    // value < 2^256 < 6r: subtract r while >= r
+    for (int k = 0; k < 5; k++) fr_cond_sub_p(r.v);
+    return r;
+}
+
+// set message bit p (0 = first bit of the message) in a word buffer laid out as SHA words
+__device__ __forceinline__ void msg_set_bit(uint32_t* msgw, uint64_t p, uint32_t bit) {
+    if (bit) atomicOr(&msgw[p >> 5], 1u << (31 - (uint32_t)(p & 31)));
+}
+
+}  // namespace hz

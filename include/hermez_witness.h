@@ -100,7 +100,8 @@ uint64_t hz_constraint_estimate(const hz_ctx* ctx);
 
 /* inputs: `name` is a main-component input signal (e.g. "siblings1"); `vals` holds `count`
  * canonical 32-byte LE integers in circom's row-major flattening of the signal's dimensions,
- * for instance `instance`. Values >= r are rejected. */
+ * for instance `instance`. For templates evaluated over n_instances, `instance` = -1 sets all
+ * instances at once (`vals` = [n_instances][flat_len]). Values >= r are rejected. */
 hz_status hz_set_input(hz_ctx* ctx, int32_t instance, const char* name, const uint8_t* vals, size_t count);
 /* same, but `vals` already lives in device memory of ctx's device */
 hz_status hz_set_input_dev(hz_ctx* ctx, int32_t instance, const char* name, const void* dvals, size_t count, void* stream);
@@ -119,7 +120,10 @@ hz_status hz_witness_run(hz_ctx* ctx, hz_error* err);
 
 /* output: copy `count` elements starting at flat index `first` of instance `instance` to host */
 hz_status hz_witness_read(hz_ctx* ctx, int32_t instance, uint64_t first, uint64_t count, uint8_t* out);
-/* device view of the whole witness buffer ([instance][hz_witness_len] x 32 B) */
+/* The physical buffer: sections stored signal-major (include/hz_layout.h); `total` elements. For
+ * instanced templates element (signal s, instance k) sits at s * n_instances + k. */
+uint64_t hz_witness_total(const hz_ctx* ctx);
+hz_status hz_witness_read_raw(hz_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out);
 const void* hz_witness_dev_ptr(const hz_ctx* ctx);
 
 /* symbols ------------------------------------------------------------------------------------ */

@@ -1069,10 +1069,10 @@ inline void build_layout(const Params& p, Layout& lo) {
             RtxInOff& r = lo.rtxi;
             T.add("main.one");
             r.o_isAmountNullified = T.add("main.isAmountNullified");
-            lo.rtx.o_accFeeOut = T.add("main.accFeeOut", F, -1, true);
+            const uint32_t o_accFeeOut = T.add("main.accFeeOut", F, -1, true);
             r.o_newStateRoot = T.add("main.newStateRoot");
             r.o_newExitRoot = T.add("main.newExitRoot");
-            lo.outputs = {{"isAmountNullified", r.o_isAmountNullified}, {"accFeeOut", lo.rtx.o_accFeeOut}, {"newStateRoot", r.o_newStateRoot}, {"newExitRoot", r.o_newExitRoot}};
+            lo.outputs = {{"isAmountNullified", r.o_isAmountNullified}, {"accFeeOut", o_accFeeOut}, {"newStateRoot", r.o_newStateRoot}, {"newExitRoot", r.o_newExitRoot}};
 #define HZL_RIN(f, cnt) r.f = in1(T, 0, #f, cnt, N, -1, true)
             HZL_RIN(feePlanTokens, F); HZL_RIN(accFeeIn, F);
             r.futureV2 = in1(T, 0, "futureTxCompressedDataV2", 3, N, -1, true);
@@ -1090,6 +1090,7 @@ inline void build_layout(const Params& p, Layout& lo) {
             HZL_RIN(oldExitRoot, 1);
 #undef HZL_RIN
             lay_rtx(T, "main.", L, F, false, lo.rtx);
+            lo.rtx.o_accFeeOut = o_accFeeOut;
             break;
         }
         case T_DECODE_TX: {

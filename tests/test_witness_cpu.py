@@ -1,0 +1,151 @@
+"""CPU-only tests: the oracle against the builder (an independent implementation of the protocol
+rules, SMT and EdDSA), against hashlib for SHA-256, layout/symbol consistency, error behaviour,
+and that the C-ABI library exports every declared symbol."""
+import os
+import re
+
+import pytest
+
+from oracle_binding import OracleCtx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+@pytest.fixture(scope="module")
+def small_batch():
+    from circuits_amd import builder as B
+    return B.synthetic_batch(8, 16, 3, 4, n_accounts=6, exits=2)
+
+
+def test_library_exports_every_declared_symbol():
+    from circuits_amd.capi import EXPORTS, Lib
+    hdr = open(os.path.join(ROOT, "include", "hermez_witness.h")).read()
+    declared = set(re.findall(r"\b(hz_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(EXPORTS), declared ^ set(EXPORTS)
+    L = Lib()
+    assert [s for s in EXPORTS if not hasattr(L.c, s)] == []
+    assert "gfx950" in L.version()
+
+
+def test_no_cpu_fallback_without_device():
+    from circuits_amd import HzError, lib
+    L = lib()
+    if L.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(HzError) as e:
+        L.poseidon_batch(3, [[1, 2]])
+    assert e.value.status == 5
+    with pytest.raises(HzError) as e:
+        L.ctx("hash-state")
+    assert e.value.status == 5
+
+
+def test_oracle_rollup_main_satisfies_all_constraints(small_batch):
+    bb = small_batch
+    o = OracleCtx("rollup-main", 8, 16, 3, 4)
+    o.set_inputs(bb.get_input())
+    assert o.run() is None
+    # the only public output, checked against an independent SHA-256 (hashlib) over the builder's packing
+    assert o.get("main.hashGlobalInputs") == bb.get_hash_inputs()
+    n, first = o.unwritten()
+    assert n == 0, first
+    assert o.get("main.one") == 1
+    # intermediate roots are the ones the builder's own SMT produced
+    inp = bb.get_input()
+    assert o.get("main.rollupTx[0].s4.out") == inp["imStateRoot"][0]
+    assert o.get("main.rollupTx[6].s5.out") == inp["imExitRoot"][6]
+
+
+def test_oracle_single_tx_matches_builder_expectations(small_batch):
+    # reference test/helpers/helpers.js:139-145 assertTxs
+    bb = small_batch
+    for i in range(bb.nTx):
+        inp, exp = bb.get_single_tx_input(i)
+        o = OracleCtx("rollup-tx", nLevels=16, maxFeeTx=4)
+        o.set_inputs(inp)
+        assert o.run() is None, i
+        assert o.get("main.newStateRoot") == exp["newStateRoot"]
+        assert o.get("main.newExitRoot") == exp["newExitRoot"]
+        assert o.get("main.isAmountNullified") == exp["isAmountNullified"]
+        assert [o.get("main.accFeeOut[%d]" % j) for j in range(4)] == exp["accFeeOut"]
+
+
+def test_oracle_detects_tampering(small_batch):
+    bb = small_batch
+    inp = dict(bb.get_input())
+    # wrong signature scalar on the first L2 tx -> eqCheck fails
+    i = inp["onChain"].index(0)
+    bad = dict(inp)
+    bad["s"] = list(inp["s"])
+    bad["s"][i] = (inp["s"][i] + 1) % P
+    o = OracleCtx("rollup-main", 8, 16, 3, 4)
+    o.set_inputs(bad)
+    r = o.run()
+    assert r is not None and r[1] == i and "eqCheck" in r[3]
+    # wrong intermediate root
+    bad = dict(inp)
+    bad["imStateRoot"] = list(inp["imStateRoot"])
+    bad["imStateRoot"][2] = (inp["imStateRoot"][2] + 1) % P
+    o = OracleCtx("rollup-main", 8, 16, 3, 4)
+    o.set_inputs(bad)
+    r = o.run()
+    assert r is not None and r[1] == 2 and "imStateRoot" in r[3]
+    # wrong sibling: processor old root mismatch ("Constraint doesn't match 1 != 0"-style product)
+    bad = dict(inp)
+    bad["siblings1"] = [list(x) for x in inp["siblings1"]]
+    bad["siblings1"][i][0] = (bad["siblings1"][i][0] + 1) % P
+    o = OracleCtx("rollup-main", 8, 16, 3, 4)
+    o.set_inputs(bad)
+    r = o.run()
+    assert r is not None and r[1] == i and "checkOldInput" in r[3] and (r[4], r[5]) == (1, 0)
+
+
+def test_oracle_withdraw(small_batch):
+    from circuits_amd import builder as B
+    bb = small_batch
+    idxs = sorted(bb.exit_leaves)
+    assert idxs
+    for idx in idxs:
+        inp, exp = B.withdraw_input(bb, idx, 16)
+        o = OracleCtx("withdraw", nLevels=16)
+        o.set_inputs(inp)
+        assert o.run() is None
+        assert o.get("main.hashGlobalInputs") == exp
+        assert o.unwritten()[0] == 0
+    # wrong balance -> root check fails with 1 != 0 (reference test/withdraw.test.js:160-171)
+    inp, _ = B.withdraw_input(bb, idxs[0], 16)
+    inp["balance"] += 1
+    o = OracleCtx("withdraw", nLevels=16)
+    o.set_inputs(inp)
+    r = o.run()
+    assert r is not None and "checkRoot" in r[3] and (r[4], r[5]) == (1, 0)
+
+
+def test_oracle_missing_and_misshaped_inputs(small_batch):
+    o = OracleCtx("rollup-main", 8, 16, 3, 4)
+    inp = dict(small_batch.get_input())
+    del inp["oldStateRoot"]
+    o.set_inputs(inp)
+    with pytest.raises(RuntimeError):
+        o.run()
+    with pytest.raises(ValueError):
+        o.set_input("siblings1", [0] * 5)
+    with pytest.raises(ValueError):
+        o.set_input("nope", [0])
+
+
+def test_symbol_names_follow_circom_convention():
+    o = OracleCtx("rollup-main", 8, 16, 3, 4)
+    for name in ("main.hashGlobalInputs", "hashGlobalInputs", "main.siblings1[3][5]", "main.decodeTx[0].n2bData.out[224]",
+                 "main.rollupTx[7].processor1.levels[16].oldProofHash.h.sigmaP[56].in4", "main.rollupTx[2].states.mux2.a10[0]",
+                 "main.rollupTx[1].feeAccumulator.chain[3].mux.out", "main.feeTx[3].processor.newRoot", "main.imStateRootFee[2]",
+                 "main.rollupTx[0].sigVerifier.mulAny.segments[1].bits[104].adder.lamda",
+                 "main.hasherInputs.n2bFeeTxsData[3].out[47]"):
+        o.lookup(name)
+    for name in ("main.imStateRootFee[3]", "main.siblings1[8][0]", "main.rollupTx[8].s4.out", "main.foo"):
+        with pytest.raises(KeyError):
+            o.lookup(name)
+    # every element of the witness has a name, except the padding slots of the arrays that are one
+    # unit shorter than their section (im*[nTx-1], imAccFeeOut[nTx-1][F], imStateRootFee[F-1])
+    assert o.o.c.orc_symbol_count(o.h) == o.witness_len() - (4 + 4 + 1)

@@ -1,0 +1,146 @@
+"""GPU parity tests: the HIP path through the C ABI against the CPU oracle, bit-exact on the whole
+witness buffer (every stored signal), on seeded inputs built by the batch builder."""
+import pytest
+
+from oracle_binding import OracleCtx
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+pytestmark = pytest.mark.gpu
+
+
+def _first_diff(g, o, octx):
+    for i in range(0, min(len(g), len(o)), 32):
+        if g[i:i + 32] != o[i:i + 32]:
+            return i // 32
+    return None
+
+
+def _compare(gctx, octx):
+    g, o = gctx.read_raw_bytes(), octx.read_raw_bytes()
+    assert len(g) == len(o)
+    if g != o:
+        k = _first_diff(g, o, octx)
+        # name of the first differing element
+        name = "?"
+        n = gctx.symbol_count()
+        total_units = 1
+        for i in range(min(n, 400000)):
+            nm, idx = gctx.symbol(i)
+            if idx == k:
+                name = nm
+                break
+        raise AssertionError("witness differs at physical element %d (%s): gpu=%d oracle=%d" % (
+            k, name, int.from_bytes(g[32 * k:32 * k + 32], "little"), int.from_bytes(o[32 * k:32 * k + 32], "little")))
+
+
+@pytest.fixture(scope="module")
+def batch():
+    from circuits_amd import builder as B
+    return B.synthetic_batch(8, 16, 3, 4, n_accounts=6, exits=2)
+
+
+def test_hash_state_config1(hz, oracle):
+    # BASELINE config 1 / reference test/lib/hash-state.test.js:31-57 (input literal, sign taken from tokenID)
+    state = {"tokenID": 1, "nonce": 49, "sign": 1, "balance": 12343256,
+             "ay": 0x144e7e10fd47e0c67a733643b760e80ed399f70e78ae97620dbb719579cd645d,
+             "ethAddr": 0x7e5f4552091a69125d5dfcb7b8c2659029395bdf}
+    g = hz.ctx("hash-state")
+    o = OracleCtx("hash-state")
+    g.set_inputs(state)
+    o.set_inputs(state)
+    g.run()
+    assert o.run() is None
+    _compare(g, o)
+    from circuits_amd import builder as B
+    assert g.get("main.out") == B.hash_state(state)
+
+
+def test_rollup_main_small_bit_exact(hz, batch):
+    g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4)
+    o = OracleCtx("rollup-main", 8, 16, 3, 4)
+    inp = batch.get_input()
+    g.set_inputs(inp)
+    o.set_inputs(inp)
+    g.run()
+    assert o.run() is None
+    assert g.witness_len() == o.witness_len()
+    assert g.get("main.hashGlobalInputs") == batch.get_hash_inputs()
+    _compare(g, o)
+
+
+def test_rollup_tx_config2_bit_exact(hz, batch):
+    # BASELINE config 2: one RollupTx witness per transaction of the batch (test/helpers/helpers.js:139-145)
+    n = batch.nTx
+    g = hz.ctx("rollup-tx", nLevels=16, maxFeeTx=4, n_instances=n)
+    o = OracleCtx("rollup-tx", nLevels=16, maxFeeTx=4, n_instances=n)
+    for i in range(n):
+        inp, exp = batch.get_single_tx_input(i)
+        g.set_inputs(inp, instance=i)
+        o.set_inputs(inp, instance=i)
+    g.run()
+    assert o.run() is None
+    _compare(g, o)
+    for i in range(n):
+        _, exp = batch.get_single_tx_input(i)
+        assert g.get("main.newStateRoot", i) == exp["newStateRoot"]
+        assert g.get("main.newExitRoot", i) == exp["newExitRoot"]
+        assert g.read(g.lookup("main.accFeeOut[0]"), 4, i) == exp["accFeeOut"]
+
+
+def test_withdraw_bit_exact(hz, batch):
+    from circuits_amd import builder as B
+    idxs = sorted(batch.exit_leaves)
+    g = hz.ctx("withdraw", nLevels=16, n_instances=len(idxs))
+    o = OracleCtx("withdraw", nLevels=16, n_instances=len(idxs))
+    exps = []
+    for k, idx in enumerate(idxs):
+        inp, exp = B.withdraw_input(batch, idx, 16)
+        g.set_inputs(inp, instance=k)
+        o.set_inputs(inp, instance=k)
+        exps.append(exp)
+    g.run()
+    assert o.run() is None
+    _compare(g, o)
+    for k, exp in enumerate(exps):
+        assert g.get("main.hashGlobalInputs", k) == exp
+
+
+def test_constraint_failures_match_oracle(hz, batch):
+    from circuits_amd import ConstraintError
+    inp = dict(batch.get_input())
+    i = inp["onChain"].index(0)
+    cases = []
+    bad = dict(inp); bad["s"] = list(inp["s"]); bad["s"][i] = (inp["s"][i] + 1) % P
+    cases.append(bad)
+    bad = dict(inp); bad["imStateRoot"] = list(inp["imStateRoot"]); bad["imStateRoot"][2] = (inp["imStateRoot"][2] + 1) % P
+    cases.append(bad)
+    bad = dict(inp); bad["siblings1"] = [list(x) for x in inp["siblings1"]]; bad["siblings1"][i][0] = (bad["siblings1"][i][0] + 1) % P
+    cases.append(bad)
+    bad = dict(inp); bad["onChain"] = list(inp["onChain"]); bad["onChain"][0] = 2
+    cases.append(bad)
+    for bad in cases:
+        g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4)
+        o = OracleCtx("rollup-main", 8, 16, 3, 4)
+        g.set_inputs(bad)
+        o.set_inputs(bad)
+        r = o.run()
+        assert r is not None
+        with pytest.raises(ConstraintError) as e:
+            g.run()
+        assert "Constraint doesn't match" in str(e.value)
+        assert (e.value.instance, e.value.unit, e.value.constraint_id, e.value.lhs, e.value.rhs) == (r[0], r[1], r[2], r[4], r[5])
+
+
+def test_input_errors(hz, batch):
+    from circuits_amd import HzError
+    g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4)
+    inp = dict(batch.get_input())
+    del inp["oldStateRoot"]
+    g.set_inputs(inp)
+    with pytest.raises(HzError) as e:
+        g.run()
+    assert e.value.status == 4 and "Not all inputs have been set" in str(e.value)
+    with pytest.raises(HzError):
+        g.set_input("siblings1", [0] * 5)
+    with pytest.raises(HzError):
+        g.set_input("nope", [0])
