@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- rollup-main tx-witnesses/sec on MI355X (BASELINE.json metric).
+
+A "step" is one complete witness pass of RollupMain(nTx, nLevels, maxL1Tx, maxFeeTx) over one
+synthetic batch whose inputs are already resident in HBM: DecodeTx + RollupTx for every
+transaction, the fee transactions and HashInputs (SHA-256), every constraint checked. Steps are
+issued round-robin over `--inflight` contexts/streams (independent batches in flight);
+the timed region is bracketed by barrier + device synchronisation and includes the constraint
+check of every step.
+
+N > 1 (launched by torch.distributed.run, one process per GPU): every rank runs its own batches
+-- batch-level data parallelism, no data-path collective (DESIGN.md "Multi-GPU") -- and the value
+is all ranks' transactions over the max-over-ranks time ("scaling": "weak").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_tx(L, F):
+    # 32 B x (DecodeTx + RollupTx R1CS variables, reference tools/circuit-constraints.js:31-44) + packed inputs
+    packed = {(32, 64): 4312, (16, 64): 3288}.get((L, F), 40 * 32 + 2 * (L + 1) * 32 + F * 24)
+    return 32 * ((4 * L + 1473) + (974 * L + 14552 + 5 * F)) + packed
+
+
+def cpu_baseline(n_tx, L, max_l1, F):
+    """The CPU oracle (restated CPU path, kind "port") on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleCtx
+    from circuits_amd import builder as B
+    bb = B.synthetic_batch(n_tx, L, max_l1, F, n_accounts=2 * n_tx, seed=7)
+    o = OracleCtx("rollup-main", n_tx, L, max_l1, F)
+    o.set_inputs(bb.get_input())
+    t = time.perf_counter()
+    r = o.run()
+    dt = time.perf_counter() - t
+    assert r is None, r
+    return {"value": round(n_tx / dt, 2), "unit": "tx-witnesses/s", "cores": 1, "kind": "port",
+            "sample": "RollupMain(nTx=%d,nLevels=%d,maxL1Tx=%d,maxFeeTx=%d), one batch, %.1f s, single thread" % (n_tx, L, max_l1, F, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nTx", type=int, default=2048)
+    ap.add_argument("--nLevels", type=int, default=32)
+    ap.add_argument("--maxL1Tx", type=int, default=256)
+    ap.add_argument("--maxFeeTx", type=int, default=64)
+    ap.add_argument("--inflight", type=int, default=4, help="independent batches in flight (contexts/streams)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="nTx of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")
+    torch.cuda.set_device(local)
+
+    from circuits_amd import lib
+    from circuits_amd import builder as B
+    L = lib()
+    if L.device_count() <= 0:
+        raise SystemExit("no gfx950 device")
+    nTx, lv, m1, F = args.nTx, args.nLevels, args.maxL1Tx, args.maxFeeTx
+    # synthetic batch (reference tools/generate-input.js recipe), same seed on every rank
+    bb = B.synthetic_batch(nTx, lv, m1, F, n_accounts=min(nTx, 4096), seed=0x48455A31)
+    inp = bb.get_input()
+    n_l2 = sum(1 for x in inp["onChain"] if not x)
+    inflight = max(1, min(args.inflight, args.steps if args.steps > 0 else 1))
+    ctxs, streams = [], []
+    for k in range(inflight):
+        c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local)
+        c.set_inputs(inp)  # inputs resident in HBM before the timed region
+        ctxs.append(c)
+        streams.append(torch.cuda.Stream(device=local))
+    # one checked pass (parity with the builder's independently computed public output)
+    ctxs[0].set_profiling(True)
+    ctxs[0].enqueue(streams[0].cuda_stream)
+    ctxs[0].check()
+    if not args.no_verify:
+        assert ctxs[0].get("main.hashGlobalInputs") == bb.get_hash_inputs(), "hashGlobalInputs mismatch"
+    ctxs[0].set_profiling(False)
+
+    def run_steps(n):
+        pending = [False] * inflight
+        for i in range(n):
+            k = i % inflight
+            if pending[k]:
+                ctxs[k].check()
+            ctxs[k].enqueue(streams[k].cuda_stream)
+            pending[k] = True
+        for k in range(inflight):
+            if pending[k]:
+                ctxs[k].check()
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel device times (HIP events on the launch stream), single batch in flight
+    ctxs[0].set_profiling(True)
+    acc = {}
+    reps = 3
+    for _ in range(reps):
+        ctxs[0].enqueue(streams[0].cuda_stream)
+        ctxs[0].check()
+        for name, ms, by, units in ctxs[0].profile():
+            a = acc.setdefault(name, [0.0, by, units])
+            a[0] += ms / reps
+    ctxs[0].set_profiling(False)
+
+    if rank == 0:
+        total_tx = nTx * args.steps * world
+        value = total_tx / dt
+        dom = max(acc.items(), key=lambda kv: kv[1][0])
+        dname, (dms, dbytes, dunits) = dom
+        achieved = dbytes / (dms * 1e-3) / 1e9
+        single_ms = sum(v[0] for v in acc.values())
+        out = {
+            "metric": "rollup-main tx-witnesses/sec (nTx=%d, nLevels=%d)" % (nTx, lv),
+            "value": round(value, 1), "unit": "tx-witnesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32x8 (254-bit Montgomery Fr, integer)", "data": "synthetic",
+            "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "batches_in_flight": inflight,
+                       "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
+                       "witness_bytes_per_batch": ctxs[0].total() * 32, "single_batch_latency_ms": round(single_ms, 3)},
+            "roofline": {"bound": "hbm", "kernel": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "note": "algorithmic bytes of the kernel's own witness signals / its mean launch duration; the path is integer-VALU bound (DESIGN.md)"},
+            "whole_pass": {"algorithmic_bytes_per_tx": algorithmic_bytes_per_tx(lv, F),
+                           "achieved_GBs": round(algorithmic_bytes_per_tx(lv, F) * value / 1e9, 2)},
+            "kernels_ms": {k: round(v[0], 3) for k, v in acc.items()},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, nTx), lv, min(m1, max(1, args.cpu_sample // 8)), F)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

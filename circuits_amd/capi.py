@@ -56,7 +56,7 @@ EXPORTS = [
     "hz_version", "hz_last_error", "hz_device_count", "hz_ctx_create", "hz_ctx_destroy", "hz_witness_len",
     "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_clear_inputs", "hz_input_count", "hz_input_name",
     "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
-    "hz_witness_total", "hz_witness_read_raw",
+    "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
     "hz_poseidon_batch_dev", "hz_shard_range",
 ]
@@ -102,6 +102,9 @@ class Lib:
         c.hz_symbol_get.argtypes = [vp, u64, ctypes.POINTER(hz_symbol)]
         c.hz_symbol_lookup.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(u64)]
         c.hz_constraint_name.restype = ctypes.c_char_p
+        c.hz_ctx_set_profiling.argtypes = [vp, ctypes.c_int32]
+        c.hz_profile_count.argtypes = [vp]
+        c.hz_profile_get.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(u64), ctypes.POINTER(u64)]
 
     def _check(self, st):
         if st != 0:
@@ -220,6 +223,18 @@ class Ctx:
         buf = ctypes.create_string_buffer(32 * max(count, 1))
         self.L._check(self.L.c.hz_witness_read_raw(self.h, first, count, buf))
         return buf.raw[:32 * count]
+
+    def set_profiling(self, on=True):
+        self.L._check(self.L.c.hz_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def profile(self):
+        """[(kernel, ms, algorithmic_bytes, units)] of the last enqueue (after check())."""
+        out = []
+        for i in range(self.L.c.hz_profile_count(self.h)):
+            nm, ms, by, un = ctypes.c_char_p(), ctypes.c_float(), ctypes.c_uint64(), ctypes.c_uint64()
+            self.L._check(self.L.c.hz_profile_get(self.h, i, ctypes.byref(nm), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(un)))
+            out.append((nm.value.decode(), ms.value, by.value, un.value))
+        return out
 
     def dev_ptr(self):
         return self.L.c.hz_witness_dev_ptr(self.h)

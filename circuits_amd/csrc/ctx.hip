@@ -28,7 +28,58 @@ struct hz_ctx {
     std::vector<BlkRef> sym_index;
     uint64_t sym_total = 0;
     std::string sym_name;
+    // optional per-kernel timing (HIP events on the launch stream)
+    bool profiling = false;
+    struct Prof { std::string name; uint64_t bytes; uint64_t units; hipEvent_t e0, e1; float ms; };
+    std::vector<Prof> prof;
+    size_t prof_used = 0;
 };
+
+// which kernel writes a block of the tx / fee / hash-inputs sections (for algorithmic byte counts)
+static const char* block_owner(const Layout& lo, int sec, const Block& b) {
+    const std::string& n = b.name;
+    auto has = [&](const char* t) { return n.find(t) != std::string::npos; };
+    if (sec == lo.sec_hi && lo.p.tmpl != T_WITHDRAW) return "hash_inputs";
+    const bool fee = (sec == lo.sec_fee);
+    if (has(".hash1Old.") || has(".hash1New.") || has("St1Hash.") || has("St2Hash.") || has("StFeePck.") || has("s1OldValue") || has("s2OldValue"))
+        return fee ? "fee_hash" : "hash4";
+    if (has(".topSwitcher.") || has(".checkOldInput.") || has(".areKeyEquals.") || has(".keysOk.") || (has(".processor") && n.size() > 8 && n.compare(n.size() - 8, 8, ".newRoot") == 0))
+        return fee ? "fee_back" : "rtx_back";
+    if (has(".processor")) return fee ? "fee_smt" : "smt";
+    if (has(".getAx.") || has(".sigVerifier.")) return "eddsa";
+    if (has(".s3.out") || has(".s4.out") || has(".s5.out") || has("L1L2TxsData.amountF")) return "rtx_back";
+    return fee ? "fee_front" : "front";
+}
+static uint64_t owner_bytes(const hz_ctx* c, const char* owner) {
+    uint64_t n = 0;
+    const Layout& lo = c->lo;
+    for (size_t si = 0; si < lo.sections.size(); si++)
+        for (const Block& b : lo.sections[si].blocks)
+            if (!strcmp(block_owner(lo, (int)si, b), owner)) n += (uint64_t)b.count * lo.sections[si].n_units;
+    return n * 32;
+}
+struct ProfScope {
+    hz_ctx* c;
+    hipStream_t s;
+    bool on;
+    ProfScope(hz_ctx* c_, hipStream_t s_, const char* name, uint64_t units) : c(c_), s(s_), on(c_->profiling) {
+        if (!on) return;
+        if (c->prof_used == c->prof.size()) {
+            hz_ctx::Prof p;
+            p.name = name; p.bytes = owner_bytes(c, name); p.units = units; p.ms = 0;
+            (void)hipEventCreate(&p.e0);
+            (void)hipEventCreate(&p.e1);
+            c->prof.push_back(p);
+        }
+        (void)hipEventRecord(c->prof[c->prof_used].e0, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(c->prof[c->prof_used].e1, s);
+        c->prof_used++;
+    }
+};
+
 
 static uint8_t* sec_ptr(hz_ctx* c, int sec) { return (uint8_t*)c->wit.p + c->lo.sections[sec].base * 32; }
 
@@ -216,17 +267,17 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     const Layout& lo = c->lo;
     Fr* sc = (Fr*)c->sc_tx.p;
     ErrBuf* err = (ErrBuf*)c->err.p;
-    HZ_HIP(launch_hash4(make_hash4_rtx(base, sc, n_units, lo.rtx), s));
+    { ProfScope ps(c, s, "hash4", n_units); HZ_HIP(launch_hash4(make_hash4_rtx(base, sc, n_units, lo.rtx), s)); }
     SmtArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 2; sa.inst_is_unit = is_main ? 0 : 1;
     sa.p[0] = make_proc(lo.rtx.p1, sib1, 0);
     sa.p[1] = make_proc(lo.rtx.p2, sib2, 1);
-    HZ_HIP(launch_smt(sa, s));
+    { ProfScope ps(c, s, "smt", n_units); HZ_HIP(launch_smt(sa, s)); }
     EddsaArgs ea;
     memset(&ea, 0, sizeof ea);
     ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.inst_is_unit = is_main ? 0 : 1; ea.ed = lo.rtx.ed;
-    HZ_HIP(launch_eddsa(ea, s));
+    { ProfScope ps(c, s, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, s)); }
     RtxBackArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.base = base; ba.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; ba.scratch = sc; ba.err = err; ba.n_units = n_units; ba.L = (uint32_t)lo.p.L;
@@ -239,7 +290,7 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     } else {
         ba.o_newStateRoot = lo.rtxi.o_newStateRoot; ba.o_newExitRoot = lo.rtxi.o_newExitRoot;
     }
-    HZ_HIP(launch_rtx_back(ba, s));
+    { ProfScope ps(c, s, "rtx_back", n_units); HZ_HIP(launch_rtx_back(ba, s)); }
     return HZ_OK;
 }
 
@@ -264,23 +315,23 @@ static hz_status enqueue_fee(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is
         fa.in_sign = f.sign; fa.in_balance = f.balance; fa.in_ay = f.ay; fa.in_ethAddr = f.ethAddr; fa.in_oldStateRoot = f.oldStateRoot;
         sib = f.siblings;
     }
-    HZ_HIP(launch_fee_front(fa, s));
+    { ProfScope ps(c, s, "fee_front", n_units); HZ_HIP(launch_fee_front(fa, s)); }
     Hash4Args h;
     memset(&h, 0, sizeof h);
     h.base = base; h.scratch = sc; h.n_units = n_units; h.n_jobs = 2;
     h.job[0] = HashJob{lo.fee.oldHash, lo.fee.p.hash1Old, SC_HS_IN + 0, SC_KEY_S1OLD, SC_LEAF_P1OLD, ~0u, 0, 0, ~0u};
     h.job[1] = HashJob{lo.fee.newHash, lo.fee.p.hash1New, SC_HS_IN + 8, SC_KEY_1, SC_LEAF_P1NEW, ~0u, 0, 0, ~0u};
-    HZ_HIP(launch_hash4(h, s));
+    { ProfScope ps(c, s, "fee_hash", n_units); HZ_HIP(launch_hash4(h, s)); }
     SmtArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 1; sa.inst_is_unit = is_main ? 0 : 1;
     sa.p[0] = make_proc(lo.fee.p, sib, 2);
-    HZ_HIP(launch_smt(sa, s));
+    { ProfScope ps(c, s, "fee_smt", n_units); HZ_HIP(launch_smt(sa, s)); }
     FeeBackArgs fb;
     memset(&fb, 0, sizeof fb);
     fb.base = base; fb.scratch = sc; fb.err = err; fb.n_units = n_units; fb.is_main = is_main; fb.p = sa.p[0];
     fb.im_stateRootFee = is_main ? lo.fi.imStateRootFee : 0; fb.o_newStateRoot = lo.fee.o_newStateRoot;
-    HZ_HIP(launch_fee_back(fb, s));
+    { ProfScope ps(c, s, "fee_back", n_units); HZ_HIP(launch_fee_back(fb, s)); }
     return HZ_OK;
 }
 
@@ -316,6 +367,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
         HZ_HIP(hipMemcpyAsync((uint8_t*)c->err.p + 8, &c->filter_stage, 8, hipMemcpyHostToDevice, s));
     }
     ErrBuf* err = (ErrBuf*)c->err.p;
+    c->prof_used = 0;
     switch (lo.p.tmpl) {
         case T_ROLLUP_MAIN: {
             MainFrontArgs fa;
@@ -323,12 +375,12 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             fa.tx_base = sec_ptr(c, lo.sec_tx); fa.fee_base = sec_ptr(c, lo.sec_fee); fa.glob_base = sec_ptr(c, lo.sec_glob);
             fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.nTx = (uint32_t)lo.p.nTx; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F;
             fa.g = lo.g; fa.mi = lo.mi; fa.fi = lo.fi; fa.dec = lo.dec; fa.rtx = lo.rtx;
-            HZ_HIP(launch_main_front(fa, s));
+            { ProfScope ps(c, s, "front", fa.nTx); HZ_HIP(launch_main_front(fa, s)); }
             hz_status st = enqueue_rtx_tail(c, fa.tx_base, fa.nTx, true, lo.mi.siblings1, lo.mi.siblings2, s);
             if (st != HZ_OK) return st;
             st = enqueue_fee(c, fa.fee_base, (uint32_t)lo.p.F, true, s);
             if (st != HZ_OK) return st;
-            HZ_HIP(launch_hash_inputs(make_hi(c, true), s));
+            { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s)); }
             break;
         }
         case T_ROLLUP_TX: {
@@ -336,7 +388,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             memset(&fa, 0, sizeof fa);
             fa.base = sec_ptr(c, 0); fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.N = lo.sections[0].n_units; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F;
             fa.in = lo.rtxi; fa.rtx = lo.rtx;
-            HZ_HIP(launch_rtx_front(fa, s));
+            { ProfScope ps(c, s, "front", fa.N); HZ_HIP(launch_rtx_front(fa, s)); }
             hz_status st = enqueue_rtx_tail(c, fa.base, fa.N, false, lo.rtxi.siblings1, lo.rtxi.siblings2, s);
             if (st != HZ_OK) return st;
             break;
@@ -412,6 +464,25 @@ extern "C" hz_status hz_witness_check(hz_ctx* c, hz_error* out) {
     fill_error(out, hd.minkey, nullptr);
     return set_err(HZ_ERR_CONSTRAINT, "Constraint doesn't match (%s, instance %d unit %d; operands not captured)", constraint_name((int)(hd.minkey & 0xFFFF)),
                    (int)(hd.minkey >> 40), (int)((hd.minkey >> 16) & 0xFFFFFF));
+}
+
+extern "C" hz_status hz_ctx_set_profiling(hz_ctx* c, int32_t on) {
+    if (!c) return set_err(HZ_ERR_ARG, "hz_ctx_set_profiling: null context");
+    c->profiling = on != 0;
+    return HZ_OK;
+}
+extern "C" int32_t hz_profile_count(const hz_ctx* c) { return c ? (int32_t)c->prof_used : 0; }
+extern "C" hz_status hz_profile_get(hz_ctx* c, int32_t i, const char** kernel, float* ms, uint64_t* algorithmic_bytes, uint64_t* units) {
+    if (!c || i < 0 || (size_t)i >= c->prof_used) return set_err(HZ_ERR_ARG, "hz_profile_get: bad index");
+    hz_ctx::Prof& p = c->prof[i];
+    HZ_HIP(hipSetDevice(c->device));
+    HZ_HIP(hipEventSynchronize(p.e1));
+    HZ_HIP(hipEventElapsedTime(&p.ms, p.e0, p.e1));
+    if (kernel) *kernel = p.name.c_str();
+    if (ms) *ms = p.ms;
+    if (algorithmic_bytes) *algorithmic_bytes = p.bytes;
+    if (units) *units = p.units;
+    return HZ_OK;
 }
 
 extern "C" hz_status hz_witness_run(hz_ctx* c, hz_error* err) {

@@ -238,10 +238,8 @@ HZ_HD Fr fr_pow(const Fr& a, const uint32_t* e) {
     }
     return r;
 }
-// Inverse by Fermat (a^(p-2)); inverse of 0 is 0, which is the convention the witness needs for
-// `x != 0 ? 1/x : 0` (circomlib comparators IsZero) and for division by zero in
-// `<--` expressions. The exponent is public, so control flow is wave-uniform.
-HZ_HD Fr fr_inv(const Fr& a) {
+// Fermat inverse a^(p-2) (kept as the cross-check of fr_inv in the self tests).
+HZ_HD Fr fr_inv_fermat(const Fr& a) {
     const uint32_t e[8] = {HZ_P0 - 2u, HZ_P1, HZ_P2, HZ_P3, HZ_P4, HZ_P5, HZ_P6, HZ_P7};
     Fr r = a;  // top bit (bit 253) of p-2 is set
 #pragma unroll 1
@@ -250,6 +248,147 @@ HZ_HD Fr fr_inv(const Fr& a) {
         if ((e[i >> 5] >> (i & 31)) & 1u) r = fr_mul(r, a);
     }
     return r;
+}
+
+// ---- modular inverse by constant-time Bernstein-Yang division steps ("safegcd") -----------------
+// 20 batches of 30 half-delta divsteps on signed 30-bit limbs (9 limbs). Control flow does not
+// depend on the data: all 64 lanes of a wavefront run the same instruction stream, which is what
+// makes this the right inversion for SIMT (a Fermat inverse costs ~380 Montgomery products, this
+// one about 20 products' worth of instructions). inverse(0) = 0, the convention the witness needs
+// for `x != 0 ? 1/x : 0` (circomlib IsZero) and for `<--` divisions by zero.
+struct Fr30 {
+    int32_t v[9];
+};
+#define HZ_M30 0x3fffffff
+HZ_HD constexpr int32_t fr_p30(int i) {
+    constexpr int32_t k[9] = {0x30000001, 0x0f87d64f, 0x1b970914, 0x0cfa121e, 0x01585d28, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x00003064};
+    return k[i];
+}
+#define HZ_P_INV30 0x10000001u  // p^-1 mod 2^30
+
+// 30 divsteps on the low limbs; returns the new zeta and the transition matrix (u,v;q,r)
+HZ_HD int32_t fr_divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, int32_t* t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+#pragma unroll 1
+    for (int i = 0; i < 30; ++i) {
+        uint32_t mask1 = (uint32_t)(zeta >> 31);
+        const uint32_t mask2 = 0u - (g & 1u);
+        const uint32_t x = (f ^ mask1) - mask1, y = (u ^ mask1) - mask1, z = (v ^ mask1) - mask1;
+        g += x & mask2;
+        q += y & mask2;
+        r += z & mask2;
+        mask1 &= mask2;
+        zeta = (int32_t)(((uint32_t)zeta ^ mask1) - 1u);
+        f += g & mask1;
+        u += q & mask1;
+        v += r & mask1;
+        g >>= 1;
+        u <<= 1;
+        v <<= 1;
+    }
+    t[0] = (int32_t)u; t[1] = (int32_t)v; t[2] = (int32_t)q; t[3] = (int32_t)r;
+    return zeta;
+}
+HZ_HD void fr_update_fg_30(Fr30& f, Fr30& g, const int32_t* t) {
+    const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
+    int64_t cf = u * f.v[0] + v * g.v[0];
+    int64_t cg = q * f.v[0] + r * g.v[0];
+    cf >>= 30;
+    cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int64_t fi = f.v[i], gi = g.v[i];
+        cf += u * fi + v * gi;
+        cg += q * fi + r * gi;
+        f.v[i - 1] = (int32_t)cf & HZ_M30; cf >>= 30;
+        g.v[i - 1] = (int32_t)cg & HZ_M30; cg >>= 30;
+    }
+    f.v[8] = (int32_t)cf;
+    g.v[8] = (int32_t)cg;
+}
+HZ_HD void fr_update_de_30(Fr30& d, Fr30& e, const int32_t* t) {
+    const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
+    const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+    int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+    int64_t cd = (int64_t)u * d.v[0] + (int64_t)v * e.v[0];
+    int64_t ce = (int64_t)q * d.v[0] + (int64_t)r * e.v[0];
+    md -= (int32_t)((HZ_P_INV30 * (uint32_t)cd + (uint32_t)md) & HZ_M30);
+    me -= (int32_t)((HZ_P_INV30 * (uint32_t)ce + (uint32_t)me) & HZ_M30);
+    cd += (int64_t)fr_p30(0) * md;
+    ce += (int64_t)fr_p30(0) * me;
+    cd >>= 30;
+    ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int64_t di = d.v[i], ei = e.v[i];
+        cd += (int64_t)u * di + (int64_t)v * ei + (int64_t)fr_p30(i) * md;
+        ce += (int64_t)q * di + (int64_t)r * ei + (int64_t)fr_p30(i) * me;
+        d.v[i - 1] = (int32_t)cd & HZ_M30; cd >>= 30;
+        e.v[i - 1] = (int32_t)ce & HZ_M30; ce >>= 30;
+    }
+    d.v[8] = (int32_t)cd;
+    e.v[8] = (int32_t)ce;
+}
+// plain (non-Montgomery) inverse of the canonical integer x (< p): x^-1 mod p, 0 for x = 0
+HZ_HD Fr fr_inv_plain(const Fr& x) {
+    Fr30 d, e, f, g;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { d.v[i] = 0; e.v[i] = 0; f.v[i] = fr_p30(i); }
+    e.v[0] = 1;
+    // 8 x 32-bit limbs -> 9 x 30-bit limbs
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+        uint64_t lo = x.v[w];
+        if (w + 1 < 8) lo |= (uint64_t)x.v[w + 1] << 32;
+        g.v[i] = (int32_t)((lo >> sh) & HZ_M30);
+    }
+    int32_t zeta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 20; ++it) {
+        int32_t t[4];
+        zeta = fr_divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        fr_update_de_30(d, e, t);
+        fr_update_fg_30(f, g, t);
+    }
+    // normalise d: add p if negative, negate if f is negative, add p if negative again
+    int32_t rr[9];
+    const int32_t cond_add = d.v[8] >> 31, cond_neg = f.v[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        rr[i] = d.v[i] + (fr_p30(i) & cond_add);
+        rr[i] = (rr[i] ^ cond_neg) - cond_neg;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { rr[i + 1] += rr[i] >> 30; rr[i] &= HZ_M30; }
+    const int32_t cond_add2 = rr[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) rr[i] += fr_p30(i) & cond_add2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { rr[i + 1] += rr[i] >> 30; rr[i] &= HZ_M30; }
+    // 9 x 30 -> 8 x 32
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int bit = 32 * i, l = bit / 30, sh = bit % 30;
+        uint64_t acc = (uint64_t)(uint32_t)rr[l] >> sh;
+        acc |= (uint64_t)(uint32_t)rr[l + 1] << (30 - sh);
+        if (l + 2 < 9) acc |= (uint64_t)(uint32_t)rr[l + 2] << (60 - sh);
+        o.v[i] = (uint32_t)acc;
+    }
+    return o;
+}
+// Montgomery-domain inverse: (aR)^-1 * R^3 / R = a^-1 R
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_FR_MUL_INLINE)
+static __device__ __attribute__((noinline)) Fr fr_inv(const Fr a) {
+#else
+HZ_HD Fr fr_inv(const Fr& a) {
+#endif
+    constexpr uint32_t r3[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu, 0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};
+    Fr k;
+#pragma unroll
+    for (int i = 0; i < 8; i++) k.v[i] = r3[i];
+    return fr_mul(fr_inv_plain(a), k);
 }
 
 }  // namespace hz

@@ -59,6 +59,13 @@ extern "C" int hzb_bjj_mul(const uint8_t* px, const uint8_t* py, const uint8_t* 
     store(oy, y);
     return 0;
 }
+// self test hooks: both inverses of a canonical element (Montgomery domain inside)
+extern "C" int hzb_fr_inv(const uint8_t* x, uint8_t* safegcd_out, uint8_t* fermat_out) {
+    const Fr a = load(x);
+    store(safegcd_out, fr_inv(a));
+    store(fermat_out, fr_inv_fermat(a));
+    return 0;
+}
 extern "C" int hzb_bjj_add(const uint8_t* px, const uint8_t* py, const uint8_t* qx, const uint8_t* qy, uint8_t* ox, uint8_t* oy) {
     const PtE r = pte_add(pte_from_affine(load(px), load(py)), pte_from_affine(load(qx), load(qy)), bj_a(), bj_d());
     Fr x, y;

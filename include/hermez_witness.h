@@ -118,6 +118,12 @@ hz_status hz_witness_enqueue(hz_ctx* ctx, void* stream);
 hz_status hz_witness_check(hz_ctx* ctx, hz_error* err);
 hz_status hz_witness_run(hz_ctx* ctx, hz_error* err);
 
+/* Per-kernel timing of the last enqueue, measured with HIP events on the launch stream.
+ * `algorithmic_bytes` = 32 B x (witness signals the kernel is responsible for) x units. */
+hz_status hz_ctx_set_profiling(hz_ctx* ctx, int32_t on);
+int32_t hz_profile_count(const hz_ctx* ctx);
+hz_status hz_profile_get(hz_ctx* ctx, int32_t i, const char** kernel, float* ms, uint64_t* algorithmic_bytes, uint64_t* units);
+
 /* output: copy `count` elements starting at flat index `first` of instance `instance` to host */
 hz_status hz_witness_read(hz_ctx* ctx, int32_t instance, uint64_t first, uint64_t count, uint8_t* out);
 /* The physical buffer: sections stored signal-major (include/hz_layout.h); `total` elements. For

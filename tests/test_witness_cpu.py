@@ -149,3 +149,17 @@ def test_symbol_names_follow_circom_convention():
     # every element of the witness has a name, except the padding slots of the arrays that are one
     # unit shorter than their section (im*[nTx-1], imAccFeeOut[nTx-1][F], imStateRootFee[F-1])
     assert o.o.c.orc_symbol_count(o.h) == o.witness_len() - (4 + 4 + 1)
+
+
+def test_host_field_inverse_safegcd_matches_fermat_and_python():
+    """circuits_amd/csrc/fr.h: constant-time Bernstein-Yang inverse vs Fermat vs Python pow (host build of the device code)."""
+    import ctypes
+    import random
+    h = ctypes.CDLL(os.path.join(ROOT, "circuits_amd", "libhz_host.so"))
+    a, b = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    rng = random.Random(5)
+    vals = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, 1 << 253, (1 << 200) + 7] + [rng.randrange(P) for _ in range(500)]
+    for x in vals:
+        h.hzb_fr_inv(x.to_bytes(32, "little"), a, b)
+        e = pow(x, P - 2, P)
+        assert int.from_bytes(a.raw, "little") == e and int.from_bytes(b.raw, "little") == e, x
