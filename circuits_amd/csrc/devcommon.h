@@ -26,25 +26,25 @@ HZ_PC(2) HZ_PC(3) HZ_PC(4) HZ_PC(5) HZ_PC(6) HZ_PC(7)
 // with 16-byte coalesced loads; caller must __syncthreads() afterwards.
 template <int T>
 __device__ __forceinline__ void stage_poseidon_consts(Fr* dst) {
-    constexpr int NC4 = poseidon_nconst<T>() * 2;  // uint4 count
-    constexpr int NM4 = T * T * 2;
-    const uint4* gc = reinterpret_cast<const uint4*>(poseidon_c_global<T>());
-    const uint4* gm = reinterpret_cast<const uint4*>(poseidon_m_global<T>());
-    uint4* d = reinterpret_cast<uint4*>(dst);
-    for (int i = threadIdx.x; i < NC4; i += blockDim.x) d[i] = gc[i];
-    for (int i = threadIdx.x; i < NM4; i += blockDim.x) d[NC4 + i] = gm[i];
+    constexpr int NCW = poseidon_nconst<T>() * 9;  // 32-bit words (an Fr is 9 limbs)
+    constexpr int NMW = T * T * 9;
+    const uint32_t* gc = poseidon_c_global<T>();
+    const uint32_t* gm = poseidon_m_global<T>();
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    for (int i = threadIdx.x; i < NCW; i += blockDim.x) d[i] = gc[i];
+    for (int i = threadIdx.x; i < NMW; i += blockDim.x) d[NCW + i] = gm[i];
 }
 
-// ---- 32-byte element I/O --------------------------------------------------------------------
-__device__ __forceinline__ Fr load_fr(const void* p) {
+// ---- 32-byte element I/O (canonical form) ------------------------------------------------------
+__device__ __forceinline__ Fc load_fr(const void* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     const uint4 a = q[0], b = q[1];
-    Fr r;
+    Fc r;
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
     r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
     return r;
 }
-__device__ __forceinline__ void store_fr(void* p, const Fr& r) {
+__device__ __forceinline__ void store_fr(void* p, const Fc& r) {
     uint4* q = reinterpret_cast<uint4*>(p);
     q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
     q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
@@ -62,7 +62,7 @@ struct WitOut {
         return base + ((size_t)sig * n_units + unit) * 32;
     }
     __device__ __forceinline__ void put_mont(uint32_t sig, const Fr& m) const { store_fr(addr(sig), fr_to_canon(m)); }
-    __device__ __forceinline__ void put_canon(uint32_t sig, const Fr& c) const { store_fr(addr(sig), c); }
+    __device__ __forceinline__ void put_canon(uint32_t sig, const Fc& c) const { store_fr(addr(sig), c); }
     __device__ __forceinline__ void put_u64(uint32_t sig, uint64_t x) const {
         uint4* q = reinterpret_cast<uint4*>(addr(sig));
         q[0] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), 0u, 0u);
@@ -112,7 +112,7 @@ __device__ __noinline__ void report_fail(ErrBuf* e, uint32_t inst, uint32_t unit
     if (e->filter != ~0ull && e->filter != key) return;
     const unsigned int slot = atomicAdd(&e->count, 1u);
     if (slot >= HZ_ERR_CAP) return;
-    const Fr l = fr_to_canon(lhs_m), r = fr_to_canon(rhs_m);
+    const Fc l = fr_to_canon(lhs_m), r = fr_to_canon(rhs_m);
     e->rec[slot].key = key;
     for (int i = 0; i < 8; i++) {
         e->rec[slot].lhs[i] = l.v[i];

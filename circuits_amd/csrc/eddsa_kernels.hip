@@ -21,7 +21,7 @@ struct PtA { Fr x, y; };
 
 __device__ __forceinline__ Fr ld_const(const uint32_t* p) {
     Fr r;
-    for (int i = 0; i < 8; i++) r.v[i] = p[i];
+    for (int i = 0; i < 9; i++) r.v[i] = p[i];
     return r;
 }
 
@@ -52,7 +52,7 @@ __device__ Fr fr_sqrt_circom_dev(const Fr& n) {
         r = fr_mul(r, b);
     }
     // normalise: canonical value > (r-1)/2 -> negate
-    const Fr rc = fr_to_canon(r);
+    const Fc rc = fr_to_canon(r);
     bool gt = false;
     for (int i = 7; i >= 0; i--) {
         if (rc.v[i] > CT_HALF_D[i]) { gt = true; break; }
@@ -133,7 +133,7 @@ __device__ __forceinline__ PtA m2e_dev(const EdCtx& c, const PtA& p) {
 
 // SegmentMulAny(n): bits e[e0 .. e0+n) of the canonical integer `e`
 struct SegAnyRes { PtA out, dbl; };
-__device__ SegAnyRes seg_any_dev(const EdCtx& c, const SegAnyOff& o, const Fr& e, int e0, int n, const PtA& p) {
+__device__ SegAnyRes seg_any_dev(const EdCtx& c, const SegAnyOff& o, const Fc& e, int e0, int n, const PtA& p) {
     const PtA m = e2m_dev(c, p);
     c.io.put_m(o.e2m, m.x); c.io.put_m(o.e2m + 1, m.y);
     PtA dblIn = m, addIn = m;
@@ -164,7 +164,7 @@ __device__ SegAnyRes seg_any_dev(const EdCtx& c, const SegAnyOff& o, const Fr& e
 }
 
 // SegmentMulFix on the constant base: window tables from HZ_BJJ_FIX_WIN
-__device__ PtA seg_fix_dev(const EdCtx& c, const SegFixOff& o, const Fr& e, int e0, int nbits, int win0, int seg) {
+__device__ PtA seg_fix_dev(const EdCtx& c, const SegFixOff& o, const Fc& e, int e0, int nbits, int win0, int seg) {
     PtA acc;
     acc.x = ld_const(HZ_BJJ_FIX_DBLLAST[2 * seg]);
     acc.y = ld_const(HZ_BJJ_FIX_DBLLAST[2 * seg + 1]);
@@ -213,14 +213,14 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
     const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
     const Fr S = sc.get(SC_ED_S), R8x = sc.get(SC_ED_R8X), R8y = sc.get(SC_ED_R8Y), M = sc.get(SC_SIGL2HASH);
     // ---- AySign2Ax
-    const Fr ay_c = fr_to_canon(aySig);
+    const Fc ay_c = fr_to_canon(aySig);
     for (int k = 0; k < 254; k++) io.put_bit(o.ax_n2bAy + k, c_bit(ay_c, k));
     if (comp_constant_dev(io, o.ax_aliasY, ay_c, CT_MINUS1_D)) report_fail(io.err, io.inst, io.err_unit, C_RTX_AX_ALIAS_Y, c.one, fr_zero());
     const Fr y = aySig;
     const Fr y2 = fr_sqr(y);
     Fr x = fr_sqrt_circom_dev(fr_div(fr_sub(c.one, y2), fr_sub(c.a, fr_mul(c.d, y2))));
     if (fr_eq(signSig, c.one)) x = fr_neg(x);
-    const Fr x_c = fr_to_canon(x);
+    const Fc x_c = fr_to_canon(x);
     io.put_c(o.ax_x, x_c);
     const Fr x2 = fr_sqr(x);
     io.put_m(o.ax_x2, x2); io.put_m(o.ax_y2, y2);
@@ -232,9 +232,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
         io.chk(C_RTX_AX_SIGN, fr_from_bit(sg), signSig);
     }
     // ---- EdDSAPoseidonVerifier
-    const Fr S_c = fr_to_canon(S);
+    const Fc S_c = fr_to_canon(S);
     num2bits_dev(io, o.snum2bits, S_c, 253, C_RTX_SIG_N2B_S);
-    const Fr S253 = c_extract(S_c, 0, 253);
+    const Fc S253 = c_extract(S_c, 0, 253);
     {
         const uint32_t gt = comp_constant_dev(io, o.sCmp, S253, CT_SUBORDER_M1_D);
         if (gt) io.chk_zero(C_RTX_SIG_S_RANGE, enabled);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
     Fr hin[5] = {R8x, R8y, x, Ay, M};
     WitSboxSink s6 = io.sbox_sink(o.hash);
     const Fr h = poseidon_hash<6>(hin, C6, M6, s6);
-    const Fr h_c = fr_to_canon(h);
+    const Fc h_c = fr_to_canon(h);
     num2bits_strict_dev(io, o.h2bits, h_c, C_RTX_SIG_H_ALIAS);
     PtA A;
     A.x = x; A.y = Ay;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
 }
 
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_eddsa, dim3((a.n_units + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<6>() * 32, s, a);
+    hipLaunchKernelGGL(k_eddsa, dim3((a.n_units + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<6>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 

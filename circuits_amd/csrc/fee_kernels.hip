@@ -75,7 +75,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hash_state_main(const HsMainArgs a
 // ---- HashInputs --------------------------------------------------------------------------------------
 // k_hi_prep: lane 0 = header/tail fields (+ their Num2Bits signals), then one lane per L1 slot,
 // per transaction and per fee transaction; every lane ORs its bits into the zeroed message buffer.
-__device__ __forceinline__ void msg_put_be(uint32_t* msgw, uint64_t pos, const Fr& canon, int n) {
+__device__ __forceinline__ void msg_put_be(uint32_t* msgw, uint64_t pos, const Fc& canon, int n) {
     for (int k = 0; k < n; k++) msg_set_bit(msgw, pos + k, c_bit(canon, n - 1 - k));
 }
 
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
     const uint64_t offTail = offFee + (uint64_t)Fn * L;
     const UnitIO hio{a.hi_base, 1, 0, 0, 0, a.err};
     if (t == 0) {
-        Fr oldLastIdx, newLastIdx, oldStateRoot, newStateRoot, newExitRoot, chainID, batch;
+        Fc oldLastIdx, newLastIdx, oldStateRoot, newStateRoot, newExitRoot, chainID, batch;
         if (a.is_main) {
             auto glob = [&](uint32_t sig) { return load_fr(a.glob_base + (size_t)sig * 32); };
             oldLastIdx = glob(a.g.oldLastIdx); oldStateRoot = glob(a.g.oldStateRoot); chainID = glob(a.g.globalChainID); batch = glob(a.g.currentNumBatch);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
             newStateRoot = hio.in_c(o.i_newStateRoot); newExitRoot = hio.in_c(o.i_newExitRoot); chainID = hio.in_c(o.i_globalChainID);
             batch = hio.in_c(o.i_currentNumBatch);
         }
-        auto idx48 = [&](uint32_t off, const Fr& v) {
+        auto idx48 = [&](uint32_t off, const Fc& v) {
             num2bits_dev(hio, off, v, 48, C_HI_N2B);
             uint32_t pad = 0;
             for (uint32_t i = L; i < 48; i++) pad += c_bit(v, i);
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
     }
     u -= nTx;
     {
-        const Fr v = a.is_main ? load_fr(a.fee_base + ((size_t)a.fi_feeIdxs * Fn + u) * 32) : hio.in_c(o.i_feeTxsData + u);
+        const Fc v = a.is_main ? load_fr(a.fee_base + ((size_t)a.fi_feeIdxs * Fn + u) * 32) : hio.in_c(o.i_feeTxsData + u);
         num2bits_dev(hio, o.n2bFee + 48 * u, v, 48, C_HI_N2B);
         uint32_t pad = 0;
         for (uint32_t i = L; i < 48; i++) pad += c_bit(v, i);
@@ -174,7 +174,7 @@ __global__ void k_sha_chain(const HashInputsArgs a) {
         for (int i = 0; i < 16; i++) w16[i] = msgw[16 * b + i];
         sha256_compress(hv, w16);
     }
-    const Fr out = sha_digest_to_fr(hv);
+    const Fc out = sha_digest_to_fr(hv);
     if (a.is_main) store_fr(a.glob_base + (size_t)a.g.hashGlobalInputs * 32, out);
     else store_fr(a.hi_base + (size_t)a.hi.out * 32, out);
     if (a.is_main) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
     const int n = (int)a.L + 1;
     const Fr one = fr_one(), zero = fr_zero();
     io.put_u64(o.one, 1);
-    const Fr rootExit_c = io.in_c(o.rootExit), ethAddr_c = io.in_c(o.ethAddr), tokenID_c = io.in_c(o.tokenID), balance_c = io.in_c(o.balance),
+    const Fc rootExit_c = io.in_c(o.rootExit), ethAddr_c = io.in_c(o.ethAddr), tokenID_c = io.in_c(o.tokenID), balance_c = io.in_c(o.balance),
              idx_c = io.in_c(o.idx);
     const Fr rootExit = fr_from_canon(rootExit_c), idx = fr_from_canon(idx_c);
     // accountState = HashState(tokenID, nonce 0, sign, balance, ay, ethAddr)
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
     h1in[0] = idx; h1in[1] = st;
     WitSboxSink sn = io.sbox_sink(v.hash1New);
     const Fr h1new = poseidon_hash<4>(h1in, C4, M4, sn);
-    num2bits_strict_dev(io, v.n2bOld, zero, C_WD_N2B_OLD);
+    num2bits_strict_dev(io, v.n2bOld, fc_zero(), C_WD_N2B_OLD);
     num2bits_strict_dev(io, v.n2bNew, idx_c, C_WD_ALIAS_NEW);
     // SMTLevIns
     uint64_t zmask = 0;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
     }
     uint32_t msg[32];
     for (int k = 0; k < 32; k++) msg[k] = 0;
-    auto put_be = [&](int pos, const Fr& c, int nb) {
+    auto put_be = [&](int pos, const Fc& c, int nb) {
         for (int k = 0; k < nb; k++)
             if (c_bit(c, nb - 1 - k)) msg[(pos + k) >> 5] |= 1u << (31 - ((pos + k) & 31));
     };
@@ -344,7 +344,7 @@ hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s) {
 }
 hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff& hs, hipStream_t s) {
     HsMainArgs a{base, N, hs};
-    hipLaunchKernelGGL(k_hash_state_main, grid1(N), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<5>() * 32, s, a);
+    hipLaunchKernelGGL(k_hash_state_main, grid1(N), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<5>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s) {
@@ -358,7 +358,7 @@ hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s) {
 }
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_withdraw, grid1(a.N), dim3(HZ_BLOCK),
-                       (size_t)(poseidon_const_frs<5>() + poseidon_const_frs<4>() + poseidon_const_frs<3>()) * 32, s, a);
+                       (size_t)(poseidon_const_frs<5>() + poseidon_const_frs<4>() + poseidon_const_frs<3>()) * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 

@@ -1,92 +1,90 @@
-// BN254 scalar field Fr for CDNA4 lanes: one element per lane, 8 x u32 little-endian limbs,
-// Montgomery form with R = 2^256. The reference's production field is ffiasm's 4x64 x86-64
-// Montgomery Fr (reference tools/helpers/actions.js:207-215, buildZqField(p,"Fr")); on gfx950 a
-// 64x64 multiply lowers to v_mad_u64_u32 chains, so the native limb is 32 bits.
-// Every function is __host__ __device__ so the host-side batch builder shares the arithmetic.
+// BN254 scalar field Fr for CDNA4 lanes -- one element per lane.
+//
+// The reference's production field is ffiasm's 4 x 64-bit x86-64 Montgomery Fr (reference
+// tools/helpers/actions.js:207-215, buildZqField(p,"Fr")). gfx950 has no cheap carry chain for a
+// 64x64 multiply; its multiplier primitive is v_mad_u64_u32 (32x32 + 64-bit accumulate). The
+// representation here is therefore 9 limbs of 29 bits with lazy carries: every column of the
+// schoolbook product and of the Montgomery reduction is a pure v_mad_u64_u32 accumulation chain
+// (9 terms of < 2^58 fit a 64-bit accumulator), so a product is 162 multiply-accumulates and a few
+// shifts/masks -- measured 3x faster per dependent product than the 8 x 32-bit CIOS form
+// (tools/microbench/mulbench.hip, DESIGN.md "Field arithmetic").
+//
+//   Fr  Montgomery domain, R = 2^261, value in [0, 2p), limbs v[0..7] < 2^29 ("normalised")
+//   Fc  canonical integer, 8 x u32 little-endian: the 32-byte element format of the ABI/witness
+//
+// Every function is __host__ __device__: the host-side batch builder shares the arithmetic.
 #pragma once
 #include <stdint.h>
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HZ_HD __host__ __device__ __forceinline__
-// The 256-bit Montgomery product is ~700 instructions: kept out of line so that callers' loops
-// stay unrollable and the hot code fits the instruction cache.
-#define HZ_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define HZ_HD inline
-#define HZ_HD_NOINLINE inline
+#endif
+// Heavy routines stay out of line on the device unless HZ_FR_INLINE is defined: the witness kernels
+// call them from hundreds of sites; one shared body keeps the kernels inside the instruction cache
+// and compiles in seconds instead of minutes.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_FR_INLINE)
+#define HZ_HD_HEAVY static __device__ __attribute__((noinline))
+#define HZ_HEAVY_ARG(T) const T
+#else
+#define HZ_HD_HEAVY HZ_HD
+#define HZ_HEAVY_ARG(T) const T&
 #endif
 
 namespace hz {
 
 struct Fr {
+    uint32_t v[9];
+};
+struct Fc {
     uint32_t v[8];
 };
 
+#define HZ_M29 0x1fffffffu
+#define HZ_INV29 0x0fffffffu  // -p^-1 mod 2^29
+
 // r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-#define HZ_P0 0xf0000001u
-#define HZ_P1 0x43e1f593u
-#define HZ_P2 0x79b97091u
-#define HZ_P3 0x2833e848u
-#define HZ_P4 0x8181585du
-#define HZ_P5 0xb85045b6u
-#define HZ_P6 0xe131a029u
-#define HZ_P7 0x30644e72u
-#define HZ_INV32 0xefffffffu  // -r^-1 mod 2^32
-
-HZ_HD constexpr uint32_t fr_p(int i) {
-    return i == 0 ? HZ_P0 : i == 1 ? HZ_P1 : i == 2 ? HZ_P2 : i == 3 ? HZ_P3 : i == 4 ? HZ_P4 : i == 5 ? HZ_P5 : i == 6 ? HZ_P6 : HZ_P7;
-}
-// R mod r (Montgomery one) and R^2 mod r
-HZ_HD constexpr uint32_t fr_r1(int i) {
-    constexpr uint32_t k[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+HZ_HD constexpr uint32_t fr_p29(int i) {
+    constexpr uint32_t k[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
     return k[i];
 }
-HZ_HD constexpr uint32_t fr_r2(int i) {
-    constexpr uint32_t k[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+HZ_HD constexpr uint32_t fr_2p29(int i) {
+    constexpr uint32_t k[9] = {0x00000002u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u, 0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
+    return k[i];
+}
+HZ_HD constexpr uint32_t fr_r1(int i) {  // R mod p
+    constexpr uint32_t k[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+    return k[i];
+}
+HZ_HD constexpr uint32_t fr_r2(int i) {  // R^2 mod p
+    constexpr uint32_t k[9] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu, 0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};
+    return k[i];
+}
+HZ_HD constexpr uint32_t fr_r3(int i) {  // R^3 mod p
+    constexpr uint32_t k[9] = {0x001fddb2u, 0x17d30b63u, 0x1a2600eeu, 0x09507c47u, 0x1496b29bu, 0x0b00a268u, 0x15b645ebu, 0x1f9fcb3du, 0x001baa96u};
+    return k[i];
+}
+// canonical modulus, 8 x u32
+HZ_HD constexpr uint32_t fc_p(int i) {
+    constexpr uint32_t k[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     return k[i];
 }
 
-HZ_HD Fr fr_zero() {
-    Fr r;
+// ---- canonical (Fc) helpers ------------------------------------------------------------------------
+HZ_HD Fc fc_zero() {
+    Fc r;
 #pragma unroll
     for (int i = 0; i < 8; i++) r.v[i] = 0;
     return r;
 }
-HZ_HD Fr fr_one() {  // Montgomery 1
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = fr_r1(i);
-    return r;
-}
-HZ_HD bool fr_is_zero(const Fr& a) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o |= a.v[i];
-    return o == 0;
-}
-HZ_HD bool fr_eq(const Fr& a, const Fr& b) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
-    return o == 0;
-}
-// a >= p ? (limb compare, raw integers)
-HZ_HD bool fr_geq_p(const uint32_t* a) {
-    // compute a - p borrow
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)a[i] - fr_p(i) - br;
-        br = (d >> 63) & 1;
-    }
-    return br == 0;
-}
-HZ_HD void fr_cond_sub_p(uint32_t* t) {
+// t -= p if t >= p (plain 256-bit integer)
+HZ_HD void fc_cond_sub_p(uint32_t* t) {
     uint32_t s[8];
     uint64_t br = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)t[i] - fr_p(i) - br;
+        const uint64_t d = (uint64_t)t[i] - fc_p(i) - br;
         s[i] = (uint32_t)d;
         br = (d >> 63) & 1;
     }
@@ -95,134 +93,189 @@ HZ_HD void fr_cond_sub_p(uint32_t* t) {
         for (int i = 0; i < 8; i++) t[i] = s[i];
     }
 }
-HZ_HD Fr fr_add(const Fr& a, const Fr& b) {
+HZ_HD bool fc_is_zero(const Fc& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.v[i];
+    return o == 0;
+}
+
+// ---- basic Fr ------------------------------------------------------------------------------------------
+HZ_HD Fr fr_zero() {
     Fr r;
-    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = 0;
+    return r;
+}
+HZ_HD Fr fr_one() {  // Montgomery 1
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = fr_r1(i);
+    return r;
+}
+HZ_HD Fr fr_from_bit(uint32_t b) {  // 0 or Montgomery 1
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = b ? fr_r1(i) : 0u;
+    return r;
+}
+HZ_HD Fr fr_select(bool c, const Fr& a, const Fr& b) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+// propagate carries: limbs 0..7 back below 2^29
+HZ_HD void fr_norm(uint32_t* t) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] + b.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
+        t[i + 1] += t[i] >> 29;
+        t[i] &= HZ_M29;
     }
-    fr_cond_sub_p(r.v);  // a+b < 2p < 2^256, no carry out
+}
+// t (normalised, value < 4p) -> t - 2p if t >= 2p
+HZ_HD void fr_cond_sub_2p(uint32_t* t) {
+    int32_t d[9];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t x = (int32_t)t[i] - (int32_t)fr_2p29(i) + c;
+        d[i] = (i < 8) ? (x & (int32_t)HZ_M29) : x;
+        c = x >> 29;
+    }
+    if (d[8] >= 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) t[i] = (uint32_t)d[i];
+    }
+}
+HZ_HD Fr fr_add(const Fr& a, const Fr& b) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    fr_norm(r.v);
+    fr_cond_sub_2p(r.v);
     return r;
 }
 HZ_HD Fr fr_sub(const Fr& a, const Fr& b) {
+    // a - b + 2p in [0, 4p), signed limb arithmetic with arithmetic carries
     Fr r;
-    uint64_t br = 0;
+    int32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)a.v[i] - b.v[i] - br;
-        r.v[i] = (uint32_t)d;
-        br = (d >> 63) & 1;
+    for (int i = 0; i < 9; i++) {
+        const int32_t x = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)fr_2p29(i) + c;
+        r.v[i] = (i < 8) ? (uint32_t)(x & (int32_t)HZ_M29) : (uint32_t)x;
+        c = x >> 29;
     }
-    if (br) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c += (uint64_t)r.v[i] + fr_p(i);
-            r.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
-    }
+    fr_cond_sub_2p(r.v);
     return r;
 }
 HZ_HD Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
 HZ_HD Fr fr_dbl(const Fr& a) { return fr_add(a, a); }
-
-// Montgomery product a*b/R mod p. CIOS, interleaved, using the "no final carry" shortcut that
-// holds because the top limb of p is < 2^31.
-// Out of line on the device unless HZ_FR_MUL_INLINE is defined: the product is ~700 instructions and
-// the witness kernels call it from hundreds of sites; one shared body keeps them inside the
-// instruction cache (and compiles in seconds instead of minutes).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_FR_MUL_INLINE)
-static __device__ __attribute__((noinline)) Fr fr_mul(const Fr a, const Fr b) {
-#else
-HZ_HD Fr fr_mul(const Fr& a, const Fr& b) {
-#endif
-    uint32_t t[8];
+// value in {0, p} (both represent zero; limbs are normalised, so each integer has one encoding)
+HZ_HD bool fr_is_zero(const Fr& a) {
+    uint32_t z = 0, e = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t bi = b.v[i];
-        uint64_t A = (uint64_t)a.v[0] * bi + t[0];
-        const uint32_t t0 = (uint32_t)A;
-        A >>= 32;
-        const uint32_t m = t0 * HZ_INV32;
-        uint64_t C = (uint64_t)m * fr_p(0) + t0;
-        C >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            A += (uint64_t)a.v[j] * bi + t[j];
-            C += (uint64_t)m * fr_p(j) + (uint32_t)A;
-            A >>= 32;
-            t[j - 1] = (uint32_t)C;
-            C >>= 32;
-        }
-        t[7] = (uint32_t)(C + A);
+    for (int i = 0; i < 9; i++) {
+        z |= a.v[i];
+        e |= a.v[i] ^ fr_p29(i);
     }
-    fr_cond_sub_p(t);
+    return z == 0 || e == 0;
+}
+HZ_HD bool fr_eq(const Fr& a, const Fr& b) { return fr_is_zero(fr_sub(a, b)); }
+
+// Montgomery product a*b/R mod p; inputs normalised with value < 2^257, output < 1.03 p, normalised.
+HZ_HD_HEAVY Fr fr_mul(HZ_HEAVY_ARG(Fr) a, HZ_HEAVY_ARG(Fr) b) {
+    uint64_t t[18];
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 8) continue;
+            acc += (uint64_t)a.v[i] * b.v[j];
+        }
+        t[k] = acc;
+    }
+    t[17] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t m = ((uint32_t)t[i] * HZ_INV29) & HZ_M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[i + j] += (uint64_t)m * fr_p29(j);
+        t[i + 1] += t[i] >> 29;
+    }
     Fr r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    for (int k = 0; k < 8; k++) {
+        r.v[k] = (uint32_t)t[9 + k] & HZ_M29;
+        t[10 + k] += t[9 + k] >> 29;
+    }
+    r.v[8] = (uint32_t)t[17];
     return r;
 }
 HZ_HD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 
-// canonical (plain integer, < p) <-> Montgomery
-HZ_HD Fr fr_from_canon(const Fr& a) {
+// canonical -> Montgomery (also accepts any 256-bit integer)
+HZ_HD Fr fr_unpack(const Fc& c) {
+    Fr x;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+        uint64_t lo = c.v[w];
+        if (w + 1 < 8) lo |= (uint64_t)c.v[w + 1] << 32;
+        x.v[i] = (uint32_t)(lo >> sh) & HZ_M29;
+    }
+    return x;
+}
+HZ_HD Fr fr_from_canon(const Fc& c) {
     Fr r2;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r2.v[i] = fr_r2(i);
-    return fr_mul(a, r2);
+    for (int i = 0; i < 9; i++) r2.v[i] = fr_r2(i);
+    return fr_mul(fr_unpack(c), r2);
 }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_FR_MUL_INLINE)
-static __device__ __attribute__((noinline)) Fr fr_to_canon(const Fr a) {
-#else
-HZ_HD Fr fr_to_canon(const Fr& a) {
-#endif
-    // Montgomery reduction of a (multiply by 1): 8 rounds of m*p accumulation only
-    uint32_t t[8];
+// Montgomery -> canonical (< p)
+HZ_HD_HEAVY Fc fr_to_canon(HZ_HEAVY_ARG(Fr) a) {
+    uint64_t t[18];
 #pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = a.v[i];
+    for (int i = 0; i < 9; i++) t[i] = a.v[i];
+#pragma unroll
+    for (int i = 9; i < 18; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t m = ((uint32_t)t[i] * HZ_INV29) & HZ_M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[i + j] += (uint64_t)m * fr_p29(j);
+        t[i + 1] += t[i] >> 29;
+    }
+    uint32_t r[9];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        r[k] = (uint32_t)t[9 + k] & HZ_M29;
+        t[10 + k] += t[9 + k] >> 29;
+    }
+    r[8] = (uint32_t)t[17];
+    // (a + m p)/R <= p: the only non-canonical outcome is exactly p
+    uint32_t e = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) e |= r[i] ^ fr_p29(i);
+    Fc o;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const uint32_t m = t[0] * HZ_INV32;
-        uint64_t C = (uint64_t)m * fr_p(0) + t[0];
-        C >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            C += (uint64_t)m * fr_p(j) + t[j];
-            t[j - 1] = (uint32_t)C;
-            C >>= 32;
-        }
-        t[7] = (uint32_t)C;
+        const int bit = 32 * i, l = bit / 29, sh = bit % 29;
+        uint64_t acc = (uint64_t)r[l] >> sh;
+        acc |= (uint64_t)r[l + 1] << (29 - sh);
+        if (l + 2 < 9) acc |= (uint64_t)r[l + 2] << (58 - sh);
+        o.v[i] = e ? (uint32_t)acc : 0u;
     }
-    fr_cond_sub_p(t);
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
-    return r;
+    return o;
 }
 // small integer -> Montgomery
 HZ_HD Fr fr_from_u64(uint64_t x) {
-    Fr c = fr_zero();
+    Fc c = fc_zero();
     c.v[0] = (uint32_t)x;
     c.v[1] = (uint32_t)(x >> 32);
     return fr_from_canon(c);
-}
-HZ_HD Fr fr_from_bit(uint32_t b) {  // 0 or Montgomery 1, branch-free
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = b ? fr_r1(i) : 0u;
-    return r;
-}
-HZ_HD Fr fr_select(bool c, const Fr& a, const Fr& b) {  // c ? a : b
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
-    return r;
 }
 
 // a^e for a public 256-bit exponent given as 8 LE limbs (square-and-multiply, MSB first).
@@ -240,14 +293,11 @@ HZ_HD Fr fr_pow(const Fr& a, const uint32_t* e) {
 }
 // Fermat inverse a^(p-2) (kept as the cross-check of fr_inv in the self tests).
 HZ_HD Fr fr_inv_fermat(const Fr& a) {
-    const uint32_t e[8] = {HZ_P0 - 2u, HZ_P1, HZ_P2, HZ_P3, HZ_P4, HZ_P5, HZ_P6, HZ_P7};
-    Fr r = a;  // top bit (bit 253) of p-2 is set
-#pragma unroll 1
-    for (int i = 252; i >= 0; i--) {
-        r = fr_sqr(r);
-        if ((e[i >> 5] >> (i & 31)) & 1u) r = fr_mul(r, a);
-    }
-    return r;
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = fc_p(i);
+    e[0] -= 2u;
+    return fr_pow(a, e);
 }
 
 // ---- modular inverse by constant-time Bernstein-Yang division steps ("safegcd") -----------------
@@ -266,7 +316,6 @@ HZ_HD constexpr int32_t fr_p30(int i) {
 }
 #define HZ_P_INV30 0x10000001u  // p^-1 mod 2^30
 
-// 30 divsteps on the low limbs; returns the new zeta and the transition matrix (u,v;q,r)
 HZ_HD int32_t fr_divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, int32_t* t) {
     uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
 #pragma unroll 1
@@ -329,20 +378,48 @@ HZ_HD void fr_update_de_30(Fr30& d, Fr30& e, const int32_t* t) {
     d.v[8] = (int32_t)cd;
     e.v[8] = (int32_t)ce;
 }
-// plain (non-Montgomery) inverse of the canonical integer x (< p): x^-1 mod p, 0 for x = 0
-HZ_HD Fr fr_inv_plain(const Fr& x) {
+// value of a (< 2p, normalised) reduced to [0, p) and re-cut into 30-bit limbs
+HZ_HD void fr_to_limbs30(const Fr& a, Fr30& g) {
+    int32_t d[9];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t x = (int32_t)a.v[i] - (int32_t)fr_p29(i) + c;
+        d[i] = (i < 8) ? (x & (int32_t)HZ_M29) : x;
+        c = x >> 29;
+    }
+    uint32_t w[9];
+    const bool ge = d[8] >= 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) w[i] = ge ? (uint32_t)d[i] : a.v[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 30 * i, l = bit / 29, sh = bit % 29;
+        uint64_t acc = 0;
+        if (l < 9) acc = (uint64_t)w[l] >> sh;
+        if (l + 1 < 9) acc |= (uint64_t)w[l + 1] << (29 - sh);
+        if (l + 2 < 9) acc |= (uint64_t)w[l + 2] << (58 - sh);
+        g.v[i] = (int32_t)((uint32_t)acc & HZ_M30);
+    }
+}
+HZ_HD Fr fr_from_limbs30(const int32_t* rr) {  // rr: 9 non-negative 30-bit limbs, value < p
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, l = bit / 30, sh = bit % 30;
+        uint64_t acc = (uint64_t)(uint32_t)rr[l] >> sh;
+        if (l + 1 < 9) acc |= (uint64_t)(uint32_t)rr[l + 1] << (30 - sh);
+        o.v[i] = (uint32_t)acc & HZ_M29;
+    }
+    return o;
+}
+// Montgomery-domain inverse: (aR)^-1 * R^3 / R = a^-1 R
+HZ_HD_HEAVY Fr fr_inv(HZ_HEAVY_ARG(Fr) a) {
     Fr30 d, e, f, g;
 #pragma unroll
     for (int i = 0; i < 9; i++) { d.v[i] = 0; e.v[i] = 0; f.v[i] = fr_p30(i); }
     e.v[0] = 1;
-    // 8 x 32-bit limbs -> 9 x 30-bit limbs
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
-        uint64_t lo = x.v[w];
-        if (w + 1 < 8) lo |= (uint64_t)x.v[w + 1] << 32;
-        g.v[i] = (int32_t)((lo >> sh) & HZ_M30);
-    }
+    fr_to_limbs30(a, g);
     int32_t zeta = -1;
 #pragma unroll 1
     for (int it = 0; it < 20; ++it) {
@@ -366,29 +443,10 @@ HZ_HD Fr fr_inv_plain(const Fr& x) {
     for (int i = 0; i < 9; i++) rr[i] += fr_p30(i) & cond_add2;
 #pragma unroll
     for (int i = 0; i < 8; i++) { rr[i + 1] += rr[i] >> 30; rr[i] &= HZ_M30; }
-    // 9 x 30 -> 8 x 32
-    Fr o;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int bit = 32 * i, l = bit / 30, sh = bit % 30;
-        uint64_t acc = (uint64_t)(uint32_t)rr[l] >> sh;
-        acc |= (uint64_t)(uint32_t)rr[l + 1] << (30 - sh);
-        if (l + 2 < 9) acc |= (uint64_t)(uint32_t)rr[l + 2] << (60 - sh);
-        o.v[i] = (uint32_t)acc;
-    }
-    return o;
-}
-// Montgomery-domain inverse: (aR)^-1 * R^3 / R = a^-1 R
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_FR_MUL_INLINE)
-static __device__ __attribute__((noinline)) Fr fr_inv(const Fr a) {
-#else
-HZ_HD Fr fr_inv(const Fr& a) {
-#endif
-    constexpr uint32_t r3[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu, 0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};
     Fr k;
 #pragma unroll
-    for (int i = 0; i < 8; i++) k.v[i] = r3[i];
-    return fr_mul(fr_inv_plain(a), k);
+    for (int i = 0; i < 9; i++) k.v[i] = fr_r3(i);
+    return fr_mul(fr_from_limbs30(rr), k);
 }
 
 }  // namespace hz

@@ -20,12 +20,12 @@ struct UnitIO {
 
     __device__ __forceinline__ uint8_t* addr(uint32_t sig) const { return base + ((size_t)sig * n_units + unit) * 32; }
     __device__ __forceinline__ uint8_t* addr_u(uint32_t sig, uint32_t u) const { return base + ((size_t)sig * n_units + u) * 32; }
-    __device__ __forceinline__ Fr in_c(uint32_t sig) const { return load_fr(addr(sig)); }                    // canonical
+    __device__ __forceinline__ Fc in_c(uint32_t sig) const { return load_fr(addr(sig)); }                    // canonical
     __device__ __forceinline__ Fr in_m(uint32_t sig) const { return fr_from_canon(load_fr(addr(sig))); }      // Montgomery
-    __device__ __forceinline__ Fr in_c_u(uint32_t sig, uint32_t u) const { return load_fr(addr_u(sig, u)); }
+    __device__ __forceinline__ Fc in_c_u(uint32_t sig, uint32_t u) const { return load_fr(addr_u(sig, u)); }
     __device__ __forceinline__ Fr in_m_u(uint32_t sig, uint32_t u) const { return fr_from_canon(load_fr(addr_u(sig, u))); }
     __device__ __forceinline__ void put_m(uint32_t sig, const Fr& m) const { store_fr(addr(sig), fr_to_canon(m)); }
-    __device__ __forceinline__ void put_c(uint32_t sig, const Fr& c) const { store_fr(addr(sig), c); }
+    __device__ __forceinline__ void put_c(uint32_t sig, const Fc& c) const { store_fr(addr(sig), c); }
     __device__ __forceinline__ void put_u64(uint32_t sig, uint64_t x) const {
         uint4* q = reinterpret_cast<uint4*>(addr(sig));
         q[0] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), 0u, 0u);
@@ -52,27 +52,27 @@ struct Scratch {
 };
 
 // ---- canonical-integer helpers ---------------------------------------------------------------------
-__device__ __forceinline__ uint32_t c_bit(const Fr& c, int i) { return (c.v[i >> 5] >> (i & 31)) & 1u; }
+__device__ __forceinline__ uint32_t c_bit(const Fc& c, int i) { return (c.v[i >> 5] >> (i & 31)) & 1u; }
 // bits [from, from+n) of a canonical integer as u64 (n <= 64)
-__device__ __forceinline__ uint64_t c_bits64(const Fr& c, int from, int n) {
+__device__ __forceinline__ uint64_t c_bits64(const Fc& c, int from, int n) {
     uint64_t r = 0;
     for (int i = 0; i < n; i++) r |= (uint64_t)c_bit(c, from + i) << i;
     return r;
 }
 // canonical integer with bits [from, from+n) of c moved to position 0 (n <= 256)
-__device__ __forceinline__ Fr c_extract(const Fr& c, int from, int n) {
-    Fr r = fr_zero();
+__device__ __forceinline__ Fc c_extract(const Fc& c, int from, int n) {
+    Fc r = fc_zero();
     for (int i = 0; i < n; i++) r.v[i >> 5] |= c_bit(c, from + i) << (i & 31);
     return r;
 }
 // is the canonical integer < 2^n ?
-__device__ __forceinline__ bool c_fits(const Fr& c, int n) {
+__device__ __forceinline__ bool c_fits(const Fc& c, int n) {
     for (int i = n; i < 256; i++)
         if (c_bit(c, i)) return false;
     return true;
 }
-__device__ __forceinline__ Fr c_pow2(int k) {  // canonical 2^k, k < 254... (k < 256 as plain integer)
-    Fr r = fr_zero();
+__device__ __forceinline__ Fc c_pow2(int k) {  // 2^k as a plain integer, k < 256
+    Fc r = fc_zero();
     r.v[k >> 5] = 1u << (k & 31);
     return r;
 }
@@ -80,11 +80,11 @@ __device__ __forceinline__ Fr c_pow2(int k) {  // canonical 2^k, k < 254... (k <
 __device__ __forceinline__ Fr m_pow2(int k) { return fr_from_canon(c_pow2(k)); }
 
 // Num2Bits(n): stores out[0..n) from the canonical value; reports `sum === in` when it cannot hold
-__device__ __forceinline__ void num2bits_dev(const UnitIO& io, uint32_t off, const Fr& canon, int n, int cid) {
+__device__ __forceinline__ void num2bits_dev(const UnitIO& io, uint32_t off, const Fc& canon, int n, int cid) {
     for (int i = 0; i < n; i++) io.put_bit(off + i, c_bit(canon, i));
     if (n < 254 && !c_fits(canon, n)) {
         // lc1 = value mod 2^n
-        Fr lc = c_extract(canon, 0, n);
+        const Fc lc = c_extract(canon, 0, n);
         report_fail(io.err, io.inst, io.err_unit, (uint32_t)cid, fr_from_canon(lc), fr_from_canon(canon));
     }
 }
@@ -122,7 +122,7 @@ __device__ __forceinline__ Fr mux1_dev(const Fr& c0, const Fr& c1, const Fr& s) 
 // num2bits.out[135]; returns out (1 if in > ct).
 // parts are small: each is  +-b_i, +-a_i, ... with a_i = 2^i, b_i = 2^128 - 2^i, so the sum fits
 // in 135 bits of a plain integer; evaluated with 192-bit integer arithmetic, no field products.
-__device__ __forceinline__ uint32_t comp_constant_dev(const UnitIO& io, const CompConstOff& off, const Fr& bits, const uint32_t* ct /*8 LE limbs*/) {
+__device__ __forceinline__ uint32_t comp_constant_dev(const UnitIO& io, const CompConstOff& off, const Fc& bits, const uint32_t* ct /*8 LE limbs*/) {
     // sum accumulates in 5 x 32-bit limbs (160 bits)
     uint32_t sum[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < 127; i++) {
@@ -139,11 +139,11 @@ __device__ __forceinline__ uint32_t comp_constant_dev(const UnitIO& io, const Co
         else if (cmsb && !clsb) sel = smsb ? (slsb ? 2 : 0) : 1;   // m=1,l=1: b - a + a = b ; m=1,l=0: -a + a = 0 ; m=0: a
         else sel = (smsb & slsb) ? 0 : 1;
         // store part
-        Fr part = fr_zero();
+        Fc part = fc_zero();
         if (sel == 1) part.v[i >> 5] = 1u << (i & 31);
         else if (sel == 2) {
             // 2^128 - 2^i
-            Fr t = fr_zero();
+            Fc t = fc_zero();
             t.v[4] = 1u;
             // subtract 2^i
             uint32_t sub[5] = {0, 0, 0, 0, 0};
@@ -173,7 +173,7 @@ __constant__ const uint32_t CT_HALF_D[8] = {0xf8000000u, 0xa1f0fac9u, 0x3cdcb848
 __constant__ const uint32_t CT_SUBORDER_M1_D[8] = {0x392126f0u, 0x677297dcu, 0x3920ee0au, 0xab3eedb8u, 0xd0302b0bu, 0x370a08b6u, 0x5c263405u, 0x060c89ceu};
 
 // Num2Bits_strict: bits + AliasCheck
-__device__ __forceinline__ void num2bits_strict_dev(const UnitIO& io, const N2BStrictOff& off, const Fr& canon, int cid_alias) {
+__device__ __forceinline__ void num2bits_strict_dev(const UnitIO& io, const N2BStrictOff& off, const Fc& canon, int cid_alias) {
     for (int i = 0; i < 254; i++) io.put_bit(off.bits + i, c_bit(canon, i));
     const uint32_t o = comp_constant_dev(io, off.cc, canon, CT_MINUS1_D);
     if (o) report_fail(io.err, io.inst, io.err_unit, (uint32_t)cid_alias, fr_one(), fr_zero());

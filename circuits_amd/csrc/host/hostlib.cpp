@@ -16,17 +16,17 @@ namespace hz {
 using namespace hz;
 
 static Fr load(const uint8_t* b) {
-    Fr c;
+    Fc c;
     memcpy(c.v, b, 32);
     return fr_from_canon(c);
 }
 static void store(uint8_t* b, const Fr& m) {
-    const Fr c = fr_to_canon(m);
+    const Fc c = fr_to_canon(m);
     memcpy(b, c.v, 32);
 }
 
 template <int T>
-static Fr hash_t(const Fr* in, const uint32_t (*C)[8], const uint32_t (*M)[8]) {
+static Fr hash_t(const Fr* in, const uint32_t (*C)[9], const uint32_t (*M)[9]) {
     NoSink s;
     return poseidon_hash<T>(in, reinterpret_cast<const Fr*>(C), reinterpret_cast<const Fr*>(M), s);
 }

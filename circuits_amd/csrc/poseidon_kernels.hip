@@ -5,7 +5,7 @@
 // HBM traffic per permutation: 32*(t-1) B in + 32 B out (digest mode), plus 96*(8t+R_P) B when the
 // S-box witness is requested. Digest mode is integer-VALU bound; witness mode is the HBM-write
 // bound regime of the rollup witness.
-#define HZ_FR_MUL_INLINE 1  // throughput kernel: keep the product inline (register-allocated operands)
+#define HZ_FR_INLINE 1  // throughput kernel: keep the product inline (register-allocated operands)
 #include <hip/hip_runtime.h>
 #include "../../include/hermez_witness.h"
 #include "devcommon.h"
@@ -44,7 +44,7 @@ static hipError_t launch_poseidon(size_t n, const void* d_in, void* d_out, void*
     const int block = 256;
     size_t blocks = (n + block - 1) / block;
     if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 blocks per CU
-    const size_t lds = (size_t)poseidon_const_frs<T>() * 32;
+    const size_t lds = (size_t)poseidon_const_frs<T>() * sizeof(Fr);
     if (d_wit)
         hipLaunchKernelGGL((poseidon_batch_kernel<T, true>), dim3((unsigned)blocks), dim3(block), lds, s,
                            (const uint8_t*)d_in, (uint8_t*)d_out, (uint8_t*)d_wit, n);

@@ -93,11 +93,11 @@ __device__ void sha256_block_witness(const UnitIO& io, uint32_t base, uint32_t* 
 }
 
 // digest (8 big-endian words) as a 256-bit integer reduced mod r -> canonical Fr
-__device__ __forceinline__ Fr sha_digest_to_fr(const uint32_t* hv) {
-    Fr r;
+__device__ __forceinline__ Fc sha_digest_to_fr(const uint32_t* hv) {
+    Fc r;
     for (int i = 0; i < 8; i++) r.v[i] = hv[7 - i];
     // value < 2^256 < 6r: subtract r while >= r
-    for (int k = 0; k < 5; k++) fr_cond_sub_p(r.v);
+    for (int k = 0; k < 5; k++) fc_cond_sub_p(r.v);
     return r;
 }
 

@@ -42,8 +42,8 @@ __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOf
     const Fr one = fr_one();
     const Fr onChain = io.in_m(in.onChain), newAccount = io.in_m(in.newAccount);
     const Fr notOn = fr_sub(one, onChain);
-    const Fr notOn_c = fr_to_canon(notOn), on_c = fr_to_canon(onChain);
-    const Fr d = io.in_c(in.txCompressedData);
+    const Fc notOn_c = fr_to_canon(notOn), on_c = fr_to_canon(onChain);
+    const Fc d = io.in_c(in.txCompressedData);
     num2bits_dev(io, o.n2bData, d, 225, C_DEC_N2B_DATA);
     const uint64_t constSig = c_bits64(d, 0, 32), chainID = c_bits64(d, 32, 16), fromIdx = c_bits64(d, 48, 48), toIdx = c_bits64(d, 96, 48);
     const uint64_t tokenID = c_bits64(d, 144, 32), nonce = c_bits64(d, 176, 40), userFee = c_bits64(d, 216, 8);
@@ -56,16 +56,16 @@ __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOf
     }
     r.fromIdx = fr_from_u64(fromIdx); r.toIdx = fr_from_u64(toIdx); r.tokenID = fr_from_u64(tokenID); r.nonce = fr_from_u64(nonce);
     r.userFee = fr_from_u64(userFee); r.toBjjSign = fr_from_bit(toBjjSign);
-    const Fr am = io.in_c(in.amountF);
+    const Fc am = io.in_c(in.amountF);
     num2bits_dev(io, o.n2bAmount, am, 40, C_DEC_N2B_AMOUNT);
     const uint64_t amountF = c_bits64(am, 0, 40);
     r.amount = decode_float_dev(io, o.dfAmount, amountF);
     // txCompressedDataV2 (:174-212): every field bit times (1-onChain)
     {
-        Fr v2bits = fr_zero();  // canonical integer of the 216 gated bits
+        Fc v2bits = fc_zero();  // plain integer of the 216 gated bits
         int k = 0;
         auto put = [&](uint32_t bit) {
-            io.put_c(o.v2in + k, bit ? notOn_c : fr_zero());
+            io.put_c(o.v2in + k, bit ? notOn_c : fc_zero());
             v2bits.v[k >> 5] |= bit << (k & 31);
             k++;
         };
@@ -80,7 +80,8 @@ __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOf
         r.v2 = v2;
     }
     // batched inverses of the six IsZero inputs of this template
-    const Fr auxFromIdx = io.in_m(in.auxFromIdx), auxToIdx = io.in_m(in.auxToIdx), maxNumBatch_c = io.in_c(in.maxNumBatch);
+    const Fr auxFromIdx = io.in_m(in.auxFromIdx), auxToIdx = io.in_m(in.auxToIdx);
+    const Fc maxNumBatch_c = io.in_c(in.maxNumBatch);
     const Fr maxNumBatch = fr_from_canon(maxNumBatch_c);
     const Fr onNew = fr_mul(onChain, newAccount);
     r.outIdx = fr_add(inIdx, onNew);
@@ -95,17 +96,17 @@ __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOf
     const Fr sel_s = fr_mul(notOn, tz);
     const Fr finalTo = mux1_dev(r.toIdx, auxToIdx, sel_s);
     io.put_m(o.selToIdx_s, sel_s);
-    const Fr finalTo_c = fr_to_canon(finalTo);
+    const Fc finalTo_c = fr_to_canon(finalTo);
     io.put_c(o.selToIdx_out, finalTo_c);
     num2bits_dev(io, o.n2bFinalToIdx, finalTo_c, L, C_DEC_N2B_FINALTOIDX);
-    for (int i = 0; i < 8; i++) io.put_c(o.l1l2Fee + (7 - i), c_bit(d, 216 + i) ? notOn_c : fr_zero());
+    for (int i = 0; i < 8; i++) io.put_c(o.l1l2Fee + (7 - i), c_bit(d, 216 + i) ? notOn_c : fc_zero());
     // sigL2Hash (:249-283)
-    const Fr te = io.in_c(in.toEthAddr);
+    const Fc te = io.in_c(in.toEthAddr);
     num2bits_dev(io, o.n2bToEthAddr, te, 160, C_DEC_N2B_TOETHADDR);
     num2bits_dev(io, o.n2bMaxNumBatch, maxNumBatch_c, 32, C_DEC_N2B_MAXNUMBATCH);
     {
         // e1 = toEthAddr[0..159] | amountF << 160 | maxNumBatch << 200 (from the bit decompositions)
-        Fr e1 = c_extract(te, 0, 160);
+        Fc e1 = c_extract(te, 0, 160);
         for (int i = 0; i < 40; i++) e1.v[(160 + i) >> 5] |= c_bit(am, i) << ((160 + i) & 31);
         for (int i = 0; i < 32; i++) e1.v[(200 + i) >> 5] |= c_bit(maxNumBatch_c, i) << ((200 + i) & 31);
         Fr hin[6];
@@ -115,11 +116,11 @@ __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOf
         r.sigL2Hash = poseidon_hash<7>(hin, C7, M7, sink);
     }
     // L1TxFullData (:285-324): every bit times onChain
-    const Fr fe = io.in_c(in.fromEthAddr), la = io.in_c(in.loadAmountF);
+    const Fc fe = io.in_c(in.fromEthAddr), la = io.in_c(in.loadAmountF);
     num2bits_dev(io, o.n2bFromEthAddr, fe, 160, C_DEC_N2B_FROMETHADDR);
     num2bits_dev(io, o.n2bLoadAmountF, la, 40, C_DEC_N2B_LOADAMOUNTF);
     {
-        auto put = [&](int pos, uint32_t bit) { io.put_c(o.l1full + pos, bit ? on_c : fr_zero()); };
+        auto put = [&](int pos, uint32_t bit) { io.put_c(o.l1full + pos, bit ? on_c : fc_zero()); };
         for (int i = 0; i < 160; i++) put(160 - 1 - i, c_bit(fe, i));
         for (int i = 0; i < 256; i++) {
             // fromBjjCompressed[i] is an input signal (checked boolean by RollupMain phase A)
@@ -154,7 +155,7 @@ __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOf
     {
         // LessThan(32)(currentNumBatch, maxNumBatch + 1): Num2Bits(33)(in0 + 2^32 - in1)
         const Fr v = fr_sub(fr_add(currentNumBatch, m_pow2(32)), fr_add(maxNumBatch, one));
-        const Fr vc = fr_to_canon(v);
+        const Fc vc = fr_to_canon(v);
         num2bits_dev(io, o.maxNumBatchLt, vc, 33, C_DEC_N2B_MAXNUMBATCH_LT);
         const Fr ok = fr_from_bit(1u - c_bit(vc, 32));
         io.chk_zero(C_DEC_MAXNUMBATCH, fr_mul(fr_sub(one, ok), fr_sub(one, mz)));
@@ -166,7 +167,7 @@ __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOf
         for (int i = 0; i < L; i++) io.put_bit(o.o_l1l2 + (L - 1 - i), c_bit(d, 48 + i));
         for (int i = 0; i < L; i++) io.put_bit(o.o_l1l2 + (2 * L - 1 - i), c_bit(finalTo_c, i));
         for (int i = 0; i < 40; i++) io.put_bit(o.o_l1l2 + (2 * L + 40 - 1 - i), c_bit(am, i));
-        for (int i = 0; i < 8; i++) io.put_c(o.o_l1l2 + (2 * L + 48 - 1 - i), c_bit(d, 216 + i) ? notOn_c : fr_zero());
+        for (int i = 0; i < 8; i++) io.put_c(o.o_l1l2 + (2 * L + 48 - 1 - i), c_bit(d, 216 + i) ? notOn_c : fc_zero());
     }
     return r;
 }
@@ -207,15 +208,15 @@ __device__ __forceinline__ Fr mux4_coef(const Fr* c, int mask) {
 }
 
 // ComputeFee (src/compute-fee.circom:12-94) incl. Mux256 (src/lib/mux256.circom)
-__device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFeeOff& o, const Fr& feeSel_c, const Fr& amount, const Fr& applyFee) {
+__device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFeeOff& o, const Fc& feeSel_c, const Fr& amount, const Fr& applyFee) {
     const Fr one = fr_one();
     io.put_m(o.applyFee, applyFee);
     num2bits_dev(io, o.n2bFeeSel, feeSel_c, 8, C_RTX_FEE_N2B_SEL);
     Fr s[8];
-    const Fr applyFee_c = fr_to_canon(applyFee);
+    const Fc applyFee_c = fr_to_canon(applyFee);
     for (int i = 0; i < 8; i++) {
         s[i] = c_bit(feeSel_c, i) ? applyFee : fr_zero();
-        io.put_c(o.muxS + i, c_bit(feeSel_c, i) ? applyFee_c : fr_zero());
+        io.put_c(o.muxS + i, c_bit(feeSel_c, i) ? applyFee_c : fc_zero());
     }
     const Fr s10 = fr_mul(s[1], s[0]), s20 = fr_mul(s[2], s[0]), s21 = fr_mul(s[2], s[1]), s210 = fr_mul(s21, s[0]);
     const Fr sp[16] = {one, s[0], s[1], s10, s[2], s20, s21, s210, s[3], fr_zero(), fr_zero(), fr_zero(), fr_zero(), fr_zero(), fr_zero(), fr_zero()};
@@ -256,7 +257,7 @@ __device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFee
         io.put_m(b + MX4V_A2, a2); io.put_m(b + MX4V_A1, a1); io.put_m(b + MX4V_A0, a0); io.put_m(b + MX4V_OUT, factor);
     }
     const Fr notShifted = fr_mul(factor, amount);
-    const Fr ns_c = fr_to_canon(notShifted);
+    const Fc ns_c = fr_to_canon(notShifted);
     io.put_c(o.feeOutNotShifted, ns_c);
     const uint32_t shiftOff = c_bit(feeSel_c, 6) & c_bit(feeSel_c, 7);
     io.put_bit(o.applyShift, 1u - shiftOff);
@@ -267,7 +268,7 @@ __device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFee
     for (int i = 128; i < 253; i++) ovN += c_bit(ns_c, i);
     if (!shiftOff && ovS) report_fail(io.err, io.inst, io.err_unit, C_RTX_FEE_OVF_SHIFTED, fr_from_u64(ovS), fr_zero());
     if (shiftOff && ovN) report_fail(io.err, io.inst, io.err_unit, C_RTX_FEE_OVF_NOTSHIFTED, fr_from_u64(ovN), fr_zero());
-    const Fr feeOut_c = shiftOff ? c_extract(ns_c, 0, 128) : c_extract(ns_c, 60, 128);
+    const Fc feeOut_c = shiftOff ? c_extract(ns_c, 0, 128) : c_extract(ns_c, 60, 128);
     io.put_c(o.feeOut, feeOut_c);
     return fr_from_canon(feeOut_c);
 }
@@ -286,7 +287,7 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
     const Fr onChain = io.in_m(in.onChain), newAccount = io.in_m(in.newAccount);
     const Fr notOn = fr_sub(one, onChain);
     // ---- A: decode loadAmountF, states
-    const Fr la_c = io.in_c(in.loadAmountF);
+    const Fc la_c = io.in_c(in.loadAmountF);
     num2bits_dev(io, o.n2bLoadAmountF, la_c, 40, C_RTX_N2B_LOADAMOUNTF);
     const Fr loadAmount = decode_float_dev(io, o.dfLoadAmount, c_bits64(la_c, 0, 40));
     const Fr auxFromIdx = io.in_m(in.auxFromIdx), auxToIdx = io.in_m(in.auxToIdx), toEthAddr = io.in_m(in.toEthAddr);
@@ -386,7 +387,7 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
     io.put_m(so.nullifyAmount_0, na0); io.put_m(so.nullifyAmount, nullifyAmount);
     // ---- B: RqTxVerifier
     {
-        const Fr rq_c = io.in_c(in.rqOffset);
+        const Fc rq_c = io.in_c(in.rqOffset);
         num2bits_dev(io, o.rq_n2b, rq_c, 3, C_RTX_RQ_N2B);
         const Fr s[3] = {fr_from_bit(c_bit(rq_c, 0)), fr_from_bit(c_bit(rq_c, 1)), fr_from_bit(c_bit(rq_c, 2))};
         const Fr* fut[3] = {x.futV2, x.futEth, x.futAy};
@@ -416,14 +417,14 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
     force_eq(o.checkTokenID1L1, Z_T1, isP1Insert, C_RTX_TOKENID1_L1);
     force_eq(o.fromEthAddrChecker, Z_FETH, isP1Insert, C_RTX_FROMETHADDR);
     // ---- E: BitsCompressed2AySign + 16 Mux1 (s1OldValue / s2OldValue need the old hashes: hash step)
-    Fr bjjAy_c = fr_zero();
+    Fc bjjAy_c = fc_zero();
     Fr bjjSign;
     {
         // fromBjjCompressed are boolean inputs (RollupMain phase A); pack bits 0..253 into an integer
         Fr acc = fr_zero();
         bool all_bool = true;
         for (int i = 0; i < 254; i++) {
-            const Fr b = io.in_c(in.fromBjjCompressed + i);
+            const Fc b = io.in_c(in.fromBjjCompressed + i);
             bool is1 = b.v[0] == 1u, is0 = b.v[0] == 0u;
             for (int k = 1; k < 8; k++) { is1 = is1 && b.v[k] == 0u; is0 = is0 && b.v[k] == 0u; }
             if (!(is0 || is1)) all_bool = false;
@@ -431,9 +432,9 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
         }
         if (all_bool) {
             // the packed integer may exceed r (2^254 > r): reduce with a field conversion
-            Fr lo = bjjAy_c;
+            Fc lo = bjjAy_c;
             // values < 2^254 < 2r: one conditional subtraction makes them canonical
-            fr_cond_sub_p(lo.v);
+            fc_cond_sub_p(lo.v);
             acc = fr_from_canon(lo);
         } else {
             for (int i = 253; i >= 0; i--) acc = fr_add(fr_dbl(acc), io.in_m(in.fromBjjCompressed + i));
@@ -464,13 +465,13 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
     io.put_m(o.ed.signSignature, signSig); io.put_m(o.ed.aySignature, aySig);
     // ---- G: BalanceUpdater
     const BalUpdOff& bo = o.bu;
-    const Fr userFee_c = fr_to_canon(x.userFee);
+    const Fc userFee_c = fr_to_canon(x.userFee);
     const Fr fee2Charge = compute_fee_dev(io, bo.fee, userFee_c, x.amount, fr_mul(notOn, fr_sub(one, nop)));
     const Fr el1 = fr_mul(loadAmount, onChain), el2 = fr_mul(el1, fr_sub(one, nullifyLoadAmount));
     const Fr ea2 = fr_mul(effAmt1, fr_sub(one, nullifyAmount));
     io.put_m(bo.effLoad1, el1); io.put_m(bo.effLoad2, el2); io.put_m(bo.effAmt1, effAmt1); io.put_m(bo.effAmt2, ea2);
     const Fr sb = fr_sub(fr_sub(fr_add(fr_add(m_pow2(192), mx[MX_S1BALANCE]), el2), ea2), fee2Charge);
-    const Fr sb_c = fr_to_canon(sb);
+    const Fc sb_c = fr_to_canon(sb);
     num2bits_dev(io, bo.n2bSender, sb_c, 193, C_RTX_BU_N2B_SENDER);
     const uint32_t ufOk = c_bit(sb_c, 192);
     const Fr underflowOk = fr_from_bit(ufOk);

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_main_front(const MainFrontArgs a) 
     bool_chk(C_MAIN_ONCHAIN_BOOL, io.in_m(m.onChain));
     bool_chk(C_MAIN_NEWACCOUNT_BOOL, io.in_m(m.newAccount));
     for (int j = 0; j < 256; j++) {
-        const Fr b = io.in_c(m.fromBjjCompressed + j);
+        const Fc b = io.in_c(m.fromBjjCompressed + j);
         uint32_t hi = 0;
         for (int k = 1; k < 8; k++) hi |= b.v[k];
         if (hi || b.v[0] > 1u) bool_chk(C_MAIN_BJJ_BOOL, fr_from_canon(b));
@@ -191,13 +191,13 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smt(const SmtArgs a) {
     const Fr one = fr_one(), zero = fr_zero();
     const Fr fnc0 = sc.get(P.sc_fnc0), fnc1 = sc.get(P.sc_fnc1), isOld0 = sc.get(P.sc_isold0);
     const Fr enabled = fr_sub(fr_add(fnc0, fnc1), fr_mul(fnc0, fnc1));
-    const Fr oldKey_c = fr_to_canon(sc.get(P.sc_oldkey)), newKey_c = fr_to_canon(sc.get(P.sc_newkey));
+    const Fc oldKey_c = fr_to_canon(sc.get(P.sc_oldkey)), newKey_c = fr_to_canon(sc.get(P.sc_newkey));
     const Fr h1old = sc.get(P.sc_leaf_old), h1new = sc.get(P.sc_leaf_new);
     // SMTLevIns: levIns[i] from the zero pattern of the siblings (both lanes need it)
     // isz[i] in {0,1}; done/levIns are 0/1 as well -> integer logic, exact for any input
     uint64_t zmask = 0;  // bit i = siblings[i] == 0
     for (int k = 0; k < n; k++) {
-        const Fr s = io.in_c(P.siblings + k);
+        const Fc s = io.in_c(P.siblings + k);
         uint32_t any = 0;
         for (int q = 0; q < 8; q++) any |= s.v[q];
         if (!any) zmask |= 1ull << k;
@@ -336,11 +336,11 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
             io.chk(C_MAIN_IM_INITFEEROOT, newStateRoot, fr_from_canon(load_fr(a.glob_base + (size_t)a.g_initfeeroot * 32)));
         }
         // H (:456-459): amountF bits of L1L2TxData times (1 - isAmountNullified)
-        const Fr keep_c = fr_to_canon(fr_sub(fr_one(), sc.get(SC_ISAMTNULL)));
+        const Fc keep_c = fr_to_canon(fr_sub(fr_one(), sc.get(SC_ISAMTNULL)));
         for (int j = 0; j < 40; j++) {
             // L1L2TxData[2L + 40 - 1 - k] = n2bAmount.out[k]
-            const Fr b = io.in_c(a.n2bAmount + (39 - j));
-            io.put_c(a.main_l1l2amt + j, b.v[0] ? keep_c : fr_zero());
+            const Fc b = io.in_c(a.n2bAmount + (39 - j));
+            io.put_c(a.main_l1l2amt + j, b.v[0] ? keep_c : fc_zero());
         }
     } else {
         io.put_m(a.o_newStateRoot, newStateRoot); io.put_m(a.o_newExitRoot, newExitRoot);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_main_front, grid1(a.nTx), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * 32, s, a);
+    hipLaunchKernelGGL(k_main_front, grid1(a.nTx), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
@@ -360,19 +360,19 @@ hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_main, grid1(a.N), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * 32, s, a);
+    hipLaunchKernelGGL(k_dec_main, grid1(a.N), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
     dim3 g = grid1(a.n_units);
     g.y = a.n_jobs;
-    hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), (size_t)(poseidon_const_frs<5>() + poseidon_const_frs<4>()) * 32, s, a);
+    hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), (size_t)(poseidon_const_frs<5>() + poseidon_const_frs<4>()) * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s) {
     dim3 g = grid1(a.n_units);
     g.y = 2 * a.n_proc;
-    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), (size_t)poseidon_const_frs<3>() * 32, s, a);
+    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), (size_t)poseidon_const_frs<3>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s) {

@@ -3,10 +3,10 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <vector>
-#define HZ_FR_MUL_INLINE 1
+#define HZ_FR_INLINE 1
 #include "../../circuits_amd/csrc/fr.h"
 using namespace hz;
-#define P(i) fr_p(i)
+#define P(i) fc_p(i)
 #define INV 0xefffffffu
 
 __device__ __forceinline__ void mac(uint64_t& acc, uint32_t& hi, uint32_t a, uint32_t b) {
@@ -16,7 +16,7 @@ __device__ __forceinline__ void mac_s(uint64_t& acc, uint32_t& hi, uint32_t a, u
     asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(hi) : "v"(a), "s"(b_const) : "vcc");
 }
 // V2: product scanning with carry-out of v_mad_u64_u32
-__device__ __forceinline__ Fr mul_v2(const Fr& a, const Fr& b) {
+__device__ __forceinline__ Fc mul_v2(const Fc& a, const Fc& b) {
     uint32_t t[16];
     uint64_t acc = 0; uint32_t hi = 0;
 #pragma unroll
@@ -36,8 +36,8 @@ __device__ __forceinline__ Fr mul_v2(const Fr& a, const Fr& b) {
         if (k < 8) { m[k] = (uint32_t)acc * INV; mac_s(acc, hi, m[k], P(0)); } else { r[k - 8] = (uint32_t)acc; }
         acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
     }
-    fr_cond_sub_p(r);
-    Fr o;
+    fc_cond_sub_p(r);
+    Fc o;
 #pragma unroll
     for (int i = 0; i < 8; i++) o.v[i] = r[i];
     return o;
@@ -83,11 +83,17 @@ __global__ __launch_bounds__(64) void kbench(uint32_t* x, int n) {
         for (int i = 0; i < n; i++) { a = mul_v3(a, b); b.v[0] ^= a.v[0] & 1; }
         for (int i = 0; i < 9; i++) x[tid * 18 + i] = a.v[i];
     } else {
-        Fr a, b;
+        Fc a, b;
         for (int i = 0; i < 8; i++) { a.v[i] = x[tid * 18 + i]; b.v[i] = x[tid * 18 + 9 + i]; }
         a.v[7] &= 0x0fffffff; b.v[7] &= 0x0fffffff;
-        for (int i = 0; i < n; i++) { a = (V == 0) ? fr_mul(a, b) : mul_v2(a, b); b.v[0] ^= a.v[0] & 1; }
-        for (int i = 0; i < 8; i++) x[tid * 18 + i] = a.v[i];
+        if (V == 0) {
+            Fr am = fr_unpack(a), bm = fr_unpack(b);
+            for (int i = 0; i < n; i++) { am = fr_mul(am, bm); bm.v[0] ^= am.v[0] & 1; }
+            for (int i = 0; i < 8; i++) x[tid * 18 + i] = am.v[i];
+        } else {
+            for (int i = 0; i < n; i++) { a = mul_v2(a, b); b.v[0] ^= a.v[0] & 1; }
+            for (int i = 0; i < 8; i++) x[tid * 18 + i] = a.v[i];
+        }
     }
 }
 
