@@ -15,12 +15,29 @@ using namespace hz;
 using namespace hzl;
 
 struct hz_ctx {
+    // optional per-kernel timing (HIP events on the launch stream)
+    bool profiling = false;
+    struct Prof { std::string name; uint64_t bytes; uint64_t units; hipEvent_t e0, e1; float ms; };
+    std::vector<Prof> prof;
+    size_t prof_used = 0;
     Layout lo;
     int device = 0;
     DevBuf wit, sc_tx, sc_fee, err, msg, chain, stage;
     std::vector<uint8_t> input_set;
     std::vector<uint8_t> host_stage;
     hipStream_t last_stream = nullptr;
+    // independent chains of one batch run concurrently: the EdDSA ladders and the fee transactions on
+    // their own streams, joined by events before HashInputs (DESIGN.md "Kernel schedule")
+    hipStream_t s_ed = nullptr, s_fee = nullptr, s_main = nullptr;   // s_main replaces a NULL caller stream
+    hipEvent_t ev_reset = nullptr, ev_front = nullptr, ev_ed = nullptr, ev_fee = nullptr;
+    ~hz_ctx() {
+        if (s_ed) (void)hipStreamDestroy(s_ed);
+        if (s_fee) (void)hipStreamDestroy(s_fee);
+        if (s_main) (void)hipStreamDestroy(s_main);
+        for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee})
+            if (e) (void)hipEventDestroy(e);
+        for (auto& p : prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    }
     unsigned long long filter_stage = ~0ull;
     bool enqueued = false;
     // symbol enumeration index: cumulative symbol counts per (section, block)
@@ -28,11 +45,6 @@ struct hz_ctx {
     std::vector<BlkRef> sym_index;
     uint64_t sym_total = 0;
     std::string sym_name;
-    // optional per-kernel timing (HIP events on the launch stream)
-    bool profiling = false;
-    struct Prof { std::string name; uint64_t bytes; uint64_t units; hipEvent_t e0, e1; float ms; };
-    std::vector<Prof> prof;
-    size_t prof_used = 0;
 };
 
 // which kernel writes a block of the tx / fee / hash-inputs sections (for algorithmic byte counts)
@@ -117,6 +129,11 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         e = c->msg.alloc((size_t)lo.hi.sha.nblocks * 64);
         if (e == hipSuccess) e = c->chain.alloc((size_t)(lo.hi.sha.nblocks + 1) * 32);
     }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_ed, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_fee, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
+    for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee})
+        if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete c;
         return set_err(HZ_ERR_HIP, "hz_ctx_create: %s (witness buffer %.1f MiB)", hipGetErrorString(e), lo.total * 32.0 / 1048576.0);
@@ -267,6 +284,15 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     const Layout& lo = c->lo;
     Fr* sc = (Fr*)c->sc_tx.p;
     ErrBuf* err = (ErrBuf*)c->err.p;
+    EddsaArgs ea;
+    memset(&ea, 0, sizeof ea);
+    ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.inst_is_unit = is_main ? 0 : 1; ea.ed = lo.rtx.ed;
+    {
+        // the signature ladders only need the front step: run them beside the hash/SMT chain
+        HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_front, 0));
+        { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed)); }
+        HZ_HIP(hipEventRecord(c->ev_ed, c->s_ed));
+    }
     { ProfScope ps(c, s, "hash4", n_units); HZ_HIP(launch_hash4(make_hash4_rtx(base, sc, n_units, lo.rtx), s)); }
     SmtArgs sa;
     memset(&sa, 0, sizeof sa);
@@ -274,10 +300,6 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     sa.p[0] = make_proc(lo.rtx.p1, sib1, 0);
     sa.p[1] = make_proc(lo.rtx.p2, sib2, 1);
     { ProfScope ps(c, s, "smt", n_units); HZ_HIP(launch_smt(sa, s)); }
-    EddsaArgs ea;
-    memset(&ea, 0, sizeof ea);
-    ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.inst_is_unit = is_main ? 0 : 1; ea.ed = lo.rtx.ed;
-    { ProfScope ps(c, s, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, s)); }
     RtxBackArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.base = base; ba.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; ba.scratch = sc; ba.err = err; ba.n_units = n_units; ba.L = (uint32_t)lo.p.L;
@@ -291,6 +313,7 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         ba.o_newStateRoot = lo.rtxi.o_newStateRoot; ba.o_newExitRoot = lo.rtxi.o_newExitRoot;
     }
     { ProfScope ps(c, s, "rtx_back", n_units); HZ_HIP(launch_rtx_back(ba, s)); }
+    HZ_HIP(hipStreamWaitEvent(s, c->ev_ed, 0));   // join the signature stream
     return HZ_OK;
 }
 
@@ -358,7 +381,9 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
     for (size_t i = 0; i < c->input_set.size(); i++)
         if (!c->input_set[i]) return set_err(HZ_ERR_INPUT, "Not all inputs have been set: %s", lo.inputs[i].name.c_str());
     HZ_HIP(hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t)stream;
+    // the legacy default stream has implicit-synchronisation semantics that do not mix with the
+    // context's non-blocking side streams: a NULL stream means "the context's own stream"
+    hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
     // error buffer header: minkey = ~0, filter (= ~0 unless hz_witness_check re-runs after an overflow), count = 0
     HZ_HIP(hipMemsetAsync(c->err.p, 0xFF, 16, s));
     HZ_HIP(hipMemsetAsync((uint8_t*)c->err.p + 16, 0, 8, s));
@@ -366,6 +391,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
         c->filter_stage = filter;
         HZ_HIP(hipMemcpyAsync((uint8_t*)c->err.p + 8, &c->filter_stage, 8, hipMemcpyHostToDevice, s));
     }
+    HZ_HIP(hipEventRecord(c->ev_reset, s));
     ErrBuf* err = (ErrBuf*)c->err.p;
     c->prof_used = 0;
     switch (lo.p.tmpl) {
@@ -375,11 +401,15 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             fa.tx_base = sec_ptr(c, lo.sec_tx); fa.fee_base = sec_ptr(c, lo.sec_fee); fa.glob_base = sec_ptr(c, lo.sec_glob);
             fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.nTx = (uint32_t)lo.p.nTx; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F;
             fa.g = lo.g; fa.mi = lo.mi; fa.fi = lo.fi; fa.dec = lo.dec; fa.rtx = lo.rtx;
+            HZ_HIP(hipStreamWaitEvent(c->s_fee, c->ev_reset, 0));
+            hz_status st = enqueue_fee(c, fa.fee_base, (uint32_t)lo.p.F, true, c->s_fee);   // independent of the transactions
+            if (st != HZ_OK) return st;
+            HZ_HIP(hipEventRecord(c->ev_fee, c->s_fee));
             { ProfScope ps(c, s, "front", fa.nTx); HZ_HIP(launch_main_front(fa, s)); }
-            hz_status st = enqueue_rtx_tail(c, fa.tx_base, fa.nTx, true, lo.mi.siblings1, lo.mi.siblings2, s);
+            HZ_HIP(hipEventRecord(c->ev_front, s));
+            st = enqueue_rtx_tail(c, fa.tx_base, fa.nTx, true, lo.mi.siblings1, lo.mi.siblings2, s);
             if (st != HZ_OK) return st;
-            st = enqueue_fee(c, fa.fee_base, (uint32_t)lo.p.F, true, s);
-            if (st != HZ_OK) return st;
+            HZ_HIP(hipStreamWaitEvent(s, c->ev_fee, 0));
             { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s)); }
             break;
         }
@@ -389,6 +419,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             fa.base = sec_ptr(c, 0); fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.N = lo.sections[0].n_units; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F;
             fa.in = lo.rtxi; fa.rtx = lo.rtx;
             { ProfScope ps(c, s, "front", fa.N); HZ_HIP(launch_rtx_front(fa, s)); }
+            HZ_HIP(hipEventRecord(c->ev_front, s));
             hz_status st = enqueue_rtx_tail(c, fa.base, fa.N, false, lo.rtxi.siblings1, lo.rtxi.siblings2, s);
             if (st != HZ_OK) return st;
             break;
@@ -443,13 +474,17 @@ extern "C" hz_status hz_witness_check(hz_ctx* c, hz_error* out) {
     HZ_HIP(hipSetDevice(c->device));
     struct { unsigned long long minkey, filter; unsigned int count, pad; } hd;
     for (int attempt = 0; attempt < 2; attempt++) {
+        // copy on the launch stream: a default-stream hipMemcpy would wait for every other batch in flight
+        HZ_HIP(hipMemcpyAsync(&hd, c->err.p, sizeof hd, hipMemcpyDeviceToHost, c->last_stream));
         HZ_HIP(hipStreamSynchronize(c->last_stream));
         c->enqueued = false;
-        HZ_HIP(hipMemcpy(&hd, c->err.p, sizeof hd, hipMemcpyDeviceToHost));
         if (hd.minkey == ~0ull) return HZ_OK;
         const unsigned int n = std::min<unsigned int>(hd.count, HZ_ERR_CAP);
         std::vector<ErrRec> recs(n);
-        if (n) HZ_HIP(hipMemcpy(recs.data(), (uint8_t*)c->err.p + offsetof(ErrBuf, rec), n * sizeof(ErrRec), hipMemcpyDeviceToHost));
+        if (n) {
+            HZ_HIP(hipMemcpyAsync(recs.data(), (uint8_t*)c->err.p + offsetof(ErrBuf, rec), n * sizeof(ErrRec), hipMemcpyDeviceToHost, c->last_stream));
+            HZ_HIP(hipStreamSynchronize(c->last_stream));
+        }
         for (const ErrRec& r : recs)
             if (r.key == hd.minkey) {
                 fill_error(out, hd.minkey, &r);

@@ -131,27 +131,56 @@ __device__ __forceinline__ PtA m2e_dev(const EdCtx& c, const PtA& p) {
     return o;
 }
 
-// SegmentMulAny(n): bits e[e0 .. e0+n) of the canonical integer `e`
+// SegmentMulAny(n): bits e[e0 .. e0+n) of the canonical integer `e`.
+// Step i is doubler_i (D_{i+1} = 2 D_i) followed by adder_i (D_{i+1} + acc_i). adder_i and
+// doubler_{i+1} both depend only on D_{i+1} and acc_i, so their two divisions share ONE field
+// inversion (Montgomery's trick): the ladder costs one inversion per scalar bit instead of two.
 struct SegAnyRes { PtA out, dbl; };
 __device__ SegAnyRes seg_any_dev(const EdCtx& c, const SegAnyOff& o, const Fc& e, int e0, int n, const PtA& p) {
     const PtA m = e2m_dev(c, p);
     c.io.put_m(o.e2m, m.x); c.io.put_m(o.e2m + 1, m.y);
-    PtA dblIn = m, addIn = m;
+    const int steps = n - 1;
+    // doubler_0 alone
+    MDbl d = mont_dbl_dev(c, m);
+    PtA addIn = m;
 #pragma unroll 1
-    for (int i = 0; i < n - 1; i++) {
+    for (int i = 0; i < steps; i++) {
         const uint32_t b = o.bits + BIT_N * i;
-        const MDbl d = mont_dbl_dev(c, dblIn);
-        const MAdd a = mont_add_dev(c, d.out, addIn);
+        // adder_i: in1 = d.out, in2 = addIn ; doubler_{i+1}: in = d.out
+        const Fr a_num = fr_sub(addIn.y, d.out.y), a_den = fr_sub(addIn.x, d.out.x);
+        const bool more = i + 1 < steps;
+        Fr nx1_2 = fr_zero(), d_num = fr_zero(), d_den = fr_zero();
+        if (more) {
+            nx1_2 = fr_sqr(d.out.x);
+            d_num = fr_add(fr_add(fr_add(fr_dbl(nx1_2), nx1_2), fr_mul(fr_dbl(c.A), d.out.x)), c.one);
+            d_den = fr_dbl(d.out.y);
+        }
+        Fr den[2] = {a_den, d_den};
+        Fr inv[2] = {a_den, d_den};
+        batch_inv<2>(inv, more ? 2 : 1);
+        MAdd a;
+        a.lamda = fr_mul(a_num, inv[0]);
+        if (fr_is_zero(den[0])) c.io.chk(C_RTX_SIG_EC, fr_zero(), a_num);
+        a.out.x = fr_sub(fr_sub(fr_sub(fr_sqr(a.lamda), c.A), d.out.x), addIn.x);
+        a.out.y = fr_sub(fr_mul(a.lamda, fr_sub(d.out.x, a.out.x)), d.out.y);
         const uint32_t sel = c_bit(e, e0 + i + 1);
         const PtA so = sel ? a.out : addIn;
         c.io.put_m(b + BIT_DBL_X1_2, d.x1_2); c.io.put_m(b + BIT_DBL_LAMDA, d.lamda); c.io.put_m(b + BIT_DBL_OUT0, d.out.x); c.io.put_m(b + BIT_DBL_OUT1, d.out.y);
         c.io.put_m(b + BIT_ADD_LAMDA, a.lamda); c.io.put_m(b + BIT_ADD_OUT0, a.out.x); c.io.put_m(b + BIT_ADD_OUT1, a.out.y);
         c.io.put_m(b + BIT_SEL_OUT0, so.x); c.io.put_m(b + BIT_SEL_OUT1, so.y);
-        dblIn = d.out;
         addIn = so;
+        if (more) {
+            MDbl nd;
+            nd.x1_2 = nx1_2;
+            nd.lamda = fr_mul(d_num, inv[1]);
+            if (fr_is_zero(den[1])) c.io.chk(C_RTX_SIG_EC, fr_zero(), d_num);
+            nd.out.x = fr_sub(fr_sub(fr_sqr(nd.lamda), c.A), fr_dbl(d.out.x));
+            nd.out.y = fr_sub(fr_mul(nd.lamda, fr_sub(d.out.x, nd.out.x)), d.out.y);
+            d = nd;
+        }
     }
     SegAnyRes r;
-    r.dbl = dblIn;
+    r.dbl = d.out;
     const PtA me = m2e_dev(c, addIn);
     c.io.put_m(o.m2e, me.x); c.io.put_m(o.m2e + 1, me.y);
     PtA negp;
