@@ -132,189 +132,6 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_dec_main(const DecMainArgs a) {
                   io.in_m(a.in.currentNumBatch), C7, M7);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// HashState x4 + SMTHash1 x4 (reference src/rollup-tx.circom:297-312,517-532 and the hash1Old /
-// hash1New components of circomlib's SMTProcessor). blockIdx.y = j.
-
-__global__ __launch_bounds__(HZ_BLOCK) void k_hash4(const Hash4Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C5 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M5 = C5 + poseidon_nconst<5>();
-    Fr* C4 = M5 + 25;
-    Fr* M4 = C4 + poseidon_nconst<4>();
-    stage_poseidon_consts<5>(C5);
-    stage_poseidon_consts<4>(C4);
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_units) return;
-    const HashJob& J = a.job[blockIdx.y];
-    const UnitIO io{a.base, a.n_units, i, 0, i, nullptr};
-    const Scratch sc{a.scratch, a.n_units, i};
-    Fr hin[4];
-    for (int k = 0; k < 4; k++) hin[k] = sc.get(J.sc_in + k);
-    WitSboxSink s5 = io.sbox_sink(J.hs);
-    const Fr h = poseidon_hash<5>(hin, C5, M5, s5);
-    Fr value = h;
-    if (J.mux_off != ~0u) {
-        // s1OldValue / s2OldValue: Mux1(c0 = old state hash, c1 = oldValue input, s = isInsert)
-        value = mux1_dev(h, sc.get(J.sc_oldvalue), sc.get(J.sc_ins));
-        io.put_m(J.mux_off, value);
-    }
-    if (J.out_sig != ~0u) io.put_m(J.out_sig, h);
-    if (J.h1 == ~0u) return;
-    Fr h1in[3] = {sc.get(J.sc_key), value, fr_one()};
-    WitSboxSink s4 = io.sbox_sink(J.h1);
-    sc.set(J.sc_leaf, poseidon_hash<4>(h1in, C4, M4, s4));
-}
-
-// ---------------------------------------------------------------------------------------------------
-// SMTProcessor level chains (circomlib smt/smtprocessor.circom + smtlevins, smtprocessorsm,
-// smtprocessorlevel, switcher). One lane per (unit, processor, side). blockIdx.y = chain.
-// The old-side lane also writes enabled, n2bOld, SMTLevIns; the new-side lane n2bNew, xors, sm.
-
-
-__global__ __launch_bounds__(HZ_BLOCK) void k_smt(const SmtArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C3 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M3 = C3 + poseidon_nconst<3>();
-    stage_poseidon_consts<3>(C3);
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_units) return;
-    const uint32_t chain = blockIdx.y, pi = chain >> 1;
-    const bool new_side = chain & 1;
-    const SmtProcDesc& P = a.p[pi];
-    const SmtProcOff& o = P.o;
-    const int n = (int)a.n_levels;
-    const UnitIO io{a.base, a.n_units, i, a.inst_is_unit ? i : 0u, a.inst_is_unit ? 0u : i, a.err};
-    const Scratch sc{a.scratch, a.n_units, i};
-    const Fr one = fr_one(), zero = fr_zero();
-    const Fr fnc0 = sc.get(P.sc_fnc0), fnc1 = sc.get(P.sc_fnc1), isOld0 = sc.get(P.sc_isold0);
-    const Fr enabled = fr_sub(fr_add(fnc0, fnc1), fr_mul(fnc0, fnc1));
-    const Fc oldKey_c = fr_to_canon(sc.get(P.sc_oldkey)), newKey_c = fr_to_canon(sc.get(P.sc_newkey));
-    const Fr h1old = sc.get(P.sc_leaf_old), h1new = sc.get(P.sc_leaf_new);
-    // SMTLevIns: levIns[i] from the zero pattern of the siblings (both lanes need it)
-    // isz[i] in {0,1}; done/levIns are 0/1 as well -> integer logic, exact for any input
-    uint64_t zmask = 0;  // bit i = siblings[i] == 0
-    for (int k = 0; k < n; k++) {
-        const Fc s = io.in_c(P.siblings + k);
-        uint32_t any = 0;
-        for (int q = 0; q < 8; q++) any |= s.v[q];
-        if (!any) zmask |= 1ull << k;
-    }
-    uint64_t levmask = 0;
-    {
-        // levIns[n-1] = 1 - isz[n-2]; done[n-2] = levIns[n-1]; levIns[i] = (1-done[i])*(1-isz[i-1]); done[i-1] = levIns[i]+done[i]
-        uint32_t done = 0;
-        uint32_t li = 1u - (uint32_t)((zmask >> (n - 2)) & 1);
-        if (li) levmask |= 1ull << (n - 1);
-        done = li;
-        for (int k = n - 2; k > 0; k--) {
-            li = (1u - done) * (1u - (uint32_t)((zmask >> (k - 1)) & 1));
-            if (li) levmask |= 1ull << k;
-            done += li;
-        }
-        if (!done) levmask |= 1ull;
-    }
-    if (!new_side) {
-        if (o.fnc != ~0u) { io.put_m(o.fnc, fnc0); io.put_m(o.fnc + 1, fnc1); }
-        io.put_m(o.enabled, enabled);
-        num2bits_strict_dev(io, o.n2bOld, oldKey_c, P.cid_alias_old);
-        // isZero[i]: batched inverses, 16 at a time
-        for (int base = 0; base < n; base += 16) {
-            const int cnt = (n - base) < 16 ? (n - base) : 16;
-            Fr z[16], zi[16];
-            for (int k = 0; k < cnt; k++) { z[k] = io.in_m(P.siblings + base + k); zi[k] = z[k]; }
-            batch_inv<16>(zi, cnt);
-            for (int k = 0; k < cnt; k++) is_zero_dev(io, o.isz + 2 * (base + k), z[k], zi[k]);
-        }
-        // (isZero[n-1].out - 1) * enabled === 0
-        if (!((zmask >> (n - 1)) & 1)) io.chk_zero(P.cid_levins, fr_neg(enabled));
-        for (int k = 1; k <= n - 2; k++) io.put_bit(o.levIns + (k - 1), (uint32_t)((levmask >> k) & 1));
-    } else {
-        num2bits_strict_dev(io, o.n2bNew, newKey_c, P.cid_alias_new);
-        for (int k = 0; k < n; k++) io.put_bit(o.xors + k, c_bit(oldKey_c, k) ^ c_bit(newKey_c, k));
-    }
-    // state machine (both lanes; the new-side lane stores it). Field arithmetic: fnc/isOld0 may be
-    // arbitrary field elements in a standalone RollupTx.
-    Fr st_top[HZ_MAX_SMT_LEVELS];
-    uint8_t code[HZ_MAX_SMT_LEVELS];  // compact copy is not possible in general: keep per-level values below
-    (void)code;
-    Fr st_sum_a[HZ_MAX_SMT_LEVELS];   // old side: st_bot+st_new1+st_upd ; new side: st_top+st_bot
-    Fr st_b[HZ_MAX_SMT_LEVELS];       // new side: st_new1
-    Fr st_c[HZ_MAX_SMT_LEVELS];       // new side: st_old0+st_upd
-    {
-        Fr p_top = enabled, p_old0 = zero, p_bot = zero, p_new1 = zero, p_na = fr_sub(one, enabled), p_upd = zero;
-        Fr last_sum = zero;
-        for (int k = 0; k < n; k++) {
-            const uint32_t lev = (uint32_t)((levmask >> k) & 1);
-            const uint32_t xr = c_bit(oldKey_c, k) ^ c_bit(newKey_c, k);
-            const Fr aux1 = lev ? p_top : zero;
-            const Fr aux2 = fr_mul(aux1, fnc0);
-            const Fr t_top = fr_sub(p_top, aux1);
-            const Fr t_old0 = fr_mul(aux2, isOld0);
-            const Fr mid = fr_add(fr_sub(aux2, t_old0), p_bot);
-            const Fr t_new1 = xr ? mid : zero;
-            const Fr t_bot = xr ? zero : mid;
-            const Fr t_upd = fr_sub(aux1, aux2);
-            const Fr t_na = fr_add(fr_add(fr_add(p_new1, p_old0), p_na), p_upd);
-            if (new_side) {
-                const uint32_t b = o.sm + SM_N * k;
-                io.put_m(b + SM_AUX1, aux1); io.put_m(b + SM_AUX2, aux2); io.put_m(b + SM_OLD0, t_old0); io.put_m(b + SM_NEW1, t_new1);
-                io.put_m(b + SM_BOT, t_bot);
-                st_sum_a[k] = fr_add(t_top, t_bot);
-                st_b[k] = t_new1;
-                st_c[k] = fr_add(t_old0, t_upd);
-            } else {
-                st_sum_a[k] = fr_add(fr_add(t_bot, t_new1), t_upd);
-            }
-            st_top[k] = t_top;
-            if (k == n - 1) last_sum = fr_add(fr_add(fr_add(t_na, t_new1), t_old0), t_upd);
-            p_top = t_top; p_old0 = t_old0; p_bot = t_bot; p_new1 = t_new1; p_na = t_na; p_upd = t_upd;
-        }
-        if (new_side) io.chk(P.cid_sm_final, last_sum, one);
-    }
-    // level chain, bottom-up
-    Fr child = zero;
-    for (int k = n - 1; k >= 0; k--) {
-        const uint32_t lv = o.levels + LV_SIZE * k;
-        const uint32_t sel = c_bit(newKey_c, k);
-        const Fr sib = io.in_m(P.siblings + k);
-        if (!new_side) {
-            // oldSwitcher(L = oldChild, R = sibling, sel); aux = (R-L)*sel
-            const Fr aux = sel ? fr_sub(sib, child) : zero;
-            io.put_m(lv + LV_OLDSW_AUX, aux);
-            Fr hin[2];
-            hin[0] = sel ? sib : child;
-            hin[1] = sel ? child : sib;
-            WitSboxSink sk = io.sbox_sink(lv + LV_OLDHASH);
-            const Fr h = poseidon_hash<3>(hin, C3, M3, sk);
-            const Fr aux0 = fr_mul(h1old, st_sum_a[k]);
-            const Fr root = fr_add(aux0, fr_mul(h, st_top[k]));
-            io.put_m(lv + LV_AUX0, aux0); io.put_m(lv + LV_OLDROOT, root);
-            child = root;
-        } else {
-            const Fr aux1 = fr_mul(child, st_sum_a[k]);
-            const Fr swL = fr_add(aux1, fr_mul(h1new, st_b[k]));
-            const Fr aux2 = fr_mul(sib, st_top[k]);
-            const Fr swR = fr_add(aux2, fr_mul(h1old, st_b[k]));
-            const Fr aux = sel ? fr_sub(swR, swL) : zero;
-            Fr hin[2];
-            hin[0] = sel ? swR : swL;
-            hin[1] = sel ? swL : swR;
-            WitSboxSink sk = io.sbox_sink(lv + LV_NEWHASH);
-            const Fr h = poseidon_hash<3>(hin, C3, M3, sk);
-            const Fr aux3 = fr_mul(h, fr_add(st_sum_a[k], st_b[k]));
-            const Fr root = fr_add(aux3, fr_mul(h1new, st_c[k]));
-            io.put_m(lv + LV_NEWSW_AUX, aux); io.put_m(lv + LV_AUX1, aux1); io.put_m(lv + LV_AUX2, aux2); io.put_m(lv + LV_AUX3, aux3);
-            io.put_m(lv + LV_NEWSW_L, swL); io.put_m(lv + LV_NEWSW_R, swR); io.put_m(lv + LV_NEWROOT, root);
-            child = root;
-        }
-    }
-    sc.set(new_side ? P.sc_root_new : P.sc_root_old, child);
-}
-
-// ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_units) return;
@@ -361,18 +178,6 @@ hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
 }
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_dec_main, grid1(a.N), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * sizeof(Fr), s, a);
-    return hipGetLastError();
-}
-hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
-    dim3 g = grid1(a.n_units);
-    g.y = a.n_jobs;
-    hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), (size_t)(poseidon_const_frs<5>() + poseidon_const_frs<4>()) * sizeof(Fr), s, a);
-    return hipGetLastError();
-}
-hipError_t launch_smt(const SmtArgs& a, hipStream_t s) {
-    dim3 g = grid1(a.n_units);
-    g.y = 2 * a.n_proc;
-    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), (size_t)poseidon_const_frs<3>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s) {
