@@ -20,6 +20,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# independent batches are issued on separate HIP streams; give the runtime enough hardware queues
+# for them to overlap (the ROCm default maps all streams onto 4)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -49,13 +52,13 @@ def cpu_baseline(n_tx, L, max_l1, F):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nTx", type=int, default=2048)
     ap.add_argument("--nLevels", type=int, default=32)
     ap.add_argument("--maxL1Tx", type=int, default=256)
     ap.add_argument("--maxFeeTx", type=int, default=64)
-    ap.add_argument("--inflight", type=int, default=4, help="independent batches in flight (contexts/streams)")
+    ap.add_argument("--inflight", type=int, default=8, help="independent batches in flight (contexts/streams)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="nTx of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()

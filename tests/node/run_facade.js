@@ -1,0 +1,50 @@
+"use strict";
+// Facade test in the style of the reference suites (test/lib/hash-state.test.js:31-57,
+// test/rollup-main.test.js:65-72 via test/helpers/helpers.js:147-155), on Node's own assert.
+// usage: node run_facade.js <fixture.json> [cpu]
+const assert = require("assert");
+const fs = require("fs");
+const path = require("path");
+const { tester, parseMain, deviceCount } = require(path.join(__dirname, "..", "..", "circuits_amd", "node", "index.js"));
+
+async function main() {
+    const fx = JSON.parse(fs.readFileSync(process.argv[2], "utf8"));
+    const m = parseMain("include \"../src/rollup-main.circom\";\ncomponent main = RollupMain(8, 16, 3, 4);");
+    assert.deepStrictEqual(m.params, { nTx: 8, nLevels: 16, maxL1Tx: 3, maxFeeTx: 4 });
+    assert.throws(() => parseMain("component main = Sha256(3);"), /not part/);
+    if (process.argv[3] === "cpu") {
+        if (deviceCount() > 0) { console.log("gpu present, cpu-only checks skipped"); return; }
+        await assert.rejects(tester("component main = HashState();"), /no usable gfx950 device/);
+        console.log("node facade (cpu): ok");
+        return;
+    }
+    // config 1: hash-state single leaf
+    {
+        const circuit = await tester("component main = HashState();", { reduceConstraints: false });
+        await circuit.loadConstraints();
+        const w = await circuit.calculateWitness(fx.hashState.input, { logTrigger: false, logOutput: false, logSet: false });
+        assert.strictEqual(w[0], 1n);
+        await circuit.assertOut(w, { out: fx.hashState.out });
+    }
+    // rollup-main batch: assertBatch
+    {
+        const p = fx.rollupMain.params;
+        const circuit = await tester(`component main = RollupMain(${p.nTx}, ${p.nLevels}, ${p.maxL1Tx}, ${p.maxFeeTx});`, { reduceConstraints: false });
+        await circuit.loadConstraints();
+        assert.strictEqual(circuit.constraints.length, fx.rollupMain.constraints);
+        const w = await circuit.calculateWitness(fx.rollupMain.input, { logTrigger: false, logOutput: false, logSet: false });
+        await circuit.assertOut(w, { hashGlobalInputs: fx.rollupMain.hashGlobalInputs });
+        assert.strictEqual((await circuit.getSignal(w, "main.rollupTx[0].s4.out")).toString(), fx.rollupMain.input.imStateRoot[0]);
+        // negative: tampered intermediate root must throw "Constraint doesn't match"
+        const bad = JSON.parse(JSON.stringify(fx.rollupMain.input));
+        bad.imStateRoot[1] = (BigInt(bad.imStateRoot[1]) + 1n).toString();
+        await assert.rejects(circuit.calculateWitness(bad, true), /Constraint doesn't match/);
+        // unknown / mis-shaped signals
+        await assert.rejects(circuit.calculateWitness(Object.assign({ nope: 1 }, fx.rollupMain.input), true), /Signal not found/);
+        const missing = Object.assign({}, fx.rollupMain.input);
+        delete missing.oldStateRoot;
+        await assert.rejects(circuit.calculateWitness(missing, true), /Not all inputs have been set/);
+    }
+    console.log("node facade: ok");
+}
+main().catch((e) => { console.error(e); process.exit(1); });
