@@ -426,6 +426,7 @@ class BatchBuilder:
                 inp["imStateRootFee"].append(db.state.root)
         self.input = inp
         self.new_state_root = db.state.root
+        self.new_last_idx = db.last_idx
         self.new_exit_root = exit_tree.root
         self.exit_tree, self.exit_leaves = exit_tree, exit_leaves
         db.exit_trees[self.current_num_batch] = (exit_tree, exit_leaves)
@@ -444,7 +445,7 @@ class BatchBuilder:
 
         def be(v, n):
             bits.extend((v >> (n - 1 - k)) & 1 for k in range(n))
-        be(inp["oldLastIdx"], 48); be(self.db.last_idx, 48); be(inp["oldStateRoot"], 256); be(self.new_state_root, 256); be(self.new_exit_root, 256)
+        be(inp["oldLastIdx"], 48); be(self.new_last_idx, 48); be(inp["oldStateRoot"], 256); be(self.new_state_root, 256); be(self.new_exit_root, 256)
         for i in range(self.maxL1):
             on = inp["onChain"][i] if i < nTx else 0
             if on:

@@ -1,0 +1,56 @@
+"use strict";
+// Extracts the LITERAL test vectors the reference's own suites hold (inputs passed to
+// circuit.calculateWitness and the expectations passed to circuit.assertOut) by running the suite
+// files under recording stand-ins for mocha / circom.tester: nothing is computed, the objects the
+// test code builds are just written down. Run in the build container only:
+//     node tests/golden/extract_reference_kats.js > tests/golden/reference_kats.json
+// Suites used: test/rollup-tx-states.test.js:38-625, test/fee-accumulator.test.js:28-130,
+// test/lib/decode-float.test.js:27-44 (all expectations there are literals; suites whose
+// expectations are computed by @hermeznetwork/commonjs are not usable as known answers).
+const Module = require("module");
+const path = require("path");
+const REF = "/root/reference/test";
+
+const realLog = console.log;
+console.log = (...a) => console.error(...a);   // the suites print constraint counts
+const records = [];
+let currentSuite = "", currentCase = "";
+const tests = [];
+const befores = [];
+global.describe = (name, fn) => { fn.call({ timeout() {} }); };
+global.it = (name, fn) => tests.push([currentSuite, name, fn]);
+global.before = (fn) => befores.push(fn);
+global.after = () => {};
+const clone = (o) => JSON.parse(JSON.stringify(o, (k, v) => (typeof v === "bigint" ? v.toString() : v)));
+const circuit = {
+    constraints: { length: 0 },
+    async loadConstraints() {},
+    async calculateWitness(input) { const w = { id: records.length }; records.push({ suite: currentSuite, case: currentCase, input: clone(input), expected: null }); return w; },
+    async assertOut(w, out) { records[w.id].expected = clone(out); },
+};
+const fsReal = require("fs");
+const fsStub = Object.assign({}, fsReal, { writeFileSync() {}, unlinkSync() {} });
+const stubs = {
+    circom: { tester: async () => circuit },
+    fs: fsStub,
+    // protocol constants the states suite refers to (reference src/rollup-tx-states.circom:131,141)
+    "@hermeznetwork/commonjs": { Constants: { exitIdx: 1, nullIdx: 0, nullEthAddr: "0xffffffffffffffffffffffffffffffffffffffff" } },
+};
+const origLoad = Module._load;
+Module._load = function (request, parent, isMain) {
+    if (Object.prototype.hasOwnProperty.call(stubs, request)) return stubs[request];
+    return origLoad.apply(this, arguments);
+};
+
+async function main() {
+    for (const f of ["rollup-tx-states.test.js", "fee-accumulator.test.js", "lib/decode-float.test.js"]) {
+        currentSuite = f;
+        tests.length = 0; befores.length = 0;
+        require(path.join(REF, f));
+        for (const b of befores) await b.call({ timeout() {} });
+        for (const [s, name, fn] of tests) { currentCase = name; await fn.call({ timeout() {} }); }
+        // the fee-accumulator suite defines 7 vectors but only executes the first (SURVEY App. D.8):
+    }
+    realLog(JSON.stringify({ source: "literal vectors recorded from /root/reference/test (see extract_reference_kats.js)", records }, null, 0));
+}
+main().catch((e) => { console.error(e); process.exit(1); });
