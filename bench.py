@@ -49,6 +49,62 @@ def cpu_baseline(n_tx, L, max_l1, F):
             "sample": "RollupMain(nTx=%d,nLevels=%d,maxL1Tx=%d,maxFeeTx=%d), one batch, %.1f s, single thread" % (n_tx, L, max_l1, F, dt)}
 
 
+def bench_sharded(args, L, bb, inp, rank, world, local, n_l2):
+    """One batch sharded by transaction index over `world` GPUs (circuits_amd/multigpu.py)."""
+    import torch
+    import torch.distributed as dist
+    from circuits_amd.multigpu import ShardedBatch
+    nTx, lv, m1, F = args.nTx, args.nLevels, args.maxL1Tx, args.maxFeeTx
+    c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local)
+    c.set_inputs(inp)
+    stream = torch.cuda.Stream(device=local)
+
+    def alloc(n):
+        return torch.zeros(n, dtype=torch.uint8, device="cuda")
+
+    def all_gather(recv, send):
+        if world == 1:
+            recv.copy_(send)
+            return
+        with torch.cuda.stream(stream):
+            dist.all_gather_into_tensor(recv, send)
+
+    sb = ShardedBatch(c, L, nTx, rank, world, alloc, all_gather)
+    sb.step(stream.cuda_stream)
+    if rank == 0 and not args.no_verify:
+        assert c.get("main.hashGlobalInputs") == bb.get_hash_inputs(), "hashGlobalInputs mismatch"
+    for _ in range(args.warmup):
+        sb.step(stream.cuda_stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sb.step(stream.cuda_stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        value = nTx * args.steps / dt
+        abytes = algorithmic_bytes_per_tx(lv, F) * nTx
+        print(json.dumps({
+            "metric": "rollup-main tx-witnesses/sec (nTx=%d, nLevels=%d)" % (nTx, lv), "value": round(value, 1), "unit": "tx-witnesses/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x9 (254-bit Montgomery Fr, 29-bit limbs, integer)",
+            "data": "synthetic",
+            "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "parallelism": "tx-shard%d" % world,
+                       "collective": "one all_gather of %d B per step" % (sb.slot * world), "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2},
+            "roofline": {"bound": "hbm", "kernel": "whole sharded pass", "achieved": round(abytes / (dt / args.steps) / 1e9, 2), "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": round(abytes / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 5), "traffic": None}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +117,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=8, help="independent batches in flight (contexts/streams)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="nTx of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--shard-tx", action="store_true",
+                    help="BASELINE config 4: shard ONE batch by transaction index over the ranks (one RCCL all_gather of the "
+                         "data-availability records, FeeTx + HashInputs on rank 0); strong scaling. Default: independent batches per rank.")
     args = ap.parse_args()
 
     import torch
@@ -83,6 +142,8 @@ def main():
     bb = B.synthetic_batch(nTx, lv, m1, F, n_accounts=min(nTx, 4096), seed=0x48455A31)
     inp = bb.get_input()
     n_l2 = sum(1 for x in inp["onChain"] if not x)
+    if args.shard_tx:
+        return bench_sharded(args, L, bb, inp, rank, world, local, n_l2)
     inflight = max(1, min(args.inflight, args.steps if args.steps > 0 else 1))
     ctxs, streams = [], []
     for k in range(inflight):
@@ -157,7 +218,7 @@ def main():
             "metric": "rollup-main tx-witnesses/sec (nTx=%d, nLevels=%d)" % (nTx, lv),
             "value": round(value, 1), "unit": "tx-witnesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32x8 (254-bit Montgomery Fr, integer)", "data": "synthetic",
+            "dtype": "u32x9 (254-bit Montgomery Fr, 29-bit limbs, integer)", "data": "synthetic",
             "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "batches_in_flight": inflight,
                        "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
                        "witness_bytes_per_batch": ctxs[0].total() * 32, "single_batch_latency_ms": round(single_ms, 3)},

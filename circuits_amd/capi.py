@@ -57,6 +57,7 @@ EXPORTS = [
     "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_clear_inputs", "hz_input_count", "hz_input_name",
     "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
+    "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
     "hz_poseidon_batch_dev", "hz_shard_range",
 ]
@@ -102,6 +103,12 @@ class Lib:
         c.hz_symbol_get.argtypes = [vp, u64, ctypes.POINTER(hz_symbol)]
         c.hz_symbol_lookup.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(u64)]
         c.hz_constraint_name.restype = ctypes.c_char_p
+        c.hz_ctx_set_shard.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        c.hz_da_record_bytes.argtypes = [vp]
+        c.hz_da_record_bytes.restype = u64
+        c.hz_da_export.argtypes = [vp, vp, vp]
+        c.hz_da_import.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
+        c.hz_witness_enqueue_tail.argtypes = [vp, vp]
         c.hz_ctx_set_profiling.argtypes = [vp, ctypes.c_int32]
         c.hz_profile_count.argtypes = [vp]
         c.hz_profile_get.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(u64), ctypes.POINTER(u64)]
@@ -223,6 +230,22 @@ class Ctx:
         buf = ctypes.create_string_buffer(32 * max(count, 1))
         self.L._check(self.L.c.hz_witness_read_raw(self.h, first, count, buf))
         return buf.raw[:32 * count]
+
+    # -- multi-GPU intra-batch shard
+    def set_shard(self, first, count, tail):
+        self.L._check(self.L.c.hz_ctx_set_shard(self.h, first, count, 1 if tail else 0))
+
+    def da_record_bytes(self):
+        return self.L.c.hz_da_record_bytes(self.h)
+
+    def da_export(self, d_buf, stream=None):
+        self.L._check(self.L.c.hz_da_export(self.h, d_buf, stream))
+
+    def da_import(self, first, count, d_buf, stream=None):
+        self.L._check(self.L.c.hz_da_import(self.h, first, count, d_buf, stream))
+
+    def enqueue_tail(self, stream=None):
+        self.L._check(self.L.c.hz_witness_enqueue_tail(self.h, stream))
 
     def set_profiling(self, on=True):
         self.L._check(self.L.c.hz_ctx_set_profiling(self.h, 1 if on else 0))

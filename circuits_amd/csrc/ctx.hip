@@ -26,6 +26,10 @@ struct hz_ctx {
     std::vector<uint8_t> input_set;
     std::vector<uint8_t> host_stage;
     hipStream_t last_stream = nullptr;
+    // multi-GPU intra-batch shard (RollupMain): this context evaluates transactions [sh_first, sh_first + sh_count);
+    // sh_count = 0 means the whole batch. The fee transactions and HashInputs run only when sh_tail is set.
+    uint32_t sh_first = 0, sh_count = 0;
+    bool sh_tail = true;
     // independent chains of one batch run concurrently: the EdDSA ladders and the fee transactions on
     // their own streams, joined by events before HashInputs (DESIGN.md "Kernel schedule")
     hipStream_t s_ed = nullptr, s_fee = nullptr, s_main = nullptr;   // s_main replaces a NULL caller stream
@@ -287,23 +291,32 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     EddsaArgs ea;
     memset(&ea, 0, sizeof ea);
     ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.inst_is_unit = is_main ? 0 : 1; ea.ed = lo.rtx.ed;
+    const uint32_t u0 = is_main ? c->sh_first : 0, ucnt = is_main ? c->sh_count : 0;
+    ea.u0 = u0; ea.ucnt = ucnt;
     {
         // the signature ladders only need the front step: run them beside the hash/SMT chain
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_front, 0));
         { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed)); }
         HZ_HIP(hipEventRecord(c->ev_ed, c->s_ed));
     }
-    { ProfScope ps(c, s, "hash4", n_units); HZ_HIP(launch_hash4(make_hash4_rtx(base, sc, n_units, lo.rtx), s)); }
+    {
+        Hash4Args h4 = make_hash4_rtx(base, sc, n_units, lo.rtx);
+        h4.u0 = u0; h4.ucnt = ucnt;
+        ProfScope ps(c, s, "hash4", n_units);
+        HZ_HIP(launch_hash4(h4, s));
+    }
     SmtArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 2; sa.inst_is_unit = is_main ? 0 : 1;
     sa.p[0] = make_proc(lo.rtx.p1, sib1, 0);
     sa.p[1] = make_proc(lo.rtx.p2, sib2, 1);
+    sa.u0 = u0; sa.ucnt = ucnt;
     { ProfScope ps(c, s, "smt", n_units); HZ_HIP(launch_smt(sa, s)); }
     RtxBackArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.base = base; ba.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; ba.scratch = sc; ba.err = err; ba.n_units = n_units; ba.L = (uint32_t)lo.p.L;
     ba.is_main = is_main ? 1 : 0;
+    ba.u0 = u0; ba.ucnt = ucnt;
     ba.p[0] = sa.p[0]; ba.p[1] = sa.p[1];
     ba.s3 = lo.rtx.s3; ba.s4 = lo.rtx.s4; ba.s5 = lo.rtx.s5;
     if (is_main) {
@@ -401,16 +414,23 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             fa.tx_base = sec_ptr(c, lo.sec_tx); fa.fee_base = sec_ptr(c, lo.sec_fee); fa.glob_base = sec_ptr(c, lo.sec_glob);
             fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.nTx = (uint32_t)lo.p.nTx; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F;
             fa.g = lo.g; fa.mi = lo.mi; fa.fi = lo.fi; fa.dec = lo.dec; fa.rtx = lo.rtx;
-            HZ_HIP(hipStreamWaitEvent(c->s_fee, c->ev_reset, 0));
-            hz_status st = enqueue_fee(c, fa.fee_base, (uint32_t)lo.p.F, true, c->s_fee);   // independent of the transactions
-            if (st != HZ_OK) return st;
-            HZ_HIP(hipEventRecord(c->ev_fee, c->s_fee));
+            hz_status st = HZ_OK;
+            const bool tail_now = c->sh_tail && c->sh_count == 0;   // sharded contexts run the tail separately (hz_witness_enqueue_tail)
+            if (tail_now) {
+                HZ_HIP(hipStreamWaitEvent(c->s_fee, c->ev_reset, 0));
+                st = enqueue_fee(c, fa.fee_base, (uint32_t)lo.p.F, true, c->s_fee);   // independent of the transactions
+                if (st != HZ_OK) return st;
+                HZ_HIP(hipEventRecord(c->ev_fee, c->s_fee));
+            }
+            fa.u0 = c->sh_first; fa.ucnt = c->sh_count;
             { ProfScope ps(c, s, "front", fa.nTx); HZ_HIP(launch_main_front(fa, s)); }
             HZ_HIP(hipEventRecord(c->ev_front, s));
             st = enqueue_rtx_tail(c, fa.tx_base, fa.nTx, true, lo.mi.siblings1, lo.mi.siblings2, s);
             if (st != HZ_OK) return st;
-            HZ_HIP(hipStreamWaitEvent(s, c->ev_fee, 0));
-            { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s)); }
+            if (tail_now) {
+                HZ_HIP(hipStreamWaitEvent(s, c->ev_fee, 0));
+                { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s)); }
+            }
             break;
         }
         case T_ROLLUP_TX: {
@@ -499,6 +519,56 @@ extern "C" hz_status hz_witness_check(hz_ctx* c, hz_error* out) {
     fill_error(out, hd.minkey, nullptr);
     return set_err(HZ_ERR_CONSTRAINT, "Constraint doesn't match (%s, instance %d unit %d; operands not captured)", constraint_name((int)(hd.minkey & 0xFFFF)),
                    (int)(hd.minkey >> 40), (int)((hd.minkey >> 16) & 0xFFFFFF));
+}
+
+// ---- multi-GPU intra-batch sharding ------------------------------------------------------------------
+extern "C" hz_status hz_ctx_set_shard(hz_ctx* c, int32_t first, int32_t count, int32_t tail) {
+    if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN) return set_err(HZ_ERR_ARG, "hz_ctx_set_shard: RollupMain contexts only");
+    if (first < 0 || count < 0 || first + count > c->lo.p.nTx) return set_err(HZ_ERR_ARG, "hz_ctx_set_shard: bad range");
+    c->sh_first = (uint32_t)first;
+    c->sh_count = (uint32_t)count;
+    c->sh_tail = tail != 0;
+    return HZ_OK;
+}
+extern "C" uint64_t hz_da_record_bytes(const hz_ctx*) { return HZ_DA_RECORD_BYTES; }
+static DaArgs make_da(hz_ctx* c, uint32_t first, uint32_t count, void* buf) {
+    const Layout& lo = c->lo;
+    DaArgs a;
+    memset(&a, 0, sizeof a);
+    a.tx_base = sec_ptr(c, lo.sec_tx); a.tx_scratch = (Fr*)c->sc_tx.p; a.buf = (uint8_t*)buf;
+    a.nTx = (uint32_t)lo.p.nTx; a.L = (uint32_t)lo.p.L; a.u0 = first; a.ucnt = count;
+    a.l1full = lo.dec.l1full; a.n2bData = lo.dec.n2bData; a.n2bFinalToIdx = lo.dec.n2bFinalToIdx; a.l1l2amt = lo.rtx.main_l1l2amt;
+    a.l1l2Fee = lo.dec.l1l2Fee; a.s5 = lo.rtx.s5;
+    return a;
+}
+extern "C" hz_status hz_da_export(hz_ctx* c, void* d_buf, void* stream) {
+    if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN || !d_buf) return set_err(HZ_ERR_ARG, "hz_da_export: bad argument");
+    HZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    const uint32_t cnt = c->sh_count ? c->sh_count : (uint32_t)c->lo.p.nTx;
+    HZ_HIP(launch_da_export(make_da(c, c->sh_first, cnt, d_buf), s));
+    return HZ_OK;
+}
+extern "C" hz_status hz_da_import(hz_ctx* c, int32_t first, int32_t count, const void* d_buf, void* stream) {
+    if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN || !d_buf || first < 0 || count < 0 || first + count > c->lo.p.nTx)
+        return set_err(HZ_ERR_ARG, "hz_da_import: bad argument");
+    HZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    HZ_HIP(launch_da_import(make_da(c, (uint32_t)first, (uint32_t)count, const_cast<void*>(d_buf)), s));
+    return HZ_OK;
+}
+// fee transactions + HashInputs of a sharded context, after the other ranks' records were imported
+extern "C" hz_status hz_witness_enqueue_tail(hz_ctx* c, void* stream) {
+    if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN) return set_err(HZ_ERR_ARG, "hz_witness_enqueue_tail: RollupMain contexts only");
+    HZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    const Layout& lo = c->lo;
+    hz_status st = enqueue_fee(c, sec_ptr(c, lo.sec_fee), (uint32_t)lo.p.F, true, s);
+    if (st != HZ_OK) return st;
+    { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s)); }
+    c->last_stream = s;
+    c->enqueued = true;
+    return HZ_OK;
 }
 
 extern "C" hz_status hz_ctx_set_profiling(hz_ctx* c, int32_t on) {

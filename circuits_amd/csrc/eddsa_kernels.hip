@@ -230,8 +230,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
     Fr* M6 = C6 + poseidon_nconst<6>();
     stage_poseidon_consts<6>(C6);
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_units) return;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
+    const uint32_t i = a.u0 + li;
     EdCtx c;
     c.io = UnitIO{a.base, a.n_units, i, a.inst_is_unit ? i : 0u, a.inst_is_unit ? 0u : i, a.err};
     c.one = fr_one();
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
 }
 
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_eddsa, dim3((a.n_units + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<6>() * sizeof(Fr), s, a);
+    hipLaunchKernelGGL(k_eddsa, dim3(((a.ucnt ? a.ucnt : a.n_units) + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<6>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 

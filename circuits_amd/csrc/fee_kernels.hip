@@ -332,6 +332,51 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
     io.put_c(o.hashGlobalInputs, sha_digest_to_fr(hv));
 }
 
+// ---- multi-GPU shard exchange: per-transaction data-availability records --------------------------------
+// record (HZ_DA_RECORD_BYTES = 160): [0,78) L1TxFullData bits | [78,84) fromIdx bits | [84,90) finalToIdx bits |
+// [90,95) amountF bits (already masked by isAmountNullified) | [95] fee bits | [96,128) decodeTx.outIdx | [128,160) newExitRoot
+__global__ __launch_bounds__(HZ_BLOCK) void k_da_export(const DaArgs a) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= a.ucnt) return;
+    const uint32_t u = a.u0 + li;
+    uint8_t* r = a.buf + (size_t)li * HZ_DA_RECORD_BYTES;
+    auto bit = [&](uint32_t sig) { return load_fr(a.tx_base + ((size_t)sig * a.nTx + u) * 32).v[0] & 1u; };
+    auto pack = [&](uint32_t sig0, uint32_t n, uint8_t* dst, uint32_t nbytes) {
+        for (uint32_t b = 0; b < nbytes; b++) {
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < 8 && 8 * b + k < n; k++) v |= bit(sig0 + 8 * b + k) << k;
+            dst[b] = (uint8_t)v;
+        }
+    };
+    pack(a.l1full, L1FULL_BITS, r, 78);
+    pack(a.n2bData + 48, a.L, r + 78, 6);
+    pack(a.n2bFinalToIdx, a.L, r + 84, 6);
+    pack(a.l1l2amt, 40, r + 90, 5);
+    pack(a.l1l2Fee, 8, r + 95, 1);
+    const Fc outIdx = fr_to_canon(a.tx_scratch[(size_t)SC_OUTIDX * a.nTx + u]);
+    const Fc exitRoot = load_fr(a.tx_base + ((size_t)a.s5 * a.nTx + u) * 32);
+    for (int k = 0; k < 8; k++) { reinterpret_cast<uint32_t*>(r + 96)[k] = outIdx.v[k]; reinterpret_cast<uint32_t*>(r + 128)[k] = exitRoot.v[k]; }
+}
+__global__ __launch_bounds__(HZ_BLOCK) void k_da_import(const DaArgs a) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= a.ucnt) return;
+    const uint32_t u = a.u0 + li;
+    const uint8_t* r = a.buf + (size_t)li * HZ_DA_RECORD_BYTES;
+    const UnitIO io{a.tx_base, a.nTx, u, 0, u, nullptr};
+    auto unpack = [&](uint32_t sig0, uint32_t n, const uint8_t* src) {
+        for (uint32_t k = 0; k < n; k++) io.put_bit(sig0 + k, (src[k >> 3] >> (k & 7)) & 1u);
+    };
+    unpack(a.l1full, L1FULL_BITS, r);
+    unpack(a.n2bData + 48, a.L, r + 78);
+    unpack(a.n2bFinalToIdx, a.L, r + 84);
+    unpack(a.l1l2amt, 40, r + 90);
+    unpack(a.l1l2Fee, 8, r + 95);
+    Fc outIdx, exitRoot;
+    for (int k = 0; k < 8; k++) { outIdx.v[k] = reinterpret_cast<const uint32_t*>(r + 96)[k]; exitRoot.v[k] = reinterpret_cast<const uint32_t*>(r + 128)[k]; }
+    a.tx_scratch[(size_t)SC_OUTIDX * a.nTx + u] = fr_from_canon(outIdx);
+    io.put_c(a.s5, exitRoot);
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 hipError_t launch_fee_front(const FeeFrontArgs& a, hipStream_t s) {
@@ -354,6 +399,14 @@ hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_hi_prep, grid1(1 + a.maxL1 + a.nTx + a.F), dim3(HZ_BLOCK), 0, s, a);
     hipLaunchKernelGGL(k_sha_chain, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_sha_expand, grid1((uint32_t)a.hi.sha.nblocks), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_da_export(const DaArgs& a, hipStream_t s) {
+    if (a.ucnt) hipLaunchKernelGGL(k_da_export, grid1(a.ucnt), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_da_import(const DaArgs& a, hipStream_t s) {
+    if (a.ucnt) hipLaunchKernelGGL(k_da_import, grid1(a.ucnt), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s) {

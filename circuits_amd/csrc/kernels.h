@@ -14,6 +14,7 @@ using namespace hzl;
 #define HZ_MAX_SMT_LEVELS 49
 
 struct MainFrontArgs {
+    uint32_t u0, ucnt;   // unit range evaluated by this launch (multi-GPU shard); ucnt = 0 means all
     uint8_t* tx_base;
     uint8_t* fee_base;
     uint8_t* glob_base;
@@ -56,6 +57,7 @@ struct HashJob {
     uint32_t out_sig;      // signal receiving the hash-state output (~0u = none)
 };
 struct Hash4Args {
+    uint32_t u0, ucnt;   // unit range evaluated by this launch (multi-GPU shard); ucnt = 0 means all
     uint8_t* base;
     Fr* scratch;
     uint32_t n_units, n_jobs;
@@ -70,6 +72,7 @@ struct SmtProcDesc {
 };
 
 struct SmtArgs {
+    uint32_t u0, ucnt;   // unit range evaluated by this launch (multi-GPU shard); ucnt = 0 means all
     uint8_t* base;
     Fr* scratch;
     ErrBuf* err;
@@ -80,6 +83,7 @@ struct SmtArgs {
 };
 
 struct RtxBackArgs {
+    uint32_t u0, ucnt;   // unit range evaluated by this launch (multi-GPU shard); ucnt = 0 means all
     uint8_t* base;
     uint8_t* glob_base;
     Fr* scratch;
@@ -94,6 +98,7 @@ struct RtxBackArgs {
 };
 
 struct EddsaArgs {
+    uint32_t u0, ucnt;   // unit range evaluated by this launch (multi-GPU shard); ucnt = 0 means all
     uint8_t* base;
     Fr* scratch;
     ErrBuf* err;
@@ -162,5 +167,17 @@ hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s);
 hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s);
 hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff& hs, hipStream_t s);
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s);
+
+// data-availability record of one transaction (multi-GPU shard exchange), see ctx.hip hz_da_export
+#define HZ_DA_RECORD_BYTES 160
+struct DaArgs {
+    uint8_t* tx_base;
+    Fr* tx_scratch;
+    uint8_t* buf;          // records of units [u0, u0 + ucnt)
+    uint32_t nTx, L, u0, ucnt;
+    uint32_t l1full, n2bData, n2bFinalToIdx, l1l2amt, l1l2Fee, s5;
+};
+hipError_t launch_da_export(const DaArgs& a, hipStream_t s);
+hipError_t launch_da_import(const DaArgs& a, hipStream_t s);
 
 }  // namespace hz

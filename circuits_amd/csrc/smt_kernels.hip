@@ -23,8 +23,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hash4(const Hash4Args a) {
     stage_poseidon_consts<5>(C5);
     stage_poseidon_consts<4>(C4);
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_units) return;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
+    const uint32_t i = a.u0 + li;
     const HashJob& J = a.job[blockIdx.y];
     const UnitIO io{a.base, a.n_units, i, 0, i, nullptr};
     const Scratch sc{a.scratch, a.n_units, i};
@@ -57,8 +58,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smt(const SmtArgs a) {
     Fr* M3 = C3 + poseidon_nconst<3>();
     stage_poseidon_consts<3>(C3);
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_units) return;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
+    const uint32_t i = a.u0 + li;
     const uint32_t chain = blockIdx.y, pi = chain >> 1;
     const bool new_side = chain & 1;
     const SmtProcDesc& P = a.p[pi];
@@ -195,13 +197,13 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smt(const SmtArgs a) {
 // ---------------------------------------------------------------------------------------------------
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
-    dim3 g = grid1(a.n_units);
+    dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
     g.y = a.n_jobs;
     hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), (size_t)(poseidon_const_frs<5>() + poseidon_const_frs<4>()) * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s) {
-    dim3 g = grid1(a.n_units);
+    dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
     g.y = 2 * a.n_proc;
     hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), (size_t)poseidon_const_frs<3>() * sizeof(Fr), s, a);
     return hipGetLastError();

@@ -46,8 +46,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_main_front(const MainFrontArgs a) 
     Fr* M7 = C7 + poseidon_nconst<7>();
     stage_poseidon_consts<7>(C7);
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.nTx) return;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= (a.ucnt ? a.ucnt : a.nTx)) return;
+    const uint32_t i = a.u0 + li;
     const UnitIO io{a.tx_base, a.nTx, i, 0, i, a.err};
     const Scratch sc{a.scratch, a.nTx, i};
     const MainTxInOff& m = a.mi;
@@ -133,8 +134,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_dec_main(const DecMainArgs a) {
 }
 
 __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_units) return;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
+    const uint32_t i = a.u0 + li;
     const UnitIO io{a.base, a.n_units, i, a.is_main ? 0u : i, a.is_main ? i : 0u, a.err};
     const Scratch sc{a.scratch, a.n_units, i};
     const Fr isExit = sc.get(SC_ISEXIT), oldExitRoot = sc.get(SC_OLDEXITROOT);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_main_front, grid1(a.nTx), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * sizeof(Fr), s, a);
+    hipLaunchKernelGGL(k_main_front, grid1(a.ucnt ? a.ucnt : a.nTx), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
@@ -181,7 +183,7 @@ hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_rtx_back, grid1(a.n_units), dim3(HZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_rtx_back, grid1(a.ucnt ? a.ucnt : a.n_units), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

@@ -146,9 +146,22 @@ const char* hz_constraint_name(int32_t constraint_id);
 hz_status hz_poseidon_batch(int32_t device, int32_t t, size_t n, const uint8_t* in, uint8_t* out, uint8_t* sbox_witness);
 hz_status hz_poseidon_batch_dev(int32_t t, size_t n, const void* d_in, void* d_out, void* d_sbox_witness, void* stream);
 
-/* multi-GPU helper (one process per GPU): the per-rank slice of transactions a rank owns when a
- * RollupMain batch is sharded by transaction index. */
+/* multi-GPU, one process per GPU (reference src/rollup-main.circom:93-99: every DecodeTx / RollupTx is
+ * independent given the im* inputs). A RollupMain batch is sharded by transaction index:
+ *   hz_shard_range      contiguous range of a rank
+ *   hz_ctx_set_shard    this context evaluates only [first, first+count); tail != 0 on the rank that
+ *                       also evaluates the fee transactions and HashInputs
+ *   hz_da_export        pack the shard's per-transaction data-availability records (hz_da_record_bytes
+ *                       each: L1TxFullData / L1L2TxData bits, outIdx, newExitRoot) into a device buffer --
+ *                       the only data HashInputs needs from other ranks (one RCCL all_gather, ~47-330 KB)
+ *   hz_da_import        write received records into this context's witness
+ *   hz_witness_enqueue_tail   FeeTx + HashInputs after the imports; then hz_witness_check */
 void hz_shard_range(int32_t nTx, int32_t world, int32_t rank, int32_t* first, int32_t* count);
+hz_status hz_ctx_set_shard(hz_ctx* ctx, int32_t first, int32_t count, int32_t tail);
+uint64_t hz_da_record_bytes(const hz_ctx* ctx);
+hz_status hz_da_export(hz_ctx* ctx, void* d_buf, void* stream);
+hz_status hz_da_import(hz_ctx* ctx, int32_t first, int32_t count, const void* d_buf, void* stream);
+hz_status hz_witness_enqueue_tail(hz_ctx* ctx, void* stream);
 
 #ifdef __cplusplus
 }
