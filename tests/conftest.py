@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # load torch's bundled ROCm runtime first: a process must not end up with two HIP runtimes
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
