@@ -99,9 +99,8 @@ struct ProfScope {
 
 static uint8_t* sec_ptr(hz_ctx* c, int sec) { return (uint8_t*)c->wit.p + c->lo.sections[sec].base * 32; }
 
-static uint32_t block_units(const Layout& lo, const Section& s, const Block& b) {
-    const uint32_t nu = lo.instanced ? 1u : s.n_units;
-    return (b.max_units >= 0 && !lo.instanced) ? (uint32_t)b.max_units : nu;
+static uint32_t block_units(const Layout&, const Section& s, const Block& b) {
+    return (b.max_units >= 0) ? (uint32_t)b.max_units : s.upi;   // symbols describe one instance
 }
 
 extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
@@ -115,8 +114,6 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     if ((lp.tmpl == T_ROLLUP_MAIN || lp.tmpl == T_HASH_INPUTS) && (lp.nTx < 1 || lp.F < 1 || lp.maxL1 < 0))
         return set_err(HZ_ERR_ARG, "RollupMain/HashInputs need nTx >= 1, maxFeeTx >= 1");
     if (lp.tmpl == T_ROLLUP_TX && lp.F < 1) return set_err(HZ_ERR_ARG, "RollupTx needs maxFeeTx >= 1");
-    if ((lp.tmpl == T_ROLLUP_MAIN || lp.tmpl == T_HASH_INPUTS) && lp.n_inst != 1)
-        return set_err(HZ_ERR_ARG, "RollupMain/HashInputs contexts hold one instance; use one context per batch in flight");
     if (hz_device_count() <= 0) return set_err(HZ_ERR_NODEVICE, "no usable gfx950 device");
     if (p->device < 0 || p->device >= hz_device_count()) return set_err(HZ_ERR_ARG, "bad device ordinal %d", p->device);
     hz_ctx* c = new hz_ctx();
@@ -130,8 +127,8 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     if (e == hipSuccess && lo.sec_tx >= 0) e = c->sc_tx.alloc((size_t)SC_COUNT * lo.sections[lo.sec_tx].n_units * sizeof(Fr));
     if (e == hipSuccess && lo.sec_fee >= 0) e = c->sc_fee.alloc((size_t)SC_COUNT * lo.sections[lo.sec_fee].n_units * sizeof(Fr));
     if (e == hipSuccess && lo.sec_hi >= 0) {
-        e = c->msg.alloc((size_t)lo.hi.sha.nblocks * 64);
-        if (e == hipSuccess) e = c->chain.alloc((size_t)(lo.hi.sha.nblocks + 1) * 32);
+        e = c->msg.alloc((size_t)lo.hi.sha.nblocks * 64 * lo.n_inst);
+        if (e == hipSuccess) e = c->chain.alloc((size_t)(lo.hi.sha.nblocks + 1) * 32 * lo.n_inst);
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_ed, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_fee, hipStreamNonBlocking);
@@ -166,7 +163,7 @@ extern "C" int32_t hz_input_count(const hz_ctx* c) { return c ? (int32_t)c->lo.i
 extern "C" const char* hz_input_name(const hz_ctx* c, int32_t i, uint64_t* flat_len) {
     if (!c || i < 0 || (size_t)i >= c->lo.inputs.size()) return nullptr;
     const InputDesc& d = c->lo.inputs[i];
-    if (flat_len) *flat_len = d.per_instance ? d.inner : (uint64_t)d.inner * d.outer;
+    if (flat_len) *flat_len = (uint64_t)d.inner * d.outer;
     return d.name.c_str();
 }
 extern "C" void hz_clear_inputs(hz_ctx* c) {
@@ -197,41 +194,47 @@ static hz_status set_input_common(hz_ctx* c, int32_t instance, const char* name,
             if (!canon_lt_p(host + 32 * i)) return set_err(HZ_ERR_INPUT, "input %s[%zu] is not a canonical field element (>= r)", name, i);
     uint8_t* dst0 = sec_ptr(c, d->section) + (size_t)d->off * s.n_units * 32;   // element (off, unit 0)
     const size_t pitch = (size_t)s.n_units * 32;
-    uint32_t outer, u0 = 0;
-    if (d->per_instance) {
-        if (instance >= 0) {
-            if ((uint32_t)instance >= s.n_units || count != d->inner)
-                return set_err(HZ_ERR_INPUT, "input %s: expected %u values for instance %d, got %zu", name, d->inner, instance, count);
-            outer = 1;
-            u0 = (uint32_t)instance;
-        } else {
-            if (count != (size_t)d->inner * s.n_units)
-                return set_err(HZ_ERR_INPUT, "input %s: expected %zu values for all instances, got %zu", name, (size_t)d->inner * s.n_units, count);
-            outer = s.n_units;
-        }
+    const uint32_t B = lo.n_inst, outer = d->outer;
+    const size_t per = (size_t)d->inner * outer;
+    uint32_t b0, b1;
+    if (instance >= 0) {
+        if ((uint32_t)instance >= B || count != per)
+            return set_err(HZ_ERR_INPUT, "input %s: expected %zu values for instance %d, got %zu", name, per, instance, count);
+        b0 = (uint32_t)instance; b1 = b0 + 1;
     } else {
-        if (instance != 0) return set_err(HZ_ERR_INPUT, "input %s: instance must be 0", name);
-        if (count != (size_t)d->inner * d->outer)
-            return set_err(HZ_ERR_INPUT, "input %s: expected %zu values, got %zu", name, (size_t)d->inner * d->outer, count);
-        outer = d->outer;
+        if (count != per * B)
+            return set_err(HZ_ERR_INPUT, "input %s: expected %zu values for all %u instances, got %zu", name, per * B, B, count);
+        b0 = 0; b1 = B;
     }
     if (host) {
-        // host transpose [outer][inner] -> [inner][outer], then one (2-D) copy
+        // host transpose [instance][outer][inner] -> [inner][instance][outer], then one 2-D copy per instance
+        // (a single copy when the signal covers every unit of the section)
+        const uint32_t nb = b1 - b0;
         c->host_stage.resize(count * 32);
         uint8_t* st = c->host_stage.data();
-        if (d->inner == 1 || outer == 1) memcpy(st, host, count * 32);
-        else
+        for (uint32_t b = 0; b < nb; b++)
             for (uint32_t u = 0; u < outer; u++)
-                for (uint32_t k = 0; k < d->inner; k++) memcpy(st + ((size_t)k * outer + u) * 32, host + ((size_t)u * d->inner + k) * 32, 32);
-        HZ_HIP(hipMemcpy2D(dst0 + (size_t)u0 * 32, pitch, st, (size_t)outer * 32, (size_t)outer * 32, d->inner, hipMemcpyHostToDevice));
-    } else {
-        if (d->inner == 1 || outer == 1) {
-            HZ_HIP(hipMemcpy2DAsync(dst0 + (size_t)u0 * 32, pitch, dev, (size_t)outer * 32, (size_t)outer * 32, d->inner, hipMemcpyDeviceToDevice, stream));
+                for (uint32_t k = 0; k < d->inner; k++)
+                    memcpy(st + (((size_t)k * nb + b) * outer + u) * 32, host + (((size_t)b * outer + u) * d->inner + k) * 32, 32);
+        if (outer == s.upi) {
+            HZ_HIP(hipMemcpy2D(dst0 + (size_t)b0 * s.upi * 32, pitch, st, (size_t)nb * outer * 32, (size_t)nb * outer * 32, d->inner, hipMemcpyHostToDevice));
         } else {
-            const size_t n = (size_t)outer * d->inner;
-            const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
-            hipLaunchKernelGGL(k_transpose32, dim3(blocks), dim3(256), 0, stream, (const uint4*)dev, (uint4*)(dst0 + (size_t)u0 * 32), outer, d->inner, s.n_units);
-            HZ_HIP(hipGetLastError());
+            for (uint32_t b = 0; b < nb; b++)
+                HZ_HIP(hipMemcpy2D(dst0 + (size_t)(b0 + b) * s.upi * 32, pitch, st + (size_t)b * outer * 32, (size_t)nb * outer * 32, (size_t)outer * 32, d->inner,
+                                   hipMemcpyHostToDevice));
+        }
+    } else {
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint8_t* src = (const uint8_t*)dev + (size_t)(b - b0) * per * 32;
+            uint8_t* dst = dst0 + (size_t)b * s.upi * 32;
+            if (d->inner == 1 || outer == 1) {
+                HZ_HIP(hipMemcpy2DAsync(dst, pitch, src, (size_t)outer * 32, (size_t)outer * 32, d->inner, hipMemcpyDeviceToDevice, stream));
+            } else {
+                const size_t n = (size_t)outer * d->inner;
+                const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+                hipLaunchKernelGGL(k_transpose32, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, outer, d->inner, s.n_units);
+                HZ_HIP(hipGetLastError());
+            }
         }
     }
     c->input_set[d - &lo.inputs[0]] = 1;
@@ -290,7 +293,7 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     ErrBuf* err = (ErrBuf*)c->err.p;
     EddsaArgs ea;
     memset(&ea, 0, sizeof ea);
-    ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.inst_is_unit = is_main ? 0 : 1; ea.ed = lo.rtx.ed;
+    ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.upi = lo.sections[lo.sec_tx].upi; ea.ed = lo.rtx.ed;
     const uint32_t u0 = is_main ? c->sh_first : 0, ucnt = is_main ? c->sh_count : 0;
     ea.u0 = u0; ea.ucnt = ucnt;
     {
@@ -307,7 +310,7 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     }
     SmtArgs sa;
     memset(&sa, 0, sizeof sa);
-    sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 2; sa.inst_is_unit = is_main ? 0 : 1;
+    sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 2; sa.upi = lo.sections[lo.sec_tx].upi;
     sa.p[0] = make_proc(lo.rtx.p1, sib1, 0);
     sa.p[1] = make_proc(lo.rtx.p2, sib2, 1);
     sa.u0 = u0; sa.ucnt = ucnt;
@@ -316,6 +319,7 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     memset(&ba, 0, sizeof ba);
     ba.base = base; ba.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; ba.scratch = sc; ba.err = err; ba.n_units = n_units; ba.L = (uint32_t)lo.p.L;
     ba.is_main = is_main ? 1 : 0;
+    ba.upi = lo.sections[lo.sec_tx].upi; ba.B = lo.n_inst;
     ba.u0 = u0; ba.ucnt = ucnt;
     ba.p[0] = sa.p[0]; ba.p[1] = sa.p[1];
     ba.s3 = lo.rtx.s3; ba.s4 = lo.rtx.s4; ba.s5 = lo.rtx.s5;
@@ -337,6 +341,7 @@ static hz_status enqueue_fee(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is
     FeeFrontArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.base = base; fa.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; fa.scratch = sc; fa.err = err; fa.n_units = n_units; fa.is_main = is_main;
+    fa.upi = lo.sections[lo.sec_fee].upi; fa.B = lo.n_inst;
     fa.fee = lo.fee;
     uint32_t sib;
     if (is_main) {
@@ -360,12 +365,12 @@ static hz_status enqueue_fee(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is
     { ProfScope ps(c, s, "fee_hash", n_units); HZ_HIP(launch_hash4(h, s)); }
     SmtArgs sa;
     memset(&sa, 0, sizeof sa);
-    sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 1; sa.inst_is_unit = is_main ? 0 : 1;
+    sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 1; sa.upi = lo.sections[lo.sec_fee].upi;
     sa.p[0] = make_proc(lo.fee.p, sib, 2);
     { ProfScope ps(c, s, "fee_smt", n_units); HZ_HIP(launch_smt(sa, s)); }
     FeeBackArgs fb;
     memset(&fb, 0, sizeof fb);
-    fb.base = base; fb.scratch = sc; fb.err = err; fb.n_units = n_units; fb.is_main = is_main; fb.p = sa.p[0];
+    fb.base = base; fb.scratch = sc; fb.err = err; fb.n_units = n_units; fb.is_main = is_main; fb.upi = lo.sections[lo.sec_fee].upi; fb.p = sa.p[0];
     fb.im_stateRootFee = is_main ? lo.fi.imStateRootFee : 0; fb.o_newStateRoot = lo.fee.o_newStateRoot;
     { ProfScope ps(c, s, "fee_back", n_units); HZ_HIP(launch_fee_back(fb, s)); }
     return HZ_OK;
@@ -377,7 +382,7 @@ static HashInputsArgs make_hi(hz_ctx* c, bool is_main) {
     memset(&a, 0, sizeof a);
     a.hi_base = sec_ptr(c, lo.sec_hi);
     a.err = (ErrBuf*)c->err.p;
-    a.nTx = (uint32_t)lo.p.nTx; a.L = (uint32_t)lo.p.L; a.maxL1 = (uint32_t)lo.p.maxL1; a.F = (uint32_t)lo.p.F; a.is_main = is_main;
+    a.nTx = (uint32_t)lo.p.nTx; a.L = (uint32_t)lo.p.L; a.maxL1 = (uint32_t)lo.p.maxL1; a.F = (uint32_t)lo.p.F; a.is_main = is_main; a.B = lo.n_inst;
     a.hi = lo.hi;
     a.msg = (uint8_t*)c->msg.p; a.chain = (uint32_t*)c->chain.p;
     if (is_main) {
@@ -412,20 +417,20 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             MainFrontArgs fa;
             memset(&fa, 0, sizeof fa);
             fa.tx_base = sec_ptr(c, lo.sec_tx); fa.fee_base = sec_ptr(c, lo.sec_fee); fa.glob_base = sec_ptr(c, lo.sec_glob);
-            fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.nTx = (uint32_t)lo.p.nTx; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F;
+            fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.nTx = (uint32_t)lo.p.nTx; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F; fa.B = lo.n_inst;
             fa.g = lo.g; fa.mi = lo.mi; fa.fi = lo.fi; fa.dec = lo.dec; fa.rtx = lo.rtx;
             hz_status st = HZ_OK;
             const bool tail_now = c->sh_tail && c->sh_count == 0;   // sharded contexts run the tail separately (hz_witness_enqueue_tail)
             if (tail_now) {
                 HZ_HIP(hipStreamWaitEvent(c->s_fee, c->ev_reset, 0));
-                st = enqueue_fee(c, fa.fee_base, (uint32_t)lo.p.F, true, c->s_fee);   // independent of the transactions
+                st = enqueue_fee(c, fa.fee_base, lo.sections[lo.sec_fee].n_units, true, c->s_fee);   // independent of the transactions
                 if (st != HZ_OK) return st;
                 HZ_HIP(hipEventRecord(c->ev_fee, c->s_fee));
             }
             fa.u0 = c->sh_first; fa.ucnt = c->sh_count;
-            { ProfScope ps(c, s, "front", fa.nTx); HZ_HIP(launch_main_front(fa, s)); }
+            { ProfScope ps(c, s, "front", (uint64_t)fa.nTx * fa.B); HZ_HIP(launch_main_front(fa, s)); }
             HZ_HIP(hipEventRecord(c->ev_front, s));
-            st = enqueue_rtx_tail(c, fa.tx_base, fa.nTx, true, lo.mi.siblings1, lo.mi.siblings2, s);
+            st = enqueue_rtx_tail(c, fa.tx_base, lo.sections[lo.sec_tx].n_units, true, lo.mi.siblings1, lo.mi.siblings2, s);
             if (st != HZ_OK) return st;
             if (tail_now) {
                 HZ_HIP(hipStreamWaitEvent(s, c->ev_fee, 0));
@@ -524,6 +529,7 @@ extern "C" hz_status hz_witness_check(hz_ctx* c, hz_error* out) {
 // ---- multi-GPU intra-batch sharding ------------------------------------------------------------------
 extern "C" hz_status hz_ctx_set_shard(hz_ctx* c, int32_t first, int32_t count, int32_t tail) {
     if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN) return set_err(HZ_ERR_ARG, "hz_ctx_set_shard: RollupMain contexts only");
+    if (c->lo.n_inst != 1) return set_err(HZ_ERR_ARG, "hz_ctx_set_shard: one batch per context when sharding");
     if (first < 0 || count < 0 || first + count > c->lo.p.nTx) return set_err(HZ_ERR_ARG, "hz_ctx_set_shard: bad range");
     c->sh_first = (uint32_t)first;
     c->sh_count = (uint32_t)count;
@@ -563,7 +569,7 @@ extern "C" hz_status hz_witness_enqueue_tail(hz_ctx* c, void* stream) {
     HZ_HIP(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
     const Layout& lo = c->lo;
-    hz_status st = enqueue_fee(c, sec_ptr(c, lo.sec_fee), (uint32_t)lo.p.F, true, s);
+    hz_status st = enqueue_fee(c, sec_ptr(c, lo.sec_fee), lo.sections[lo.sec_fee].n_units, true, s);
     if (st != HZ_OK) return st;
     { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s)); }
     c->last_stream = s;
@@ -596,20 +602,47 @@ extern "C" hz_status hz_witness_run(hz_ctx* c, hz_error* err) {
     return hz_witness_check(c, err);
 }
 
+// gather `count` elements of the per-instance (virtual) witness of instance `inst` into a dense buffer
+struct SecMap { uint64_t vbase, base; uint32_t upi, n_units; };
+struct GatherArgs { const uint4* wit; uint4* out; uint64_t first, count; uint32_t inst, nsec; SecMap sec[4]; };
+__global__ void k_gather_virtual(const GatherArgs a) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.count; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = a.first + t;
+        uint32_t si = a.nsec - 1;
+        while (si > 0 && a.sec[si].vbase > v) si--;
+        const SecMap m = a.sec[si];
+        const uint64_t rel = v - m.vbase;
+        const uint64_t p = m.base + (rel / m.upi) * m.n_units + (uint64_t)a.inst * m.upi + rel % m.upi;
+        a.out[2 * t] = a.wit[2 * p];
+        a.out[2 * t + 1] = a.wit[2 * p + 1];
+    }
+}
+
 extern "C" hz_status hz_witness_read(hz_ctx* c, int32_t instance, uint64_t first, uint64_t count, uint8_t* out) {
     if (!c || !out) return set_err(HZ_ERR_ARG, "hz_witness_read: null argument");
     const Layout& lo = c->lo;
     if (first + count > lo.per_instance) return set_err(HZ_ERR_ARG, "hz_witness_read: range beyond the witness");
+    if (instance < 0 || (uint32_t)instance >= lo.n_inst) return set_err(HZ_ERR_ARG, "hz_witness_read: bad instance");
     HZ_HIP(hipSetDevice(c->device));
     if (count == 0) return HZ_OK;
-    if (lo.instanced) {
-        const uint32_t N = lo.sections[0].n_units;
-        if (instance < 0 || (uint32_t)instance >= N) return set_err(HZ_ERR_ARG, "hz_witness_read: bad instance");
-        const uint8_t* src = (const uint8_t*)c->wit.p + ((size_t)first * N + (uint32_t)instance) * 32;
-        HZ_HIP(hipMemcpy2D(out, 32, src, (size_t)N * 32, 32, count, hipMemcpyDeviceToHost));
-    } else {
-        if (instance != 0) return set_err(HZ_ERR_ARG, "hz_witness_read: bad instance");
+    if (lo.n_inst == 1) {   // virtual == physical
         HZ_HIP(hipMemcpy(out, (const uint8_t*)c->wit.p + first * 32, count * 32, hipMemcpyDeviceToHost));
+        return HZ_OK;
+    }
+    // chunked gather through a staging buffer
+    const uint64_t chunk = std::min<uint64_t>(count, 1u << 22);
+    if (c->stage.bytes < chunk * 32) HZ_HIP(c->stage.alloc(chunk * 32));
+    GatherArgs g;
+    memset(&g, 0, sizeof g);
+    g.wit = (const uint4*)c->wit.p; g.out = (uint4*)c->stage.p; g.inst = (uint32_t)instance; g.nsec = (uint32_t)lo.sections.size();
+    for (size_t i = 0; i < lo.sections.size() && i < 4; i++) g.sec[i] = SecMap{lo.sections[i].vbase, lo.sections[i].base, lo.sections[i].upi, lo.sections[i].n_units};
+    for (uint64_t done = 0; done < count; done += chunk) {
+        g.first = first + done;
+        g.count = std::min<uint64_t>(chunk, count - done);
+        hipLaunchKernelGGL(k_gather_virtual, dim3((unsigned)std::min<uint64_t>((g.count + 255) / 256, 4096)), dim3(256), 0, c->s_main, g);
+        HZ_HIP(hipGetLastError());
+        HZ_HIP(hipMemcpyAsync(out + done * 32, c->stage.p, g.count * 32, hipMemcpyDeviceToHost, c->s_main));
+        HZ_HIP(hipStreamSynchronize(c->s_main));
     }
     return HZ_OK;
 }

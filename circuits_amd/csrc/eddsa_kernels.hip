@@ -234,7 +234,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
     const uint32_t i = a.u0 + li;
     EdCtx c;
-    c.io = UnitIO{a.base, a.n_units, i, a.inst_is_unit ? i : 0u, a.inst_is_unit ? 0u : i, a.err};
+    c.io = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
     c.one = fr_one();
     c.a = fr_from_u64(168700); c.d = fr_from_u64(168696); c.A = fr_from_u64(168698);
     const UnitIO& io = c.io;

@@ -11,7 +11,8 @@ namespace hz {
 __global__ __launch_bounds__(HZ_BLOCK) void k_fee_front(const FeeFrontArgs a) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.n_units) return;
-    const UnitIO io{a.base, a.n_units, j, a.is_main ? 0u : j, a.is_main ? j : 0u, a.err};
+    const uint32_t b = j / a.upi, jj = j % a.upi;   // batch, fee slot inside the batch
+    const UnitIO io{a.base, a.n_units, j, b, jj, a.err};
     const Scratch sc{a.scratch, a.n_units, j};
     const Fr one = fr_one(), zero = fr_zero();
     if (!a.is_main) io.put_u64(0, 1);
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_fee_front(const FeeFrontArgs a) {
     sc.set(SC_P1_FNC0, zero); sc.set(SC_P1_FNC1, fr_sub(one, fz)); sc.set(SC_ISOLD0_1, zero);
     Fr oldRoot;
     if (a.is_main) {
-        oldRoot = j == 0 ? fr_from_canon(load_fr(a.glob_base + (size_t)a.g_initfeeroot * 32)) : io.in_m_u(a.im_stateRootFee, j - 1);
+        oldRoot = jj == 0 ? fr_from_canon(load_fr(a.glob_base + ((size_t)a.g_initfeeroot * a.B + b) * 32)) : io.in_m_u(a.im_stateRootFee, j - 1);
     } else {
         oldRoot = io.in_m(a.in_oldStateRoot);
     }
@@ -41,12 +42,12 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_fee_front(const FeeFrontArgs a) {
 __global__ __launch_bounds__(HZ_BLOCK) void k_fee_back(const FeeBackArgs a) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.n_units) return;
-    const UnitIO io{a.base, a.n_units, j, a.is_main ? 0u : j, a.is_main ? j : 0u, a.err};
+    const UnitIO io{a.base, a.n_units, j, j / a.upi, j % a.upi, a.err};
     const Scratch sc{a.scratch, a.n_units, j};
     const Fr root = smt_top_dev(io, sc, a.p, sc.get(SC_OLDSTATEROOT), C_FEE_P_OLDROOT, C_FEE_P_KEYS);
     sc.set(SC_ROOT_P2NEW, root);  // feeTx.newStateRoot for HashInputs
     if (a.is_main) {
-        if (j + 1 < a.n_units) io.chk(C_MAIN_IM_FEEROOT, root, io.in_m(a.im_stateRootFee));
+        if (j % a.upi + 1 < a.upi) io.chk(C_MAIN_IM_FEEROOT, root, io.in_m(a.im_stateRootFee));
     } else {
         io.put_m(a.o_newStateRoot, root);
     }
@@ -80,23 +81,25 @@ __device__ __forceinline__ void msg_put_be(uint32_t* msgw, uint64_t pos, const F
 }
 
 __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t L = a.L, nTx = a.nTx, maxL1 = a.maxL1, Fn = a.F;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t L = a.L, nTx = a.nTx, maxL1 = a.maxL1, Fn = a.F, B = a.B;
     const uint32_t n_items = 1 + maxL1 + nTx + Fn;
-    if (t >= n_items) return;
-    uint32_t* msgw = reinterpret_cast<uint32_t*>(a.msg);
+    if (gt >= n_items * B) return;
+    const uint32_t bt = gt / n_items, t = gt % n_items;   // batch, item
+    const uint32_t txU = B * nTx, feeU = B * Fn, tx0 = bt * nTx, fee0 = bt * Fn;
+    uint32_t* msgw = reinterpret_cast<uint32_t*>(a.msg) + (size_t)bt * a.hi.sha.nblocks * 16;
     const HashInputsOff& o = a.hi;
     const uint64_t offL1 = 2 * 48 + 3 * 256, offL2 = offL1 + (uint64_t)maxL1 * L1FULL_BITS, offFee = offL2 + (uint64_t)nTx * (2 * L + 48);
     const uint64_t offTail = offFee + (uint64_t)Fn * L;
-    const UnitIO hio{a.hi_base, 1, 0, 0, 0, a.err};
+    const UnitIO hio{a.hi_base, B, bt, bt, 0, a.err};
     if (t == 0) {
         Fc oldLastIdx, newLastIdx, oldStateRoot, newStateRoot, newExitRoot, chainID, batch;
         if (a.is_main) {
-            auto glob = [&](uint32_t sig) { return load_fr(a.glob_base + (size_t)sig * 32); };
+            auto glob = [&](uint32_t sig) { return load_fr(a.glob_base + ((size_t)sig * B + bt) * 32); };
             oldLastIdx = glob(a.g.oldLastIdx); oldStateRoot = glob(a.g.oldStateRoot); chainID = glob(a.g.globalChainID); batch = glob(a.g.currentNumBatch);
-            newLastIdx = fr_to_canon(a.tx_scratch[(size_t)SC_OUTIDX * nTx + (nTx - 1)]);
-            newStateRoot = fr_to_canon(a.fee_scratch[(size_t)SC_ROOT_P2NEW * Fn + (Fn - 1)]);
-            newExitRoot = load_fr(a.tx_base + ((size_t)a.rtx_s5 * nTx + (nTx - 1)) * 32);
+            newLastIdx = fr_to_canon(a.tx_scratch[(size_t)SC_OUTIDX * txU + tx0 + (nTx - 1)]);
+            newStateRoot = fr_to_canon(a.fee_scratch[(size_t)SC_ROOT_P2NEW * feeU + fee0 + (Fn - 1)]);
+            newExitRoot = load_fr(a.tx_base + ((size_t)a.rtx_s5 * txU + tx0 + (nTx - 1)) * 32);
         } else {
             hio.put_u64(o.one, 1);
             oldLastIdx = hio.in_c(o.i_oldLastIdx); newLastIdx = hio.in_c(o.i_newLastIdx); oldStateRoot = hio.in_c(o.i_oldStateRoot);
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
             num2bits_dev(hio, off, v, 48, C_HI_N2B);
             uint32_t pad = 0;
             for (uint32_t i = L; i < 48; i++) pad += c_bit(v, i);
-            if (pad) report_fail(hio.err, 0, 0, C_HI_PAD, fr_from_u64(pad), fr_zero());
+            if (pad) report_fail(hio.err, bt, 0, C_HI_PAD, fr_from_u64(pad), fr_zero());
         };
         idx48(o.n2bOldLastIdx, oldLastIdx);
         idx48(o.n2bNewLastIdx, newLastIdx);
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
     if (u < maxL1) {   // L1TxsFullData slot u: the stored products are bit*onChain
         for (uint32_t k = 0; k < L1FULL_BITS; k++) {
             uint32_t bit;
-            if (a.is_main) bit = (u < nTx) ? (load_fr(a.tx_base + ((size_t)(a.dec.l1full + k) * nTx + u) * 32).v[0] & 1u) : 0u;
+            if (a.is_main) bit = (u < nTx) ? (load_fr(a.tx_base + ((size_t)(a.dec.l1full + k) * txU + tx0 + u) * 32).v[0] & 1u) : 0u;
             else bit = hio.in_c(o.i_L1TxsFullData + u * L1FULL_BITS + k).v[0] & 1u;
             msg_set_bit(msgw, offL1 + (uint64_t)u * L1FULL_BITS + k, bit);
         }
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
     if (u < nTx) {
         const uint64_t pos = offL2 + (uint64_t)u * (2 * L + 48);
         if (a.is_main) {
-            auto txs = [&](uint32_t sig) { return load_fr(a.tx_base + ((size_t)sig * nTx + u) * 32).v[0] & 1u; };
+            auto txs = [&](uint32_t sig) { return load_fr(a.tx_base + ((size_t)sig * txU + tx0 + u) * 32).v[0] & 1u; };
             for (uint32_t k = 0; k < L; k++) msg_set_bit(msgw, pos + (L - 1 - k), txs(a.dec.n2bData + 48 + k));
             for (uint32_t k = 0; k < L; k++) msg_set_bit(msgw, pos + (2 * L - 1 - k), txs(a.dec.n2bFinalToIdx + k));
             for (uint32_t k = 0; k < 40; k++) msg_set_bit(msgw, pos + 2 * L + k, txs(a.rtx_main_l1l2amt + k));
@@ -152,33 +155,35 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
     }
     u -= nTx;
     {
-        const Fc v = a.is_main ? load_fr(a.fee_base + ((size_t)a.fi_feeIdxs * Fn + u) * 32) : hio.in_c(o.i_feeTxsData + u);
+        const Fc v = a.is_main ? load_fr(a.fee_base + ((size_t)a.fi_feeIdxs * feeU + fee0 + u) * 32) : hio.in_c(o.i_feeTxsData + u);
         num2bits_dev(hio, o.n2bFee + 48 * u, v, 48, C_HI_N2B);
         uint32_t pad = 0;
         for (uint32_t i = L; i < 48; i++) pad += c_bit(v, i);
-        if (pad) report_fail(hio.err, 0, 0, C_HI_PAD, fr_from_u64(pad), fr_zero());
+        if (pad) report_fail(hio.err, bt, 0, C_HI_PAD, fr_from_u64(pad), fr_zero());
         msg_put_be(msgw, offFee + (uint64_t)u * L, v, (int)L);
     }
 }
 
 // sequential chaining values: chain[b] = state before block b; then the digest -> output signal
 __global__ void k_sha_chain(const HashInputsArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg);
+    const uint32_t bt = blockIdx.x * blockDim.x + threadIdx.x;   // one lane per batch: the chains of different batches are independent
+    if (bt >= a.B) return;
+    const int nb = a.hi.sha.nblocks;
+    const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg) + (size_t)bt * nb * 16;
+    uint32_t* chain = a.chain + (size_t)bt * (nb + 1) * 8;
     uint32_t hv[8];
     for (int i = 0; i < 8; i++) hv[i] = SHA_H0[i];
-    const int nb = a.hi.sha.nblocks;
     for (int b = 0; b < nb; b++) {
-        for (int i = 0; i < 8; i++) a.chain[8 * b + i] = hv[i];
+        for (int i = 0; i < 8; i++) chain[8 * b + i] = hv[i];
         uint32_t w16[16];
         for (int i = 0; i < 16; i++) w16[i] = msgw[16 * b + i];
         sha256_compress(hv, w16);
     }
     const Fc out = sha_digest_to_fr(hv);
-    if (a.is_main) store_fr(a.glob_base + (size_t)a.g.hashGlobalInputs * 32, out);
-    else store_fr(a.hi_base + (size_t)a.hi.out * 32, out);
+    if (a.is_main) store_fr(a.glob_base + ((size_t)a.g.hashGlobalInputs * a.B + bt) * 32, out);
+    else store_fr(a.hi_base + ((size_t)a.hi.out * a.B + bt) * 32, out);
     if (a.is_main) {
-        uint4* q = reinterpret_cast<uint4*>(a.glob_base + (size_t)a.g.one * 32);
+        uint4* q = reinterpret_cast<uint4*>(a.glob_base + ((size_t)a.g.one * a.B + bt) * 32);
         q[0] = make_uint4(1u, 0u, 0u, 0u);
         q[1] = make_uint4(0u, 0u, 0u, 0u);
     }
@@ -186,12 +191,14 @@ __global__ void k_sha_chain(const HashInputsArgs a) {
 
 // per-block bit-level witness: one lane per block
 __global__ __launch_bounds__(HZ_BLOCK) void k_sha_expand(const HashInputsArgs a) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= (uint32_t)a.hi.sha.nblocks) return;
-    const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg);
-    const UnitIO hio{a.hi_base, 1, 0, 0, 0, a.err};
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nb = (uint32_t)a.hi.sha.nblocks;
+    if (gt >= nb * a.B) return;
+    const uint32_t bt = gt % a.B, b = gt / a.B;   // consecutive lanes = consecutive batches: coalesced stores
+    const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg) + (size_t)bt * nb * 16;
+    const UnitIO hio{a.hi_base, a.B, bt, bt, 0, a.err};
     uint32_t hv[8], w16[16];
-    for (int i = 0; i < 8; i++) hv[i] = a.chain[8 * b + i];
+    for (int i = 0; i < 8; i++) hv[i] = a.chain[((size_t)bt * (nb + 1) + b) * 8 + i];
     for (int i = 0; i < 16; i++) w16[i] = msgw[16 * b + i];
     sha256_block_witness(hio, a.hi.sha.blocks + b * a.hi.sha.block_size, hv, w16);
 }
@@ -393,12 +400,12 @@ hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff&
     return hipGetLastError();
 }
 hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s) {
-    const size_t msg_bytes = (size_t)a.hi.sha.nblocks * 64;
+    const size_t msg_bytes = (size_t)a.hi.sha.nblocks * 64 * a.B;
     hipError_t e = hipMemsetAsync(a.msg, 0, msg_bytes, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_hi_prep, grid1(1 + a.maxL1 + a.nTx + a.F), dim3(HZ_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(k_sha_chain, dim3(1), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_sha_expand, grid1((uint32_t)a.hi.sha.nblocks), dim3(HZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_hi_prep, grid1((1 + a.maxL1 + a.nTx + a.F) * a.B), dim3(HZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_sha_chain, grid1(a.B), dim3(HZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_sha_expand, grid1((uint32_t)a.hi.sha.nblocks * a.B), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_da_export(const DaArgs& a, hipStream_t s) {

@@ -20,7 +20,7 @@ struct MainFrontArgs {
     uint8_t* glob_base;
     Fr* scratch;
     ErrBuf* err;
-    uint32_t nTx, L, F;
+    uint32_t nTx, L, F, B;   // B = batches (instances) evaluated by this launch; units = B * nTx
     MainGlobOff g;
     MainTxInOff mi;
     MainFeeInOff fi;
@@ -78,7 +78,7 @@ struct SmtArgs {
     ErrBuf* err;
     uint32_t n_units, n_levels;   // n_levels = L + 1
     uint32_t n_proc;
-    uint32_t inst_is_unit;
+    uint32_t upi;
     SmtProcDesc p[2];
 };
 
@@ -88,7 +88,7 @@ struct RtxBackArgs {
     uint8_t* glob_base;
     Fr* scratch;
     ErrBuf* err;
-    uint32_t n_units, L, is_main;
+    uint32_t n_units, L, is_main, upi, B;
     SmtProcDesc p[2];
     uint32_t s3, s4, s5;
     // main: integrity checks + data-availability masking
@@ -102,7 +102,7 @@ struct EddsaArgs {
     uint8_t* base;
     Fr* scratch;
     ErrBuf* err;
-    uint32_t n_units, inst_is_unit;
+    uint32_t n_units, upi;
     EddsaOff ed;
 };
 
@@ -113,7 +113,7 @@ struct FeeFrontArgs {
     uint8_t* glob_base;
     Fr* scratch;
     ErrBuf* err;
-    uint32_t n_units, is_main;
+    uint32_t n_units, is_main, upi, B;
     FeeTxOff fee;
     // input offsets (MainFeeInOff names for main, FeeTxInOff for standalone)
     uint32_t in_feePlanToken, in_feeIdx, in_accFee, in_tokenID, in_nonce, in_sign, in_balance, in_ay, in_ethAddr, in_oldStateRoot;
@@ -123,7 +123,7 @@ struct FeeBackArgs {
     uint8_t* base;
     Fr* scratch;
     ErrBuf* err;
-    uint32_t n_units, is_main;
+    uint32_t n_units, is_main, upi;
     SmtProcDesc p;
     uint32_t im_stateRootFee, o_newStateRoot;
 };
@@ -136,7 +136,7 @@ struct HashInputsArgs {
     Fr* tx_scratch;
     Fr* fee_scratch;
     ErrBuf* err;
-    uint32_t nTx, L, maxL1, F, is_main;
+    uint32_t nTx, L, maxL1, F, is_main, B;
     HashInputsOff hi;
     MainGlobOff g;
     uint32_t mi_onChain, fi_feeIdxs;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smt(const SmtArgs a) {
     const SmtProcDesc& P = a.p[pi];
     const SmtProcOff& o = P.o;
     const int n = (int)a.n_levels;
-    const UnitIO io{a.base, a.n_units, i, a.inst_is_unit ? i : 0u, a.inst_is_unit ? 0u : i, a.err};
+    const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
     const Scratch sc{a.scratch, a.n_units, i};
     const Fr one = fr_one(), zero = fr_zero();
     const Fr fnc0 = sc.get(P.sc_fnc0), fnc1 = sc.get(P.sc_fnc1), isOld0 = sc.get(P.sc_isold0);

@@ -18,17 +18,18 @@ namespace hz {
 struct FeeSrcMain {
     const UnitIO* io;         // tx section
     const uint8_t* fee_base;  // fee section base
-    uint32_t n_fee;           // F
+    uint32_t n_fee_units;     // B * F
+    uint32_t fee0;            // b * F: first fee unit of this batch
     uint32_t plan_off;        // fi.feePlanTokens
     uint32_t final_off;       // fi.imFinalAccFee
     uint32_t im_off;          // mi.imAccFeeOut
-    uint32_t nTx;
-    __device__ __forceinline__ Fr plan(int j) const { return fr_from_canon(load_fr(fee_base + ((size_t)plan_off * n_fee + j) * 32)); }
-    __device__ __forceinline__ Fr acc(int j) const { return io->unit == 0 ? fr_zero() : io->in_m_u(im_off + j, io->unit - 1); }
+    uint32_t nTx, i;          // transactions per batch, index inside the batch
+    __device__ __forceinline__ Fr plan(int j) const { return fr_from_canon(load_fr(fee_base + ((size_t)plan_off * n_fee_units + fee0 + j) * 32)); }
+    __device__ __forceinline__ Fr acc(int j) const { return i == 0 ? fr_zero() : io->in_m_u(im_off + j, io->unit - 1); }
     __device__ __forceinline__ void out(const UnitIO& w, int j, const Fr& v) const {
         // phase E / G of RollupMain (src/rollup-main.circom:386-388,429-431)
-        if (w.unit + 1 < nTx) w.chk(C_MAIN_IM_ACCFEE, v, w.in_m(im_off + j));
-        else w.chk(C_MAIN_IM_FINALACCFEE, v, fr_from_canon(load_fr(fee_base + ((size_t)final_off * n_fee + j) * 32)));
+        if (i + 1 < nTx) w.chk(C_MAIN_IM_ACCFEE, v, w.in_m(im_off + j));
+        else w.chk(C_MAIN_IM_FINALACCFEE, v, fr_from_canon(load_fr(fee_base + ((size_t)final_off * n_fee_units + fee0 + j) * 32)));
     }
 };
 struct FeeSrcRtx {
@@ -47,12 +48,14 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_main_front(const MainFrontArgs a) 
     stage_poseidon_consts<7>(C7);
     __syncthreads();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= (a.ucnt ? a.ucnt : a.nTx)) return;
-    const uint32_t i = a.u0 + li;
-    const UnitIO io{a.tx_base, a.nTx, i, 0, i, a.err};
-    const Scratch sc{a.scratch, a.nTx, i};
+    const uint32_t n_units = a.B * a.nTx;
+    if (li >= (a.ucnt ? a.ucnt : n_units)) return;
+    const uint32_t u = a.u0 + li;                 // global unit = batch * nTx + transaction
+    const uint32_t b = u / a.nTx, i = u % a.nTx;
+    const UnitIO io{a.tx_base, n_units, u, b, i, a.err};
+    const Scratch sc{a.scratch, n_units, u};
     const MainTxInOff& m = a.mi;
-    auto glob = [&](uint32_t sig) { return fr_from_canon(load_fr(a.glob_base + (size_t)sig * 32)); };
+    auto glob = [&](uint32_t sig) { return fr_from_canon(load_fr(a.glob_base + ((size_t)sig * a.B + b) * 32)); };
     const Fr one = fr_one();
     // A (src/rollup-main.circom:207-219)
     auto bool_chk = [&](int cid, const Fr& v) { io.chk_zero(cid, fr_mul(v, fr_sub(v, one))); };
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_main_front(const MainFrontArgs a) 
     bool_chk(C_MAIN_ISOLD0_1_BOOL, io.in_m(m.isOld0_1));
     bool_chk(C_MAIN_ISOLD0_2_BOOL, io.in_m(m.isOld0_2));
     // B
-    const Fr previousOnChain = i == 0 ? one : io.in_m_u(m.imOnChain, i - 1);
-    const Fr inIdx = i == 0 ? glob(a.g.oldLastIdx) : io.in_m_u(m.imOutIdx, i - 1);
+    const Fr previousOnChain = i == 0 ? one : io.in_m_u(m.imOnChain, u - 1);
+    const Fr inIdx = i == 0 ? glob(a.g.oldLastIdx) : io.in_m_u(m.imOutIdx, u - 1);
     const DecResult d = decode_tx_dev(io, a.dec, m, (int)a.L, previousOnChain, inIdx, glob(a.g.globalChainID), glob(a.g.currentNumBatch), C7, M7);
     // C (:258-265)
     io.chk(C_MAIN_IM_V2, d.v2, io.in_m(m.txCompressedDataV2));
@@ -82,21 +85,21 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_main_front(const MainFrontArgs a) 
     RtxExt x;
     x.fromIdx = d.fromIdx; x.toIdx = d.toIdx; x.toBjjSign = d.toBjjSign; x.amount = d.amount; x.tokenID = d.tokenID; x.nonce = d.nonce;
     x.userFee = d.userFee; x.sigL2Hash = d.sigL2Hash;
-    x.oldStateRoot = i == 0 ? glob(a.g.oldStateRoot) : io.in_m_u(m.imStateRoot, i - 1);
-    x.oldExitRoot = i == 0 ? fr_zero() : io.in_m_u(m.imExitRoot, i - 1);
+    x.oldStateRoot = i == 0 ? glob(a.g.oldStateRoot) : io.in_m_u(m.imStateRoot, u - 1);
+    x.oldExitRoot = i == 0 ? fr_zero() : io.in_m_u(m.imExitRoot, u - 1);
     for (int j = 0; j < 3; j++) {
         const bool ok = i + j + 1 < a.nTx;
-        x.futV2[j] = ok ? io.in_m_u(m.txCompressedDataV2, i + j + 1) : fr_zero();
-        x.futEth[j] = ok ? io.in_m_u(m.toEthAddr, i + j + 1) : fr_zero();
-        x.futAy[j] = ok ? io.in_m_u(m.toBjjAy, i + j + 1) : fr_zero();
+        x.futV2[j] = ok ? io.in_m_u(m.txCompressedDataV2, u + j + 1) : fr_zero();
+        x.futEth[j] = ok ? io.in_m_u(m.toEthAddr, u + j + 1) : fr_zero();
+        x.futAy[j] = ok ? io.in_m_u(m.toBjjAy, u + j + 1) : fr_zero();
     }
     for (int j = 0; j < 4; j++) {
         const bool ok = (int)i - j - 1 >= 0;
-        x.pastV2[j] = ok ? io.in_m_u(m.txCompressedDataV2, i - j - 1) : fr_zero();
-        x.pastEth[j] = ok ? io.in_m_u(m.toEthAddr, i - j - 1) : fr_zero();
-        x.pastAy[j] = ok ? io.in_m_u(m.toBjjAy, i - j - 1) : fr_zero();
+        x.pastV2[j] = ok ? io.in_m_u(m.txCompressedDataV2, u - j - 1) : fr_zero();
+        x.pastEth[j] = ok ? io.in_m_u(m.toEthAddr, u - j - 1) : fr_zero();
+        x.pastAy[j] = ok ? io.in_m_u(m.toBjjAy, u - j - 1) : fr_zero();
     }
-    const FeeSrcMain fs{&io, a.fee_base, a.F, a.fi.feePlanTokens, a.fi.imFinalAccFee, m.imAccFeeOut, a.nTx};
+    const FeeSrcMain fs{&io, a.fee_base, a.B * a.F, b * a.F, a.fi.feePlanTokens, a.fi.imFinalAccFee, m.imAccFeeOut, a.nTx, i};
     rollup_tx_front_dev(io, sc, a.rtx, m, x, (int)a.F, fs);
 }
 
@@ -136,9 +139,10 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_dec_main(const DecMainArgs a) {
 __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
-    const uint32_t i = a.u0 + li;
-    const UnitIO io{a.base, a.n_units, i, a.is_main ? 0u : i, a.is_main ? i : 0u, a.err};
-    const Scratch sc{a.scratch, a.n_units, i};
+    const uint32_t u = a.u0 + li;
+    const uint32_t b = u / a.upi, i = u % a.upi;
+    const UnitIO io{a.base, a.n_units, u, b, i, a.err};
+    const Scratch sc{a.scratch, a.n_units, u};
     const Fr isExit = sc.get(SC_ISEXIT), oldExitRoot = sc.get(SC_OLDEXITROOT);
     const Fr p1root = smt_top_dev(io, sc, a.p[0], sc.get(SC_OLDSTATEROOT), C_RTX_P1_OLDROOT, C_RTX_P1_KEYS);
     const Fr s3 = mux1_dev(p1root, oldExitRoot, isExit);
@@ -148,11 +152,11 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
     io.put_m(a.s4, newStateRoot); io.put_m(a.s5, newExitRoot);
     if (a.is_main) {
         // E / G (src/rollup-main.circom:383-389,427)
-        if (i + 1 < a.n_units) {
+        if (i + 1 < a.upi) {
             io.chk(C_MAIN_IM_STATEROOT, newStateRoot, io.in_m(a.im_stateroot));
             io.chk(C_MAIN_IM_EXITROOT, newExitRoot, io.in_m(a.im_exitroot));
         } else {
-            io.chk(C_MAIN_IM_INITFEEROOT, newStateRoot, fr_from_canon(load_fr(a.glob_base + (size_t)a.g_initfeeroot * 32)));
+            io.chk(C_MAIN_IM_INITFEEROOT, newStateRoot, fr_from_canon(load_fr(a.glob_base + ((size_t)a.g_initfeeroot * a.B + b) * 32)));
         }
         // H (:456-459): amountF bits of L1L2TxData times (1 - isAmountNullified)
         const Fc keep_c = fr_to_canon(fr_sub(fr_one(), sc.get(SC_ISAMTNULL)));
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_main_front, grid1(a.ucnt ? a.ucnt : a.nTx), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * sizeof(Fr), s, a);
+    hipLaunchKernelGGL(k_main_front, grid1(a.ucnt ? a.ucnt : a.B * a.nTx), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {

@@ -432,14 +432,15 @@ struct InputDesc {
     int section = 0;
     uint32_t off = 0;   // signal offset of element [.][0]
     uint32_t inner = 1; // elements per unit
-    uint32_t outer = 1; // number of units that carry it (nTx, nTx-1, maxFeeTx, 1, n_instances)
-    bool per_instance = false;  // outer index is the instance (standalone templates)
+    uint32_t outer = 1; // units per instance that carry it (nTx, nTx-1, maxFeeTx, 1)
 };
 
 struct Section {
     std::string tag;
-    uint64_t base = 0;      // first element in the flat witness
-    uint32_t n_units = 1;
+    uint64_t base = 0;      // first element in the physical buffer
+    uint64_t vbase = 0;     // first element in the per-instance (virtual) witness
+    uint32_t upi = 1;       // units per instance (transactions, fee slots, 1)
+    uint32_t n_units = 1;   // upi * n_instances: unit index = instance * upi + local unit
     uint32_t n_sigs = 0;
     std::vector<Block> blocks;
 
@@ -524,7 +525,7 @@ struct Layout {
     std::vector<std::pair<std::string, uint64_t>> outputs;  // main outputs: name, virtual index (first element)
     uint64_t total = 0;        // elements in the physical buffer
     uint64_t per_instance = 0; // virtual witness length of one instance
-    bool instanced = false;    // standalone template evaluated for n_inst instances (units = instances)
+    uint32_t n_inst = 1;       // instances evaluated together (independent batches / witnesses)
 
     // offsets
     MainGlobOff g{};
@@ -541,7 +542,7 @@ struct Layout {
     WithdrawOff wd{};
     int sec_tx = -1, sec_fee = -1, sec_glob = -1, sec_hi = -1;  // section indices
 
-    // physical index of (section, sig, unit)
+    // physical index of (section, sig, global unit = instance * upi + local unit)
     uint64_t phys(int sec, uint32_t sig, uint32_t unit) const {
         const Section& s = sections[sec];
         return s.base + (uint64_t)sig * s.n_units + unit;
@@ -552,9 +553,9 @@ struct Layout {
     void for_each_symbol(Fn f, bool expand_poseidon = true) const {
         for (size_t si = 0; si < sections.size(); si++) {
             const Section& s = sections[si];
-            const uint32_t nu = instanced ? 1 : s.n_units;  // instanced: names do not carry the instance
+            const uint32_t nu = s.upi;  // names describe ONE instance; the instance is not part of a name
             for (const Block& b : s.blocks) {
-                const uint32_t units = (b.max_units >= 0 && !instanced) ? (uint32_t)b.max_units : nu;
+                const uint32_t units = (b.max_units >= 0) ? (uint32_t)b.max_units : nu;
                 for (uint32_t u = 0; u < units; u++) {
                     const std::string base = ssub(b.name, "{u}", istr(u));
                     if (b.kind == BK_POSEIDON) {
@@ -569,15 +570,18 @@ struct Layout {
             }
         }
     }
-    // virtual (per-instance) index of (section, sig, unit)
+    // virtual (per-instance) index of (section, sig, local unit)
     uint64_t virt(int sec, uint32_t sig, uint32_t unit) const {
-        if (instanced) return sig;  // single section, unit == instance
-        return phys(sec, sig, unit);
+        const Section& s = sections[sec];
+        return s.vbase + (uint64_t)sig * s.upi + unit;
     }
     // physical index of virtual index v of instance inst
     uint64_t virt_to_phys(uint64_t v, uint32_t inst) const {
-        if (instanced) return v * sections[0].n_units + inst;
-        return v;
+        size_t si = sections.size() - 1;
+        while (si > 0 && sections[si].vbase > v) si--;
+        const Section& s = sections[si];
+        const uint64_t rel = v - s.vbase;
+        return s.base + (rel / s.upi) * s.n_units + (uint64_t)inst * s.upi + rel % s.upi;
     }
 
     // name -> virtual index. Accepts names with or without "main.".
@@ -618,7 +622,7 @@ struct Layout {
             if (it == index_.end()) continue;
             const Section& s = sections[it->second.first];
             const Block& b = s.blocks[it->second.second];
-            const uint32_t units = (b.max_units >= 0 && !instanced) ? (uint32_t)b.max_units : (instanced ? 1u : s.n_units);
+            const uint32_t units = (b.max_units >= 0) ? (uint32_t)b.max_units : s.upi;
             if (unit < 0 || (uint64_t)unit >= units) return false;
             if (b.kind == BK_POSEIDON) {
                 if (suffix.empty() || has_k) return false;
@@ -995,9 +999,9 @@ inline void lay_hashinputs(Section& s, const std::string& pre, int L, int nTx, i
     o.sha.blocks = s.add(pre + "inputsHasher.sha256compression", (uint32_t)((uint64_t)o.sha.nblocks * SHA_BLOCK_SIGS));
 }
 
-inline void add_input(Layout& lo, const std::string& name, int sec, uint32_t off, uint32_t inner, uint32_t outer, bool per_instance) {
+inline void add_input(Layout& lo, const std::string& name, int sec, uint32_t off, uint32_t inner, uint32_t outer, bool /*unused*/) {
     InputDesc d;
-    d.name = name; d.section = sec; d.off = off; d.inner = inner; d.outer = outer; d.per_instance = per_instance;
+    d.name = name; d.section = sec; d.off = off; d.inner = inner; d.outer = outer;
     lo.inputs.push_back(d);
 }
 
@@ -1006,16 +1010,18 @@ inline void build_layout(const Params& p, Layout& lo) {
     lo.p = p;
     const int L = p.L, F = p.F, nTx = p.nTx;
     const uint32_t N = (uint32_t)(p.n_inst > 0 ? p.n_inst : 1);
+    lo.n_inst = N;
+    // perinst = the signal is a scalar/array of the main component itself (no per-unit index in its name)
     auto in1 = [&](Section& s, int sec, const std::string& nm, uint32_t cnt, uint32_t outer, int32_t maxu, bool perinst) {
         uint32_t o = s.add("main." + nm + (perinst ? "" : "[{u}]"), cnt, maxu);
-        add_input(lo, nm, sec, o, cnt, outer, perinst);
+        add_input(lo, nm, sec, o, cnt, perinst ? 1u : outer, perinst);
         return o;
     };
     switch (p.tmpl) {
         case T_ROLLUP_MAIN: {
             lo.sections.resize(4);
             lo.sec_glob = 0; lo.sec_tx = 1; lo.sec_fee = 2; lo.sec_hi = 3;
-            Section& G = lo.sections[0]; G.tag = "global"; G.n_units = 1;
+            Section& G = lo.sections[0]; G.tag = "global"; G.upi = 1;
             lo.g.one = G.add("main.one");
             lo.g.hashGlobalInputs = G.add("main.hashGlobalInputs");
             lo.outputs.push_back({"hashGlobalInputs", 0});
@@ -1023,7 +1029,7 @@ inline void build_layout(const Params& p, Layout& lo) {
             lo.g.oldLastIdx = gin("oldLastIdx"); lo.g.oldStateRoot = gin("oldStateRoot");
             lo.g.globalChainID = gin("globalChainID"); lo.g.currentNumBatch = gin("currentNumBatch");
             lo.g.imInitStateRootFee = gin("imInitStateRootFee");
-            Section& T = lo.sections[1]; T.tag = "tx"; T.n_units = (uint32_t)nTx;
+            Section& T = lo.sections[1]; T.tag = "tx"; T.upi = (uint32_t)nTx;
             MainTxInOff& m = lo.mi;
             const int32_t nm1 = nTx - 1;
             m.imOnChain = in1(T, 1, "imOnChain", 1, nm1, nm1, false);
@@ -1046,7 +1052,7 @@ inline void build_layout(const Params& p, Layout& lo) {
             lay_decode(T, "main.decodeTx[{u}].", L, false, lo.dec);
             lay_rtx(T, "main.rollupTx[{u}].", L, F, true, lo.rtx);
             lo.rtx.main_l1l2amt = T.add("main.hasherInputs.L1L2TxsData.amountF[{u}]", 40);
-            Section& Fs = lo.sections[2]; Fs.tag = "fee"; Fs.n_units = (uint32_t)F;
+            Section& Fs = lo.sections[2]; Fs.tag = "fee"; Fs.upi = (uint32_t)F;
             MainFeeInOff& f = lo.fi;
             f.feeIdxs = in1(Fs, 2, "feeIdxs", 1, F, -1, false);
             f.feePlanTokens = in1(Fs, 2, "feePlanTokens", 1, F, -1, false);
@@ -1057,15 +1063,14 @@ inline void build_layout(const Params& p, Layout& lo) {
             f.ay3 = in1(Fs, 2, "ay3", 1, F, -1, false); f.ethAddr3 = in1(Fs, 2, "ethAddr3", 1, F, -1, false);
             f.siblings3 = in1(Fs, 2, "siblings3", L + 1, F, -1, false);
             lay_feetx(Fs, "main.feeTx[{u}].", L, lo.fee);
-            Section& H = lo.sections[3]; H.tag = "hashinputs"; H.n_units = 1;
+            Section& H = lo.sections[3]; H.tag = "hashinputs"; H.upi = 1;
             lay_hashinputs(H, "main.hasherInputs.", L, nTx, p.maxL1, F, false, lo.hi);
             break;
         }
         case T_ROLLUP_TX: {
-            lo.instanced = true;
             lo.sections.resize(1);
             lo.sec_tx = 0;
-            Section& T = lo.sections[0]; T.tag = "rollup-tx"; T.n_units = N;
+            Section& T = lo.sections[0]; T.tag = "rollup-tx"; T.upi = 1;
             RtxInOff& r = lo.rtxi;
             T.add("main.one");
             r.o_isAmountNullified = T.add("main.isAmountNullified");
@@ -1094,10 +1099,9 @@ inline void build_layout(const Params& p, Layout& lo) {
             break;
         }
         case T_DECODE_TX: {
-            lo.instanced = true;
             lo.sections.resize(1);
             lo.sec_tx = 0;
-            Section& T = lo.sections[0]; T.tag = "decode-tx"; T.n_units = N;
+            Section& T = lo.sections[0]; T.tag = "decode-tx"; T.upi = 1;
             T.add("main.one");
             DecInOff& d = lo.deci;
 #define HZL_DIN(f, cnt) d.f = in1(T, 0, #f, cnt, N, -1, true)
@@ -1115,10 +1119,9 @@ inline void build_layout(const Params& p, Layout& lo) {
             break;
         }
         case T_FEE_TX: {
-            lo.instanced = true;
             lo.sections.resize(1);
             lo.sec_fee = 0;
-            Section& T = lo.sections[0]; T.tag = "fee-tx"; T.n_units = N;
+            Section& T = lo.sections[0]; T.tag = "fee-tx"; T.upi = 1;
             T.add("main.one");
             lo.fee.o_newStateRoot = 0;
             uint32_t o_root = T.add("main.newStateRoot");
@@ -1133,9 +1136,8 @@ inline void build_layout(const Params& p, Layout& lo) {
             break;
         }
         case T_HASH_STATE: {
-            lo.instanced = true;
             lo.sections.resize(1);
-            Section& T = lo.sections[0]; T.tag = "hash-state"; T.n_units = N;
+            Section& T = lo.sections[0]; T.tag = "hash-state"; T.upi = 1;
             HashStateOff& h = lo.hs;
             h.one = T.add("main.one");
             h.out = T.add("main.out");
@@ -1147,9 +1149,8 @@ inline void build_layout(const Params& p, Layout& lo) {
             break;
         }
         case T_WITHDRAW: {
-            lo.instanced = true;
             lo.sections.resize(1);
-            Section& T = lo.sections[0]; T.tag = "withdraw"; T.n_units = N;
+            Section& T = lo.sections[0]; T.tag = "withdraw"; T.upi = 1;
             WithdrawOff& w = lo.wd;
             w.one = T.add("main.one");
             w.hashGlobalInputs = T.add("main.hashGlobalInputs");
@@ -1171,7 +1172,7 @@ inline void build_layout(const Params& p, Layout& lo) {
         case T_HASH_INPUTS: {
             lo.sections.resize(1);
             lo.sec_hi = 0;
-            Section& H = lo.sections[0]; H.tag = "hashinputs"; H.n_units = 1;
+            Section& H = lo.sections[0]; H.tag = "hashinputs"; H.upi = 1;
             lay_hashinputs(H, "main.", L, nTx, p.maxL1, F, true, lo.hi);
             HashInputsOff& o = lo.hi;
             add_input(lo, "oldLastIdx", 0, o.i_oldLastIdx, 1, 1, false); add_input(lo, "newLastIdx", 0, o.i_newLastIdx, 1, 1, false);
@@ -1185,13 +1186,16 @@ inline void build_layout(const Params& p, Layout& lo) {
             break;
         }
     }
-    uint64_t base = 0;
+    uint64_t base = 0, vbase = 0;
     for (Section& s : lo.sections) {
+        s.n_units = s.upi * N;
         s.base = base;
+        s.vbase = vbase;
         base += s.size();
+        vbase += (uint64_t)s.n_sigs * s.upi;
     }
     lo.total = base;
-    lo.per_instance = lo.instanced ? lo.sections[0].n_sigs : base;
+    lo.per_instance = vbase;
 }
 
 // closed-form constraint estimate of the reference (tools/circuit-constraints.js:31-75)

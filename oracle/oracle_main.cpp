@@ -45,42 +45,34 @@ extern "C" int orc_set_input(void* h, int instance, const char* name, const uint
     const InputDesc* d = c->lo.find_input(name);
     if (!d) return 4;
     const Section& s = c->lo.sections[d->section];
+    const uint32_t B = c->lo.n_inst;
     for (size_t i = 0; i < count; i++)
         if (!lt_p(v + 32 * i)) return 4;
-    if (d->per_instance) {
-        if (instance >= 0) {
-            if (count != d->inner || (uint32_t)instance >= s.n_units) return 4;
-            for (uint32_t k = 0; k < d->inner; k++) {
-                const uint64_t p = c->lo.phys(d->section, d->off + k, (uint32_t)instance);
-                c->vals[p] = F::from_bytes(v + 32 * k);
-                c->written[p] = 1;
-            }
-        } else {
-            if (count != (size_t)d->inner * s.n_units) return 4;
-            for (uint32_t u = 0; u < s.n_units; u++)
-                for (uint32_t k = 0; k < d->inner; k++) {
-                    const uint64_t p = c->lo.phys(d->section, d->off + k, u);
-                    c->vals[p] = F::from_bytes(v + 32 * ((size_t)u * d->inner + k));
-                    c->written[p] = 1;
-                }
-        }
+    const size_t per = (size_t)d->inner * d->outer;
+    uint32_t b0, b1;
+    if (instance >= 0) {
+        if ((uint32_t)instance >= B || count != per) return 4;
+        b0 = (uint32_t)instance; b1 = b0 + 1;
     } else {
-        if (instance != 0 || count != (size_t)d->inner * d->outer) return 4;
+        if (count != per * B) return 4;
+        b0 = 0; b1 = B;
+    }
+    for (uint32_t b = b0; b < b1; b++)
         for (uint32_t u = 0; u < d->outer; u++)
             for (uint32_t k = 0; k < d->inner; k++) {
-                const uint64_t p = c->lo.phys(d->section, d->off + k, u);
-                c->vals[p] = F::from_bytes(v + 32 * ((size_t)u * d->inner + k));
+                const uint64_t p = c->lo.phys(d->section, d->off + k, b * s.upi + u);
+                c->vals[p] = F::from_bytes(v + 32 * (((size_t)(b - b0) * d->outer + u) * d->inner + k));
                 c->written[p] = 1;
             }
-    }
     c->input_set[d - &c->lo.inputs[0]] = 1;
     return 0;
 }
 
-static void run_rollup_main(OrcCtx* c) {
+static void run_rollup_main(OrcCtx* c, uint32_t b) {
     const Layout& lo = c->lo;
     const int L = lo.p.L, Fn = lo.p.F, nTx = lo.p.nTx, maxL1 = lo.p.maxL1;
-    W g{&lo, &c->vals, &c->written, &c->fail, lo.sec_glob, 0, 0, 0};
+    const uint32_t tx0 = b * (uint32_t)lo.p.nTx, fee0 = b * (uint32_t)lo.p.F;
+    W g{&lo, &c->vals, &c->written, &c->fail, lo.sec_glob, b, b, 0};
     g.set(lo.g.one, F(1));
     const MainTxInOff& m = lo.mi;
     std::vector<DecOut> dec(nTx);
@@ -89,9 +81,9 @@ static void run_rollup_main(OrcCtx* c) {
     hin.L1L2TxsData.resize((size_t)nTx * (2 * L + 48));
     hin.L1TxsFullData.resize((size_t)maxL1 * hzl::L1FULL_BITS);
     for (int i = 0; i < nTx; i++) {
-        W w{&lo, &c->vals, &c->written, &c->fail, lo.sec_tx, (uint32_t)i, 0, i};
+        W w{&lo, &c->vals, &c->written, &c->fail, lo.sec_tx, tx0 + (uint32_t)i, b, i};
         auto in = [&](uint32_t off) { return w.get(off); };
-        auto inu = [&](uint32_t off, int u) { return w.get_unit(off, (uint32_t)u); };
+        auto inu = [&](uint32_t off, int u) { return w.get_unit(off, tx0 + (uint32_t)u); };
         // A (:207-219)
         if (i < nTx - 1) w.chk(C_MAIN_IMONCHAIN_BOOL, in(m.imOnChain) * (in(m.imOnChain) - F(1)), F(0));
         w.chk(C_MAIN_ONCHAIN_BOOL, in(m.onChain) * (in(m.onChain) - F(1)), F(0));
@@ -121,9 +113,9 @@ static void run_rollup_main(OrcCtx* c) {
         // D (:269-379)
         RtxIn ri;
         ri.feePlanTokens.resize(Fn); ri.accFeeIn.resize(Fn);
-        W fw{&lo, &c->vals, nullptr, &c->fail, lo.sec_fee, 0, 0, 0};
+        W fw{&lo, &c->vals, nullptr, &c->fail, lo.sec_fee, fee0, b, 0};
         for (int j = 0; j < Fn; j++) {
-            ri.feePlanTokens[j] = fw.get_unit(lo.fi.feePlanTokens, (uint32_t)j);
+            ri.feePlanTokens[j] = fw.get_unit(lo.fi.feePlanTokens, fee0 + (uint32_t)j);
             ri.accFeeIn[j] = i == 0 ? F(0) : inu(m.imAccFeeOut + j, i - 1);
         }
         for (int j = 0; j < 3; j++) {
@@ -162,7 +154,7 @@ static void run_rollup_main(OrcCtx* c) {
         } else {
             // G (:427-431)
             w.chk(C_MAIN_IM_INITFEEROOT, rtx[i].newStateRoot, g.get(lo.g.imInitStateRootFee));
-            for (int j = 0; j < Fn; j++) w.chk(C_MAIN_IM_FINALACCFEE, rtx[i].accFeeOut[j], fw.get_unit(lo.fi.imFinalAccFee, (uint32_t)j));
+            for (int j = 0; j < Fn; j++) w.chk(C_MAIN_IM_FINALACCFEE, rtx[i].accFeeOut[j], fw.get_unit(lo.fi.imFinalAccFee, fee0 + (uint32_t)j));
         }
         // H, data availability (:443-464)
         const int W2 = 2 * L + 48;
@@ -181,10 +173,10 @@ static void run_rollup_main(OrcCtx* c) {
     F feeRoot(0);
     hin.feeTxsData.resize(Fn);
     for (int j = 0; j < Fn; j++) {
-        W w{&lo, &c->vals, &c->written, &c->fail, lo.sec_fee, (uint32_t)j, 0, j};
+        W w{&lo, &c->vals, &c->written, &c->fail, lo.sec_fee, fee0 + (uint32_t)j, b, j};
         const MainFeeInOff& f = lo.fi;
         FeeIn fi;
-        fi.oldStateRoot = j == 0 ? g.get(lo.g.imInitStateRootFee) : w.get_unit(f.imStateRootFee, (uint32_t)(j - 1));
+        fi.oldStateRoot = j == 0 ? g.get(lo.g.imInitStateRootFee) : w.get_unit(f.imStateRootFee, fee0 + (uint32_t)(j - 1));
         fi.feePlanToken = w.get(f.feePlanTokens); fi.feeIdx = w.get(f.feeIdxs); fi.accFee = w.get(f.imFinalAccFee);
         fi.tokenID = w.get(f.tokenID3); fi.nonce = w.get(f.nonce3); fi.sign = w.get(f.sign3); fi.balance = w.get(f.balance3);
         fi.ay = w.get(f.ay3); fi.ethAddr = w.get(f.ethAddr3);
@@ -198,7 +190,7 @@ static void run_rollup_main(OrcCtx* c) {
     hin.oldLastIdx = g.get(lo.g.oldLastIdx); hin.newLastIdx = dec[nTx - 1].outIdx; hin.oldStateRoot = g.get(lo.g.oldStateRoot);
     hin.newStateRoot = feeRoot; hin.newExitRoot = rtx[nTx - 1].newExitRoot;
     hin.globalChainID = g.get(lo.g.globalChainID); hin.currentNumBatch = g.get(lo.g.currentNumBatch);
-    W hw{&lo, &c->vals, &c->written, &c->fail, lo.sec_hi, 0, 0, 0};
+    W hw{&lo, &c->vals, &c->written, &c->fail, lo.sec_hi, b, b, 0};
     const F h = hash_inputs(hw, lo.hi, L, nTx, maxL1, Fn, hin);
     g.set(lo.g.hashGlobalInputs, h);
 }
@@ -283,7 +275,9 @@ extern "C" int orc_run(void* h, int32_t* err_inst, int32_t* err_unit, int32_t* e
     for (size_t i = 0; i < c->input_set.size(); i++)
         if (!c->input_set[i]) return 4;
     c->fail = Fail();
-    if (c->lo.p.tmpl == T_ROLLUP_MAIN) run_rollup_main(c);
+    if (c->lo.p.tmpl == T_ROLLUP_MAIN) {
+        for (uint32_t b = 0; b < c->lo.n_inst; b++) run_rollup_main(c, b);
+    }
     else if (c->lo.p.tmpl == T_HASH_INPUTS) {
         const Layout& lo = c->lo;
         W w{&lo, &c->vals, &c->written, &c->fail, 0, 0, 0, 0};
@@ -328,9 +322,8 @@ extern "C" uint64_t orc_unwritten(void* h, char* name_out, size_t cap) {
     bool have = false;
     c->lo.for_each_symbol([&](const std::string& nm, int sec, uint32_t sig, uint32_t unit) {
         const Section& s = c->lo.sections[sec];
-        const uint32_t units = c->lo.instanced ? s.n_units : 1;
-        for (uint32_t u = 0; u < units; u++) {
-            const uint64_t p = c->lo.phys(sec, sig, c->lo.instanced ? u : unit);
+        for (uint32_t u = 0; u < c->lo.n_inst; u++) {
+            const uint64_t p = c->lo.phys(sec, sig, u * s.upi + unit);
             if (!c->written[p]) {
                 n++;
                 if (!have && name_out) { snprintf(name_out, cap, "%s", nm.c_str()); have = true; }

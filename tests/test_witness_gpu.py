@@ -144,3 +144,34 @@ def test_input_errors(hz, batch):
         g.set_input("siblings1", [0] * 5)
     with pytest.raises(HzError):
         g.set_input("nope", [0])
+
+
+def test_rollup_main_two_batches_per_launch_bit_exact(hz):
+    """n_instances = 2: two different batches evaluated by the same kernel launches (unit = batch * nTx + tx)."""
+    from circuits_amd import builder as B
+    from circuits_amd import ConstraintError
+    b0 = B.synthetic_batch(8, 16, 3, 4, n_accounts=6, exits=2)
+    b1 = B.synthetic_batch(8, 16, 3, 4, n_accounts=7, exits=1, seed=99)
+    g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4, n_instances=2)
+    o = OracleCtx("rollup-main", 8, 16, 3, 4, n_instances=2)
+    for k, bb in enumerate((b0, b1)):
+        g.set_inputs(bb.get_input(), instance=k)
+        o.set_inputs(bb.get_input(), instance=k)
+    g.run()
+    assert o.run() is None
+    assert g.witness_len() == o.witness_len() and g.total() == 2 * g.witness_len()
+    for k, bb in enumerate((b0, b1)):
+        assert g.get("main.hashGlobalInputs", k) == bb.get_hash_inputs()
+        idx = g.lookup("main.rollupTx[5].processor2.levels[3].newProofHash.h.sigmaP[7].out")
+        assert g.read(idx, 3, k) == o.read(idx, 3, k)
+    _compare(g, o)
+    # a failure in the second batch is reported with instance = 1
+    bad = dict(b1.get_input())
+    bad["imExitRoot"] = list(bad["imExitRoot"])
+    bad["imExitRoot"][4] = (bad["imExitRoot"][4] + 1) % P
+    g.set_inputs(bad, instance=1)
+    o.set_inputs(bad, instance=1)
+    r = o.run()
+    with pytest.raises(ConstraintError) as e:
+        g.run()
+    assert (e.value.instance, e.value.unit, e.value.constraint_id) == (1, r[1], r[2]) and r[0] == 1
