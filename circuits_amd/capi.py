@@ -54,7 +54,7 @@ TEMPLATES = {"rollup-main": 0, "rollup-tx": 1, "decode-tx": 2, "fee-tx": 3, "has
 # every symbol include/hermez_witness.h declares; tests check the .so exports all of them
 EXPORTS = [
     "hz_version", "hz_last_error", "hz_device_count", "hz_ctx_create", "hz_ctx_destroy", "hz_witness_len",
-    "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_clear_inputs", "hz_input_count", "hz_input_name",
+    "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_copy_instance_inputs", "hz_clear_inputs", "hz_input_count", "hz_input_name",
     "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
@@ -88,6 +88,7 @@ class Lib:
             getattr(c, f).restype = u64
         c.hz_set_input.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
         c.hz_set_input_dev.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p, vp, ctypes.c_size_t, vp]
+        c.hz_copy_instance_inputs.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp]
         c.hz_clear_inputs.argtypes = [vp]
         c.hz_clear_inputs.restype = None
         c.hz_input_count.argtypes = [vp]
@@ -199,6 +200,10 @@ class Ctx:
     def set_inputs(self, d, instance=0):
         for k, v in d.items():
             self.set_input(k, v, instance)
+
+    def copy_instance_inputs(self, src, dst, stream=None):
+        """Replicate the inputs of instance `src` onto instance `dst` on the device."""
+        self.L._check(self.L.c.hz_copy_instance_inputs(self.h, src, dst, stream))
 
     def clear_inputs(self):
         self.L.c.hz_clear_inputs(self.h)

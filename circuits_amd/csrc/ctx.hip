@@ -248,6 +248,25 @@ extern "C" hz_status hz_set_input_dev(hz_ctx* c, int32_t instance, const char* n
     return set_input_common(c, instance, name, nullptr, dvals, count, (hipStream_t)stream);
 }
 
+// Copy every input signal of instance `src` onto instance `dst` (device to device). Serving code that
+// proves the same batch shape repeatedly, and the benchmark, fill instance 0 once and replicate.
+extern "C" hz_status hz_copy_instance_inputs(hz_ctx* c, int32_t src, int32_t dst, void* stream) {
+    if (!c) return set_err(HZ_ERR_ARG, "hz_copy_instance_inputs: null context");
+    const Layout& lo = c->lo;
+    if (src < 0 || dst < 0 || (uint32_t)src >= lo.n_inst || (uint32_t)dst >= lo.n_inst)
+        return set_err(HZ_ERR_ARG, "hz_copy_instance_inputs: instance out of range (n_instances = %u)", lo.n_inst);
+    if (src == dst) return HZ_OK;
+    HZ_HIP(hipSetDevice(c->device));
+    for (const InputDesc& d : lo.inputs) {
+        const Section& s = lo.sections[d.section];
+        uint8_t* base = sec_ptr(c, d.section) + (size_t)d.off * s.n_units * 32;
+        const size_t pitch = (size_t)s.n_units * 32;
+        HZ_HIP(hipMemcpy2DAsync(base + (size_t)dst * s.upi * 32, pitch, base + (size_t)src * s.upi * 32, pitch, (size_t)d.outer * 32, d.inner,
+                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return HZ_OK;
+}
+
 // ---- kernel schedule ---------------------------------------------------------------------------------
 static SmtProcDesc make_proc(const SmtProcOff& o, uint32_t siblings, int which /*0: p1, 1: p2, 2: fee*/) {
     SmtProcDesc d;

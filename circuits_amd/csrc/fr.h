@@ -214,7 +214,68 @@ HZ_HD_HEAVY Fr fr_mul(HZ_HEAVY_ARG(Fr) a, HZ_HEAVY_ARG(Fr) b) {
     r.v[8] = (uint32_t)t[17];
     return r;
 }
-HZ_HD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
+// shared tail of the product routines: Montgomery-reduce the 17 column sums t[0..16] (t[17] = 0)
+HZ_HD Fr fr_reduce_cols(uint64_t* t) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t m = ((uint32_t)t[i] * HZ_INV29) & HZ_M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[i + j] += (uint64_t)m * fr_p29(j);
+        t[i + 1] += t[i] >> 29;
+    }
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        r.v[k] = (uint32_t)t[9 + k] & HZ_M29;
+        t[10 + k] += t[9 + k] >> 29;
+    }
+    r.v[8] = (uint32_t)t[17];
+    return r;
+}
+// a^2 / R: 36 doubled cross products + 9 squares instead of 81 products
+HZ_HD_HEAVY Fr fr_sqr(HZ_HEAVY_ARG(Fr) a) {
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;   // < 2^30
+    uint64_t t[18];
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 8 || i > j) continue;
+            acc += (i == j) ? (uint64_t)a.v[i] * a.v[i] : (uint64_t)d[i] * a.v[j];
+        }
+        t[k] = acc;
+    }
+    t[17] = 0;
+    return fr_reduce_cols(t);
+}
+// sum_{n<N} a[n]*b[n] / R with ONE Montgomery reduction (N <= 6: 9N+9 terms of < 2^58 fit 64 bits).
+// The MDS mix of Poseidon is t such dot products per round.
+template <int N>
+HZ_HD Fr fr_dot(const Fr* a, const Fr* b) {
+    static_assert(N >= 1 && N <= 6, "fr_dot: at most 6 products per reduction");
+    uint64_t t[18];
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int j = k - i;
+                if (j < 0 || j > 8) continue;
+                acc += (uint64_t)a[n].v[i] * b[n].v[j];
+            }
+        }
+        t[k] = acc;
+    }
+    t[17] = 0;
+    return fr_reduce_cols(t);
+}
+
 
 // canonical -> Montgomery (also accepts any 256-bit integer)
 HZ_HD Fr fr_unpack(const Fc& c) {

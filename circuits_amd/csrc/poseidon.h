@@ -44,15 +44,18 @@ HZ_HD Fr poseidon_sbox(const Fr& x, int k, Sink& sink) {
     return x5;
 }
 
+// Mix: out[i] = sum_j M[i][j] * st[j], one lazily reduced dot product per output (rows of more than
+// 6 terms are split in two)
 template <int T>
 HZ_HD void poseidon_mix(Fr (&st)[T], const Fr* M) {
     Fr o[T];
 #pragma unroll
     for (int i = 0; i < T; i++) {
-        Fr acc = fr_mul(M[i * T + 0], st[0]);
-#pragma unroll
-        for (int j = 1; j < T; j++) acc = fr_add(acc, fr_mul(M[i * T + j], st[j]));
-        o[i] = acc;
+        if constexpr (T <= 6) {
+            o[i] = fr_dot<T>(M + i * T, st);
+        } else {
+            o[i] = fr_add(fr_dot<4>(M + i * T, st), fr_dot<T - 4>(M + i * T + 4, st + 4));
+        }
     }
 #pragma unroll
     for (int i = 0; i < T; i++) st[i] = o[i];

@@ -106,6 +106,9 @@ hz_status hz_set_input(hz_ctx* ctx, int32_t instance, const char* name, const ui
 /* same, but `vals` already lives in device memory of ctx's device */
 hz_status hz_set_input_dev(hz_ctx* ctx, int32_t instance, const char* name, const void* dvals, size_t count, void* stream);
 /* forget which inputs were set (values are kept; calculateWitness semantics need a fresh set) */
+/* Replicate all input signals of instance `src` onto instance `dst`, device to device, on `stream`.
+ * (No reference counterpart: snarkjs computes one witness per call; this fills a multi-instance context.) */
+hz_status hz_copy_instance_inputs(hz_ctx* ctx, int32_t src, int32_t dst, void* stream);
 void hz_clear_inputs(hz_ctx* ctx);
 /* enumerate the input signals the template expects */
 int32_t hz_input_count(const hz_ctx* ctx);

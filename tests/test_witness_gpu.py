@@ -175,3 +175,20 @@ def test_rollup_main_two_batches_per_launch_bit_exact(hz):
     with pytest.raises(ConstraintError) as e:
         g.run()
     assert (e.value.instance, e.value.unit, e.value.constraint_id) == (1, r[1], r[2]) and r[0] == 1
+
+
+def test_copy_instance_inputs_replicates_on_device(hz):
+    """hz_copy_instance_inputs: instance 1 filled device-to-device from instance 0 yields the same witness."""
+    from circuits_amd import builder as B
+    bb = B.synthetic_batch(8, 16, 3, 4, n_accounts=6, exits=2)
+    g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4, n_instances=3)
+    g.set_inputs(bb.get_input(), instance=0)
+    g.copy_instance_inputs(0, 1)
+    g.copy_instance_inputs(0, 2)
+    g.run()
+    n = g.witness_len()
+    w0 = g.read(0, n, 0)
+    assert g.read(0, n, 1) == w0 and g.read(0, n, 2) == w0
+    assert g.get("main.hashGlobalInputs", 2) == bb.get_hash_inputs()
+    with pytest.raises(Exception):
+        g.copy_instance_inputs(0, 3)
