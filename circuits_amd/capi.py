@@ -7,7 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libhermez_witness.so")
+    # HZ_WITNESS_LIB: alternative build of the same library (kernel tuning experiments)
+    return os.environ.get("HZ_WITNESS_LIB") or os.path.join(_HERE, "libhermez_witness.so")
 
 
 class HzError(RuntimeError):
@@ -252,8 +253,8 @@ class Ctx:
     def enqueue_tail(self, stream=None):
         self.L._check(self.L.c.hz_witness_enqueue_tail(self.h, stream))
 
-    def set_profiling(self, on=True):
-        self.L._check(self.L.c.hz_ctx_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, on=True, exclusive=False):
+        self.L._check(self.L.c.hz_ctx_set_profiling(self.h, (2 if exclusive else 1) if on else 0))
 
     def profile(self):
         """[(kernel, ms, algorithmic_bytes, units)] of the last enqueue (after check())."""

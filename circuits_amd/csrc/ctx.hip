@@ -32,6 +32,7 @@ struct hz_ctx {
     bool sh_tail = true;
     // independent chains of one batch run concurrently: the EdDSA ladders and the fee transactions on
     // their own streams, joined by events before HashInputs (DESIGN.md "Kernel schedule")
+    bool exclusive = false;   // hz_ctx_set_profiling(ctx, 2)
     hipStream_t s_ed = nullptr, s_fee = nullptr, s_main = nullptr;   // s_main replaces a NULL caller stream
     hipEvent_t ev_reset = nullptr, ev_front = nullptr, ev_ed = nullptr, ev_fee = nullptr;
     ~hz_ctx() {
@@ -421,6 +422,12 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
     // the legacy default stream has implicit-synchronisation semantics that do not mix with the
     // context's non-blocking side streams: a NULL stream means "the context's own stream"
     hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    // profiling mode 2: every kernel alone on the device (the side streams alias the launch stream)
+    struct StreamAlias {
+        hz_ctx* c; hipStream_t ed, fee;
+        StreamAlias(hz_ctx* c_, hipStream_t s_) : c(c_), ed(c_->s_ed), fee(c_->s_fee) { if (c->exclusive) c->s_ed = c->s_fee = s_; }
+        ~StreamAlias() { c->s_ed = ed; c->s_fee = fee; }
+    } alias(c, s);
     // error buffer header: minkey = ~0, filter (= ~0 unless hz_witness_check re-runs after an overflow), count = 0
     HZ_HIP(hipMemsetAsync(c->err.p, 0xFF, 16, s));
     HZ_HIP(hipMemsetAsync((uint8_t*)c->err.p + 16, 0, 8, s));
@@ -599,6 +606,7 @@ extern "C" hz_status hz_witness_enqueue_tail(hz_ctx* c, void* stream) {
 extern "C" hz_status hz_ctx_set_profiling(hz_ctx* c, int32_t on) {
     if (!c) return set_err(HZ_ERR_ARG, "hz_ctx_set_profiling: null context");
     c->profiling = on != 0;
+    c->exclusive = on == 2;
     return HZ_OK;
 }
 extern "C" int32_t hz_profile_count(const hz_ctx* c) { return c ? (int32_t)c->prof_used : 0; }

@@ -3,9 +3,13 @@
 // escalarmulany, escalarmulfix, montgomery, compconstant, aliascheck) -- call site
 // reference src/rollup-tx.circom:467-482. One transaction per lane.
 //
-// Every intermediate point of the two scalar multiplications is a witness signal, so the ladder
-// is evaluated in the circuit's own affine Montgomery-curve formulas; each division is one field
-// inversion. EscalarMulFix's window tables are compile-time constants (bjj_consts.inc).
+// Every intermediate point of the two scalar multiplications is a witness signal, so the ladders
+// are evaluated in the circuit's own affine Montgomery-curve formulas, one division per curve
+// operation. A field inversion costs ~85 products (tools/microbench/invbench.hip) and there are
+// ~340 of them per signature, so each lane walks HZ_ED_G signatures in lockstep and shares ONE
+// inversion per ladder step / window among them (Montgomery's trick): 3 extra products per shared
+// element instead of an inversion. EscalarMulFix's window tables are compile-time constants
+// (bjj_consts.inc).
 #include <hip/hip_runtime.h>
 #include "gadgets_dev.h"
 #include "tx_dev.h"
@@ -61,14 +65,23 @@ __device__ Fr fr_sqrt_circom_dev(const Fr& n) {
     return gt ? fr_neg(r) : r;
 }
 
+#ifndef HZ_ED_G
+#define HZ_ED_G 4   // signatures per lane
+#endif
+
 struct EdCtx {
     UnitIO io;
     Fr a, d, A;   // 168700, 168696, 168698 (Montgomery-curve A; B = 1)
     Fr one;
 };
+// the curve constants once per lane, the witness cursor per signature
+struct EdK {
+    Fr a, d, A, one;
+    __device__ __forceinline__ EdCtx with(const UnitIO& io) const { return EdCtx{io, a, d, A, one}; }
+};
 
 // BabyAdd: stores beta,gamma,delta,tau,xout,yout; checks the two division constraints
-__device__ __forceinline__ PtA baby_add_dev(const EdCtx& c, BabyAddOff off, const PtA& p, const PtA& q) {
+__device__ __noinline__ PtA baby_add_dev(const EdCtx& c, BabyAddOff off, const PtA& p, const PtA& q) {
     const Fr beta = fr_mul(p.x, q.y), gamma = fr_mul(p.y, q.x);
     const Fr delta = fr_mul(fr_sub(p.y, fr_mul(c.a, p.x)), fr_add(q.x, q.y));
     const Fr tau = fr_mul(beta, gamma);
@@ -87,7 +100,7 @@ __device__ __forceinline__ PtA baby_add_dev(const EdCtx& c, BabyAddOff off, cons
     return r;
 }
 struct MDbl { Fr x1_2, lamda; PtA out; };
-__device__ __forceinline__ MDbl mont_dbl_dev(const EdCtx& c, const PtA& p) {
+__device__ __noinline__ MDbl mont_dbl_dev(const EdCtx& c, const PtA& p) {
     MDbl r;
     r.x1_2 = fr_sqr(p.x);
     const Fr num = fr_add(fr_add(fr_add(fr_dbl(r.x1_2), r.x1_2), fr_mul(fr_dbl(c.A), p.x)), c.one);
@@ -98,17 +111,7 @@ __device__ __forceinline__ MDbl mont_dbl_dev(const EdCtx& c, const PtA& p) {
     r.out.y = fr_sub(fr_mul(r.lamda, fr_sub(p.x, r.out.x)), p.y);
     return r;
 }
-struct MAdd { Fr lamda; PtA out; };
-__device__ __forceinline__ MAdd mont_add_dev(const EdCtx& c, const PtA& p1, const PtA& p2) {
-    MAdd r;
-    const Fr num = fr_sub(p2.y, p1.y), den = fr_sub(p2.x, p1.x);
-    r.lamda = fr_div(num, den);
-    if (fr_is_zero(den)) c.io.chk(C_RTX_SIG_EC, fr_zero(), num);
-    r.out.x = fr_sub(fr_sub(fr_sub(fr_sqr(r.lamda), c.A), p1.x), p2.x);
-    r.out.y = fr_sub(fr_mul(r.lamda, fr_sub(p1.x, r.out.x)), p1.y);
-    return r;
-}
-__device__ __forceinline__ PtA e2m_dev(const EdCtx& c, const PtA& p) {
+__device__ __noinline__ PtA e2m_dev(const EdCtx& c, const PtA& p) {
     Fr den[2] = {fr_sub(c.one, p.y), p.x};
     Fr inv[2] = {den[0], den[1]};
     batch_inv<2>(inv, 2);
@@ -119,7 +122,7 @@ __device__ __forceinline__ PtA e2m_dev(const EdCtx& c, const PtA& p) {
     if (fr_is_zero(den[1])) c.io.chk(C_RTX_SIG_EC, fr_zero(), o.x);
     return o;
 }
-__device__ __forceinline__ PtA m2e_dev(const EdCtx& c, const PtA& p) {
+__device__ __noinline__ PtA m2e_dev(const EdCtx& c, const PtA& p) {
     Fr den[2] = {p.y, fr_add(p.x, c.one)};
     Fr inv[2] = {den[0], den[1]};
     batch_inv<2>(inv, 2);
@@ -131,115 +134,163 @@ __device__ __forceinline__ PtA m2e_dev(const EdCtx& c, const PtA& p) {
     return o;
 }
 
-// SegmentMulAny(n): bits e[e0 .. e0+n) of the canonical integer `e`.
+// SegmentMulAny(n) for G signatures in lockstep: bits e[g][e0 .. e0+n) of the canonical integers.
 // Step i is doubler_i (D_{i+1} = 2 D_i) followed by adder_i (D_{i+1} + acc_i). adder_i and
-// doubler_{i+1} both depend only on D_{i+1} and acc_i, so their two divisions share ONE field
-// inversion (Montgomery's trick): the ladder costs one inversion per scalar bit instead of two.
-struct SegAnyRes { PtA out, dbl; };
-__device__ SegAnyRes seg_any_dev(const EdCtx& c, const SegAnyOff& o, const Fc& e, int e0, int n, const PtA& p) {
-    const PtA m = e2m_dev(c, p);
-    c.io.put_m(o.e2m, m.x); c.io.put_m(o.e2m + 1, m.y);
+// doubler_{i+1} both depend only on D_{i+1} and acc_i, so one step needs 2 divisions per signature:
+// all 2G of them share one inversion.
+// in: p[g] (Edwards). out: p[g] <- segment output (Edwards), dbl[g] <- last doubler output (Montgomery).
+template <int G>
+__device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl) {
+    PtA dout[G], addIn[G];
+    Fr nx1_2[G], d_num[G];
     const int steps = n - 1;
-    // doubler_0 alone
-    MDbl d = mont_dbl_dev(c, m);
-    PtA addIn = m;
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const EdCtx c = K.with(io[g]);
+        const PtA m = e2m_dev(c, p[g]);
+        c.io.put_m(o.e2m, m.x); c.io.put_m(o.e2m + 1, m.y);
+        const MDbl d = mont_dbl_dev(c, m);   // doubler_0
+        c.io.put_m(o.bits + BIT_DBL_X1_2, d.x1_2); c.io.put_m(o.bits + BIT_DBL_LAMDA, d.lamda);
+        c.io.put_m(o.bits + BIT_DBL_OUT0, d.out.x); c.io.put_m(o.bits + BIT_DBL_OUT1, d.out.y);
+        dout[g] = d.out;
+        addIn[g] = m;
+    }
+    const Fr A2 = fr_dbl(K.A);
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
-        const uint32_t b = o.bits + BIT_N * i;
-        // adder_i: in1 = d.out, in2 = addIn ; doubler_{i+1}: in = d.out
-        const Fr a_num = fr_sub(addIn.y, d.out.y), a_den = fr_sub(addIn.x, d.out.x);
         const bool more = i + 1 < steps;
-        Fr nx1_2 = fr_zero(), d_num = fr_zero(), d_den = fr_zero();
-        if (more) {
-            nx1_2 = fr_sqr(d.out.x);
-            d_num = fr_add(fr_add(fr_add(fr_dbl(nx1_2), nx1_2), fr_mul(fr_dbl(c.A), d.out.x)), c.one);
-            d_den = fr_dbl(d.out.y);
-        }
-        Fr den[2] = {a_den, d_den};
-        Fr inv[2] = {a_den, d_den};
-        batch_inv<2>(inv, more ? 2 : 1);
-        MAdd a;
-        a.lamda = fr_mul(a_num, inv[0]);
-        if (fr_is_zero(den[0])) c.io.chk(C_RTX_SIG_EC, fr_zero(), a_num);
-        a.out.x = fr_sub(fr_sub(fr_sub(fr_sqr(a.lamda), c.A), d.out.x), addIn.x);
-        a.out.y = fr_sub(fr_mul(a.lamda, fr_sub(d.out.x, a.out.x)), d.out.y);
-        const uint32_t sel = c_bit(e, e0 + i + 1);
-        const PtA so = sel ? a.out : addIn;
-        c.io.put_m(b + BIT_DBL_X1_2, d.x1_2); c.io.put_m(b + BIT_DBL_LAMDA, d.lamda); c.io.put_m(b + BIT_DBL_OUT0, d.out.x); c.io.put_m(b + BIT_DBL_OUT1, d.out.y);
-        c.io.put_m(b + BIT_ADD_LAMDA, a.lamda); c.io.put_m(b + BIT_ADD_OUT0, a.out.x); c.io.put_m(b + BIT_ADD_OUT1, a.out.y);
-        c.io.put_m(b + BIT_SEL_OUT0, so.x); c.io.put_m(b + BIT_SEL_OUT1, so.y);
-        addIn = so;
-        if (more) {
-            MDbl nd;
-            nd.x1_2 = nx1_2;
-            nd.lamda = fr_mul(d_num, inv[1]);
-            if (fr_is_zero(den[1])) c.io.chk(C_RTX_SIG_EC, fr_zero(), d_num);
-            nd.out.x = fr_sub(fr_sub(fr_sqr(nd.lamda), c.A), fr_dbl(d.out.x));
-            nd.out.y = fr_sub(fr_mul(nd.lamda, fr_sub(d.out.x, nd.out.x)), d.out.y);
-            d = nd;
-        }
-    }
-    SegAnyRes r;
-    r.dbl = d.out;
-    const PtA me = m2e_dev(c, addIn);
-    c.io.put_m(o.m2e, me.x); c.io.put_m(o.m2e + 1, me.y);
-    PtA negp;
-    negp.x = fr_neg(p.x);
-    negp.y = p.y;
-    const PtA ea = baby_add_dev(c, o.eadder, me, negp);
-    r.out = c_bit(e, e0) ? me : ea;
-    c.io.put_m(o.lastSel, r.out.x); c.io.put_m(o.lastSel + 1, r.out.y);
-    return r;
-}
-
-// SegmentMulFix on the constant base: window tables from HZ_BJJ_FIX_WIN
-__device__ PtA seg_fix_dev(const EdCtx& c, const SegFixOff& o, const Fc& e, int e0, int nbits, int win0, int seg) {
-    PtA acc;
-    acc.x = ld_const(HZ_BJJ_FIX_DBLLAST[2 * seg]);
-    acc.y = ld_const(HZ_BJJ_FIX_DBLLAST[2 * seg + 1]);
+        const uint32_t b = o.bits + BIT_N * i;
+        Fr inv[2 * G];
+        uint32_t zmask = 0;
 #pragma unroll 1
-    for (int i = 0; i < o.nwin; i++) {
-        uint32_t k = 0, b0 = 0, b1 = 0;
-        for (int j = 0; j < 3; j++) {
-            const uint32_t bit = (3 * i + j < nbits) ? c_bit(e, e0 + 3 * i + j) : 0u;
-            k |= bit << j;
-            if (j == 0) b0 = bit;
-            if (j == 1) b1 = bit;
+        for (int g = 0; g < G; g++) {
+            // adder_i: in1 = dout, in2 = addIn ; doubler_{i+1}: in = dout
+            const Fr a_den = fr_sub(addIn[g].x, dout[g].x);
+            Fr dd = fr_zero();
+            if (more) {
+                nx1_2[g] = fr_sqr(dout[g].x);
+                d_num[g] = fr_add(fr_add(fr_add(fr_dbl(nx1_2[g]), nx1_2[g]), fr_mul(A2, dout[g].x)), K.one);
+                dd = fr_dbl(dout[g].y);
+            }
+            inv[2 * g] = a_den;
+            inv[2 * g + 1] = dd;
+            if (fr_is_zero(a_den)) zmask |= 1u << (2 * g);
+            if (more && fr_is_zero(dd)) zmask |= 1u << (2 * g + 1);
         }
-        PtA mo;
-        mo.x = ld_const(HZ_BJJ_FIX_WIN[((win0 + i) * 8 + k) * 2]);
-        mo.y = ld_const(HZ_BJJ_FIX_WIN[((win0 + i) * 8 + k) * 2 + 1]);
-        const uint32_t wb = o.windows + WIN_N * i;
-        c.io.put_bit(wb + WIN_S10, b1 & b0);
-        c.io.put_m(wb + WIN_MUX0, mo.x); c.io.put_m(wb + WIN_MUX1, mo.y);
-        const MAdd a = mont_add_dev(c, acc, mo);
-        c.io.put_m(wb + WIN_ADD_LAMDA, a.lamda); c.io.put_m(wb + WIN_ADD_OUT0, a.out.x); c.io.put_m(wb + WIN_ADD_OUT1, a.out.y);
-        acc = a.out;
+        batch_inv<2 * G>(inv, 2 * G);
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const UnitIO& w = io[g];
+            const Fr a_num = fr_sub(addIn[g].y, dout[g].y);
+            const Fr a_lamda = fr_mul(a_num, inv[2 * g]);
+            if ((zmask >> (2 * g)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), a_num);
+            PtA ao;
+            ao.x = fr_sub(fr_sub(fr_sub(fr_sqr(a_lamda), K.A), dout[g].x), addIn[g].x);
+            ao.y = fr_sub(fr_mul(a_lamda, fr_sub(dout[g].x, ao.x)), dout[g].y);
+            const uint32_t sel = c_bit(e[g], e0 + i + 1);
+            const PtA so = sel ? ao : addIn[g];
+            w.put_m(b + BIT_ADD_LAMDA, a_lamda); w.put_m(b + BIT_ADD_OUT0, ao.x); w.put_m(b + BIT_ADD_OUT1, ao.y);
+            w.put_m(b + BIT_SEL_OUT0, so.x); w.put_m(b + BIT_SEL_OUT1, so.y);
+            addIn[g] = so;
+            if (more) {
+                const Fr lamda = fr_mul(d_num[g], inv[2 * g + 1]);
+                if ((zmask >> (2 * g + 1)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), d_num[g]);
+                PtA no;
+                no.x = fr_sub(fr_sub(fr_sqr(lamda), K.A), fr_dbl(dout[g].x));
+                no.y = fr_sub(fr_mul(lamda, fr_sub(dout[g].x, no.x)), dout[g].y);
+                const uint32_t bn = b + BIT_N;
+                w.put_m(bn + BIT_DBL_X1_2, nx1_2[g]); w.put_m(bn + BIT_DBL_LAMDA, lamda); w.put_m(bn + BIT_DBL_OUT0, no.x); w.put_m(bn + BIT_DBL_OUT1, no.y);
+                dout[g] = no;
+            }
+        }
     }
-    const PtA me = m2e_dev(c, acc);
-    c.io.put_m(o.m2e, me.x); c.io.put_m(o.m2e + 1, me.y);
-    PtA cn;
-    cn.x = ld_const(HZ_BJJ_FIX_CNEG[2 * seg]);
-    cn.y = ld_const(HZ_BJJ_FIX_CNEG[2 * seg + 1]);
-    return baby_add_dev(c, o.cAdd, me, cn);
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const EdCtx c = K.with(io[g]);
+        dbl[g] = dout[g];
+        const PtA me = m2e_dev(c, addIn[g]);
+        c.io.put_m(o.m2e, me.x); c.io.put_m(o.m2e + 1, me.y);
+        PtA negp;
+        negp.x = fr_neg(p[g].x);
+        negp.y = p[g].y;
+        const PtA ea = baby_add_dev(c, o.eadder, me, negp);
+        const PtA r = c_bit(e[g], e0) ? me : ea;
+        c.io.put_m(o.lastSel, r.x); c.io.put_m(o.lastSel + 1, r.y);
+        p[g] = r;
+    }
 }
 
-__global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C6 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M6 = C6 + poseidon_nconst<6>();
-    stage_poseidon_consts<6>(C6);
-    __syncthreads();
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
-    const uint32_t i = a.u0 + li;
-    EdCtx c;
-    c.io = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
-    c.one = fr_one();
-    c.a = fr_from_u64(168700); c.d = fr_from_u64(168696); c.A = fr_from_u64(168698);
-    const UnitIO& io = c.io;
-    const Scratch sc{a.scratch, a.n_units, i};
-    const EddsaOff& o = a.ed;
+// SegmentMulFix on the constant base for G signatures in lockstep: window tables from
+// HZ_BJJ_FIX_WIN; the G additions of one window share one inversion.
+__device__ __forceinline__ uint32_t fix_window_bits(const Fc& e, int e0, int nbits, int i) {
+    uint32_t k = 0;
+    for (int j = 0; j < 3; j++) {
+        const uint32_t bit = (3 * i + j < nbits) ? c_bit(e, e0 + 3 * i + j) : 0u;
+        k |= bit << j;
+    }
+    return k;
+}
+template <int G>
+__device__ __noinline__ void seg_fix_lock(const EdK& K, const UnitIO* io, const SegFixOff& o, const Fc* e, int e0, int nbits, int win0, int seg, PtA* out) {
+    PtA acc[G];
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        acc[g].x = ld_const(HZ_BJJ_FIX_DBLLAST[2 * seg]);
+        acc[g].y = ld_const(HZ_BJJ_FIX_DBLLAST[2 * seg + 1]);
+    }
+#pragma unroll 1
+    for (int i = 0; i < (int)o.nwin; i++) {
+        const uint32_t wb = o.windows + WIN_N * i;
+        Fr inv[G];
+        uint32_t zmask = 0;
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const uint32_t k = fix_window_bits(e[g], e0, nbits, i);
+            const Fr mx = ld_const(HZ_BJJ_FIX_WIN[((win0 + i) * 8 + k) * 2]);
+            inv[g] = fr_sub(mx, acc[g].x);
+            if (fr_is_zero(inv[g])) zmask |= 1u << g;
+        }
+        batch_inv<G>(inv, G);
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const UnitIO& w = io[g];
+            const uint32_t k = fix_window_bits(e[g], e0, nbits, i);
+            PtA mo;
+            mo.x = ld_const(HZ_BJJ_FIX_WIN[((win0 + i) * 8 + k) * 2]);
+            mo.y = ld_const(HZ_BJJ_FIX_WIN[((win0 + i) * 8 + k) * 2 + 1]);
+            w.put_bit(wb + WIN_S10, (k & 1) & ((k >> 1) & 1));
+            w.put_m(wb + WIN_MUX0, mo.x); w.put_m(wb + WIN_MUX1, mo.y);
+            const Fr num = fr_sub(mo.y, acc[g].y);
+            const Fr lamda = fr_mul(num, inv[g]);
+            if ((zmask >> g) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), num);
+            PtA ao;
+            ao.x = fr_sub(fr_sub(fr_sub(fr_sqr(lamda), K.A), acc[g].x), mo.x);
+            ao.y = fr_sub(fr_mul(lamda, fr_sub(acc[g].x, ao.x)), acc[g].y);
+            w.put_m(wb + WIN_ADD_LAMDA, lamda); w.put_m(wb + WIN_ADD_OUT0, ao.x); w.put_m(wb + WIN_ADD_OUT1, ao.y);
+            acc[g] = ao;
+        }
+    }
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const EdCtx c = K.with(io[g]);
+        const PtA me = m2e_dev(c, acc[g]);
+        c.io.put_m(o.m2e, me.x); c.io.put_m(o.m2e + 1, me.y);
+        PtA cn;
+        cn.x = ld_const(HZ_BJJ_FIX_CNEG[2 * seg]);
+        cn.y = ld_const(HZ_BJJ_FIX_CNEG[2 * seg + 1]);
+        out[g] = baby_add_dev(c, o.cAdd, me, cn);
+    }
+}
+
+// Everything before the scalar multiplications of one signature: AySign2Ax, the S range check,
+// the message hash and its bits, 8*A and the zero-point substitution.
+struct EdSig {
+    Fc h_c, S253;
+    Fr enabled, zp;
+    PtA R8, p0;
+};
+__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* C6, const Fr* M6, EdSig& out) {
+    const EdCtx c = K.with(io);
     const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
     const Fr S = sc.get(SC_ED_S), R8x = sc.get(SC_ED_R8X), R8y = sc.get(SC_ED_R8Y), M = sc.get(SC_SIGL2HASH);
     // ---- AySign2Ax
@@ -264,63 +315,111 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
     // ---- EdDSAPoseidonVerifier
     const Fc S_c = fr_to_canon(S);
     num2bits_dev(io, o.snum2bits, S_c, 253, C_RTX_SIG_N2B_S);
-    const Fc S253 = c_extract(S_c, 0, 253);
+    out.S253 = c_extract(S_c, 0, 253);
     {
-        const uint32_t gt = comp_constant_dev(io, o.sCmp, S253, CT_SUBORDER_M1_D);
+        const uint32_t gt = comp_constant_dev(io, o.sCmp, out.S253, CT_SUBORDER_M1_D);
         if (gt) io.chk_zero(C_RTX_SIG_S_RANGE, enabled);
     }
     Fr hin[5] = {R8x, R8y, x, Ay, M};
     WitSboxSink s6 = io.sbox_sink(o.hash);
     const Fr h = poseidon_hash<6>(hin, C6, M6, s6);
-    const Fc h_c = fr_to_canon(h);
-    num2bits_strict_dev(io, o.h2bits, h_c, C_RTX_SIG_H_ALIAS);
+    out.h_c = fr_to_canon(h);
+    num2bits_strict_dev(io, o.h2bits, out.h_c, C_RTX_SIG_H_ALIAS);
     PtA A;
     A.x = x; A.y = Ay;
     const PtA d1 = baby_add_dev(c, o.dbl1, A, A);
     const PtA d2 = baby_add_dev(c, o.dbl2, d1, d1);
     const PtA d3 = baby_add_dev(c, o.dbl3, d2, d2);
-    {
-        // isZero.in <== dbl3.x (the input x of the third doubling) ; zeropoint.in <== dbl3.xout
-        Fr z[2] = {d2.x, d3.x};
-        Fr zi[2] = {z[0], z[1]};
-        batch_inv<2>(zi, 2);
-        const Fr az = is_zero_dev(io, o.isZero, z[0], zi[0]);
-        io.chk_zero(C_RTX_SIG_A_NONZERO, fr_mul(az, enabled));
-        const Fr zp = is_zero_dev(io, o.zeropoint, z[1], zi[1]);
-        const bool zpb = fr_is_zero(z[1]);
-        PtA p0;
-        p0.x = zpb ? ld_const(HZ_BJJ_BASE8_X) : d3.x;
-        p0.y = zpb ? ld_const(HZ_BJJ_BASE8_Y) : d3.y;
-        io.put_m(o.seg0p, p0.x); io.put_m(o.seg0p + 1, p0.y);
-        const SegAnyRes s0 = seg_any_dev(c, o.seg[0], h_c, 0, 148, p0);
-        const MDbl dd = mont_dbl_dev(c, s0.dbl);
-        io.put_m(o.dblr, dd.x1_2); io.put_m(o.dblr + 1, dd.lamda); io.put_m(o.dblr + 2, dd.out.x); io.put_m(o.dblr + 3, dd.out.y);
-        const PtA p1 = m2e_dev(c, dd.out);
-        io.put_m(o.m2e0, p1.x); io.put_m(o.m2e0 + 1, p1.y);
-        const SegAnyRes s1 = seg_any_dev(c, o.seg[1], h_c, 148, 106, p1);
-        const PtA sum = baby_add_dev(c, o.adders0, s0.out, s1.out);
+    // isZero.in <== dbl3.x (the input x of the third doubling) ; zeropoint.in <== dbl3.xout
+    Fr z[2] = {d2.x, d3.x};
+    Fr zi[2] = {z[0], z[1]};
+    batch_inv<2>(zi, 2);
+    const Fr az = is_zero_dev(io, o.isZero, z[0], zi[0]);
+    io.chk_zero(C_RTX_SIG_A_NONZERO, fr_mul(az, enabled));
+    out.zp = is_zero_dev(io, o.zeropoint, z[1], zi[1]);
+    const bool zpb = fr_is_zero(z[1]);
+    out.p0.x = zpb ? ld_const(HZ_BJJ_BASE8_X) : d3.x;
+    out.p0.y = zpb ? ld_const(HZ_BJJ_BASE8_Y) : d3.y;
+    io.put_m(o.seg0p, out.p0.x); io.put_m(o.seg0p + 1, out.p0.y);
+    out.enabled = enabled;
+    out.R8.x = R8x; out.R8.y = R8y;
+}
+
+// Lane li evaluates the signatures of units li, li + nl, li + 2 nl, ... (nl lanes): consecutive
+// lanes keep writing consecutive units. A slot past the end repeats the lane's first unit (same
+// values to the same addresses).
+template <int G>
+__global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    Fr* C6 = reinterpret_cast<Fr*>(lds_raw);
+    Fr* M6 = C6 + poseidon_nconst<6>();
+    stage_poseidon_consts<6>(C6);
+    __syncthreads();
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t nl = (n + G - 1) / G;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= nl) return;
+    EdK K;
+    K.one = fr_one();
+    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EddsaOff& o = a.ed;
+    UnitIO io[G];
+    Fc h_c[G], S253[G];
+    Fr enabled[G], zp[G];
+    PtA R8[G], p[G], q[G], dbl[G];
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        uint32_t ui = li + (uint32_t)g * nl;
+        if (ui >= n) ui = li;
+        const uint32_t i = a.u0 + ui;
+        io[g] = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+        const Scratch sc{a.scratch, a.n_units, i};
+        EdSig sg;
+        ed_prologue(K, io[g], sc, o, C6, M6, sg);
+        h_c[g] = sg.h_c; S253[g] = sg.S253; enabled[g] = sg.enabled; zp[g] = sg.zp; R8[g] = sg.R8; p[g] = sg.p0;
+    }
+    // ---- mulAny = h * 8A: two SegmentMulAny (148 + 106 bits)
+    seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);   // p <- segment 0 output
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const EdCtx c = K.with(io[g]);
+        const MDbl dd = mont_dbl_dev(c, dbl[g]);
+        c.io.put_m(o.dblr, dd.x1_2); c.io.put_m(o.dblr + 1, dd.lamda); c.io.put_m(o.dblr + 2, dd.out.x); c.io.put_m(o.dblr + 3, dd.out.y);
+        q[g] = m2e_dev(c, dd.out);
+        c.io.put_m(o.m2e0, q[g].x); c.io.put_m(o.m2e0 + 1, q[g].y);
+    }
+    seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, q, dbl);  // q <- segment 1 output
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const EdCtx c = K.with(io[g]);
+        const PtA sum = baby_add_dev(c, o.adders0, p[g], q[g]);
         PtA any;
-        any.x = fr_mul(sum.x, fr_sub(c.one, zp));
-        any.y = fr_add(sum.y, fr_mul(fr_sub(c.one, sum.y), zp));
-        io.put_m(o.anyOut, any.x); io.put_m(o.anyOut + 1, any.y);
-        PtA R8;
-        R8.x = R8x; R8.y = R8y;
-        const PtA right = baby_add_dev(c, o.addRight, R8, any);
-        const PtA f0 = seg_fix_dev(c, o.fseg[0], S253, 0, 246, 0, 0);
-        const PtA f1 = seg_fix_dev(c, o.fseg[1], S253, 246, 7, 82, 1);
-        const PtA left = baby_add_dev(c, o.fadders0, f0, f1);
-        Fr q[2] = {fr_sub(right.x, left.x), fr_sub(right.y, left.y)};   // eqCheck: in[0] = mulFix.out, in[1] = addRight
-        Fr qi[2] = {q[0], q[1]};
-        batch_inv<2>(qi, 2);
-        const Fr ex = is_zero_dev(io, o.eqCheckX, q[0], qi[0]);
-        io.chk_zero(C_RTX_SIG_EQX, fr_mul(fr_sub(c.one, ex), enabled));
-        const Fr ey = is_zero_dev(io, o.eqCheckY, q[1], qi[1]);
-        io.chk_zero(C_RTX_SIG_EQY, fr_mul(fr_sub(c.one, ey), enabled));
+        any.x = fr_mul(sum.x, fr_sub(c.one, zp[g]));
+        any.y = fr_add(sum.y, fr_mul(fr_sub(c.one, sum.y), zp[g]));
+        c.io.put_m(o.anyOut, any.x); c.io.put_m(o.anyOut + 1, any.y);
+        p[g] = baby_add_dev(c, o.addRight, R8[g], any);   // right side: R8 + h*8A
+    }
+    // ---- mulFix = S * B8: two SegmentMulFix (82 + 3 windows)
+    seg_fix_lock<G>(K, io, o.fseg[0], S253, 0, 246, 0, 0, q);
+    seg_fix_lock<G>(K, io, o.fseg[1], S253, 246, 7, 82, 1, dbl);
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const EdCtx c = K.with(io[g]);
+        const PtA left = baby_add_dev(c, o.fadders0, q[g], dbl[g]);
+        Fr d2[2] = {fr_sub(p[g].x, left.x), fr_sub(p[g].y, left.y)};   // eqCheck: in[0] = mulFix.out, in[1] = addRight
+        Fr di[2] = {d2[0], d2[1]};
+        batch_inv<2>(di, 2);
+        const Fr ex = is_zero_dev(c.io, o.eqCheckX, d2[0], di[0]);
+        c.io.chk_zero(C_RTX_SIG_EQX, fr_mul(fr_sub(c.one, ex), enabled[g]));
+        const Fr ey = is_zero_dev(c.io, o.eqCheckY, d2[1], di[1]);
+        c.io.chk_zero(C_RTX_SIG_EQY, fr_mul(fr_sub(c.one, ey), enabled[g]));
     }
 }
 
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_eddsa, dim3(((a.ucnt ? a.ucnt : a.n_units) + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<6>() * sizeof(Fr), s, a);
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t nl = (n + HZ_ED_G - 1) / HZ_ED_G;
+    hipLaunchKernelGGL(k_eddsa<HZ_ED_G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<6>() * sizeof(Fr), s, a);
     return hipGetLastError();
 }
 

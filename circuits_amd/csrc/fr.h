@@ -252,15 +252,16 @@ HZ_HD_HEAVY Fr fr_sqr(HZ_HEAVY_ARG(Fr) a) {
     t[17] = 0;
     return fr_reduce_cols(t);
 }
-// sum_{n<N} a[n]*b[n] / R with ONE Montgomery reduction (N <= 6: 9N+9 terms of < 2^58 fit 64 bits).
+// (sum_{n<N} a[n]*b[n] + addend) / R with ONE Montgomery reduction (N <= 6: 9N+9 terms of < 2^58 and
+// one 29-bit limb fit 64 bits). `addend` is a value < p in 29-bit limbs, i.e. the result gains addend/R.
 // The MDS mix of Poseidon is t such dot products per round.
 template <int N>
-HZ_HD Fr fr_dot(const Fr* a, const Fr* b) {
+HZ_HD Fr fr_dot(const Fr* a, const Fr* b, const Fr* addend = nullptr) {
     static_assert(N >= 1 && N <= 6, "fr_dot: at most 6 products per reduction");
     uint64_t t[18];
 #pragma unroll
     for (int k = 0; k < 17; k++) {
-        uint64_t acc = 0;
+        uint64_t acc = (addend && k < 9) ? addend->v[k] : 0;
 #pragma unroll
         for (int n = 0; n < N; n++) {
 #pragma unroll

@@ -44,60 +44,68 @@ HZ_HD Fr poseidon_sbox(const Fr& x, int k, Sink& sink) {
     return x5;
 }
 
-// Mix: out[i] = sum_j M[i][j] * st[j], one lazily reduced dot product per output (rows of more than
-// 6 terms are split in two)
+// Mix followed by the next round's AddRoundConstants: out[i] = sum_j M[i][j] * st[j] + c[i], one lazily
+// reduced dot product per output (rows of more than 6 terms are split in two). `Cn` = the next round's
+// constants in c*R^2 form (nullptr after the last round): added to the column sums before the division
+// by R they cost 9 integer additions instead of a modular addition.
 template <int T>
-HZ_HD void poseidon_mix(Fr (&st)[T], const Fr* M) {
+HZ_HD void poseidon_mix_ark(Fr (&st)[T], const Fr* M, const Fr* Cn) {
     Fr o[T];
 #pragma unroll
     for (int i = 0; i < T; i++) {
         if constexpr (T <= 6) {
-            o[i] = fr_dot<T>(M + i * T, st);
+            o[i] = fr_dot<T>(M + i * T, st, Cn ? Cn + i : nullptr);
         } else {
-            o[i] = fr_add(fr_dot<4>(M + i * T, st), fr_dot<T - 4>(M + i * T + 4, st + 4));
+            o[i] = fr_add(fr_dot<4>(M + i * T, st, Cn ? Cn + i : nullptr), fr_dot<T - 4>(M + i * T + 4, st + 4));
         }
     }
 #pragma unroll
     for (int i = 0; i < T; i++) st[i] = o[i];
 }
 
-// Full permutation; `in` are the T-1 inputs (Montgomery). `C`/`M` point at the staged constants.
+// Full permutation; `in` are the T-1 inputs (Montgomery). `C`/`M` point at the staged constants
+// (gen/poseidon_consts.inc: round 0 in Montgomery form, later rounds in c*R^2 form).
 // S-box k is numbered in evaluation order: 4 full rounds (T each), R_P partial, 4 full rounds.
 template <int T, class Sink>
 HZ_HD Fr poseidon_hash(const Fr* in, const Fr* C, const Fr* M, Sink& sink) {
     constexpr int RP = PoseidonCfg<T>::RP;
     Fr st[T];
-    st[0] = fr_zero();
+    st[0] = C[0];
 #pragma unroll
-    for (int j = 1; j < T; j++) st[j] = in[j - 1];
+    for (int j = 1; j < T; j++) st[j] = fr_add(in[j - 1], C[j]);
     int k = 0;
-    int c = 0;
+    int c = T;   // constants of the NEXT round
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int j = 0; j < T; j++) st[j] = poseidon_sbox(fr_add(st[j], C[c + j]), k + j, sink);
-        c += T;
+        for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
         k += T;
-        poseidon_mix<T>(st, M);
+        poseidon_mix_ark<T>(st, M, C + c);
+        c += T;
     }
 #pragma unroll 1
     for (int r = 0; r < RP; r++) {
-        st[0] = poseidon_sbox(fr_add(st[0], C[c]), k, sink);
-#pragma unroll
-        for (int j = 1; j < T; j++) st[j] = fr_add(st[j], C[c + j]);
-        c += T;
+        st[0] = poseidon_sbox(st[0], k, sink);
         k += 1;
-        poseidon_mix<T>(st, M);
+        poseidon_mix_ark<T>(st, M, C + c);
+        c += T;
     }
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 3; r++) {
 #pragma unroll
-        for (int j = 0; j < T; j++) st[j] = poseidon_sbox(fr_add(st[j], C[c + j]), k + j, sink);
-        c += T;
+        for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
         k += T;
-        poseidon_mix<T>(st, M);
+        poseidon_mix_ark<T>(st, M, C + c);
+        c += T;
     }
-    return st[0];
+#pragma unroll
+    for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
+    // only state[0] of the last Mix is the digest
+    if constexpr (T <= 6) {
+        return fr_dot<T>(M, st);
+    } else {
+        return fr_add(fr_dot<4>(M, st), fr_dot<T - 4>(M + 4, st + 4));
+    }
 }
 
 }  // namespace hz

@@ -16,11 +16,16 @@ namespace hz {
 template <int T, bool WIT>
 __global__ __launch_bounds__(256) void poseidon_batch_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                               uint8_t* __restrict__ wit, size_t n) {
+#ifdef HZ_POSEIDON_SCONST
+    const Fr* C = reinterpret_cast<const Fr*>(poseidon_c_global<T>());
+    const Fr* M = reinterpret_cast<const Fr*>(poseidon_m_global<T>());
+#else
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     Fr* C = reinterpret_cast<Fr*>(lds_raw);
     Fr* M = C + poseidon_nconst<T>();
     stage_poseidon_consts<T>(C);
     __syncthreads();
+#endif
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         Fr x[T - 1];

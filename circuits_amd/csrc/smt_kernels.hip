@@ -14,7 +14,10 @@ namespace hz {
 // HashState x4 + SMTHash1 x4 (reference src/rollup-tx.circom:297-312,517-532 and the hash1Old /
 // hash1New components of circomlib's SMTProcessor). blockIdx.y = j.
 
-__global__ __launch_bounds__(HZ_BLOCK) void k_hash4(const Hash4Args a) {
+#ifndef HZ_HASH4_WAVES
+#define HZ_HASH4_WAVES 2
+#endif
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HASH4_WAVES))) void k_hash4(const Hash4Args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     Fr* C5 = reinterpret_cast<Fr*>(lds_raw);
     Fr* M5 = C5 + poseidon_nconst<5>();
@@ -52,7 +55,10 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hash4(const Hash4Args a) {
 // The old-side lane also writes enabled, n2bOld, SMTLevIns; the new-side lane n2bNew, xors, sm.
 
 
-__global__ __launch_bounds__(HZ_BLOCK) void k_smt(const SmtArgs a) {
+#ifndef HZ_SMT_WAVES
+#define HZ_SMT_WAVES 2
+#endif
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT_WAVES))) void k_smt(const SmtArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     Fr* C3 = reinterpret_cast<Fr*>(lds_raw);
     Fr* M3 = C3 + poseidon_nconst<3>();
@@ -100,12 +106,12 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smt(const SmtArgs a) {
         if (o.fnc != ~0u) { io.put_m(o.fnc, fnc0); io.put_m(o.fnc + 1, fnc1); }
         io.put_m(o.enabled, enabled);
         num2bits_strict_dev(io, o.n2bOld, oldKey_c, P.cid_alias_old);
-        // isZero[i]: batched inverses, 16 at a time
-        for (int base = 0; base < n; base += 16) {
-            const int cnt = (n - base) < 16 ? (n - base) : 16;
-            Fr z[16], zi[16];
+        // isZero[i]: batched inverses, 8 at a time
+        for (int base = 0; base < n; base += 8) {
+            const int cnt = (n - base) < 8 ? (n - base) : 8;
+            Fr z[8], zi[8];
             for (int k = 0; k < cnt; k++) { z[k] = io.in_m(P.siblings + base + k); zi[k] = z[k]; }
-            batch_inv<16>(zi, cnt);
+            batch_inv<8>(zi, cnt);
             for (int k = 0; k < cnt; k++) is_zero_dev(io, o.isz + 2 * (base + k), z[k], zi[k]);
         }
         // (isZero[n-1].out - 1) * enabled === 0
@@ -115,45 +121,43 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smt(const SmtArgs a) {
         num2bits_strict_dev(io, o.n2bNew, newKey_c, P.cid_alias_new);
         for (int k = 0; k < n; k++) io.put_bit(o.xors + k, c_bit(oldKey_c, k) ^ c_bit(newKey_c, k));
     }
-    // state machine (both lanes; the new-side lane stores it). Field arithmetic: fnc/isOld0 may be
-    // arbitrary field elements in a standalone RollupTx.
-    Fr st_top[HZ_MAX_SMT_LEVELS];
-    uint8_t code[HZ_MAX_SMT_LEVELS];  // compact copy is not possible in general: keep per-level values below
-    (void)code;
-    Fr st_sum_a[HZ_MAX_SMT_LEVELS];   // old side: st_bot+st_new1+st_upd ; new side: st_top+st_bot
-    Fr st_b[HZ_MAX_SMT_LEVELS];       // new side: st_new1
-    Fr st_c[HZ_MAX_SMT_LEVELS];       // new side: st_old0+st_upd
-    {
-        Fr p_top = enabled, p_old0 = zero, p_bot = zero, p_new1 = zero, p_na = fr_sub(one, enabled), p_upd = zero;
+    // State machine (smtprocessorsm.circom). levIns is one-hot (integer logic above) and the xor bits
+    // are integers, so every per-level state is one of a few field values selected by the level's
+    // position relative to kl (the level with levIns = 1) and kx (the first level >= kl whose key
+    // bits differ): no per-level arrays are kept for the bottom-up pass.
+    //   k <  kl : top = E, everything else 0
+    //   k == kl : aux1 = E, aux2 = E*fnc0, old0 = aux2*isOld0, upd = E - aux2, m = aux2 - old0 -> new1 or bot
+    //   k >  kl : bot = m until kx, new1 = m at kx, 0 afterwards
+    // fnc0 / fnc1 / isOld0 may be arbitrary field elements in a standalone RollupTx: field arithmetic.
+    const uint64_t keylo_old = (uint64_t)oldKey_c.v[0] | ((uint64_t)oldKey_c.v[1] << 32), keylo_new = (uint64_t)newKey_c.v[0] | ((uint64_t)newKey_c.v[1] << 32);
+    const uint64_t xmask = (keylo_old ^ keylo_new) & ((1ull << n) - 1);   // n <= HZ_MAX_SMT_LEVELS < 64
+    const int kl = __builtin_ctzll(levmask);
+    const uint64_t xabove = xmask >> kl;
+    const int kx = xabove ? kl + __builtin_ctzll(xabove) : n;   // n: the keys agree on every level >= kl
+    const Fr A2 = fr_mul(enabled, fnc0);
+    const Fr O = fr_mul(A2, isOld0);
+    const Fr U = fr_sub(enabled, A2);
+    const Fr m = fr_sub(A2, O);
+    if (new_side) {
+        Fr p_na = fr_sub(one, enabled), p_new1 = zero, p_old0 = zero, p_upd = zero;
         Fr last_sum = zero;
         for (int k = 0; k < n; k++) {
-            const uint32_t lev = (uint32_t)((levmask >> k) & 1);
-            const uint32_t xr = c_bit(oldKey_c, k) ^ c_bit(newKey_c, k);
-            const Fr aux1 = lev ? p_top : zero;
-            const Fr aux2 = fr_mul(aux1, fnc0);
-            const Fr t_top = fr_sub(p_top, aux1);
-            const Fr t_old0 = fr_mul(aux2, isOld0);
-            const Fr mid = fr_add(fr_sub(aux2, t_old0), p_bot);
-            const Fr t_new1 = xr ? mid : zero;
-            const Fr t_bot = xr ? zero : mid;
-            const Fr t_upd = fr_sub(aux1, aux2);
+            const Fr aux1 = k == kl ? enabled : zero;
+            const Fr aux2 = k == kl ? A2 : zero;
+            const Fr t_old0 = k == kl ? O : zero;
+            const Fr t_upd = k == kl ? U : zero;
+            const Fr t_new1 = k == kx ? m : zero;
+            const Fr t_bot = (k >= kl && k < kx) ? m : zero;
             const Fr t_na = fr_add(fr_add(fr_add(p_new1, p_old0), p_na), p_upd);
-            if (new_side) {
-                const uint32_t b = o.sm + SM_N * k;
-                io.put_m(b + SM_AUX1, aux1); io.put_m(b + SM_AUX2, aux2); io.put_m(b + SM_OLD0, t_old0); io.put_m(b + SM_NEW1, t_new1);
-                io.put_m(b + SM_BOT, t_bot);
-                st_sum_a[k] = fr_add(t_top, t_bot);
-                st_b[k] = t_new1;
-                st_c[k] = fr_add(t_old0, t_upd);
-            } else {
-                st_sum_a[k] = fr_add(fr_add(t_bot, t_new1), t_upd);
-            }
-            st_top[k] = t_top;
+            const uint32_t b = o.sm + SM_N * k;
+            io.put_m(b + SM_AUX1, aux1); io.put_m(b + SM_AUX2, aux2); io.put_m(b + SM_OLD0, t_old0); io.put_m(b + SM_NEW1, t_new1);
+            io.put_m(b + SM_BOT, t_bot);
             if (k == n - 1) last_sum = fr_add(fr_add(fr_add(t_na, t_new1), t_old0), t_upd);
-            p_top = t_top; p_old0 = t_old0; p_bot = t_bot; p_new1 = t_new1; p_na = t_na; p_upd = t_upd;
+            p_old0 = t_old0; p_new1 = t_new1; p_na = t_na; p_upd = t_upd;
         }
-        if (new_side) io.chk(P.cid_sm_final, last_sum, one);
+        io.chk(P.cid_sm_final, last_sum, one);
     }
+    const Fr mU = fr_add(m, U), OU = fr_add(O, U);
     // level chain, bottom-up
     Fr child = zero;
     for (int k = n - 1; k >= 0; k--) {
@@ -169,23 +173,28 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smt(const SmtArgs a) {
             hin[1] = sel ? child : sib;
             WitSboxSink sk = io.sbox_sink(lv + LV_OLDHASH);
             const Fr h = poseidon_hash<3>(hin, C3, M3, sk);
-            const Fr aux0 = fr_mul(h1old, st_sum_a[k]);
-            const Fr root = fr_add(aux0, fr_mul(h, st_top[k]));
+            // st_bot + st_new1 + st_upd ; st_top
+            const Fr s_a = k < kl ? zero : k == kl ? mU : k <= kx ? m : zero;
+            const Fr aux0 = fr_mul(h1old, s_a);
+            const Fr root = k < kl ? fr_add(aux0, fr_mul(h, enabled)) : aux0;
             io.put_m(lv + LV_AUX0, aux0); io.put_m(lv + LV_OLDROOT, root);
             child = root;
         } else {
-            const Fr aux1 = fr_mul(child, st_sum_a[k]);
-            const Fr swL = fr_add(aux1, fr_mul(h1new, st_b[k]));
-            const Fr aux2 = fr_mul(sib, st_top[k]);
-            const Fr swR = fr_add(aux2, fr_mul(h1old, st_b[k]));
+            // st_top + st_bot ; st_new1 ; st_old0 + st_upd ; st_top
+            const Fr s_tb = k < kl ? enabled : k < kx ? m : zero;
+            const Fr s_n1 = k == kx ? m : zero;
+            const Fr aux1 = fr_mul(child, s_tb);
+            const Fr swL = fr_add(aux1, fr_mul(h1new, s_n1));
+            const Fr aux2 = k < kl ? fr_mul(sib, enabled) : zero;
+            const Fr swR = fr_add(aux2, fr_mul(h1old, s_n1));
             const Fr aux = sel ? fr_sub(swR, swL) : zero;
             Fr hin[2];
             hin[0] = sel ? swR : swL;
             hin[1] = sel ? swL : swR;
             WitSboxSink sk = io.sbox_sink(lv + LV_NEWHASH);
             const Fr h = poseidon_hash<3>(hin, C3, M3, sk);
-            const Fr aux3 = fr_mul(h, fr_add(st_sum_a[k], st_b[k]));
-            const Fr root = fr_add(aux3, fr_mul(h1new, st_c[k]));
+            const Fr aux3 = fr_mul(h, fr_add(s_tb, s_n1));
+            const Fr root = k == kl ? fr_add(aux3, fr_mul(h1new, OU)) : aux3;
             io.put_m(lv + LV_NEWSW_AUX, aux); io.put_m(lv + LV_AUX1, aux1); io.put_m(lv + LV_AUX2, aux2); io.put_m(lv + LV_AUX3, aux3);
             io.put_m(lv + LV_NEWSW_L, swL); io.put_m(lv + LV_NEWSW_R, swR); io.put_m(lv + LV_NEWROOT, root);
             child = root;

@@ -122,7 +122,9 @@ hz_status hz_witness_check(hz_ctx* ctx, hz_error* err);
 hz_status hz_witness_run(hz_ctx* ctx, hz_error* err);
 
 /* Per-kernel timing of the last enqueue, measured with HIP events on the launch stream.
- * `algorithmic_bytes` = 32 B x (witness signals the kernel is responsible for) x units. */
+ * `algorithmic_bytes` = 32 B x (witness signals the kernel is responsible for) x units.
+ * on = 1: the normal schedule (EdDSA and fee chains overlap the hash/SMT chain on side streams);
+ * on = 2: exclusive, every kernel alone on the device (durations usable for a per-kernel roofline). */
 hz_status hz_ctx_set_profiling(hz_ctx* ctx, int32_t on);
 int32_t hz_profile_count(const hz_ctx* ctx);
 hz_status hz_profile_get(hz_ctx* ctx, int32_t i, const char** kernel, float* ms, uint64_t* algorithmic_bytes, uint64_t* units);
