@@ -14,25 +14,35 @@ namespace hz {
 #include "gen/fee_table.inc"
 #undef HZ_CONST_ARR
 
-template <int T> __device__ __forceinline__ const uint32_t* poseidon_c_global();
-template <int T> __device__ __forceinline__ const uint32_t* poseidon_m_global();
-#define HZ_PC(T)                                                                                          \
-    template <> __device__ __forceinline__ const uint32_t* poseidon_c_global<T>() { return &HZ_POSEIDON_C_T##T[0][0]; } \
-    template <> __device__ __forceinline__ const uint32_t* poseidon_m_global<T>() { return &HZ_POSEIDON_M_T##T[0][0]; }
+template <int T> __device__ __forceinline__ const Fr* poseidon_k_global();
+#define HZ_PC(T) \
+    template <> __device__ __forceinline__ const Fr* poseidon_k_global<T>() { return reinterpret_cast<const Fr*>(&HZ_POSEIDON_K_T##T[0][0]); }
 HZ_PC(2) HZ_PC(3) HZ_PC(4) HZ_PC(5) HZ_PC(6) HZ_PC(7)
 #undef HZ_PC
 
-// Stage the width-T constants (C then M) into LDS at `dst` (Fr-aligned). Whole block cooperates
-// with 16-byte coalesced loads; caller must __syncthreads() afterwards.
+// Where the kernels read the Poseidon constants from. Every lane of a wavefront needs the same
+// constant at the same time, so the block is either read straight from device memory through the
+// scalar cache (s_load into SGPRs, which v_mad_u64_u32 takes as an operand: no VGPRs, no LDS), or
+// staged once per workgroup into LDS and read as broadcasts (HZ_POSEIDON_LDS = 1).
+#ifndef HZ_POSEIDON_LDS
+#define HZ_POSEIDON_LDS 0
+#endif
+template <int T> constexpr size_t poseidon_lds_bytes() { return HZ_POSEIDON_LDS ? (size_t)poseidon_const_frs<T>() * sizeof(Fr) : 0; }
+
+// Returns the width-T constant block; in LDS mode the whole block cooperates in copying it to
+// `lds` (advanced past the block) and the caller must __syncthreads() before the first use.
 template <int T>
-__device__ __forceinline__ void stage_poseidon_consts(Fr* dst) {
-    constexpr int NCW = poseidon_nconst<T>() * 9;  // 32-bit words (an Fr is 9 limbs)
-    constexpr int NMW = T * T * 9;
-    const uint32_t* gc = poseidon_c_global<T>();
-    const uint32_t* gm = poseidon_m_global<T>();
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-    for (int i = threadIdx.x; i < NCW; i += blockDim.x) d[i] = gc[i];
-    for (int i = threadIdx.x; i < NMW; i += blockDim.x) d[NCW + i] = gm[i];
+__device__ __forceinline__ const Fr* poseidon_consts(uint32_t*& lds) {
+#if HZ_POSEIDON_LDS
+    constexpr int NW = poseidon_const_frs<T>() * 9;  // 32-bit words (an Fr is 9 limbs)
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(poseidon_k_global<T>());
+    uint32_t* d = lds;
+    for (int i = threadIdx.x; i < NW; i += blockDim.x) d[i] = g[i];
+    lds += NW;
+    return reinterpret_cast<const Fr*>(d);
+#else
+    return poseidon_k_global<T>();
+#endif
 }
 
 // ---- 32-byte element I/O (canonical form) ------------------------------------------------------

@@ -289,7 +289,7 @@ struct EdSig {
     Fr enabled, zp;
     PtA R8, p0;
 };
-__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* C6, const Fr* M6, EdSig& out) {
+__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out) {
     const EdCtx c = K.with(io);
     const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
     const Fr S = sc.get(SC_ED_S), R8x = sc.get(SC_ED_R8X), R8y = sc.get(SC_ED_R8Y), M = sc.get(SC_SIGL2HASH);
@@ -322,7 +322,7 @@ __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const S
     }
     Fr hin[5] = {R8x, R8y, x, Ay, M};
     WitSboxSink s6 = io.sbox_sink(o.hash);
-    const Fr h = poseidon_hash<6>(hin, C6, M6, s6);
+    const Fr h = poseidon_hash<6>(hin, K6, s6);
     out.h_c = fr_to_canon(h);
     num2bits_strict_dev(io, o.h2bits, out.h_c, C_RTX_SIG_H_ALIAS);
     PtA A;
@@ -351,9 +351,8 @@ __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const S
 template <int G>
 __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C6 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M6 = C6 + poseidon_nconst<6>();
-    stage_poseidon_consts<6>(C6);
+    uint32_t* lds = lds_raw;
+    const Fr* K6 = poseidon_consts<6>(lds);
     __syncthreads();
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t nl = (n + G - 1) / G;
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
         io[g] = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
         const Scratch sc{a.scratch, a.n_units, i};
         EdSig sg;
-        ed_prologue(K, io[g], sc, o, C6, M6, sg);
+        ed_prologue(K, io[g], sc, o, K6, sg);
         h_c[g] = sg.h_c; S253[g] = sg.S253; enabled[g] = sg.enabled; zp[g] = sg.zp; R8[g] = sg.R8; p[g] = sg.p0;
     }
     // ---- mulAny = h * 8A: two SegmentMulAny (148 + 106 bits)
@@ -419,7 +418,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t nl = (n + HZ_ED_G - 1) / HZ_ED_G;
-    hipLaunchKernelGGL(k_eddsa<HZ_ED_G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<6>() * sizeof(Fr), s, a);
+    hipLaunchKernelGGL(k_eddsa<HZ_ED_G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
     return hipGetLastError();
 }
 

@@ -57,9 +57,8 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_fee_back(const FeeBackArgs a) {
 struct HsMainArgs { uint8_t* base; uint32_t N; HashStateOff hs; };
 __global__ __launch_bounds__(HZ_BLOCK) void k_hash_state_main(const HsMainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C5 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M5 = C5 + poseidon_nconst<5>();
-    stage_poseidon_consts<5>(C5);
+    uint32_t* lds = lds_raw;
+    const Fr* K5 = poseidon_consts<5>(lds);
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hash_state_main(const HsMainArgs a
     hin[0] = fr_add(fr_add(io.in_m(h.tokenID), fr_mul(io.in_m(h.nonce), m_pow2(32))), fr_mul(io.in_m(h.sign), m_pow2(72)));
     hin[1] = io.in_m(h.balance); hin[2] = io.in_m(h.ay); hin[3] = io.in_m(h.ethAddr);
     WitSboxSink s5 = io.sbox_sink(h.hash);
-    io.put_m(h.out, poseidon_hash<5>(hin, C5, M5, s5));
+    io.put_m(h.out, poseidon_hash<5>(hin, K5, s5));
 }
 
 // ---- HashInputs --------------------------------------------------------------------------------------
@@ -206,15 +205,10 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_sha_expand(const HashInputsArgs a)
 // ---- Withdraw: lane = instance -----------------------------------------------------------------------
 __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C5 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M5 = C5 + poseidon_nconst<5>();
-    Fr* C4 = M5 + 25;
-    Fr* M4 = C4 + poseidon_nconst<4>();
-    Fr* C3 = M4 + 16;
-    Fr* M3 = C3 + poseidon_nconst<3>();
-    stage_poseidon_consts<5>(C5);
-    stage_poseidon_consts<4>(C4);
-    stage_poseidon_consts<3>(C3);
+    uint32_t* lds = lds_raw;
+    const Fr* K5 = poseidon_consts<5>(lds);
+    const Fr* K4 = poseidon_consts<4>(lds);
+    const Fr* K3 = poseidon_consts<3>(lds);
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
@@ -231,16 +225,16 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
     hin[0] = fr_add(fr_from_canon(tokenID_c), fr_mul(io.in_m(o.sign), m_pow2(72)));
     hin[1] = fr_from_canon(balance_c); hin[2] = io.in_m(o.ay); hin[3] = fr_from_canon(ethAddr_c);
     WitSboxSink s5 = io.sbox_sink(o.accountState);
-    const Fr st = poseidon_hash<5>(hin, C5, M5, s5);
+    const Fr st = poseidon_hash<5>(hin, K5, s5);
     // SMTVerifier(n): enabled = 1, fnc = 0, oldKey = oldValue = isOld0 = 0
     const SmtVerOff& v = o.ver;
     Fr h1in[3] = {zero, zero, one};
     WitSboxSink so = io.sbox_sink(v.hash1Old);
-    const Fr h1old = poseidon_hash<4>(h1in, C4, M4, so);
+    const Fr h1old = poseidon_hash<4>(h1in, K4, so);
     (void)h1old;
     h1in[0] = idx; h1in[1] = st;
     WitSboxSink sn = io.sbox_sink(v.hash1New);
-    const Fr h1new = poseidon_hash<4>(h1in, C4, M4, sn);
+    const Fr h1new = poseidon_hash<4>(h1in, K4, sn);
     num2bits_strict_dev(io, v.n2bOld, fc_zero(), C_WD_N2B_OLD);
     num2bits_strict_dev(io, v.n2bNew, idx_c, C_WD_ALIAS_NEW);
     // SMTLevIns
@@ -296,7 +290,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
         h2[0] = sel ? sib : child;
         h2[1] = sel ? child : sib;
         WitSboxSink sk = io.sbox_sink(lv + VL_HASH);
-        const Fr ph = poseidon_hash<3>(h2, C3, M3, sk);
+        const Fr ph = poseidon_hash<3>(h2, K3, sk);
         const Fr a0 = ((topmask >> k) & 1) ? ph : zero;
         const Fr root = ((inewmask >> k) & 1) ? fr_add(a0, h1new) : a0;
         io.put_m(lv + VL_AUX0, a0); io.put_u64(lv + VL_AUX1, 0); io.put_m(lv + VL_ROOT, root);
@@ -396,7 +390,7 @@ hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s) {
 }
 hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff& hs, hipStream_t s) {
     HsMainArgs a{base, N, hs};
-    hipLaunchKernelGGL(k_hash_state_main, grid1(N), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<5>() * sizeof(Fr), s, a);
+    hipLaunchKernelGGL(k_hash_state_main, grid1(N), dim3(HZ_BLOCK), poseidon_lds_bytes<5>(), s, a);
     return hipGetLastError();
 }
 hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s) {
@@ -418,7 +412,7 @@ hipError_t launch_da_import(const DaArgs& a, hipStream_t s) {
 }
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_withdraw, grid1(a.N), dim3(HZ_BLOCK),
-                       (size_t)(poseidon_const_frs<5>() + poseidon_const_frs<4>() + poseidon_const_frs<3>()) * sizeof(Fr), s, a);
+                       poseidon_lds_bytes<5>() + poseidon_lds_bytes<4>() + poseidon_lds_bytes<3>(), s, a);
     return hipGetLastError();
 }
 

@@ -53,6 +53,10 @@ HZ_HD constexpr uint32_t fr_2p29(int i) {
     constexpr uint32_t k[9] = {0x00000002u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u, 0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
     return k[i];
 }
+HZ_HD constexpr uint32_t fr_4p29(int i) {
+    constexpr uint32_t k[9] = {0x00000004u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
+    return k[i];
+}
 HZ_HD constexpr uint32_t fr_r1(int i) {  // R mod p
     constexpr uint32_t k[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
     return k[i];
@@ -140,6 +144,21 @@ HZ_HD void fr_cond_sub_2p(uint32_t* t) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         const int32_t x = (int32_t)t[i] - (int32_t)fr_2p29(i) + c;
+        d[i] = (i < 8) ? (x & (int32_t)HZ_M29) : x;
+        c = x >> 29;
+    }
+    if (d[8] >= 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) t[i] = (uint32_t)d[i];
+    }
+}
+// t (normalised, value < 8p) -> t - 4p if t >= 4p
+HZ_HD void fr_cond_sub_4p(uint32_t* t) {
+    int32_t d[9];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t x = (int32_t)t[i] - (int32_t)fr_4p29(i) + c;
         d[i] = (i < 8) ? (x & (int32_t)HZ_M29) : x;
         c = x >> 29;
     }
@@ -276,7 +295,23 @@ HZ_HD Fr fr_dot(const Fr* a, const Fr* b, const Fr* addend = nullptr) {
     t[17] = 0;
     return fr_reduce_cols(t);
 }
-
+// (a*b + s*R) / R = a*b/R + s with one reduction: s enters the upper nine columns. a < p, b and s
+// normalised with b < 2^257, s < 8p; the result is normalised and < s + 1.01 p.
+HZ_HD Fr fr_muladd(const Fr& a, const Fr& b, const Fr& s) {
+    uint64_t t[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        uint64_t acc = k >= 9 ? s.v[k - 9] : 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 8) continue;
+            acc += (uint64_t)a.v[i] * b.v[j];
+        }
+        t[k] = acc;
+    }
+    return fr_reduce_cols(t);
+}
 
 // canonical -> Montgomery (also accepts any 256-bit integer)
 HZ_HD Fr fr_unpack(const Fc& c) {

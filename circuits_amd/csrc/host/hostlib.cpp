@@ -26,9 +26,9 @@ static void store(uint8_t* b, const Fr& m) {
 }
 
 template <int T>
-static Fr hash_t(const Fr* in, const uint32_t (*C)[9], const uint32_t (*M)[9]) {
+static Fr hash_t(const Fr* in, const uint32_t (*K)[9]) {
     NoSink s;
-    return poseidon_hash<T>(in, reinterpret_cast<const Fr*>(C), reinterpret_cast<const Fr*>(M), s);
+    return poseidon_hash<T>(in, reinterpret_cast<const Fr*>(K), s);
 }
 
 extern "C" int hzb_poseidon(int n_in, const uint8_t* in, uint8_t* out) {
@@ -37,12 +37,12 @@ extern "C" int hzb_poseidon(int n_in, const uint8_t* in, uint8_t* out) {
     for (int i = 0; i < n_in; i++) x[i] = load(in + 32 * i);
     Fr h;
     switch (n_in + 1) {
-        case 2: h = hash_t<2>(x, HZ_POSEIDON_C_T2, HZ_POSEIDON_M_T2); break;
-        case 3: h = hash_t<3>(x, HZ_POSEIDON_C_T3, HZ_POSEIDON_M_T3); break;
-        case 4: h = hash_t<4>(x, HZ_POSEIDON_C_T4, HZ_POSEIDON_M_T4); break;
-        case 5: h = hash_t<5>(x, HZ_POSEIDON_C_T5, HZ_POSEIDON_M_T5); break;
-        case 6: h = hash_t<6>(x, HZ_POSEIDON_C_T6, HZ_POSEIDON_M_T6); break;
-        default: h = hash_t<7>(x, HZ_POSEIDON_C_T7, HZ_POSEIDON_M_T7); break;
+        case 2: h = hash_t<2>(x, HZ_POSEIDON_K_T2); break;
+        case 3: h = hash_t<3>(x, HZ_POSEIDON_K_T3); break;
+        case 4: h = hash_t<4>(x, HZ_POSEIDON_K_T4); break;
+        case 5: h = hash_t<5>(x, HZ_POSEIDON_K_T5); break;
+        case 6: h = hash_t<6>(x, HZ_POSEIDON_K_T6); break;
+        default: h = hash_t<7>(x, HZ_POSEIDON_K_T7); break;
     }
     store(out, h);
     return 0;

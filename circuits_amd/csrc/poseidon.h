@@ -4,8 +4,11 @@
 // EdDSAPoseidonVerifier n=5). x^5 S-box, R_F = 8, R_P(t) = {56,57,56,60,60,63}[t-2],
 // state[0] = 0 (capacity first), state[1..] = inputs, out = state[0] after the last Mix.
 //
-// One permutation per lane. Round constants and the MDS matrix live in LDS (Montgomery form);
-// every lane reads the same address in the same cycle, i.e. an LDS broadcast, no bank conflicts.
+// One permutation per lane. The partial rounds are evaluated in the sparse form derived in
+// tools/poseidon_sparse.py: only lane 0 receives a constant and passes the S-box, lanes 1..T-1 are
+// updated with one product each, and lane 0's S-box inputs and outputs -- the only partial-round
+// values the witness holds -- are bit-identical to the circuit's dense evaluation (2T-1 constant
+// products per round instead of T^2). The oracle keeps the dense form.
 #pragma once
 #include "fr.h"
 
@@ -21,10 +24,27 @@ template <> struct PoseidonCfg<6> { static constexpr int RP = 60; };
 template <> struct PoseidonCfg<7> { static constexpr int RP = 63; };
 
 template <int T> constexpr int poseidon_rounds() { return 8 + PoseidonCfg<T>::RP; }
-template <int T> constexpr int poseidon_nconst() { return T * poseidon_rounds<T>(); }
 template <int T> constexpr int poseidon_nsbox() { return 8 * T + PoseidonCfg<T>::RP; }
-// number of Fr the constant block of width T occupies: C then M
-template <int T> constexpr int poseidon_const_frs() { return poseidon_nconst<T>() + T * T; }
+
+// Layout of the constant block of width T (gen/poseidon_consts.inc, HZ_POSEIDON_K_T<T>, written by
+// tools/gen_constants.py from tools/poseidon_sparse.py), in Fr units:
+//   HEAD   4T        Ark constants of full rounds 0..3 (round 0 in Montgomery form, the others c*R^2)
+//   E0     1         lane-0 constant of partial round 0 (c*R^2)
+//   PART   RP * 2T   per partial round: row[T], col[T-1] (Montgomery form), then the lane-0 constant
+//                    of the NEXT round (c*R^2; after the last partial round: lane 0 of the following
+//                    full round, with the pushed-forward constants folded in)
+//   DENSE  (T-1)^2   the pending lanes-1.. matrix applied once after the partial rounds
+//   CF     T-1       lanes 1.. of the full round that follows (c*R^2, pushed constants folded in)
+//   TAIL   3T        Ark constants of the last three full rounds (c*R^2)
+//   M      T*T       MDS matrix, row-major (Montgomery form)
+template <int T> constexpr int poseidon_k_e0() { return 4 * T; }
+template <int T> constexpr int poseidon_k_part() { return 4 * T + 1; }
+template <int T> constexpr int poseidon_k_dense() { return poseidon_k_part<T>() + PoseidonCfg<T>::RP * 2 * T; }
+template <int T> constexpr int poseidon_k_cf() { return poseidon_k_dense<T>() + (T - 1) * (T - 1); }
+template <int T> constexpr int poseidon_k_tail() { return poseidon_k_cf<T>() + (T - 1); }
+template <int T> constexpr int poseidon_k_m() { return poseidon_k_tail<T>() + 3 * T; }
+// number of Fr the constant block of width T occupies
+template <int T> constexpr int poseidon_const_frs() { return poseidon_k_m<T>() + T * T; }
 
 HZ_HD constexpr int poseidon_nsbox_rt(int t) {
     return 8 * t + (t == 2 ? 56 : t == 3 ? 57 : t == 4 ? 56 : t == 5 ? 60 : t == 6 ? 60 : 63);
@@ -44,68 +64,88 @@ HZ_HD Fr poseidon_sbox(const Fr& x, int k, Sink& sink) {
     return x5;
 }
 
+// one row of a constant matrix times the state, plus an optional c*R^2 addend, one reduction
+// (rows of more than 6 terms are split in two)
+template <int N>
+HZ_HD Fr poseidon_row(const Fr* row, const Fr* st, const Fr* addend) {
+    if constexpr (N <= 6) {
+        return fr_dot<N>(row, st, addend);
+    } else {
+        return fr_add(fr_dot<4>(row, st, addend), fr_dot<N - 4>(row + 4, st + 4));
+    }
+}
+
 // Mix followed by the next round's AddRoundConstants: out[i] = sum_j M[i][j] * st[j] + c[i], one lazily
-// reduced dot product per output (rows of more than 6 terms are split in two). `Cn` = the next round's
-// constants in c*R^2 form (nullptr after the last round): added to the column sums before the division
-// by R they cost 9 integer additions instead of a modular addition.
-template <int T>
+// reduced dot product per output. `Cn` = the next round's constants in c*R^2 form: added to the column
+// sums before the division by R they cost 9 integer additions instead of a modular addition.
+// NC = how many lanes receive a constant (T, or 1 before the first partial round).
+template <int T, int NC>
 HZ_HD void poseidon_mix_ark(Fr (&st)[T], const Fr* M, const Fr* Cn) {
     Fr o[T];
 #pragma unroll
-    for (int i = 0; i < T; i++) {
-        if constexpr (T <= 6) {
-            o[i] = fr_dot<T>(M + i * T, st, Cn ? Cn + i : nullptr);
-        } else {
-            o[i] = fr_add(fr_dot<4>(M + i * T, st, Cn ? Cn + i : nullptr), fr_dot<T - 4>(M + i * T + 4, st + 4));
-        }
-    }
+    for (int i = 0; i < T; i++) o[i] = poseidon_row<T>(M + i * T, st, i < NC ? Cn + i : nullptr);
 #pragma unroll
     for (int i = 0; i < T; i++) st[i] = o[i];
 }
 
-// Full permutation; `in` are the T-1 inputs (Montgomery). `C`/`M` point at the staged constants
-// (gen/poseidon_consts.inc: round 0 in Montgomery form, later rounds in c*R^2 form).
+// Full permutation; `in` are the T-1 inputs (Montgomery), K the constant block (layout above).
 // S-box k is numbered in evaluation order: 4 full rounds (T each), R_P partial, 4 full rounds.
 template <int T, class Sink>
-HZ_HD Fr poseidon_hash(const Fr* in, const Fr* C, const Fr* M, Sink& sink) {
+HZ_HD Fr poseidon_hash(const Fr* in, const Fr* K, Sink& sink) {
     constexpr int RP = PoseidonCfg<T>::RP;
+    const Fr* M = K + poseidon_k_m<T>();
     Fr st[T];
-    st[0] = C[0];
+    st[0] = K[0];
 #pragma unroll
-    for (int j = 1; j < T; j++) st[j] = fr_add(in[j - 1], C[j]);
+    for (int j = 1; j < T; j++) st[j] = fr_add(in[j - 1], K[j]);
     int k = 0;
-    int c = T;   // constants of the NEXT round
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 3; r++) {
 #pragma unroll
         for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
         k += T;
-        poseidon_mix_ark<T>(st, M, C + c);
-        c += T;
+        poseidon_mix_ark<T, T>(st, M, K + T * (r + 1));
     }
+#pragma unroll
+    for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
+    k += T;
+    poseidon_mix_ark<T, 1>(st, M, K + poseidon_k_e0<T>());
+    // partial rounds, sparse form: lane 0 <- row . (y, lanes) + next constant ; lane i <- lane i + col[i] * y.
+    // Lanes 1.. grow by at most ~1.01 p per round and are brought back below 4p every second round.
+    const Fr* S = K + poseidon_k_part<T>();
 #pragma unroll 1
     for (int r = 0; r < RP; r++) {
         st[0] = poseidon_sbox(st[0], k, sink);
         k += 1;
-        poseidon_mix_ark<T>(st, M, C + c);
-        c += T;
+        const Fr s0 = poseidon_row<T>(S, st, S + 2 * T - 1);
+#pragma unroll
+        for (int j = 1; j < T; j++) st[j] = fr_muladd(S[T + j - 1], st[0], st[j]);
+        st[0] = s0;
+        if (r & 1) {
+#pragma unroll
+            for (int j = 1; j < T; j++) fr_cond_sub_4p(st[j].v);
+        }
+        S += 2 * T;
+    }
+    {
+        // pending lanes-1.. matrix, with the constants of the following full round
+        Fr o[T];
+#pragma unroll
+        for (int i = 1; i < T; i++) o[i] = poseidon_row<T - 1>(K + poseidon_k_dense<T>() + (i - 1) * (T - 1), st + 1, K + poseidon_k_cf<T>() + (i - 1));
+#pragma unroll
+        for (int i = 1; i < T; i++) st[i] = o[i];
     }
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {
 #pragma unroll
         for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
         k += T;
-        poseidon_mix_ark<T>(st, M, C + c);
-        c += T;
+        poseidon_mix_ark<T, T>(st, M, K + poseidon_k_tail<T>() + T * r);
     }
 #pragma unroll
     for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
     // only state[0] of the last Mix is the digest
-    if constexpr (T <= 6) {
-        return fr_dot<T>(M, st);
-    } else {
-        return fr_add(fr_dot<4>(M, st), fr_dot<T - 4>(M + 4, st + 4));
-    }
+    return poseidon_row<T>(M, st, nullptr);
 }
 
 }  // namespace hz

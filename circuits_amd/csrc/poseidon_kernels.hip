@@ -16,16 +16,10 @@ namespace hz {
 template <int T, bool WIT>
 __global__ __launch_bounds__(256) void poseidon_batch_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                               uint8_t* __restrict__ wit, size_t n) {
-#ifdef HZ_POSEIDON_SCONST
-    const Fr* C = reinterpret_cast<const Fr*>(poseidon_c_global<T>());
-    const Fr* M = reinterpret_cast<const Fr*>(poseidon_m_global<T>());
-#else
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M = C + poseidon_nconst<T>();
-    stage_poseidon_consts<T>(C);
+    uint32_t* lds = lds_raw;
+    const Fr* K = poseidon_consts<T>(lds);
     __syncthreads();
-#endif
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         Fr x[T - 1];
@@ -34,10 +28,10 @@ __global__ __launch_bounds__(256) void poseidon_batch_kernel(const uint8_t* __re
         Fr h;
         if (WIT) {
             WitSboxSink sink{WitOut{wit, (uint32_t)n, (uint32_t)i}, 0u};
-            h = poseidon_hash<T>(x, C, M, sink);
+            h = poseidon_hash<T>(x, K, sink);
         } else {
             NoSink sink;
-            h = poseidon_hash<T>(x, C, M, sink);
+            h = poseidon_hash<T>(x, K, sink);
         }
         store_fr(out + i * 32, fr_to_canon(h));
     }
@@ -49,7 +43,7 @@ static hipError_t launch_poseidon(size_t n, const void* d_in, void* d_out, void*
     const int block = 256;
     size_t blocks = (n + block - 1) / block;
     if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 blocks per CU
-    const size_t lds = (size_t)poseidon_const_frs<T>() * sizeof(Fr);
+    const size_t lds = poseidon_lds_bytes<T>();
     if (d_wit)
         hipLaunchKernelGGL((poseidon_batch_kernel<T, true>), dim3((unsigned)blocks), dim3(block), lds, s,
                            (const uint8_t*)d_in, (uint8_t*)d_out, (uint8_t*)d_wit, n);

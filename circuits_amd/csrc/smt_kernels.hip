@@ -19,12 +19,9 @@ namespace hz {
 #endif
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HASH4_WAVES))) void k_hash4(const Hash4Args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C5 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M5 = C5 + poseidon_nconst<5>();
-    Fr* C4 = M5 + 25;
-    Fr* M4 = C4 + poseidon_nconst<4>();
-    stage_poseidon_consts<5>(C5);
-    stage_poseidon_consts<4>(C4);
+    uint32_t* lds = lds_raw;
+    const Fr* K5 = poseidon_consts<5>(lds);
+    const Fr* K4 = poseidon_consts<4>(lds);
     __syncthreads();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
@@ -35,7 +32,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HAS
     Fr hin[4];
     for (int k = 0; k < 4; k++) hin[k] = sc.get(J.sc_in + k);
     WitSboxSink s5 = io.sbox_sink(J.hs);
-    const Fr h = poseidon_hash<5>(hin, C5, M5, s5);
+    const Fr h = poseidon_hash<5>(hin, K5, s5);
     Fr value = h;
     if (J.mux_off != ~0u) {
         // s1OldValue / s2OldValue: Mux1(c0 = old state hash, c1 = oldValue input, s = isInsert)
@@ -46,7 +43,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HAS
     if (J.h1 == ~0u) return;
     Fr h1in[3] = {sc.get(J.sc_key), value, fr_one()};
     WitSboxSink s4 = io.sbox_sink(J.h1);
-    sc.set(J.sc_leaf, poseidon_hash<4>(h1in, C4, M4, s4));
+    sc.set(J.sc_leaf, poseidon_hash<4>(h1in, K4, s4));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -60,9 +57,8 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HAS
 #endif
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT_WAVES))) void k_smt(const SmtArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C3 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M3 = C3 + poseidon_nconst<3>();
-    stage_poseidon_consts<3>(C3);
+    uint32_t* lds = lds_raw;
+    const Fr* K3 = poseidon_consts<3>(lds);
     __syncthreads();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
@@ -172,7 +168,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
             hin[0] = sel ? sib : child;
             hin[1] = sel ? child : sib;
             WitSboxSink sk = io.sbox_sink(lv + LV_OLDHASH);
-            const Fr h = poseidon_hash<3>(hin, C3, M3, sk);
+            const Fr h = poseidon_hash<3>(hin, K3, sk);
             // st_bot + st_new1 + st_upd ; st_top
             const Fr s_a = k < kl ? zero : k == kl ? mU : k <= kx ? m : zero;
             const Fr aux0 = fr_mul(h1old, s_a);
@@ -192,7 +188,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
             hin[0] = sel ? swR : swL;
             hin[1] = sel ? swL : swR;
             WitSboxSink sk = io.sbox_sink(lv + LV_NEWHASH);
-            const Fr h = poseidon_hash<3>(hin, C3, M3, sk);
+            const Fr h = poseidon_hash<3>(hin, K3, sk);
             const Fr aux3 = fr_mul(h, fr_add(s_tb, s_n1));
             const Fr root = k == kl ? fr_add(aux3, fr_mul(h1new, OU)) : aux3;
             io.put_m(lv + LV_NEWSW_AUX, aux); io.put_m(lv + LV_AUX1, aux1); io.put_m(lv + LV_AUX2, aux2); io.put_m(lv + LV_AUX3, aux3);
@@ -208,13 +204,13 @@ static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
     dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
     g.y = a.n_jobs;
-    hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), (size_t)(poseidon_const_frs<5>() + poseidon_const_frs<4>()) * sizeof(Fr), s, a);
+    hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), poseidon_lds_bytes<5>() + poseidon_lds_bytes<4>(), s, a);
     return hipGetLastError();
 }
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s) {
     dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
     g.y = 2 * a.n_proc;
-    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), (size_t)poseidon_const_frs<3>() * sizeof(Fr), s, a);
+    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), poseidon_lds_bytes<3>(), s, a);
     return hipGetLastError();
 }
 

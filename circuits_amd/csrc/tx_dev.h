@@ -34,10 +34,10 @@ struct DecResult {
 };
 
 // DecodeTx. `IN` provides the signal offsets of the inputs inside the lane's section (MainTxInOff
-// or DecInOff share the member names used here). C7/M7 = staged Poseidon t=7 constants.
+// or DecInOff share the member names used here). K7 = Poseidon t=7 constant block.
 template <class IN>
 __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOff& o, const IN& in, int L, const Fr& previousOnChain,
-                                                   const Fr& inIdx, const Fr& globalChainID, const Fr& currentNumBatch, const Fr* C7, const Fr* M7) {
+                                                   const Fr& inIdx, const Fr& globalChainID, const Fr& currentNumBatch, const Fr* K7) {
     DecResult r;
     const Fr one = fr_one();
     const Fr onChain = io.in_m(in.onChain), newAccount = io.in_m(in.newAccount);
@@ -113,7 +113,7 @@ __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOf
         hin[0] = fr_from_canon(d); hin[1] = fr_from_canon(e1); hin[2] = io.in_m(in.toBjjAy); hin[3] = io.in_m(in.rqTxCompressedDataV2);
         hin[4] = io.in_m(in.rqToEthAddr); hin[5] = io.in_m(in.rqToBjjAy);
         WitSboxSink sink = io.sbox_sink(o.hashSig);
-        r.sigL2Hash = poseidon_hash<7>(hin, C7, M7, sink);
+        r.sigL2Hash = poseidon_hash<7>(hin, K7, sink);
     }
     // L1TxFullData (:285-324): every bit times onChain
     const Fc fe = io.in_c(in.fromEthAddr), la = io.in_c(in.loadAmountF);

@@ -43,9 +43,8 @@ struct FeeSrcRtx {
 
 __global__ __launch_bounds__(HZ_BLOCK) void k_main_front(const MainFrontArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C7 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M7 = C7 + poseidon_nconst<7>();
-    stage_poseidon_consts<7>(C7);
+    uint32_t* lds = lds_raw;
+    const Fr* K7 = poseidon_consts<7>(lds);
     __syncthreads();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_units = a.B * a.nTx;
@@ -73,7 +72,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_main_front(const MainFrontArgs a) 
     // B
     const Fr previousOnChain = i == 0 ? one : io.in_m_u(m.imOnChain, u - 1);
     const Fr inIdx = i == 0 ? glob(a.g.oldLastIdx) : io.in_m_u(m.imOutIdx, u - 1);
-    const DecResult d = decode_tx_dev(io, a.dec, m, (int)a.L, previousOnChain, inIdx, glob(a.g.globalChainID), glob(a.g.currentNumBatch), C7, M7);
+    const DecResult d = decode_tx_dev(io, a.dec, m, (int)a.L, previousOnChain, inIdx, glob(a.g.globalChainID), glob(a.g.currentNumBatch), K7);
     // C (:258-265)
     io.chk(C_MAIN_IM_V2, d.v2, io.in_m(m.txCompressedDataV2));
     if (i + 1 < a.nTx) {
@@ -124,16 +123,15 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_front(const RtxFrontArgs a) {
 
 __global__ __launch_bounds__(HZ_BLOCK) void k_dec_main(const DecMainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    Fr* C7 = reinterpret_cast<Fr*>(lds_raw);
-    Fr* M7 = C7 + poseidon_nconst<7>();
-    stage_poseidon_consts<7>(C7);
+    uint32_t* lds = lds_raw;
+    const Fr* K7 = poseidon_consts<7>(lds);
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
     io.put_u64(0, 1);
     decode_tx_dev(io, a.dec, a.in, (int)a.L, io.in_m(a.in.previousOnChain), io.in_m(a.in.inIdx), io.in_m(a.in.globalChainID),
-                  io.in_m(a.in.currentNumBatch), C7, M7);
+                  io.in_m(a.in.currentNumBatch), K7);
 }
 
 __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
@@ -175,7 +173,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_main_front, grid1(a.ucnt ? a.ucnt : a.B * a.nTx), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * sizeof(Fr), s, a);
+    hipLaunchKernelGGL(k_main_front, grid1(a.ucnt ? a.ucnt : a.B * a.nTx), dim3(HZ_BLOCK), poseidon_lds_bytes<7>(), s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
@@ -183,7 +181,7 @@ hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_main, grid1(a.N), dim3(HZ_BLOCK), (size_t)poseidon_const_frs<7>() * sizeof(Fr), s, a);
+    hipLaunchKernelGGL(k_dec_main, grid1(a.N), dim3(HZ_BLOCK), poseidon_lds_bytes<7>(), s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s) {
