@@ -34,6 +34,49 @@ def algorithmic_bytes_per_tx(L, F):
     return 32 * ((4 * L + 1473) + (974 * L + 14552 + 5 * F)) + packed
 
 
+def poseidon_rates(L, torch):
+    """BASELINE.json's second metric, Poseidon-BN254/sec: 2^20 permutations per launch, digest-only and with the
+    S-box witness (the circuit's Poseidon signals), HIP events on the launch stream."""
+    out = {}
+    n = 1 << 20
+    s = torch.cuda.current_stream().cuda_stream
+    for t in (3, 5):
+        nsbox = 8 * t + [56, 57, 56, 60, 60, 63][t - 2]
+        g = torch.Generator(device="cpu").manual_seed(t)
+        x = torch.randint(0, 2**31 - 1, (n * (t - 1), 8), dtype=torch.int32, generator=g)
+        x[:, 7] &= 0x0FFFFFFF  # < 2^252 < r
+        d_in = x.cuda()
+        d_out = torch.empty((n, 8), dtype=torch.int32, device="cuda")
+        d_wit = torch.empty((3 * nsbox * n, 8), dtype=torch.int32, device="cuda")
+        for mode, wit in (("digest", None), ("witness", d_wit.data_ptr())):
+            L.poseidon_batch_dev(t, n, d_in.data_ptr(), d_out.data_ptr(), wit, s)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                L.poseidon_batch_dev(t, n, d_in.data_ptr(), d_out.data_ptr(), wit, s)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            by = n * (32 * (t - 1) + 32 + (96 * nsbox if wit else 0))
+            out["t%d_%s" % (t, mode)] = {"perm_per_s": round(n / ms * 1e3, 0), "GBs": round(by / ms / 1e6, 1)}
+        del d_in, d_out, d_wit
+    return out
+
+
+def measured_traffic(kernel, bpl):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_hbm_counters.json,
+    collected by tools/profile.sh on the same command line); None when that file does not cover this configuration."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")))
+        if d.get("batches_per_launch") != bpl:
+            return None
+        k = d["kernels"][kernel]
+        return int(k["fetch_bytes"] + k["write_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(n_tx, L, max_l1, F):
     """The CPU oracle (restated CPU path, kind "port") on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -115,11 +158,15 @@ def main():
     ap.add_argument("--nLevels", type=int, default=32)
     ap.add_argument("--maxL1Tx", type=int, default=256)
     ap.add_argument("--maxFeeTx", type=int, default=64)
-    ap.add_argument("--inflight", type=int, default=1, help="independent batches in flight (contexts/streams)")
+    ap.add_argument("--inflight", type=int, default=2, help="contexts in flight (each with its own witness buffers and streams): the fee/SHA tail of one step overlaps the next step's kernels")
     ap.add_argument("--cpu-sample", type=int, default=256, help="nTx of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batches-per-launch", type=int, default=32,
                     help="independent batches evaluated by ONE set of kernel launches (context with n_instances = B): more wavefronts per launch")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon-BN254/sec secondary metric")
+    ap.add_argument("--calibrate-copy", action="store_true",
+                    help="profiling aid: one 1 GiB device-to-device tensor copy before the timed region, a known byte count that "
+                         "calibrates the FETCH_SIZE / WRITE_SIZE counters of a rocprofv3 --pmc pass (tools/profile.sh)")
     ap.add_argument("--shard-tx", action="store_true",
                     help="BASELINE config 4: shard ONE batch by transaction index over the ranks (one RCCL all_gather of the "
                          "data-availability records, FeeTx + HashInputs on rank 0); strong scaling. Default: independent batches per rank.")
@@ -178,6 +225,12 @@ def main():
             if pending[k]:
                 ctxs[k].check()
 
+    if args.calibrate_copy:
+        a = torch.zeros(1 << 28, dtype=torch.int32, device="cuda")
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        del a, b
     run_steps(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -218,9 +271,17 @@ def main():
     if rank == 0:
         total_tx = nTx * Bp * args.steps * world
         value = total_tx / dt
-        dom = max(acc.items(), key=lambda kv: kv[1][0])
-        dname, (dms, dbytes, dunits) = dom
+        # dominant kernel = most GPU time per step over all its launches (k_smt runs for the transactions and for the
+        # fee transactions); its roofline is quoted on the transaction launch
+        kern = {"smt": "k_smt", "fee_smt": "k_smt", "hash4": "k_hash4", "fee_hash": "k_hash4", "eddsa": "k_eddsa", "front": "k_main_front"}
+        tot = {}
+        for name, v in acc.items():
+            tot[kern.get(name, name)] = tot.get(kern.get(name, name), 0.0) + v[0]
+        dk = max(tot.items(), key=lambda kv: kv[1])[0]
+        dname = max((n for n in acc if kern.get(n, n) == dk), key=lambda n: acc[n][0])
+        dms, dbytes, dunits = acc[dname]
         achieved = dbytes / (dms * 1e-3) / 1e9
+        traffic = measured_traffic(dk, Bp)
         out = {
             "metric": "rollup-main tx-witnesses/sec (nTx=%d, nLevels=%d)" % (nTx, lv),
             "value": round(value, 1), "unit": "tx-witnesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,13 +290,18 @@ def main():
             "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "batches_per_launch": Bp, "contexts_in_flight": inflight,
                        "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
                        "witness_bytes_per_batch": ctxs[0].witness_len() * 32, "single_batch_latency_ms": round(single_ms, 3)},
-            "roofline": {"bound": "hbm", "kernel": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "note": "algorithmic bytes of the kernel's own witness signals / its mean launch duration; the path is integer-VALU bound (DESIGN.md)"},
+            "roofline": {"bound": "hbm", "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "launch_ms": round(dms, 3),
+                         "algorithmic_bytes_per_launch": int(dbytes), "gpu_ms_per_step_all_launches": round(tot[dk], 3),
+                         "note": "algorithmic bytes = 32 B x the witness signals this launch is responsible for; duration = HIP events on its "
+                                 "stream with the kernel alone on the device; traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes. "
+                                 "The kernel is integer-VALU issue bound, not HBM bound (DESIGN.md 4)"},
             "whole_pass": {"algorithmic_bytes_per_tx": algorithmic_bytes_per_tx(lv, F),
                            "achieved_GBs": round(algorithmic_bytes_per_tx(lv, F) * value / 1e9, 2)},
             "kernels_ms": {k: round(v[0], 3) for k, v in acc.items()},
         }
+        if world == 1 and not args.no_poseidon:
+            out["poseidon_bn254"] = poseidon_rates(L, torch)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, nTx), lv, min(m1, max(1, args.cpu_sample // 8)), F)
         print(json.dumps(out))

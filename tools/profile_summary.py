@@ -1,0 +1,101 @@
+"""Summarise the rocprofv3 outputs of tools/profile.sh into the files committed under profiles/:
+kernel_stats.csv (calls, total/average duration, share of GPU time) and hbm_counters.{csv,json}
+(FETCH_SIZE / WRITE_SIZE per dispatch, corrected with the calibration copy of the same run)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out, cmd = sys.argv[1], sys.argv[2]
+GIB = 1 << 30
+
+
+def short(n):
+    return n.split("(")[0].replace("void ", "").replace("hz::", "")
+
+
+# ---- kernel stats ----
+f = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    with open(out + "/kernel_stats.csv", "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats -- %s   (round 1, MI355X)\n" % cmd)
+        o.write("name,calls,total_duration_us,average_us,percentage\n")
+        for r in rows:
+            o.write("%s,%s,%.0f,%.1f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    # the same trace, largest-grid dispatches only (the transaction launch of each kernel): bench.py's last phase runs every
+    # kernel alone on the device three times -- the three shortest such dispatches are those, comparable with bench.py's
+    # roofline.launch_ms; the mean over all of them includes the launches that share the device with the other context
+    t = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)
+    if t:
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(t[0])):
+            per[short(r["Kernel_Name"])].append((int(r.get("Grid_Size", 0) or 0), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        with open(out + "/kernel_stats.csv", "a") as o:
+            o.write("# largest-grid dispatches of each kernel: count, mean us (all, incl. concurrent with the other context), mean us of the 3 shortest (kernel alone on the device)\n")
+            o.write("name,grid,calls,mean_us_all,mean_us_alone\n")
+            for k, v in sorted(per.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
+                g = max(x[0] for x in v)
+                d = sorted(x[1] for x in v if x[0] == g)
+                if d and sum(d) > 1000:
+                    o.write("%s,%d,%d,%.1f,%.1f\n" % (k, g, len(d), sum(d) / len(d), sum(d[:3]) / len(d[:3])))
+    print(open(out + "/kernel_stats.csv").read()[:2500])
+
+
+def pmc(kind):
+    f = glob.glob(out + "/pmc_%s/**/*counter_collection.csv" % kind, recursive=True)
+    acc = collections.defaultdict(list)
+    if not f:
+        return acc
+    per = collections.defaultdict(float)
+    name = {}
+    grid = {}
+    for r in csv.DictReader(open(f[0])):
+        per[r["Dispatch_Id"]] += float(r["Counter_Value"])
+        name[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+        grid[r["Dispatch_Id"]] = int(r.get("Grid_Size", 0) or 0)
+    for d, v in per.items():
+        acc[name[d]].append((v, grid[d]))
+    return acc
+
+
+fetch, write = pmc("fetch"), pmc("write")
+if fetch or write:
+    # calibration: the 1 GiB tensor copy (--calibrate-copy) is the largest elementwise copy kernel of the run
+    def cal(acc):
+        best = None
+        for k, v in acc.items():
+            if "elementwise" in k or "copy" in k.lower():
+                m = max(x[0] for x in v)
+                if best is None or m > best[1]:
+                    best = (k, m)
+        return best
+    cf, cw = cal(fetch), cal(write)
+    # rocprofv3 reports the derived counters in KiB
+    f_corr = (GIB / 1024.0) / cf[1] if cf and cf[1] > 0 else 1.0
+    w_corr = (GIB / 1024.0) / cw[1] if cw and cw[1] > 0 else 1.0
+    kernels = {}
+    with open(out + "/hbm_counters.csv", "w") as o:
+        o.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- %s --calibrate-copy\n" % cmd)
+        o.write("# raw values are the derived counters in KiB per dispatch. Calibration on the 1 GiB device-to-device copy of the same run:\n")
+        o.write("#   FETCH_SIZE reported %.0f KiB for 1048576 KiB read  -> correction x%.3f ; WRITE_SIZE reported %.0f KiB for 1048576 KiB written -> x%.3f\n"
+                % (cf[1] if cf else 0, f_corr, cw[1] if cw else 0, w_corr))
+        o.write("kernel,dispatches,max_grid,FETCH_SIZE_KiB_mean,FETCH_SIZE_KiB_max,WRITE_SIZE_KiB_mean,WRITE_SIZE_KiB_max\n")
+        for k in sorted(set(fetch) | set(write), key=lambda k: -max([x[0] for x in write.get(k, [(0, 0)])])):
+            fv = [x[0] for x in fetch.get(k, [])] or [0]
+            wv = [x[0] for x in write.get(k, [])] or [0]
+            g = max([x[1] for x in fetch.get(k, [])] + [x[1] for x in write.get(k, [])] + [0])
+            o.write("%s,%d,%d,%.1f,%.1f,%.1f,%.1f\n" % (k, max(len(fv), len(wv)), g, sum(fv) / len(fv), max(fv), sum(wv) / len(wv), max(wv)))
+            # the largest dispatch of a kernel is its transaction launch (the fee-transaction launch of the same kernel is small)
+            kernels["k_" + k.split("<")[0].replace("k_", "")] = {"fetch_bytes": max(fv) * 1024 * f_corr, "write_bytes": max(wv) * 1024 * w_corr}
+    bpl = 32
+    for tok in cmd.split():
+        pass
+    if "--batches-per-launch" in cmd:
+        bpl = int(cmd.split("--batches-per-launch")[1].split()[0])
+    json.dump({"command": cmd, "batches_per_launch": bpl, "fetch_correction": f_corr, "write_correction": w_corr,
+               "note": "bytes per LARGEST dispatch of each kernel (the transaction launch), corrected", "kernels": kernels},
+              open(out + "/hbm_counters.json", "w"), indent=1)
+    print(open(out + "/hbm_counters.csv").read()[:2500])
