@@ -32,7 +32,7 @@ if f:
     if t:
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(t[0])):
-            per[short(r["Kernel_Name"])].append((int(r.get("Grid_Size", 0) or 0), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+            per[short(r["Kernel_Name"])].append((int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
         with open(out + "/kernel_stats.csv", "a") as o:
             o.write("# largest-grid dispatches of each kernel: count, mean us (all, incl. concurrent with the other context), mean us of the 3 shortest (kernel alone on the device)\n")
             o.write("name,grid,calls,mean_us_all,mean_us_alone\n")
