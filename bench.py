@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--maxL1Tx", type=int, default=256)
     ap.add_argument("--maxFeeTx", type=int, default=64)
     ap.add_argument("--inflight", type=int, default=2, help="contexts in flight (each with its own witness buffers and streams): the fee/SHA tail of one step overlaps the next step's kernels")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="nTx of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=768, help="nTx of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batches-per-launch", type=int, default=32,
                     help="independent batches evaluated by ONE set of kernel launches (context with n_instances = B): more wavefronts per launch")
     ap.add_argument("--no-verify", action="store_true")
@@ -196,6 +196,15 @@ def main():
         return bench_sharded(args, L, bb, inp, rank, world, local, n_l2)
     Bp = max(1, args.batches_per_launch)
     inflight = max(1, min(args.inflight, args.steps if args.steps > 0 else 1))
+    # every batch keeps its whole witness resident (3.86 GB at the default shape): fit batches x contexts into free HBM
+    probe = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=1)
+    per_batch = probe.witness_len() * 32 * 1.04 + (64 << 20)
+    del probe
+    free_b, _total_b = torch.cuda.mem_get_info()
+    fit = int((free_b - (6 << 30)) // (per_batch * inflight))
+    if fit < Bp:
+        print("bench: %d batches x %d contexts do not fit %.0f GB of free HBM, using %d batches per launch" % (Bp, inflight, free_b / 1e9, max(1, fit)), file=sys.stderr)
+        Bp = max(1, fit)
     ctxs, streams = [], []
     for k in range(inflight):
         c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=Bp)
