@@ -275,12 +275,18 @@ class BatchBuilder:
         self.tx_meta = []  # per-tx facts used by get_single_tx_input
         ordered = [t for t in self.txs if t.get("onChain")] + [t for t in self.txs if not t.get("onChain")]
         self.txs = ordered
+        ETH_ADDR_ANY = (1 << 160) - 1
         for i in range(nTx):
             tx = ordered[i] if i < len(ordered) else {"onChain": 0, "nop": True}
+            # State transition of one transaction, restated from the circuit itself: selectors of
+            # src/rollup-tx-states.circom:99-313, balances of src/balance-updater.circom:56-105, leaf
+            # multiplexers and processors of src/rollup-tx.circom:318-591 (the JS BatchBuilder the
+            # reference calls at test/helpers/helpers.js:46 is not on disk).
             on = 1 if tx.get("onChain") else 0
             from_idx, to_idx = tx.get("fromIdx", 0), tx.get("toIdx", 0)
             amount = tx.get("amount", 0)
-            amount_f = fix2float(amount)
+            amount_f = tx["amountF"] if "amountF" in tx and "amount" not in tx else fix2float(amount)
+            amount = float2fix(amount_f)
             tx["amountF"] = amount_f
             load_f = tx.get("loadAmountF", 0)
             load_amount = float2fix(load_f)
@@ -288,92 +294,128 @@ class BatchBuilder:
             user_fee = tx.get("userFee", 0)
             new_account = 1 if (on and from_idx == 0) else 0
             aux_from = 0
+            aux_to = tx.get("auxToIdx", 0)
             zero_state = {"tokenID": 0, "nonce": 0, "sign": 0, "balance": 0, "ay": 0, "ethAddr": 0}
             st1, st2 = dict(zero_state), dict(zero_state)
             sib1, sib2 = [], []
             isold1 = isold2 = oldk1 = oldk2 = oldv1 = oldv2 = 0
             new_exit = 0
-            is_nullified = 0
             sig = {"r8x": 0, "r8y": 0, "s": 0}
             bjj = tx.get("fromBjjCompressed", 0)
             from_eth = tx.get("fromEthAddr", 0)
-            final_from = from_idx
-            if on:
+            if not on and (load_f or new_account):
+                raise ValueError("loadAmount / newAccount on an L2 tx (the circuit rejects this tx)")
+            if new_account:
+                db.last_idx += 1
+                aux_from = db.last_idx
+            final_from = aux_from if new_account else from_idx
+            final_to = aux_to if (not on and to_idx == 0) else to_idx
+            is_exit = final_to == EXIT_IDX
+            nop = final_from == 0
+            is_nullified = 0
+            if not nop:
+                # ---- sender leaf as processor 1 sees it
                 if new_account:
-                    db.last_idx += 1
-                    aux_from = db.last_idx
-                    final_from = aux_from
                     ay = bjj & ((1 << 254) - 1)
                     sg = (bjj >> 255) & 1
-                    new_st = {"tokenID": token, "nonce": 0, "sign": sg, "balance": load_amount, "ay": ay, "ethAddr": from_eth}
-                    res = db.state.insert(aux_from, hash_state(new_st))
-                    db.leaves[aux_from] = new_st
-                    # coordinator-chosen leaf data for an INSERT: tokenID1/ethAddr1 are forced equal to the tx
-                    st1 = {"tokenID": token, "nonce": 0, "sign": sg, "balance": 0, "ay": ay, "ethAddr": from_eth}
-                    sib1 = res["siblings"]
+                    # coordinator-chosen leaf data for an INSERT: the circuit takes every field from the tx
+                    old1 = {"tokenID": token, "nonce": 0, "sign": sg, "balance": 0, "ay": ay, "ethAddr": from_eth}
+                    st1 = dict(old1)
+                else:
+                    if from_idx not in db.leaves:
+                        raise ValueError("sender account %d does not exist" % from_idx)
+                    old1 = dict(db.leaves[from_idx])
+                    st1 = dict(old1)
+                if not on and token != old1["tokenID"]:
+                    raise ValueError("L2 tokenID does not match the sender leaf (the circuit rejects this tx)")
+                # ---- processor 2 key (src/rollup-tx-states.circom:213-221)
+                key2 = final_from if is_exit else (final_to if amount else 0)
+                p2_insert = is_exit and key2 not in exit_leaves
+                # ---- nullifiers (L1 only)
+                not_create = on and not new_account
+                null_eth = bool(not_create and amount and from_eth != old1["ethAddr"])
+                null_tok1 = bool(not_create and token != old1["tokenID"])
+                null_load = null_tok1 and load_amount != 0
+                # ---- balances
+                fee = compute_fee(amount, user_fee) if not on else 0
+                eff_load = 0 if (null_load or not on) else load_amount
+
+                # the leaf processor 2 works on; a state-tree receiver is read after processor 1 has written the sender
+                def receiver_leaf(sender_new):
+                    if is_exit:
+                        return dict(exit_leaves[key2]) if key2 in exit_leaves else None
+                    if key2 == final_from:
+                        return dict(sender_new)
+                    if key2 not in db.leaves:
+                        raise ValueError("receiver account %d does not exist" % key2)
+                    return dict(db.leaves[key2])
+                # tokenID2 does not depend on balances: probe the leaf before processor 1 runs
+                probe = receiver_leaf(old1) if amount else None
+                tok2 = probe["tokenID"] if probe is not None else None
+                null_tok2 = bool(on and amount and not p2_insert and probe is not None and token != tok2)
+                null_amount = bool(null_eth or null_tok2 or (null_tok1 and amount != 0))
+                eff_amount2 = 0 if null_amount else amount
+                underflow_ok = old1["balance"] + eff_load - eff_amount2 - fee >= 0
+                if not on and not underflow_ok:
+                    raise ValueError("L2 underflow (the circuit rejects this tx)")
+                eff_amount3 = eff_amount2 if underflow_ok else 0
+                is_nullified = 0 if (not null_amount and underflow_ok) else 1
+                new1 = dict(old1)
+                new1["balance"] = old1["balance"] + eff_load - eff_amount3 - fee
+                new1["nonce"] = old1["nonce"] + (0 if on else 1)
+                if not on:
+                    tx.setdefault("nonce", old1["nonce"])
+                if new_account:
+                    res = db.state.insert(final_from, hash_state(new1))
                     isold1 = 1 if res["isOld0"] else 0
                     oldk1 = 0 if res["isOld0"] else res["oldKey"]
                     oldv1 = 0 if res["isOld0"] else res["oldValue"]
-                    if amount:
-                        raise NotImplementedError("createAccountDepositTransfer")
-                elif from_idx:
-                    cur = db.leaves[from_idx]
-                    st1 = dict(cur)
-                    eff_load = load_amount if token == cur["tokenID"] else 0
-                    new_st = dict(cur)
-                    new_st["balance"] += eff_load
-                    res = db.state.update(from_idx, hash_state(new_st))
-                    db.leaves[from_idx] = new_st
-                    sib1 = res["siblings"]
-                    if amount:
-                        raise NotImplementedError("L1 transfers / force exit")
-            elif from_idx:
-                # L2 transfer or exit
-                cur = db.leaves[from_idx]
-                st1 = dict(cur)
-                tx.setdefault("nonce", cur["nonce"])
-                fee = compute_fee(amount, user_fee)
-                if cur["balance"] < amount + fee:
-                    raise ValueError("L2 underflow (the circuit rejects this tx)")
-                new_st = dict(cur)
-                new_st["nonce"] += 1
-                new_st["balance"] -= amount + fee
-                res = db.state.update(from_idx, hash_state(new_st))
-                db.leaves[from_idx] = new_st
+                else:
+                    res = db.state.update(final_from, hash_state(new1))
+                db.leaves[final_from] = new1
                 sib1 = res["siblings"]
-                if token in plan:
+                if not on and token in plan:
                     acc_fee[plan.index(token)] += fee
+                # ---- processor 2: NOP unless the transaction carries an amount (nullified or not)
                 if amount:
-                    if to_idx == EXIT_IDX:
-                        if from_idx in exit_leaves:
-                            ecur = exit_leaves[from_idx]
-                            st2 = dict(ecur)
-                            enew = dict(ecur)
-                            enew["balance"] += amount
-                            r2 = exit_tree.update(from_idx, hash_state(enew))
-                            exit_leaves[from_idx] = enew
-                            sib2 = r2["siblings"]
-                        else:
+                    if is_exit:
+                        if p2_insert:
                             new_exit = 1
-                            enew = {"tokenID": cur["tokenID"], "nonce": 0, "sign": cur["sign"], "balance": amount, "ay": cur["ay"], "ethAddr": cur["ethAddr"]}
-                            r2 = exit_tree.insert(from_idx, hash_state(enew))
-                            exit_leaves[from_idx] = enew
-                            sib2 = r2["siblings"]
+                            enew = {"tokenID": old1["tokenID"], "nonce": 0, "sign": old1["sign"], "balance": eff_amount3, "ay": old1["ay"], "ethAddr": old1["ethAddr"]}
+                            r2 = exit_tree.insert(key2, hash_state(enew))
                             isold2 = 1 if r2["isOld0"] else 0
                             oldk2 = 0 if r2["isOld0"] else r2["oldKey"]
                             oldv2 = 0 if r2["isOld0"] else r2["oldValue"]
+                        else:
+                            st2 = dict(exit_leaves[key2])
+                            enew = dict(st2)
+                            enew["balance"] += eff_amount3
+                            r2 = exit_tree.update(key2, hash_state(enew))
+                        exit_leaves[key2] = enew
+                        sib2 = r2["siblings"]
                     else:
-                        rcur = db.leaves[to_idx]
+                        rcur = receiver_leaf(new1)
+                        if not on and to_idx == 0:
+                            # transferToEthAddr / transferToBjj (src/rollup-tx.circom:253-276): the signed receiver must match
+                            # 0xFF..FF selects transferToBjj, and still has to equal the leaf's ethAddr (Bjj-only accounts hold 0xFF..FF)
+                            te = tx.get("toEthAddr", 0)
+                            if te != rcur["ethAddr"]:
+                                raise ValueError("toEthAddr does not match the receiver leaf (the circuit rejects this tx)")
+                            if te == ETH_ADDR_ANY and (tx.get("toBjjAy", 0) != rcur["ay"] or tx.get("toBjjSign", 0) != rcur["sign"]):
+                                raise ValueError("toBjj does not match the receiver leaf (the circuit rejects this tx)")
                         st2 = dict(rcur)
                         rnew = dict(rcur)
-                        rnew["balance"] += amount
-                        r2 = db.state.update(to_idx, hash_state(rnew))
-                        db.leaves[to_idx] = rnew
+                        rnew["balance"] += eff_amount3
+                        r2 = db.state.update(key2, hash_state(rnew))
+                        db.leaves[key2] = rnew
                         sib2 = r2["siblings"]
-                if "signer" in tx:
-                    sig = tx["signer"].sign_msg(build_hash_sig(tx, db.chain_id))
-                else:
-                    sig = {k: tx.get(k, 0) for k in ("r8x", "r8y", "s")}
+                elif not on:
+                    st2["tokenID"] = token   # processor 2 is a NOP, but the L2 receiver-token check still compares tokenID2 (src/rollup-tx.circom:270-274)
+                if not on:
+                    if "signer" in tx:
+                        sig = tx["signer"].sign_msg(build_hash_sig(tx, db.chain_id))
+                    else:
+                        sig = {k: tx.get(k, 0) for k in ("r8x", "r8y", "s")}
             txc = build_tx_compressed_data(tx, db.chain_id) if not on else (
                 CONST_SIG | (db.chain_id << 32) | (from_idx << 48) | (to_idx << 96) | (token << 144))
             inp["txCompressedData"].append(txc)

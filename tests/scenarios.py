@@ -1,0 +1,61 @@
+"""Batches that walk every transaction type of the table in reference src/rollup-tx-states.circom:41-54 and every L1
+nullifier row of :245-253 (test infrastructure shared by the CPU and the GPU suites)."""
+from circuits_amd import builder as B
+
+SHAPE = (14, 16, 10, 4)  # nTx, nLevels, maxL1Tx, maxFeeTx
+ETH_ANY = (1 << 160) - 1
+
+
+def all_tx_types():
+    """Returns (db, [batch1, batch2], facts). Batch 1 creates four accounts (the last one Bjj-only, token 2 on the third);
+    batch 2 holds one transaction of every type plus the invalid-L1 cases the circuit nullifies instead of rejecting."""
+    nTx, L, m1, F = SHAPE
+    db = B.RollupDB(chain_id=1)
+    acc = [B.Account(i + 1) for i in range(5)]
+
+    def l1(bb, **kw):
+        d = {"onChain": 1, "fromIdx": 0, "toIdx": 0, "tokenID": 1, "loadAmountF": 0}
+        d.update(kw)
+        bb.add_tx(d)
+
+    bb1 = db.build_batch(nTx, L, m1, F)
+    for a, amt, tok, eth in ((acc[0], 1000, 1, None), (acc[1], 2000, 1, None), (acc[2], 500, 2, None), (acc[4], 40, 1, ETH_ANY)):
+        l1(bb1, fromBjjCompressed=a.bjj_compressed, fromEthAddr=a.eth_addr if eth is None else eth, loadAmountF=B.fix2float(amt), tokenID=tok)
+    bb1.build()   # idx 256, 257 (token 1), 258 (token 2), 259 (Bjj-only account)
+
+    bb2 = db.build_batch(nTx, L, m1, F)
+    # createAccountDepositTransfer: account 260 with 300, 100 of it to 256
+    l1(bb2, fromBjjCompressed=acc[3].bjj_compressed, fromEthAddr=acc[3].eth_addr, loadAmountF=B.fix2float(300), toIdx=256, amount=100)
+    # depositTransfer
+    l1(bb2, fromIdx=257, fromEthAddr=acc[1].eth_addr, loadAmountF=B.fix2float(50), toIdx=256, amount=70)
+    # forceTransfer
+    l1(bb2, fromIdx=256, fromEthAddr=acc[0].eth_addr, toIdx=257, amount=10)
+    # forceExit creating the exit leaf, then updating it
+    l1(bb2, fromIdx=256, fromEthAddr=acc[0].eth_addr, toIdx=1, amount=20)
+    l1(bb2, fromIdx=256, fromEthAddr=acc[0].eth_addr, toIdx=1, amount=5)
+    # invalid L1: deposit with the wrong token (loadAmount nullified)
+    l1(bb2, fromIdx=257, fromEthAddr=acc[1].eth_addr, loadAmountF=B.fix2float(77), tokenID=2)
+    # invalid L1: forceTransfer signed by another ethAddr (amount nullified)
+    l1(bb2, fromIdx=257, fromEthAddr=acc[0].eth_addr, toIdx=256, amount=10)
+    # invalid L1: forceTransfer to an account of another token (amount nullified)
+    l1(bb2, fromIdx=257, fromEthAddr=acc[1].eth_addr, toIdx=258, amount=10)
+    # invalid L1: not enough funds (underflow, amount nullified)
+    l1(bb2, fromIdx=256, fromEthAddr=acc[0].eth_addr, toIdx=257, amount=10 ** 6)
+    # invalid L1: forceExit of more than the balance into a NEW exit leaf (inserted with balance 0)
+    l1(bb2, fromIdx=257, fromEthAddr=acc[1].eth_addr, toIdx=1, amount=10 ** 7)
+    # L2 transferToEthAddr, transferToBjj, exit onto the existing exit leaf, zero-amount transfer
+    bb2.add_tx({"fromIdx": 257, "toIdx": 0, "auxToIdx": 256, "toEthAddr": acc[0].eth_addr, "amount": 15, "tokenID": 1, "userFee": 100, "onChain": 0, "signer": acc[1]})
+    bb2.add_tx({"fromIdx": 257, "toIdx": 0, "auxToIdx": 259, "toEthAddr": ETH_ANY, "toBjjAy": acc[4].ay, "toBjjSign": acc[4].sign, "amount": 15, "tokenID": 1,
+                "userFee": 120, "onChain": 0, "signer": acc[1]})
+    bb2.add_tx({"fromIdx": 256, "toIdx": 1, "amount": 30, "tokenID": 1, "userFee": 90, "onChain": 0, "signer": acc[0]})
+    bb2.add_tx({"fromIdx": 257, "toIdx": 256, "amount": 0, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": acc[1]})
+    bb2.add_token(1)
+    bb2.add_fee_idx(256)
+    bb2.build()
+    facts = {
+        "nullified": [0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0],
+        # 256: 1000 +100 +70 -10 -20 -5 +15 -30 -fee(30,90) ; 257: 2000 +50 -70 +10 -15 -fee(15,100) -15 -fee(15,120) ; fees go to 256
+        "fee": B.compute_fee(15, 100) + B.compute_fee(15, 120) + B.compute_fee(30, 90),
+        "exit": {256: 55, 257: 0},
+    }
+    return db, [bb1, bb2], facts

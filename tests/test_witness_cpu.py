@@ -163,3 +163,26 @@ def test_host_field_inverse_safegcd_matches_fermat_and_python():
         h.hzb_fr_inv(x.to_bytes(32, "little"), a, b)
         e = pow(x, P - 2, P)
         assert int.from_bytes(a.raw, "little") == e and int.from_bytes(b.raw, "little") == e, x
+
+
+def test_oracle_every_transaction_type_and_l1_nullifier():
+    """Every row of the tx-type table (reference src/rollup-tx-states.circom:41-54) and of the L1 nullifier table (:245-253),
+    built by the generalised batch builder: all constraints hold in the oracle, the public hash matches the builder's
+    independent SHA-256, nullified amounts and balances come out as the circuit's rules say."""
+    from scenarios import SHAPE, all_tx_types
+    from circuits_amd import builder as B
+    db, batches, facts = all_tx_types()
+    for bb in batches:
+        o = OracleCtx("rollup-main", *SHAPE)
+        o.set_inputs(bb.get_input())
+        assert o.run() is None
+        assert o.get("main.hashGlobalInputs") == bb.get_hash_inputs()
+    bb = batches[1]
+    assert [m["isAmountNullified"] for m in bb.tx_meta] == facts["nullified"]
+    for i in range(SHAPE[0]):
+        assert o.get("main.rollupTx[%d].balanceUpdater.isAmountNullified" % i) == facts["nullified"][i]
+    f30 = B.compute_fee(30, 90)
+    assert db.leaves[256]["balance"] == 1000 + 100 + 70 - 10 - 20 - 5 + 15 - 30 - f30 + facts["fee"]
+    assert db.leaves[257]["balance"] == 2000 + 50 - 70 + 10 - 15 - 15 - (facts["fee"] - f30)
+    assert db.leaves[258]["balance"] == 500 and db.leaves[259]["balance"] == 40 + 15 and db.leaves[260]["balance"] == 200
+    assert {k: v["balance"] for k, v in bb.exit_leaves.items()} == facts["exit"]

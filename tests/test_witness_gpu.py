@@ -192,3 +192,19 @@ def test_copy_instance_inputs_replicates_on_device(hz):
     assert g.get("main.hashGlobalInputs", 2) == bb.get_hash_inputs()
     with pytest.raises(Exception):
         g.copy_instance_inputs(0, 3)
+
+
+def test_every_transaction_type_bit_exact(hz):
+    """Every transaction type and L1 nullifier row (tests/scenarios.py): whole witness buffer against the oracle."""
+    from scenarios import SHAPE, all_tx_types
+    _, batches, _ = all_tx_types()
+    nTx, L, m1, F = SHAPE
+    for bb in batches:
+        g = hz.ctx("rollup-main", nTx=nTx, nLevels=L, maxL1Tx=m1, maxFeeTx=F)
+        o = OracleCtx("rollup-main", *SHAPE)
+        g.set_inputs(bb.get_input())
+        o.set_inputs(bb.get_input())
+        g.run()
+        assert o.run() is None
+        assert g.get("main.hashGlobalInputs") == bb.get_hash_inputs()
+        _compare(g, o)
