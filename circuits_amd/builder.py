@@ -276,6 +276,27 @@ class BatchBuilder:
         ordered = [t for t in self.txs if t.get("onChain")] + [t for t in self.txs if not t.get("onChain")]
         self.txs = ordered
         ETH_ADDR_ANY = (1 << 160) - 1
+        # Atomic transactions (src/rq-tx-verifier.circom:34-45, src/rollup-main.circom:286-309): a tx with rqOffset k signs
+        # the txCompressedDataV2 / toEthAddr / toBjjAy of the tx at i+1..i+3 (k = 1..3) or i-4..i-1 (k = 4..7). Those fields
+        # hold the neighbour's nonce, so nonces are assigned in a pre-pass (each L2 tx consumes one of its sender's).
+        nonce_sim = {}
+        for t in ordered:
+            if not t.get("onChain") and t.get("fromIdx"):
+                f = t["fromIdx"]
+                cur = nonce_sim.get(f, db.leaves[f]["nonce"] if f in db.leaves else 0)
+                t.setdefault("nonce", cur)
+                nonce_sim[f] = cur + 1
+            if "amountF" not in t or "amount" in t:
+                t["amountF"] = fix2float(t.get("amount", 0))
+        for i, t in enumerate(ordered):
+            k = t.get("rqOffset", 0)
+            if k:
+                j = i + k if k <= 3 else i - (8 - k)
+                if not (0 <= j < len(ordered)) or ordered[j].get("onChain"):
+                    raise ValueError("rqOffset %d of tx %d does not point at an L2 tx of this batch" % (k, i))
+                t["rqTxCompressedDataV2"] = build_tx_compressed_data_v2(ordered[j])
+                t["rqToEthAddr"] = ordered[j].get("toEthAddr", 0)
+                t["rqToBjjAy"] = ordered[j].get("toBjjAy", 0)
         for i in range(nTx):
             tx = ordered[i] if i < len(ordered) else {"onChain": 0, "nop": True}
             # State transition of one transaction, restated from the circuit itself: selectors of
@@ -425,7 +446,8 @@ class BatchBuilder:
             inp["toIdx"].append(to_idx); inp["auxToIdx"].append(tx.get("auxToIdx", 0))
             inp["toBjjAy"].append(tx.get("toBjjAy", 0)); inp["toEthAddr"].append(tx.get("toEthAddr", 0))
             inp["maxNumBatch"].append(tx.get("maxNumBatch", 0)); inp["onChain"].append(on); inp["newAccount"].append(new_account)
-            inp["rqOffset"].append(0); inp["rqTxCompressedDataV2"].append(0); inp["rqToEthAddr"].append(0); inp["rqToBjjAy"].append(0)
+            inp["rqOffset"].append(tx.get("rqOffset", 0)); inp["rqTxCompressedDataV2"].append(tx.get("rqTxCompressedDataV2", 0))
+            inp["rqToEthAddr"].append(tx.get("rqToEthAddr", 0)); inp["rqToBjjAy"].append(tx.get("rqToBjjAy", 0))
             inp["s"].append(sig["s"]); inp["r8x"].append(sig["r8x"]); inp["r8y"].append(sig["r8y"])
             inp["loadAmountF"].append(load_f); inp["fromEthAddr"].append(from_eth)
             inp["fromBjjCompressed"].append([(bjj >> k) & 1 for k in range(256)])
@@ -519,13 +541,18 @@ class BatchBuilder:
         txc = inp["txCompressedData"][i]
         r = {
             "feePlanTokens": inp["feePlanTokens"], "accFeeIn": [0] * F,
-            "futureTxCompressedDataV2": [0] * 3, "pastTxCompressedDataV2": [0] * 4, "futureToEthAddr": [0] * 3, "pastToEthAddr": [0] * 4,
-            "futureToBjjAy": [0] * 3, "pastToBjjAy": [0] * 4,
+            "futureTxCompressedDataV2": [inp["txCompressedDataV2"][i + j + 1] if i + j + 1 < self.nTx else 0 for j in range(3)],
+            "pastTxCompressedDataV2": [inp["txCompressedDataV2"][i - j - 1] if i - j - 1 >= 0 else 0 for j in range(4)],
+            "futureToEthAddr": [inp["toEthAddr"][i + j + 1] if i + j + 1 < self.nTx else 0 for j in range(3)],
+            "pastToEthAddr": [inp["toEthAddr"][i - j - 1] if i - j - 1 >= 0 else 0 for j in range(4)],
+            "futureToBjjAy": [inp["toBjjAy"][i + j + 1] if i + j + 1 < self.nTx else 0 for j in range(3)],
+            "pastToBjjAy": [inp["toBjjAy"][i - j - 1] if i - j - 1 >= 0 else 0 for j in range(4)],
             "fromIdx": (txc >> 48) & ((1 << 48) - 1), "auxFromIdx": inp["auxFromIdx"][i], "toIdx": (txc >> 96) & ((1 << 48) - 1),
             "auxToIdx": inp["auxToIdx"][i], "toBjjAy": inp["toBjjAy"][i], "toBjjSign": (txc >> 224) & 1, "toEthAddr": inp["toEthAddr"][i],
             "amount": float2fix(inp["amountF"][i]), "tokenID": (txc >> 144) & 0xFFFFFFFF, "nonce": (txc >> 176) & ((1 << 40) - 1),
             "userFee": (txc >> 216) & 0xFF, "rqOffset": inp["rqOffset"][i], "onChain": inp["onChain"][i], "newAccount": inp["newAccount"][i],
-            "rqTxCompressedDataV2": 0, "rqToEthAddr": 0, "rqToBjjAy": 0, "sigL2Hash": self.tx_meta[i]["sigL2Hash"],
+            "rqTxCompressedDataV2": inp["rqTxCompressedDataV2"][i], "rqToEthAddr": inp["rqToEthAddr"][i], "rqToBjjAy": inp["rqToBjjAy"][i],
+            "sigL2Hash": self.tx_meta[i]["sigL2Hash"],
             "s": inp["s"][i], "r8x": inp["r8x"][i], "r8y": inp["r8y"][i], "fromEthAddr": inp["fromEthAddr"][i],
             "fromBjjCompressed": inp["fromBjjCompressed"][i], "loadAmountF": inp["loadAmountF"][i],
             "oldStateRoot": inp["imStateRoot"][i - 1] if i > 0 else inp["oldStateRoot"],

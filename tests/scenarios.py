@@ -59,3 +59,24 @@ def all_tx_types():
         "exit": {256: 55, 257: 0},
     }
     return db, [bb1, bb2], facts
+
+
+def atomic_pair():
+    """Two linked L2 transfers (reference src/rq-tx-verifier.circom): tx 0 requires tx 1 (rqOffset 1 = next), tx 1 requires tx 0
+    (rqOffset 7 = previous), a third requires the tx three places ahead (rqOffset 3); one carries maxNumBatch."""
+    nTx, L, m1, F = 8, 16, 2, 2
+    db = B.RollupDB(chain_id=1)
+    a, b = B.Account(11), B.Account(12)
+    bb = db.build_batch(nTx, L, m1, F)
+    for k in (a, b):
+        bb.add_tx({"onChain": 1, "fromIdx": 0, "toIdx": 0, "tokenID": 1, "loadAmountF": B.fix2float(1000), "fromBjjCompressed": k.bjj_compressed, "fromEthAddr": k.eth_addr})
+    bb.build()
+    bb2 = db.build_batch(nTx, L, m1, F)
+    bb2.add_tx({"fromIdx": 256, "toIdx": 257, "amount": 10, "tokenID": 1, "userFee": 50, "onChain": 0, "signer": a, "rqOffset": 1})
+    bb2.add_tx({"fromIdx": 257, "toIdx": 256, "amount": 20, "tokenID": 1, "userFee": 60, "onChain": 0, "signer": b, "rqOffset": 7, "maxNumBatch": 5})
+    bb2.add_tx({"fromIdx": 256, "toIdx": 257, "amount": 1, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": a, "rqOffset": 3})
+    bb2.add_tx({"fromIdx": 256, "toIdx": 257, "amount": 2, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": a})
+    bb2.add_tx({"fromIdx": 257, "toIdx": 0, "auxToIdx": 256, "toEthAddr": a.eth_addr, "amount": 3, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": b, "rqOffset": 4 + 2})
+    bb2.add_tx({"fromIdx": 257, "toIdx": 256, "amount": 4, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": b})
+    bb2.build()
+    return (nTx, L, m1, F), [bb, bb2]

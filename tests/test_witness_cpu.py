@@ -186,3 +186,29 @@ def test_oracle_every_transaction_type_and_l1_nullifier():
     assert db.leaves[257]["balance"] == 2000 + 50 - 70 + 10 - 15 - 15 - (facts["fee"] - f30)
     assert db.leaves[258]["balance"] == 500 and db.leaves[259]["balance"] == 40 + 15 and db.leaves[260]["balance"] == 200
     assert {k: v["balance"] for k, v in bb.exit_leaves.items()} == facts["exit"]
+
+
+def test_oracle_atomic_transactions_and_single_tx_slices():
+    """rqOffset links (reference src/rq-tx-verifier.circom:34-94) inside RollupMain, and the same transactions one by one through
+    RollupTx with the neighbour data sliced out the way reference test/helpers/helpers.js:45-137 does."""
+    from scenarios import atomic_pair
+    shape, batches = atomic_pair()
+    for bb in batches:
+        o = OracleCtx("rollup-main", *shape)
+        o.set_inputs(bb.get_input())
+        assert o.run() is None
+        assert o.get("main.hashGlobalInputs") == bb.get_hash_inputs()
+    bb = batches[1]
+    for i in range(6):
+        tin, tout = bb.get_single_tx_input(i)
+        o = OracleCtx("rollup-tx", nLevels=shape[1], maxFeeTx=shape[3])
+        o.set_inputs(tin)
+        assert o.run() is None, i
+        assert o.get("main.newStateRoot") == tout["newStateRoot"]
+    # a broken link is a constraint failure
+    bad = dict(bb.get_input())
+    bad["rqOffset"] = list(bad["rqOffset"])
+    bad["rqOffset"][0] = 2
+    o = OracleCtx("rollup-main", *shape)
+    o.set_inputs(bad)
+    assert o.run() is not None

@@ -208,3 +208,25 @@ def test_every_transaction_type_bit_exact(hz):
         assert o.run() is None
         assert g.get("main.hashGlobalInputs") == bb.get_hash_inputs()
         _compare(g, o)
+
+
+def test_atomic_transactions_bit_exact(hz):
+    from scenarios import atomic_pair
+    shape, batches = atomic_pair()
+    for bb in batches:
+        g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3])
+        o = OracleCtx("rollup-main", *shape)
+        g.set_inputs(bb.get_input())
+        o.set_inputs(bb.get_input())
+        g.run()
+        assert o.run() is None
+        _compare(g, o)
+    tin, tout = batches[1].get_single_tx_input(4)
+    g = hz.ctx("rollup-tx", nLevels=shape[1], maxFeeTx=shape[3])
+    o = OracleCtx("rollup-tx", nLevels=shape[1], maxFeeTx=shape[3])
+    g.set_inputs(tin)
+    o.set_inputs(tin)
+    g.run()
+    assert o.run() is None
+    _compare(g, o)
+    assert g.get("main.newStateRoot") == tout["newStateRoot"]
