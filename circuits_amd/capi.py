@@ -60,7 +60,7 @@ EXPORTS = [
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
-    "hz_poseidon_batch_dev", "hz_shard_range",
+    "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym",
 ]
 
 
@@ -102,6 +102,10 @@ class Lib:
         c.hz_witness_read_raw.argtypes = [vp, u64, u64, vp]
         c.hz_witness_dev_ptr.argtypes = [vp]
         c.hz_witness_dev_ptr.restype = vp
+        c.hz_set_inputs_json.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t]
+        c.hz_witness_write_json.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p]
+        c.hz_witness_write_wtns.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p]
+        c.hz_symbols_write_sym.argtypes = [vp, ctypes.c_char_p]
         c.hz_symbol_get.argtypes = [vp, u64, ctypes.POINTER(hz_symbol)]
         c.hz_symbol_lookup.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(u64)]
         c.hz_constraint_name.restype = ctypes.c_char_p
@@ -225,6 +229,19 @@ class Ctx:
     def check(self):
         err = hz_error()
         self._raise(self.L.c.hz_witness_check(self.h, ctypes.byref(err)), err)
+
+    def set_inputs_json(self, text, instance=0):
+        b = text.encode() if isinstance(text, str) else text
+        self.L._check(self.L.c.hz_set_inputs_json(self.h, instance, b, len(b)))
+
+    def write_wtns(self, path, instance=0):
+        self.L._check(self.L.c.hz_witness_write_wtns(self.h, instance, path.encode()))
+
+    def write_json(self, path, instance=0):
+        self.L._check(self.L.c.hz_witness_write_json(self.h, instance, path.encode()))
+
+    def write_sym(self, path):
+        self.L._check(self.L.c.hz_symbols_write_sym(self.h, path.encode()))
 
     def read(self, first, count, instance=0):
         buf = ctypes.create_string_buffer(32 * max(count, 1))

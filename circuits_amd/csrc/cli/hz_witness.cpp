@@ -1,0 +1,141 @@
+// hz_witness -- the native witness binary of the MI355X generator: the counterpart of the circom-generated
+// `./circuit input.json witness.json` the reference runs at tools/helpers/actions.js:132-146 (and of
+// `snarkjs wtns calculate` for the .wtns output). Plain C++ over the C ABI of include/hermez_witness.h.
+//
+//   hz_witness "RollupMain(2048,32,256,64)" input.json witness.wtns [--sym circuit.sym] [--device 0]
+//   hz_witness path/to/main.circom input.json witness.json
+//
+// The first argument is `Template(params)` or a .circom file whose `component main = Template(params);` line is
+// used (the reference writes exactly such files: tools/build-circuit.js, test/*.test.js). The output format follows
+// the extension (.wtns binary, anything else witness.json). Exit status 1 and the reference's error text
+// ("Constraint doesn't match <lhs> != <rhs>") when a constraint fails.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../../include/hermez_witness.h"
+
+static std::string slurp(const char* path, bool* ok) {
+    std::string s;
+    FILE* f = fopen(path, "rb");
+    *ok = f != nullptr;
+    if (!f) return s;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    return s;
+}
+
+static std::string dec(const uint8_t* b) {
+    uint32_t w[8];
+    memcpy(w, b, 32);
+    std::string out;
+    bool nz = true;
+    while (nz) {
+        uint64_t rem = 0;
+        nz = false;
+        for (int i = 7; i >= 0; i--) {
+            const uint64_t cur = (rem << 32) | w[i];
+            w[i] = (uint32_t)(cur / 10);
+            rem = cur % 10;
+            if (w[i]) nz = true;
+        }
+        out.insert(out.begin(), (char)('0' + rem));
+    }
+    return out;
+}
+
+struct Tmpl { const char* name; int id; int nparams; int order[4]; };   // order: index into {nTx, nLevels, maxL1Tx, maxFeeTx}
+static const Tmpl TEMPLATES[] = {
+    {"RollupMain", HZ_T_ROLLUP_MAIN, 4, {0, 1, 2, 3}}, {"RollupTx", HZ_T_ROLLUP_TX, 2, {1, 3, 0, 0}}, {"DecodeTx", HZ_T_DECODE_TX, 1, {1, 0, 0, 0}},
+    {"FeeTx", HZ_T_FEE_TX, 1, {1, 0, 0, 0}}, {"HashState", HZ_T_HASH_STATE, 0, {0, 0, 0, 0}}, {"Withdraw", HZ_T_WITHDRAW, 1, {1, 0, 0, 0}},
+    {"HashInputs", HZ_T_HASH_INPUTS, 4, {1, 0, 2, 3}},
+};
+
+static bool parse_main(std::string spec, hz_params* p) {
+    const size_t at = spec.find("component main");
+    if (at != std::string::npos) {
+        const size_t eq = spec.find('=', at);
+        if (eq == std::string::npos) return false;
+        spec = spec.substr(eq + 1);
+    }
+    size_t i = 0;
+    while (i < spec.size() && (spec[i] == ' ' || spec[i] == '\t' || spec[i] == '\n')) i++;
+    size_t j = i;
+    while (j < spec.size() && (isalnum((unsigned char)spec[j]) || spec[j] == '_')) j++;
+    const std::string name = spec.substr(i, j - i);
+    const size_t lp = spec.find('(', j), rp = spec.find(')', j);
+    if (lp == std::string::npos || rp == std::string::npos || rp < lp) return false;
+    std::vector<int> args;
+    const std::string inner = spec.substr(lp + 1, rp - lp - 1);
+    const char* q = inner.c_str();
+    while (*q) {
+        while (*q == ' ' || *q == ',') q++;
+        if (!*q) break;
+        char* end;
+        args.push_back((int)strtol(q, &end, 10));
+        if (end == q) return false;
+        q = end;
+    }
+    for (const Tmpl& t : TEMPLATES) {
+        if (name == t.name) {
+            if ((int)args.size() != t.nparams) return false;
+            int v[4] = {0, 0, 0, 0};
+            for (int k = 0; k < t.nparams; k++) v[t.order[k]] = args[k];
+            memset(p, 0, sizeof *p);
+            p->template_id = t.id; p->nTx = v[0]; p->nLevels = v[1]; p->maxL1Tx = v[2]; p->maxFeeTx = v[3];
+            return true;
+        }
+    }
+    return false;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        fprintf(stderr, "usage: %s \"Template(params)\"|main.circom input.json witness.{wtns,json} [--sym out.sym] [--device N]\n", argv[0]);
+        return 2;
+    }
+    const char* sym = nullptr;
+    int device = 0;
+    for (int i = 4; i < argc; i++) {
+        if (!strcmp(argv[i], "--sym") && i + 1 < argc) sym = argv[++i];
+        else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    std::string spec = argv[1];
+    bool ok;
+    if (spec.find('(') == std::string::npos) {
+        spec = slurp(argv[1], &ok);
+        if (!ok) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
+    }
+    hz_params p;
+    if (!parse_main(spec, &p)) { fprintf(stderr, "no supported `component main = Template(params)` in %s\n", argv[1]); return 2; }
+    p.device = device;
+    p.n_instances = 1;
+    const std::string input = slurp(argv[2], &ok);
+    if (!ok) { fprintf(stderr, "cannot read %s\n", argv[2]); return 2; }
+    hz_ctx* c = nullptr;
+    if (hz_ctx_create(&p, &c) != HZ_OK) { fprintf(stderr, "%s\n", hz_last_error()); return 1; }
+    int rc = 0;
+    hz_error err;
+    hz_status st = hz_set_inputs_json(c, 0, input.data(), input.size());
+    if (st == HZ_OK) st = hz_witness_run(c, &err);
+    if (st == HZ_ERR_CONSTRAINT) {
+        fprintf(stderr, "Error: Constraint doesn't match %s != %s (%s, unit %d)\n", dec(err.lhs).c_str(), dec(err.rhs).c_str(),
+                hz_constraint_name(err.constraint_id), err.unit);
+        rc = 1;
+    } else if (st != HZ_OK) {
+        fprintf(stderr, "Error: %s\n", hz_last_error());
+        rc = 1;
+    } else {
+        const size_t n = strlen(argv[3]);
+        const bool wtns = n > 5 && !strcmp(argv[3] + n - 5, ".wtns");
+        st = wtns ? hz_witness_write_wtns(c, 0, argv[3]) : hz_witness_write_json(c, 0, argv[3]);
+        if (st == HZ_OK && sym) st = hz_symbols_write_sym(c, sym);
+        if (st != HZ_OK) { fprintf(stderr, "Error: %s\n", hz_last_error()); rc = 1; }
+    }
+    hz_ctx_destroy(c);
+    return rc;
+}

@@ -137,6 +137,17 @@ uint64_t hz_witness_total(const hz_ctx* ctx);
 hz_status hz_witness_read_raw(hz_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out);
 const void* hz_witness_dev_ptr(const hz_ctx* ctx);
 
+/* wire / disk formats ------------------------------------------------------------
+ * hz_set_inputs_json: the input.json the reference's tools write (tools/generate-input.js:109; decimal strings, bare
+ *   integers, 0x-hex, nested arrays; values reduced mod r) -> hz_set_input per key.
+ * hz_witness_write_json: witness.json, array of decimal strings (tools/helpers/actions.js:136-139).
+ * hz_witness_write_wtns: snarkjs .wtns (version 2: header section {n8 = 32, prime, nVars}, data section nVars x 32 B LE).
+ * hz_symbols_write_sym: circom .sym lines `labelIdx,varIdx,componentIdx,name` for the stored signals. */
+hz_status hz_set_inputs_json(hz_ctx* ctx, int32_t instance, const char* json, size_t len);
+hz_status hz_witness_write_json(hz_ctx* ctx, int32_t instance, const char* path);
+hz_status hz_witness_write_wtns(hz_ctx* ctx, int32_t instance, const char* path);
+hz_status hz_symbols_write_sym(const hz_ctx* ctx, const char* path);
+
 /* symbols ------------------------------------------------------------------------------------ */
 uint64_t hz_symbol_count(const hz_ctx* ctx);
 hz_status hz_symbol_get(const hz_ctx* ctx, uint64_t i, hz_symbol* out);

@@ -230,3 +230,64 @@ def test_atomic_transactions_bit_exact(hz):
     assert o.run() is None
     _compare(g, o)
     assert g.get("main.newStateRoot") == tout["newStateRoot"]
+
+
+def _parse_wtns(path):
+    import struct
+    b = open(path, "rb").read()
+    assert b[:4] == b"wtns" and struct.unpack_from("<II", b, 4) == (2, 2)
+    sid, size = struct.unpack_from("<IQ", b, 12)
+    assert (sid, size) == (1, 40)
+    n8, = struct.unpack_from("<I", b, 24)
+    prime = int.from_bytes(b[28:60], "little")
+    nvars, = struct.unpack_from("<I", b, 60)
+    sid2, size2 = struct.unpack_from("<IQ", b, 64)
+    assert n8 == 32 and prime == P and sid2 == 2 and size2 == 32 * nvars and len(b) == 76 + size2
+    return [int.from_bytes(b[76 + 32 * i:108 + 32 * i], "little") for i in range(nvars)]
+
+
+def test_native_witness_binary_and_file_formats(hz, batch, tmp_path):
+    """The native witness binary (`./circuit input.json witness.json` of reference tools/helpers/actions.js:132-146): input.json in,
+    .wtns / witness.json / .sym out, identical to the witness read through the C ABI; a violated constraint exits 1 with the
+    reference's error text."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "circuits_amd", "bin", "hz_witness")
+    inp = batch.get_input()
+    # the way the reference's tools stringify BigInts, with a hex literal and a negative number thrown in
+    js = {k: (v if not isinstance(v, int) else str(v)) for k, v in inp.items()}
+    js["oldStateRoot"] = hex(inp["oldStateRoot"])
+    js["globalChainID"] = str(inp["globalChainID"] - P)
+    js["siblings1"] = [[str(x) for x in row] for row in inp["siblings1"]]
+    ipath, wpath, jpath, spath = (str(tmp_path / n) for n in ("input.json", "w.wtns", "w.json", "c.sym"))
+    json.dump(js, open(ipath, "w"))
+    main = str(tmp_path / "main.circom")
+    open(main, "w").write('include "../src/rollup-main.circom";\ncomponent main = RollupMain(8, 16, 3, 4);\n')
+    subprocess.run([cli, main, ipath, wpath, "--sym", spath], check=True)
+    subprocess.run([cli, "RollupMain(8,16,3,4)", ipath, jpath], check=True)
+    g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4)
+    g.set_inputs(inp)
+    g.run()
+    ref = g.read(0, g.witness_len())
+    assert ref[0] == 1
+    assert _parse_wtns(wpath) == ref
+    assert [int(x) for x in json.load(open(jpath))] == ref
+    sym = [l.rstrip("\n").split(",") for l in open(spath)]
+    assert len(sym) == g.symbol_count()
+    idx = g.lookup("main.hashGlobalInputs")
+    assert [str(idx), str(idx), "0", "main.hashGlobalInputs"] in sym
+    # ABI writers give the same files
+    g.write_wtns(str(tmp_path / "w2.wtns"))
+    assert open(str(tmp_path / "w2.wtns"), "rb").read() == open(wpath, "rb").read()
+    # constraint failure: wrong intermediate root
+    bad = dict(js)
+    bad["imStateRoot"] = [str(int(x) + 1) for x in inp["imStateRoot"]]
+    json.dump(bad, open(ipath, "w"))
+    r = subprocess.run([cli, "RollupMain(8,16,3,4)", ipath, jpath], capture_output=True, text=True)
+    assert r.returncode == 1 and "Constraint doesn't match" in r.stderr
+    # malformed input
+    open(ipath, "w").write('{"oldLastIdx": "12a"}')
+    r = subprocess.run([cli, "RollupMain(8,16,3,4)", ipath, jpath], capture_output=True, text=True)
+    assert r.returncode == 1 and "oldLastIdx" in r.stderr
