@@ -149,6 +149,82 @@ def bench_sharded(args, L, bb, inp, rank, world, local, n_l2):
         dist.destroy_process_group()
 
 
+def bench_withdraw(args, L, rank, world, local):
+    """BASELINE config 5: 2^20 independent Withdraw(nLevels) witnesses (SMTVerifier + HashState + 2-block SHA-256 bit witness),
+    `--withdraw-per-launch` instances per kernel launch, exits drawn from one exit tree. One lane per witness."""
+    import torch
+    import torch.distributed as dist
+    from circuits_amd import builder as B
+    lv = args.nLevels
+    n_leaves = 256
+    db = B.RollupDB(chain_id=1)
+    keys = [B.Account(900 + i) for i in range(8)]
+    nTx = 2 * n_leaves
+    bb = db.build_batch(nTx, lv, n_leaves, 1)
+    for i in range(n_leaves):
+        a = keys[i % 8]
+        bb.add_tx({"fromIdx": 0, "loadAmountF": B.fix2float(1000 + i), "tokenID": 1, "fromBjjCompressed": a.bjj_compressed, "fromEthAddr": a.eth_addr, "toIdx": 0, "onChain": 1})
+    bb.build()
+    bb2 = db.build_batch(nTx, lv, n_leaves, 1)
+    for i in range(n_leaves):
+        bb2.add_tx({"fromIdx": 256 + i, "toIdx": 1, "amount": 10 + i, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": keys[i % 8]})
+    bb2.build()
+    ins = [B.withdraw_input(bb2, 256 + i, lv) for i in range(n_leaves)]
+    N = args.withdraw_per_launch
+    free_b, _ = torch.cuda.mem_get_info()
+    probe = L.ctx("withdraw", nLevels=lv, device=local, n_instances=1)
+    wl = probe.witness_len()
+    del probe
+    N = max(64, min(N, int((free_b - (6 << 30)) // (wl * 32 * 1.02)) // 64 * 64))
+    c = L.ctx("withdraw", nLevels=lv, device=local, n_instances=N)
+    names = [n for n, _ in c.input_names()]
+    for name in names:
+        rows = [ins[k % n_leaves][0][name] for k in range(N)]
+        c.set_input(name, rows, instance=-1)
+    stream = torch.cuda.Stream(device=local)
+    c.set_profiling(True)
+    c.enqueue(stream.cuda_stream)
+    c.check()
+    for k in (0, N - 1):
+        assert c.get("main.hashGlobalInputs", k) == ins[k % n_leaves][1], "hashGlobalInputs mismatch"
+    ms_kernel = sum(p[1] for p in c.profile())
+    c.set_profiling(False)
+    launches = max(1, (args.withdraw_total + N - 1) // N)
+    for _ in range(args.warmup):
+        c.enqueue(stream.cuda_stream)
+        c.check()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for _ in range(launches):
+            c.enqueue(stream.cuda_stream)
+        c.check()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        total = launches * N * args.steps * world
+        abytes = wl * 32 * N
+        print(json.dumps({
+            "metric": "withdraw witnesses/sec (nLevels=%d)" % lv, "value": round(total / dt, 1), "unit": "witnesses/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32x9 (254-bit Montgomery Fr, 29-bit limbs, integer)", "data": "synthetic",
+            "config": {"workload": "withdraw nLevels=%d, %d witnesses per step in %d launches of %d" % (lv, launches * N, launches, N),
+                       "witness_elements": wl, "distinct_exit_leaves": n_leaves},
+            "roofline": {"bound": "hbm", "kernel": "k_withdraw", "achieved": round(abytes / (ms_kernel * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(abytes / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "launch_ms": round(ms_kernel, 3),
+                         "algorithmic_bytes_per_launch": int(abytes)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +238,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=768, help="nTx of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batches-per-launch", type=int, default=32,
                     help="independent batches evaluated by ONE set of kernel launches (context with n_instances = B): more wavefronts per launch")
+    ap.add_argument("--workload", choices=["rollup-main", "withdraw"], default="rollup-main",
+                    help="withdraw = BASELINE config 5 (2^20 independent Withdraw(nLevels) witnesses)")
+    ap.add_argument("--withdraw-total", type=int, default=1 << 20)
+    ap.add_argument("--withdraw-per-launch", type=int, default=1 << 16)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon-BN254/sec secondary metric")
     ap.add_argument("--calibrate-copy", action="store_true",
@@ -187,6 +267,8 @@ def main():
     L = lib()
     if L.device_count() <= 0:
         raise SystemExit("no gfx950 device")
+    if args.workload == "withdraw":
+        return bench_withdraw(args, L, rank, world, local)
     nTx, lv, m1, F = args.nTx, args.nLevels, args.maxL1Tx, args.maxFeeTx
     # synthetic batch (reference tools/generate-input.js recipe), same seed on every rank
     bb = B.synthetic_batch(nTx, lv, m1, F, n_accounts=min(nTx, 4096), seed=0x48455A31)

@@ -70,6 +70,7 @@ static const char* block_owner(const Layout& lo, int sec, const Block& b) {
 static uint64_t owner_bytes(const hz_ctx* c, const char* owner) {
     uint64_t n = 0;
     const Layout& lo = c->lo;
+    if (!strcmp(owner, "withdraw")) return lo.total * 32;   // one kernel writes the whole witness
     for (size_t si = 0; si < lo.sections.size(); si++)
         for (const Block& b : lo.sections[si].blocks)
             if (!strcmp(block_owner(lo, (int)si, b), owner)) n += (uint64_t)b.count * lo.sections[si].n_units;
@@ -494,7 +495,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             WithdrawArgs wa;
             memset(&wa, 0, sizeof wa);
             wa.base = sec_ptr(c, 0); wa.err = err; wa.N = lo.sections[0].n_units; wa.L = (uint32_t)lo.p.L; wa.wd = lo.wd;
-            HZ_HIP(launch_withdraw(wa, s));
+            { ProfScope ps(c, s, "withdraw", wa.N); HZ_HIP(launch_withdraw(wa, s)); }
             break;
         }
         case T_HASH_INPUTS:
