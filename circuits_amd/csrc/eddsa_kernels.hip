@@ -348,8 +348,11 @@ __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const S
 // Lane li evaluates the signatures of units li, li + nl, li + 2 nl, ... (nl lanes): consecutive
 // lanes keep writing consecutive units. A slot past the end repeats the lane's first unit (same
 // values to the same addresses).
+#ifndef HZ_ED_WAVES
+#define HZ_ED_WAVES 2
+#endif
 template <int G>
-__global__ __launch_bounds__(HZ_BLOCK) void k_eddsa(const EddsaArgs a) {
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa(const EddsaArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
     const Fr* K6 = poseidon_consts<6>(lds);

@@ -154,21 +154,38 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
         io.chk(P.cid_sm_final, last_sum, one);
     }
     const Fr mU = fr_add(m, U), OU = fr_add(O, U);
-    // level chain, bottom-up
+    // level chain, bottom-up. Both sides run the level hash through ONE inlined copy of the permutation (the kernel's
+    // hot code): wavefronts of the old and the new side that share a CU then share its instruction-cache lines.
     Fr child = zero;
     for (int k = n - 1; k >= 0; k--) {
         const uint32_t lv = o.levels + LV_SIZE * k;
         const uint32_t sel = c_bit(newKey_c, k);
         const Fr sib = io.in_m(P.siblings + k);
+        Fr hin[2];
+        Fr s_tb = zero, s_n1 = zero;
         if (!new_side) {
             // oldSwitcher(L = oldChild, R = sibling, sel); aux = (R-L)*sel
             const Fr aux = sel ? fr_sub(sib, child) : zero;
             io.put_m(lv + LV_OLDSW_AUX, aux);
-            Fr hin[2];
             hin[0] = sel ? sib : child;
             hin[1] = sel ? child : sib;
-            WitSboxSink sk = io.sbox_sink(lv + LV_OLDHASH);
-            const Fr h = poseidon_hash<3>(hin, K3, sk);
+        } else {
+            // st_top + st_bot ; st_new1 ; st_old0 + st_upd ; st_top
+            s_tb = k < kl ? enabled : k < kx ? m : zero;
+            s_n1 = k == kx ? m : zero;
+            const Fr aux1 = fr_mul(child, s_tb);
+            const Fr swL = fr_add(aux1, fr_mul(h1new, s_n1));
+            const Fr aux2 = k < kl ? fr_mul(sib, enabled) : zero;
+            const Fr swR = fr_add(aux2, fr_mul(h1old, s_n1));
+            const Fr aux = sel ? fr_sub(swR, swL) : zero;
+            hin[0] = sel ? swR : swL;
+            hin[1] = sel ? swL : swR;
+            io.put_m(lv + LV_NEWSW_AUX, aux); io.put_m(lv + LV_AUX1, aux1); io.put_m(lv + LV_AUX2, aux2);
+            io.put_m(lv + LV_NEWSW_L, swL); io.put_m(lv + LV_NEWSW_R, swR);
+        }
+        WitSboxSink sk = io.sbox_sink(lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
+        const Fr h = poseidon_hash<3>(hin, K3, sk);
+        if (!new_side) {
             // st_bot + st_new1 + st_upd ; st_top
             const Fr s_a = k < kl ? zero : k == kl ? mU : k <= kx ? m : zero;
             const Fr aux0 = fr_mul(h1old, s_a);
@@ -176,23 +193,9 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
             io.put_m(lv + LV_AUX0, aux0); io.put_m(lv + LV_OLDROOT, root);
             child = root;
         } else {
-            // st_top + st_bot ; st_new1 ; st_old0 + st_upd ; st_top
-            const Fr s_tb = k < kl ? enabled : k < kx ? m : zero;
-            const Fr s_n1 = k == kx ? m : zero;
-            const Fr aux1 = fr_mul(child, s_tb);
-            const Fr swL = fr_add(aux1, fr_mul(h1new, s_n1));
-            const Fr aux2 = k < kl ? fr_mul(sib, enabled) : zero;
-            const Fr swR = fr_add(aux2, fr_mul(h1old, s_n1));
-            const Fr aux = sel ? fr_sub(swR, swL) : zero;
-            Fr hin[2];
-            hin[0] = sel ? swR : swL;
-            hin[1] = sel ? swL : swR;
-            WitSboxSink sk = io.sbox_sink(lv + LV_NEWHASH);
-            const Fr h = poseidon_hash<3>(hin, K3, sk);
             const Fr aux3 = fr_mul(h, fr_add(s_tb, s_n1));
             const Fr root = k == kl ? fr_add(aux3, fr_mul(h1new, OU)) : aux3;
-            io.put_m(lv + LV_NEWSW_AUX, aux); io.put_m(lv + LV_AUX1, aux1); io.put_m(lv + LV_AUX2, aux2); io.put_m(lv + LV_AUX3, aux3);
-            io.put_m(lv + LV_NEWSW_L, swL); io.put_m(lv + LV_NEWSW_R, swR); io.put_m(lv + LV_NEWROOT, root);
+            io.put_m(lv + LV_AUX3, aux3); io.put_m(lv + LV_NEWROOT, root);
             child = root;
         }
     }

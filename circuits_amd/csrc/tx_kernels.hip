@@ -41,7 +41,10 @@ struct FeeSrcRtx {
 };
 
 
-__global__ __launch_bounds__(HZ_BLOCK) void k_main_front(const MainFrontArgs a) {
+#ifndef HZ_FRONT_WAVES
+#define HZ_FRONT_WAVES 2
+#endif
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_main_front(const MainFrontArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
     const Fr* K7 = poseidon_consts<7>(lds);
