@@ -277,7 +277,8 @@ def main():
     if args.shard_tx:
         return bench_sharded(args, L, bb, inp, rank, world, local, n_l2)
     Bp = max(1, args.batches_per_launch)
-    inflight = max(1, min(args.inflight, args.steps if args.steps > 0 else 1))
+    # more than 4 contexts (3 streams each) exhaust the runtime's per-queue scratch reservations (HSA_STATUS_ERROR_OUT_OF_RESOURCES)
+    inflight = max(1, min(args.inflight, 4, args.steps if args.steps > 0 else 1))
     # every batch keeps its whole witness resident (3.86 GB at the default shape): fit batches x contexts into free HBM
     probe = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=1)
     per_batch = probe.witness_len() * 32 * 1.04 + (64 << 20)

@@ -418,11 +418,24 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     }
 }
 
+// Signatures per lane: sharing an inversion among G signatures cuts the instruction count (throughput) but leaves 1/G of the
+// wavefronts, each G times as long (latency). Few units (a single batch or a handful): the device is far from full and
+// latency is what counts; many units per launch: the integer pipe is the limit.
+template <int G>
+static hipError_t launch_eddsa_g(const EddsaArgs& a, uint32_t n, hipStream_t s) {
+    const uint32_t nl = (n + G - 1) / G;
+    hipLaunchKernelGGL(k_eddsa<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
+    return hipGetLastError();
+}
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
-    const uint32_t nl = (n + HZ_ED_G - 1) / HZ_ED_G;
-    hipLaunchKernelGGL(k_eddsa<HZ_ED_G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
-    return hipGetLastError();
+#ifdef HZ_ED_G_FIXED
+    return launch_eddsa_g<HZ_ED_G>(a, n, s);
+#else
+    if (n <= 8192) return launch_eddsa_g<1>(a, n, s);
+    if (n <= 16384) return launch_eddsa_g<2>(a, n, s);
+    return launch_eddsa_g<HZ_ED_G>(a, n, s);
+#endif
 }
 
 }  // namespace hz
