@@ -106,7 +106,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRO
 }
 
 
-__global__ __launch_bounds__(HZ_BLOCK) void k_rtx_front(const RtxFrontArgs a) {
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_rtx_front(const RtxFrontArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_front(const RtxFrontArgs a) {
     io.put_m(r.o_isAmountNullified, fo.isAmountNullified);
 }
 
-__global__ __launch_bounds__(HZ_BLOCK) void k_dec_main(const DecMainArgs a) {
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_dec_main(const DecMainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
     const Fr* K7 = poseidon_consts<7>(lds);
