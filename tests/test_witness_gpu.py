@@ -291,3 +291,52 @@ def test_native_witness_binary_and_file_formats(hz, batch, tmp_path):
     open(ipath, "w").write('{"oldLastIdx": "12a"}')
     r = subprocess.run([cli, "RollupMain(8,16,3,4)", ipath, jpath], capture_output=True, text=True)
     assert r.returncode == 1 and "oldLastIdx" in r.stderr
+
+
+def _compare_chunked(g, o, chunk=1 << 21):
+    """Whole physical witness buffers, 64 MB at a time (the full-size witnesses are GBs)."""
+    total = g.total()
+    assert total == o.total()
+    for first in range(0, total, chunk):
+        n = min(chunk, total - first)
+        a, b = g.read_raw_bytes(first, n), o.read_raw_bytes(first, n)
+        if a != b:
+            k = next(i for i in range(n) if a[32 * i:32 * i + 32] != b[32 * i:32 * i + 32])
+            raise AssertionError("witness differs at physical element %d: gpu=%d oracle=%d" % (
+                first + k, int.from_bytes(a[32 * k:32 * k + 32], "little"), int.from_bytes(b[32 * k:32 * k + 32], "little")))
+
+
+def test_config3_rollup_main_256_16_bit_exact(hz):
+    """BASELINE config 3: RollupMain(nTx=256, nLevels=16, maxL1Tx=128, maxFeeTx=64), whole witness against the oracle."""
+    from circuits_amd import builder as B
+    shape = (256, 16, 128, 64)
+    bb = B.synthetic_batch(*shape, n_accounts=512, exits=16, seed=33)
+    g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3])
+    o = OracleCtx("rollup-main", *shape)
+    g.set_inputs(bb.get_input())
+    o.set_inputs(bb.get_input())
+    g.run()
+    assert o.run() is None
+    assert g.get("main.hashGlobalInputs") == bb.get_hash_inputs()
+    _compare_chunked(g, o)
+
+
+def test_config4_rollup_main_2048_32_full_size_bit_exact(hz):
+    """BASELINE config 4 shape on one GPU: RollupMain(2048, 32, 256, 64), the benchmark's own synthetic batch. The full 3.86 GB
+    witness is compared with the oracle's, plus the size-independent properties: no constraint fails, the public hash equals the
+    builder's independent SHA-256 over the data-availability bits, and the last intermediate roots chain to the new state."""
+    from circuits_amd import builder as B
+    shape = (2048, 32, 256, 64)
+    bb = B.synthetic_batch(*shape, n_accounts=2048, exits=32, seed=0x48455A31)
+    inp = bb.get_input()
+    g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3])
+    g.set_inputs(inp)
+    g.run()
+    assert g.witness_len() == 120493511
+    assert g.get("main.hashGlobalInputs") == bb.get_hash_inputs()
+    assert g.get("main.rollupTx[2047].s4.out") == inp["imInitStateRootFee"]
+    assert g.get("main.rollupTx[2046].s4.out") == inp["imStateRoot"][2046]
+    o = OracleCtx("rollup-main", *shape)
+    o.set_inputs(inp)
+    assert o.run() is None
+    _compare_chunked(g, o)
