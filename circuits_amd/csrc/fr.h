@@ -152,20 +152,21 @@ HZ_HD void fr_cond_sub_2p(uint32_t* t) {
         for (int i = 0; i < 9; i++) t[i] = (uint32_t)d[i];
     }
 }
-// t (normalised, value < 8p) -> t - 4p if t >= 4p
-HZ_HD void fr_cond_sub_4p(uint32_t* t) {
+// a (normalised, value < 8p) -> a - 4p if a >= 4p; branch-free (selects), by value
+HZ_HD Fr fr_cond_sub_4p(const Fr& a) {
     int32_t d[9];
     int32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        const int32_t x = (int32_t)t[i] - (int32_t)fr_4p29(i) + c;
+        const int32_t x = (int32_t)a.v[i] - (int32_t)fr_4p29(i) + c;
         d[i] = (i < 8) ? (x & (int32_t)HZ_M29) : x;
         c = x >> 29;
     }
-    if (d[8] >= 0) {
+    const bool ge = d[8] >= 0;
+    Fr r;
 #pragma unroll
-        for (int i = 0; i < 9; i++) t[i] = (uint32_t)d[i];
-    }
+    for (int i = 0; i < 9; i++) r.v[i] = ge ? (uint32_t)d[i] : a.v[i];
+    return r;
 }
 HZ_HD Fr fr_add(const Fr& a, const Fr& b) {
     Fr r;
@@ -307,6 +308,24 @@ HZ_HD Fr fr_muladd(const Fr& a, const Fr& b, const Fr& s) {
             const int j = k - i;
             if (j < 0 || j > 8) continue;
             acc += (uint64_t)a.v[i] * b.v[j];
+        }
+        t[k] = acc;
+    }
+    return fr_reduce_cols(t);
+}
+
+// (a0*b0 + a1*b1 + s*R) / R with one reduction; a0, a1 < p, b0, b1 normalised < 2^257, s < 8p.
+HZ_HD Fr fr_muladd2(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& s) {
+    uint64_t t[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        uint64_t acc = k >= 9 ? s.v[k - 9] : 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 8) continue;
+            acc += (uint64_t)a0.v[i] * b0.v[j];
+            acc += (uint64_t)a1.v[i] * b1.v[j];
         }
         t[k] = acc;
     }

@@ -30,16 +30,19 @@ template <int T> constexpr int poseidon_nsbox() { return 8 * T + PoseidonCfg<T>:
 // tools/gen_constants.py from tools/poseidon_sparse.py), in Fr units:
 //   HEAD   4T        Ark constants of full rounds 0..3 (round 0 in Montgomery form, the others c*R^2)
 //   E0     1         lane-0 constant of partial round 0 (c*R^2)
-//   PART   RP * 2T   per partial round: row[T], col[T-1] (Montgomery form), then the lane-0 constant
-//                    of the NEXT round (c*R^2; after the last partial round: lane 0 of the following
-//                    full round, with the pushed-forward constants folded in)
+//   PART   per PAIR of partial rounds (a, b), 4T+1 Fr: rowA[T], eB, rowB[T], beta, eNext, colA[T-1], colB[T-1];
+//          an odd last round, 2T Fr: row[T], col[T-1], eNext. rows/cols/beta in Montgomery form; e* = lane-0
+//          constant of the following round as c*R^2 (after the last partial round: lane 0 of the next full
+//          round, with the pushed-forward constants folded in)
 //   DENSE  (T-1)^2   the pending lanes-1.. matrix applied once after the partial rounds
 //   CF     T-1       lanes 1.. of the full round that follows (c*R^2, pushed constants folded in)
 //   TAIL   3T        Ark constants of the last three full rounds (c*R^2)
 //   M      T*T       MDS matrix, row-major (Montgomery form)
 template <int T> constexpr int poseidon_k_e0() { return 4 * T; }
 template <int T> constexpr int poseidon_k_part() { return 4 * T + 1; }
-template <int T> constexpr int poseidon_k_dense() { return poseidon_k_part<T>() + PoseidonCfg<T>::RP * 2 * T; }
+template <int T> constexpr int poseidon_k_dense() {
+    return poseidon_k_part<T>() + (PoseidonCfg<T>::RP / 2) * (4 * T + 1) + (PoseidonCfg<T>::RP % 2) * 2 * T;
+}
 template <int T> constexpr int poseidon_k_cf() { return poseidon_k_dense<T>() + (T - 1) * (T - 1); }
 template <int T> constexpr int poseidon_k_tail() { return poseidon_k_cf<T>() + (T - 1); }
 template <int T> constexpr int poseidon_k_m() { return poseidon_k_tail<T>() + 3 * T; }
@@ -71,7 +74,7 @@ HZ_HD Fr poseidon_row(const Fr* row, const Fr* st, const Fr* addend) {
     if constexpr (N <= 6) {
         return fr_dot<N>(row, st, addend);
     } else {
-        return fr_add(fr_dot<4>(row, st, addend), fr_dot<N - 4>(row + 4, st + 4));
+        return fr_add(fr_dot<4>(row, st, addend), fr_dot<N - 4>(row + 4, st + 4));   // N <= 8
     }
 }
 
@@ -110,22 +113,36 @@ HZ_HD Fr poseidon_hash(const Fr* in, const Fr* K, Sink& sink) {
     for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
     k += T;
     poseidon_mix_ark<T, 1>(st, M, K + poseidon_k_e0<T>());
-    // partial rounds, sparse form: lane 0 <- row . (y, lanes) + next constant ; lane i <- lane i + col[i] * y.
-    // Lanes 1.. grow by at most ~1.01 p per round and are brought back below 4p every second round.
+    // Partial rounds, sparse form: lane 0 <- row . (y, lanes) + next constant ; lane i <- lane i + col[i] * y. Two rounds
+    // per iteration so that lanes 1.. are reduced once per pair: round b's row is applied to the lanes as they were before
+    // round a (its constants absorb colA through beta * yA), then lane i <- lane i + colA[i]*yA + colB[i]*yB in one
+    // reduction. Lanes 1.. grow by at most ~1.02 p per pair and are brought back below 4p after every pair.
     const Fr* S = K + poseidon_k_part<T>();
 #pragma unroll 1
-    for (int r = 0; r < RP; r++) {
+    for (int r = 0; r + 1 < RP; r += 2) {
+        Fr v[T + 1];
+        v[0] = poseidon_sbox(st[0], k, sink);
+#pragma unroll
+        for (int j = 1; j < T; j++) v[j] = st[j];
+        const Fr sa = poseidon_row<T>(S, v, S + T);
+        v[T] = v[0];                                   // yA, multiplied by beta
+        v[0] = poseidon_sbox(sa, k + 1, sink);         // yB
+        k += 2;
+        st[0] = poseidon_row<T + 1>(S + T + 1, v, S + 2 * T + 2);
+        const Fr* CA = S + 2 * T + 3;
+#pragma unroll
+        for (int j = 1; j < T; j++) {
+            st[j] = fr_cond_sub_4p(fr_muladd2(CA[j - 1], v[T], CA[T - 1 + j - 1], v[0], st[j]));
+        }
+        S += 4 * T + 1;
+    }
+    if constexpr (RP % 2 == 1) {
         st[0] = poseidon_sbox(st[0], k, sink);
         k += 1;
         const Fr s0 = poseidon_row<T>(S, st, S + 2 * T - 1);
 #pragma unroll
         for (int j = 1; j < T; j++) st[j] = fr_muladd(S[T + j - 1], st[0], st[j]);
         st[0] = s0;
-        if (r & 1) {
-#pragma unroll
-            for (int j = 1; j < T; j++) fr_cond_sub_4p(st[j].v);
-        }
-        S += 2 * T;
     }
     {
         // pending lanes-1.. matrix, with the constants of the following full round
