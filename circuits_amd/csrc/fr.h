@@ -147,10 +147,9 @@ HZ_HD void fr_cond_sub_2p(uint32_t* t) {
         d[i] = (i < 8) ? (x & (int32_t)HZ_M29) : x;
         c = x >> 29;
     }
-    if (d[8] >= 0) {
+    const bool ge = d[8] >= 0;   // selects, not a branch: no exec-masked stores
 #pragma unroll
-        for (int i = 0; i < 9; i++) t[i] = (uint32_t)d[i];
-    }
+    for (int i = 0; i < 9; i++) t[i] = ge ? (uint32_t)d[i] : t[i];
 }
 // a (normalised, value < 8p) -> a - 4p if a >= 4p; branch-free (selects), by value
 HZ_HD Fr fr_cond_sub_4p(const Fr& a) {
