@@ -70,7 +70,13 @@ static const char* block_owner(const Layout& lo, int sec, const Block& b) {
 static uint64_t owner_bytes(const hz_ctx* c, const char* owner) {
     uint64_t n = 0;
     const Layout& lo = c->lo;
-    if (!strcmp(owner, "withdraw")) return lo.total * 32;   // one kernel writes the whole witness
+    if (!strcmp(owner, "withdraw") || !strcmp(owner, "withdraw_sha")) {   // the SHA part owns the sha256 blocks and the bit decompositions
+        uint64_t sha = 0;
+        for (size_t si = 0; si < lo.sections.size(); si++)
+            for (const Block& b : lo.sections[si].blocks)
+                if (b.name.find("main.hasherInputs.") == 0) sha += (uint64_t)b.count * lo.sections[si].n_units;
+        return (!strcmp(owner, "withdraw_sha") ? sha : lo.total - sha) * 32;
+    }
     for (size_t si = 0; si < lo.sections.size(); si++)
         for (const Block& b : lo.sections[si].blocks)
             if (!strcmp(block_owner(lo, (int)si, b), owner)) n += (uint64_t)b.count * lo.sections[si].n_units;
@@ -495,7 +501,12 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             WithdrawArgs wa;
             memset(&wa, 0, sizeof wa);
             wa.base = sec_ptr(c, 0); wa.err = err; wa.N = lo.sections[0].n_units; wa.L = (uint32_t)lo.p.L; wa.wd = lo.wd;
+            // the SHA-256 bit witness (store bound) runs beside the Poseidon / SMT part (integer bound) on a side stream
+            HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_reset, 0));
+            { ProfScope ps(c, c->s_ed, "withdraw_sha", wa.N); HZ_HIP(launch_withdraw_sha(wa, c->s_ed)); }
+            HZ_HIP(hipEventRecord(c->ev_ed, c->s_ed));
             { ProfScope ps(c, s, "withdraw", wa.N); HZ_HIP(launch_withdraw(wa, s)); }
+            HZ_HIP(hipStreamWaitEvent(s, c->ev_ed, 0));
             break;
         }
         case T_HASH_INPUTS:

@@ -306,13 +306,26 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
         const Fr e = is_zero_dev(io, v.checkRoot, z[1], zi[1]);
         io.chk_zero(C_WD_ROOT, fr_sub(one, e));
     }
-    // HashInputsWithdrawal
-    for (int k = 0; k < 256; k++) io.put_bit(o.n2bRootExit + k, c_bit(rootExit_c, k));
-    num2bits_dev(io, o.n2bEthAddr, ethAddr_c, 160, C_WD_HI_N2B);
-    num2bits_dev(io, o.n2bTokenID, tokenID_c, 32, C_WD_HI_N2B);
-    num2bits_dev(io, o.n2bBalance, balance_c, 192, C_WD_HI_N2B);
-    num2bits_dev(io, o.n2bIdx, idx_c, 48, C_WD_HI_N2B);
-    {
+}
+
+// HashInputsWithdrawal (reference src/withdraw.circom:73-176): bit decompositions, the 688-bit message and the bit-level
+// witness of its two SHA-256 blocks. Lane = (instance, block): 86 % of a Withdraw witness is this store stream, which runs
+// beside the Poseidon-bound k_withdraw on a second stream instead of behind it in the same lane.
+__global__ __launch_bounds__(HZ_BLOCK) void k_withdraw_sha(const WithdrawArgs a) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt >= 2 * a.N) return;
+    const uint32_t i = gt % a.N, blk = gt / a.N;   // consecutive lanes = consecutive instances: coalesced stores
+    const UnitIO io{a.base, a.N, i, i, 0, a.err};
+    const WithdrawOff& o = a.wd;
+    const Fr zero = fr_zero();
+    const Fc rootExit_c = io.in_c(o.rootExit), ethAddr_c = io.in_c(o.ethAddr), tokenID_c = io.in_c(o.tokenID), balance_c = io.in_c(o.balance),
+             idx_c = io.in_c(o.idx);
+    if (blk == 0) {
+        for (int k = 0; k < 256; k++) io.put_bit(o.n2bRootExit + k, c_bit(rootExit_c, k));
+        num2bits_dev(io, o.n2bEthAddr, ethAddr_c, 160, C_WD_HI_N2B);
+        num2bits_dev(io, o.n2bTokenID, tokenID_c, 32, C_WD_HI_N2B);
+        num2bits_dev(io, o.n2bBalance, balance_c, 192, C_WD_HI_N2B);
+        num2bits_dev(io, o.n2bIdx, idx_c, 48, C_WD_HI_N2B);
         uint32_t pad = 0;
         for (int j = (int)a.L; j < 48; j++) pad += c_bit(idx_c, j);
         if (pad) report_fail(io.err, io.inst, 0, C_WD_HI_PAD, fr_from_u64(pad), zero);
@@ -328,9 +341,13 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
     msg[31] = 688;
     uint32_t hv[8];
     for (int k = 0; k < 8; k++) hv[k] = SHA_H0[k];
-    sha256_block_witness(io, o.sha.blocks, hv, msg);
-    sha256_block_witness(io, o.sha.blocks + o.sha.block_size, hv, msg + 16);
-    io.put_c(o.hashGlobalInputs, sha_digest_to_fr(hv));
+    if (blk == 0) {
+        sha256_block_witness(io, o.sha.blocks, hv, msg);
+    } else {
+        sha256_compress(hv, msg);   // chaining value of block 0, recomputed (64 rounds) rather than exchanged
+        sha256_block_witness(io, o.sha.blocks + o.sha.block_size, hv, msg + 16);
+        io.put_c(o.hashGlobalInputs, sha_digest_to_fr(hv));
+    }
 }
 
 // ---- multi-GPU shard exchange: per-transaction data-availability records --------------------------------
@@ -413,6 +430,10 @@ hipError_t launch_da_import(const DaArgs& a, hipStream_t s) {
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_withdraw, grid1(a.N), dim3(HZ_BLOCK),
                        poseidon_lds_bytes<5>() + poseidon_lds_bytes<4>() + poseidon_lds_bytes<3>(), s, a);
+    return hipGetLastError();
+}
+hipError_t launch_withdraw_sha(const WithdrawArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_withdraw_sha, grid1(2 * a.N), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

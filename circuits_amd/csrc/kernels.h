@@ -155,6 +155,7 @@ struct WithdrawArgs {
     WithdrawOff wd;
 };
 
+hipError_t launch_withdraw_sha(const WithdrawArgs& a, hipStream_t s);
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s);
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s);
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s);
