@@ -3,9 +3,10 @@
 // src/decode-tx.circom:1-3, src/withdraw.circom:1-4 ...). circomlib is pinned in the reference's
 // package-lock.json:861-862 but absent from /root/reference: each gadget follows the published
 // template (SURVEY Appendix A is the working spec) and names the template it restates.
-// Parity status: Poseidon pinned on upstream known answers; BabyJubjub/EdDSA/SMT pinned on
-// self-checks (group law, sign/verify round trip, independent tree rebuild) -- "parity unpinned"
-// against the reference repository itself, whose tests hold no literal values for them.
+// Parity status: Poseidon and EdDSA-Poseidon pinned on upstream circomlib known answers
+// (tests/golden/poseidon_kat.json, eddsa_poseidon_kat.json); SMT pinned on self-checks (independent tree
+// rebuild, membership proofs) -- "parity unpinned" against the reference repository itself, whose tests hold
+// no literal values for hashes, roots or signatures.
 #pragma once
 #include <functional>
 #include <string>

@@ -80,3 +80,28 @@ def atomic_pair():
     bb2.add_tx({"fromIdx": 257, "toIdx": 256, "amount": 4, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": b})
     bb2.build()
     return (nTx, L, m1, F), [bb, bb2]
+
+
+def eddsa_kat_rollup_tx(tamper=False):
+    """A RollupTx(16, 2) input whose L2 signature is the upstream circomlib EdDSA-Poseidon known answer
+    (tests/golden/eddsa_poseidon_kat.json): the sender leaf carries the vector's public key, `sigL2Hash` (an input of the
+    standalone RollupTx, reference src/rollup-tx.circom:121) is the vector's message."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eddsa_poseidon_kat.json")))
+    ax, ay = (int(x) for x in kat["A"])
+    L, F = 16, 2
+    db = B.RollupDB(chain_id=1)
+    other = B.Account(21)
+    for st in ({"tokenID": 1, "nonce": 0, "sign": 1 if ax > (B.P - 1) // 2 else 0, "balance": 1000, "ay": ay, "ethAddr": 0x1234},
+               {"tokenID": 1, "nonce": 0, "sign": other.sign, "balance": 5, "ay": other.ay, "ethAddr": other.eth_addr}):
+        db.last_idx += 1
+        db.state.insert(db.last_idx, B.hash_state(st))
+        db.leaves[db.last_idx] = st
+    bb = db.build_batch(2, L, 1, F)
+    bb.add_tx({"fromIdx": 256, "toIdx": 257, "amount": 10, "tokenID": 1, "userFee": 0, "onChain": 0,
+               "r8x": int(kat["R8"][0]), "r8y": int(kat["R8"][1]), "s": (int(kat["S"]) + (1 if tamper else 0))})
+    bb.build()
+    tin, tout = bb.get_single_tx_input(0)
+    tin["sigL2Hash"] = int(kat["msg"])
+    return (L, F), tin, tout

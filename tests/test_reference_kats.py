@@ -256,3 +256,71 @@ def test_hip_fee_scenario_and_overflow_edge(hz):
     with pytest.raises(ConstraintError) as e:
         g.run()
     assert "lcOverflowNotShifted" in e.value.name
+
+
+# ---- EdDSA-Poseidon: upstream known answer through the circuit's own verifier ---------------------------------------
+def _eddsa_kat():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eddsa_poseidon_kat.json")))
+
+
+def test_eddsa_poseidon_upstream_kat_is_self_consistent():
+    """Both points on BabyJubjub and S*B8 == R8 + 8*H(R8x,R8y,Ax,Ay,M)*A with the product's host-side Poseidon (t = 6)."""
+    from circuits_amd import builder as B
+    kat = _eddsa_kat()
+    Pm = B.P
+    A, R8 = tuple(int(x) for x in kat["A"]), tuple(int(x) for x in kat["R8"])
+    S, msg = int(kat["S"]), int(kat["msg"])
+    a, d = 168700, 168696
+
+    def add(p, q):
+        t = d * p[0] * q[0] * p[1] * q[1] % Pm
+        return ((p[0] * q[1] + p[1] * q[0]) * pow(1 + t, Pm - 2, Pm) % Pm, (p[1] * q[1] - a * p[0] * q[0]) * pow(1 - t, Pm - 2, Pm) % Pm)
+
+    def mul(p, k):
+        acc = (0, 1)
+        while k:
+            if k & 1:
+                acc = add(acc, p)
+            p = add(p, p)
+            k >>= 1
+        return acc
+    for x, y in (A, R8):
+        assert (a * x * x + y * y - 1 - d * x * x * y * y) % Pm == 0
+    b8 = (5299619240641551281634865583518297030282874472190772894086521144482721001553, 16950150798460657717958625567821834550301663161624707787222815936182638968203)
+    h = B.host().poseidon([R8[0], R8[1], A[0], A[1], msg])
+    assert mul(b8, S) == add(R8, mul(A, 8 * h))
+
+
+def test_oracle_verifies_upstream_eddsa_kat_and_rejects_tampering():
+    from scenarios import eddsa_kat_rollup_tx
+    (Lv, Fv), tin, tout = eddsa_kat_rollup_tx()
+    o = OracleCtx("rollup-tx", nLevels=Lv, maxFeeTx=Fv)
+    o.set_inputs(tin)
+    assert o.run() is None
+    assert o.get("main.newStateRoot") == tout["newStateRoot"]
+    _, bad, _ = eddsa_kat_rollup_tx(tamper=True)
+    o = OracleCtx("rollup-tx", nLevels=Lv, maxFeeTx=Fv)
+    o.set_inputs(bad)
+    r = o.run()
+    assert r is not None and "sigVerifier" in r[3]
+
+
+@pytest.mark.gpu
+def test_hip_verifies_upstream_eddsa_kat_and_rejects_tampering(hz):
+    from circuits_amd import ConstraintError
+    from scenarios import eddsa_kat_rollup_tx
+    (Lv, Fv), tin, tout = eddsa_kat_rollup_tx()
+    g = hz.ctx("rollup-tx", nLevels=Lv, maxFeeTx=Fv)
+    o = OracleCtx("rollup-tx", nLevels=Lv, maxFeeTx=Fv)
+    g.set_inputs(tin)
+    o.set_inputs(tin)
+    g.run()
+    assert o.run() is None
+    assert g.read_raw_bytes() == o.read_raw_bytes()
+    _, bad, _ = eddsa_kat_rollup_tx(tamper=True)
+    g = hz.ctx("rollup-tx", nLevels=Lv, maxFeeTx=Fv)
+    g.set_inputs(bad)
+    with pytest.raises(ConstraintError) as e:
+        g.run()
+    assert "sigVerifier" in e.value.name
