@@ -290,6 +290,11 @@ def test_eddsa_poseidon_upstream_kat_is_self_consistent():
     b8 = (5299619240641551281634865583518297030282874472190772894086521144482721001553, 16950150798460657717958625567821834550301663161624707787222815936182638968203)
     h = B.host().poseidon([R8[0], R8[1], A[0], A[1], msg])
     assert mul(b8, S) == add(R8, mul(A, 8 * h))
+    # upstream BabyAdd known answers, through the product's host-side curve arithmetic (libhz_host.so) as well
+    ba = kat["babyadd"]
+    p1, p2 = tuple(int(x) for x in ba["p1"]), tuple(int(x) for x in ba["p2"])
+    assert add(p1, p1) == tuple(int(x) for x in ba["p1_plus_p1"]) and add(p1, p2) == tuple(int(x) for x in ba["p1_plus_p2"])
+    assert B.host().bjj_mul(p1, 2) == tuple(int(x) for x in ba["p1_plus_p1"])
 
 
 def test_oracle_verifies_upstream_eddsa_kat_and_rejects_tampering():
