@@ -60,7 +60,7 @@ EXPORTS = [
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
-    "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym",
+    "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym", "hz_fr_ops",
 ]
 
 
@@ -78,6 +78,7 @@ class Lib:
         c.hz_device_count.restype = ctypes.c_int32
         c.hz_poseidon_batch.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
         c.hz_poseidon_batch_dev.argtypes = [ctypes.c_int32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        c.hz_fr_ops.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
         c.hz_shard_range.argtypes = [ctypes.c_int32] * 3 + [ctypes.POINTER(ctypes.c_int32)] * 2
         c.hz_shard_range.restype = None
         vp, u64 = ctypes.c_void_p, ctypes.c_uint64
@@ -141,6 +142,13 @@ class Lib:
 
     def poseidon_batch_dev(self, t, n, d_in, d_out, d_wit=None, stream=None):
         self._check(self.c.hz_poseidon_batch_dev(t, n, d_in, d_out, d_wit, stream))
+
+    def fr_ops(self, op, a, b=None, device=0):
+        """out[i] = a[i] (op) b[i]; op: 0 add, 1 sub, 2 mul, 3 sqr, 4 inv, 5 a*b+a+b, 6 2a*(-b)."""
+        n = len(a)
+        out = ctypes.create_string_buffer(32 * max(n, 1))
+        self._check(self.c.hz_fr_ops(device, op, n, fr_to_bytes(a), fr_to_bytes(b) if b is not None else None, out))
+        return fr_from_bytes(out.raw[:32 * n])
 
     def ctx(self, template, **kw):
         return Ctx(self, template, **kw)

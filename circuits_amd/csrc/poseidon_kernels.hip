@@ -53,6 +53,26 @@ static hipError_t launch_poseidon(size_t n, const void* d_in, void* d_out, void*
     return hipGetLastError();
 }
 
+// K0 fr_ops: one field operation per lane on canonical operands (SURVEY 8a' K0), the self test of fr.h on the device
+__global__ __launch_bounds__(256) void fr_ops_kernel(int op, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const Fr x = fr_from_canon(load_fr(a + i * 32));
+        const Fr y = b ? fr_from_canon(load_fr(b + i * 32)) : fr_zero();
+        Fr r;
+        switch (op) {
+            case HZ_FR_ADD: r = fr_add(x, y); break;
+            case HZ_FR_SUB: r = fr_sub(x, y); break;
+            case HZ_FR_MUL: r = fr_mul(x, y); break;
+            case HZ_FR_SQR: r = fr_sqr(x); break;
+            case HZ_FR_INV: r = fr_inv(x); break;
+            case HZ_FR_MULADD: r = fr_cond_sub_4p(fr_muladd(x, y, fr_add(x, y))); break;   // x*y + (x + y)
+            default: r = fr_mul(fr_dbl(x), fr_neg(y)); break;                          // HZ_FR_MIX: 2x * (-y)
+        }
+        store_fr(out + i * 32, fr_to_canon(r));
+    }
+}
+
 hipError_t poseidon_batch_launch(int t, size_t n, const void* d_in, void* d_out, void* d_wit, hipStream_t s) {
     switch (t) {
         case 2: return launch_poseidon<2>(n, d_in, d_out, d_wit, s);
@@ -73,6 +93,30 @@ extern "C" hz_status hz_poseidon_batch_dev(int32_t t, size_t n, const void* d_in
     if (t < 2 || t > 7 || (n && (!d_in || !d_out))) return set_err(HZ_ERR_ARG, "hz_poseidon_batch_dev: bad argument");
     if (hz_device_count() <= 0) return set_err(HZ_ERR_NODEVICE, "no usable gfx950 device");
     HZ_HIP(poseidon_batch_launch(t, n, d_in, d_out, d_sbox_witness, (hipStream_t)stream));
+    return HZ_OK;
+}
+
+extern "C" hz_status hz_fr_ops(int32_t device, int32_t op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    if (op < 0 || op > HZ_FR_MIX || (n && (!a || !out))) return set_err(HZ_ERR_ARG, "hz_fr_ops: bad argument");
+    if (hz_device_count() <= 0) return set_err(HZ_ERR_NODEVICE, "no usable gfx950 device");
+    if (n == 0) return HZ_OK;
+    HZ_HIP(hipSetDevice(device));
+    for (size_t i = 0; i < n; i++)
+        if (!canon_lt_p(a + i * 32) || (b && !canon_lt_p(b + i * 32))) return set_err(HZ_ERR_INPUT, "hz_fr_ops: operand >= r");
+    DevBuf d_a, d_b, d_o;
+    HZ_HIP(d_a.alloc(n * 32));
+    HZ_HIP(d_o.alloc(n * 32));
+    HZ_HIP(hipMemcpy(d_a.p, a, n * 32, hipMemcpyHostToDevice));
+    if (b) {
+        HZ_HIP(d_b.alloc(n * 32));
+        HZ_HIP(hipMemcpy(d_b.p, b, n * 32, hipMemcpyHostToDevice));
+    }
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fr_ops_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, op, (const uint8_t*)d_a.p, (const uint8_t*)d_b.p, (uint8_t*)d_o.p, n);
+    HZ_HIP(hipGetLastError());
+    HZ_HIP(hipDeviceSynchronize());
+    HZ_HIP(hipMemcpy(out, d_o.p, n * 32, hipMemcpyDeviceToHost));
     return HZ_OK;
 }
 

@@ -162,6 +162,11 @@ const char* hz_constraint_name(int32_t constraint_id);
 hz_status hz_poseidon_batch(int32_t device, int32_t t, size_t n, const uint8_t* in, uint8_t* out, uint8_t* sbox_witness);
 hz_status hz_poseidon_batch_dev(int32_t t, size_t n, const void* d_in, void* d_out, void* d_sbox_witness, void* stream);
 
+/* Field self test (SURVEY 8a' K0): out[i] = a[i] (op) b[i] over BN254 Fr, one operation per lane, canonical operands and results.
+ * No reference counterpart (the reference's field is ffiasm's Fr, tools/helpers/actions.js:207-215); used by tests/ only. */
+enum { HZ_FR_ADD = 0, HZ_FR_SUB = 1, HZ_FR_MUL = 2, HZ_FR_SQR = 3, HZ_FR_INV = 4 /* inverse(0) = 0 */, HZ_FR_MULADD = 5 /* a*b + a + b */, HZ_FR_MIX = 6 /* 2a * (-b) */ };
+hz_status hz_fr_ops(int32_t device, int32_t op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
+
 /* multi-GPU, one process per GPU (reference src/rollup-main.circom:93-99: every DecodeTx / RollupTx is
  * independent given the im* inputs). A RollupMain batch is sharded by transaction index:
  *   hz_shard_range      contiguous range of a rank

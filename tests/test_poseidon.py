@@ -91,3 +91,23 @@ def test_hip_poseidon_empty_and_bad_input(hz):
     assert st == 4
     with pytest.raises(HzError):
         hz._check(hz.c.hz_poseidon_batch(0, 9, 1, bad, out, None))
+
+
+@pytest.mark.gpu
+def test_hip_field_ops_against_python_bigints(hz):
+    """K0 (SURVEY 8a'): fr.h on the device, 2^16 random and edge operands per operation, against Python integers."""
+    import random
+    rng = random.Random(5)
+    Pm = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    edge = [0, 1, 2, Pm - 1, Pm - 2, (Pm - 1) // 2, (Pm + 1) // 2, 1 << 253, (1 << 253) - 1, (1 << 29) - 1, 1 << 29, (1 << 232) - 1]
+    n = 1 << 16
+    a = [edge[i % len(edge)] if i < 200 else rng.randrange(Pm) for i in range(n)]
+    b = [edge[(i // len(edge)) % len(edge)] if i < 200 else rng.randrange(Pm) for i in range(n)]
+    ref = {
+        0: lambda x, y: (x + y) % Pm, 1: lambda x, y: (x - y) % Pm, 2: lambda x, y: x * y % Pm, 3: lambda x, y: x * x % Pm,
+        4: lambda x, y: pow(x, Pm - 2, Pm), 5: lambda x, y: (x * y + x + y) % Pm, 6: lambda x, y: (2 * x * (Pm - y)) % Pm,
+    }
+    for op, f in ref.items():
+        m = n if op != 4 else 4096
+        got = hz.fr_ops(op, a[:m], b[:m])
+        assert got == [f(x, y) for x, y in zip(a[:m], b[:m])], "field op %d" % op
