@@ -253,8 +253,6 @@ class BatchBuilder:
 
     def build(self):
         db, L, F, nTx = self.db, self.L, self.F, self.nTx
-        if any(not t.get("onChain") for t in self.txs[:0]):
-            pass
         n_l1 = sum(1 for t in self.txs if t.get("onChain"))
         if n_l1 > self.maxL1:
             raise ValueError("too many L1 txs")
