@@ -212,3 +212,22 @@ def test_oracle_atomic_transactions_and_single_tx_slices():
     o = OracleCtx("rollup-main", *shape)
     o.set_inputs(bad)
     assert o.run() is not None
+
+
+def test_command_line_input_and_constraints(tmp_path):
+    """`python -m circuits_amd input|constraints` (reference tools/build-circuit.js `input`, tools/circuit-constraints.js): the estimate
+    reproduces the reference model's number for its own README example shape, the written input.json satisfies the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "circuits_amd", "constraints", "2048", "32", "256", "64"], cwd=root, capture_output=True, text=True, check=True).stdout
+    assert "Constraints: 121754144" in out       # SURVEY 8d: the reference's closed form at the BASELINE config-4 shape
+    d = str(tmp_path / "b")
+    subprocess.run([sys.executable, "-m", "circuits_amd", "input", "4", "16", "2", "2", d], cwd=root, check=True, capture_output=True)
+    inp = json.load(open(os.path.join(d, "input.json")))
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    o = OracleCtx("rollup-main", 4, 16, 2, 2)
+    o.set_inputs({k: (v if isinstance(v, list) else int(v)) for k, v in inp.items()})
+    assert o.run() is None
+    assert o.get("main.hashGlobalInputs") == int(exp["hashGlobalInputs"])

@@ -340,3 +340,20 @@ def test_config4_rollup_main_2048_32_full_size_bit_exact(hz):
     o.set_inputs(inp)
     assert o.run() is None
     _compare_chunked(g, o)
+
+
+def test_command_line_input_then_witness(hz, tmp_path):
+    """`python -m circuits_amd input` then `witness` (the reference's `node build-circuit.js input|witness` pair): the .wtns holds
+    the public hash the builder predicted."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = str(tmp_path / "b")
+    for cmd in ("input", "witness"):
+        subprocess.run([sys.executable, "-m", "circuits_amd", cmd, "6", "16", "3", "2", d], cwd=root, check=True, capture_output=True)
+    w = _parse_wtns(os.path.join(d, "witness.wtns"))
+    g = hz.ctx("rollup-main", nTx=6, nLevels=16, maxL1Tx=3, maxFeeTx=2)
+    assert w[0] == 1 and len(w) == g.witness_len()
+    assert w[g.lookup("main.hashGlobalInputs")] == int(json.load(open(os.path.join(d, "expected.json")))["hashGlobalInputs"])
