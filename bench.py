@@ -262,9 +262,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "HZ_BENCH_DEVICE" in os.environ:   # test hook: several ranks on one GPU (with HZ_BENCH_BACKEND=gloo)
+        local = int(os.environ["HZ_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("HZ_BENCH_BACKEND", "nccl"))
     torch.cuda.set_device(local)
 
     from circuits_amd import lib
