@@ -195,6 +195,50 @@ class Account:
         return {"r8x": r8[0], "r8y": r8[1], "s": s}
 
 
+_SHA_K = None
+
+
+def sha256_bits(bits):
+    """SHA-256 of a bit string (FIPS 180-4 padding at bit granularity; the circuit's Sha256(nBits) hashes bit strings whose length
+    need not be a multiple of 8, e.g. nLevels = 10). Byte-aligned inputs go through hashlib."""
+    global _SHA_K
+    if len(bits) % 8 == 0:
+        return hashlib.sha256(bytes(sum(bits[8 * i + k] << (7 - k) for k in range(8)) for i in range(len(bits) // 8))).digest()
+    if _SHA_K is None:
+        pr = [n for n in range(2, 312) if all(n % d for d in range(2, int(n ** 0.5) + 1))][:64]
+
+        def frac_root(n, k):
+            # floor(2^32 * frac(n^(1/k))) by integer root of n * 2^(32k)
+            x, lo, hi = n << (32 * k), 0, 1 << 40
+            while lo < hi:
+                mid = (lo + hi + 1) // 2
+                if mid ** k <= x:
+                    lo = mid
+                else:
+                    hi = mid - 1
+            return lo & 0xFFFFFFFF
+        _SHA_K = ([frac_root(q, 3) for q in pr], [frac_root(q, 2) for q in pr[:8]])
+    K, H0 = _SHA_K
+    msg = list(bits) + [1]
+    msg += [0] * ((448 - len(msg)) % 512)
+    msg += [(len(bits) >> (63 - k)) & 1 for k in range(64)]
+    h = list(H0)
+    rotr = lambda x, r: ((x >> r) | (x << (32 - r))) & 0xFFFFFFFF   # noqa: E731
+    for b in range(0, len(msg), 512):
+        w = [sum(msg[b + 32 * i + k] << (31 - k) for k in range(32)) for i in range(16)]
+        for i in range(16, 64):
+            s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3)
+            s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10)
+            w.append((w[i - 16] + s0 + w[i - 7] + s1) & 0xFFFFFFFF)
+        a, bb, c, d, e, f, g, hh = h
+        for i in range(64):
+            t1 = (hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i]) & 0xFFFFFFFF
+            t2 = ((rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c))) & 0xFFFFFFFF
+            a, bb, c, d, e, f, g, hh = (t1 + t2) & 0xFFFFFFFF, a, bb, c, (d + t1) & 0xFFFFFFFF, e, f, g
+        h = [(x + y) & 0xFFFFFFFF for x, y in zip(h, (a, bb, c, d, e, f, g, hh))]
+    return b"".join(x.to_bytes(4, "big") for x in h)
+
+
 def hash_state(st):
     e0 = st["tokenID"] + (st["nonce"] << 32) + (st["sign"] << 72)
     return host().poseidon([e0, st["balance"], st["ay"], st["ethAddr"]])
@@ -529,9 +573,7 @@ class BatchBuilder:
         for j in range(F):
             be(inp["feeIdxs"][j], L)
         be(inp["globalChainID"], 16); be(inp["currentNumBatch"], 32)
-        assert len(bits) % 8 == 0
-        by = bytes(sum(bits[8 * i + k] << (7 - k) for k in range(8)) for i in range(len(bits) // 8))
-        return int.from_bytes(hashlib.sha256(by).digest(), "big") % P
+        return int.from_bytes(sha256_bits(bits), "big") % P
 
     # reference test/helpers/helpers.js:45-137 getSingleTxInput
     def get_single_tx_input(self, i):

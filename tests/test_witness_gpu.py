@@ -357,3 +357,24 @@ def test_command_line_input_then_witness(hz, tmp_path):
     g = hz.ctx("rollup-main", nTx=6, nLevels=16, maxL1Tx=3, maxFeeTx=2)
     assert w[0] == 1 and len(w) == g.witness_len()
     assert w[g.lookup("main.hashGlobalInputs")] == int(json.load(open(os.path.join(d, "expected.json")))["hashGlobalInputs"])
+
+
+@pytest.mark.parametrize("shape,inst", [((5, 10, 2, 1), 1), ((70, 10, 3, 3), 3), ((130, 24, 65, 5), 2), ((1, 48, 1, 1), 1)])
+def test_odd_shapes_bit_exact(hz, shape, inst):
+    """Ragged sizes: transaction counts that are not a multiple of the wavefront, a shallow and the deepest tree (account indices start at 256, so nLevels >= 9), a single fee
+    slot, several instances per launch (instance b holds its own batch)."""
+    from circuits_amd import builder as B
+    nTx, L, m1, F = shape
+    g = hz.ctx("rollup-main", nTx=nTx, nLevels=L, maxL1Tx=m1, maxFeeTx=F, n_instances=inst)
+    o = OracleCtx("rollup-main", nTx, L, m1, F, n_instances=inst)
+    hashes = []
+    for b in range(inst):
+        bb = B.synthetic_batch(nTx, L, m1, F, n_accounts=max(2, min(nTx, 40)), exits=min(2, max(0, nTx - m1 - 1)), seed=100 + 7 * b + nTx)
+        g.set_inputs(bb.get_input(), instance=b)
+        o.set_inputs(bb.get_input(), instance=b)
+        hashes.append(bb.get_hash_inputs())
+    g.run()
+    assert o.run() is None
+    for b in range(inst):
+        assert g.get("main.hashGlobalInputs", b) == hashes[b]
+    _compare_chunked(g, o)
