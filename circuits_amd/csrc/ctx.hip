@@ -3,6 +3,7 @@
 // include/hermez_witness.h (the calls that replace circom's tester()/calculateWitness()/assertOut(),
 // reference test/helpers/helpers.js:139-155).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>

@@ -79,6 +79,7 @@ struct SmtArgs {
     uint32_t n_units, n_levels;   // n_levels = L + 1
     uint32_t n_proc;
     uint32_t upi;
+    uint32_t k_hi, k_lo;          // levels evaluated by this launch, k_hi down to k_lo (launch_smt chunks the chain)
     SmtProcDesc p[2];
 };
 

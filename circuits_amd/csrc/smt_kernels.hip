@@ -98,7 +98,10 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
         }
         if (!done) levmask |= 1ull;
     }
-    if (!new_side) {
+    const bool first = a.k_hi + 1 == a.n_levels;   // the chunk that holds the bottom level also writes the per-processor signals
+    if (!first) {
+        // nothing: bit decompositions, IsZero witnesses and the state machine belong to the first chunk
+    } else if (!new_side) {
         if (o.fnc != ~0u) { io.put_m(o.fnc, fnc0); io.put_m(o.fnc + 1, fnc1); }
         io.put_m(o.enabled, enabled);
         num2bits_strict_dev(io, o.n2bOld, oldKey_c, P.cid_alias_old);
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
     const Fr O = fr_mul(A2, isOld0);
     const Fr U = fr_sub(enabled, A2);
     const Fr m = fr_sub(A2, O);
-    if (new_side) {
+    if (new_side && first) {
         Fr p_na = fr_sub(one, enabled), p_new1 = zero, p_old0 = zero, p_upd = zero;
         Fr last_sum = zero;
         for (int k = 0; k < n; k++) {
@@ -156,8 +159,10 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
     const Fr mU = fr_add(m, U), OU = fr_add(O, U);
     // level chain, bottom-up. Both sides run the level hash through ONE inlined copy of the permutation (the kernel's
     // hot code): wavefronts of the old and the new side that share a CU then share its instruction-cache lines.
-    Fr child = zero;
-    for (int k = n - 1; k >= 0; k--) {
+    // levels k_hi .. k_lo of the chain; the running root travels between chunks through the scratch slot of the final root
+    const int root_slot = new_side ? P.sc_root_new : P.sc_root_old;
+    Fr child = first ? zero : sc.get(root_slot);
+    for (int k = (int)a.k_hi; k >= (int)a.k_lo; k--) {
         const uint32_t lv = o.levels + LV_SIZE * k;
         const uint32_t sel = c_bit(newKey_c, k);
         const Fr sib = io.in_m(P.siblings + k);
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
             child = root;
         }
     }
-    sc.set(new_side ? P.sc_root_new : P.sc_root_old, child);
+    sc.set(root_slot, child);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -210,10 +215,25 @@ hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
     hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), poseidon_lds_bytes<5>() + poseidon_lds_bytes<4>(), s, a);
     return hipGetLastError();
 }
-hipError_t launch_smt(const SmtArgs& a, hipStream_t s) {
+// A chain lane lives for all n_levels hashes (~20 ms at nLevels = 32) and the grid is twice what the device holds: launched as
+// one kernel, no workgroup slot turns over for tens of milliseconds and every other queue of the process (the other context's
+// front / signature / SHA kernels, even host-side launches) waits behind it. The chain is therefore launched in chunks of
+// `HZ_SMT_CHUNK` levels: slots turn over every few milliseconds and the queues interleave.
+#ifndef HZ_SMT_CHUNK
+#define HZ_SMT_CHUNK 11
+#endif
+hipError_t launch_smt(const SmtArgs& a0, hipStream_t s) {
+    SmtArgs a = a0;
     dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
     g.y = 2 * a.n_proc;
-    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), poseidon_lds_bytes<3>(), s, a);
+    const int n = (int)a.n_levels;
+    // small launches (a single batch) are latency bound: one launch
+    const int chunk = ((uint64_t)g.x * g.y <= 2048) ? n : HZ_SMT_CHUNK;
+    for (int hi = n - 1; hi >= 0; hi -= chunk) {
+        a.k_hi = (uint32_t)hi;
+        a.k_lo = (uint32_t)(hi - chunk + 1 > 0 ? hi - chunk + 1 : 0);
+        hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), poseidon_lds_bytes<3>(), s, a);
+    }
     return hipGetLastError();
 }
 
