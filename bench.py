@@ -65,8 +65,9 @@ def poseidon_rates(L, torch):
 
 
 def measured_traffic(kernel, bpl):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_hbm_counters.json,
-    collected by tools/profile.sh on the same command line); None when that file does not cover this configuration."""
+    """HBM bytes of one launch of `kernel` (its largest dispatch) from the committed rocprofv3 PMC passes
+    (profiles/r01_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
+    this configuration."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")))
         if d.get("batches_per_launch") != bpl:
@@ -239,7 +240,7 @@ def main():
     ap.add_argument("--maxL1Tx", type=int, default=256)
     ap.add_argument("--maxFeeTx", type=int, default=64)
     ap.add_argument("--inflight", type=int, default=2, help="contexts in flight (each with its own witness buffers and streams): the fee/SHA tail of one step overlaps the next step's kernels")
-    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = min(64, logical CPUs))")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = min(16, logical CPUs); 64 processes were measured slower in total: 867 vs 956 tx/s)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="nTx of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batches-per-launch", type=int, default=32,
                     help="independent batches evaluated by ONE set of kernel launches (context with n_instances = B): more wavefronts per launch")
@@ -363,8 +364,9 @@ def main():
         ctxs[0].enqueue(streams[0].cuda_stream)
         ctxs[0].check()
         for name, ms, by, units in ctxs[0].profile():
-            a = acc.setdefault(name, [0.0, by, units])
-            a[0] += ms / reps
+            a = acc.setdefault(name, [0.0, by, units, 0])
+            a[0] += ms / reps      # a kernel launched in several pieces (the SMT chain: chunks of levels) adds up over its launches
+            a[3] += 1.0 / reps
     ctxs[0].set_profiling(False)
 
     if rank == 0:
@@ -383,7 +385,8 @@ def main():
         # near-ties in GPU time (k_eddsa's one long launch vs k_smt's two) go to the kernel that moves more witness bytes
         dk = max((k for k in tot if tot[k] >= 0.95 * top), key=lambda k: byt[k])
         dname = max((n for n in acc if kern.get(n, n) == dk), key=lambda n: acc[n][0])
-        dms, dbytes, dunits = acc[dname]
+        dms, dbytes, dunits, dlaunches = acc[dname]
+        dlaunches = max(1, int(round(dlaunches)))
         achieved = dbytes / (dms * 1e-3) / 1e9
         traffic = measured_traffic(dk, Bp)
         out = {
@@ -395,10 +398,12 @@ def main():
                        "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
                        "witness_bytes_per_batch": ctxs[0].witness_len() * 32, "single_batch_latency_ms": round(single_ms, 3)},
             "roofline": {"bound": "hbm", "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "launch_ms": round(dms, 3),
-                         "algorithmic_bytes_per_launch": int(dbytes), "gpu_ms_per_step_all_launches": round(tot[dk], 3),
-                         "note": "algorithmic bytes = 32 B x the witness signals this launch is responsible for; duration = HIP events on its "
-                                 "stream with the kernel alone on the device; traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes. "
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "launches_per_step": dlaunches, "launch_ms": round(dms / dlaunches, 3),
+                         "algorithmic_bytes_per_launch": int(dbytes // dlaunches), "gpu_ms_per_step_all_launches": round(tot[dk], 3),
+                         "note": "algorithmic bytes = 32 B x the witness signals this launch is responsible for (the SMT chain is launched in chunks "
+                                 "of levels: per-launch figures are the mean over a step's launches); duration = HIP events on its stream with the "
+                                 "kernel alone on the device; traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes. "
                                  "The kernel is integer-VALU issue bound, not HBM bound (DESIGN.md 4)"},
             "whole_pass": {"algorithmic_bytes_per_tx": algorithmic_bytes_per_tx(lv, F),
                            "achieved_GBs": round(algorithmic_bytes_per_tx(lv, F) * value / 1e9, 2)},
@@ -408,7 +413,7 @@ def main():
         if world == 1 and not args.no_poseidon:
             out["poseidon_bn254"] = poseidon_rates(L, torch)
         if world == 1 and args.cpu_sample > 0:
-            workers = args.cpu_workers if args.cpu_workers > 0 else max(1, min(64, (os.cpu_count() or 1)))
+            workers = args.cpu_workers if args.cpu_workers > 0 else max(1, min(16, (os.cpu_count() or 1)))
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, nTx), lv, min(m1, max(1, args.cpu_sample // 8)), F, workers)
         print(json.dumps(out))
     if world > 1:

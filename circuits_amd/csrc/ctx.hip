@@ -315,6 +315,17 @@ static Hash4Args make_hash4_rtx(uint8_t* base, Fr* sc, uint32_t n_units, const R
     return h;
 }
 
+// the SMT chain kernel, in chunks of levels (bottom level first); every launch is its own profile entry of the same name
+static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa, const char* name, hipStream_t s) {
+    const int n = (int)sa.n_levels, chunk = smt_chunk_levels(sa);
+    for (int hi = n - 1; hi >= 0; hi -= chunk) {
+        ProfScope ps(c, s, name, sa.n_units);
+        const hipError_t e = launch_smt_levels(sa, hi, hi - chunk + 1 > 0 ? hi - chunk + 1 : 0, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, uint32_t sib1, uint32_t sib2, hipStream_t s) {
     const Layout& lo = c->lo;
     Fr* sc = (Fr*)c->sc_tx.p;
@@ -342,7 +353,7 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     sa.p[0] = make_proc(lo.rtx.p1, sib1, 0);
     sa.p[1] = make_proc(lo.rtx.p2, sib2, 1);
     sa.u0 = u0; sa.ucnt = ucnt;
-    { ProfScope ps(c, s, "smt", n_units); HZ_HIP(launch_smt(sa, s)); }
+    HZ_HIP(enqueue_smt_chain(c, sa, "smt", s));
     RtxBackArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.base = base; ba.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; ba.scratch = sc; ba.err = err; ba.n_units = n_units; ba.L = (uint32_t)lo.p.L;
@@ -395,7 +406,7 @@ static hz_status enqueue_fee(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is
     memset(&sa, 0, sizeof sa);
     sa.base = base; sa.scratch = sc; sa.err = err; sa.n_units = n_units; sa.n_levels = (uint32_t)lo.p.L + 1; sa.n_proc = 1; sa.upi = lo.sections[lo.sec_fee].upi;
     sa.p[0] = make_proc(lo.fee.p, sib, 2);
-    { ProfScope ps(c, s, "fee_smt", n_units); HZ_HIP(launch_smt(sa, s)); }
+    HZ_HIP(enqueue_smt_chain(c, sa, "fee_smt", s));
     FeeBackArgs fb;
     memset(&fb, 0, sizeof fb);
     fb.base = base; fb.scratch = sc; fb.err = err; fb.n_units = n_units; fb.is_main = is_main; fb.upi = lo.sections[lo.sec_fee].upi; fb.p = sa.p[0];

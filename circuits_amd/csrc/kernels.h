@@ -161,7 +161,8 @@ hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s);
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s);
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s);
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
-hipError_t launch_smt(const SmtArgs& a, hipStream_t s);
+int smt_chunk_levels(const SmtArgs& a);   // levels per launch (the chain is launched in chunks, smt_kernels.hip)
+hipError_t launch_smt_levels(const SmtArgs& a, int k_hi, int k_lo, hipStream_t s);
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s);
 hipError_t launch_fee_front(const FeeFrontArgs& a, hipStream_t s);

@@ -222,18 +222,17 @@ hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
 #ifndef HZ_SMT_CHUNK
 #define HZ_SMT_CHUNK 11
 #endif
-hipError_t launch_smt(const SmtArgs& a0, hipStream_t s) {
+int smt_chunk_levels(const SmtArgs& a) {
+    const uint64_t lanes = (uint64_t)((a.ucnt ? a.ucnt : a.n_units) + HZ_BLOCK - 1) / HZ_BLOCK * 2 * a.n_proc;
+    return lanes <= 2048 ? (int)a.n_levels : HZ_SMT_CHUNK;   // a launch the device holds at once (a single batch) is latency bound: one kernel
+}
+hipError_t launch_smt_levels(const SmtArgs& a0, int k_hi, int k_lo, hipStream_t s) {
     SmtArgs a = a0;
     dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
     g.y = 2 * a.n_proc;
-    const int n = (int)a.n_levels;
-    // small launches (a single batch) are latency bound: one launch
-    const int chunk = ((uint64_t)g.x * g.y <= 2048) ? n : HZ_SMT_CHUNK;
-    for (int hi = n - 1; hi >= 0; hi -= chunk) {
-        a.k_hi = (uint32_t)hi;
-        a.k_lo = (uint32_t)(hi - chunk + 1 > 0 ? hi - chunk + 1 : 0);
-        hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), poseidon_lds_bytes<3>(), s, a);
-    }
+    a.k_hi = (uint32_t)k_hi;
+    a.k_lo = (uint32_t)k_lo;
+    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), poseidon_lds_bytes<3>(), s, a);
     return hipGetLastError();
 }
 
