@@ -374,7 +374,7 @@ def main():
         value = total_tx / dt
         # dominant kernel = most GPU time per step over all its launches (k_smt runs for the transactions and for the
         # fee transactions); its roofline is quoted on the transaction launch
-        kern = {"smt": "k_smt", "fee_smt": "k_smt", "hash4": "k_hash4", "fee_hash": "k_hash4", "eddsa": "k_eddsa", "front": "k_main_front"}
+        kern = {"smt": "k_smt", "fee_smt": "k_smt", "hash4": "k_hash4", "fee_hash": "k_hash4", "eddsa": "k_eddsa", "eddsa_fix": "k_eddsa_fix", "front": "k_main_front"}
         tot = {}
         for name, v in acc.items():
             tot[kern.get(name, name)] = tot.get(kern.get(name, name), 0.0) + v[0]

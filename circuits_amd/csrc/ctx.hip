@@ -35,12 +35,14 @@ struct hz_ctx {
     // their own streams, joined by events before HashInputs (DESIGN.md "Kernel schedule")
     bool exclusive = false;   // hz_ctx_set_profiling(ctx, 2)
     hipStream_t s_ed = nullptr, s_fee = nullptr, s_main = nullptr;   // s_main replaces a NULL caller stream
-    hipEvent_t ev_reset = nullptr, ev_front = nullptr, ev_ed = nullptr, ev_fee = nullptr;
+    hipEvent_t ev_reset = nullptr, ev_front = nullptr, ev_ed = nullptr, ev_fee = nullptr, ev_fix = nullptr;
+    hipStream_t s_fix = nullptr;   // the fixed-base half of the signature check
     ~hz_ctx() {
         if (s_ed) (void)hipStreamDestroy(s_ed);
         if (s_fee) (void)hipStreamDestroy(s_fee);
         if (s_main) (void)hipStreamDestroy(s_main);
-        for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee})
+        if (s_fix) (void)hipStreamDestroy(s_fix);
+        for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee, ev_fix})
             if (e) (void)hipEventDestroy(e);
         for (auto& p : prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     }
@@ -64,6 +66,8 @@ static const char* block_owner(const Layout& lo, int sec, const Block& b) {
     if (has(".topSwitcher.") || has(".checkOldInput.") || has(".areKeyEquals.") || has(".keysOk.") || (has(".processor") && n.size() > 8 && n.compare(n.size() - 8, 8, ".newRoot") == 0))
         return fee ? "fee_back" : "rtx_back";
     if (has(".processor")) return fee ? "fee_smt" : "smt";
+    if (has(".sigVerifier.mulFix.") || has(".sigVerifier.snum2bits") || has(".sigVerifier.compConstant")) return "eddsa_fix";
+    if (has(".sigVerifier.eqCheck")) return "eddsa_final";
     if (has(".getAx.") || has(".sigVerifier.")) return "eddsa";
     if (has(".s3.out") || has(".s4.out") || has(".s5.out") || has("L1L2TxsData.amountF")) return "rtx_back";
     return fee ? "fee_front" : "front";
@@ -142,7 +146,8 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_ed, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_fee, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
-    for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee})
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_fix, hipStreamNonBlocking);
+    for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix})
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete c;
@@ -337,8 +342,15 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     ea.u0 = u0; ea.ucnt = ucnt;
     {
         // the signature ladders only need the front step: run them beside the hash/SMT chain
+        // the two halves of the check (S*B8 and R8 + h*8A) are independent: two kernels on two streams, then the equality
+        hipStream_t sfix = c->exclusive ? c->s_ed : c->s_fix;
+        HZ_HIP(hipStreamWaitEvent(sfix, c->ev_front, 0));
+        { ProfScope ps(c, sfix, "eddsa_fix", n_units); HZ_HIP(launch_eddsa_fix(ea, sfix)); }
+        HZ_HIP(hipEventRecord(c->ev_fix, sfix));
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_front, 0));
         { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed)); }
+        HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_fix, 0));
+        { ProfScope ps(c, c->s_ed, "eddsa_final", n_units); HZ_HIP(launch_eddsa_final(ea, c->s_ed)); }
         HZ_HIP(hipEventRecord(c->ev_ed, c->s_ed));
     }
     {

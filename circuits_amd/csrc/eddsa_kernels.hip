@@ -285,14 +285,14 @@ __device__ __noinline__ void seg_fix_lock(const EdK& K, const UnitIO* io, const 
 // Everything before the scalar multiplications of one signature: AySign2Ax, the S range check,
 // the message hash and its bits, 8*A and the zero-point substitution.
 struct EdSig {
-    Fc h_c, S253;
+    Fc h_c;
     Fr enabled, zp;
     PtA R8, p0;
 };
 __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out) {
     const EdCtx c = K.with(io);
     const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
-    const Fr S = sc.get(SC_ED_S), R8x = sc.get(SC_ED_R8X), R8y = sc.get(SC_ED_R8Y), M = sc.get(SC_SIGL2HASH);
+    const Fr R8x = sc.get(SC_ED_R8X), R8y = sc.get(SC_ED_R8Y), M = sc.get(SC_SIGL2HASH);
     // ---- AySign2Ax
     const Fc ay_c = fr_to_canon(aySig);
     for (int k = 0; k < 254; k++) io.put_bit(o.ax_n2bAy + k, c_bit(ay_c, k));
@@ -312,14 +312,7 @@ __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const S
         const uint32_t sg = comp_constant_dev(io, o.ax_signCalc, x_c, CT_HALF_D);
         io.chk(C_RTX_AX_SIGN, fr_from_bit(sg), signSig);
     }
-    // ---- EdDSAPoseidonVerifier
-    const Fc S_c = fr_to_canon(S);
-    num2bits_dev(io, o.snum2bits, S_c, 253, C_RTX_SIG_N2B_S);
-    out.S253 = c_extract(S_c, 0, 253);
-    {
-        const uint32_t gt = comp_constant_dev(io, o.sCmp, out.S253, CT_SUBORDER_M1_D);
-        if (gt) io.chk_zero(C_RTX_SIG_S_RANGE, enabled);
-    }
+    // ---- EdDSAPoseidonVerifier (the S decomposition and range check belong to k_eddsa_fix)
     Fr hin[5] = {R8x, R8y, x, Ay, M};
     WitSboxSink s6 = io.sbox_sink(o.hash);
     const Fr h = poseidon_hash<6>(hin, K6, s6);
@@ -366,7 +359,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
     const EddsaOff& o = a.ed;
     UnitIO io[G];
-    Fc h_c[G], S253[G];
+    Fc h_c[G];
     Fr enabled[G], zp[G];
     PtA R8[G], p[G], q[G], dbl[G];
 #pragma unroll 1
@@ -378,7 +371,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         const Scratch sc{a.scratch, a.n_units, i};
         EdSig sg;
         ed_prologue(K, io[g], sc, o, K6, sg);
-        h_c[g] = sg.h_c; S253[g] = sg.S253; enabled[g] = sg.enabled; zp[g] = sg.zp; R8[g] = sg.R8; p[g] = sg.p0;
+        h_c[g] = sg.h_c; enabled[g] = sg.enabled; zp[g] = sg.zp; R8[g] = sg.R8; p[g] = sg.p0;
     }
     // ---- mulAny = h * 8A: two SegmentMulAny (148 + 106 bits)
     seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);   // p <- segment 0 output
@@ -401,21 +394,71 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         c.io.put_m(o.anyOut, any.x); c.io.put_m(o.anyOut + 1, any.y);
         p[g] = baby_add_dev(c, o.addRight, R8[g], any);   // right side: R8 + h*8A
     }
-    // ---- mulFix = S * B8: two SegmentMulFix (82 + 3 windows)
+    // the right-hand side goes to k_eddsa_final through the scratch buffer
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const Scratch sc{a.scratch, a.n_units, io[g].unit};
+        sc.set(SC_ED_RIGHTX, p[g].x); sc.set(SC_ED_RIGHTY, p[g].y);
+    }
+    (void)enabled;
+}
+
+// mulFix = S * B8 (two SegmentMulFix: 82 + 3 windows of the constant base) with the S decomposition and range check: it depends on
+// nothing but S, so it runs beside the variable-base ladder in its own kernel with its own signatures-per-lane (85 inversions
+// per lane: more signatures share each of them than in the 254-step ladder kernel).
+template <int G>
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_fix(const EddsaArgs a) {
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t nl = (n + G - 1) / G;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= nl) return;
+    EdK K;
+    K.one = fr_one();
+    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EddsaOff& o = a.ed;
+    UnitIO io[G];
+    Fc S253[G];
+    PtA q[G], r[G];
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        uint32_t ui = li + (uint32_t)g * nl;
+        if (ui >= n) ui = li;
+        const uint32_t i = a.u0 + ui;
+        io[g] = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+        const Scratch sc{a.scratch, a.n_units, i};
+        const Fc S_c = fr_to_canon(sc.get(SC_ED_S));
+        num2bits_dev(io[g], o.snum2bits, S_c, 253, C_RTX_SIG_N2B_S);
+        S253[g] = c_extract(S_c, 0, 253);
+        if (comp_constant_dev(io[g], o.sCmp, S253[g], CT_SUBORDER_M1_D)) io[g].chk_zero(C_RTX_SIG_S_RANGE, sc.get(SC_ED_ENABLED));
+    }
     seg_fix_lock<G>(K, io, o.fseg[0], S253, 0, 246, 0, 0, q);
-    seg_fix_lock<G>(K, io, o.fseg[1], S253, 246, 7, 82, 1, dbl);
+    seg_fix_lock<G>(K, io, o.fseg[1], S253, 246, 7, 82, 1, r);
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const EdCtx c = K.with(io[g]);
-        const PtA left = baby_add_dev(c, o.fadders0, q[g], dbl[g]);
-        Fr d2[2] = {fr_sub(p[g].x, left.x), fr_sub(p[g].y, left.y)};   // eqCheck: in[0] = mulFix.out, in[1] = addRight
-        Fr di[2] = {d2[0], d2[1]};
-        batch_inv<2>(di, 2);
-        const Fr ex = is_zero_dev(c.io, o.eqCheckX, d2[0], di[0]);
-        c.io.chk_zero(C_RTX_SIG_EQX, fr_mul(fr_sub(c.one, ex), enabled[g]));
-        const Fr ey = is_zero_dev(c.io, o.eqCheckY, d2[1], di[1]);
-        c.io.chk_zero(C_RTX_SIG_EQY, fr_mul(fr_sub(c.one, ey), enabled[g]));
+        const PtA left = baby_add_dev(c, o.fadders0, q[g], r[g]);
+        const Scratch sc{a.scratch, a.n_units, io[g].unit};
+        sc.set(SC_ED_LEFTX, left.x); sc.set(SC_ED_LEFTY, left.y);
     }
+}
+
+// eqCheck: in[0] = mulFix.out (left), in[1] = addRight; both gated by `enabled`
+__global__ __launch_bounds__(HZ_BLOCK) void k_eddsa_final(const EddsaArgs a) {
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n) return;
+    const uint32_t i = a.u0 + li;
+    const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+    const Scratch sc{a.scratch, a.n_units, i};
+    const EddsaOff& o = a.ed;
+    const Fr one = fr_one(), enabled = sc.get(SC_ED_ENABLED);
+    Fr d2[2] = {fr_sub(sc.get(SC_ED_RIGHTX), sc.get(SC_ED_LEFTX)), fr_sub(sc.get(SC_ED_RIGHTY), sc.get(SC_ED_LEFTY))};
+    Fr di[2] = {d2[0], d2[1]};
+    batch_inv<2>(di, 2);
+    const Fr ex = is_zero_dev(io, o.eqCheckX, d2[0], di[0]);
+    io.chk_zero(C_RTX_SIG_EQX, fr_mul(fr_sub(one, ex), enabled));
+    const Fr ey = is_zero_dev(io, o.eqCheckY, d2[1], di[1]);
+    io.chk_zero(C_RTX_SIG_EQY, fr_mul(fr_sub(one, ey), enabled));
 }
 
 // Signatures per lane: sharing an inversion among G signatures cuts the instruction count (throughput) but leaves 1/G of the
@@ -427,6 +470,12 @@ static hipError_t launch_eddsa_g(const EddsaArgs& a, uint32_t n, hipStream_t s) 
     hipLaunchKernelGGL(k_eddsa<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
     return hipGetLastError();
 }
+template <int G>
+static hipError_t launch_eddsa_fix_g(const EddsaArgs& a, uint32_t n, hipStream_t s) {
+    const uint32_t nl = (n + G - 1) / G;
+    hipLaunchKernelGGL(k_eddsa_fix<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
 #ifdef HZ_ED_G_FIXED
@@ -436,6 +485,21 @@ hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
     if (n <= 40960) return launch_eddsa_g<2>(a, n, s);   // measured: 16 batches per launch 808 k tx/s with 2, 690 k with 4; 32 batches 961 k vs 994 k
     return launch_eddsa_g<HZ_ED_G>(a, n, s);
 #endif
+}
+hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+#ifdef HZ_ED_GF_FIXED
+    return launch_eddsa_fix_g<HZ_ED_GF_FIXED>(a, n, s);
+#else
+    if (n <= 8192) return launch_eddsa_fix_g<1>(a, n, s);
+    if (n <= 40960) return launch_eddsa_fix_g<4>(a, n, s);
+    return launch_eddsa_fix_g<8>(a, n, s);
+#endif
+}
+hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s) {
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    hipLaunchKernelGGL(k_eddsa_final, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
 }
 
 }  // namespace hz

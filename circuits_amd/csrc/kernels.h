@@ -164,7 +164,9 @@ hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
 int smt_chunk_levels(const SmtArgs& a);   // levels per launch (the chain is launched in chunks, smt_kernels.hip)
 hipError_t launch_smt_levels(const SmtArgs& a, int k_hi, int k_lo, hipStream_t s);
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
-hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s);
+hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s);         // AySign2Ax, message hash, variable-base ladder, R8 + h*8A
+hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s);     // S bits / range, S*B8 (independent of the above)
+hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s);   // the equality of the two sides
 hipError_t launch_fee_front(const FeeFrontArgs& a, hipStream_t s);
 hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s);
 hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s);

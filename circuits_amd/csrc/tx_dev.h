@@ -21,6 +21,7 @@ enum ScratchField {
     SC_P1_FNC0, SC_P1_FNC1, SC_P2_FNC0, SC_P2_FNC1, SC_ISOLD0_1, SC_ISOLD0_2,
     SC_ISEXIT, SC_OLDSTATEROOT, SC_OLDEXITROOT,
     SC_ED_ENABLED, SC_ED_SIGN, SC_ED_AYSIG, SC_ED_AY, SC_ED_S, SC_ED_R8X, SC_ED_R8Y,
+    SC_ED_LEFTX, SC_ED_LEFTY, SC_ED_RIGHTX, SC_ED_RIGHTY,   // S*B8 (k_eddsa_fix) and R8 + h*8A (k_eddsa) for k_eddsa_final
     SC_ISAMTNULL,
     // written by the hash step
     SC_LEAF_P1OLD, SC_LEAF_P1NEW, SC_LEAF_P2OLD, SC_LEAF_P2NEW,
