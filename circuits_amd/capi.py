@@ -171,10 +171,10 @@ def _flatten(v):
 class Ctx:
     """One circuit context (hz_ctx): the object the reference's `tester()` returns."""
 
-    def __init__(self, L, template, nTx=0, nLevels=0, maxL1Tx=0, maxFeeTx=0, n_instances=1, device=0):
+    def __init__(self, L, template, nTx=0, nLevels=0, maxL1Tx=0, maxFeeTx=0, n_instances=1, device=0, flags=0):
         self.L = L
         self.h = ctypes.c_void_p()
-        p = hz_params(TEMPLATES[template], nTx, nLevels, maxL1Tx, maxFeeTx, device, n_instances, 0)
+        p = hz_params(TEMPLATES[template], nTx, nLevels, maxL1Tx, maxFeeTx, device, n_instances, flags)
         L._check(L.c.hz_ctx_create(ctypes.byref(p), ctypes.byref(self.h)))
         self.n_instances = n_instances
 

@@ -34,6 +34,8 @@ struct hz_ctx {
     // independent chains of one batch run concurrently: the EdDSA ladders and the fee transactions on
     // their own streams, joined by events before HashInputs (DESIGN.md "Kernel schedule")
     bool exclusive = false;   // hz_ctx_set_profiling(ctx, 2)
+    bool partitioned = false; // latency-bound context: CU-masked internal streams (hz_ctx_create)
+    hipEvent_t ev_user_in = nullptr, ev_user_out = nullptr;
     hipStream_t s_ed = nullptr, s_fee = nullptr, s_main = nullptr;   // s_main replaces a NULL caller stream
     hipEvent_t ev_reset = nullptr, ev_front = nullptr, ev_ed = nullptr, ev_fee = nullptr, ev_fix = nullptr;
     hipStream_t s_fix = nullptr;   // the fixed-base half of the signature check
@@ -42,7 +44,7 @@ struct hz_ctx {
         if (s_fee) (void)hipStreamDestroy(s_fee);
         if (s_main) (void)hipStreamDestroy(s_main);
         if (s_fix) (void)hipStreamDestroy(s_fix);
-        for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee, ev_fix})
+        for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee, ev_fix, ev_user_in, ev_user_out})
             if (e) (void)hipEventDestroy(e);
         for (auto& p : prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     }
@@ -143,11 +145,33 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         e = c->msg.alloc((size_t)lo.hi.sha.nblocks * 64 * lo.n_inst);
         if (e == hipSuccess) e = c->chain.alloc((size_t)(lo.hi.sha.nblocks + 1) * 32 * lo.n_inst);
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_ed, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_fee, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_fix, hipStreamNonBlocking);
-    for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix})
+    {
+        // A context that is latency bound (one to four batches: a few dozen wavefronts per kernel) gives each of its concurrent
+        // chains its own compute units through CU-masked streams: kernels that share a CU share its instruction cache and issue
+        // slots, and the 213 KB k_smt, the signature kernels and the fee chain evict each other (single batch: 36.5 -> 25 ms).
+        // Throughput-sized contexts keep unmasked streams: the integer pipe is their limit and every CU should take any work.
+        hipDeviceProp_t prop;
+        const uint64_t units = (uint64_t)lo.n_inst * (lo.sec_tx >= 0 ? lo.sections[lo.sec_tx].upi : 0);
+        // Opt-in (HZ_FLAG_LATENCY). Measured, tx/s with one context: 1 batch 56 k -> 81 k (36.5 -> 25 ms), 4: 228 k -> 334 k,
+        // 8: 390 k -> 479 k, 16: 448 k -> 575 k; with two contexts in flight the partition loses (32 x 2: 1007 k -> 662 k).
+        // Not automatic: every CU-masked stream owns a hardware queue, and a process that started while another one had
+        // created and destroyed ~130 of them blocked in its first launch (tests with HZ_FORCE_LATENCY_SCHEDULING).
+        (void)units;
+        const bool want = (p->flags & HZ_FLAG_LATENCY) != 0 || getenv("HZ_FORCE_LATENCY_SCHEDULING") != nullptr;
+        c->partitioned = lo.p.tmpl == T_ROLLUP_MAIN && want && hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 64;
+        const int ncu = c->partitioned ? prop.multiProcessorCount : 0;
+        auto make_stream = [&](hipStream_t* st, int lo_cu, int hi_cu) {
+            if (!c->partitioned) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            for (int b = lo_cu; b < hi_cu; b++) mask[b >> 5] |= 1u << (b & 31);
+            return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+        };
+        if (e == hipSuccess) e = make_stream(&c->s_ed, 0, ncu / 4);                  // variable-base ladder
+        if (e == hipSuccess) e = make_stream(&c->s_fix, ncu / 4, ncu * 3 / 8);       // fixed-base half
+        if (e == hipSuccess) e = make_stream(&c->s_fee, ncu * 3 / 8, ncu / 2);       // fee-transaction chain
+        if (e == hipSuccess) e = make_stream(&c->s_main, ncu / 2, ncu);              // front, hash-state, SMT chains, HashInputs
+    }
+    for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix, &c->ev_user_in, &c->ev_user_out})
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete c;
@@ -381,8 +405,7 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         ba.o_newStateRoot = lo.rtxi.o_newStateRoot; ba.o_newExitRoot = lo.rtxi.o_newExitRoot;
     }
     { ProfScope ps(c, s, "rtx_back", n_units); HZ_HIP(launch_rtx_back(ba, s)); }
-    HZ_HIP(hipStreamWaitEvent(s, c->ev_ed, 0));   // join the signature stream
-    return HZ_OK;
+    return HZ_OK;   // the caller joins the signature stream (ev_ed) after whatever else it launches on `s`
 }
 
 static hz_status enqueue_fee(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, hipStream_t s) {
@@ -453,6 +476,13 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
     // the legacy default stream has implicit-synchronisation semantics that do not mix with the
     // context's non-blocking side streams: a NULL stream means "the context's own stream"
     hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    // partitioned contexts run their main sequence on the CU-masked stream, ordered after / before the caller's stream by two events
+    hipStream_t s_user = s;
+    if (c->partitioned && s != c->s_main) {
+        HZ_HIP(hipEventRecord(c->ev_user_in, s_user));
+        s = c->s_main;
+        HZ_HIP(hipStreamWaitEvent(s, c->ev_user_in, 0));
+    }
     // profiling mode 2: every kernel alone on the device (the side streams alias the launch stream)
     struct StreamAlias {
         hz_ctx* c; hipStream_t ed, fee;
@@ -490,9 +520,11 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             st = enqueue_rtx_tail(c, fa.tx_base, lo.sections[lo.sec_tx].n_units, true, lo.mi.siblings1, lo.mi.siblings2, s);
             if (st != HZ_OK) return st;
             if (tail_now) {
+                // HashInputs needs the roots and the data-availability bits, not the signatures: it runs beside the ladders
                 HZ_HIP(hipStreamWaitEvent(s, c->ev_fee, 0));
                 { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s)); }
             }
+            HZ_HIP(hipStreamWaitEvent(s, c->ev_ed, 0));   // join the signature stream
             break;
         }
         case T_ROLLUP_TX: {
@@ -504,6 +536,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             HZ_HIP(hipEventRecord(c->ev_front, s));
             hz_status st = enqueue_rtx_tail(c, fa.base, fa.N, false, lo.rtxi.siblings1, lo.rtxi.siblings2, s);
             if (st != HZ_OK) return st;
+            HZ_HIP(hipStreamWaitEvent(s, c->ev_ed, 0));   // join the signature stream
             break;
         }
         case T_DECODE_TX: {
@@ -537,7 +570,11 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             HZ_HIP(launch_hash_inputs(make_hi(c, false), s));
             break;
     }
-    c->last_stream = s;
+    if (s != s_user) {
+        HZ_HIP(hipEventRecord(c->ev_user_out, s));
+        HZ_HIP(hipStreamWaitEvent(s_user, c->ev_user_out, 0));
+    }
+    c->last_stream = s_user;
     c->enqueued = true;
     return HZ_OK;
 }

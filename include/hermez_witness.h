@@ -67,8 +67,14 @@ typedef struct {
      * (e.g. 2^20 Withdraw witnesses, or several RollupMain batches in flight). Inputs and the
      * witness carry the instance as the outermost index. 0 means 1. */
     int32_t n_instances;
-    int32_t flags;       /* reserved, 0 */
+    int32_t flags;       /* 0, or one of HZ_FLAG_* */
 } hz_params;
+/* HZ_FLAG_LATENCY: a RollupMain context that serves one request at a time (one to ~16 batches, nothing else on the device) puts
+ * its concurrent kernel chains -- front/hash/SMT/HashInputs, the two signature kernels, the fee chain -- on disjoint sets of compute
+ * units through CU-masked streams: single-batch latency 36.5 -> 25 ms. Default (0 or HZ_FLAG_THROUGHPUT): any kernel on any CU,
+ * the right choice when a second context is in flight. */
+#define HZ_FLAG_THROUGHPUT 1
+#define HZ_FLAG_LATENCY 2
 
 typedef struct {
     int32_t instance;      /* which instance failed */

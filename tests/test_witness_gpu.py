@@ -378,3 +378,22 @@ def test_odd_shapes_bit_exact(hz, shape, inst):
     for b in range(inst):
         assert g.get("main.hashGlobalInputs", b) == hashes[b]
     _compare_chunked(g, o)
+
+
+def test_latency_scheduling_flag_bit_exact(hz):
+    """HZ_FLAG_LATENCY (CU-masked internal streams): same witness, through a caller stream and through the context's own."""
+    from circuits_amd import builder as B
+    shape = (64, 16, 8, 4)
+    bb = B.synthetic_batch(*shape, n_accounts=32, exits=3, seed=77)
+    o = OracleCtx("rollup-main", *shape)
+    o.set_inputs(bb.get_input())
+    assert o.run() is None
+    g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3], flags=2)
+    g.set_inputs(bb.get_input())
+    g.run()
+    _compare(g, o)
+    import torch
+    s = torch.cuda.Stream()
+    g.enqueue(s.cuda_stream)
+    g.check()
+    _compare(g, o)
