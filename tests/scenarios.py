@@ -105,3 +105,59 @@ def eddsa_kat_rollup_tx(tamper=False):
     tin, tout = bb.get_single_tx_input(0)
     tin["sigL2Hash"] = int(kat["msg"])
     return (L, F), tin, tout
+
+
+def fee_tx_cases(L=16):
+    """Inputs of FeeTx(nLevels) as `component main` (reference test/fee-tx.test.js:40-150): the empty case, feeIdx = 0 with random
+    everything else (root unchanged), and the fee slots of a built batch (expected root = the next intermediate fee root)."""
+    import random
+    rng = random.Random(9)
+    zero = {k: 0 for k in "oldStateRoot feePlanToken feeIdx accFee tokenID nonce sign balance ay ethAddr".split()}
+    zero["siblings"] = [0] * (L + 1)
+    cases = [(dict(zero), 0)]
+    r = {"oldStateRoot": rng.randrange(1 << 253), "feePlanToken": rng.randrange(1 << 32), "feeIdx": 0, "accFee": rng.randrange(1 << 128),
+         "tokenID": rng.randrange(1 << 32), "nonce": rng.randrange(1 << 40), "sign": rng.randrange(2), "balance": rng.randrange(1 << 128),
+         "ay": rng.randrange(1 << 253), "ethAddr": rng.randrange(1 << 160), "siblings": [rng.randrange(1 << 253) for _ in range(L + 1)]}
+    cases.append((r, r["oldStateRoot"]))
+    bb = B.synthetic_batch(12, L, 3, 4, n_accounts=10, exits=1, seed=5)
+    inp = bb.get_input()
+    roots = [inp["imInitStateRootFee"]] + list(inp["imStateRootFee"]) + [bb.new_state_root]
+    for j in range(4):
+        c = {"oldStateRoot": roots[j], "feePlanToken": inp["feePlanTokens"][j], "feeIdx": inp["feeIdxs"][j], "accFee": inp["imFinalAccFee"][j],
+             "tokenID": inp["tokenID3"][j], "nonce": inp["nonce3"][j], "sign": inp["sign3"][j], "balance": inp["balance3"][j], "ay": inp["ay3"][j],
+             "ethAddr": inp["ethAddr3"][j], "siblings": inp["siblings3"][j]}
+        cases.append((c, roots[j + 1]))
+    return cases
+
+
+def hash_inputs_case(shape=(6, 16, 3, 2)):
+    """Inputs of HashInputs(nLevels, nTx, maxL1Tx, maxFeeTx) as `component main` (reference test/hash-inputs.test.js), cut out of
+    a built batch the way src/rollup-main.circom:433-470 wires them; expected output = the builder's SHA-256."""
+    nTx, L, m1, F = shape
+    bb = B.synthetic_batch(nTx, L, m1, F, n_accounts=6, exits=1, seed=12)
+    inp = bb.get_input()
+    l1 = []
+    for i in range(m1):
+        on = inp["onChain"][i] if i < nTx else 0
+        if on:
+            txc = inp["txCompressedData"][i]
+            bjj = sum(b << k for k, b in enumerate(inp["fromBjjCompressed"][i]))
+            bits = []
+            for v, n in ((inp["fromEthAddr"][i], 160), (bjj, 256), ((txc >> 48) & ((1 << 48) - 1), 48), (inp["loadAmountF"][i], 40),
+                         (inp["amountF"][i], 40), ((txc >> 144) & 0xFFFFFFFF, 32), ((txc >> 96) & ((1 << 48) - 1), 48)):
+                bits += [(v >> (n - 1 - k)) & 1 for k in range(n)]
+            l1 += bits
+        else:
+            l1 += [0] * 624
+    l2 = []
+    for i in range(nTx):
+        txc, on = inp["txCompressedData"][i], inp["onChain"][i]
+        frm, to = (txc >> 48) & ((1 << 48) - 1), (txc >> 96) & ((1 << 48) - 1)
+        final_to = inp["auxToIdx"][i] if (not on and to == 0) else to
+        amt = 0 if bb.tx_meta[i]["isAmountNullified"] else inp["amountF"][i]
+        for v, n in ((frm, L), (final_to, L), (amt, 40), (0 if on else (txc >> 216) & 0xFF, 8)):
+            l2 += [(v >> (n - 1 - k)) & 1 for k in range(n)]
+    hin = {"oldLastIdx": inp["oldLastIdx"], "newLastIdx": bb.new_last_idx, "oldStateRoot": inp["oldStateRoot"], "newStateRoot": bb.new_state_root,
+           "newExitRoot": bb.new_exit_root, "L1TxsFullData": l1, "L1L2TxsData": l2, "feeTxsData": inp["feeIdxs"],
+           "globalChainID": inp["globalChainID"], "currentNumBatch": inp["currentNumBatch"]}
+    return shape, hin, bb.get_hash_inputs()

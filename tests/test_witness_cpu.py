@@ -244,3 +244,18 @@ def test_builder_bit_level_sha256_matches_nist_and_hashlib():
     assert B.sha256_bits(bits) == hashlib.sha256(data).digest()
     # the slow path itself on aligned data: hash 1599 bits two ways is impossible with hashlib, so check prefix-extension consistency
     assert B.sha256_bits(bits[:1597]) != B.sha256_bits(bits[:1598])
+
+
+def test_oracle_fee_tx_and_hash_inputs_as_main_components():
+    """FeeTx(nLevels) and HashInputs(...) as `component main` (reference test/fee-tx.test.js:40-150, test/hash-inputs.test.js)."""
+    from scenarios import fee_tx_cases, hash_inputs_case
+    for inp, root in fee_tx_cases(16):
+        o = OracleCtx("fee-tx", nLevels=16)
+        o.set_inputs(inp)
+        assert o.run() is None
+        assert o.get("main.newStateRoot") == root
+    (nTx, L, m1, F), hin, exp = hash_inputs_case()
+    o = OracleCtx("hash-inputs", nTx, L, m1, F)
+    o.set_inputs(hin)
+    assert o.run() is None
+    assert o.get("main.hashInputsOut") == exp

@@ -397,3 +397,27 @@ def test_latency_scheduling_flag_bit_exact(hz):
     g.enqueue(s.cuda_stream)
     g.check()
     _compare(g, o)
+
+
+def test_fee_tx_and_hash_inputs_mains_bit_exact(hz):
+    from scenarios import fee_tx_cases, hash_inputs_case
+    cases = fee_tx_cases(16)
+    g = hz.ctx("fee-tx", nLevels=16, n_instances=len(cases))
+    o = OracleCtx("fee-tx", nLevels=16, n_instances=len(cases))
+    for k, (inp, _) in enumerate(cases):
+        g.set_inputs(inp, instance=k)
+        o.set_inputs(inp, instance=k)
+    g.run()
+    assert o.run() is None
+    _compare(g, o)
+    for k, (_, root) in enumerate(cases):
+        assert g.get("main.newStateRoot", k) == root
+    (nTx, L, m1, F), hin, exp = hash_inputs_case()
+    g = hz.ctx("hash-inputs", nTx=nTx, nLevels=L, maxL1Tx=m1, maxFeeTx=F)
+    o = OracleCtx("hash-inputs", nTx, L, m1, F)
+    g.set_inputs(hin)
+    o.set_inputs(hin)
+    g.run()
+    assert o.run() is None
+    assert g.get("main.hashInputsOut") == exp
+    _compare(g, o)
