@@ -161,3 +161,110 @@ def hash_inputs_case(shape=(6, 16, 3, 2)):
            "newExitRoot": bb.new_exit_root, "L1TxsFullData": l1, "L1L2TxsData": l2, "feeTxsData": inp["feeIdxs"],
            "globalChainID": inp["globalChainID"], "currentNumBatch": inp["currentNumBatch"]}
     return shape, hin, bb.get_hash_inputs()
+
+
+def reference_rollup_main_scripts():
+    """The scenario scripts of reference test/rollup-main.test.js (RollupMain(3, 16, 2, 2), accounts 1..3 at idx 256..258) with the
+    literal balances the suite asserts after each batch (`assertAccountsBalances`, None = not asserted). Transactions are written with
+    the suite's own field values; `signer` / `auxToIdx` replace what the JS batch builder derives by itself."""
+    acc = [B.Account(i + 1) for i in range(3)]
+    idx = [256, 257, 258]
+    nul = (1 << 160) - 1
+
+    def dep(a, token, amount, eth=None):
+        return {"fromIdx": 0, "loadAmountF": B.fix2float(amount), "tokenID": token, "fromBjjCompressed": acc[a].bjj_compressed,
+                "fromEthAddr": acc[a].eth_addr if eth is None else eth, "toIdx": 0, "onChain": 1}
+
+    def l1(frm, to, amount, load=0, eth=None):
+        return {"fromIdx": idx[frm], "loadAmountF": load, "tokenID": 1, "fromBjjCompressed": 0, "fromEthAddr": acc[frm].eth_addr if eth is None else eth,
+                "toIdx": to, "amount": amount, "userFee": 0, "onChain": 1}
+
+    def l2(frm, to, amount, fee=0, **kw):
+        d = {"fromIdx": idx[frm], "toIdx": to, "amount": amount, "tokenID": 1, "userFee": fee, "onChain": 0, "signer": acc[frm]}
+        d.update(kw)
+        return d
+    two_deposits = ([dep(0, 1, 1000), dep(1, 1, 1000)], [], None)
+    S = []
+    S.append(("empty tx (:65)", [([], [], None)]))
+    S.append(("L1 createAccount (:74)", [([dep(0, 1, 0), dep(1, 2, 0)], [], None), ([dep(2, 1, 0)], [], [0, 0, 0])]))
+    S.append(("L1 createAccountDeposit & deposit (:93)", [
+        ([dep(0, 1, 1000)], [], None),
+        ([{"fromIdx": 256, "loadAmountF": 500, "tokenID": 1, "fromBjjCompressed": 0, "fromEthAddr": 0, "toIdx": 0, "amount": 0, "userFee": 0, "onChain": 1}], [], [1500, None, None])]))
+    S.append(("L1 createAccountDepositTransfer & depositTransfer (:121)", [
+        two_deposits,
+        ([{"fromIdx": 0, "loadAmountF": 500, "tokenID": 1, "fromBjjCompressed": acc[2].bjj_compressed, "fromEthAddr": acc[2].eth_addr, "toIdx": 256,
+           "amount": 100, "userFee": 0, "onChain": 1},
+          {"fromIdx": 258, "loadAmountF": 200, "tokenID": 1, "fromBjjCompressed": 0, "fromEthAddr": acc[2].eth_addr, "toIdx": 257, "amount": 100,
+           "userFee": 126, "onChain": 1}], [], [1100, 1100, 500])]))
+    S.append(("L1 forceTransfer & forceExit (:166)", [
+        two_deposits,
+        ([l1(0, 257, 100), l1(0, 1, 300)], [], [600, 1100, None]),
+        ([l1(1, 1, 550), l1(1, 1, 550)], [], [600, 0, None])]))
+    S.append(("L2 transfer & exit (:247)", [
+        two_deposits,
+        ([l2(0, 257, 100), l2(1, 1, 100)], [], [900, 1000, None]),
+        ([l2(1, 1, 525), l2(1, 1, 450)], [], [900, 25, None])]))
+    S.append(("L2 transfer & exit with 0 amount (:337)", [
+        two_deposits,
+        ([l2(0, 257, 0)], [], [1000, 1000, None]),
+        ([l2(1, 1, 0)], [], [1000, 1000, None]),
+        ([l2(1, 1, 500), l2(1, 1, 0)], [], [1000, 500, None]),
+        ([l2(0, 257, 500), l2(0, 257, 0)], [], [500, 1000, None])]))
+    S.append(("L2 transfer to ethAddr & transfer to Bjj (:558)", [
+        ([dep(0, 1, 1000), dep(1, 1, 1000, eth=nul)], [], None),
+        ([dep(2, 1, 0), l2(1, 0, 500, 184, toEthAddr=acc[0].eth_addr, auxToIdx=256),
+          l2(0, 0, 100, 0, toEthAddr=nul, toBjjAy=acc[1].ay, toBjjSign=acc[1].sign, auxToIdx=257)], [(1, 258)], [1400, 222, 378])]))
+    return (3, 16, 2, 2), idx, S
+
+
+def reference_l1_edge_scripts():
+    """The L1 edge cases of reference test/rollup-main-L1.test.js:88-519 (RollupMain(3, 16, 2, 2)): each entry is
+    (name, setup batches, [(tx, expected isAmountNullified, expected sender-balance delta or None)]); every edge transaction goes in a
+    batch of its own, the circuit must accept all of them (invalid L1 transactions are nullified, never rejected)."""
+    acc = [B.Account(i + 1) for i in range(3)]
+    rnd_eth = 0xD8Af0C5c6dEE7dCe32E59577675C026e1aDe4De5
+
+    def dep(a, token, amount):
+        return {"fromIdx": 0, "loadAmountF": B.fix2float(amount), "tokenID": token, "fromBjjCompressed": acc[a].bjj_compressed,
+                "fromEthAddr": acc[a].eth_addr, "toIdx": 0, "onChain": 1}
+
+    def tx(**kw):
+        d = {"fromIdx": 0, "loadAmountF": 0, "tokenID": 1, "amountF": 0, "fromBjjCompressed": 0, "fromEthAddr": acc[0].eth_addr, "toIdx": 0, "onChain": 1}
+        d.update(kw)
+        return d
+    S = []
+    ca = dict(fromBjjCompressed=acc[0].bjj_compressed)
+    S.append(("createAccount (:88)", [], [
+        (tx(**ca), 0, None), (tx(fromBjjCompressed=0x12345), 0, None), (tx(fromBjjCompressed=(1 << 256) - 1), 0, None)]))
+    S.append(("createAccountDeposit (:125)", [], [
+        (tx(loadAmountF=0, **ca), 0, None), (tx(loadAmountF=0xFFFF, **ca), 0, None)]))
+    base = dict(loadAmountF=500, fromBjjCompressed=acc[2].bjj_compressed, fromEthAddr=acc[2].eth_addr, toIdx=256, amountF=100)
+    S.append(("createAccountDepositTransfer (:158)", [[dep(0, 1, 1000), dep(1, 2, 1000)]], [
+        (tx(**dict(base, amountF=0)), 0, None),
+        (tx(**dict(base, amountF=0xFFFF)), 1, None),                          # not enough funds: amount nullified
+        (tx(**dict(base, loadAmountF=0xFFFF, amountF=0xFFFF)), 0, None),      # transfers all it loaded
+        (tx(**dict(base, toIdx=257)), 1, None)]))                              # receiver of another token: amount nullified
+    d = dict(fromIdx=256, loadAmountF=500)
+    S.append(("deposit (:219)", [[dep(0, 1, 1000), dep(1, 2, 1000)]], [
+        (tx(**dict(d, tokenID=2)), 0, 0),                                      # wrong token: loadAmount nullified, balance unchanged
+        (tx(**dict(d, fromEthAddr=rnd_eth)), 0, 500),                          # anybody may deposit
+        (tx(**dict(d, loadAmountF=0)), 0, 0)]))
+    dt = dict(fromIdx=256, loadAmountF=200, toIdx=258, amountF=100, userFee=184)
+    S.append(("depositTransfer (:273)", [[dep(0, 1, 1000), dep(1, 2, 1000)], [dep(2, 1, 1000)]], [
+        (tx(**dict(dt, tokenID=2)), 1, 0),                                     # load and amount nullified
+        (tx(**dict(dt, toIdx=257)), 1, 200),                                   # amount nullified, deposit kept
+        (tx(**dict(dt, fromEthAddr=acc[2].eth_addr)), 1, 200)]))
+    ft = dict(fromIdx=256, toIdx=258, amountF=B.fix2float(500))
+    S.append(("forceTransfer (:338)", [[dep(0, 1, 1000), dep(1, 2, 1000)], [dep(2, 1, 1000)]], [
+        (tx(**dict(ft, toIdx=257)), 1, 0),
+        (tx(**dict(ft, toIdx=257, tokenID=2)), 1, 0),
+        (tx(**dict(ft, fromEthAddr=acc[2].eth_addr)), 1, 0),
+        (tx(**dict(ft, amountF=0)), 0, 0),
+        (tx(**ft), 0, -500)]))
+    fe = dict(fromIdx=256, toIdx=1, amountF=B.fix2float(100))
+    S.append(("forceExit (:419)", [[dep(0, 1, 1000), dep(1, 2, 1000)]], [
+        (tx(**dict(fe, tokenID=2)), 1, 0),                                     # creates an exit leaf with balance 0
+        (tx(**dict(fe, fromEthAddr=acc[1].eth_addr)), 1, 0),
+        (tx(**dict(fe, amountF=0)), 0, 0),                                     # no exit leaf
+        (tx(**fe), 0, -100)]))
+    return (3, 16, 2, 2), S

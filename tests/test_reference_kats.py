@@ -503,3 +503,87 @@ def test_hip_balance_updater_reference_vectors(hz):
         except ConstraintError as e:
             return str(e)
     _bu_scenarios(lambda: hz.ctx("rollup-tx", nLevels=L, maxFeeTx=F), failure_of)
+
+
+# ---- the scenario scripts of the reference's rollup-main suite, with the balances it asserts -------------------------------
+def _replay_rollup_main_scripts(make_ctx, run):
+    from circuits_amd import builder as B
+    from scenarios import reference_rollup_main_scripts
+    shape, idx, scripts = reference_rollup_main_scripts()
+    for name, batches in scripts:
+        db = B.RollupDB(chain_id=1)
+        for txs, fees, balances in batches:
+            bb = db.build_batch(*shape)
+            for t in txs:
+                bb.add_tx(t)
+            for token, fidx in fees:
+                bb.add_token(token)
+                bb.add_fee_idx(fidx)
+            bb.build()
+            c = make_ctx(shape)
+            c.set_inputs(bb.get_input())
+            assert run(c) is None, name
+            assert c.get("main.hashGlobalInputs") == bb.get_hash_inputs(), name
+            if balances is not None:
+                got = [db.leaves[i]["balance"] if b is not None else None for i, b in zip(idx, balances)]
+                assert got == balances, (name, got, balances)
+
+
+def test_oracle_replays_reference_rollup_main_scripts():
+    _replay_rollup_main_scripts(lambda s: _O("rollup-main", *s), lambda c: c.o.run())
+
+
+@pytest.mark.gpu
+def test_hip_replays_reference_rollup_main_scripts(hz):
+    from circuits_amd import ConstraintError
+
+    def run(c):
+        try:
+            c.run()
+            return None
+        except ConstraintError as e:
+            return str(e)
+    _replay_rollup_main_scripts(lambda s: hz.ctx("rollup-main", nTx=s[0], nLevels=s[1], maxL1Tx=s[2], maxFeeTx=s[3]), run)
+
+
+def _replay_l1_edge_scripts(make_ctx, run):
+    from circuits_amd import builder as B
+    from scenarios import reference_l1_edge_scripts
+    shape, scripts = reference_l1_edge_scripts()
+    for name, setup, cases in scripts:
+        db = B.RollupDB(chain_id=1)
+        for txs in setup:
+            bb = db.build_batch(*shape)
+            for t in txs:
+                bb.add_tx(t)
+            bb.build()
+        for k, (t, nullified, delta) in enumerate(cases):
+            before = db.leaves[t["fromIdx"]]["balance"] if t["fromIdx"] else None
+            bb = db.build_batch(*shape)
+            bb.add_tx(dict(t))
+            bb.build()
+            c = make_ctx(shape)
+            c.set_inputs(bb.get_input())
+            assert run(c) is None, (name, k)
+            assert c.get("main.hashGlobalInputs") == bb.get_hash_inputs(), (name, k)
+            assert bb.tx_meta[0]["isAmountNullified"] == nullified, (name, k)
+            assert c.get("main.rollupTx[0].balanceUpdater.isAmountNullified") == nullified, (name, k)
+            if delta is not None:
+                assert db.leaves[t["fromIdx"]]["balance"] - before == delta, (name, k)
+
+
+def test_oracle_replays_reference_l1_edge_cases():
+    _replay_l1_edge_scripts(lambda s: _O("rollup-main", *s), lambda c: c.o.run())
+
+
+@pytest.mark.gpu
+def test_hip_replays_reference_l1_edge_cases(hz):
+    from circuits_amd import ConstraintError
+
+    def run(c):
+        try:
+            c.run()
+            return None
+        except ConstraintError as e:
+            return str(e)
+    _replay_l1_edge_scripts(lambda s: hz.ctx("rollup-main", nTx=s[0], nLevels=s[1], maxL1Tx=s[2], maxFeeTx=s[3]), run)
