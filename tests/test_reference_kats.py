@@ -587,3 +587,81 @@ def test_hip_replays_reference_l1_edge_cases(hz):
         except ConstraintError as e:
             return str(e)
     _replay_l1_edge_scripts(lambda s: hz.ctx("rollup-main", nTx=s[0], nLevels=s[1], maxL1Tx=s[2], maxFeeTx=s[3]), run)
+
+
+# ---- reference test/rollup-tx.test.js pattern (`assertTxs`, test/helpers/helpers.js:139-145): every transaction of a built batch,
+# sliced out with getSingleTxInput, through the standalone RollupTx with the builder's expected outputs ---------------------------
+def _single_tx_batches():
+    from circuits_amd import builder as B
+    from scenarios import all_tx_types, reference_rollup_main_scripts, SHAPE
+    out = []
+    _, batches, _ = all_tx_types()
+    out.append((SHAPE, batches[1]))
+    shape, _, scripts = reference_rollup_main_scripts()
+    for name, steps in scripts[3:]:
+        db = B.RollupDB(chain_id=1)
+        for txs, fees, _ in steps:
+            bb = db.build_batch(*shape)
+            for t in txs:
+                bb.add_tx(dict(t))
+            for token, fidx in fees:
+                bb.add_token(token)
+                bb.add_fee_idx(fidx)
+            bb.build()
+        out.append((shape, bb))    # the last batch of each script
+    return out
+
+
+def _assert_txs(make_ctx):
+    for shape, bb in _single_tx_batches():
+        nTx, Lv, _, Fv = shape
+        c = make_ctx(Lv, Fv, nTx)
+        outs = []
+        for i in range(nTx):
+            tin, tout = bb.get_single_tx_input(i)
+            c.set_inputs(tin, i)
+            outs.append(tout)
+        assert c.run() is None
+        for i, tout in enumerate(outs):
+            assert c.get("main.newStateRoot", i) == tout["newStateRoot"] and c.get("main.newExitRoot", i) == tout["newExitRoot"]
+            assert c.get("main.isAmountNullified", i) == tout["isAmountNullified"]
+            assert [c.get("main.accFeeOut[%d]" % j, i) for j in range(Fv)] == tout["accFeeOut"]
+
+
+def test_oracle_single_transactions_of_every_scenario():
+    class C:
+        def __init__(self, Lv, Fv, n):
+            self.o = OracleCtx("rollup-tx", nLevels=Lv, maxFeeTx=Fv, n_instances=n)
+
+        def set_inputs(self, d, i):
+            self.o.set_inputs(d, instance=i)
+
+        def run(self):
+            return self.o.run()
+
+        def get(self, name, i):
+            return self.o.get(name, i)
+    _assert_txs(C)
+
+
+@pytest.mark.gpu
+def test_hip_single_transactions_of_every_scenario(hz):
+    from circuits_amd import ConstraintError
+
+    class C:
+        def __init__(self, Lv, Fv, n):
+            self.g = hz.ctx("rollup-tx", nLevels=Lv, maxFeeTx=Fv, n_instances=n)
+
+        def set_inputs(self, d, i):
+            self.g.set_inputs(d, instance=i)
+
+        def run(self):
+            try:
+                self.g.run()
+                return None
+            except ConstraintError as e:
+                return str(e)
+
+        def get(self, name, i):
+            return self.g.get(name, i)
+    _assert_txs(C)
