@@ -52,6 +52,10 @@ static const Tmpl TEMPLATES[] = {
     {"RollupMain", HZ_T_ROLLUP_MAIN, 4, {0, 1, 2, 3}}, {"RollupTx", HZ_T_ROLLUP_TX, 2, {1, 3, 0, 0}}, {"DecodeTx", HZ_T_DECODE_TX, 1, {1, 0, 0, 0}},
     {"FeeTx", HZ_T_FEE_TX, 1, {1, 0, 0, 0}}, {"HashState", HZ_T_HASH_STATE, 0, {0, 0, 0, 0}}, {"Withdraw", HZ_T_WITHDRAW, 1, {1, 0, 0, 0}},
     {"HashInputs", HZ_T_HASH_INPUTS, 4, {1, 0, 2, 3}},
+    {"DecodeFloat", HZ_T_DECODE_FLOAT, 0, {0, 0, 0, 0}}, {"ComputeFee", HZ_T_COMPUTE_FEE, 0, {0, 0, 0, 0}},
+    {"FeeAccumulator", HZ_T_FEE_ACCUMULATOR, 1, {3, 0, 0, 0}}, {"BalanceUpdater", HZ_T_BALANCE_UPDATER, 0, {0, 0, 0, 0}},
+    {"RollupTxStates", HZ_T_ROLLUP_TX_STATES, 0, {0, 0, 0, 0}}, {"RqTxVerifier", HZ_T_RQ_TX_VERIFIER, 0, {0, 0, 0, 0}},
+    {"Mux256", HZ_T_MUX256, 0, {0, 0, 0, 0}}, {"BitsCompressed2AySign", HZ_T_BITS2AYSIGN, 0, {0, 0, 0, 0}}, {"AySign2Ax", HZ_T_AYSIGN2AX, 0, {0, 0, 0, 0}},
 };
 
 static bool parse_main(std::string spec, hz_params* p) {

@@ -124,7 +124,8 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     Params lp;
     lp.tmpl = p->template_id; lp.nTx = p->nTx; lp.L = p->nLevels; lp.maxL1 = p->maxL1Tx; lp.F = p->maxFeeTx;
     lp.n_inst = p->n_instances > 0 ? p->n_instances : 1;
-    const bool needs_L = lp.tmpl != T_HASH_STATE;
+    const bool needs_L = lp.tmpl != T_HASH_STATE && lp.tmpl < T_DECODE_FLOAT;
+    if (lp.tmpl == T_FEE_ACCUMULATOR && lp.F < 1) return set_err(HZ_ERR_ARG, "FeeAccumulator needs maxFeeTx >= 1");
     if (needs_L && (lp.L < 2 || lp.L > 48)) return set_err(HZ_ERR_ARG, "nLevels must be in [2,48]");
     if ((lp.tmpl == T_ROLLUP_MAIN || lp.tmpl == T_HASH_INPUTS) && (lp.nTx < 1 || lp.F < 1 || lp.maxL1 < 0))
         return set_err(HZ_ERR_ARG, "RollupMain/HashInputs need nTx >= 1, maxFeeTx >= 1");
@@ -569,6 +570,18 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
         case T_HASH_INPUTS:
             HZ_HIP(launch_hash_inputs(make_hi(c, false), s));
             break;
+        case T_DECODE_FLOAT: case T_COMPUTE_FEE: case T_FEE_ACCUMULATOR: case T_BALANCE_UPDATER: case T_ROLLUP_TX_STATES: case T_RQ_TX_VERIFIER:
+        case T_MUX256: case T_BITS2AYSIGN: case T_AYSIGN2AX: {
+            GadgetArgs ga;
+            memset(&ga, 0, sizeof ga);
+            ga.base = sec_ptr(c, 0); ga.err = err; ga.N = lo.sections[0].n_units; ga.F = (uint32_t)lo.p.F; ga.io = lo.gad;
+            ga.n2b40 = lo.rtx.n2bLoadAmountF; ga.df = lo.rtx.dfLoadAmount; ga.bu = lo.rtx.bu; ga.feeAcc = lo.rtx.feeAcc; ga.st = lo.rtx.st;
+            ga.rq_n2b = lo.rtx.rq_n2b;
+            for (int m = 0; m < 3; m++) ga.rq_mux[m] = lo.rtx.rq_mux[m];
+            if (lo.p.tmpl == T_AYSIGN2AX) HZ_HIP(launch_ay_sign_2_ax_main(ga, lo.rtx.ed, s));
+            else HZ_HIP(launch_gadget(lo.p.tmpl, ga, s));
+            break;
+        }
     }
     if (s != s_user) {
         HZ_HIP(hipEventRecord(c->ev_user_out, s));

@@ -289,11 +289,8 @@ struct EdSig {
     Fr enabled, zp;
     PtA R8, p0;
 };
-__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out) {
-    const EdCtx c = K.with(io);
-    const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
-    const Fr R8x = sc.get(SC_ED_R8X), R8y = sc.get(SC_ED_R8Y), M = sc.get(SC_SIGL2HASH);
-    // ---- AySign2Ax
+// AySign2Ax (src/lib/utils-bjj.circom:37-58) with circomlib's Bits2Point_Strict: x from y and the sign, both alias checks
+__device__ __forceinline__ Fr ay_sign_2_ax_dev(const EdCtx& c, const UnitIO& io, const EddsaOff& o, const Fr& aySig, const Fr& signSig) {
     const Fc ay_c = fr_to_canon(aySig);
     for (int k = 0; k < 254; k++) io.put_bit(o.ax_n2bAy + k, c_bit(ay_c, k));
     if (comp_constant_dev(io, o.ax_aliasY, ay_c, CT_MINUS1_D)) report_fail(io.err, io.inst, io.err_unit, C_RTX_AX_ALIAS_Y, c.one, fr_zero());
@@ -308,10 +305,16 @@ __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const S
     io.chk(C_RTX_AX_BABYCHECK, fr_add(fr_mul(c.a, x2), y2), fr_add(c.one, fr_mul(fr_mul(c.d, x2), y2)));
     for (int k = 0; k < 254; k++) io.put_bit(o.ax_n2bX + k, c_bit(x_c, k));
     if (comp_constant_dev(io, o.ax_aliasX, x_c, CT_MINUS1_D)) report_fail(io.err, io.inst, io.err_unit, C_RTX_AX_ALIAS_X, c.one, fr_zero());
-    {
-        const uint32_t sg = comp_constant_dev(io, o.ax_signCalc, x_c, CT_HALF_D);
-        io.chk(C_RTX_AX_SIGN, fr_from_bit(sg), signSig);
-    }
+    const uint32_t sg = comp_constant_dev(io, o.ax_signCalc, x_c, CT_HALF_D);
+    io.chk(C_RTX_AX_SIGN, fr_from_bit(sg), signSig);
+    return x;
+}
+
+__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out) {
+    const EdCtx c = K.with(io);
+    const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
+    const Fr R8x = sc.get(SC_ED_R8X), R8y = sc.get(SC_ED_R8Y), M = sc.get(SC_SIGL2HASH);
+    const Fr x = ay_sign_2_ax_dev(c, io, o, aySig, signSig);
     // ---- EdDSAPoseidonVerifier (the S decomposition and range check belong to k_eddsa_fix)
     Fr hin[5] = {R8x, R8y, x, Ay, M};
     WitSboxSink s6 = io.sbox_sink(o.hash);
@@ -499,6 +502,22 @@ hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     hipLaunchKernelGGL(k_eddsa_final, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+// `component main = AySign2Ax()` (test/lib/utils-bjj.test.js:104-150): one lane per instance
+__global__ __launch_bounds__(HZ_BLOCK) void k_ay_sign_2_ax_main(const GadgetArgs a, const EddsaOff o) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N) return;
+    const UnitIO io{a.base, a.N, i, i, 0, a.err};
+    io.put_u64(0, 1);
+    EdK K;
+    K.one = fr_one();
+    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    io.put_m(a.io.out[0], ay_sign_2_ax_dev(K.with(io), io, o, io.in_m(a.io.in[0]), io.in_m(a.io.in[1])));
+}
+hipError_t launch_ay_sign_2_ax_main(const GadgetArgs& a, const EddsaOff& o, hipStream_t s) {
+    hipLaunchKernelGGL(k_ay_sign_2_ax_main, dim3((a.N + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a, o);
     return hipGetLastError();
 }
 

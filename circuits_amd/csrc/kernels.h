@@ -45,6 +45,21 @@ struct DecMainArgs {
     DecOff dec;
 };
 
+// a gadget main (gadget_kernels.hip): the offsets of the one gadget the template instantiates are set, the rest unused
+struct GadgetArgs {
+    uint8_t* base;
+    ErrBuf* err;
+    uint32_t N, F;
+    GadIO io;
+    uint32_t n2b40;          // DecodeFloat: n2b.out[40]
+    DecodeFloatOff df;
+    BalUpdOff bu;            // ComputeFee uses bu.fee
+    uint32_t feeAcc;
+    StatesOff st;
+    uint32_t rq_n2b;
+    Mux3Off rq_mux[3];
+};
+
 // one hash-state job of k_hash4 (blockIdx.y selects the job)
 struct HashJob {
     PoseidonOff hs;        // HashState Poseidon (t = 5) signals
@@ -160,6 +175,8 @@ hipError_t launch_withdraw_sha(const WithdrawArgs& a, hipStream_t s);
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s);
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s);
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s);
+hipError_t launch_gadget(int tmpl, const GadgetArgs& a, hipStream_t s);
+hipError_t launch_ay_sign_2_ax_main(const GadgetArgs& a, const EddsaOff& o, hipStream_t s);   // eddsa_kernels.hip (shares the curve code)
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
 int smt_chunk_levels(const SmtArgs& a);   // levels per launch (the chain is launched in chunks, smt_kernels.hip)
 hipError_t launch_smt_levels(const SmtArgs& a, int k_hi, int k_lo, hipStream_t s);

@@ -208,6 +208,26 @@ __device__ __forceinline__ Fr mux4_coef(const Fr* c, int mask) {
     return acc;
 }
 
+// MultiMux4(1) with signal inputs: stores s10,s20,s21,s210 and the 14 product terms + out (MX4V_* order)
+__device__ __forceinline__ Fr mux4_var_dev(const UnitIO& io, uint32_t b, const Fr* c, const Fr* t) {
+    const Fr t10 = fr_mul(t[1], t[0]), t20 = fr_mul(t[2], t[0]), t21 = fr_mul(t[2], t[1]), t210 = fr_mul(t21, t[0]);
+    const Fr a3210 = fr_mul(mux4_coef(c, 15), t210), a321 = fr_mul(mux4_coef(c, 14), t21), a320 = fr_mul(mux4_coef(c, 13), t20);
+    const Fr a310 = fr_mul(mux4_coef(c, 11), t10), a32 = fr_mul(mux4_coef(c, 12), t[2]), a31 = fr_mul(mux4_coef(c, 10), t[1]);
+    const Fr a30 = fr_mul(mux4_coef(c, 9), t[0]), a3 = mux4_coef(c, 8);
+    const Fr a210 = fr_mul(mux4_coef(c, 7), t210), a21 = fr_mul(mux4_coef(c, 6), t21), a20 = fr_mul(mux4_coef(c, 5), t20);
+    const Fr a10 = fr_mul(mux4_coef(c, 3), t10), a2 = fr_mul(mux4_coef(c, 4), t[2]), a1 = fr_mul(mux4_coef(c, 2), t[1]);
+    const Fr a0 = fr_mul(mux4_coef(c, 1), t[0]);
+    const Fr hi = fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(a3210, a321), a320), a310), a32), a31), a30), a3);
+    const Fr lo = fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(a210, a21), a20), a10), a2), a1), a0), c[0]);
+    const Fr out = fr_add(fr_mul(hi, t[3]), lo);
+    io.put_m(b + MX4_S10, t10); io.put_m(b + MX4_S20, t20); io.put_m(b + MX4_S21, t21); io.put_m(b + MX4_S210, t210);
+    io.put_m(b + MX4V_A3210, a3210); io.put_m(b + MX4V_A321, a321); io.put_m(b + MX4V_A320, a320); io.put_m(b + MX4V_A310, a310);
+    io.put_m(b + MX4V_A32, a32); io.put_m(b + MX4V_A31, a31); io.put_m(b + MX4V_A30, a30);
+    io.put_m(b + MX4V_A210, a210); io.put_m(b + MX4V_A21, a21); io.put_m(b + MX4V_A20, a20); io.put_m(b + MX4V_A10, a10);
+    io.put_m(b + MX4V_A2, a2); io.put_m(b + MX4V_A1, a1); io.put_m(b + MX4V_A0, a0); io.put_m(b + MX4V_OUT, out);
+    return out;
+}
+
 // ComputeFee (src/compute-fee.circom:12-94) incl. Mux256 (src/lib/mux256.circom)
 __device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFeeOff& o, const Fc& feeSel_c, const Fr& amount, const Fr& applyFee) {
     const Fr one = fr_one();
@@ -238,25 +258,7 @@ __device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFee
         io.put_m(b + MX4_OUT_C, lvl1[m]);
     }
     // second level: selectors s[4..7], signal inputs: every product term is stored
-    const Fr* t = s + 4;
-    const Fr t10 = fr_mul(t[1], t[0]), t20 = fr_mul(t[2], t[0]), t21 = fr_mul(t[2], t[1]), t210 = fr_mul(t21, t[0]);
-    const Fr a3210 = fr_mul(mux4_coef(lvl1, 15), t210), a321 = fr_mul(mux4_coef(lvl1, 14), t21), a320 = fr_mul(mux4_coef(lvl1, 13), t20);
-    const Fr a310 = fr_mul(mux4_coef(lvl1, 11), t10), a32 = fr_mul(mux4_coef(lvl1, 12), t[2]), a31 = fr_mul(mux4_coef(lvl1, 10), t[1]);
-    const Fr a30 = fr_mul(mux4_coef(lvl1, 9), t[0]), a3 = mux4_coef(lvl1, 8);
-    const Fr a210 = fr_mul(mux4_coef(lvl1, 7), t210), a21 = fr_mul(mux4_coef(lvl1, 6), t21), a20 = fr_mul(mux4_coef(lvl1, 5), t20);
-    const Fr a10 = fr_mul(mux4_coef(lvl1, 3), t10), a2 = fr_mul(mux4_coef(lvl1, 4), t[2]), a1 = fr_mul(mux4_coef(lvl1, 2), t[1]);
-    const Fr a0 = fr_mul(mux4_coef(lvl1, 1), t[0]);
-    const Fr hi = fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(a3210, a321), a320), a310), a32), a31), a30), a3);
-    const Fr lo = fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(a210, a21), a20), a10), a2), a1), a0), lvl1[0]);
-    const Fr factor = fr_add(fr_mul(hi, t[3]), lo);
-    {
-        const uint32_t b = o.mux2;
-        io.put_m(b + MX4_S10, t10); io.put_m(b + MX4_S20, t20); io.put_m(b + MX4_S21, t21); io.put_m(b + MX4_S210, t210);
-        io.put_m(b + MX4V_A3210, a3210); io.put_m(b + MX4V_A321, a321); io.put_m(b + MX4V_A320, a320); io.put_m(b + MX4V_A310, a310);
-        io.put_m(b + MX4V_A32, a32); io.put_m(b + MX4V_A31, a31); io.put_m(b + MX4V_A30, a30);
-        io.put_m(b + MX4V_A210, a210); io.put_m(b + MX4V_A21, a21); io.put_m(b + MX4V_A20, a20); io.put_m(b + MX4V_A10, a10);
-        io.put_m(b + MX4V_A2, a2); io.put_m(b + MX4V_A1, a1); io.put_m(b + MX4V_A0, a0); io.put_m(b + MX4V_OUT, factor);
-    }
+    const Fr factor = mux4_var_dev(io, o.mux2, lvl1, s + 4);
     const Fr notShifted = fr_mul(factor, amount);
     const Fc ns_c = fr_to_canon(notShifted);
     io.put_c(o.feeOutNotShifted, ns_c);

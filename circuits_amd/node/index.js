@@ -29,6 +29,15 @@ const TEMPLATES = {
     HashState: [4, []],
     Withdraw: [5, ["nLevels"]],
     HashInputs: [6, ["nLevels", "nTx", "maxL1Tx", "maxFeeTx"]],
+    DecodeFloat: [7, []],
+    ComputeFee: [8, []],
+    FeeAccumulator: [9, ["maxFeeTx"]],
+    BalanceUpdater: [10, []],
+    RollupTxStates: [11, []],
+    RqTxVerifier: [12, []],
+    Mux256: [13, []],
+    BitsCompressed2AySign: [14, []],
+    AySign2Ax: [15, []],
 };
 
 function parseMain(spec) {

@@ -53,6 +53,16 @@ typedef enum {
     HZ_T_HASH_STATE = 4,  /* HashState()                               src/lib/hash-state.circom:18*/
     HZ_T_WITHDRAW = 5,    /* Withdraw(nLevels)                         src/withdraw.circom:21      */
     HZ_T_HASH_INPUTS = 6, /* HashInputs(nLevels,nTx,maxL1Tx,maxFeeTx)  src/hash-inputs.circom:23   */
+    /* gadget mains of the reference's unit suites (one witness per instance, a single small kernel) */
+    HZ_T_DECODE_FLOAT = 7,     /* DecodeFloat()                        src/lib/decode-float.circom:51   */
+    HZ_T_COMPUTE_FEE = 8,      /* ComputeFee()                         src/compute-fee.circom:12        */
+    HZ_T_FEE_ACCUMULATOR = 9,  /* FeeAccumulator(maxFeeTx)             src/fee-accumulator.circom:56    */
+    HZ_T_BALANCE_UPDATER = 10, /* BalanceUpdater()                     src/balance-updater.circom:24    */
+    HZ_T_ROLLUP_TX_STATES = 11,/* RollupTxStates()                     src/rollup-tx-states.circom:39   */
+    HZ_T_RQ_TX_VERIFIER = 12,  /* RqTxVerifier()                       src/rq-tx-verifier.circom:19     */
+    HZ_T_MUX256 = 13,          /* Mux256()                             src/lib/mux256.circom:10         */
+    HZ_T_BITS2AYSIGN = 14,     /* BitsCompressed2AySign()              src/lib/utils-bjj.circom:12      */
+    HZ_T_AYSIGN2AX = 15,       /* AySign2Ax()                          src/lib/utils-bjj.circom:37      */
     HZ_T_COUNT
 } hz_template;
 

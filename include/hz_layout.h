@@ -36,7 +36,11 @@ namespace hzl {
 
 // ------------------------------------------------------------------------------------------------
 // template ids (== hz_template in hermez_witness.h)
-enum { T_ROLLUP_MAIN = 0, T_ROLLUP_TX = 1, T_DECODE_TX = 2, T_FEE_TX = 3, T_HASH_STATE = 4, T_WITHDRAW = 5, T_HASH_INPUTS = 6, T_COUNT = 7 };
+enum { T_ROLLUP_MAIN = 0, T_ROLLUP_TX = 1, T_DECODE_TX = 2, T_FEE_TX = 3, T_HASH_STATE = 4, T_WITHDRAW = 5, T_HASH_INPUTS = 6,
+       // the gadget templates the reference's remaining suites instantiate as `component main`
+       T_DECODE_FLOAT = 7, T_COMPUTE_FEE = 8, T_FEE_ACCUMULATOR = 9, T_BALANCE_UPDATER = 10, T_ROLLUP_TX_STATES = 11, T_RQ_TX_VERIFIER = 12,
+       T_MUX256 = 13, T_BITS2AYSIGN = 14, T_AYSIGN2AX = 15,
+       T_COUNT = 16 };
 
 struct Params {
     int tmpl = 0, nTx = 0, L = 0, maxL1 = 0, F = 0, n_inst = 1;
@@ -518,6 +522,10 @@ inline std::string poseidon_signame(int t, int j) {
 struct Layout;
 inline void build_layout(const Params& p, Layout& out);  // defined below
 
+// inputs / outputs of a gadget main, in the declaration order of its template (the gadget's internal signals reuse the offset
+// structs of RtxOff: StatesOff, BalUpdOff, ComputeFeeOff, DecodeFloatOff, the rq muxes, the fee-accumulator chain)
+struct GadIO { uint32_t in[24]; uint32_t out[16]; uint32_t mux; /* Mux256: first of 17 variable-input Mux4 blocks */ };
+
 struct Layout {
     Params p;
     std::vector<Section> sections;
@@ -540,6 +548,7 @@ struct Layout {
     HashStateOff hs{};
     HashInputsOff hi{};
     WithdrawOff wd{};
+    GadIO gad{};
     int sec_tx = -1, sec_fee = -1, sec_glob = -1, sec_hi = -1;  // section indices
 
     // physical index of (section, sig, global unit = instance * upi + local unit)
@@ -805,6 +814,15 @@ inline void lay_states(Section& s, const std::string& pre, StatesOff& o) {
     o.nullifyAmount = s.add(pre + "nullifyAmount");
 }
 
+// circomlib mux4.circom MultiMux4(1) whose inputs are signals: every product term is a variable (MX4V_* order)
+inline uint32_t lay_mux4v(Section& s, const std::string& q) {
+    const uint32_t base = s.add(q + "s10"); s.add(q + "s20"); s.add(q + "s21"); s.add(q + "s210");
+    static const char* an[14] = {"a3210", "a321", "a320", "a310", "a32", "a31", "a30", "a210", "a21", "a20", "a10", "a2", "a1", "a0"};
+    for (int i = 0; i < 14; i++) s.add(q + an[i] + "[0]");
+    s.add(q + "out");
+    return base;
+}
+
 inline void lay_computefee(Section& s, const std::string& pre, ComputeFeeOff& o) {
     o.applyFee = s.add(pre + "applyFee");
     o.n2bFeeSel = s.add(pre + "n2bFeeSel.out", 8);
@@ -814,13 +832,7 @@ inline void lay_computefee(Section& s, const std::string& pre, ComputeFeeOff& o)
         const std::string q = pre + "mux256.mux[" + istr(i) + "].";
         s.add(q + "s10"); s.add(q + "s20"); s.add(q + "s21"); s.add(q + "s210"); s.add(q + "out");
     }
-    {
-        const std::string q = pre + "mux256.mux[16].";
-        o.mux2 = s.add(q + "s10"); s.add(q + "s20"); s.add(q + "s21"); s.add(q + "s210");
-        static const char* an[14] = {"a3210", "a321", "a320", "a310", "a32", "a31", "a30", "a210", "a21", "a20", "a10", "a2", "a1", "a0"};
-        for (int i = 0; i < 14; i++) s.add(q + an[i] + "[0]");
-        s.add(q + "out");
-    }
+    o.mux2 = lay_mux4v(s, pre + "mux256.mux[16].");
     o.feeOutNotShifted = s.add(pre + "feeOutNotShifted");
     o.applyShift = s.add(pre + "applyShift");
     o.bits = s.add(pre + "bitsFeeOut", 253);
@@ -854,10 +866,8 @@ inline void lay_seg_fix(Section& s, const std::string& pre, int nwin, SegFixOff&
     o.cAdd = s.add_babyadd(pre + "cAdd");
 }
 
-inline void lay_eddsa(Section& s, const std::string& pre, EddsaOff& o) {
-    o.signSignature = s.add(pre + "signSignature.out");
-    o.aySignature = s.add(pre + "aySignature.out");
-    const std::string g = pre + "getAx.";
+// AySign2Ax (src/lib/utils-bjj.circom:37-58) incl. circomlib pointbits.circom Bits2Point_Strict
+inline void lay_ax(Section& s, const std::string& g, EddsaOff& o) {
     o.ax_n2bAy = s.add(g + "n2bAy.out", 254);
     o.ax_aliasY = s.add_cc(g + "b2Point.aliasCheckY.compConstant");
     o.ax_x = s.add(g + "b2Point.out[0]");
@@ -866,6 +876,12 @@ inline void lay_eddsa(Section& s, const std::string& pre, EddsaOff& o) {
     o.ax_n2bX = s.add(g + "b2Point.n2bX.out", 254);
     o.ax_aliasX = s.add_cc(g + "b2Point.aliasCheckX.compConstant");
     o.ax_signCalc = s.add_cc(g + "b2Point.signCalc");
+}
+
+inline void lay_eddsa(Section& s, const std::string& pre, EddsaOff& o) {
+    o.signSignature = s.add(pre + "signSignature.out");
+    o.aySignature = s.add(pre + "aySignature.out");
+    lay_ax(s, pre + "getAx.", o);
     const std::string v = pre + "sigVerifier.";
     o.snum2bits = s.add(v + "snum2bits.out", 253);
     o.sCmp = s.add_cc(v + "compConstant");
@@ -891,17 +907,40 @@ inline void lay_eddsa(Section& s, const std::string& pre, EddsaOff& o) {
     o.eqCheckY = s.add_isz(v + "eqCheckY.isz");
 }
 
+inline void lay_balupd(Section& s, const std::string& b, BalUpdOff& o) {
+    lay_computefee(s, b + "computeFee.", o.fee);
+    o.effLoad1 = s.add(b + "effectiveLoadAmount1");
+    o.effLoad2 = s.add(b + "effectiveLoadAmount2");
+    o.effAmt1 = s.add(b + "effectiveAmount1");
+    o.effAmt2 = s.add(b + "effectiveAmount2");
+    o.n2bSender = s.add(b + "n2bSender.out", 193);
+    o.effAmt3 = s.add(b + "effectiveAmount3");
+    o.effAmtIsZero = s.add_isz(b + "effectiveAmountIsZero");
+    o.isAmountNullified = s.add(b + "isAmountNullified");
+}
+inline uint32_t lay_feeacc(Section& s, const std::string& pre, int F) {
+    const uint32_t first = s.n_sigs;
+    for (int i = 0; i < F; i++) {
+        const std::string q = pre + "chain[" + istr(i) + "].";
+        s.add(q + "isEqual.isz.inv"); s.add(q + "isEqual.isz.out"); s.add(q + "isSelectedOut"); s.add(q + "mux.s"); s.add(q + "mux.out");
+    }
+    return first;
+}
+template <class RTX>
+inline void lay_rq(Section& s, const std::string& pre, RTX& o) {
+    o.rq_n2b = s.add(pre + "n2b.out", 3);
+    static const char* mn[3] = {"muxTxCompressedDataV2", "muxToEthAddr", "muxToBjjAy"};
+    for (int m = 0; m < 3; m++) {
+        const std::string q = pre + mn[m] + ".mux.";
+        o.rq_mux[m].base = s.add(q + "s10");
+        s.add(q + "a210[0]"); s.add(q + "a21[0]"); s.add(q + "a20[0]"); s.add(q + "a10[0]"); s.add(q + "a1[0]"); s.add(q + "a0[0]"); s.add(q + "out[0]");
+    }
+}
 inline void lay_rtx(Section& s, const std::string& pre, int L, int F, bool in_main, RtxOff& o) {
     o.n2bLoadAmountF = s.add(pre + "n2bloadAmountF.out", 40);
     o.dfLoadAmount = lay_decodefloat(s, pre + "dfLoadAmount.");
     lay_states(s, pre + "states.", o.st);
-    o.rq_n2b = s.add(pre + "rqTxVerifier.n2b.out", 3);
-    static const char* mn[3] = {"muxTxCompressedDataV2", "muxToEthAddr", "muxToBjjAy"};
-    for (int m = 0; m < 3; m++) {
-        const std::string q = pre + "rqTxVerifier." + mn[m] + ".mux.";
-        o.rq_mux[m].base = s.add(q + "s10");
-        s.add(q + "a210[0]"); s.add(q + "a21[0]"); s.add(q + "a20[0]"); s.add(q + "a10[0]"); s.add(q + "a1[0]"); s.add(q + "a0[0]"); s.add(q + "out[0]");
-    }
+    lay_rq(s, pre + "rqTxVerifier.", o);
     o.nonceChecker = s.add_isz(pre + "nonceChecker.isz");
     o.checkToEthAddr = s.add_isz(pre + "checkToEthAddr.isz");
     o.checkToEthAddr_en = s.add(pre + "checkToEthAddr.enabled");
@@ -919,21 +958,8 @@ inline void lay_rtx(Section& s, const std::string& pre, int L, int F, bool in_ma
     o.mux16 = s.n_sigs;
     for (int i = 0; i < MX_N; i++) s.add(pre + mx[i] + ".out");
     lay_eddsa(s, pre, o.ed);
-    lay_computefee(s, pre + "balanceUpdater.computeFee.", o.bu.fee);
-    const std::string b = pre + "balanceUpdater.";
-    o.bu.effLoad1 = s.add(b + "effectiveLoadAmount1");
-    o.bu.effLoad2 = s.add(b + "effectiveLoadAmount2");
-    o.bu.effAmt1 = s.add(b + "effectiveAmount1");
-    o.bu.effAmt2 = s.add(b + "effectiveAmount2");
-    o.bu.n2bSender = s.add(b + "n2bSender.out", 193);
-    o.bu.effAmt3 = s.add(b + "effectiveAmount3");
-    o.bu.effAmtIsZero = s.add_isz(b + "effectiveAmountIsZero");
-    o.bu.isAmountNullified = s.add(b + "isAmountNullified");
-    o.feeAcc = s.n_sigs;
-    for (int i = 0; i < F; i++) {
-        const std::string q = pre + "feeAccumulator.chain[" + istr(i) + "].";
-        s.add(q + "isEqual.isz.inv"); s.add(q + "isEqual.isz.out"); s.add(q + "isSelectedOut"); s.add(q + "mux.s"); s.add(q + "mux.out");
-    }
+    lay_balupd(s, pre + "balanceUpdater.", o.bu);
+    o.feeAcc = lay_feeacc(s, pre + "feeAccumulator.", F);
     o.newSt1Hash = s.add_poseidon(pre + "newSt1Hash.hash", 5);
     o.newSt2Hash = s.add_poseidon(pre + "newSt2Hash.hash", 5);
     lay_smtproc(s, pre + "processor1.", L + 1, false, o.p1);
@@ -1133,6 +1159,70 @@ inline void build_layout(const Params& p, Layout& lo) {
             lay_feetx(T, "main.", L, lo.fee);
             lo.fee.o_newStateRoot = o_root;
             lo.outputs = {{"newStateRoot", o_root}};
+            break;
+        }
+        case T_DECODE_FLOAT: case T_COMPUTE_FEE: case T_FEE_ACCUMULATOR: case T_BALANCE_UPDATER: case T_ROLLUP_TX_STATES: case T_RQ_TX_VERIFIER:
+        case T_MUX256: case T_BITS2AYSIGN: case T_AYSIGN2AX: {
+            // gadget mains (reference test/lib/decode-float.test.js, test/compute-fee.test.js, test/fee-accumulator.test.js,
+            // test/balance-updater.test.js, test/rollup-tx-states.test.js, test/rq-tx-verifier.test.js): one instance per unit
+            lo.sections.resize(1);
+            Section& T = lo.sections[0]; T.tag = "gadget"; T.upi = 1;
+            T.add("main.one");
+            GadIO& g = lo.gad;
+            int ni = 0, no = 0;
+            auto gin = [&](const char* nm, uint32_t cnt = 1) { g.in[ni++] = in1(T, 0, nm, cnt, N, -1, true); };
+            auto gin_at = [&](const char* nm, uint32_t off) { g.in[ni++] = off; add_input(lo, nm, 0, off, 1, 1, true); };
+            auto gout_new = [&](const char* nm, uint32_t cnt = 1) { g.out[no++] = T.add(std::string("main.") + nm, cnt); lo.outputs.push_back({nm, g.out[no - 1]}); };
+            auto gout_at = [&](const char* nm, uint32_t off) { g.out[no++] = off; lo.outputs.push_back({nm, off}); };
+            if (p.tmpl == T_DECODE_FLOAT) {            // src/lib/decode-float.circom:50-64
+                gin("in");
+                gout_new("out");
+                lo.rtx.n2bLoadAmountF = T.add("main.n2b.out", 40);
+                lo.rtx.dfLoadAmount = lay_decodefloat(T, "main.decoder.");
+            } else if (p.tmpl == T_COMPUTE_FEE) {      // src/compute-fee.circom:12-109
+                gin("feeSel"); gin("amount");
+                lay_computefee(T, "main.", lo.rtx.bu.fee);
+                gin_at("applyFee", lo.rtx.bu.fee.applyFee);
+                gout_at("feeOut", lo.rtx.bu.fee.feeOut);
+            } else if (p.tmpl == T_FEE_ACCUMULATOR) {  // src/fee-accumulator.circom:56-91
+                gin("tokenID"); gin("fee2Charge"); gin("feePlanTokenID", (uint32_t)F); gin("accFeeIn", (uint32_t)F);
+                gout_new("accFeeOut", (uint32_t)F);
+                lo.rtx.feeAcc = lay_feeacc(T, "main.", F);
+            } else if (p.tmpl == T_BALANCE_UPDATER) {  // src/balance-updater.circom:24-105
+                for (const char* nm : {"oldStBalanceSender", "oldStBalanceReceiver", "amount", "loadAmount", "feeSelector", "onChain", "nop", "nullifyLoadAmount", "nullifyAmount"}) gin(nm);
+                gout_new("newStBalanceSender"); gout_new("newStBalanceReceiver"); gout_new("isP2Nop"); gout_new("fee2Charge");
+                lay_balupd(T, "main.", lo.rtx.bu);
+                gout_at("isAmountNullified", lo.rtx.bu.isAmountNullified);
+            } else if (p.tmpl == T_ROLLUP_TX_STATES) { // src/rollup-tx-states.circom:39-314
+                for (const char* nm : {"fromIdx", "toIdx", "toEthAddr", "auxFromIdx", "auxToIdx", "amount", "newExit", "loadAmount", "newAccount", "onChain",
+                                       "fromEthAddr", "ethAddr1", "tokenID", "tokenID1", "tokenID2"}) gin(nm);
+                StatesOff& st = lo.rtx.st;
+                lay_states(T, "main.", st);
+                gout_at("isP1Insert", st.isP1Insert); gout_at("isP2Insert", st.isP2Insert);
+                gout_new("key1"); gout_new("key2");
+                gout_at("P1_fnc0", st.P1_fnc0); gout_at("P1_fnc1", st.P1_fnc1); gout_at("P2_fnc0", st.P2_fnc0); gout_at("P2_fnc1", st.P2_fnc1);
+                gout_new("isExit");
+                gout_at("verifySignEnabled", st.verifySignEnabled);
+                gout_new("nop");
+                gout_at("checkToEthAddr", st.checkToEthAddr); gout_at("checkToBjj", st.checkToBjj);
+                gout_at("nullifyLoadAmount", st.nullifyLoadAmount); gout_at("nullifyAmount", st.nullifyAmount);
+            } else if (p.tmpl == T_MUX256) {           // src/lib/mux256.circom:10-52 (test/lib/mux256.test.js)
+                gin("s", 8); gin("in", 256);
+                gout_new("out");
+                g.mux = T.n_sigs;
+                for (int i = 0; i < 17; i++) lay_mux4v(T, "main.mux[" + istr(i) + "].");
+            } else if (p.tmpl == T_BITS2AYSIGN) {      // src/lib/utils-bjj.circom:12-28 (test/lib/utils-bjj.test.js)
+                gin("bjjCompressed", 256);
+                gout_new("ay"); gout_new("sign");
+            } else if (p.tmpl == T_AYSIGN2AX) {        // src/lib/utils-bjj.circom:37-58
+                gin("ay"); gin("sign");
+                gout_new("ax");
+                lay_ax(T, "main.", lo.rtx.ed);
+            } else {                                   // src/rq-tx-verifier.circom:19-94
+                gin("futureTxCompressedDataV2", 3); gin("pastTxCompressedDataV2", 4); gin("futureToEthAddr", 3); gin("pastToEthAddr", 4);
+                gin("futureToBjjAy", 3); gin("pastToBjjAy", 4); gin("rqTxCompressedDataV2"); gin("rqToEthAddr"); gin("rqToBjjAy"); gin("rqTxOffset");
+                lay_rq(T, "main.", lo.rtx);
+            }
             break;
         }
         case T_HASH_STATE: {

@@ -204,6 +204,10 @@ static void run_instanced(OrcCtx* c) {
         auto in = [&](uint32_t off) { return w.get(off); };
         w.set(0, F(1));  // main.one
         switch (lo.p.tmpl) {
+            case T_DECODE_FLOAT: case T_COMPUTE_FEE: case T_FEE_ACCUMULATOR: case T_BALANCE_UPDATER: case T_ROLLUP_TX_STATES: case T_RQ_TX_VERIFIER:
+            case T_MUX256: case T_BITS2AYSIGN: case T_AYSIGN2AX:
+                gadget_main(w, lo);
+                break;
             case T_HASH_STATE: {
                 const HashStateOff& h = lo.hs;
                 hash_state_main(w, h, in(h.tokenID), in(h.nonce), in(h.sign), in(h.balance), in(h.ay), in(h.ethAddr));

@@ -613,4 +613,73 @@ F hash_state_main(const W& w, const HashStateOff& o, const F& tokenID, const F& 
     return out;
 }
 
+// The gadget templates instantiated as `component main` by the reference's unit suites (test/lib/decode-float.test.js,
+// test/compute-fee.test.js, test/fee-accumulator.test.js, test/balance-updater.test.js, test/rollup-tx-states.test.js,
+// test/rq-tx-verifier.test.js): inputs/outputs per GadIO, internals through the same functions RollupTx uses.
+void gadget_main(const W& w, const Layout& lo) {
+    const GadIO& g = lo.gad;
+    auto in = [&](int k, int j = 0) { return w.get(g.in[k] + j); };
+    switch (lo.p.tmpl) {
+        case T_DECODE_FLOAT: {   // src/lib/decode-float.circom:50-64
+            const std::vector<int> b = num2bits(w, lo.rtx.n2bLoadAmountF, in(0), 40, C_RTX_N2B_LOADAMOUNTF);
+            w.set(g.out[0], decode_float_bin(w, lo.rtx.dfLoadAmount, b));
+            break;
+        }
+        case T_COMPUTE_FEE:      // src/compute-fee.circom:12-109 (feeOut and applyFee are the gadget's own signals)
+            compute_fee(w, lo.rtx.bu.fee, in(0), in(1), in(2));
+            break;
+        case T_FEE_ACCUMULATOR: {
+            const int Fn = lo.p.F;
+            std::vector<F> plan(Fn), acc(Fn), out(Fn);
+            for (int i = 0; i < Fn; i++) { plan[i] = in(2, i); acc[i] = in(3, i); }
+            fee_accumulator(w, lo.rtx.feeAcc, Fn, in(0), in(1), plan.data(), acc.data(), out.data());
+            for (int i = 0; i < Fn; i++) w.set(g.out[0] + i, out[i]);
+            break;
+        }
+        case T_BALANCE_UPDATER: {
+            const BalOut r = balance_updater(w, lo.rtx.bu, in(0), in(1), in(2), in(3), in(4), in(5), in(6), in(7), in(8));
+            w.set(g.out[0], r.newSender); w.set(g.out[1], r.newReceiver); w.set(g.out[2], r.isP2Nop); w.set(g.out[3], r.fee2Charge);
+            break;
+        }
+        case T_ROLLUP_TX_STATES: {
+            RtxIn ri;
+            ri.fromIdx = in(0); ri.toIdx = in(1); ri.toEthAddr = in(2); ri.auxFromIdx = in(3); ri.auxToIdx = in(4); ri.amount = in(5);
+            ri.newExit = in(6); ri.newAccount = in(8); ri.onChain = in(9); ri.fromEthAddr = in(10); ri.ethAddr1 = in(11);
+            ri.tokenID = in(12); ri.tokenID1 = in(13); ri.tokenID2 = in(14);
+            const StatesOut r = rollup_tx_states(w, lo.rtx.st, ri, in(7));
+            w.set(g.out[2], r.key1); w.set(g.out[3], r.key2); w.set(g.out[8], r.isExit); w.set(g.out[10], r.nop);
+            break;
+        }
+        case T_RQ_TX_VERIFIER: {
+            RtxIn ri;
+            for (int j = 0; j < 3; j++) { ri.futureV2[j] = in(0, j); ri.futureToEthAddr[j] = in(2, j); ri.futureToBjjAy[j] = in(4, j); }
+            for (int j = 0; j < 4; j++) { ri.pastV2[j] = in(1, j); ri.pastToEthAddr[j] = in(3, j); ri.pastToBjjAy[j] = in(5, j); }
+            ri.rqTxCompressedDataV2 = in(6); ri.rqToEthAddr = in(7); ri.rqToBjjAy = in(8); ri.rqOffset = in(9);
+            rq_tx_verifier(w, lo.rtx, ri);
+            break;
+        }
+        case T_MUX256: {         // src/lib/mux256.circom:10-52: 16 Mux4 on s[0..3], one Mux4 on s[4..7]
+            F sel[8], lvl1[16];
+            for (int i = 0; i < 8; i++) sel[i] = in(0, i);
+            for (int m = 0; m < 16; m++) {
+                F c[16];
+                for (int k = 0; k < 16; k++) c[k] = in(1, 16 * m + k);
+                lvl1[m] = mux4_var(w, g.mux + MX4V_N * m, c, sel);
+            }
+            w.set(g.out[0], mux4_var(w, g.mux + MX4V_N * 16, lvl1, sel + 4));
+            break;
+        }
+        case T_BITS2AYSIGN: {    // src/lib/utils-bjj.circom:12-28
+            F ay(0);
+            for (int i = 0; i < 254; i++) ay += in(0, i) * pow2(i);
+            w.set(g.out[0], ay); w.set(g.out[1], in(0, 255));
+            break;
+        }
+        case T_AYSIGN2AX:        // src/lib/utils-bjj.circom:37-58
+            w.set(g.out[0], ay_sign_2_ax(w, lo.rtx.ed, in(0), in(1)));
+            break;
+        default: break;
+    }
+}
+
 }  // namespace orc

@@ -34,6 +34,7 @@ struct FeeIn {
 DecOut decode_tx(const W& w, const hzl::DecOff& o, int L, const DecIn& in);
 RtxOut rollup_tx(const W& w, const hzl::RtxOff& o, int L, int F, const RtxIn& in);
 F fee_tx(const W& w, const hzl::FeeTxOff& o, int L, const FeeIn& in);
+void gadget_main(const W& w, const hzl::Layout& lo);
 F hash_state_main(const W& w, const hzl::HashStateOff& o, const F& tokenID, const F& nonce, const F& sign, const F& balance, const F& ay, const F& ethAddr);
 
 // SHA-256 bit-level witness (circomlib sha256/*.circom): hashes `bits` (MSB-first message bits),

@@ -45,6 +45,19 @@ async function main() {
         delete missing.oldStateRoot;
         await assert.rejects(circuit.calculateWitness(missing, true), /Not all inputs have been set/);
     }
+    // gadget mains, as the reference's unit suites drive them (test/balance-updater.test.js:31-56,170-190;
+    // test/lib/decode-float.test.js:28-38; test/fee-accumulator.test.js)
+    {
+        const circuit = await tester("include \"../src/balance-updater.circom\";\ncomponent main = BalanceUpdater();", { reduceConstraints: false });
+        const input = { oldStBalanceSender: 100, oldStBalanceReceiver: 200, amount: 50, loadAmount: 0, feeSelector: 126, onChain: 0, nop: 0, nullifyLoadAmount: 0, nullifyAmount: 0 };
+        const w = await circuit.calculateWitness(input, { logOutput: false });
+        await circuit.assertOut(w, { newStBalanceSender: 100 - 50 - 5, newStBalanceReceiver: 250, fee2Charge: 5, isP2Nop: 1, isAmountNullified: 0 });
+        await assert.rejects(circuit.calculateWitness(Object.assign({}, input, { amount: 98, feeSelector: 200 }), true), /Constraint doesn't match 1 != 0/);
+        const df = await tester("component main = DecodeFloat();");
+        await df.assertOut(await df.calculateWitness({ in: "0xF8000002FF" }, true), { out: 767n * 10n ** 31n });
+        const fa = await tester("component main = FeeAccumulator(4);");
+        await fa.assertOut(await fa.calculateWitness({ tokenID: 3, fee2Charge: 7, feePlanTokenID: [1, 3, 3, 4], accFeeIn: [10, 20, 30, 40] }, true), { accFeeOut: [10, 27, 30, 40] });
+    }
     console.log("node facade: ok");
 }
 main().catch((e) => { console.error(e); process.exit(1); });
