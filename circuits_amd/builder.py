@@ -98,11 +98,102 @@ def fix2float(v):
 
 
 # ---- circomlib-compatible sparse Merkle tree ---------------------------------------------------
+class DagHasher:
+    """Deferred Poseidon for the device-side batch builder. poseidon() records a job and returns a REFERENCE
+    (a negative integer: field values are never negative) that can be stored in the tree, used as a dictionary key and fed to
+    later jobs; no hash is computed while the batch is walked. Every node a job depends on lies deeper in a tree (own child:
+    same update; sibling: an earlier update), so the dependency depth of the whole batch is nLevels + 3 whatever the number of
+    transactions: resolve() sorts the jobs by depth and evaluates each depth as ONE launch of hz_poseidon_dag (all node
+    versions of a tree level in parallel) instead of 2*(nLevels+1) dependent hashes per transaction on a CPU thread
+    (reference: @hermeznetwork/commonjs BatchBuilder via test/helpers/helpers.js:46, tools/generate-input.js:70-107)."""
+    CONST = 1 << 31
+    _PAD = [0] * 6
+
+    def __init__(self, evaluate):
+        self.evaluate = evaluate   # (vals: bytearray, job_in, job_out, seg_t, seg_first, seg_count) -> device ms or None
+        self.stats = {"jobs": 0, "segments": 0, "device_ms": 0.0, "resolve_s": 0.0}
+        self._reset()
+
+    def _reset(self):
+        import array
+        self.n = 0
+        self.wave, self.arity = [], []
+        self.flat = array.array("I")
+        self.consts, self.cidx = [], {}
+        self.out = None
+
+    def poseidon(self, xs):
+        w, idx = 0, []
+        for x in xs:
+            if x < 0:
+                j = -x - 1
+                idx.append(j)
+                if self.wave[j] >= w:
+                    w = self.wave[j] + 1
+            else:
+                c = self.cidx.get(x)
+                if c is None:
+                    c = self.cidx[x] = len(self.consts)
+                    self.consts.append(x)
+                idx.append(self.CONST | c)
+        self.wave.append(w)
+        self.arity.append(len(idx))
+        self.flat.extend(idx + self._PAD[len(idx):])
+        self.n += 1
+        return -self.n
+
+    def resolve(self):
+        """Evaluates the recorded jobs; returns value(ref_or_int) -> int and forgets the jobs."""
+        import time
+        import numpy as np
+        n = self.n
+        if n == 0:
+            return lambda x: x
+        t0 = time.time()
+        wave = np.asarray(self.wave, dtype=np.int64)
+        ar = np.asarray(self.arity, dtype=np.int64)
+        order = np.lexsort((ar, wave))
+        a = np.frombuffer(self.flat, dtype=np.uint32).reshape(n, 6).astype(np.int64)
+        a = np.where(a >= self.CONST, (a & (self.CONST - 1)) + n, a)
+        job_in = np.ascontiguousarray(a[order].astype(np.uint32))
+        job_out = np.ascontiguousarray(order.astype(np.uint32))
+        key = wave[order] * 8 + ar[order]
+        cut = np.flatnonzero(np.diff(key)) + 1
+        seg_first = np.concatenate(([0], cut)).astype(np.uint64)
+        seg_count = np.diff(np.concatenate((seg_first, [n]))).astype(np.uint64)
+        seg_t = (ar[order][seg_first.astype(np.int64)] + 1).astype(np.uint32)
+        vals = bytearray(32 * n) + b"".join(int(c % P).to_bytes(32, "little") for c in self.consts)
+        ms = self.evaluate(vals, job_in, job_out, seg_t, seg_first, seg_count)
+        out = [int.from_bytes(vals[32 * i:32 * i + 32], "little") for i in range(n)]
+        self.stats["jobs"] += n
+        self.stats["segments"] += len(seg_t)
+        self.stats["device_ms"] += ms or 0.0
+        self.stats["resolve_s"] += time.time() - t0
+        self._reset()
+        return lambda x: x if x >= 0 else out[-x - 1]
+
+
 class SMT:
-    def __init__(self):
-        self.h = host()
+    def __init__(self, hasher=None):
+        self.h = hasher or host()
+        self.lazy = isinstance(self.h, DagHasher)
+        self.fresh = []   # lazy mode: node ids created since the last rekey()
         self.root = 0
         self.nodes = {}  # hash -> ("leaf", key, value) | ("mid", left, right)
+
+    def _put(self, k, node):
+        self.nodes[k] = node
+        if self.lazy:
+            self.fresh.append(k)
+
+    def rekey(self, val):
+        """lazy mode, after DagHasher.resolve(): node ids (references) become the hashes they stand for"""
+        for k in self.fresh:
+            n = self.nodes.pop(k, None)
+            if n is not None:
+                self.nodes[val(k)] = (n[0], n[1], val(n[2])) if n[0] == "leaf" else (n[0], val(n[1]), val(n[2]))
+        self.fresh = []
+        self.root = val(self.root)
 
     def _hash1(self, k, v):
         return self.h.poseidon([k, v, 1])
@@ -119,7 +210,7 @@ class SMT:
             if n[0] == "leaf":
                 if n[1] == key:
                     return {"found": True, "siblings": sib, "foundValue": n[2], "isOld0": False}
-                return {"found": False, "siblings": sib, "notFoundKey": n[1], "notFoundValue": n[2], "isOld0": False}
+                return {"found": False, "siblings": sib, "notFoundKey": n[1], "notFoundValue": n[2], "isOld0": False, "node": node}
             if (key >> lvl) & 1:
                 sib.append(n[1])
                 node = n[2]
@@ -133,7 +224,7 @@ class SMT:
         for i in range(len(sib) - 1, -1, -1):
             l, r = (sib[i], rt) if (key >> i) & 1 else (rt, sib[i])
             rt = self._hash0(l, r)
-            self.nodes[rt] = ("mid", l, r)
+            self._put(rt, ("mid", l, r))
         return rt
 
     def insert(self, key, value):
@@ -149,9 +240,9 @@ class SMT:
             while ((ok >> i) & 1) == ((key >> i) & 1):
                 full.append(0)
                 i += 1
-            full.append(self._hash1(ok, f["notFoundValue"]))
+            full.append(f["node"])   # the leaf found on the way = hash1(oldKey, oldValue)
         lh = self._hash1(key, value)
-        self.nodes[lh] = ("leaf", key, value)
+        self._put(lh, ("leaf", key, value))
         self.root = self._up(key, lh, full)
         if not f["isOld0"]:
             full.pop()
@@ -167,7 +258,7 @@ class SMT:
             raise KeyError("key not found")
         res = {"oldRoot": self.root, "oldKey": key, "oldValue": f["foundValue"], "siblings": list(f["siblings"])}
         lh = self._hash1(key, value)
-        self.nodes[lh] = ("leaf", key, value)
+        self._put(lh, ("leaf", key, value))
         self.root = self._up(key, lh, f["siblings"])
         res["newRoot"] = self.root
         return res
@@ -239,9 +330,9 @@ def sha256_bits(bits):
     return b"".join(x.to_bytes(4, "big") for x in h)
 
 
-def hash_state(st):
+def hash_state(st, hasher=None):
     e0 = st["tokenID"] + (st["nonce"] << 32) + (st["sign"] << 72)
-    return host().poseidon([e0, st["balance"], st["ay"], st["ethAddr"]])
+    return (hasher or host()).poseidon([e0, st["balance"], st["ay"], st["ethAddr"]])
 
 
 def build_tx_compressed_data(tx, chain_id):
@@ -260,14 +351,41 @@ def build_hash_sig(tx, chain_id):
                             tx.get("rqToEthAddr", 0), tx.get("rqToBjjAy", 0)])
 
 
+def _device_dag_evaluator(device):
+    from . import lib
+    L = lib()
+    if L.device_count() <= 0:
+        raise RuntimeError("RollupDB(device=%d): no usable gfx950 device (the device batch builder has no CPU fallback)" % device)
+    return lambda *a: L.poseidon_dag(*a, device=device)
+
+
 class RollupDB:
-    def __init__(self, chain_id=1):
+    def __init__(self, chain_id=1, device=None, dag_evaluator=None):
+        """device=N: the Merkle / state hashing of every batch runs on GPU N (DagHasher); default: host hashing, one at a time.
+        Both produce identical trees and circuit inputs."""
         self.chain_id = chain_id
-        self.state = SMT()
+        self.hasher = host()
+        if device is not None or dag_evaluator is not None:
+            self.hasher = DagHasher(dag_evaluator or _device_dag_evaluator(device))
+        self.lazy = isinstance(self.hasher, DagHasher)
+        self.state = SMT(self.hasher)
         self.leaves = {}  # idx -> state dict
         self.last_idx = 255
         self.num_batch = 0
         self.exit_trees = {}
+
+    def hash_state(self, st):
+        return hash_state(st, self.hasher)
+
+    def flush(self, extra_trees=()):
+        """lazy mode: evaluates the pending hashes on the device and turns the references held by the trees into values;
+        returns value(ref_or_int) for whatever else holds references"""
+        if not self.lazy:
+            return lambda x: x
+        val = self.hasher.resolve()
+        for t in (self.state,) + tuple(extra_trees):
+            t.rekey(val)
+        return val
 
     def build_batch(self, n_tx, n_levels, max_l1, max_fee):
         return BatchBuilder(self, n_tx, n_levels, max_l1, max_fee)
@@ -305,6 +423,7 @@ class BatchBuilder:
             "rqOffset rqTxCompressedDataV2 rqToEthAddr rqToBjjAy s r8x r8y loadAmountF fromEthAddr fromBjjCompressed tokenID1 nonce1 sign1 "
             "balance1 ay1 ethAddr1 siblings1 isOld0_1 oldKey1 oldValue1 tokenID2 nonce2 sign2 balance2 ay2 ethAddr2 siblings2 newExit isOld0_2 "
             "oldKey2 oldValue2 imOnChain imOutIdx imStateRoot imExitRoot imAccFeeOut").split()}
+        db.flush()   # hashes queued outside a batch (direct state construction)
         inp["oldLastIdx"] = db.last_idx
         inp["oldStateRoot"] = db.state.root
         inp["globalChainID"] = db.chain_id
@@ -312,7 +431,7 @@ class BatchBuilder:
         plan = list(self.fee_tokens) + [0] * (F - len(self.fee_tokens))
         inp["feePlanTokens"] = plan
         acc_fee = [0] * F
-        exit_tree = SMT()
+        exit_tree = SMT(db.hasher)
         exit_leaves = {}
         self.tx_meta = []  # per-tx facts used by get_single_tx_input
         ordered = [t for t in self.txs if t.get("onChain")] + [t for t in self.txs if not t.get("onChain")]
@@ -429,12 +548,12 @@ class BatchBuilder:
                 if not on:
                     tx.setdefault("nonce", old1["nonce"])
                 if new_account:
-                    res = db.state.insert(final_from, hash_state(new1))
+                    res = db.state.insert(final_from, db.hash_state(new1))
                     isold1 = 1 if res["isOld0"] else 0
                     oldk1 = 0 if res["isOld0"] else res["oldKey"]
                     oldv1 = 0 if res["isOld0"] else res["oldValue"]
                 else:
-                    res = db.state.update(final_from, hash_state(new1))
+                    res = db.state.update(final_from, db.hash_state(new1))
                 db.leaves[final_from] = new1
                 sib1 = res["siblings"]
                 if not on and token in plan:
@@ -445,7 +564,7 @@ class BatchBuilder:
                         if p2_insert:
                             new_exit = 1
                             enew = {"tokenID": old1["tokenID"], "nonce": 0, "sign": old1["sign"], "balance": eff_amount3, "ay": old1["ay"], "ethAddr": old1["ethAddr"]}
-                            r2 = exit_tree.insert(key2, hash_state(enew))
+                            r2 = exit_tree.insert(key2, db.hash_state(enew))
                             isold2 = 1 if r2["isOld0"] else 0
                             oldk2 = 0 if r2["isOld0"] else r2["oldKey"]
                             oldv2 = 0 if r2["isOld0"] else r2["oldValue"]
@@ -453,7 +572,7 @@ class BatchBuilder:
                             st2 = dict(exit_leaves[key2])
                             enew = dict(st2)
                             enew["balance"] += eff_amount3
-                            r2 = exit_tree.update(key2, hash_state(enew))
+                            r2 = exit_tree.update(key2, db.hash_state(enew))
                         exit_leaves[key2] = enew
                         sib2 = r2["siblings"]
                     else:
@@ -469,7 +588,7 @@ class BatchBuilder:
                         st2 = dict(rcur)
                         rnew = dict(rcur)
                         rnew["balance"] += eff_amount3
-                        r2 = db.state.update(key2, hash_state(rnew))
+                        r2 = db.state.update(key2, db.hash_state(rnew))
                         db.leaves[key2] = rnew
                         sib2 = r2["siblings"]
                 elif not on:
@@ -522,7 +641,7 @@ class BatchBuilder:
                 st3 = dict(cur)
                 new = dict(cur)
                 new["balance"] += acc_fee[j]
-                r3 = db.state.update(idxs[j], hash_state(new))
+                r3 = db.state.update(idxs[j], db.hash_state(new))
                 db.leaves[idxs[j]] = new
                 sib3 = r3["siblings"]
             for f, nm in (("tokenID", "tokenID3"), ("nonce", "nonce3"), ("sign", "sign3"), ("balance", "balance3"), ("ay", "ay3"), ("ethAddr", "ethAddr3")):
@@ -530,6 +649,16 @@ class BatchBuilder:
             inp["siblings3"].append(self._pad(sib3))
             if j < F - 1:
                 inp["imStateRootFee"].append(db.state.root)
+        if db.lazy:
+            # every hash of the batch in nLevels + 3 device launches; then references -> values
+            val = db.flush(extra_trees=(exit_tree,))
+            for k in ("siblings1", "siblings2", "siblings3"):
+                inp[k] = [[val(x) for x in row] for row in inp[k]]
+            for k in ("oldValue1", "oldValue2", "imStateRoot", "imExitRoot", "imStateRootFee"):
+                inp[k] = [val(x) for x in inp[k]]
+            inp["imInitStateRootFee"] = val(inp["imInitStateRootFee"])
+            for m in self.tx_meta:
+                m["stateRoot"], m["exitRoot"] = val(m["stateRoot"]), val(m["exitRoot"])
         self.input = inp
         self.new_state_root = db.state.root
         self.new_last_idx = db.last_idx
@@ -626,14 +755,14 @@ def withdraw_input(batch, idx, n_levels):
     return inp, int.from_bytes(hashlib.sha256(by).digest(), "big") % P
 
 
-def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0):
+def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, dag_evaluator=None):
     """Seeded synthetic batch following reference tools/generate-input.js:61-109 and
     tools/helpers/gen-inputs-utils.js: pre-populated accounts (token 1), then one batch of `max_l1` L1
     createAccountDeposit txs followed by signed L2 transfers of 20 % of the sender balance with
     userFee 176 (plus `exits` L2 exits), one fee token and one fee receiver."""
     import random
     rng = random.Random(seed)
-    db = RollupDB(chain_id=1)
+    db = RollupDB(chain_id=1, device=device, dag_evaluator=dag_evaluator)
     keys = [Account(seed * 1000 + i) for i in range(n_keys)]
     n_accounts = n_accounts if n_accounts is not None else max(2, min(4 * n_tx, 4096))
     owner = {}
@@ -643,7 +772,7 @@ def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts
         a = keys[rng.randrange(n_keys)]
         bal = float2fix(floor_fix2float(rng.randrange(1 << 96)))
         st = {"tokenID": 1, "nonce": 0, "sign": a.sign, "balance": bal, "ay": a.ay, "ethAddr": a.eth_addr}
-        db.state.insert(db.last_idx, hash_state(st))
+        db.state.insert(db.last_idx, db.hash_state(st))
         db.leaves[db.last_idx] = st
         owner[db.last_idx] = a
     bb = db.build_batch(n_tx, n_levels, max_l1, max_fee)

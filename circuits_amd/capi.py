@@ -61,7 +61,7 @@ EXPORTS = [
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
-    "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym", "hz_fr_ops",
+    "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym", "hz_fr_ops", "hz_poseidon_dag",
 ]
 
 
@@ -79,6 +79,8 @@ class Lib:
         c.hz_device_count.restype = ctypes.c_int32
         c.hz_poseidon_batch.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
         c.hz_poseidon_batch_dev.argtypes = [ctypes.c_int32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        c.hz_poseidon_dag.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         c.hz_fr_ops.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
         c.hz_shard_range.argtypes = [ctypes.c_int32] * 3 + [ctypes.POINTER(ctypes.c_int32)] * 2
         c.hz_shard_range.restype = None
@@ -150,6 +152,19 @@ class Lib:
         out = ctypes.create_string_buffer(32 * max(n, 1))
         self._check(self.c.hz_fr_ops(device, op, n, fr_to_bytes(a), fr_to_bytes(b) if b is not None else None, out))
         return fr_from_bytes(out.raw[:32 * n])
+
+    def poseidon_dag(self, vals, job_in, job_out, seg_t, seg_first, seg_count, device=0):
+        """vals: bytearray of 32-byte elements (known values in, digests out); job_in uint32[n,6], job_out uint32[n];
+        segments (seg_t uint32, seg_first / seg_count uint64) in execution order. Returns the device time in ms."""
+        import numpy as np
+        assert job_in.dtype == np.uint32 and job_out.dtype == np.uint32 and seg_t.dtype == np.uint32
+        assert seg_first.dtype == np.uint64 and seg_count.dtype == np.uint64 and job_in.flags.c_contiguous
+        buf = (ctypes.c_char * len(vals)).from_buffer(vals)
+        ms = ctypes.c_double(0.0)
+        self._check(self.c.hz_poseidon_dag(device, buf, len(vals) // 32, job_in.ctypes.data_as(ctypes.c_void_p), job_out.ctypes.data_as(ctypes.c_void_p),
+                                           ctypes.c_uint64(len(job_out)), seg_t.ctypes.data_as(ctypes.c_void_p), seg_first.ctypes.data_as(ctypes.c_void_p),
+                                           seg_count.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(seg_t)), ctypes.byref(ms)))
+        return ms.value
 
     def ctx(self, template, **kw):
         return Ctx(self, template, **kw)

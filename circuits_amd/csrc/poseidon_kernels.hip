@@ -53,6 +53,35 @@ static hipError_t launch_poseidon(size_t n, const void* d_in, void* d_out, void*
     return hipGetLastError();
 }
 
+// Poseidon DAG (the batch builder's Merkle work): lane = one hash job whose inputs are gathered from a table of
+// field elements and whose digest goes back into the table. The host orders the jobs so that a segment only reads values
+// written by earlier segments: all node versions of one tree level are one segment (level-parallel path recomputation).
+template <int T>
+__global__ __launch_bounds__(256) void poseidon_dag_kernel(uint8_t* __restrict__ vals, const uint32_t* __restrict__ job_in,
+                                                            const uint32_t* __restrict__ job_out, size_t first, size_t count) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    uint32_t* lds = lds_raw;
+    const Fr* K = poseidon_consts<T>(lds);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const size_t job = first + i;
+    Fr x[T - 1];
+#pragma unroll
+    for (int j = 0; j < T - 1; j++) x[j] = fr_from_canon(load_fr(vals + (size_t)job_in[job * HZ_DAG_MAX_IN + j] * 32));
+    NoSink sink;
+    const Fr h = poseidon_hash<T>(x, K, sink);
+    store_fr(vals + (size_t)job_out[job] * 32, fr_to_canon(h));
+}
+
+template <int T>
+static hipError_t launch_poseidon_dag(uint8_t* vals, const uint32_t* job_in, const uint32_t* job_out, size_t first, size_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    // one wavefront per workgroup: a level of a 2048-transaction batch is a few thousand jobs, which should spread over all CUs
+    hipLaunchKernelGGL(poseidon_dag_kernel<T>, dim3((unsigned)((count + 63) / 64)), dim3(64), poseidon_lds_bytes<T>(), s, vals, job_in, job_out, first, count);
+    return hipGetLastError();
+}
+
 // K0 fr_ops: one field operation per lane on canonical operands (SURVEY 8a' K0), the self test of fr.h on the device
 __global__ __launch_bounds__(256) void fr_ops_kernel(int op, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* __restrict__ out, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -117,6 +146,61 @@ extern "C" hz_status hz_fr_ops(int32_t device, int32_t op, size_t n, const uint8
     HZ_HIP(hipGetLastError());
     HZ_HIP(hipDeviceSynchronize());
     HZ_HIP(hipMemcpy(out, d_o.p, n * 32, hipMemcpyDeviceToHost));
+    return HZ_OK;
+}
+
+extern "C" hz_status hz_poseidon_dag(int32_t device, uint8_t* vals, uint64_t n_vals, const uint32_t* job_in, const uint32_t* job_out, uint64_t n_jobs,
+                                     const uint32_t* seg_t, const uint64_t* seg_first, const uint64_t* seg_count, uint32_t n_segs, double* device_ms) {
+    if ((n_vals && !vals) || (n_jobs && (!job_in || !job_out)) || (n_segs && (!seg_t || !seg_first || !seg_count)))
+        return set_err(HZ_ERR_ARG, "hz_poseidon_dag: null argument");
+    if (n_vals >= 0xFFFFFFFFull) return set_err(HZ_ERR_ARG, "hz_poseidon_dag: the value table is indexed with 32 bits");
+    if (hz_device_count() <= 0) return set_err(HZ_ERR_NODEVICE, "no usable gfx950 device");
+    for (uint32_t g = 0; g < n_segs; g++) {
+        if (seg_t[g] < 2 || seg_t[g] > 7) return set_err(HZ_ERR_ARG, "hz_poseidon_dag: segment %u has width %u (2..7)", g, seg_t[g]);
+        if (seg_first[g] + seg_count[g] > n_jobs) return set_err(HZ_ERR_ARG, "hz_poseidon_dag: segment %u exceeds the job list", g);
+        for (uint64_t j = seg_first[g]; j < seg_first[g] + seg_count[g]; j++) {
+            if (job_out[j] >= n_vals) return set_err(HZ_ERR_ARG, "hz_poseidon_dag: job %llu writes outside the table", (unsigned long long)j);
+            for (uint32_t k = 0; k + 1 < seg_t[g]; k++)
+                if (job_in[j * HZ_DAG_MAX_IN + k] >= n_vals) return set_err(HZ_ERR_ARG, "hz_poseidon_dag: job %llu reads outside the table", (unsigned long long)j);
+        }
+    }
+    if (n_segs == 0 || n_jobs == 0) return HZ_OK;
+    HZ_HIP(hipSetDevice(device));
+    DevBuf d_vals, d_in, d_out;
+    HZ_HIP(d_vals.alloc(n_vals * 32));
+    HZ_HIP(d_in.alloc(n_jobs * HZ_DAG_MAX_IN * sizeof(uint32_t)));
+    HZ_HIP(d_out.alloc(n_jobs * sizeof(uint32_t)));
+    HZ_HIP(hipMemcpy(d_vals.p, vals, n_vals * 32, hipMemcpyHostToDevice));
+    HZ_HIP(hipMemcpy(d_in.p, job_in, n_jobs * HZ_DAG_MAX_IN * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HZ_HIP(hipMemcpy(d_out.p, job_out, n_jobs * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (device_ms) { HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1)); HZ_HIP(hipEventRecord(e0, 0)); }
+    hipError_t e = hipSuccess;
+    for (uint32_t g = 0; g < n_segs && e == hipSuccess; g++) {
+        uint8_t* v = (uint8_t*)d_vals.p;
+        const uint32_t* ji = (const uint32_t*)d_in.p;
+        const uint32_t* jo = (const uint32_t*)d_out.p;
+        switch (seg_t[g]) {
+            case 2: e = launch_poseidon_dag<2>(v, ji, jo, seg_first[g], seg_count[g], 0); break;
+            case 3: e = launch_poseidon_dag<3>(v, ji, jo, seg_first[g], seg_count[g], 0); break;
+            case 4: e = launch_poseidon_dag<4>(v, ji, jo, seg_first[g], seg_count[g], 0); break;
+            case 5: e = launch_poseidon_dag<5>(v, ji, jo, seg_first[g], seg_count[g], 0); break;
+            case 6: e = launch_poseidon_dag<6>(v, ji, jo, seg_first[g], seg_count[g], 0); break;
+            default: e = launch_poseidon_dag<7>(v, ji, jo, seg_first[g], seg_count[g], 0); break;
+        }
+    }
+    if (device_ms && e == hipSuccess) {
+        e = hipEventRecord(e1, 0);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        *device_ms = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    HZ_HIP(e);
+    HZ_HIP(hipDeviceSynchronize());
+    HZ_HIP(hipMemcpy(vals, d_vals.p, n_vals * 32, hipMemcpyDeviceToHost));
     return HZ_OK;
 }
 

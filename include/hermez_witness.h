@@ -171,6 +171,18 @@ hz_status hz_symbol_get(const hz_ctx* ctx, uint64_t i, hz_symbol* out);
 int32_t hz_symbol_lookup(const hz_ctx* ctx, const char* name, uint64_t* index);
 const char* hz_constraint_name(int32_t constraint_id);
 
+/* Evaluates a DAG of Poseidon hashes on the device, level by level: the Merkle work of a batch builder (the counterpart of
+ * @hermeznetwork/commonjs RollupDB / BatchBuilder, called by the reference at test/helpers/helpers.js:46,148 and
+ * tools/generate-input.js:70-107, which hashes 2*(nLevels+1) dependent nodes per transaction on one CPU thread).
+ * `vals` is a table of n_vals field elements (32-byte little-endian, canonical) in host memory: known values on entry, every
+ * job's digest on return. Job j hashes the seg_t-1 elements vals[job_in[6*j + k]] and stores Poseidon(seg_t) at vals[job_out[j]].
+ * Jobs are listed in execution order in segments [seg_first, seg_first+seg_count) of one width seg_t (2..7); the jobs of a segment
+ * must not depend on each other (all node versions of one tree level form one segment). device_ms (optional) receives the
+ * device time of the segment launches. */
+#define HZ_DAG_MAX_IN 6
+hz_status hz_poseidon_dag(int32_t device, uint8_t* vals, uint64_t n_vals, const uint32_t* job_in, const uint32_t* job_out, uint64_t n_jobs,
+                          const uint32_t* seg_t, const uint64_t* seg_first, const uint64_t* seg_count, uint32_t n_segs, double* device_ms);
+
 /* Poseidon batch: n independent permutations of width t = n_inputs + 1 (2..7). ----------------
  * `in`  : [n][t-1] canonical elements; `out`: [n] digests (state[0] after the last round).
  * If `sbox_witness` is non-NULL it receives the S-box signals (in2,in4,out per S-box, the

@@ -1,0 +1,142 @@
+"""Device-side batch builder: the Merkle / state hashing of a batch recorded as a DAG of Poseidon jobs
+(circuits_amd.builder.DagHasher) and evaluated level by level by hz_poseidon_dag, against the eager host builder that hashes
+one node at a time. The bar: identical circuit inputs, identical trees, for the synthetic benchmark batch and for every scenario
+batch of tests/scenarios.py (all transaction types, exits, nullified L1 transactions, atomic pairs, fee transactions).
+
+CPU half: the recorded DAG is evaluated by a host loop (test hook `dag_evaluator`), which checks the recording, the level
+ordering and the reference -> value substitution without a GPU. GPU half: the same through the C ABI.
+"""
+import numpy as np
+import pytest
+
+import scenarios
+from circuits_amd import builder as B
+
+
+def host_dag_evaluator(vals, job_in, job_out, seg_t, seg_first, seg_count):
+    """evaluates the segments in order with the host's Poseidon, checking that no job reads a value a later segment writes"""
+    h = B.host()
+    n_jobs = len(job_out)
+    written = np.zeros(len(vals) // 32, dtype=bool)
+    written[n_jobs:] = True   # constants
+    for t, first, count in zip(seg_t, seg_first, seg_count):
+        outs = []
+        for j in range(int(first), int(first + count)):
+            idx = [int(x) for x in job_in[j][:int(t) - 1]]
+            assert all(written[i] for i in idx), "job %d reads a value that has not been produced yet" % j
+            xs = [int.from_bytes(vals[32 * i:32 * i + 32], "little") for i in idx]
+            outs.append((int(job_out[j]), h.poseidon(xs)))
+        for o, v in outs:   # a segment's jobs are independent: publish after the whole segment
+            vals[32 * o:32 * o + 32] = v.to_bytes(32, "little")
+            written[o] = True
+    assert written.all()
+    return None
+
+
+def _same_batch(a, b):
+    ia, ib = a.get_input(), b.get_input()
+    assert ia.keys() == ib.keys()
+    for k in ia:
+        assert ia[k] == ib[k], k
+    assert (a.new_state_root, a.new_exit_root, a.new_last_idx) == (b.new_state_root, b.new_exit_root, b.new_last_idx)
+    assert a.get_hash_inputs() == b.get_hash_inputs()
+    assert a.tx_meta == b.tx_meta
+
+
+def _lazy_db_class(evaluator=None, device=None):
+    class LazyDB(B.RollupDB):
+        instances = []
+
+        def __init__(self, chain_id=1, **kw):
+            super().__init__(chain_id, device=device, dag_evaluator=evaluator)
+            LazyDB.instances.append(self)
+    return LazyDB
+
+
+def _check_synthetic(**kw):
+    shape = (48, 16, 8, 4)
+    eager = B.synthetic_batch(*shape, exits=3)
+    lazy = B.synthetic_batch(*shape, exits=3, **kw)
+    _same_batch(eager, lazy)
+    assert lazy.db.hasher.stats["jobs"] > 48 * 2 * 10
+    # dependency depth, not transaction count, bounds the number of launches: one segment per (level, width)
+    assert lazy.db.hasher.stats["segments"] <= 2 * (16 + 1 + 3) + 4, lazy.db.hasher.stats
+    assert eager.db.state.root == lazy.db.state.root and set(eager.db.state.nodes) == set(lazy.db.state.nodes)
+    assert eager.db.state.nodes == lazy.db.state.nodes
+    # the exit tree serves withdrawals afterwards
+    idx = sorted(lazy.exit_leaves)[0]
+    assert B.withdraw_input(eager, idx, 16) == B.withdraw_input(lazy, idx, 16)
+
+
+def _check_scenarios(monkeypatch, **kw):
+    _, eager_batches, _ = scenarios.all_tx_types()
+    _, eager_atomic = scenarios.atomic_pair()
+    eager_scripts = scenarios.reference_rollup_main_scripts()
+    cls = _lazy_db_class(**kw)
+    monkeypatch.setattr(B, "RollupDB", cls)
+    _, lazy_batches, _ = scenarios.all_tx_types()
+    _, lazy_atomic = scenarios.atomic_pair()
+    lazy_scripts = scenarios.reference_rollup_main_scripts()
+    assert cls.instances and all(d.lazy for d in cls.instances)
+    for a, b in zip(eager_batches + eager_atomic, lazy_batches + lazy_atomic):
+        _same_batch(a, b)
+    assert len(eager_scripts) == len(lazy_scripts)
+
+
+def test_dag_builder_matches_eager_builder_on_the_synthetic_batch():
+    _check_synthetic(dag_evaluator=host_dag_evaluator)
+
+
+def test_dag_builder_matches_eager_builder_on_every_scenario(monkeypatch):
+    _check_scenarios(monkeypatch, evaluator=host_dag_evaluator)
+
+
+def test_dag_levels_do_not_grow_with_the_number_of_transactions():
+    segs = []
+    for n in (16, 64):
+        b = B.synthetic_batch(n, 16, 4, 2, dag_evaluator=host_dag_evaluator)
+        segs.append(b.db.hasher.stats["segments"])
+    assert segs[1] <= segs[0] + 6, segs
+
+
+def test_device_builder_fails_loudly_without_a_gpu():
+    from circuits_amd import lib
+    if lib().device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no usable gfx950 device"):
+        B.RollupDB(device=0)
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_dag_builder_matches_eager_builder_on_the_synthetic_batch(hz):
+    _check_synthetic(device=0)
+
+
+@pytest.mark.gpu
+def test_hip_dag_builder_matches_eager_builder_on_every_scenario(hz, monkeypatch):
+    _check_scenarios(monkeypatch, device=0)
+
+
+@pytest.mark.gpu
+def test_hip_poseidon_dag_rejects_bad_tables(hz):
+    from circuits_amd.capi import HzError
+    vals = bytearray(32 * 4)
+    ji = np.zeros((1, 6), dtype=np.uint32)
+    ji[0, 0] = 9   # outside the table
+    with pytest.raises(HzError):
+        hz.poseidon_dag(vals, ji, np.zeros(1, dtype=np.uint32), np.array([3], dtype=np.uint32), np.array([0], dtype=np.uint64), np.array([1], dtype=np.uint64))
+    with pytest.raises(HzError):
+        hz.poseidon_dag(vals, np.zeros((1, 6), dtype=np.uint32), np.zeros(1, dtype=np.uint32), np.array([9], dtype=np.uint32), np.array([0], dtype=np.uint64),
+                        np.array([1], dtype=np.uint64))
+
+
+@pytest.mark.gpu
+def test_hip_dag_built_batch_is_accepted_by_the_witness_generator(hz):
+    """end to end on the device: inputs built by the DAG builder -> RollupMain witness, no constraint fails"""
+    shape = (32, 16, 8, 4)
+    b = B.synthetic_batch(*shape, exits=2, device=0)
+    g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3])
+    g.set_inputs(b.get_input())
+    g.run()
+    assert g.get("main.hashGlobalInputs") == b.get_hash_inputs()
