@@ -73,14 +73,100 @@ __device__ __forceinline__ F29 mul_v3(const F29& a, const F29& b) {
     return r;
 }
 
+// V4: the same limbs, product and reduction fused column by column (one running accumulator whose carry feeds the next
+// column's multiply-accumulate chain: no separate carry additions, no 18 live column sums)
+__device__ __forceinline__ F29 mul_v4(const F29& a, const F29& b) {
+    uint32_t m[9];
+    F29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p29(k - i);
+        m[k] = ((uint32_t)acc * INV29) & M29;
+        acc += (uint64_t)m[k] * p29(0);
+        acc >>= 29;
+        asm("" : "+v"(acc));   // keep the carry as the head of the next column's accumulation chain
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * p29(k - i);
+        r.v[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+        asm("" : "+v"(acc));
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
+// V5: V4 with the multiply-accumulates written as instructions, so that the compiler cannot re-associate the column sums
+// back into independent partial sums joined by 64-bit additions
+__device__ __forceinline__ void mad_vv(uint64_t& acc, uint32_t a, uint32_t b) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc"); }
+__device__ __forceinline__ void mad_vs(uint64_t& acc, uint32_t a, uint32_t b) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(b) : "vcc"); }
+__device__ __forceinline__ F29 mul_v5(const F29& a, const F29& b) {
+    uint32_t m[9];
+    F29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) mad_vv(acc, a.v[i], b.v[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; i++) mad_vs(acc, m[i], p29(k - i));
+        m[k] = ((uint32_t)acc * INV29) & M29;
+        mad_vs(acc, m[k], p29(0));
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) mad_vv(acc, a.v[i], b.v[k - i]);
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) mad_vs(acc, m[i], p29(k - i));
+        r.v[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+// V6: two chains per column (products / reduction terms) joined by one addition: half the dependent chain length of V5
+__device__ __forceinline__ F29 mul_v6(const F29& a, const F29& b) {
+    uint32_t m[9];
+    F29 r;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t pa = carry, pm = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const int j = k - i; if (j < 0 || j > 8) continue; mad_vv(pa, a.v[i], b.v[j]); }
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const int j = k - i; if (j < 1 || j > 8 || i >= k) continue; mad_vs(pm, m[i], p29(j)); }
+        uint64_t acc = pa + pm;
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * INV29) & M29;
+            mad_vs(acc, m[k], p29(0));
+        } else {
+            r.v[k - 9] = (uint32_t)acc & M29;
+        }
+        carry = acc >> 29;
+    }
+    r.v[8] = (uint32_t)carry;
+    return r;
+}
+
 template <int V>
 __global__ __launch_bounds__(64) void kbench(uint32_t* x, int n) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (V == 3) {
+    if (V >= 3) {
         F29 a, b;
         for (int i = 0; i < 9; i++) { a.v[i] = x[tid * 18 + i] & M29; b.v[i] = x[tid * 18 + 9 + i] & M29; }
         a.v[8] &= 0xffff; b.v[8] &= 0xffff;
-        for (int i = 0; i < n; i++) { a = mul_v3(a, b); b.v[0] ^= a.v[0] & 1; }
+        for (int i = 0; i < n; i++) { a = (V == 3) ? mul_v3(a, b) : (V == 4) ? mul_v4(a, b) : (V == 5) ? mul_v5(a, b) : mul_v6(a, b); b.v[0] ^= a.v[0] & 1; }
         for (int i = 0; i < 9; i++) x[tid * 18 + i] = a.v[i];
     } else {
         Fc a, b;
@@ -105,7 +191,7 @@ int main() {
         for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t)(i * 2654435761u + 12345);
         uint32_t* d;
         hipMalloc(&d, h.size() * 4);
-        for (int v : {0, 2, 3}) {
+        for (int v : {3, 4, 5, 6}) {
             hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
@@ -113,6 +199,9 @@ int main() {
                 if (v == 0) hipLaunchKernelGGL(kbench<0>, dim3(waves), dim3(64), 0, 0, d, n);
                 if (v == 2) hipLaunchKernelGGL(kbench<2>, dim3(waves), dim3(64), 0, 0, d, n);
                 if (v == 3) hipLaunchKernelGGL(kbench<3>, dim3(waves), dim3(64), 0, 0, d, n);
+                if (v == 4) hipLaunchKernelGGL(kbench<4>, dim3(waves), dim3(64), 0, 0, d, n);
+                if (v == 5) hipLaunchKernelGGL(kbench<5>, dim3(waves), dim3(64), 0, 0, d, n);
+                if (v == 6) hipLaunchKernelGGL(kbench<6>, dim3(waves), dim3(64), 0, 0, d, n);
             };
             launch();
             hipDeviceSynchronize();
@@ -122,6 +211,9 @@ int main() {
             hipEventSynchronize(e1);
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
+            uint32_t chk[9];
+            hipMemcpy(chk, d + 18 * 777, sizeof chk, hipMemcpyDeviceToHost);
+            printf("[%08x %08x] ", chk[0], chk[8]);
             printf("waves/SIMD=%d variant=%d: %.2f ms  %.1f ns per dependent mul per wave  %.2f Gmul/s\n", waves / 1024, v, ms, ms * 1e6 / n, (double)threads * n / ms / 1e6);
         }
         hipFree(d);
