@@ -290,7 +290,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
         h2[0] = sel ? sib : child;
         h2[1] = sel ? child : sib;
         WitSboxSink sk = io.sbox_sink(lv + VL_HASH);
-        const Fr ph = poseidon_hash<3>(h2, K3, sk);
+        Fr ph;
+        if (HZ_SMT_ZERO_FAST && __all(fr_is_zero(h2[0]) && fr_is_zero(h2[1]))) ph = poseidon3_zero_level(io, lv + VL_HASH);   // empty subtree (smt_dev.h)
+        else ph = poseidon_hash<3>(h2, K3, sk);
         const Fr a0 = ((topmask >> k) & 1) ? ph : zero;
         const Fr root = ((inewmask >> k) & 1) ? fr_add(a0, h1new) : a0;
         io.put_m(lv + VL_AUX0, a0); io.put_u64(lv + VL_AUX1, 0); io.put_m(lv + VL_ROOT, root);

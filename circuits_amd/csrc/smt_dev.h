@@ -36,4 +36,27 @@ __device__ __forceinline__ Fr smt_top_dev(const UnitIO& io, const Scratch& sc, c
 
 
 
+// The level hash of an empty subtree. Below the leaf every level of a sparse Merkle proof hashes (child, sibling) = (0, 0)
+// (smtprocessorlevel.circom: the old / new roots of the `na` levels are 0 and the padded siblings are 0): at nLevels = 32 and a
+// tree of a few thousand leaves that is more than half of the 33 levels. Its 243 S-box signals are constants
+// (gen/poseidon_consts.inc, HZ_POSEIDON3_ZERO_WIT): when every lane of the wavefront is in that case the block is stored from the
+// table -- the level is then bound by its HBM stores instead of 160 k integer instructions. Same bytes, same values.
+#ifndef HZ_SMT_ZERO_FAST
+#define HZ_SMT_ZERO_FAST 1
+#endif
+__device__ __forceinline__ Fr poseidon3_zero_level(const UnitIO& io, uint32_t sig0) {
+#pragma unroll 3
+    for (int s = 0; s < 243; s++) {
+        const uint4* q = reinterpret_cast<const uint4*>(&HZ_POSEIDON3_ZERO_WIT[s][0]);
+        uint4* d = reinterpret_cast<uint4*>(io.addr(sig0 + s));
+        d[0] = q[0];
+        d[1] = q[1];
+    }
+    Fr h;
+#pragma unroll
+    for (int i = 0; i < 9; i++) h.v[i] = HZ_POSEIDON3_ZERO_HASH[i];
+    return h;
+}
+
+
 }  // namespace hz

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "tx_dev.h"
 #include "kernels.h"
+#include "smt_dev.h"
 
 namespace hz {
 
@@ -189,7 +190,9 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
             io.put_m(lv + LV_NEWSW_L, swL); io.put_m(lv + LV_NEWSW_R, swR);
         }
         WitSboxSink sk = io.sbox_sink(lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
-        const Fr h = poseidon_hash<3>(hin, K3, sk);
+        Fr h;
+        if (HZ_SMT_ZERO_FAST && __all(fr_is_zero(hin[0]) && fr_is_zero(hin[1]))) h = poseidon3_zero_level(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
+        else h = poseidon_hash<3>(hin, K3, sk);
         if (!new_side) {
             // st_bot + st_new1 + st_upd ; st_top
             const Fr s_a = k < kl ? zero : k == kl ? mU : k <= kx ? m : zero;

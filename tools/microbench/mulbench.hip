@@ -134,6 +134,34 @@ __device__ __forceinline__ F29 mul_v5(const F29& a, const F29& b) {
     r.v[8] = (uint32_t)acc;
     return r;
 }
+// V7: V4 with every partial sum given a second (empty) use, which stops the re-association without opaque producers
+#define KEEP(x) asm volatile("" :: "v"(x))
+__device__ __forceinline__ F29 mul_v7(const F29& a, const F29& b) {
+    uint32_t m[9];
+    F29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; KEEP(acc); }
+#pragma unroll
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * p29(k - i); KEEP(acc); }
+        m[k] = ((uint32_t)acc * INV29) & M29;
+        acc += (uint64_t)m[k] * p29(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) { acc += (uint64_t)a.v[i] * b.v[k - i]; KEEP(acc); }
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) { acc += (uint64_t)m[i] * p29(k - i); KEEP(acc); }
+        r.v[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
 // V6: two chains per column (products / reduction terms) joined by one addition: half the dependent chain length of V5
 __device__ __forceinline__ F29 mul_v6(const F29& a, const F29& b) {
     uint32_t m[9];
@@ -166,7 +194,7 @@ __global__ __launch_bounds__(64) void kbench(uint32_t* x, int n) {
         F29 a, b;
         for (int i = 0; i < 9; i++) { a.v[i] = x[tid * 18 + i] & M29; b.v[i] = x[tid * 18 + 9 + i] & M29; }
         a.v[8] &= 0xffff; b.v[8] &= 0xffff;
-        for (int i = 0; i < n; i++) { a = (V == 3) ? mul_v3(a, b) : (V == 4) ? mul_v4(a, b) : (V == 5) ? mul_v5(a, b) : mul_v6(a, b); b.v[0] ^= a.v[0] & 1; }
+        for (int i = 0; i < n; i++) { a = (V == 3) ? mul_v3(a, b) : (V == 4) ? mul_v4(a, b) : (V == 5) ? mul_v5(a, b) : (V == 6) ? mul_v6(a, b) : mul_v7(a, b); b.v[0] ^= a.v[0] & 1; }
         for (int i = 0; i < 9; i++) x[tid * 18 + i] = a.v[i];
     } else {
         Fc a, b;
@@ -191,7 +219,7 @@ int main() {
         for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t)(i * 2654435761u + 12345);
         uint32_t* d;
         hipMalloc(&d, h.size() * 4);
-        for (int v : {3, 4, 5, 6}) {
+        for (int v : {3, 4, 5, 7}) {
             hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
@@ -202,6 +230,7 @@ int main() {
                 if (v == 4) hipLaunchKernelGGL(kbench<4>, dim3(waves), dim3(64), 0, 0, d, n);
                 if (v == 5) hipLaunchKernelGGL(kbench<5>, dim3(waves), dim3(64), 0, 0, d, n);
                 if (v == 6) hipLaunchKernelGGL(kbench<6>, dim3(waves), dim3(64), 0, 0, d, n);
+                if (v == 7) hipLaunchKernelGGL(kbench<7>, dim3(waves), dim3(64), 0, 0, d, n);
             };
             launch();
             hipDeviceSynchronize();
