@@ -385,9 +385,10 @@ def main():
         byt = {}
         for name, v in acc.items():
             byt[kern.get(name, name)] = byt.get(kern.get(name, name), 0) + v[1]
-        top = max(tot.values())
-        # near-ties in GPU time (k_eddsa's one long launch vs k_smt's two) go to the kernel that moves more witness bytes
-        dk = max((k for k in tot if tot[k] >= 0.95 * top), key=lambda k: byt[k])
+        # dominant kernel for an HBM roofline = the kernel that writes most of the witness (k_smt: three quarters of a step's
+        # bytes, and the only one besides the front / hash kernels that fills the device). k_eddsa's single launch lasts longer
+        # but runs on 384 wavefronts, latency bound, underneath the others: its figures are in kernels_ms / kernels_GBs.
+        dk = max(tot, key=lambda k: byt[k])
         dname = max((n for n in acc if kern.get(n, n) == dk), key=lambda n: acc[n][0])
         dms, dbytes, dunits, dlaunches = acc[dname]
         dlaunches = max(1, int(round(dlaunches)))
@@ -408,7 +409,8 @@ def main():
                          "note": "algorithmic bytes = 32 B x the witness signals this launch is responsible for (the SMT chain is launched in chunks "
                                  "of levels: per-launch figures are the mean over a step's launches); duration = HIP events on its stream with the "
                                  "kernel alone on the device; traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes. "
-                                 "The kernel is integer-VALU issue bound, not HBM bound (DESIGN.md 4)"},
+                                 "Levels of an SMT proof below the leaf (the hash of an empty subtree) are stored from a constant block and are "
+                                 "HBM-store bound; the levels that hash data are integer-VALU issue bound (DESIGN.md 4)"},
             "whole_pass": {"algorithmic_bytes_per_tx": algorithmic_bytes_per_tx(lv, F),
                            "achieved_GBs": round(algorithmic_bytes_per_tx(lv, F) * value / 1e9, 2)},
             "kernels_ms": {k: round(v[0], 3) for k, v in acc.items()},

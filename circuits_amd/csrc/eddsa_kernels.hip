@@ -66,7 +66,7 @@ __device__ Fr fr_sqrt_circom_dev(const Fr& n) {
 }
 
 #ifndef HZ_ED_G
-#define HZ_ED_G 4   // signatures per lane
+#define HZ_ED_G 2   // signatures per lane (launches above 8192 signatures)
 #endif
 
 struct EdCtx {
@@ -485,7 +485,10 @@ hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
     return launch_eddsa_g<HZ_ED_G>(a, n, s);
 #else
     if (n <= 8192) return launch_eddsa_g<1>(a, n, s);
-    if (n <= 40960) return launch_eddsa_g<2>(a, n, s);   // measured: 16 batches per launch 808 k tx/s with 2, 690 k with 4; 32 batches 961 k vs 994 k
+    // Two signatures per lane. Four (one inversion shared by four ladder steps) issue fewer instructions but take 42.6 ms against
+    // 28.5 ms per 65 536 signatures: since the SMT chain stores its empty-subtree levels from a table (25 ms per step instead of 42)
+    // the ladder is the longest chain of a step, and its length, not its instruction count, sets the step: 1.27 vs 1.19 M tx/s
+    // (one per lane: 20.8 ms, 1.23 M tx/s).
     return launch_eddsa_g<HZ_ED_G>(a, n, s);
 #endif
 }
@@ -495,8 +498,7 @@ hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {
     return launch_eddsa_fix_g<HZ_ED_GF_FIXED>(a, n, s);
 #else
     if (n <= 8192) return launch_eddsa_fix_g<1>(a, n, s);
-    if (n <= 40960) return launch_eddsa_fix_g<4>(a, n, s);
-    return launch_eddsa_fix_g<8>(a, n, s);
+    return launch_eddsa_fix_g<4>(a, n, s);   // 9.2 ms per 65 536 signatures (eight per lane: 14.1 ms, same step time)
 #endif
 }
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s) {
