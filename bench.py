@@ -65,7 +65,7 @@ def poseidon_rates(L, torch):
 
 
 def measured_traffic(kernel, bpl):
-    """HBM bytes of one launch of `kernel` (its largest dispatch) from the committed rocprofv3 PMC passes
+    """HBM bytes of one launch of `kernel` (mean over its launches of the transaction grid) from the committed rocprofv3 PMC passes
     (profiles/r01_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
     this configuration."""
     try:
@@ -73,6 +73,8 @@ def measured_traffic(kernel, bpl):
         if d.get("batches_per_launch") != bpl:
             return None
         k = d["kernels"][kernel]
+        if "fetch_bytes_mean" in k:   # per launch like `achieved`: mean over the kernel's launches of the transaction grid
+            return int(k["fetch_bytes_mean"] + k["write_bytes_mean"])
         return int(k["fetch_bytes"] + k["write_bytes"])
     except (OSError, KeyError, ValueError):
         return None

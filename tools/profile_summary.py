@@ -32,18 +32,19 @@ if f:
     if t:
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(t[0])):
-            per[short(r["Kernel_Name"])].append((int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+            per[short(r["Kernel_Name"])].append((int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                                 int(r["Start_Timestamp"])))
         with open(out + "/kernel_stats.csv", "a") as o:
-            o.write("# largest-grid dispatches of each kernel: count, mean us (all, incl. concurrent with the other context), mean us of the exclusive dispatches (the 3 x launches-per-step shortest: kernel alone on the device)\n")
+            o.write("# largest-grid dispatches of each kernel: count, mean us (all, incl. concurrent with the other context), mean us of the exclusive dispatches (the last 3 x launches-per-step in time: bench.py's final phase runs every kernel alone on the device)\n")
             o.write("name,grid,calls,mean_us_all,mean_us_alone\n")
             for k, v in sorted(per.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
                 g = max(x[0] for x in v)
-                d = sorted(x[1] for x in v if x[0] == g)
+                d = [x[1] for x in sorted((y for y in v if y[0] == g), key=lambda y: y[2])]   # in time order
                 if d and sum(d) > 1000:
                     # the profiled command enqueues 12 steps (1 checked + 1 warm-up + 4 timed + 3 latency + 3 exclusive): a kernel
                     # launched k times per step has 3k exclusive dispatches
                     k_per_step = max(1, int(round(len(d) / 12.0)))
-                    alone = d[:3 * k_per_step]
+                    alone = d[-3 * k_per_step:]
                     o.write("%s,%d,%d,%.1f,%.1f\n" % (k, g, len(d), sum(d) / len(d), sum(alone) / len(alone)))
     print(open(out + "/kernel_stats.csv").read()[:2500])
 
@@ -93,13 +94,19 @@ if fetch or write:
             g = max([x[1] for x in fetch.get(k, [])] + [x[1] for x in write.get(k, [])] + [0])
             o.write("%s,%d,%d,%.1f,%.1f,%.1f,%.1f\n" % (k, max(len(fv), len(wv)), g, sum(fv) / len(fv), max(fv), sum(wv) / len(wv), max(wv)))
             # the largest dispatch of a kernel is its transaction launch (the fee-transaction launch of the same kernel is small)
-            kernels["k_" + k.split("<")[0].replace("k_", "")] = {"fetch_bytes": max(fv) * 1024 * f_corr, "write_bytes": max(wv) * 1024 * w_corr}
+            # a kernel launched in pieces (the SMT chain: chunks of levels, the bottom one stored from a table) has launches of the same
+            # grid that move different amounts: the mean over its largest-grid dispatches is what bench.py's per-launch mean compares with
+            fg = [x[0] for x in fetch.get(k, []) if x[1] == g] or [0]
+            wg = [x[0] for x in write.get(k, []) if x[1] == g] or [0]
+            kernels["k_" + k.split("<")[0].replace("k_", "")] = {"fetch_bytes": max(fv) * 1024 * f_corr, "write_bytes": max(wv) * 1024 * w_corr,
+                                                                 "fetch_bytes_mean": sum(fg) / len(fg) * 1024 * f_corr, "write_bytes_mean": sum(wg) / len(wg) * 1024 * w_corr,
+                                                                 "largest_grid_dispatches": max(len(fg), len(wg))}
     bpl = 32
     for tok in cmd.split():
         pass
     if "--batches-per-launch" in cmd:
         bpl = int(cmd.split("--batches-per-launch")[1].split()[0])
     json.dump({"command": cmd, "batches_per_launch": bpl, "fetch_correction": f_corr, "write_correction": w_corr,
-               "note": "bytes per LARGEST dispatch of each kernel (the transaction launch), corrected", "kernels": kernels},
+               "note": "fetch/write_bytes: the LARGEST dispatch of each kernel (the transaction launch); *_mean: mean over the dispatches of that grid; corrected", "kernels": kernels},
               open(out + "/hbm_counters.json", "w"), indent=1)
     print(open(out + "/hbm_counters.csv").read()[:2500])
