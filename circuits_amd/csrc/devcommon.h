@@ -19,6 +19,17 @@ template <int T> __device__ __forceinline__ const Fr* poseidon_k_global();
     template <> __device__ __forceinline__ const Fr* poseidon_k_global<T>() { return reinterpret_cast<const Fr*>(&HZ_POSEIDON_K_T##T[0][0]); }
 HZ_PC(2) HZ_PC(3) HZ_PC(4) HZ_PC(5) HZ_PC(6) HZ_PC(7)
 #undef HZ_PC
+// the block for sinks that store the S-box witness (canonical S-box outputs, poseidon.h)
+template <int T> __device__ __forceinline__ const Fr* poseidon_k_global_w();
+#if HZ_POSEIDON_CANON_SBOX
+#define HZ_PC(T) \
+    template <> __device__ __forceinline__ const Fr* poseidon_k_global_w<T>() { return reinterpret_cast<const Fr*>(&HZ_POSEIDON_KW_T##T[0][0]); }
+#else
+#define HZ_PC(T) \
+    template <> __device__ __forceinline__ const Fr* poseidon_k_global_w<T>() { return reinterpret_cast<const Fr*>(&HZ_POSEIDON_K_T##T[0][0]); }
+#endif
+HZ_PC(2) HZ_PC(3) HZ_PC(4) HZ_PC(5) HZ_PC(6) HZ_PC(7)
+#undef HZ_PC
 
 // Where the kernels read the Poseidon constants from. Every lane of a wavefront needs the same
 // constant at the same time, so the block is either read straight from device memory through the
@@ -31,19 +42,22 @@ template <int T> constexpr size_t poseidon_lds_bytes() { return HZ_POSEIDON_LDS 
 
 // Returns the width-T constant block; in LDS mode the whole block cooperates in copying it to
 // `lds` (advanced past the block) and the caller must __syncthreads() before the first use.
-template <int T>
+template <int T, bool W = false>
 __device__ __forceinline__ const Fr* poseidon_consts(uint32_t*& lds) {
 #if HZ_POSEIDON_LDS
     constexpr int NW = poseidon_const_frs<T>() * 9;  // 32-bit words (an Fr is 9 limbs)
-    const uint32_t* g = reinterpret_cast<const uint32_t*>(poseidon_k_global<T>());
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(W ? poseidon_k_global_w<T>() : poseidon_k_global<T>());
     uint32_t* d = lds;
     for (int i = threadIdx.x; i < NW; i += blockDim.x) d[i] = g[i];
     lds += NW;
     return reinterpret_cast<const Fr*>(d);
 #else
-    return poseidon_k_global<T>();
+    return W ? poseidon_k_global_w<T>() : poseidon_k_global<T>();
 #endif
 }
+// the block for a sink that stores the S-box witness (every witness kernel)
+template <int T>
+__device__ __forceinline__ const Fr* poseidon_consts_w(uint32_t*& lds) { return poseidon_consts<T, true>(lds); }
 
 // ---- 32-byte element I/O (canonical form) ------------------------------------------------------
 __device__ __forceinline__ Fc load_fr(const void* p) {
@@ -83,12 +97,19 @@ struct WitOut {
 
 // Poseidon S-box sink that stores the three product signals of S-box k at sig0 + 3k + {0,1,2}.
 struct WitSboxSink {
+    static constexpr bool kCanon = HZ_POSEIDON_CANON_SBOX != 0;   // the S-box hands over canonical values (29-bit limbs, < p)
     WitOut w;
     uint32_t sig0;
     __device__ __forceinline__ void operator()(int k, const Fr& x2, const Fr& x4, const Fr& x5) const {
-        w.put_mont(sig0 + 3 * k + 0, x2);
-        w.put_mont(sig0 + 3 * k + 1, x4);
-        w.put_mont(sig0 + 3 * k + 2, x5);
+        if constexpr (kCanon) {
+            w.put_canon(sig0 + 3 * k + 0, fr_pack_canon(x2));
+            w.put_canon(sig0 + 3 * k + 1, fr_pack_canon(x4));
+            w.put_canon(sig0 + 3 * k + 2, fr_pack_canon(x5));
+        } else {
+            w.put_mont(sig0 + 3 * k + 0, x2);
+            w.put_mont(sig0 + 3 * k + 1, x4);
+            w.put_mont(sig0 + 3 * k + 2, x5);
+        }
     }
 };
 

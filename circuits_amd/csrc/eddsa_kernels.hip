@@ -351,7 +351,7 @@ template <int G>
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa(const EddsaArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
-    const Fr* K6 = poseidon_consts<6>(lds);
+    const Fr* K6 = poseidon_consts_w<6>(lds);
     __syncthreads();
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t nl = (n + G - 1) / G;

@@ -58,7 +58,7 @@ struct HsMainArgs { uint8_t* base; uint32_t N; HashStateOff hs; };
 __global__ __launch_bounds__(HZ_BLOCK) void k_hash_state_main(const HsMainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
-    const Fr* K5 = poseidon_consts<5>(lds);
+    const Fr* K5 = poseidon_consts_w<5>(lds);
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
@@ -206,9 +206,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_sha_expand(const HashInputsArgs a)
 __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
-    const Fr* K5 = poseidon_consts<5>(lds);
-    const Fr* K4 = poseidon_consts<4>(lds);
-    const Fr* K3 = poseidon_consts<3>(lds);
+    const Fr* K5 = poseidon_consts_w<5>(lds);
+    const Fr* K4 = poseidon_consts_w<4>(lds);
+    const Fr* K3 = poseidon_consts_w<3>(lds);
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;

@@ -398,6 +398,45 @@ HZ_HD_HEAVY Fc fr_to_canon(HZ_HEAVY_ARG(Fr) a) {
     }
     return o;
 }
+// ---- canonical values in 29-bit limbs (the witness form of the Poseidon S-box, poseidon.h) ----------------
+// t (normalised limbs, value < 2p) -> t - p if t >= p: the unique representative in [0, p)
+HZ_HD Fr fr_cond_sub_p(const Fr& a) {
+    int32_t d[9];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t x = (int32_t)a.v[i] - (int32_t)fr_p29(i) + c;
+        d[i] = (i < 8) ? (x & (int32_t)HZ_M29) : x;
+        c = x >> 29;
+    }
+    const bool ge = d[8] >= 0;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = ge ? (uint32_t)d[i] : a.v[i];
+    return r;
+}
+// Montgomery -> canonical, kept in 29-bit limbs (a usable multiplicand: x * canon(y) / R = xy/R^... see poseidon_sbox)
+HZ_HD Fr fr_canon_limbs(const Fr& a) {
+    uint64_t t[18];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = a.v[i];
+#pragma unroll
+    for (int i = 9; i < 18; i++) t[i] = 0;
+    return fr_cond_sub_p(fr_reduce_cols(t));   // (a + m p)/R <= p
+}
+// canonical value in 29-bit limbs (< p) -> 8 x u32
+HZ_HD Fc fr_pack_canon(const Fr& r) {
+    Fc o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int bit = 32 * i, l = bit / 29, sh = bit % 29;
+        uint64_t acc = (uint64_t)r.v[l] >> sh;
+        acc |= (uint64_t)r.v[l + 1] << (29 - sh);
+        if (l + 2 < 9) acc |= (uint64_t)r.v[l + 2] << (58 - sh);
+        o.v[i] = (uint32_t)acc;
+    }
+    return o;
+}
 // small integer -> Montgomery
 HZ_HD Fr fr_from_u64(uint64_t x) {
     Fc c = fc_zero();

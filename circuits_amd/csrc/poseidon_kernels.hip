@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void poseidon_batch_kernel(const uint8_t* __re
                                                               uint8_t* __restrict__ wit, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
-    const Fr* K = poseidon_consts<T>(lds);
+    const Fr* K = poseidon_consts<T, WIT>(lds);   // the witness sink takes canonical S-box outputs: its own constant block
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {

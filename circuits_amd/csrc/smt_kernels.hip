@@ -21,8 +21,8 @@ namespace hz {
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HASH4_WAVES))) void k_hash4(const Hash4Args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
-    const Fr* K5 = poseidon_consts<5>(lds);
-    const Fr* K4 = poseidon_consts<4>(lds);
+    const Fr* K5 = poseidon_consts_w<5>(lds);
+    const Fr* K4 = poseidon_consts_w<4>(lds);
     __syncthreads();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HAS
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT_WAVES))) void k_smt(const SmtArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
-    const Fr* K3 = poseidon_consts<3>(lds);
+    const Fr* K3 = poseidon_consts_w<3>(lds);
     __syncthreads();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;

@@ -47,7 +47,7 @@ struct FeeSrcRtx {
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_main_front(const MainFrontArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
-    const Fr* K7 = poseidon_consts<7>(lds);
+    const Fr* K7 = poseidon_consts_w<7>(lds);
     __syncthreads();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_units = a.B * a.nTx;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRO
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_dec_main(const DecMainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
-    const Fr* K7 = poseidon_consts<7>(lds);
+    const Fr* K7 = poseidon_consts_w<7>(lds);
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;

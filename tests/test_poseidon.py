@@ -111,3 +111,15 @@ def test_hip_field_ops_against_python_bigints(hz):
         m = n if op != 4 else 4096
         got = hz.fr_ops(op, a[:m], b[:m])
         assert got == [f(x, y) for x, y in zip(a[:m], b[:m])], "field op %d" % op
+
+
+def test_canonical_sbox_form_matches_the_montgomery_form(tmp_path):
+    """poseidon.h has two evaluations: digest only (Montgomery S-box, constant block K) and witness (S-box products straight in
+    canonical form, constant block KW). Host build of both over the product headers: same digests, same S-box signals, t = 2..7."""
+    import subprocess
+    src = os.path.join(os.path.dirname(__file__), "native", "poseidon_canon_check.cpp")
+    exe = str(tmp_path / "canon_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("mismatches=0") == 6
