@@ -68,10 +68,24 @@ __device__ __forceinline__ Fc load_fr(const void* p) {
     r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
     return r;
 }
+// witness elements are written once and (with few exceptions) never read again by the device. Marking the stores non-temporal
+// (HZ_NT_STORES=1) was measured and is much SLOWER (k_smt 24 -> 37 ms, withdraw 1.90 -> 0.78 M/s): a lane writes 32 bytes, the
+// wavefront's 2 KB per signal are combined in L2, which streaming stores bypass.
+#ifndef HZ_NT_STORES
+#define HZ_NT_STORES 0
+#endif
+typedef uint32_t hz_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_fr(void* p, const Fc& r) {
+#if HZ_NT_STORES
+    hz_u32x4* q = reinterpret_cast<hz_u32x4*>(p);
+    hz_u32x4 a = {r.v[0], r.v[1], r.v[2], r.v[3]}, b = {r.v[4], r.v[5], r.v[6], r.v[7]};
+    __builtin_nontemporal_store(a, q);
+    __builtin_nontemporal_store(b, q + 1);
+#else
     uint4* q = reinterpret_cast<uint4*>(p);
     q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
     q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+#endif
 }
 
 // ---- witness writer ---------------------------------------------------------------------------
@@ -88,9 +102,10 @@ struct WitOut {
     __device__ __forceinline__ void put_mont(uint32_t sig, const Fr& m) const { store_fr(addr(sig), fr_to_canon(m)); }
     __device__ __forceinline__ void put_canon(uint32_t sig, const Fc& c) const { store_fr(addr(sig), c); }
     __device__ __forceinline__ void put_u64(uint32_t sig, uint64_t x) const {
-        uint4* q = reinterpret_cast<uint4*>(addr(sig));
-        q[0] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), 0u, 0u);
-        q[1] = make_uint4(0u, 0u, 0u, 0u);
+        Fc c;
+        c.v[0] = (uint32_t)x; c.v[1] = (uint32_t)(x >> 32);
+        c.v[2] = c.v[3] = c.v[4] = c.v[5] = c.v[6] = c.v[7] = 0u;
+        store_fr(addr(sig), c);
     }
     __device__ __forceinline__ void put_bit(uint32_t sig, uint32_t b) const { put_u64(sig, b & 1u); }
 };

@@ -27,9 +27,10 @@ struct UnitIO {
     __device__ __forceinline__ void put_m(uint32_t sig, const Fr& m) const { store_fr(addr(sig), fr_to_canon(m)); }
     __device__ __forceinline__ void put_c(uint32_t sig, const Fc& c) const { store_fr(addr(sig), c); }
     __device__ __forceinline__ void put_u64(uint32_t sig, uint64_t x) const {
-        uint4* q = reinterpret_cast<uint4*>(addr(sig));
-        q[0] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), 0u, 0u);
-        q[1] = make_uint4(0u, 0u, 0u, 0u);
+        Fc c;
+        c.v[0] = (uint32_t)x; c.v[1] = (uint32_t)(x >> 32);
+        c.v[2] = c.v[3] = c.v[4] = c.v[5] = c.v[6] = c.v[7] = 0u;
+        store_fr(addr(sig), c);
     }
     __device__ __forceinline__ void put_bit(uint32_t sig, uint32_t b) const { put_u64(sig, b & 1u); }
     // `lhs === rhs` (Montgomery operands)

@@ -47,10 +47,10 @@ __device__ __forceinline__ Fr smt_top_dev(const UnitIO& io, const Scratch& sc, c
 __device__ __forceinline__ Fr poseidon3_zero_level(const UnitIO& io, uint32_t sig0) {
 #pragma unroll 3
     for (int s = 0; s < 243; s++) {
-        const uint4* q = reinterpret_cast<const uint4*>(&HZ_POSEIDON3_ZERO_WIT[s][0]);
-        uint4* d = reinterpret_cast<uint4*>(io.addr(sig0 + s));
-        d[0] = q[0];
-        d[1] = q[1];
+        Fc c;
+#pragma unroll
+        for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[s][q];
+        store_fr(io.addr(sig0 + s), c);
     }
     Fr h;
 #pragma unroll
