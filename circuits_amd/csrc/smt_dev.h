@@ -41,6 +41,8 @@ __device__ __forceinline__ Fr smt_top_dev(const UnitIO& io, const Scratch& sc, c
 // tree of a few thousand leaves that is more than half of the 33 levels. Its 243 S-box signals are constants
 // (gen/poseidon_consts.inc, HZ_POSEIDON3_ZERO_WIT): when every lane of the wavefront is in that case the block is stored from the
 // table -- the level is then bound by its HBM stores instead of 160 k integer instructions. Same bytes, same values.
+// (Writing the block as fully contiguous 1 KB stores -- lane l the 16-byte piece l of the wavefront's 2 KB per signal -- instead
+// of 16 bytes at a 32-byte stride per lane was measured: no difference, L2 combines the halves either way.)
 #ifndef HZ_SMT_ZERO_FAST
 #define HZ_SMT_ZERO_FAST 1
 #endif
