@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--nLevels", type=int, default=32)
     ap.add_argument("--maxL1Tx", type=int, default=256)
     ap.add_argument("--maxFeeTx", type=int, default=64)
+    ap.add_argument("--accounts", type=int, default=0, help="accounts in the synthetic state before the batch (default 4 * nTx, the reference recipe)")
     ap.add_argument("--inflight", type=int, default=2, help="contexts in flight (each with its own witness buffers and streams): the fee/SHA tail of one step overlaps the next step's kernels")
     ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = min(16, logical CPUs); 64 processes were measured slower in total: 867 vs 956 tx/s)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="nTx of the CPU-baseline sample (0 = skip)")
@@ -283,8 +284,12 @@ def main():
     if args.workload == "withdraw":
         return bench_withdraw(args, L, rank, world, local)
     nTx, lv, m1, F = args.nTx, args.nLevels, args.maxL1Tx, args.maxFeeTx
-    # synthetic batch (reference tools/generate-input.js recipe), same seed on every rank
-    bb = B.synthetic_batch(nTx, lv, m1, F, n_accounts=min(nTx, 4096), seed=0x48455A31)
+    # synthetic batch (reference tools/generate-input.js recipe, SURVEY 8d: a state of 4*nTx accounts), same seed on every rank;
+    # built with the device batch builder (circuits_amd/builder.py DagHasher: the tree hashing of the 4*nTx + maxL1Tx accounts and of
+    # the batch in ~60 launches). The state size matters: the Merkle proofs of a tree of 2^13 leaves reach their leaf at level 13-14,
+    # the levels below hash empty subtrees.
+    n_acc = args.accounts if args.accounts > 0 else 4 * nTx
+    bb = B.synthetic_batch(nTx, lv, m1, F, n_accounts=n_acc, seed=0x48455A31, device=local)
     inp = bb.get_input()
     n_l2 = sum(1 for x in inp["onChain"] if not x)
     if args.shard_tx:
@@ -402,7 +407,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x9 (254-bit Montgomery Fr, 29-bit limbs, integer)", "data": "synthetic",
             "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "batches_per_launch": Bp, "contexts_in_flight": inflight,
-                       "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
+                       "state_accounts": n_acc, "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
                        "witness_bytes_per_batch": ctxs[0].witness_len() * 32, "step_latency_ms": round(single_ms, 3)},
             "roofline": {"bound": "hbm", "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
