@@ -21,9 +21,10 @@
 #else
 #define HZ_HD inline
 #endif
-// Heavy routines stay out of line on the device unless HZ_FR_INLINE is defined: the witness kernels
-// call them from hundreds of sites; one shared body keeps the kernels inside the instruction cache
-// and compiles in seconds instead of minutes.
+// Heavy routines stay out of line on the device unless HZ_FR_INLINE is defined (one shared body, seconds to compile). Every
+// kernel on the RollupMain path defines it: measured, the call overhead (operands copied through the argument registers) costs
+// more than the larger code -- k_smt, k_hash4, the signature kernels (-8 %) and k_main_front (-11 %). Only the fee / withdraw /
+// SHA kernels (fee_kernels.hip: latency or store bound, no difference) and the gadget mains keep the out-of-line form.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_FR_INLINE)
 #define HZ_HD_HEAVY static __device__ __attribute__((noinline))
 #define HZ_HEAVY_ARG(T) const T
