@@ -51,7 +51,7 @@ class hz_symbol(ctypes.Structure):
 
 
 TEMPLATES = {"rollup-main": 0, "rollup-tx": 1, "decode-tx": 2, "fee-tx": 3, "hash-state": 4, "withdraw": 5, "hash-inputs": 6, "decode-float": 7, "compute-fee": 8, "fee-accumulator": 9, "balance-updater": 10,
-             "rollup-tx-states": 11, "rq-tx-verifier": 12, "mux256": 13, "bits-compressed-2-ay-sign": 14, "ay-sign-2-ax": 15}
+             "rollup-tx-states": 11, "rq-tx-verifier": 12, "mux256": 13, "bits-compressed-2-ay-sign": 14, "ay-sign-2-ax": 15, "smt-processor": 16, "smt-verifier": 17}
 
 # every symbol include/hermez_witness.h declares; tests check the .so exports all of them
 EXPORTS = [

@@ -124,7 +124,7 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     Params lp;
     lp.tmpl = p->template_id; lp.nTx = p->nTx; lp.L = p->nLevels; lp.maxL1 = p->maxL1Tx; lp.F = p->maxFeeTx;
     lp.n_inst = p->n_instances > 0 ? p->n_instances : 1;
-    const bool needs_L = lp.tmpl != T_HASH_STATE && lp.tmpl < T_DECODE_FLOAT;
+    const bool needs_L = (lp.tmpl != T_HASH_STATE && lp.tmpl < T_DECODE_FLOAT) || lp.tmpl == T_SMT_PROCESSOR || lp.tmpl == T_SMT_VERIFIER;
     if (lp.tmpl == T_FEE_ACCUMULATOR && lp.F < 1) return set_err(HZ_ERR_ARG, "FeeAccumulator needs maxFeeTx >= 1");
     if (needs_L && (lp.L < 2 || lp.L > 48)) return set_err(HZ_ERR_ARG, "nLevels must be in [2,48]");
     if ((lp.tmpl == T_ROLLUP_MAIN || lp.tmpl == T_HASH_INPUTS) && (lp.nTx < 1 || lp.F < 1 || lp.maxL1 < 0))
@@ -307,7 +307,7 @@ extern "C" hz_status hz_copy_instance_inputs(hz_ctx* c, int32_t src, int32_t dst
 }
 
 // ---- kernel schedule ---------------------------------------------------------------------------------
-static SmtProcDesc make_proc(const SmtProcOff& o, uint32_t siblings, int which /*0: p1, 1: p2, 2: fee*/) {
+static SmtProcDesc make_proc(const SmtProcOff& o, uint32_t siblings, int which /*0: p1, 1: p2, 2: fee, 3: SMTProcessor main*/) {
     SmtProcDesc d;
     d.o = o;
     d.siblings = siblings;
@@ -320,6 +320,8 @@ static SmtProcDesc make_proc(const SmtProcOff& o, uint32_t siblings, int which /
         d.sc_leaf_old = SC_LEAF_P1OLD; d.sc_leaf_new = SC_LEAF_P1NEW; d.sc_root_old = SC_ROOT_P1OLD; d.sc_root_new = SC_ROOT_P1NEW;
         if (which == 0) {
             d.cid_alias_old = C_RTX_P1_ALIAS_OLD; d.cid_alias_new = C_RTX_P1_ALIAS_NEW; d.cid_levins = C_RTX_P1_LEVINS; d.cid_sm_final = C_RTX_P1_SM_FINAL;
+        } else if (which == 3) {
+            d.cid_alias_old = C_SMTP_ALIAS_OLD; d.cid_alias_new = C_SMTP_ALIAS_NEW; d.cid_levins = C_SMTP_LEVINS; d.cid_sm_final = C_SMTP_SM_FINAL;
         } else {
             d.cid_alias_old = C_FEE_P_ALIAS_OLD; d.cid_alias_new = C_FEE_P_ALIAS_NEW; d.cid_levins = C_FEE_P_LEVINS; d.cid_sm_final = C_FEE_P_SM_FINAL;
         }
@@ -570,6 +572,25 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
         case T_HASH_INPUTS:
             HZ_HIP(launch_hash_inputs(make_hi(c, false), s));
             break;
+        case T_SMT_PROCESSOR: case T_SMT_VERIFIER: {
+            SmtMainArgs ma;
+            memset(&ma, 0, sizeof ma);
+            ma.base = sec_ptr(c, 0); ma.scratch = (Fr*)c->sc_fee.p; ma.err = err; ma.N = lo.sections[0].n_units; ma.n_levels = (uint32_t)lo.p.L;
+            if (lo.p.tmpl == T_SMT_VERIFIER) {
+                ma.vin = lo.smtvi; ma.ver = lo.smtv;
+                HZ_HIP(launch_smtver_main(ma, s));
+                break;
+            }
+            ma.pin = lo.smtpi; ma.proc = make_proc(lo.smtp, lo.smtpi.siblings, 3);
+            HZ_HIP(launch_smtproc_front(ma, s));
+            SmtArgs sa;
+            memset(&sa, 0, sizeof sa);
+            sa.base = ma.base; sa.scratch = ma.scratch; sa.err = err; sa.n_units = ma.N; sa.n_levels = ma.n_levels; sa.n_proc = 1; sa.upi = 1;
+            sa.p[0] = ma.proc;
+            HZ_HIP(enqueue_smt_chain(c, sa, "smt", s));
+            HZ_HIP(launch_smtproc_back(ma, s));
+            break;
+        }
         case T_DECODE_FLOAT: case T_COMPUTE_FEE: case T_FEE_ACCUMULATOR: case T_BALANCE_UPDATER: case T_ROLLUP_TX_STATES: case T_RQ_TX_VERIFIER:
         case T_MUX256: case T_BITS2AYSIGN: case T_AYSIGN2AX: {
             GadgetArgs ga;

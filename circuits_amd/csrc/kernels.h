@@ -171,6 +171,21 @@ struct WithdrawArgs {
     WithdrawOff wd;
 };
 
+// SMTProcessor(n) / SMTVerifier(n) as main (smt_main_kernels.hip)
+struct SmtMainArgs {
+    uint8_t* base;
+    Fr* scratch;
+    ErrBuf* err;
+    uint32_t N, n_levels;
+    SmtProcInOff pin;
+    SmtProcDesc proc;
+    SmtVerInOff vin;
+    SmtVerOff ver;
+};
+hipError_t launch_smtproc_front(const SmtMainArgs& a, hipStream_t s);
+hipError_t launch_smtproc_back(const SmtMainArgs& a, hipStream_t s);
+hipError_t launch_smtver_main(const SmtMainArgs& a, hipStream_t s);
+
 hipError_t launch_withdraw_sha(const WithdrawArgs& a, hipStream_t s);
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s);
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s);

@@ -63,6 +63,12 @@ typedef enum {
     HZ_T_MUX256 = 13,          /* Mux256()                             src/lib/mux256.circom:10         */
     HZ_T_BITS2AYSIGN = 14,     /* BitsCompressed2AySign()              src/lib/utils-bjj.circom:12      */
     HZ_T_AYSIGN2AX = 15,       /* AySign2Ax()                          src/lib/utils-bjj.circom:37      */
+    /* circomlib 0.5.2's own sparse-Merkle-tree templates as main: the components behind src/rollup-tx.circom:537-570,
+     * src/fee-tx.circom:97 (SMTProcessor(nLevels+1)) and src/withdraw.circom:47-58 (SMTVerifier(nLevels+1)). Here nLevels is the
+     * template's own parameter (number of levels). Inputs as in circomlib: oldRoot, siblings[n], oldKey, oldValue, isOld0, newKey,
+     * newValue, fnc[2] -> newRoot; enabled, root, siblings[n], oldKey, oldValue, isOld0, key, value, fnc. */
+    HZ_T_SMT_PROCESSOR = 16,
+    HZ_T_SMT_VERIFIER = 17,
     HZ_T_COUNT
 } hz_template;
 

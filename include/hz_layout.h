@@ -40,7 +40,10 @@ enum { T_ROLLUP_MAIN = 0, T_ROLLUP_TX = 1, T_DECODE_TX = 2, T_FEE_TX = 3, T_HASH
        // the gadget templates the reference's remaining suites instantiate as `component main`
        T_DECODE_FLOAT = 7, T_COMPUTE_FEE = 8, T_FEE_ACCUMULATOR = 9, T_BALANCE_UPDATER = 10, T_ROLLUP_TX_STATES = 11, T_RQ_TX_VERIFIER = 12,
        T_MUX256 = 13, T_BITS2AYSIGN = 14, T_AYSIGN2AX = 15,
-       T_COUNT = 16 };
+       // circomlib's own SMT templates as `component main` (SMTProcessor(nLevels), SMTVerifier(nLevels)): the route through which
+       // the published sparse-Merkle-tree known answers (tests/golden/smt_kat.json) reach the level-hash kernels
+       T_SMT_PROCESSOR = 16, T_SMT_VERIFIER = 17,
+       T_COUNT = 18 };
 
 struct Params {
     int tmpl = 0, nTx = 0, L = 0, maxL1 = 0, F = 0, n_inst = 1;
@@ -169,7 +172,24 @@ inline int poseidon_nsig(int t) { return 3 * poseidon_nsbox(t); }
     X(C_WD_KEYS, "withdraw.smtVerify: keysOk.out === 0")                                            \
     X(C_WD_ROOT, "withdraw.smtVerify.checkRoot")                                                    \
     X(C_WD_HI_N2B, "withdraw.hasherInputs: Num2Bits sum")                                           \
-    X(C_WD_HI_PAD, "withdraw.hasherInputs: paddingIdx === 0")
+    X(C_WD_HI_PAD, "withdraw.hasherInputs: paddingIdx === 0")                                       \
+    /* SMTProcessor(n) / SMTVerifier(n) as main (circomlib smt/smtprocessor.circom, smt/smtverifier.circom) */ \
+    X(C_SMTP_N2B_OLD, "smtProcessor.n2bOld")                                                        \
+    X(C_SMTP_ALIAS_OLD, "smtProcessor.n2bOld.aliasCheck")                                           \
+    X(C_SMTP_N2B_NEW, "smtProcessor.n2bNew")                                                        \
+    X(C_SMTP_ALIAS_NEW, "smtProcessor.n2bNew.aliasCheck")                                           \
+    X(C_SMTP_LEVINS, "smtProcessor.smtLevIns: last sibling must be zero")                           \
+    X(C_SMTP_SM_FINAL, "smtProcessor: final state")                                                 \
+    X(C_SMTP_OLDROOT, "smtProcessor.checkOldInput")                                                 \
+    X(C_SMTP_KEYS, "smtProcessor: keysOk.out === 0")                                                \
+    X(C_SMTV_N2B_OLD, "smtVerifier.n2bOld")                                                         \
+    X(C_SMTV_ALIAS_OLD, "smtVerifier.n2bOld.aliasCheck")                                            \
+    X(C_SMTV_N2B_NEW, "smtVerifier.n2bNew")                                                         \
+    X(C_SMTV_ALIAS_NEW, "smtVerifier.n2bNew.aliasCheck")                                            \
+    X(C_SMTV_LEVINS, "smtVerifier.smtLevIns: last sibling must be zero")                            \
+    X(C_SMTV_SM_FINAL, "smtVerifier: final state")                                                  \
+    X(C_SMTV_KEYS, "smtVerifier: keysOk.out === 0")                                                 \
+    X(C_SMTV_ROOT, "smtVerifier.checkRoot")
 
 enum ConstraintId {
 #define X(id, text) id,
@@ -392,6 +412,9 @@ struct DecInOff {
         auxToIdx, inIdx;
 };
 struct FeeTxInOff { uint32_t oldStateRoot, feePlanToken, feeIdx, accFee, tokenID, nonce, sign, balance, ay, ethAddr, siblings; };
+// SMTProcessor(n) / SMTVerifier(n) as main: input offsets (the gadgets' own signals are SmtProcOff / SmtVerOff)
+struct SmtProcInOff { uint32_t one, oldRoot, siblings, oldKey, oldValue, isOld0, newKey, newValue, fnc; };
+struct SmtVerInOff { uint32_t one, enabled, root, siblings, oldKey, oldValue, isOld0, key, value, fnc; };
 struct HashStateOff { uint32_t one, out, tokenID, nonce, sign, balance, ay, ethAddr; PoseidonOff hash; };
 
 // SHA-256 bit-level witness (circomlib sha256): per block, see sha256 section in DESIGN.md
@@ -549,6 +572,10 @@ struct Layout {
     HashInputsOff hi{};
     WithdrawOff wd{};
     GadIO gad{};
+    SmtProcOff smtp{};
+    SmtProcInOff smtpi{};
+    SmtVerOff smtv{};
+    SmtVerInOff smtvi{};
     int sec_tx = -1, sec_fee = -1, sec_glob = -1, sec_hi = -1;  // section indices
 
     // physical index of (section, sig, global unit = instance * upi + local unit)
@@ -1257,6 +1284,32 @@ inline void build_layout(const Params& p, Layout& lo) {
             w.sha.nblocks = 2; w.sha.block_size = SHA_BLOCK_SIGS;
             w.sha.blocks = T.add(h + "inputsHasher.sha256compression", 2 * SHA_BLOCK_SIGS);
             lo.outputs = {{"hashGlobalInputs", w.hashGlobalInputs}};
+            break;
+        }
+        case T_SMT_PROCESSOR: {   // circomlib smt/smtprocessor.circom: SMTProcessor(nLevels), n = nLevels levels
+            lo.sections.resize(1);
+            lo.sec_fee = 0;   // shares the fee-transaction scratch allocation (one SMTProcessor per unit)
+            Section& T = lo.sections[0]; T.tag = "smt-processor"; T.upi = 1;
+            SmtProcInOff& d = lo.smtpi;
+            d.one = T.add("main.one");
+            d.oldRoot = in1(T, 0, "oldRoot", 1, N, -1, true); d.siblings = in1(T, 0, "siblings", (uint32_t)L, N, -1, true);
+            d.oldKey = in1(T, 0, "oldKey", 1, N, -1, true); d.oldValue = in1(T, 0, "oldValue", 1, N, -1, true);
+            d.isOld0 = in1(T, 0, "isOld0", 1, N, -1, true); d.newKey = in1(T, 0, "newKey", 1, N, -1, true);
+            d.newValue = in1(T, 0, "newValue", 1, N, -1, true); d.fnc = in1(T, 0, "fnc", 2, N, -1, true);
+            lay_smtproc(T, "main.", L, false, lo.smtp);
+            lo.outputs = {{"newRoot", lo.smtp.newRoot}};
+            break;
+        }
+        case T_SMT_VERIFIER: {    // circomlib smt/smtverifier.circom: SMTVerifier(nLevels)
+            lo.sections.resize(1);
+            Section& T = lo.sections[0]; T.tag = "smt-verifier"; T.upi = 1;
+            SmtVerInOff& d = lo.smtvi;
+            d.one = T.add("main.one");
+            d.enabled = in1(T, 0, "enabled", 1, N, -1, true); d.root = in1(T, 0, "root", 1, N, -1, true);
+            d.siblings = in1(T, 0, "siblings", (uint32_t)L, N, -1, true); d.oldKey = in1(T, 0, "oldKey", 1, N, -1, true);
+            d.oldValue = in1(T, 0, "oldValue", 1, N, -1, true); d.isOld0 = in1(T, 0, "isOld0", 1, N, -1, true);
+            d.key = in1(T, 0, "key", 1, N, -1, true); d.value = in1(T, 0, "value", 1, N, -1, true); d.fnc = in1(T, 0, "fnc", 1, N, -1, true);
+            lay_smtver(T, "main.", L, lo.smtv);
             break;
         }
         case T_HASH_INPUTS: {

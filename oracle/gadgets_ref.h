@@ -213,6 +213,11 @@ struct SmtCids { int n2b_old, alias_old, n2b_new, alias_new, levins, sm_final, o
 F smt_processor(const W& w, const hzl::SmtProcOff& o, int n, const F& oldRoot, const F* siblings, const F& oldKey, const F& oldValue,
                 const F& isOld0, const F& newKey, const F& newValue, const F& fnc0, const F& fnc1, const SmtCids& c);
 
+// SMTVerifier(n) (circomlib smt/smtverifier.circom + smtverifierlevel, smtverifiersm), withdraw_ref.cpp
+struct SmtVerCids { int n2b_old, alias_old, n2b_new, alias_new, levins, sm_final, keys, root; };
+void smt_verifier(const W& w, const hzl::SmtVerOff& o, int n, const F& enabled, const F& root, const F* siblings, const F& oldKey,
+                  const F& oldValue, const F& isOld0, const F& key, const F& value, const F& fnc, const SmtVerCids& c);
+
 // writes the S-box signals of a Poseidon and returns the digest
 F poseidon_w(const W& w, hzl::PoseidonOff off, const F* in, int n_in);
 

@@ -270,6 +270,24 @@ static void run_instanced(OrcCtx* c) {
                 withdraw_main(w, lo.wd, L);
                 break;
             }
+            case T_SMT_PROCESSOR: {   // circomlib SMTProcessor(nLevels) as main: n = L levels
+                const SmtProcInOff& d = lo.smtpi;
+                std::vector<F> sib(L);
+                for (int k = 0; k < L; k++) sib[k] = in(d.siblings + k);
+                static const SmtCids cids{C_SMTP_N2B_OLD, C_SMTP_ALIAS_OLD, C_SMTP_N2B_NEW, C_SMTP_ALIAS_NEW, C_SMTP_LEVINS, C_SMTP_SM_FINAL, C_SMTP_OLDROOT, C_SMTP_KEYS};
+                smt_processor(w, lo.smtp, L, in(d.oldRoot), sib.data(), in(d.oldKey), in(d.oldValue), in(d.isOld0), in(d.newKey), in(d.newValue),
+                              in(d.fnc), in(d.fnc + 1), cids);
+                break;
+            }
+            case T_SMT_VERIFIER: {    // circomlib SMTVerifier(nLevels) as main
+                const SmtVerInOff& d = lo.smtvi;
+                std::vector<F> sib(L);
+                for (int k = 0; k < L; k++) sib[k] = in(d.siblings + k);
+                static const SmtVerCids cids{C_SMTV_N2B_OLD, C_SMTV_ALIAS_OLD, C_SMTV_N2B_NEW, C_SMTV_ALIAS_NEW, C_SMTV_LEVINS, C_SMTV_SM_FINAL, C_SMTV_KEYS, C_SMTV_ROOT};
+                smt_verifier(w, lo.smtv, L, in(d.enabled), in(d.root), sib.data(), in(d.oldKey), in(d.oldValue), in(d.isOld0), in(d.key), in(d.value),
+                             in(d.fnc), cids);
+                break;
+            }
         }
     }
 }

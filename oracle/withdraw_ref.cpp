@@ -6,15 +6,15 @@
 namespace orc {
 using namespace hzl;
 
-static void smt_verifier(const W& w, const SmtVerOff& o, int n, const F& enabled, const F& root, const F* siblings, const F& oldKey,
-                         const F& oldValue, const F& isOld0, const F& key, const F& value, const F& fnc) {
+void smt_verifier(const W& w, const SmtVerOff& o, int n, const F& enabled, const F& root, const F* siblings, const F& oldKey,
+                  const F& oldValue, const F& isOld0, const F& key, const F& value, const F& fnc, const SmtVerCids& c) {
     const F h1old = smt_hash1(w, o.hash1Old, oldKey, oldValue);
     const F h1new = smt_hash1(w, o.hash1New, key, value);
-    num2bits_strict(w, o.n2bOld, oldKey, C_WD_N2B_OLD, C_WD_N2B_OLD);
-    const std::vector<int> bNew = num2bits_strict(w, o.n2bNew, key, C_WD_N2B_NEW, C_WD_ALIAS_NEW);
+    num2bits_strict(w, o.n2bOld, oldKey, c.n2b_old, c.alias_old);
+    const std::vector<int> bNew = num2bits_strict(w, o.n2bNew, key, c.n2b_new, c.alias_new);
     std::vector<F> isz(n), levIns(n), done(n);
     for (int i = 0; i < n; i++) isz[i] = is_zero(w, o.isz + 2 * i, siblings[i]);
-    w.chk(C_WD_LEVINS, (isz[n - 1] - F(1)) * enabled, F(0));
+    w.chk(c.levins, (isz[n - 1] - F(1)) * enabled, F(0));
     levIns[n - 1] = F(1) - isz[n - 2];
     done[n - 2] = levIns[n - 1];
     for (int i = n - 2; i > 0; i--) {
@@ -37,7 +37,7 @@ static void smt_verifier(const W& w, const SmtVerOff& o, int n, const F& enabled
         w.set(o.sm + VSM_N * i + VSM_IOLD, st_iold[i]); w.set(o.sm + VSM_N * i + VSM_I0, st_i0[i]);
         p_top = st_top[i]; p_i0 = st_i0[i]; p_iold = st_iold[i]; p_inew = st_inew[i]; p_na = st_na[i];
     }
-    w.chk(C_WD_SM_FINAL, st_na[n - 1] + st_iold[n - 1] + st_inew[n - 1] + st_i0[n - 1], F(1));
+    w.chk(c.sm_final, st_na[n - 1] + st_iold[n - 1] + st_inew[n - 1] + st_i0[n - 1], F(1));
     F child(0);
     for (int i = n - 1; i >= 0; i--) {
         const uint32_t lv = o.levels + VL_SIZE * i;
@@ -55,8 +55,8 @@ static void smt_verifier(const W& w, const SmtVerOff& o, int n, const F& enabled
     // MultiAND(4)(fnc, 1-isOld0, keq, enabled): ands[0]=AND(in0,in1), ands[1]=AND(in2,in3), and2
     const F aa = fnc * (F(1) - isOld0), ab = keq * enabled, ac = aa * ab;
     w.set(o.and_a, aa); w.set(o.and_b, ab); w.set(o.and_c, ac);
-    w.chk(C_WD_KEYS, ac, F(0));
-    force_equal_if_enabled(w, o.checkRoot, enabled, child, root, C_WD_ROOT);
+    w.chk(c.keys, ac, F(0));
+    force_equal_if_enabled(w, o.checkRoot, enabled, child, root, c.root);
 }
 
 F withdraw_main(const W& w, const WithdrawOff& o, int L) {
@@ -68,7 +68,8 @@ F withdraw_main(const W& w, const WithdrawOff& o, int L) {
     const F e0 = tokenID + sign * pow2(72);
     F hin[4] = {e0, balance, ay, ethAddr};
     const F st = poseidon_w(w, o.accountState, hin, 4);
-    smt_verifier(w, o.ver, L + 1, F(1), rootExit, sib.data(), F(0), F(0), F(0), idx, st, F(0));
+    static const SmtVerCids cids{C_WD_N2B_OLD, C_WD_N2B_OLD, C_WD_N2B_NEW, C_WD_ALIAS_NEW, C_WD_LEVINS, C_WD_SM_FINAL, C_WD_KEYS, C_WD_ROOT};
+    smt_verifier(w, o.ver, L + 1, F(1), rootExit, sib.data(), F(0), F(0), F(0), idx, st, F(0), cids);
     // HashInputsWithdrawal (:84-176)
     const std::vector<int> bR = num2bits(w, o.n2bRootExit, rootExit, 256, C_WD_HI_N2B);
     const std::vector<int> bE = num2bits(w, o.n2bEthAddr, ethAddr, 160, C_WD_HI_N2B);
