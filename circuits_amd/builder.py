@@ -755,6 +755,26 @@ def withdraw_input(batch, idx, n_levels):
     return inp, int.from_bytes(hashlib.sha256(by).digest(), "big") % P
 
 
+class ExitTreeFixture:
+    """An exit tree built directly (what a batch of `n_leaves` exits leaves behind; reference test/withdraw.test.js:39-157 reaches it
+    through four exit transactions): exit_tree / exit_leaves as withdraw_input() reads them. device=N hashes the tree on GPU N."""
+
+    def __init__(self, n_leaves, seed=0x57495448, first_idx=256, n_keys=8, device=None, dag_evaluator=None):
+        import random
+        rng = random.Random(seed)
+        lazy = device is not None or dag_evaluator is not None
+        hasher = DagHasher(dag_evaluator or _device_dag_evaluator(device)) if lazy else host()
+        keys = [Account(seed * 1000 + i) for i in range(n_keys)]
+        self.exit_tree, self.exit_leaves = SMT(hasher), {}
+        for i in range(n_leaves):
+            a = keys[rng.randrange(n_keys)]
+            st = {"tokenID": rng.randrange(1, 1 << 32), "nonce": 0, "sign": a.sign, "balance": rng.randrange(1, 1 << 192), "ay": a.ay, "ethAddr": a.eth_addr}
+            self.exit_tree.insert(first_idx + i, hash_state(st, hasher))
+            self.exit_leaves[first_idx + i] = st
+        if lazy:
+            self.exit_tree.rekey(hasher.resolve())
+
+
 def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, dag_evaluator=None):
     """Seeded synthetic batch following reference tools/generate-input.js:61-109 and
     tools/helpers/gen-inputs-utils.js: pre-populated accounts (token 1), then one batch of `max_l1` L1

@@ -28,9 +28,14 @@ struct hz_ctx {
     std::vector<uint8_t> host_stage;
     hipStream_t last_stream = nullptr;
     // multi-GPU intra-batch shard (RollupMain): this context evaluates transactions [sh_first, sh_first + sh_count);
-    // sh_count = 0 means the whole batch. The fee transactions and HashInputs run only when sh_tail is set.
+    // only meaningful when `sharded`. The fee transactions and HashInputs of a sharded context run in hz_witness_enqueue_tail.
     uint32_t sh_first = 0, sh_count = 0;
+    bool sharded = false;   // hz_ctx_set_shard with count >= 0 (an empty range is a legal shard: more ranks than transactions)
     bool sh_tail = true;
+    // device-side input writes (hz_set_input_dev, hz_copy_instance_inputs, hz_inputs_upload) are asynchronous on the stream they were
+    // given; the next enqueue waits for this event on ITS stream, whichever that is
+    hipEvent_t ev_inputs = nullptr;
+    bool inputs_pending = false;
     // independent chains of one batch run concurrently: the EdDSA ladders and the fee transactions on
     // their own streams, joined by events before HashInputs (DESIGN.md "Kernel schedule")
     bool exclusive = false;   // hz_ctx_set_profiling(ctx, 2)
@@ -44,7 +49,7 @@ struct hz_ctx {
         if (s_fee) (void)hipStreamDestroy(s_fee);
         if (s_main) (void)hipStreamDestroy(s_main);
         if (s_fix) (void)hipStreamDestroy(s_fix);
-        for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee, ev_fix, ev_user_in, ev_user_out})
+        for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee, ev_fix, ev_user_in, ev_user_out, ev_inputs})
             if (e) (void)hipEventDestroy(e);
         for (auto& p : prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     }
@@ -130,6 +135,13 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     if ((lp.tmpl == T_ROLLUP_MAIN || lp.tmpl == T_HASH_INPUTS) && (lp.nTx < 1 || lp.F < 1 || lp.maxL1 < 0))
         return set_err(HZ_ERR_ARG, "RollupMain/HashInputs need nTx >= 1, maxFeeTx >= 1");
     if (lp.tmpl == T_ROLLUP_TX && lp.F < 1) return set_err(HZ_ERR_ARG, "RollupTx needs maxFeeTx >= 1");
+    if (lp.tmpl == T_ROLLUP_MAIN && lp.maxL1 > lp.nTx) return set_err(HZ_ERR_ARG, "RollupMain: maxL1Tx (%d) > nTx (%d) cannot be instantiated", lp.maxL1, lp.nTx);
+    {
+        // the failure key holds instance and unit in 24 bits each; unit counts are 32-bit
+        const uint64_t upi = (lp.tmpl == T_ROLLUP_MAIN || lp.tmpl == T_HASH_INPUTS) ? (uint64_t)std::max(lp.nTx, lp.F) : 1;
+        if ((uint64_t)lp.n_inst >= (1u << 24) || upi >= (1u << 24) || (uint64_t)lp.n_inst * upi >= (1ull << 31))
+            return set_err(HZ_ERR_ARG, "hz_ctx_create: n_instances (%d) x units per instance (%llu) out of range", lp.n_inst, (unsigned long long)upi);
+    }
     if (hz_device_count() <= 0) return set_err(HZ_ERR_NODEVICE, "no usable gfx950 device");
     if (p->device < 0 || p->device >= hz_device_count()) return set_err(HZ_ERR_ARG, "bad device ordinal %d", p->device);
     hz_ctx* c = new hz_ctx();
@@ -172,7 +184,7 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         if (e == hipSuccess) e = make_stream(&c->s_fee, ncu * 3 / 8, ncu / 2);       // fee-transaction chain
         if (e == hipSuccess) e = make_stream(&c->s_main, ncu / 2, ncu);              // front, hash-state, SMT chains, HashInputs
     }
-    for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix, &c->ev_user_in, &c->ev_user_out})
+    for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix, &c->ev_user_in, &c->ev_user_out, &c->ev_inputs})
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete c;
@@ -263,6 +275,7 @@ static hz_status set_input_common(hz_ctx* c, int32_t instance, const char* name,
                                    hipMemcpyHostToDevice));
         }
     } else {
+        if (!stream) stream = c->s_main;   // never the legacy default stream (hermez_witness.h "streams")
         for (uint32_t b = b0; b < b1; b++) {
             const uint8_t* src = (const uint8_t*)dev + (size_t)(b - b0) * per * 32;
             uint8_t* dst = dst0 + (size_t)b * s.upi * 32;
@@ -275,6 +288,8 @@ static hz_status set_input_common(hz_ctx* c, int32_t instance, const char* name,
                 HZ_HIP(hipGetLastError());
             }
         }
+        HZ_HIP(hipEventRecord(c->ev_inputs, stream));
+        c->inputs_pending = true;
     }
     c->input_set[d - &lo.inputs[0]] = 1;
     return HZ_OK;
@@ -296,13 +311,16 @@ extern "C" hz_status hz_copy_instance_inputs(hz_ctx* c, int32_t src, int32_t dst
         return set_err(HZ_ERR_ARG, "hz_copy_instance_inputs: instance out of range (n_instances = %u)", lo.n_inst);
     if (src == dst) return HZ_OK;
     HZ_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
     for (const InputDesc& d : lo.inputs) {
         const Section& s = lo.sections[d.section];
         uint8_t* base = sec_ptr(c, d.section) + (size_t)d.off * s.n_units * 32;
         const size_t pitch = (size_t)s.n_units * 32;
         HZ_HIP(hipMemcpy2DAsync(base + (size_t)dst * s.upi * 32, pitch, base + (size_t)src * s.upi * 32, pitch, (size_t)d.outer * 32, d.inner,
-                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
+                                hipMemcpyDeviceToDevice, st));
     }
+    HZ_HIP(hipEventRecord(c->ev_inputs, st));
+    c->inputs_pending = true;
     return HZ_OK;
 }
 
@@ -479,6 +497,10 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
     // the legacy default stream has implicit-synchronisation semantics that do not mix with the
     // context's non-blocking side streams: a NULL stream means "the context's own stream"
     hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    if (c->inputs_pending) {
+        HZ_HIP(hipStreamWaitEvent(s, c->ev_inputs, 0));
+        c->inputs_pending = false;
+    }
     // partitioned contexts run their main sequence on the CU-masked stream, ordered after / before the caller's stream by two events
     hipStream_t s_user = s;
     if (c->partitioned && s != c->s_main) {
@@ -510,7 +532,8 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             fa.scratch = (Fr*)c->sc_tx.p; fa.err = err; fa.nTx = (uint32_t)lo.p.nTx; fa.L = (uint32_t)lo.p.L; fa.F = (uint32_t)lo.p.F; fa.B = lo.n_inst;
             fa.g = lo.g; fa.mi = lo.mi; fa.fi = lo.fi; fa.dec = lo.dec; fa.rtx = lo.rtx;
             hz_status st = HZ_OK;
-            const bool tail_now = c->sh_tail && c->sh_count == 0;   // sharded contexts run the tail separately (hz_witness_enqueue_tail)
+            const bool tail_now = !c->sharded;   // sharded contexts run the tail separately (hz_witness_enqueue_tail)
+            if (c->sharded && c->sh_count == 0) break;   // an empty shard (more ranks than transactions): nothing to evaluate
             if (tail_now) {
                 HZ_HIP(hipStreamWaitEvent(c->s_fee, c->ev_reset, 0));
                 st = enqueue_fee(c, fa.fee_base, lo.sections[lo.sec_fee].n_units, true, c->s_fee);   // independent of the transactions
@@ -663,7 +686,12 @@ extern "C" hz_status hz_witness_check(hz_ctx* c, hz_error* out) {
 extern "C" hz_status hz_ctx_set_shard(hz_ctx* c, int32_t first, int32_t count, int32_t tail) {
     if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN) return set_err(HZ_ERR_ARG, "hz_ctx_set_shard: RollupMain contexts only");
     if (c->lo.n_inst != 1) return set_err(HZ_ERR_ARG, "hz_ctx_set_shard: one batch per context when sharding");
-    if (first < 0 || count < 0 || first + count > c->lo.p.nTx) return set_err(HZ_ERR_ARG, "hz_ctx_set_shard: bad range");
+    if (count < 0) {   // back to the whole batch
+        c->sharded = false; c->sh_first = c->sh_count = 0; c->sh_tail = true;
+        return HZ_OK;
+    }
+    if (first < 0 || first > c->lo.p.nTx || count > c->lo.p.nTx - first) return set_err(HZ_ERR_ARG, "hz_ctx_set_shard: bad range");
+    c->sharded = true;
     c->sh_first = (uint32_t)first;
     c->sh_count = (uint32_t)count;
     c->sh_tail = tail != 0;
@@ -684,12 +712,12 @@ extern "C" hz_status hz_da_export(hz_ctx* c, void* d_buf, void* stream) {
     if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN || !d_buf) return set_err(HZ_ERR_ARG, "hz_da_export: bad argument");
     HZ_HIP(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
-    const uint32_t cnt = c->sh_count ? c->sh_count : (uint32_t)c->lo.p.nTx;
+    const uint32_t cnt = c->sharded ? c->sh_count : (uint32_t)c->lo.p.nTx;
     HZ_HIP(launch_da_export(make_da(c, c->sh_first, cnt, d_buf), s));
     return HZ_OK;
 }
 extern "C" hz_status hz_da_import(hz_ctx* c, int32_t first, int32_t count, const void* d_buf, void* stream) {
-    if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN || !d_buf || first < 0 || count < 0 || first + count > c->lo.p.nTx)
+    if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN || !d_buf || first < 0 || count < 0 || first > c->lo.p.nTx || count > c->lo.p.nTx - first)
         return set_err(HZ_ERR_ARG, "hz_da_import: bad argument");
     HZ_HIP(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
@@ -755,7 +783,7 @@ __global__ void k_gather_virtual(const GatherArgs a) {
 extern "C" hz_status hz_witness_read(hz_ctx* c, int32_t instance, uint64_t first, uint64_t count, uint8_t* out) {
     if (!c || !out) return set_err(HZ_ERR_ARG, "hz_witness_read: null argument");
     const Layout& lo = c->lo;
-    if (first + count > lo.per_instance) return set_err(HZ_ERR_ARG, "hz_witness_read: range beyond the witness");
+    if (first > lo.per_instance || count > lo.per_instance - first) return set_err(HZ_ERR_ARG, "hz_witness_read: range beyond the witness");
     if (instance < 0 || (uint32_t)instance >= lo.n_inst) return set_err(HZ_ERR_ARG, "hz_witness_read: bad instance");
     HZ_HIP(hipSetDevice(c->device));
     if (count == 0) return HZ_OK;
@@ -784,7 +812,7 @@ extern "C" hz_status hz_witness_read(hz_ctx* c, int32_t instance, uint64_t first
 // raw physical view (signal-major), for bulk consumers and tests
 extern "C" hz_status hz_witness_read_raw(hz_ctx* c, uint64_t first, uint64_t count, uint8_t* out) {
     if (!c || !out) return set_err(HZ_ERR_ARG, "hz_witness_read_raw: null argument");
-    if (first + count > c->lo.total) return set_err(HZ_ERR_ARG, "hz_witness_read_raw: range beyond the buffer");
+    if (first > c->lo.total || count > c->lo.total - first) return set_err(HZ_ERR_ARG, "hz_witness_read_raw: range beyond the buffer");
     HZ_HIP(hipSetDevice(c->device));
     if (count) HZ_HIP(hipMemcpy(out, (const uint8_t*)c->wit.p + first * 32, count * 32, hipMemcpyDeviceToHost));
     return HZ_OK;

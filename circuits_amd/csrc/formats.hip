@@ -107,6 +107,7 @@ struct JsonIn {
     const char* p;
     const char* e;
     std::string err;
+    int depth = 0;   // nesting of arrays: a signal has at most a few dimensions; hostile input must not overflow the stack
     void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
     bool fail(const char* m) { if (err.empty()) err = m; return false; }
     bool string(std::string& out) {
@@ -126,22 +127,24 @@ struct JsonIn {
         ws();
         if (p >= e) return fail("unexpected end of input");
         if (*p == '[') {
+            if (depth >= 16) return fail("arrays nested deeper than 16 levels");
             p++;
             ws();
             if (p < e && *p == ']') { p++; return true; }
+            depth++;
             for (;;) {
                 if (!value(vals)) return false;
                 ws();
                 if (p < e && *p == ',') { p++; continue; }
-                if (p < e && *p == ']') { p++; return true; }
+                if (p < e && *p == ']') { p++; depth--; return true; }
                 return fail("expected , or ] in array");
             }
         }
         std::string tok;
         if (*p == '"') {
             if (!string(tok)) return false;
-        } else if (!strncmp(p, "true", 4)) { tok = "1"; p += 4;
-        } else if (!strncmp(p, "false", 5)) { tok = "0"; p += 5;
+        } else if (e - p >= 4 && !memcmp(p, "true", 4)) { tok = "1"; p += 4;
+        } else if (e - p >= 5 && !memcmp(p, "false", 5)) { tok = "0"; p += 5;
         } else {
             const char* s = p;
             while (p < e && (*p == '-' || *p == '+' || (*p >= '0' && *p <= '9') || *p == 'x' || *p == 'X' || (*p >= 'a' && *p <= 'f') || (*p >= 'A' && *p <= 'F'))) p++;
@@ -210,6 +213,7 @@ extern "C" hz_status hz_witness_write_wtns(hz_ctx* ctx, int32_t instance, const 
         if (st != HZ_OK) { fclose(f); return st; }
         if (fwrite(buf.data(), 32, c, f) != c) { fclose(f); return set_err(HZ_ERR_ARG, "short write to %s", path); }
     }
+    if (ferror(f)) { fclose(f); return set_err(HZ_ERR_ARG, "write to %s failed", path); }
     if (fclose(f) != 0) return set_err(HZ_ERR_ARG, "close of %s failed", path);
     return HZ_OK;
 }
@@ -235,6 +239,7 @@ extern "C" hz_status hz_witness_write_json(hz_ctx* ctx, int32_t instance, const 
         fwrite(line.data(), 1, line.size(), f);
     }
     fputs("]\n", f);
+    if (ferror(f)) { fclose(f); return set_err(HZ_ERR_ARG, "write to %s failed", path); }
     if (fclose(f) != 0) return set_err(HZ_ERR_ARG, "close of %s failed", path);
     return HZ_OK;
 }
@@ -251,6 +256,7 @@ extern "C" hz_status hz_symbols_write_sym(const hz_ctx* ctx, const char* path) {
         // every stored signal is its own variable: label index = variable index; component ids are not modelled
         fprintf(f, "%llu,%llu,0,%s\n", (unsigned long long)s.index, (unsigned long long)s.index, s.name);
     }
+    if (ferror(f)) { fclose(f); return set_err(HZ_ERR_ARG, "write to %s failed", path); }
     if (fclose(f) != 0) return set_err(HZ_ERR_ARG, "close of %s failed", path);
     return HZ_OK;
 }

@@ -33,7 +33,12 @@ class ShardedBatch:
         self.recv = alloc(self.slot * world)
         ctx.set_shard(self.first, self.count, rank == 0)
 
-    def step(self, stream=None):
+    def step(self, stream):
+        """One sharded pass on HIP stream `stream` (a hipStream_t handle, required): export, collective, imports and the tail
+        are ordered by that stream, so `all_gather` must enqueue the collective on it too (bench.py: `with torch.cuda.stream(s)`),
+        or block until `send` is complete and `recv` filled."""
+        if not stream:
+            raise ValueError("ShardedBatch.step needs an explicit stream: the collective has to be ordered with the export/import kernels")
         c = self.ctx
         c.enqueue(stream)                       # this rank's transactions
         c.da_export(self.send.data_ptr(), stream)

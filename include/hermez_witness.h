@@ -24,6 +24,13 @@
  * exceptions cross the ABI. A context is used by one thread at a time.
  * There is NO CPU fallback: every entry point that computes returns HZ_ERR_NODEVICE when no
  * gfx950 device is usable.
+ *
+ * Streams. Every `void* stream` argument is a hipStream_t. NULL never means HIP's legacy default stream: it means the
+ * context's own non-blocking stream, in every entry point alike. Asynchronous input writes (hz_set_input_dev,
+ * hz_copy_instance_inputs, hz_inputs_upload) are ordered before the next hz_witness_enqueue / hz_witness_run of the same
+ * context on whatever stream that call uses (an event, no host synchronisation). Everything else follows stream order:
+ * hz_da_export / hz_da_import / hz_witness_enqueue_tail must be given the stream of the hz_witness_enqueue they follow, and a
+ * collective between them must be ordered on that stream by the caller.
  */
 #ifndef HERMEZ_WITNESS_H
 #define HERMEZ_WITNESS_H
@@ -205,7 +212,8 @@ hz_status hz_fr_ops(int32_t device, int32_t op, size_t n, const uint8_t* a, cons
  * independent given the im* inputs). A RollupMain batch is sharded by transaction index:
  *   hz_shard_range      contiguous range of a rank
  *   hz_ctx_set_shard    this context evaluates only [first, first+count); tail != 0 on the rank that
- *                       also evaluates the fee transactions and HashInputs
+ *                       also evaluates the fee transactions and HashInputs. count = 0 is a legal (empty) shard -- more
+ *                       ranks than transactions --, count < 0 returns the context to the whole batch
  *   hz_da_export        pack the shard's per-transaction data-availability records (hz_da_record_bytes
  *                       each: L1TxFullData / L1L2TxData bits, outIdx, newExitRoot) into a device buffer --
  *                       the only data HashInputs needs from other ranks (one RCCL all_gather, ~47-330 KB)

@@ -98,7 +98,7 @@ def _worker(rank, world, port, n_tx, out):
 
     sb = ShardedBatch(ctx, lib(), n_tx, rank, world, alloc, all_gather)
     ctx.send, ctx.recv = sb.send, sb.recv
-    sb.step()
+    sb.step(1)   # the fake context ignores the stream handle
     ok = ctx.log[0] == "enqueue" and ctx.log[1] == "export" and ctx.log[-1] == "check"
     if rank == 0:
         ok = ok and ctx.log[-2] == "tail" and len(ctx.imported) == n_tx - sb.count and ctx.tail
@@ -141,15 +141,17 @@ def test_sharded_batch_on_one_gpu_matches_oracle(hz):
         return torch.zeros(n, dtype=torch.uint8, device="cuda")
 
     sbs = []
+    streams = [torch.cuda.Stream() for _ in range(world)]
     for r in range(world):
         def all_gather(recv, send, r=r):
-            torch.cuda.synchronize()
-            mailbox[r] = send.clone()
-            if r == 0:  # rank 0 runs last in this single-process stand-in: every send is in the mailbox
-                recv.copy_(torch.cat([mailbox[k] for k in range(world)]))
+            with torch.cuda.stream(streams[r]):   # ordered with the export / import kernels of this "rank"
+                mailbox[r] = send.clone()
+                if r == 0:  # rank 0 runs last in this single-process stand-in: every send is in the mailbox
+                    streams[0].wait_stream(streams[1])
+                    recv.copy_(torch.cat([mailbox[k] for k in range(world)]))
         sbs.append(ShardedBatch(ctxs[r], hz, n_tx, r, world, alloc, all_gather))
     for r in (1, 0):
-        sbs[r].step()
+        sbs[r].step(streams[r].cuda_stream)
     assert ctxs[0].get("main.hashGlobalInputs") == bb.get_hash_inputs()
     o = OracleCtx("rollup-main", n_tx, 16, 3, 4)
     o.set_inputs(inp)

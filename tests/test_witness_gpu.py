@@ -105,6 +105,39 @@ def test_withdraw_bit_exact(hz, batch):
         assert g.get("main.hashGlobalInputs", k) == exp
 
 
+def test_withdraw_config5_at_size(hz):
+    """BASELINE config 5 at its stated shape: Withdraw(nLevels = 32), 4 160 instances = 65 wavefronts with a ragged tail, exits drawn
+    from an exit tree of 2^12 leaves (hashed on the device, f1), whole buffer vs the oracle; every instance's hashGlobalInputs vs
+    hashlib over the builder's own bit packing (reference src/withdraw.circom:21-176, test/withdraw.test.js:150)."""
+    from circuits_amd import builder as B
+    fx = B.ExitTreeFixture(1 << 12, device=0)
+    host_fx = B.ExitTreeFixture(64)   # the device-hashed tree construction agrees with host hashing
+    dev_fx = B.ExitTreeFixture(64, device=0)
+    assert host_fx.exit_tree.root == dev_fx.exit_tree.root
+    n = 4160
+    idxs = sorted(fx.exit_leaves)
+    g = hz.ctx("withdraw", nLevels=32, n_instances=n)
+    o = OracleCtx("withdraw", nLevels=32, n_instances=n)
+    ins = [B.withdraw_input(fx, idxs[(k * 37) % len(idxs)], 32) for k in range(n)]
+    for name, _ in g.input_names():
+        rows = [ins[k][0][name] for k in range(n)]
+        g.set_input(name, rows, instance=-1)
+        for k in range(n):
+            o.set_input(name, rows[k], instance=k)
+    g.run()
+    assert o.run() is None
+    _compare_chunked(g, o)   # 4 160 x 2.2 MB
+    got = g.read_raw_bytes(g.lookup("main.hashGlobalInputs") * n, n)
+    assert [int.from_bytes(got[32 * k:32 * k + 32], "little") for k in range(n)] == [ins[k][1] for k in range(n)]
+    # a wrong balance in the last (ragged) wavefront is reported for exactly that instance (test/withdraw.test.js:159-171)
+    from circuits_amd import ConstraintError
+    bad = dict(ins[n - 3][0], balance=ins[n - 3][0]["balance"] + 1)
+    g.set_inputs(bad, instance=n - 3)
+    with pytest.raises(ConstraintError) as e:
+        g.run()
+    assert e.value.instance == n - 3 and e.value.name == "withdraw.smtVerify.checkRoot" and (e.value.lhs, e.value.rhs) == (1, 0)
+
+
 def test_constraint_failures_match_oracle(hz, batch):
     from circuits_amd import ConstraintError
     inp = dict(batch.get_input())
