@@ -3,19 +3,27 @@
 
 A "step" is one complete witness pass of RollupMain(nTx, nLevels, maxL1Tx, maxFeeTx) over
 `--batches-per-launch` independent synthetic batches (one context, one set of kernel launches; the
-value counts every transaction of every batch) whose inputs are already resident in HBM: DecodeTx + RollupTx for every
-transaction, the fee transactions and HashInputs (SHA-256), every constraint checked. Steps are
-issued round-robin over `--inflight` contexts/streams (independent batches in flight, SURVEY 8d);
-the timed region is bracketed by barrier + device synchronisation and includes the constraint
-check of every step.
+value counts every transaction of every batch): DecodeTx + RollupTx for every transaction, the fee
+transactions and HashInputs (SHA-256), every constraint checked. Steps are issued round-robin over
+`--inflight` contexts/streams (independent batches in flight); the timed region is
+bracketed by barrier + device synchronisation and includes the constraint check of every step.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): every rank runs its own batches
--- batch-level data parallelism, no data-path collective (DESIGN.md "Multi-GPU") -- and the value
-is all ranks' transactions over the max-over-ranks time ("scaling": "weak").
+Every instance of every context holds a DIFFERENT seeded batch (circuits_amd/batchgen.py builds them on the host cores before the
+timed region). `value` is measured with the inputs resident in HBM; `value_e2e` repeats the run with every batch's packed inputs
+uploaded from pinned host memory inside the timed region (hz_inputs_upload: the boundary the reference's calculateWitness(input)
+really has, test/helpers/helpers.js:147-149).
+
+`--gpus N` with N > 1 launches N ranks itself (torch.distributed.run, one process per GPU over RCCL) unless it already runs
+under a launcher: every rank runs its own batches -- batch-level data parallelism, no data-path collective (DESIGN.md
+"Multi-GPU") -- and the value is all ranks' transactions over the max-over-ranks time ("scaling": "weak"); the same line carries
+BASELINE config 4, ONE batch sharded by transaction index with its single all_gather, as `shard_tx` (strong scaling).
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +34,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DTYPE = "u32x9 (254-bit Montgomery Fr, 29-bit limbs, integer)"
+SEED = 0x48455A31
 
 
 def algorithmic_bytes_per_tx(L, F):
@@ -34,9 +44,54 @@ def algorithmic_bytes_per_tx(L, F):
     return 32 * ((4 * L + 1473) + (974 * L + 14552 + 5 * F)) + packed
 
 
+class Dist:
+    """rank / world / collectives for timing; backend "nccl" (= RCCL) unless the test hook asks for gloo"""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("HZ_BENCH_BACKEND", "nccl")
+        if "HZ_BENCH_DEVICE" in os.environ:   # test hook: several ranks on one GPU (with HZ_BENCH_BACKEND=gloo)
+            self.local = int(os.environ["HZ_BENCH_DEVICE"])
+        import torch
+        self.torch = torch
+        torch.cuda.set_device(self.local)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(self.backend)
+            self.dist = dist
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.backend == "gloo" else "cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn):
+        """fn() bracketed by barrier + device synchronisation on both sides; max over ranks, seconds"""
+        self.barrier()
+        t0 = time.perf_counter()
+        fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
 def poseidon_rates(L, torch):
     """BASELINE.json's second metric, Poseidon-BN254/sec: 2^20 permutations per launch, digest-only and with the
-    S-box witness (the circuit's Poseidon signals), HIP events on the launch stream."""
+    S-box witness (the circuit's Poseidon signals), HIP events on the launch stream. With the witness the kernel is an
+    HBM-store stream: its roofline is reported against the same peak."""
     out = {}
     n = 1 << 20
     s = torch.cuda.current_stream().cuda_stream
@@ -59,18 +114,22 @@ def poseidon_rates(L, torch):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 3
             by = n * (32 * (t - 1) + 32 + (96 * nsbox if wit else 0))
-            out["t%d_%s" % (t, mode)] = {"perm_per_s": round(n / ms * 1e3, 0), "GBs": round(by / ms / 1e6, 1)}
+            r = {"perm_per_s": round(n / ms * 1e3, 0), "GBs": round(by / ms / 1e6, 1), "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": by}
+            if wit:
+                r["roofline"] = {"bound": "hbm", "kernel": "poseidon_batch_kernel<%d, witness>" % t, "achieved": r["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 5), "traffic": measured_traffic("poseidon_t%d_witness" % t, None)}
+            out["t%d_%s" % (t, mode)] = r
         del d_in, d_out, d_wit
     return out
 
 
 def measured_traffic(kernel, bpl):
     """HBM bytes of one launch of `kernel` (mean over its launches of the transaction grid) from the committed rocprofv3 PMC passes
-    (profiles/r01_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
+    (profiles/r02_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
     this configuration."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")))
-        if d.get("batches_per_launch") != bpl:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_counters.json")))
+        if bpl is not None and d.get("batches_per_launch") != bpl:
             return None
         k = d["kernels"][kernel]
         if "fetch_bytes_mean" in k:   # per launch like `achieved`: mean over the kernel's launches of the transaction grid
@@ -83,7 +142,6 @@ def measured_traffic(kernel, bpl):
 def cpu_baseline(n_tx, L, max_l1, F, workers):
     """The CPU oracle (restated CPU path, kind "port") on a bounded sample of the same workload: `workers` processes, one batch
     of `n_tx` transactions each, started together (tests/cpu_baseline_worker.py); value = all their transactions / the slowest run."""
-    import subprocess
     script = os.path.join(ROOT, "tests", "cpu_baseline_worker.py")
     start = time.time() + 6.0 + 0.012 * n_tx   # every worker has built its batch by then
     procs = [subprocess.Popen([sys.executable, script, str(n_tx), str(L), str(max_l1), str(F), repr(start)], stdout=subprocess.PIPE, text=True)
@@ -100,136 +158,138 @@ def cpu_baseline(n_tx, L, max_l1, F, workers):
                       % (n_tx, L, max_l1, F, workers, dt, os.cpu_count() or 0)}
 
 
-def bench_sharded(args, L, bb, inp, rank, world, local, n_l2):
-    """One batch sharded by transaction index over `world` GPUs (circuits_amd/multigpu.py)."""
-    import torch
-    import torch.distributed as dist
+def bench_sharded(args, L, D, packed, expected):
+    """BASELINE config 4: ONE batch sharded by transaction index over the ranks (circuits_amd/multigpu.py): one all_gather of the
+    160-byte data-availability records, FeeTx + HashInputs on rank 0. Returns the result object (rank 0) or None."""
+    torch = D.torch
     from circuits_amd.multigpu import ShardedBatch
     nTx, lv, m1, F = args.nTx, args.nLevels, args.maxL1Tx, args.maxFeeTx
-    c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local)
-    c.set_inputs(inp)
-    stream = torch.cuda.Stream(device=local)
+    c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=D.local)
+    c.upload(0, packed)   # the same batch on every rank (same seed)
+    stream = torch.cuda.Stream(device=D.local)
 
     def alloc(n):
         return torch.zeros(n, dtype=torch.uint8, device="cuda")
 
     def all_gather(recv, send):
-        if world == 1:
-            recv.copy_(send)
-            return
-        with torch.cuda.stream(stream):
-            dist.all_gather_into_tensor(recv, send)
+        if D.world == 1:
+            with torch.cuda.stream(stream):
+                recv.copy_(send)
+        elif D.backend == "gloo":   # test hook (CPU collectives): through the host, blocking -- "send complete, recv filled" on return
+            stream.synchronize()
+            h = send.cpu()
+            parts = [torch.empty_like(h) for _ in range(D.world)]
+            D.dist.all_gather(parts, h)
+            recv.copy_(torch.cat(parts))
+            torch.cuda.synchronize()
+        else:
+            with torch.cuda.stream(stream):   # RCCL enqueues on the current stream: ordered with the export / import kernels
+                D.dist.all_gather_into_tensor(recv, send)
 
-    sb = ShardedBatch(c, L, nTx, rank, world, alloc, all_gather)
+    sb = ShardedBatch(c, L, nTx, D.rank, D.world, alloc, all_gather)
     sb.step(stream.cuda_stream)
-    if rank == 0 and not args.no_verify:
-        assert c.get("main.hashGlobalInputs") == bb.get_hash_inputs(), "hashGlobalInputs mismatch"
-    for _ in range(args.warmup):
+    if D.rank == 0 and not args.no_verify:
+        assert c.get("main.hashGlobalInputs") == expected, "hashGlobalInputs mismatch (sharded)"
+    for _ in range(max(1, args.warmup)):
         sb.step(stream.cuda_stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sb.step(stream.cuda_stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        value = nTx * args.steps / dt
+    steps = max(4, args.steps)
+    dt = D.timed(lambda: [sb.step(stream.cuda_stream) for _ in range(steps)])
+    res = None
+    if D.rank == 0:
         abytes = algorithmic_bytes_per_tx(lv, F) * nTx
-        print(json.dumps({
-            "metric": "rollup-main tx-witnesses/sec (nTx=%d, nLevels=%d)" % (nTx, lv), "value": round(value, 1), "unit": "tx-witnesses/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x9 (254-bit Montgomery Fr, 29-bit limbs, integer)",
-            "data": "synthetic",
-            "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "parallelism": "tx-shard%d" % world,
-                       "collective": "one all_gather of %d B per step" % (sb.slot * world), "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2},
-            "roofline": {"bound": "hbm", "kernel": "whole sharded pass", "achieved": round(abytes / (dt / args.steps) / 1e9, 2), "peak": HBM_PEAK_GBS * world,
-                         "unit": "GB/s", "frac": round(abytes / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 5), "traffic": None}}))
-    if world > 1:
-        dist.destroy_process_group()
+        res = {"value": round(nTx * steps / dt, 1), "unit": "tx-witnesses/s", "scaling": "strong", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+               "parallelism": "tx-shard%d" % D.world, "collective": "one all_gather of %d B per step (%s)" % (sb.slot * D.world, D.backend),
+               "transactions_per_rank": sb.count,
+               "whole_pass_GBs": round(abytes / (dt / steps) / 1e9, 2)}
+    del sb, c
+    return res
 
 
-def bench_withdraw(args, L, rank, world, local):
+def bench_withdraw(args, L, D, launches=None, steps=None):
     """BASELINE config 5: 2^20 independent Withdraw(nLevels) witnesses (SMTVerifier + HashState + 2-block SHA-256 bit witness),
-    `--withdraw-per-launch` instances per kernel launch, exits drawn from one exit tree. One lane per witness."""
-    import torch
-    import torch.distributed as dist
+    `--withdraw-per-launch` instances per kernel launch, exits drawn from one exit tree of `--withdraw-leaves` leaves (hashed on
+    the device). One lane per witness. Returns the result object (rank 0)."""
+    torch = D.torch
     from circuits_amd import builder as B
     lv = args.nLevels
-    n_leaves = 256
-    db = B.RollupDB(chain_id=1)
-    keys = [B.Account(900 + i) for i in range(8)]
-    nTx = 2 * n_leaves
-    bb = db.build_batch(nTx, lv, n_leaves, 1)
-    for i in range(n_leaves):
-        a = keys[i % 8]
-        bb.add_tx({"fromIdx": 0, "loadAmountF": B.fix2float(1000 + i), "tokenID": 1, "fromBjjCompressed": a.bjj_compressed, "fromEthAddr": a.eth_addr, "toIdx": 0, "onChain": 1})
-    bb.build()
-    bb2 = db.build_batch(nTx, lv, n_leaves, 1)
-    for i in range(n_leaves):
-        bb2.add_tx({"fromIdx": 256 + i, "toIdx": 1, "amount": 10 + i, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": keys[i % 8]})
-    bb2.build()
-    ins = [B.withdraw_input(bb2, 256 + i, lv) for i in range(n_leaves)]
+    n_leaves = args.withdraw_leaves
+    fx = B.ExitTreeFixture(n_leaves, device=D.local)
+    idxs = sorted(fx.exit_leaves)
     N = args.withdraw_per_launch
     free_b, _ = torch.cuda.mem_get_info()
-    probe = L.ctx("withdraw", nLevels=lv, device=local, n_instances=1)
+    probe = L.ctx("withdraw", nLevels=lv, device=D.local, n_instances=1)
     wl = probe.witness_len()
+    names = [n for n, _ in probe.input_names()]
     del probe
     N = max(64, min(N, int((free_b - (6 << 30)) // (wl * 32 * 1.02)) // 64 * 64))
-    c = L.ctx("withdraw", nLevels=lv, device=local, n_instances=N)
-    names = [n for n, _ in c.input_names()]
+    c = L.ctx("withdraw", nLevels=lv, device=D.local, n_instances=N)
+    # every instance withdraws a different leaf when the tree has that many (instance k -> leaf k * 40503 mod n_leaves: scattered)
+    pick = [idxs[(k * 40503) % n_leaves] for k in range(N)]
+    uniq = {}
+    for i in set(pick):
+        uniq[i] = B.withdraw_input(fx, i, lv)
     for name in names:
-        rows = [ins[k % n_leaves][0][name] for k in range(N)]
-        c.set_input(name, rows, instance=-1)
-    stream = torch.cuda.Stream(device=local)
-    c.set_profiling(True)
+        c.set_input(name, [uniq[i][0][name] for i in pick], instance=-1)
+    stream = torch.cuda.Stream(device=D.local)
     c.enqueue(stream.cuda_stream)
     c.check()
-    for k in (0, N - 1):
-        assert c.get("main.hashGlobalInputs", k) == ins[k % n_leaves][1], "hashGlobalInputs mismatch"
-    c.set_profiling(False)
-    launches = max(1, (args.withdraw_total + N - 1) // N)
-    for _ in range(args.warmup):
+    for k in (0, N // 2 + 1, N - 1):
+        assert c.get("main.hashGlobalInputs", k) == uniq[pick[k]][1], "hashGlobalInputs mismatch (withdraw)"
+    launches = launches or max(1, (args.withdraw_total + N - 1) // N)
+    steps = steps or args.steps
+    for _ in range(max(1, args.warmup)):
         c.enqueue(stream.cuda_stream)
         c.check()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        for _ in range(launches):
-            c.enqueue(stream.cuda_stream)
+
+    def run():
+        for _ in range(steps):
+            for _ in range(launches):
+                c.enqueue(stream.cuda_stream)
+            c.check()
+
+    dt = D.timed(run)
+    # each kernel alone on the device (HIP events on its stream): the per-kernel rooflines
+    c.set_profiling(True, exclusive=True)
+    acc = {}
+    for _ in range(3):
+        c.enqueue(stream.cuda_stream)
         c.check()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        total = launches * N * args.steps * world
+        for name, ms, by, units in c.profile():
+            a = acc.setdefault(name, [0.0, by])
+            a[0] += ms / 3
+    c.set_profiling(False)
+    res = None
+    if D.rank == 0:
+        total = launches * N * steps * D.world
         abytes = wl * 32 * N
-        ms_kernel = dt / (args.steps * launches) * 1e3   # the two kernels of a launch run concurrently: wall time per launch
-        print(json.dumps({
-            "metric": "withdraw witnesses/sec (nLevels=%d)" % lv, "value": round(total / dt, 1), "unit": "witnesses/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x9 (254-bit Montgomery Fr, 29-bit limbs, integer)", "data": "synthetic",
-            "config": {"workload": "withdraw nLevels=%d, %d witnesses per step in %d launches of %d" % (lv, launches * N, launches, N),
-                       "witness_elements": wl, "distinct_exit_leaves": n_leaves},
-            "roofline": {"bound": "hbm", "kernel": "k_withdraw_sha || k_withdraw", "achieved": round(abytes / (ms_kernel * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(abytes / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "launch_ms": round(ms_kernel, 3),
-                         "algorithmic_bytes_per_launch": int(abytes)}}))
-    if world > 1:
-        dist.destroy_process_group()
+        ms_launch = dt / (steps * launches) * 1e3   # the two kernels of a launch run concurrently: wall time per launch
+        dk = max(acc, key=lambda k: acc[k][1])
+        res = {"metric": "withdraw witnesses/sec (nLevels=%d)" % lv, "value": round(total / dt, 1), "unit": "witnesses/s", "n_gpus": D.world,
+               "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "scaling": "weak",
+               "config": {"workload": "withdraw nLevels=%d, %d witnesses per step in %d launches of %d" % (lv, launches * N, launches, N),
+                          "witness_elements": wl, "exit_tree_leaves": n_leaves, "distinct_leaves_per_launch": len(uniq)},
+               "whole_launch": {"achieved_GBs": round(abytes / (ms_launch * 1e-3) / 1e9, 2), "frac": round(abytes / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                "launch_ms": round(ms_launch, 3), "algorithmic_bytes_per_launch": int(abytes), "note": "k_withdraw_sha || k_withdraw, wall time"},
+               "roofline": {"bound": "hbm", "kernel": "k_" + dk, "achieved": round(acc[dk][1] / (acc[dk][0] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(acc[dk][1] / (acc[dk][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": measured_traffic("k_" + dk, None),
+                            "launch_ms": round(acc[dk][0], 3), "algorithmic_bytes_per_launch": int(acc[dk][1])},
+               "kernels_ms": {k: round(v[0], 3) for k, v in acc.items()},
+               "kernels_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in acc.items() if v[0] > 0}}
+    del c
+    return res
+
+
+def respawn(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks (one process per GPU) and hand over."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -244,93 +304,139 @@ def main():
     ap.add_argument("--accounts", type=int, default=0, help="accounts in the synthetic state before the batch (default 4 * nTx, the reference recipe)")
     ap.add_argument("--inflight", type=int, default=2, help="contexts in flight (each with its own witness buffers and streams): the fee/SHA tail of one step overlaps the next step's kernels")
     ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = min(16, logical CPUs); 64 processes were measured slower in total: 867 vs 956 tx/s)")
-    ap.add_argument("--cpu-sample", type=int, default=768, help="nTx of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="nTx of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batches-per-launch", type=int, default=32,
                     help="independent batches evaluated by ONE set of kernel launches (context with n_instances = B): more wavefronts per launch")
+    ap.add_argument("--distinct-batches", type=int, default=0,
+                    help="differently seeded batches built for the run (0 = one per resident instance: batches-per-launch x inflight); fewer are reused round-robin")
+    ap.add_argument("--build-workers", type=int, default=0, help="host processes building the synthetic batches (0 = min(batches, CPUs - 2, 64))")
     ap.add_argument("--workload", choices=["rollup-main", "withdraw"], default="rollup-main",
-                    help="withdraw = BASELINE config 5 (2^20 independent Withdraw(nLevels) witnesses)")
+                    help="withdraw = BASELINE config 5 (2^20 independent Withdraw(nLevels) witnesses) as the main line")
     ap.add_argument("--withdraw-total", type=int, default=1 << 20)
     ap.add_argument("--withdraw-per-launch", type=int, default=1 << 16)
+    ap.add_argument("--withdraw-leaves", type=int, default=1 << 16, help="leaves of the exit tree the withdrawals are drawn from (SURVEY 8d: 2^16)")
     ap.add_argument("--latency-scheduling", action="store_true",
                     help="with --inflight 1: HZ_FLAG_LATENCY contexts (concurrent kernel chains on disjoint compute units); for the "
                          "single-batch latency figure: --batches-per-launch 1 --inflight 1 --latency-scheduling")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon-BN254/sec secondary metric")
+    ap.add_argument("--no-withdraw", action="store_true", help="skip the config-5 (withdraw) secondary line")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the upload-inclusive run (value_e2e)")
+    ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the tx-sharded (config 4, strong scaling) secondary line")
     ap.add_argument("--calibrate-copy", action="store_true",
                     help="profiling aid: one 1 GiB device-to-device tensor copy before the timed region, a known byte count that "
                          "calibrates the FETCH_SIZE / WRITE_SIZE counters of a rocprofv3 --pmc pass (tools/profile.sh)")
-    ap.add_argument("--shard-tx", action="store_true",
-                    help="BASELINE config 4: shard ONE batch by transaction index over the ranks (one RCCL all_gather of the "
-                         "data-availability records, FeeTx + HashInputs on rank 0); strong scaling. Default: independent batches per rank.")
+    ap.add_argument("--shard-tx", action="store_true", help="only the tx-sharded line (BASELINE config 4) as the main line")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if "HZ_BENCH_DEVICE" in os.environ:   # test hook: several ranks on one GPU (with HZ_BENCH_BACKEND=gloo)
-        local = int(os.environ["HZ_BENCH_DEVICE"])
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(os.environ.get("HZ_BENCH_BACKEND", "nccl"))
-    torch.cuda.set_device(local)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(args)
+    D = Dist()
+    torch = D.torch
+    rank, world, local = D.rank, D.world, D.local
+    if world != max(1, args.gpus) and rank == 0:
+        print("bench: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
 
     from circuits_amd import lib
-    from circuits_amd import builder as B
+    from circuits_amd.batchgen import build_packed_batches
     L = lib()
     if L.device_count() <= 0:
         raise SystemExit("no gfx950 device")
     if args.workload == "withdraw":
-        return bench_withdraw(args, L, rank, world, local)
+        res = bench_withdraw(args, L, D)
+        if rank == 0:
+            res.update({"warmup": args.warmup, "higher_is_better": True, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic"})
+            print(json.dumps(res))
+        return D.close()
     nTx, lv, m1, F = args.nTx, args.nLevels, args.maxL1Tx, args.maxFeeTx
-    # synthetic batch (reference tools/generate-input.js recipe, SURVEY 8d: a state of 4*nTx accounts), same seed on every rank;
-    # built with the device batch builder (circuits_amd/builder.py DagHasher: the tree hashing of the 4*nTx + maxL1Tx accounts and of
-    # the batch in ~60 launches). The state size matters: the Merkle proofs of a tree of 2^13 leaves reach their leaf at level 13-14,
-    # the levels below hash empty subtrees.
     n_acc = args.accounts if args.accounts > 0 else 4 * nTx
-    bb = B.synthetic_batch(nTx, lv, m1, F, n_accounts=n_acc, seed=0x48455A31, device=local)
-    inp = bb.get_input()
-    n_l2 = sum(1 for x in inp["onChain"] if not x)
-    if args.shard_tx:
-        return bench_sharded(args, L, bb, inp, rank, world, local, n_l2)
     Bp = max(1, args.batches_per_launch)
     # more than 4 contexts (3 streams each) exhaust the runtime's per-queue scratch reservations (HSA_STATUS_ERROR_OUT_OF_RESOURCES)
     inflight = max(1, min(args.inflight, 4, args.steps if args.steps > 0 else 1))
     # every batch keeps its whole witness resident (3.86 GB at the default shape): fit batches x contexts into free HBM
     probe = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=1)
-    per_batch = probe.witness_len() * 32 * 1.04 + (64 << 20)
+    layout = probe.packed_layout()
+    per_batch = probe.witness_len() * 32 * 1.04 + (64 << 20) + layout[0]
     del probe
     free_b, _total_b = torch.cuda.mem_get_info()
+    if "HZ_BENCH_DEVICE" in os.environ:
+        free_b //= world   # test hook: the ranks share one device
     fit = int((free_b - (6 << 30)) // (per_batch * inflight))
     if fit < Bp:
         print("bench: %d batches x %d contexts do not fit %.0f GB of free HBM, using %d batches per launch" % (Bp, inflight, free_b / 1e9, max(1, fit)), file=sys.stderr)
         Bp = max(1, fit)
+    # synthetic batches (reference tools/generate-input.js recipe, SURVEY 8d: a state of 4*nTx accounts): one per resident instance,
+    # each from its own seed (own accounts, balances, transactions, signatures, Merkle paths). The state size matters: the proofs
+    # of a tree of 2^13 leaves reach their leaf at level 13-14, the levels below hash empty subtrees.
+    n_res = Bp * inflight
+    n_distinct = min(n_res, args.distinct_batches) if args.distinct_batches > 0 else n_res
+    t_build = time.time()
+    if args.shard_tx:
+        n_distinct = 1
+    # the sharded line needs ONE batch that every rank holds (seed SEED); the weak-scaling batches are per rank
+    want_shard = args.shard_tx or (world > 1 and not args.no_shard)
+    seeds = [] if args.shard_tx else [SEED + 1 + 1000 * rank + i for i in range(n_distinct)]
+    batches = build_packed_batches(seeds + ([SEED] if want_shard else []), nTx, lv, m1, F, n_acc, layout, args.build_workers)
+    t_build = time.time() - t_build
+    shared = batches.pop() if want_shard else None
+    n_l2 = (batches[0] if batches else shared)[2]
+    if args.shard_tx:
+        res = bench_sharded(args, L, D, shared[0], shared[1])
+        if rank == 0:
+            print(json.dumps({"metric": "rollup-main tx-witnesses/sec (nTx=%d, nLevels=%d)" % (nTx, lv), "value": res["value"], "unit": "tx-witnesses/s",
+                              "n_gpus": world, "steps": res["steps"], "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+                              "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+                              "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "parallelism": res["parallelism"],
+                                         "collective": res["collective"], "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2},
+                              "roofline": {"bound": "hbm", "kernel": "whole sharded pass", "achieved": res["whole_pass_GBs"], "peak": HBM_PEAK_GBS * world,
+                                           "unit": "GB/s", "frac": round(res["whole_pass_GBs"] / (HBM_PEAK_GBS * world), 5), "traffic": None}}))
+        return D.close()
+    # pinned host copies of the packed inputs: the source of every upload
+    pbytes = layout[0]
+    pin = L.host_alloc(pbytes * n_distinct)
+    for i, (pk, _, _) in enumerate(batches):
+        ctypes.memmove(pin + i * pbytes, pk, pbytes)
+    expected = [b[1] for b in batches]
+    del batches
     ctxs, streams = [], []
     for k in range(inflight):
         c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=Bp,
                   flags=2 if (args.latency_scheduling and inflight == 1) else 0)
-        c.set_inputs(inp, instance=0)  # inputs resident in HBM before the timed region
-        for b in range(1, Bp):
-            c.copy_instance_inputs(0, b)  # same synthetic batch in every instance (device-to-device)
         ctxs.append(c)
         streams.append(torch.cuda.Stream(device=local))
-    # one checked pass (parity with the builder's independently computed public output)
+
+    def slot(k, b):   # which batch lives in instance b of context k
+        return (k * Bp + b) % n_distinct
+
+    def upload(k):
+        for b in range(Bp):
+            ctxs[k].upload(b, pin + slot(k, b) * pbytes, pbytes, streams[k].cuda_stream)
+
+    for k in range(inflight):
+        upload(k)   # inputs resident in HBM before the timed region
+    # one checked pass per context: parity of every batch's public output with the builder's independently computed value
     ctxs[0].set_profiling(True)
-    ctxs[0].enqueue(streams[0].cuda_stream)
-    ctxs[0].check()
-    if not args.no_verify:
-        for b in (0, Bp - 1):
-            assert ctxs[0].get("main.hashGlobalInputs", b) == bb.get_hash_inputs(), "hashGlobalInputs mismatch"
+    for k in range(inflight):
+        ctxs[k].enqueue(streams[k].cuda_stream)
+        ctxs[k].check()
+        if not args.no_verify:
+            for b in range(Bp):
+                assert ctxs[k].get("main.hashGlobalInputs", b) == expected[slot(k, b)], "hashGlobalInputs mismatch (context %d, batch %d)" % (k, b)
     ctxs[0].set_profiling(False)
 
-    def run_steps(n):
+    def stage(k):   # the inputs of context k's NEXT step: the PCIe copies run beside the kernels of the step just enqueued
+        for b in range(Bp):
+            ctxs[k].stage(b, pin + slot(k, b) * pbytes, pbytes)
+
+    def run_steps(n, with_upload=False):
         pending = [False] * inflight
         for i in range(n):
             k = i % inflight
             if pending[k]:
                 ctxs[k].check()
-            ctxs[k].enqueue(streams[k].cuda_stream)
+            ctxs[k].enqueue(streams[k].cuda_stream)   # with_upload: first scatters the inputs staged for this step
+            if with_upload:
+                stage(k)
             pending[k] = True
         for k in range(inflight):
             if pending[k]:
@@ -343,19 +449,14 @@ def main():
         torch.cuda.synchronize()
         del a, b
     run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.timed(lambda: run_steps(args.steps))
+    dt_e2e = None
+    if not args.no_e2e:
+        for k in range(inflight):
+            stage(k)
+        run_steps(max(inflight, args.warmup), True)   # every timed step below consumes inputs staged during the step before it
+        dt_e2e = D.timed(lambda: run_steps(args.steps, True))
+        run_steps(inflight, False)   # drain the last staged inputs
 
     # latency of one step alone on the device (wall clock around enqueue + check; `batches_per_launch` batches)
     lat = []
@@ -379,38 +480,49 @@ def main():
             a[0] += ms / reps      # a kernel launched in several pieces (the SMT chain: chunks of levels) adds up over its launches
             a[3] += 1.0 / reps
     ctxs[0].set_profiling(False)
+    # upload path alone: one instance's packed inputs, host -> device -> witness layout (HIP events on the stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(streams[0]):
+        e0.record()
+        upload(0)
+        e1.record()
+    torch.cuda.synchronize()
+    upload_ms = e0.elapsed_time(e1) / Bp
+    witness_bytes = ctxs[0].witness_len() * 32
+    del ctxs, c
+    L.host_free(pin)
+    torch.cuda.empty_cache()
 
+    out = None
     if rank == 0:
         total_tx = nTx * Bp * args.steps * world
         value = total_tx / dt
         # dominant kernel = most GPU time per step over all its launches (k_smt runs for the transactions and for the
         # fee transactions); its roofline is quoted on the transaction launch
         kern = {"smt": "k_smt", "fee_smt": "k_smt", "hash4": "k_hash4", "fee_hash": "k_hash4", "eddsa": "k_eddsa", "eddsa_fix": "k_eddsa_fix", "front": "k_main_front"}
-        tot = {}
+        tot, byt = {}, {}
         for name, v in acc.items():
             tot[kern.get(name, name)] = tot.get(kern.get(name, name), 0.0) + v[0]
-        byt = {}
-        for name, v in acc.items():
             byt[kern.get(name, name)] = byt.get(kern.get(name, name), 0) + v[1]
         # dominant kernel for an HBM roofline = the kernel that writes most of the witness (k_smt: three quarters of a step's
-        # bytes, and the only one besides the front / hash kernels that fills the device). k_eddsa's single launch lasts longer
-        # but runs on 384 wavefronts, latency bound, underneath the others: its figures are in kernels_ms / kernels_GBs.
+        # bytes, and the only one besides the front / hash kernels that fills the device). k_eddsa's launches last longer
+        # but run on few wavefronts, latency bound, underneath the others: their figures are in kernels_ms / kernels_GBs.
         dk = max(tot, key=lambda k: byt[k])
         dname = max((n for n in acc if kern.get(n, n) == dk), key=lambda n: acc[n][0])
         dms, dbytes, dunits, dlaunches = acc[dname]
         dlaunches = max(1, int(round(dlaunches)))
         achieved = dbytes / (dms * 1e-3) / 1e9
-        traffic = measured_traffic(dk, Bp)
         out = {
             "metric": "rollup-main tx-witnesses/sec (nTx=%d, nLevels=%d)" % (nTx, lv),
             "value": round(value, 1), "unit": "tx-witnesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32x9 (254-bit Montgomery Fr, 29-bit limbs, integer)", "data": "synthetic",
+            "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "batches_per_launch": Bp, "contexts_in_flight": inflight,
-                       "state_accounts": n_acc, "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
-                       "witness_bytes_per_batch": ctxs[0].witness_len() * 32, "step_latency_ms": round(single_ms, 3)},
+                       "distinct_batches": n_distinct, "state_accounts": n_acc, "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
+                       "world_size": world, "backend": D.backend if world > 1 else None,
+                       "witness_bytes_per_batch": witness_bytes, "step_latency_ms": round(single_ms, 3), "batch_build_s": round(t_build, 1)},
             "roofline": {"bound": "hbm", "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dk, Bp),
                          "launches_per_step": dlaunches, "launch_ms": round(dms / dlaunches, 3),
                          "algorithmic_bytes_per_launch": int(dbytes // dlaunches), "gpu_ms_per_step_all_launches": round(tot[dk], 3),
                          "note": "algorithmic bytes = 32 B x the witness signals this launch is responsible for (the SMT chain is launched in chunks "
@@ -419,18 +531,32 @@ def main():
                                  "Levels of an SMT proof below the leaf (the hash of an empty subtree) are stored from a constant block and are "
                                  "HBM-store bound; the levels that hash data are integer-VALU issue bound (DESIGN.md 4)"},
             "whole_pass": {"algorithmic_bytes_per_tx": algorithmic_bytes_per_tx(lv, F),
-                           "achieved_GBs": round(algorithmic_bytes_per_tx(lv, F) * value / 1e9, 2)},
+                           "achieved_GBs": round(algorithmic_bytes_per_tx(lv, F) * value / world / 1e9, 2),
+                           "frac": round(algorithmic_bytes_per_tx(lv, F) * value / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernels_ms": {k: round(v[0], 3) for k, v in acc.items()},
             "kernels_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in acc.items() if v[0] > 0},
         }
+        if dt_e2e is not None:
+            out["value_e2e"] = round(total_tx / dt_e2e, 1)
+            out["e2e"] = {"ms_per_step": round(dt_e2e / args.steps * 1e3, 3), "ratio_to_value": round(dt / dt_e2e, 4), "packed_input_bytes_per_batch": pbytes,
+                          "upload_ms_per_batch": round(upload_ms, 4), "upload_GBs": round(pbytes / upload_ms / 1e6, 2),
+                          "note": "timed region = per step and batch one hz_inputs_stage from pinned host memory (async H2D beside the previous step's kernels) "
+                                  "+ unpack kernel + witness kernels + check; upload_* = hz_inputs_upload (copy + unpack) alone on the device"}
+    # secondary lines: config 4 sharded (N > 1), config 5 withdraw, Poseidon-BN254/sec, CPU baseline
+    if world > 1 and not args.no_shard:
+        sh = bench_sharded(args, L, D, shared[0], shared[1])
+        if rank == 0:
+            out["shard_tx"] = sh
+    if world == 1 and not args.no_withdraw:
+        out["withdraw"] = bench_withdraw(args, L, D, launches=max(1, (1 << 18) // args.withdraw_per_launch), steps=2)
+    if rank == 0:
         if world == 1 and not args.no_poseidon:
             out["poseidon_bn254"] = poseidon_rates(L, torch)
         if world == 1 and args.cpu_sample > 0:
             workers = args.cpu_workers if args.cpu_workers > 0 else max(1, min(16, (os.cpu_count() or 1)))
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, nTx), lv, min(m1, max(1, args.cpu_sample // 8)), F, workers)
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

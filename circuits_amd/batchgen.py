@@ -1,0 +1,34 @@
+"""Synthetic batches for the benchmark, built in parallel on the host cores.
+
+The batch builder (circuits_amd/builder.py, the counterpart of @hermeznetwork/commonjs BatchBuilder called at reference
+tools/generate-input.js:61-109) is caller-side work: a rollup coordinator produces the circuit inputs, the witness generator
+consumes them. bench.py needs many DIFFERENT batches resident at once (64 at the default shape), so a process pool builds them
+-- one seeded batch per task, host hashing, no GPU in the workers -- and returns each one already in the packed bulk-upload
+format of hz_inputs_upload together with the public hash the builder expects."""
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _one(task):
+    seed, n_tx, n_levels, max_l1, max_fee, n_accounts, layout = task
+    if _ROOT not in sys.path:
+        sys.path.insert(0, _ROOT)
+    from circuits_amd import builder as B
+    from circuits_amd.capi import pack_inputs
+    bb = B.synthetic_batch(n_tx, n_levels, max_l1, max_fee, n_accounts=n_accounts, seed=seed)
+    inp = bb.get_input()
+    return pack_inputs(layout, inp), bb.get_hash_inputs(), sum(1 for x in inp["onChain"] if not x)
+
+
+def build_packed_batches(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, workers=0):
+    """one batch per seed: [(packed bytes, expected hashGlobalInputs, signed L2 transactions)]"""
+    import multiprocessing as mp
+    tasks = [(s, n_tx, n_levels, max_l1, max_fee, n_accounts, layout) for s in seeds]
+    n = len(tasks)
+    workers = workers or max(1, min(n, (os.cpu_count() or 2) - 2, 64))
+    if workers == 1:
+        return [_one(t) for t in tasks]
+    with mp.get_context("spawn").Pool(workers) as pool:   # spawn: the parent holds a HIP context
+        return pool.map(_one, tasks, chunksize=1)

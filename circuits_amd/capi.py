@@ -56,7 +56,8 @@ TEMPLATES = {"rollup-main": 0, "rollup-tx": 1, "decode-tx": 2, "fee-tx": 3, "has
 # every symbol include/hermez_witness.h declares; tests check the .so exports all of them
 EXPORTS = [
     "hz_version", "hz_last_error", "hz_device_count", "hz_ctx_create", "hz_ctx_destroy", "hz_witness_len",
-    "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_copy_instance_inputs", "hz_clear_inputs", "hz_input_count", "hz_input_name",
+    "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_copy_instance_inputs", "hz_inputs_packed_bytes", "hz_input_packed_width",
+    "hz_input_packed_offset", "hz_host_alloc", "hz_host_free", "hz_inputs_upload", "hz_inputs_stage", "hz_clear_inputs", "hz_input_count", "hz_input_name",
     "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
@@ -96,6 +97,17 @@ class Lib:
         c.hz_copy_instance_inputs.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp]
         c.hz_clear_inputs.argtypes = [vp]
         c.hz_clear_inputs.restype = None
+        c.hz_inputs_packed_bytes.argtypes = [vp]
+        c.hz_inputs_packed_bytes.restype = u64
+        c.hz_input_packed_width.argtypes = [vp, ctypes.c_int32]
+        c.hz_input_packed_offset.argtypes = [vp, ctypes.c_int32]
+        c.hz_input_packed_offset.restype = u64
+        c.hz_host_alloc.argtypes = [ctypes.c_size_t]
+        c.hz_host_alloc.restype = vp
+        c.hz_host_free.argtypes = [vp]
+        c.hz_host_free.restype = None
+        c.hz_inputs_upload.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_size_t, vp]
+        c.hz_inputs_stage.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_size_t, vp]
         c.hz_input_count.argtypes = [vp]
         c.hz_input_name.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(u64)]
         c.hz_input_name.restype = ctypes.c_char_p
@@ -169,10 +181,36 @@ class Lib:
     def ctx(self, template, **kw):
         return Ctx(self, template, **kw)
 
+    def host_alloc(self, nbytes):
+        """pinned host memory for hz_inputs_upload (address as int); free with host_free"""
+        p = self.c.hz_host_alloc(nbytes)
+        if not p:
+            raise HzError(2, self.c.hz_last_error().decode())
+        return p
+
+    def host_free(self, p):
+        self.c.hz_host_free(p)
+
     def shard_range(self, n_tx, world, rank):
         f, c = ctypes.c_int32(), ctypes.c_int32()
         self.c.hz_shard_range(n_tx, world, rank, ctypes.byref(f), ctypes.byref(c))
         return f.value, c.value
+
+
+def pack_inputs(layout, inputs):
+    """The packed bulk-upload buffer (bytes) of one instance from an input object {signal: number | nested lists} and
+    Ctx.packed_layout(). Pure Python: usable in worker processes that have no GPU."""
+    total, sigs = layout
+    out = bytearray(total)
+    for name, off, width, flat_len in sigs:
+        flat = _flatten(inputs[name])
+        if len(flat) != flat_len:
+            raise ValueError("input %s: expected %d values, got %d" % (name, flat_len, len(flat)))
+        if width == 32:
+            out[off:off + 32 * flat_len] = fr_to_bytes(flat)
+        else:
+            out[off:off + flat_len] = bytes(flat)
+    return bytes(out)
 
 
 def _flatten(v):
@@ -229,6 +267,27 @@ class Ctx:
     def set_inputs(self, d, instance=0):
         for k, v in d.items():
             self.set_input(k, v, instance)
+
+    def packed_layout(self):
+        """(total bytes, [(name, byte offset, element bytes, flat length)]) of the bulk-upload buffer of one instance"""
+        total = self.L.c.hz_inputs_packed_bytes(self.h)
+        if not total:
+            raise HzError(2, self.L.c.hz_last_error().decode())
+        return total, [(nm, self.L.c.hz_input_packed_offset(self.h, i), self.L.c.hz_input_packed_width(self.h, i), ln) for i, (nm, ln) in enumerate(self.input_names())]
+
+    def upload(self, instance, packed, nbytes=None, stream=None):
+        """hz_inputs_upload: `packed` is bytes / bytearray, or the address of a (pinned) host buffer of nbytes"""
+        if isinstance(packed, (bytes, bytearray)):
+            nbytes = len(packed)
+            buf = (ctypes.c_char * nbytes).from_buffer_copy(packed)
+            self.L._check(self.L.c.hz_inputs_upload(self.h, instance, ctypes.addressof(buf), nbytes, stream))
+            self._keep = getattr(self, "_keep", [])[-63:] + [buf]   # pageable source: keep it alive until the copy has run
+        else:
+            self.L._check(self.L.c.hz_inputs_upload(self.h, instance, packed, nbytes, stream))
+
+    def stage(self, instance, packed_addr, nbytes, stream=None):
+        """hz_inputs_stage: the H2D copy alone (pinned source); the next enqueue scatters the staged instances"""
+        self.L._check(self.L.c.hz_inputs_stage(self.h, instance, packed_addr, nbytes, stream))
 
     def copy_instance_inputs(self, src, dst, stream=None):
         """Replicate the inputs of instance `src` onto instance `dst` on the device."""

@@ -36,6 +36,18 @@ struct hz_ctx {
     // given; the next enqueue waits for this event on ITS stream, whichever that is
     hipEvent_t ev_inputs = nullptr;
     bool inputs_pending = false;
+    // bulk upload (hz_inputs_upload): one packed buffer per instance -> device staging -> k_unpack_inputs into the witness layout
+    DevBuf upl, upl_desc, upl_bad;
+    uint64_t upl_bytes = 0;                 // packed bytes of one instance
+    std::vector<uint64_t> upl_off;          // per input: byte offset inside the packed buffer
+    uint32_t upl_blocks = 0;
+    bool upl_used = false;                  // hz_witness_check also reads the range-check flag of the unpack kernel
+    // hz_inputs_stage: the H2D half alone, ahead of time (while the previous step still computes on the old inputs); the unpack
+    // kernels of the staged instances run at the head of the next enqueue
+    std::vector<uint8_t> staged;
+    bool any_staged = false;
+    hipStream_t s_copy = nullptr;
+    hipEvent_t ev_staged = nullptr, ev_unpacked = nullptr;
     // independent chains of one batch run concurrently: the EdDSA ladders and the fee transactions on
     // their own streams, joined by events before HashInputs (DESIGN.md "Kernel schedule")
     bool exclusive = false;   // hz_ctx_set_profiling(ctx, 2)
@@ -49,6 +61,9 @@ struct hz_ctx {
         if (s_fee) (void)hipStreamDestroy(s_fee);
         if (s_main) (void)hipStreamDestroy(s_main);
         if (s_fix) (void)hipStreamDestroy(s_fix);
+        if (s_copy) (void)hipStreamDestroy(s_copy);
+        for (hipEvent_t e : {ev_staged, ev_unpacked})
+            if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee, ev_fix, ev_user_in, ev_user_out, ev_inputs})
             if (e) (void)hipEventDestroy(e);
         for (auto& p : prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -324,6 +339,151 @@ extern "C" hz_status hz_copy_instance_inputs(hz_ctx* c, int32_t src, int32_t dst
     return HZ_OK;
 }
 
+// ---- bulk input path ---------------------------------------------------------------------------------------
+// The per-signal hz_set_input walks host memory three times (range check, transpose, pageable copy). A serving process that feeds
+// batch after batch hands over ONE packed buffer per instance instead -- every input signal in hz_input_name order, each as
+// [outer][inner] little-endian elements of hz_input_packed_width bytes (what hz_set_input takes, concatenated; bit signals one
+// byte each) -- ideally in pinned memory (hz_host_alloc): one asynchronous H2D copy into a device staging slot, then one kernel
+// transposes every signal into the witness layout and range-checks the elements (< r) on the way.
+struct UnpackDesc { uint64_t src_off, dst_elem0; uint32_t inner, outer, ebytes, n_units, upi, first_block, index, pad; };
+struct UnpackBad { unsigned long long key; };   // ~0 = none; else (input index << 40) | element
+__global__ __launch_bounds__(256) void k_unpack_inputs(const UnpackDesc* __restrict__ desc, uint32_t n_desc, const uint8_t* __restrict__ src,
+                                                       uint8_t* __restrict__ wit, uint32_t inst, UnpackBad* bad) {
+    uint32_t lo = 0, hi = n_desc - 1;   // the input this block belongs to
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (desc[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const UnpackDesc d = desc[lo];
+    const uint64_t t = (uint64_t)(blockIdx.x - d.first_block) * 256 + threadIdx.x;
+    if (t >= (uint64_t)d.inner * d.outer) return;
+    const uint32_t k = (uint32_t)(t / d.outer), u = (uint32_t)(t % d.outer);   // consecutive lanes -> consecutive units: coalesced stores
+    const uint8_t* sp = src + d.src_off + ((uint64_t)u * d.inner + k) * d.ebytes;
+    uint4 a, b;
+    if (d.ebytes == 32) {
+        a = reinterpret_cast<const uint4*>(sp)[0];
+        b = reinterpret_cast<const uint4*>(sp)[1];
+        // < r ? (compare from the top limb)
+        const uint32_t P[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        bool lt = false, decided = false;
+        for (int i = 7; i >= 0; i--)
+            if (!decided && v[i] != P[i]) { lt = v[i] < P[i]; decided = true; }
+        if (!lt) atomicMin(&bad->key, ((unsigned long long)d.index << 40) | t);
+    } else {
+        a = make_uint4(sp[0], 0u, 0u, 0u);
+        b = make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint4* dp = reinterpret_cast<uint4*>(wit + (d.dst_elem0 + (uint64_t)k * d.n_units + (uint64_t)inst * d.upi + u) * 32);
+    dp[0] = a;
+    dp[1] = b;
+}
+
+static hz_status upload_prepare(hz_ctx* c) {
+    if (c->upl_desc.p) return HZ_OK;
+    const Layout& lo = c->lo;
+    std::vector<UnpackDesc> ds;
+    uint64_t off = 0;
+    uint32_t blocks = 0;
+    c->upl_off.clear();
+    for (size_t i = 0; i < lo.inputs.size(); i++) {
+        const InputDesc& d = lo.inputs[i];
+        const Section& s = lo.sections[d.section];
+        off = (off + 31) & ~31ull;   // every signal starts 32-byte aligned (vector loads)
+        UnpackDesc u;
+        memset(&u, 0, sizeof u);
+        u.src_off = off; u.dst_elem0 = s.base + (uint64_t)d.off * s.n_units; u.inner = d.inner; u.outer = d.outer; u.ebytes = d.ebytes;
+        u.n_units = s.n_units; u.upi = s.upi; u.first_block = blocks; u.index = (uint32_t)i;
+        ds.push_back(u);
+        c->upl_off.push_back(off);
+        off += (uint64_t)d.inner * d.outer * d.ebytes;
+        blocks += (uint32_t)(((uint64_t)d.inner * d.outer + 255) / 256);
+    }
+    c->upl_bytes = (off + 31) & ~31ull;
+    c->upl_blocks = blocks;
+    HZ_HIP(c->upl_desc.alloc(ds.size() * sizeof(UnpackDesc)));
+    HZ_HIP(hipMemcpy(c->upl_desc.p, ds.data(), ds.size() * sizeof(UnpackDesc), hipMemcpyHostToDevice));
+    HZ_HIP(c->upl_bad.alloc(sizeof(UnpackBad)));
+    HZ_HIP(hipMemset(c->upl_bad.p, 0xFF, sizeof(UnpackBad)));
+    return HZ_OK;
+}
+extern "C" uint64_t hz_inputs_packed_bytes(const hz_ctx* cc) {
+    hz_ctx* c = const_cast<hz_ctx*>(cc);
+    if (!c || hipSetDevice(c->device) != hipSuccess || upload_prepare(c) != HZ_OK) return 0;
+    return c->upl_bytes;
+}
+extern "C" int32_t hz_input_packed_width(const hz_ctx* c, int32_t i) {
+    return (!c || i < 0 || (size_t)i >= c->lo.inputs.size()) ? 0 : (int32_t)c->lo.inputs[i].ebytes;
+}
+extern "C" uint64_t hz_input_packed_offset(const hz_ctx* cc, int32_t i) {
+    hz_ctx* c = const_cast<hz_ctx*>(cc);
+    if (!c || i < 0 || (size_t)i >= c->lo.inputs.size() || hipSetDevice(c->device) != hipSuccess || upload_prepare(c) != HZ_OK) return ~0ull;
+    return c->upl_off[i];
+}
+extern "C" void* hz_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)set_err(HZ_ERR_HIP, "hz_host_alloc: %zu bytes of pinned memory", bytes); return nullptr; }
+    return p;
+}
+extern "C" void hz_host_free(void* p) { if (p) (void)hipHostFree(p); }
+static hz_status upload_common(hz_ctx* c, const char* who, int32_t instance, const void* packed, size_t bytes, uint8_t** slot) {
+    if (!c || !packed) return set_err(HZ_ERR_ARG, "%s: null argument", who);
+    HZ_HIP(hipSetDevice(c->device));
+    const hz_status st = upload_prepare(c);
+    if (st != HZ_OK) return st;
+    const Layout& lo = c->lo;
+    if (instance < 0 || (uint32_t)instance >= lo.n_inst) return set_err(HZ_ERR_ARG, "%s: instance %d out of range (n_instances = %u)", who, instance, lo.n_inst);
+    if (bytes != c->upl_bytes) return set_err(HZ_ERR_INPUT, "%s: expected %llu packed bytes, got %zu", who, (unsigned long long)c->upl_bytes, bytes);
+    if (!c->upl.p) HZ_HIP(c->upl.alloc((size_t)c->upl_bytes * lo.n_inst));
+    *slot = (uint8_t*)c->upl.p + (size_t)instance * c->upl_bytes;
+    return HZ_OK;
+}
+static hz_status launch_unpack(hz_ctx* c, uint32_t instance, hipStream_t s) {
+    const uint8_t* slot = (const uint8_t*)c->upl.p + (size_t)instance * c->upl_bytes;
+    hipLaunchKernelGGL(k_unpack_inputs, dim3(c->upl_blocks), dim3(256), 0, s, (const UnpackDesc*)c->upl_desc.p, (uint32_t)c->lo.inputs.size(), slot, (uint8_t*)c->wit.p,
+                       instance, (UnpackBad*)c->upl_bad.p);
+    HZ_HIP(hipGetLastError());
+    c->upl_used = true;
+    std::fill(c->input_set.begin(), c->input_set.end(), 1);   // like hz_set_input: "set" is tracked per signal, not per instance
+    return HZ_OK;
+}
+extern "C" hz_status hz_inputs_upload(hz_ctx* c, int32_t instance, const void* packed, size_t bytes, void* stream) {
+    uint8_t* slot = nullptr;
+    hz_status st = upload_common(c, "hz_inputs_upload", instance, packed, bytes, &slot);
+    if (st != HZ_OK) return st;
+    hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    if (c->ev_unpacked) HZ_HIP(hipStreamWaitEvent(s, c->ev_unpacked, 0));   // a staged copy of this slot may still be waiting for its unpack
+    HZ_HIP(hipMemcpyAsync(slot, packed, bytes, hipMemcpyHostToDevice, s));
+    st = launch_unpack(c, (uint32_t)instance, s);
+    if (st != HZ_OK) return st;
+    HZ_HIP(hipEventRecord(c->ev_inputs, s));
+    c->inputs_pending = true;
+    return HZ_OK;
+}
+// The copy alone. Typical use: right after hz_witness_enqueue of step N, stage the inputs of step N + 1 -- the PCIe transfer
+// runs beside step N's kernels (which still read the old inputs from the witness buffer); the next hz_witness_enqueue scatters
+// every staged instance into the witness layout first.
+extern "C" hz_status hz_inputs_stage(hz_ctx* c, int32_t instance, const void* packed, size_t bytes, void* stream) {
+    uint8_t* slot = nullptr;
+    const hz_status st = upload_common(c, "hz_inputs_stage", instance, packed, bytes, &slot);
+    if (st != HZ_OK) return st;
+    if (!c->s_copy) {
+        HZ_HIP(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+        HZ_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+        HZ_HIP(hipEventCreateWithFlags(&c->ev_unpacked, hipEventDisableTiming));
+        HZ_HIP(hipEventRecord(c->ev_unpacked, c->s_copy));
+        c->staged.assign(c->lo.n_inst, 0);
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : c->s_copy;
+    HZ_HIP(hipStreamWaitEvent(s, c->ev_unpacked, 0));   // the slot's previous content has been scattered
+    HZ_HIP(hipMemcpyAsync(slot, packed, bytes, hipMemcpyHostToDevice, s));
+    HZ_HIP(hipEventRecord(c->ev_staged, s));   // all stage calls between two enqueues use one stream: the last record covers them
+    c->staged[instance] = 1;
+    c->any_staged = true;
+    std::fill(c->input_set.begin(), c->input_set.end(), 1);
+    return HZ_OK;
+}
+
 // ---- kernel schedule ---------------------------------------------------------------------------------
 static SmtProcDesc make_proc(const SmtProcOff& o, uint32_t siblings, int which /*0: p1, 1: p2, 2: fee, 3: SMTProcessor main*/) {
     SmtProcDesc d;
@@ -497,6 +657,17 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
     // the legacy default stream has implicit-synchronisation semantics that do not mix with the
     // context's non-blocking side streams: a NULL stream means "the context's own stream"
     hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    if (c->any_staged) {   // scatter the staged inputs (hz_inputs_stage) into the witness layout
+        HZ_HIP(hipStreamWaitEvent(s, c->ev_staged, 0));
+        for (uint32_t b = 0; b < lo.n_inst; b++)
+            if (c->staged[b]) {
+                const hz_status st = launch_unpack(c, b, s);
+                if (st != HZ_OK) return st;
+                c->staged[b] = 0;
+            }
+        HZ_HIP(hipEventRecord(c->ev_unpacked, s));
+        c->any_staged = false;
+    }
     if (c->inputs_pending) {
         HZ_HIP(hipStreamWaitEvent(s, c->ev_inputs, 0));
         c->inputs_pending = false;
@@ -656,9 +827,17 @@ extern "C" hz_status hz_witness_check(hz_ctx* c, hz_error* out) {
     struct { unsigned long long minkey, filter; unsigned int count, pad; } hd;
     for (int attempt = 0; attempt < 2; attempt++) {
         // copy on the launch stream: a default-stream hipMemcpy would wait for every other batch in flight
+        unsigned long long bad = ~0ull;
         HZ_HIP(hipMemcpyAsync(&hd, c->err.p, sizeof hd, hipMemcpyDeviceToHost, c->last_stream));
+        if (c->upl_used && attempt == 0) HZ_HIP(hipMemcpyAsync(&bad, c->upl_bad.p, sizeof bad, hipMemcpyDeviceToHost, c->last_stream));
         HZ_HIP(hipStreamSynchronize(c->last_stream));
         c->enqueued = false;
+        if (bad != ~0ull) {   // an uploaded element was >= r: the witness computed from it means nothing
+            HZ_HIP(hipMemsetAsync(c->upl_bad.p, 0xFF, sizeof bad, c->last_stream));
+            const size_t idx = (size_t)(bad >> 40);
+            return set_err(HZ_ERR_INPUT, "input %s[%llu] is not a canonical field element (>= r)", idx < c->lo.inputs.size() ? c->lo.inputs[idx].name.c_str() : "?",
+                           (unsigned long long)(bad & ((1ull << 40) - 1)));
+        }
         if (hd.minkey == ~0ull) return HZ_OK;
         const unsigned int n = std::min<unsigned int>(hd.count, HZ_ERR_CAP);
         std::vector<ErrRec> recs(n);

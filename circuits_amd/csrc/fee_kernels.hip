@@ -5,6 +5,9 @@
 #include "sha_dev.h"
 #include "smt_dev.h"
 
+#ifndef HZ_SHA_CHAIN_PRIO
+#define HZ_SHA_CHAIN_PRIO 0
+#endif
 namespace hz {
 
 // ---- FeeTx front: lane = fee tx ---------------------------------------------------------------
@@ -165,6 +168,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
 
 // sequential chaining values: chain[b] = state before block b; then the digest -> output signal
 __global__ void k_sha_chain(const HashInputsArgs a) {
+#if HZ_SHA_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);   // one wavefront, the step's critical path: issue ahead of the integer-bound wavefronts sharing its SIMD
+#endif
     const uint32_t bt = blockIdx.x * blockDim.x + threadIdx.x;   // one lane per batch: the chains of different batches are independent
     if (bt >= a.B) return;
     const int nb = a.hi.sha.nblocks;
@@ -420,8 +426,10 @@ hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s) {
     hipError_t e = hipMemsetAsync(a.msg, 0, msg_bytes, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_hi_prep, grid1((1 + a.maxL1 + a.nTx + a.F) * a.B), dim3(HZ_BLOCK), 0, s, a);
+#if !defined(HZ_EXPERIMENT_NO_SHA)   // timing experiment only (wrong witness)
     hipLaunchKernelGGL(k_sha_chain, grid1(a.B), dim3(HZ_BLOCK), 0, s, a);
     hipLaunchKernelGGL(k_sha_expand, grid1((uint32_t)a.hi.sha.nblocks * a.B), dim3(HZ_BLOCK), 0, s, a);
+#endif
     return hipGetLastError();
 }
 hipError_t launch_da_export(const DaArgs& a, hipStream_t s) {

@@ -47,6 +47,7 @@ __device__ __forceinline__ Fr smt_top_dev(const UnitIO& io, const Scratch& sc, c
 #define HZ_SMT_ZERO_FAST 1
 #endif
 __device__ __forceinline__ Fr poseidon3_zero_level(const UnitIO& io, uint32_t sig0) {
+#if !defined(HZ_EXPERIMENT_NO_ZERO_STORES)   // timing experiment only (wrong witness): what the step costs without these stores
 #pragma unroll 3
     for (int s = 0; s < 243; s++) {
         Fc c;
@@ -54,6 +55,7 @@ __device__ __forceinline__ Fr poseidon3_zero_level(const UnitIO& io, uint32_t si
         for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[s][q];
         store_fr(io.addr(sig0 + s), c);
     }
+#endif
     Fr h;
 #pragma unroll
     for (int i = 0; i < 9; i++) h.v[i] = HZ_POSEIDON3_ZERO_HASH[i];

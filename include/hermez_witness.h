@@ -139,6 +139,24 @@ hz_status hz_set_input_dev(hz_ctx* ctx, int32_t instance, const char* name, cons
  * (No reference counterpart: snarkjs computes one witness per call; this fills a multi-instance context.) */
 hz_status hz_copy_instance_inputs(hz_ctx* ctx, int32_t src, int32_t dst, void* stream);
 void hz_clear_inputs(hz_ctx* ctx);
+/* Bulk input path (the marshalling half of calculateWitness(input), reference test/helpers/helpers.js:147-149, for a process that
+ * feeds batch after batch): ONE packed buffer per instance instead of one call per signal. Layout: every input signal in
+ * hz_input_name order at hz_input_packed_offset(i) (32-byte aligned), as [outer][inner] little-endian elements -- the flattening
+ * hz_set_input takes -- of hz_input_packed_width(i) bytes each: 32, or 1 for bit-valued signals (fromBjjCompressed).
+ * hz_inputs_upload copies the buffer to the device asynchronously on `stream` (truly so from hz_host_alloc'ed pinned memory, which
+ * the caller must keep unchanged until the stream reaches the copy) and one kernel scatters it into the witness layout and
+ * range-checks the 32-byte elements; an element >= r is reported by the next hz_witness_check as HZ_ERR_INPUT. */
+uint64_t hz_inputs_packed_bytes(const hz_ctx* ctx);
+int32_t hz_input_packed_width(const hz_ctx* ctx, int32_t i);
+uint64_t hz_input_packed_offset(const hz_ctx* ctx, int32_t i);
+void* hz_host_alloc(size_t bytes);
+void hz_host_free(void* p);
+hz_status hz_inputs_upload(hz_ctx* ctx, int32_t instance, const void* packed, size_t bytes, void* stream);
+/* The copy alone, ahead of time: the packed buffer goes to the instance's device staging slot on `stream` (NULL = the context's
+ * copy stream) and the NEXT hz_witness_enqueue / hz_witness_run scatters every staged instance into the witness layout before
+ * its kernels. Called right after the enqueue of step N with the inputs of step N + 1, the PCIe transfer overlaps step N's
+ * kernels, which still read the old inputs. All stage calls between two enqueues of a context must use the same stream. */
+hz_status hz_inputs_stage(hz_ctx* ctx, int32_t instance, const void* packed, size_t bytes, void* stream);
 /* enumerate the input signals the template expects */
 int32_t hz_input_count(const hz_ctx* ctx);
 const char* hz_input_name(const hz_ctx* ctx, int32_t i, uint64_t* flat_len);

@@ -171,3 +171,23 @@ def test_sharded_batch_on_one_gpu_matches_oracle(hz):
     # fee-tx and hash-inputs sections on rank 0
     fee0 = ctxs[0].lookup("main.feeTx[0].feeIdxIsZero.inv")
     assert gb[0][32 * fee0:] == ob[32 * fee0:]
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_spawns_two_ranks_and_exchanges_real_records(hz):
+    """`python bench.py --gpus 2` launches its two ranks itself and, with the one-GPU test hook (both ranks on
+    device 0, gloo collectives), moves REAL hz_da_export records between two processes: the sharded pass must reproduce the
+    builder's hashGlobalInputs on rank 0 (bench.py asserts it) and the line must say n_gpus = 2."""
+    import json
+    import subprocess
+    env = dict(os.environ, HZ_BENCH_DEVICE="0", HZ_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nTx", "40", "--nLevels", "16", "--maxL1Tx", "8", "--maxFeeTx", "4",
+           "--batches-per-launch", "2", "--inflight", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--build-workers", "1"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["distinct_batches"] == 2 and line["value"] > 0 and line["value_e2e"] > 0
+    sh = line["shard_tx"]
+    assert sh["scaling"] == "strong" and sh["transactions_per_rank"] == 20 and "all_gather" in sh["collective"]
