@@ -55,6 +55,7 @@ struct hz_ctx {
     hipEvent_t ev_user_in = nullptr, ev_user_out = nullptr;
     hipStream_t s_ed = nullptr, s_fee = nullptr, s_main = nullptr;   // s_main replaces a NULL caller stream
     hipEvent_t ev_reset = nullptr, ev_front = nullptr, ev_ed = nullptr, ev_fee = nullptr, ev_fix = nullptr;
+    hipEvent_t ev_sha[9] = {};   // HashInputs: chain group g done (0..7), expansion done (8)
     hipStream_t s_fix = nullptr;   // the fixed-base half of the signature check
     ~hz_ctx() {
         if (s_ed) (void)hipStreamDestroy(s_ed);
@@ -65,6 +66,8 @@ struct hz_ctx {
         for (hipEvent_t e : {ev_staged, ev_unpacked})
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee, ev_fix, ev_user_in, ev_user_out, ev_inputs})
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_sha)
             if (e) (void)hipEventDestroy(e);
         for (auto& p : prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     }
@@ -201,6 +204,9 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     }
     for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix, &c->ev_user_in, &c->ev_user_out, &c->ev_inputs})
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    if (lo.sec_hi >= 0)
+        for (hipEvent_t& ev : c->ev_sha)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete c;
         return set_err(HZ_ERR_HIP, "hz_ctx_create: %s (witness buffer %.1f MiB)", hipGetErrorString(e), lo.total * 32.0 / 1048576.0);
@@ -719,7 +725,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             if (tail_now) {
                 // HashInputs needs the roots and the data-availability bits, not the signatures: it runs beside the ladders
                 HZ_HIP(hipStreamWaitEvent(s, c->ev_fee, 0));
-                { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s)); }
+                { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s, c->partitioned ? nullptr : c->s_fee, c->ev_sha, 9)); }
             }
             HZ_HIP(hipStreamWaitEvent(s, c->ev_ed, 0));   // join the signature stream
             break;
@@ -764,7 +770,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             break;
         }
         case T_HASH_INPUTS:
-            HZ_HIP(launch_hash_inputs(make_hi(c, false), s));
+            HZ_HIP(launch_hash_inputs(make_hi(c, false), s, c->s_fee, c->ev_sha, 9));
             break;
         case T_SMT_PROCESSOR: case T_SMT_VERIFIER: {
             SmtMainArgs ma;
@@ -911,7 +917,7 @@ extern "C" hz_status hz_witness_enqueue_tail(hz_ctx* c, void* stream) {
     const Layout& lo = c->lo;
     hz_status st = enqueue_fee(c, sec_ptr(c, lo.sec_fee), lo.sections[lo.sec_fee].n_units, true, s);
     if (st != HZ_OK) return st;
-    { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s)); }
+    { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s, c->s_fee, c->ev_sha, 9)); }
     c->last_stream = s;
     c->enqueued = true;
     return HZ_OK;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "sha_dev.h"
+#include <algorithm>
 #include "smt_dev.h"
 
 #ifndef HZ_SHA_CHAIN_PRIO
@@ -166,23 +167,71 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
     }
 }
 
-// sequential chaining values: chain[b] = state before block b; then the digest -> output signal
-__global__ void k_sha_chain(const HashInputsArgs a) {
-#if HZ_SHA_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(3);   // one wavefront, the step's critical path: issue ahead of the integer-bound wavefronts sharing its SIMD
-#endif
-    const uint32_t bt = blockIdx.x * blockDim.x + threadIdx.x;   // one lane per batch: the chains of different batches are independent
-    if (bt >= a.B) return;
+// Sequential chaining values of blocks [blk0, blk1): chain[b] = state before block b; after the last block the digest -> output signal.
+// One lane per batch (the chains of different batches are independent), 766 dependent compressions at nTx = 2048: the critical
+// path of a step's tail. Alone the lane is bound by its own instruction stream; beside the integer-bound kernels of the other
+// context it used to wait on every block's message load (HBM latency under a store stream: 3.7 ms alone became 16 ms). The
+// workgroup is therefore four wavefronts: all of them prefetch the next HZ_SHA_CHUNK blocks of every batch into LDS (global ->
+// registers before the compute, registers -> LDS after it) while wavefront 0 walks the current chunk out of LDS.
+#define HZ_SHA_CHUNK 8
+#define HZ_SHA_ROW (HZ_SHA_CHUNK * 16 + 1)   // words per batch and chunk, odd: lanes reading the same word of their rows hit different banks
+__global__ __launch_bounds__(256) void k_sha_chain(const HashInputsArgs a) {
+    __shared__ uint32_t buf[2][64 * HZ_SHA_ROW];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t bt0 = blockIdx.x * 64;              // first batch of this workgroup
+    const uint32_t nbt = min(64u, a.B - bt0);          // batches of this workgroup
     const int nb = a.hi.sha.nblocks;
-    const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg) + (size_t)bt * nb * 16;
+    const int blk0 = (int)a.blk0, blk1 = (int)a.blk1;
+    const uint4* msg4 = reinterpret_cast<const uint4*>(a.msg);
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
+    // prefetch: item q = (batch l, uint4 w of the chunk's 8 x 4): the 512 bytes of a batch's chunk are contiguous in the message
+    uint4 pre[8];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t q = tid + 256u * r, l = q >> 5, w = q & 31;
+            const int b = c0 + (int)(w >> 2);
+            pre[r] = (l < nbt && b < blk1) ? msg4[((size_t)(bt0 + l) * nb + b) * 4 + (w & 3)] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stash = [&](int which) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t q = tid + 256u * r, l = q >> 5, w = q & 31;
+            uint32_t* d = &buf[which][l * HZ_SHA_ROW + w * 4];
+            d[0] = pre[r].x; d[1] = pre[r].y; d[2] = pre[r].z; d[3] = pre[r].w;
+        }
+    };
+    fetch(blk0);
+    stash(0);
+    __syncthreads();
+    const bool active = wave == 0 && lane < nbt;
+    const uint32_t bt = bt0 + lane;
     uint32_t* chain = a.chain + (size_t)bt * (nb + 1) * 8;
     uint32_t hv[8];
-    for (int i = 0; i < 8; i++) hv[i] = SHA_H0[i];
-    for (int b = 0; b < nb; b++) {
-        for (int i = 0; i < 8; i++) chain[8 * b + i] = hv[i];
-        uint32_t w16[16];
-        for (int i = 0; i < 16; i++) w16[i] = msgw[16 * b + i];
-        sha256_compress(hv, w16);
+    if (active)
+        for (int i = 0; i < 8; i++) hv[i] = blk0 == 0 ? SHA_H0[i] : chain[8 * blk0 + i];
+    int which = 0;
+    for (int c0 = blk0; c0 < blk1; c0 += HZ_SHA_CHUNK) {
+        const bool more = c0 + HZ_SHA_CHUNK < blk1;
+        if (more) fetch(c0 + HZ_SHA_CHUNK);
+        if (active) {
+            const int cnt = min(HZ_SHA_CHUNK, blk1 - c0);
+            for (int j = 0; j < cnt; j++) {
+                for (int i = 0; i < 8; i++) chain[8 * (c0 + j) + i] = hv[i];
+                uint32_t w16[16];
+                for (int i = 0; i < 16; i++) w16[i] = buf[which][lane * HZ_SHA_ROW + j * 16 + i];
+                sha256_compress(hv, w16);
+            }
+        }
+        if (more) stash(which ^ 1);
+        __syncthreads();
+        which ^= 1;
+    }
+    if (!active) return;
+    if (blk1 < nb) {   // the next group's launch continues from here
+        for (int i = 0; i < 8; i++) chain[8 * blk1 + i] = hv[i];
+        return;
     }
     const Fc out = sha_digest_to_fr(hv);
     if (a.is_main) store_fr(a.glob_base + ((size_t)a.g.hashGlobalInputs * a.B + bt) * 32, out);
@@ -194,18 +243,25 @@ __global__ void k_sha_chain(const HashInputsArgs a) {
     }
 }
 
-// per-block bit-level witness: one lane per block
+// per-block bit-level witness of blocks [blk0, blk1): HZ_SHA_PARTS lanes per (block, batch), each storing one slice of the block's
+// rounds (sha_dev.h). Lane order (part, block, batch): consecutive lanes = consecutive batches (coalesced stores) and a wavefront
+// works on one part. A batch has only 766 blocks: one lane per block left this 0.7 GB-per-batch store stream on 12 wavefronts per
+// batch, each 29 k signals long; eight lanes per block fill the device and shorten the step's tail accordingly.
+#ifndef HZ_SHA_PARTS
+#define HZ_SHA_PARTS 8
+#endif
 __global__ __launch_bounds__(HZ_BLOCK) void k_sha_expand(const HashInputsArgs a) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nb = (uint32_t)a.hi.sha.nblocks;
-    if (gt >= nb * a.B) return;
-    const uint32_t bt = gt % a.B, b = gt / a.B;   // consecutive lanes = consecutive batches: coalesced stores
+    const uint32_t nb = (uint32_t)a.hi.sha.nblocks, nblk = a.blk1 - a.blk0;
+    if (gt >= nblk * a.B * HZ_SHA_PARTS) return;
+    const uint32_t bt = gt % a.B, rest = gt / a.B;
+    const uint32_t b = a.blk0 + rest % nblk, part = rest / nblk;
     const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg) + (size_t)bt * nb * 16;
     const UnitIO hio{a.hi_base, a.B, bt, bt, 0, a.err};
     uint32_t hv[8], w16[16];
     for (int i = 0; i < 8; i++) hv[i] = a.chain[((size_t)bt * (nb + 1) + b) * 8 + i];
     for (int i = 0; i < 16; i++) w16[i] = msgw[16 * b + i];
-    sha256_block_witness(hio, a.hi.sha.blocks + b * a.hi.sha.block_size, hv, w16);
+    sha256_block_witness_part(hio, a.hi.sha.blocks + b * a.hi.sha.block_size, hv, w16, part, HZ_SHA_PARTS);
 }
 
 // ---- Withdraw: lane = instance -----------------------------------------------------------------------
@@ -421,14 +477,39 @@ hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff&
     hipLaunchKernelGGL(k_hash_state_main, grid1(N), dim3(HZ_BLOCK), poseidon_lds_bytes<5>(), s, a);
     return hipGetLastError();
 }
-hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s) {
+// The chain is sequential, the expansion (a 0.7 GB store stream per batch) is not: the blocks are split into groups, group g's
+// expansion runs on the side stream while the main stream chains group g + 1, and the main stream joins at the end. The tail
+// of a step is then about chain + expansion / groups instead of chain + expansion. side == s (or no events): one after the other.
+#ifndef HZ_SHA_GROUPS
+#define HZ_SHA_GROUPS 8
+#endif
+hipError_t launch_hash_inputs(const HashInputsArgs& a0, hipStream_t s, hipStream_t side, hipEvent_t* ev, int n_ev) {
+    HashInputsArgs a = a0;
     const size_t msg_bytes = (size_t)a.hi.sha.nblocks * 64 * a.B;
     hipError_t e = hipMemsetAsync(a.msg, 0, msg_bytes, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_hi_prep, grid1((1 + a.maxL1 + a.nTx + a.F) * a.B), dim3(HZ_BLOCK), 0, s, a);
 #if !defined(HZ_EXPERIMENT_NO_SHA)   // timing experiment only (wrong witness)
-    hipLaunchKernelGGL(k_sha_chain, grid1(a.B), dim3(HZ_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(k_sha_expand, grid1((uint32_t)a.hi.sha.nblocks * a.B), dim3(HZ_BLOCK), 0, s, a);
+    const uint32_t nb = (uint32_t)a.hi.sha.nblocks;
+    const bool piped = side && side != s && ev && n_ev >= 2 && nb >= 64;
+    const uint32_t groups = piped ? (uint32_t)std::min<int>(HZ_SHA_GROUPS, n_ev - 1) : 1u;
+    const uint32_t per = (nb + groups - 1) / groups;
+    for (uint32_t g = 0, b0 = 0; b0 < nb; g++, b0 += per) {
+        a.blk0 = b0;
+        a.blk1 = std::min(nb, b0 + per);
+        hipLaunchKernelGGL(k_sha_chain, dim3((a.B + 63) / 64), dim3(256), 0, s, a);
+        hipStream_t sx = s;
+        if (piped) {
+            if ((e = hipEventRecord(ev[g], s)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(side, ev[g], 0)) != hipSuccess) return e;
+            sx = side;
+        }
+        hipLaunchKernelGGL(k_sha_expand, grid1((a.blk1 - a.blk0) * a.B * HZ_SHA_PARTS), dim3(HZ_BLOCK), 0, sx, a);
+    }
+    if (piped) {
+        if ((e = hipEventRecord(ev[n_ev - 1], side)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(s, ev[n_ev - 1], 0)) != hipSuccess) return e;
+    }
 #endif
     return hipGetLastError();
 }

@@ -161,6 +161,7 @@ struct HashInputsArgs {
     uint32_t fee_newRoot_sc;   // scratch field holding feeTx newStateRoot
     uint8_t* msg;              // device byte buffer for the padded message (nblocks * 64)
     uint32_t* chain;           // device buffer: (nblocks + 1) * 8 chaining words
+    uint32_t blk0, blk1;       // SHA-256 blocks handled by one k_sha_chain / k_sha_expand launch (set by launch_hash_inputs)
 };
 
 struct WithdrawArgs {
@@ -201,7 +202,7 @@ hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s);     // S bits / 
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s);   // the equality of the two sides
 hipError_t launch_fee_front(const FeeFrontArgs& a, hipStream_t s);
 hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s);
-hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s);
+hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s, hipStream_t side = nullptr, hipEvent_t* ev = nullptr, int n_ev = 0);
 hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff& hs, hipStream_t s);
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s);
 

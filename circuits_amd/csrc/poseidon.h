@@ -104,13 +104,40 @@ HZ_HD Fr poseidon_row(const Fr* row, const Fr* st, const Fr* addend) {
 // reduced dot product per output. `Cn` = the next round's constants in c*R^2 form: added to the column
 // sums before the division by R they cost 9 integer additions instead of a modular addition.
 // NC = how many lanes receive a constant (T, or 1 before the first partial round).
+//
+// The loops over the T lanes stay ROLLED (one S-box / one row body per loop: the code of a permutation has to stay small, eight
+// wavefronts of a CU stream through it at different places) and must not index the state with the loop counter: an array indexed
+// at run time lives in scratch memory, and every round then loads and stores its lanes through it (k_hash4 moved 2.6x its
+// witness bytes that way). The state ROTATES instead -- lane 0 is processed, everything moves down one place, the result is
+// appended -- so that every access has a constant index and the state never leaves the registers; T-1 register moves per step.
+template <int T>
+HZ_HD void poseidon_rotate_in(Fr (&a)[T], const Fr& v) {
+#pragma unroll
+    for (int i = 0; i + 1 < T; i++) a[i] = a[i + 1];
+    a[T - 1] = v;
+}
 template <int T, int NC>
 HZ_HD void poseidon_mix_ark(Fr (&st)[T], const Fr* M, const Fr* Cn) {
+    static_assert(NC == T || NC == 1, "constants for every lane or for lane 0 only");
     Fr o[T];
 #pragma unroll
-    for (int i = 0; i < T; i++) o[i] = poseidon_row<T>(M + i * T, st, i < NC ? Cn + i : nullptr);
+    for (int i = 0; i < T; i++) o[i] = st[i];
+    if constexpr (NC == T) {
+#pragma unroll 1
+        for (int i = 0; i < T; i++) poseidon_rotate_in<T>(o, poseidon_row<T>(M + i * T, st, Cn + i));
+    } else {
+        poseidon_rotate_in<T>(o, poseidon_row<T>(M, st, Cn));
+#pragma unroll 1
+        for (int i = 1; i < T; i++) poseidon_rotate_in<T>(o, poseidon_row<T>(M + i * T, st, nullptr));
+    }
 #pragma unroll
     for (int i = 0; i < T; i++) st[i] = o[i];
+}
+// the S-box on every lane (a full round), S-boxes numbered k .. k+T-1
+template <int T, class Sink>
+HZ_HD void poseidon_sbox_layer(Fr (&st)[T], int k, Sink& sink) {
+#pragma unroll 1
+    for (int j = 0; j < T; j++) poseidon_rotate_in<T>(st, poseidon_sbox(st[0], k + j, sink));
 }
 
 // Full permutation; `in` are the T-1 inputs (Montgomery), K the constant block (layout above) in the form the sink asks for:
@@ -127,13 +154,11 @@ HZ_HD Fr poseidon_hash(const Fr* in, const Fr* K, Sink& sink) {
     int k = 0;
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {
-#pragma unroll
-        for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
+        poseidon_sbox_layer<T>(st, k, sink);
         k += T;
         poseidon_mix_ark<T, T>(st, M, K + T * (r + 1));
     }
-#pragma unroll
-    for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
+    poseidon_sbox_layer<T>(st, k, sink);
     k += T;
     poseidon_mix_ark<T, 1>(st, M, K + poseidon_k_e0<T>());
     // Partial rounds, sparse form: lane 0 <- row . (y, lanes) + next constant ; lane i <- lane i + col[i] * y. Two rounds
@@ -168,22 +193,23 @@ HZ_HD Fr poseidon_hash(const Fr* in, const Fr* K, Sink& sink) {
         st[0] = s0;
     }
     {
-        // pending lanes-1.. matrix, with the constants of the following full round
-        Fr o[T];
+        // pending lanes-1.. matrix, with the constants of the following full round (rolled over the rows, rotating like the mix)
+        Fr o[T - 1];
 #pragma unroll
-        for (int i = 1; i < T; i++) o[i] = poseidon_row<T - 1>(K + poseidon_k_dense<T>() + (i - 1) * (T - 1), st + 1, K + poseidon_k_cf<T>() + (i - 1));
+        for (int i = 0; i + 1 < T; i++) o[i] = st[i + 1];
+#pragma unroll 1
+        for (int i = 0; i + 1 < T; i++)
+            poseidon_rotate_in<T - 1>(o, poseidon_row<T - 1>(K + poseidon_k_dense<T>() + i * (T - 1), st + 1, K + poseidon_k_cf<T>() + i));
 #pragma unroll
-        for (int i = 1; i < T; i++) st[i] = o[i];
+        for (int i = 1; i < T; i++) st[i] = o[i - 1];
     }
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {
-#pragma unroll
-        for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
+        poseidon_sbox_layer<T>(st, k, sink);
         k += T;
         poseidon_mix_ark<T, T>(st, M, K + poseidon_k_tail<T>() + T * r);
     }
-#pragma unroll
-    for (int j = 0; j < T; j++) st[j] = poseidon_sbox(st[j], k + j, sink);
+    poseidon_sbox_layer<T>(st, k, sink);
     // only state[0] of the last Mix is the digest
     return poseidon_row<T>(M, st, nullptr);
 }

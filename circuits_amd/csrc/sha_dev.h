@@ -92,6 +92,62 @@ __device__ void sha256_block_witness(const UnitIO& io, uint32_t base, uint32_t* 
     }
 }
 
+// The same witness split over `nparts` lanes: lane `part` stores the schedule steps and the rounds of its slice (and the last lane
+// the final additions); what precedes its slice is recomputed without stores (at most 48 + 64 cheap steps against ~3 600 stored
+// signals per lane at nparts = 8). A block is then nparts independent store streams instead of one 29 k-signal stream.
+__device__ void sha256_block_witness_part(const UnitIO& io, uint32_t base, const uint32_t* hv, const uint32_t* w16, uint32_t part, uint32_t nparts) {
+    uint32_t w[64];
+    for (int t = 0; t < 16; t++) w[t] = w16[t];
+    const int s_lo = 16 + (int)(48u * part / nparts), s_hi = 16 + (int)(48u * (part + 1) / nparts);
+    const int r_lo = (int)(64u * part / nparts), r_hi = (int)(64u * (part + 1) / nparts);
+#pragma unroll 1
+    for (int t = 16; t < 64; t++) {
+        const uint32_t x15 = w[t - 15], x2 = w[t - 2];
+        if (t >= s_lo && t < s_hi) {
+            const uint32_t o = base + (uint32_t)(t - 16) * SHA_SCHED_W;
+            const uint32_t s0 = xor3_dev(io, o, rotr32(x15, 7), rotr32(x15, 18), x15 >> 3);
+            const uint32_t s1 = xor3_dev(io, o + 64, rotr32(x2, 17), rotr32(x2, 19), x2 >> 10);
+            const uint64_t sum = (uint64_t)s1 + w[t - 7] + s0 + w[t - 16];
+            put_word_bits(io, o + 128, sum, 34);
+            w[t] = (uint32_t)sum;
+        } else {
+            const uint32_t s0 = rotr32(x15, 7) ^ rotr32(x15, 18) ^ (x15 >> 3);
+            const uint32_t s1 = rotr32(x2, 17) ^ rotr32(x2, 19) ^ (x2 >> 10);
+            w[t] = s1 + w[t - 7] + s0 + w[t - 16];
+        }
+    }
+    uint32_t a = hv[0], b = hv[1], c = hv[2], d = hv[3], e = hv[4], f = hv[5], g = hv[6], h = hv[7];
+    const uint32_t rbase = base + 48 * SHA_SCHED_W;
+#pragma unroll 1
+    for (int t = 0; t < r_hi; t++) {
+        const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+        const uint32_t ch = (e & f) ^ (~e & g);
+        const uint64_t t1 = (uint64_t)h + S1 + ch + SHA_K[t] + w[t];
+        const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+        const uint32_t mid = b & c, maj = (a & b) ^ (a & c) ^ (b & c);
+        const uint64_t t2 = (uint64_t)S0 + maj;
+        const uint64_t se = (uint64_t)d + (uint32_t)t1, sa = (uint64_t)(uint32_t)t1 + (uint32_t)t2;
+        if (t >= r_lo) {
+            const uint32_t o = rbase + (uint32_t)t * SHA_ROUND_W;
+            (void)xor3_dev(io, o, rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+            put_word_bits(io, o + 64, ch, 32);
+            put_word_bits(io, o + 96, t1, 35);
+            (void)xor3_dev(io, o + 131, rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+            put_word_bits(io, o + 195, mid, 32);
+            put_word_bits(io, o + 227, maj, 32);
+            put_word_bits(io, o + 259, t2, 33);
+            put_word_bits(io, o + 292, se, 33);
+            put_word_bits(io, o + 325, sa, 33);
+        }
+        h = g; g = f; f = e; e = (uint32_t)se; d = c; c = b; b = a; a = (uint32_t)sa;
+    }
+    if (part + 1 == nparts) {
+        const uint32_t fbase = rbase + 64 * SHA_ROUND_W;
+        const uint32_t st[8] = {a, b, c, d, e, f, g, h};
+        for (int i = 0; i < 8; i++) put_word_bits(io, fbase + 33 * i, (uint64_t)hv[i] + st[i], 33);
+    }
+}
+
 // digest (8 big-endian words) as a 256-bit integer reduced mod r -> canonical Fr
 __device__ __forceinline__ Fc sha_digest_to_fr(const uint32_t* hv) {
     Fc r;
