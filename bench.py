@@ -428,12 +428,16 @@ def main():
         for b in range(Bp):
             ctxs[k].stage(b, pin + slot(k, b) * pbytes, pbytes)
 
+    phase_ms = float(os.environ.get("HZ_BENCH_OFFSET_MS", "0"))   # experiment: start the contexts this far apart
+
     def run_steps(n, with_upload=False):
         pending = [False] * inflight
         for i in range(n):
             k = i % inflight
             if pending[k]:
                 ctxs[k].check()
+            elif phase_ms and k:
+                time.sleep(phase_ms * 1e-3)
             ctxs[k].enqueue(streams[k].cuda_stream)   # with_upload: first scatters the inputs staged for this step
             if with_upload:
                 stage(k)

@@ -61,6 +61,7 @@ EXPORTS = [
     "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
+    "hz_symmap_create", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
     "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym", "hz_fr_ops", "hz_poseidon_dag",
 ]
@@ -123,6 +124,16 @@ class Lib:
         c.hz_witness_write_wtns.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p]
         c.hz_symbols_write_sym.argtypes = [vp, ctypes.c_char_p]
         c.hz_symbol_get.argtypes = [vp, u64, ctypes.POINTER(hz_symbol)]
+        c.hz_symmap_create.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(vp)]
+        c.hz_symmap_destroy.argtypes = [vp]
+        c.hz_symmap_destroy.restype = None
+        c.hz_symmap_nvars.argtypes = [vp]
+        c.hz_symmap_nvars.restype = u64
+        c.hz_symmap_unresolved.argtypes = [vp, u64, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_char_p)]
+        c.hz_symmap_unresolved.restype = u64
+        c.hz_witness_read_sym.argtypes = [vp, vp, ctypes.c_int32, u64, u64, vp]
+        c.hz_witness_write_wtns_sym.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_char_p]
+        c.hz_witness_gather.argtypes = [vp, ctypes.c_int32, vp, u64, vp]
         c.hz_symbol_lookup.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(u64)]
         c.hz_constraint_name.restype = ctypes.c_char_p
         c.hz_ctx_set_shard.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
@@ -377,6 +388,13 @@ class Ctx:
     def get(self, name, instance=0):
         return self.read(self.lookup(name), 1, instance)[0]
 
+    def import_sym(self, text):
+        """circom .sym text -> SymMap (the witness in the compiler's variable order)"""
+        b = text.encode() if isinstance(text, str) else text
+        h = ctypes.c_void_p()
+        self.L._check(self.L.c.hz_symmap_create(self.h, b, len(b), ctypes.byref(h)))
+        return SymMap(self, h)
+
     def symbol_count(self):
         return self.L.c.hz_symbol_count(self.h)
 
@@ -384,6 +402,39 @@ class Ctx:
         s = hz_symbol()
         self.L._check(self.L.c.hz_symbol_get(self.h, i, ctypes.byref(s)))
         return s.name.decode(), s.index
+
+
+class SymMap:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def __del__(self):
+        try:
+            self.ctx.L.c.hz_symmap_destroy(self.h)
+        except Exception:
+            pass
+
+    def nvars(self):
+        return self.ctx.L.c.hz_symmap_nvars(self.h)
+
+    def unresolved(self):
+        """[(variable, a label)] of the variables none of whose labels the layout stores"""
+        out = []
+        n = self.ctx.L.c.hz_symmap_unresolved(self.h, 0, None, None)
+        for i in range(n):
+            v, nm = ctypes.c_uint64(), ctypes.c_char_p()
+            self.ctx.L.c.hz_symmap_unresolved(self.h, i, ctypes.byref(v), ctypes.byref(nm))
+            out.append((v.value, nm.value.decode()))
+        return out
+
+    def read(self, first=0, count=None, instance=0):
+        count = self.nvars() - first if count is None else count
+        buf = ctypes.create_string_buffer(32 * max(count, 1))
+        self.ctx.L._check(self.ctx.L.c.hz_witness_read_sym(self.ctx.h, self.h, instance, first, count, buf))
+        return fr_from_bytes(buf.raw[:32 * count])
+
+    def write_wtns(self, path, instance=0):
+        self.ctx.L._check(self.ctx.L.c.hz_witness_write_wtns_sym(self.ctx.h, self.h, instance, path.encode()))
 
 
 _lib = None

@@ -2,13 +2,16 @@
 // `./circuit input.json witness.json` the reference runs at tools/helpers/actions.js:132-146 (and of
 // `snarkjs wtns calculate` for the .wtns output). Plain C++ over the C ABI of include/hermez_witness.h.
 //
-//   hz_witness "RollupMain(2048,32,256,64)" input.json witness.wtns [--sym circuit.sym] [--device 0]
+//   hz_witness "RollupMain(2048,32,256,64)" input.json witness.wtns [--sym out.sym] [--circom-sym circuit.sym] [--device 0]
 //   hz_witness path/to/main.circom input.json witness.json
 //
 // The first argument is `Template(params)` or a .circom file whose `component main = Template(params);` line is
 // used (the reference writes exactly such files: tools/build-circuit.js, test/*.test.js). The output format follows
 // the extension (.wtns binary, anything else witness.json). Exit status 1 and the reference's error text
 // ("Constraint doesn't match <lhs> != <rhs>") when a constraint fails.
+// Without --circom-sym the witness is in this library's own signal numbering (--sym writes the matching symbol file): good for
+// name-based checks, NOT for the reference's prover. With --circom-sym <the .sym of the circom compile> the .wtns is written
+// in the compiler's variable order (name join, hz_symmap_create); it fails listing the variables this layout does not store.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -96,15 +99,22 @@ static bool parse_main(std::string spec, hz_params* p) {
     return false;
 }
 
+static hz_status set_json_unsupported() {
+    fprintf(stderr, "--circom-sym writes .wtns only\n");
+    return HZ_ERR_ARG;
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s \"Template(params)\"|main.circom input.json witness.{wtns,json} [--sym out.sym] [--device N]\n", argv[0]);
+        fprintf(stderr, "usage: %s \"Template(params)\"|main.circom input.json witness.{wtns,json} [--sym out.sym] [--circom-sym circuit.sym] [--device N]\n", argv[0]);
         return 2;
     }
     const char* sym = nullptr;
+    const char* circom_sym = nullptr;
     int device = 0;
     for (int i = 4; i < argc; i++) {
         if (!strcmp(argv[i], "--sym") && i + 1 < argc) sym = argv[++i];
+        else if (!strcmp(argv[i], "--circom-sym") && i + 1 < argc) circom_sym = argv[++i];
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -136,6 +146,23 @@ int main(int argc, char** argv) {
     } else {
         const size_t n = strlen(argv[3]);
         const bool wtns = n > 5 && !strcmp(argv[3] + n - 5, ".wtns");
+        if (circom_sym) {
+            const std::string st_text = slurp(circom_sym, &ok);
+            hz_symmap* m = nullptr;
+            if (!ok) { fprintf(stderr, "cannot read %s\n", circom_sym); hz_ctx_destroy(c); return 2; }
+            st = hz_symmap_create(c, st_text.data(), st_text.size(), &m);
+            if (st == HZ_OK) {
+                const char* nm = nullptr;
+                uint64_t var = 0;
+                const uint64_t miss = hz_symmap_unresolved(m, 0, &var, &nm);
+                for (uint64_t i = 0; i < miss && i < 10; i++) {
+                    hz_symmap_unresolved(m, i, &var, &nm);
+                    fprintf(stderr, "not stored by this layout: variable %llu (%s)\n", (unsigned long long)var, nm);
+                }
+                st = wtns ? hz_witness_write_wtns_sym(c, m, 0, argv[3]) : set_json_unsupported();
+                hz_symmap_destroy(m);
+            }
+        } else
         st = wtns ? hz_witness_write_wtns(c, 0, argv[3]) : hz_witness_write_json(c, 0, argv[3]);
         if (st == HZ_OK && sym) st = hz_symbols_write_sym(c, sym);
         if (st != HZ_OK) { fprintf(stderr, "Error: %s\n", hz_last_error()); rc = 1; }

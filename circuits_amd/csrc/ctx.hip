@@ -56,6 +56,11 @@ struct hz_ctx {
     hipStream_t s_ed = nullptr, s_fee = nullptr, s_main = nullptr;   // s_main replaces a NULL caller stream
     hipEvent_t ev_reset = nullptr, ev_front = nullptr, ev_ed = nullptr, ev_fee = nullptr, ev_fix = nullptr;
     hipEvent_t ev_sha[9] = {};   // HashInputs: chain group g done (0..7), expansion done (8)
+    // HZ_STAGGER=n (experiment): a RollupMain step does not start before the context enqueued just before it (another one) has
+    // finished the n-th piece of its SMT chain: two contexts in flight then run half a step apart instead of in lock-step
+    hipEvent_t ev_mid = nullptr;
+    int stagger_piece = 0;
+    bool mid_valid = false;
     hipStream_t s_fix = nullptr;   // the fixed-base half of the signature check
     ~hz_ctx() {
         if (s_ed) (void)hipStreamDestroy(s_ed);
@@ -204,6 +209,10 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     }
     for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix, &c->ev_user_in, &c->ev_user_out, &c->ev_inputs})
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    if (lo.p.tmpl == T_ROLLUP_MAIN && getenv("HZ_STAGGER") && atoi(getenv("HZ_STAGGER")) > 0 && e == hipSuccess) {
+        c->stagger_piece = atoi(getenv("HZ_STAGGER"));
+        e = hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming);
+    }
     if (lo.sec_hi >= 0)
         for (hipEvent_t& ev : c->ev_sha)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
@@ -534,10 +543,14 @@ static Hash4Args make_hash4_rtx(uint8_t* base, Fr* sc, uint32_t n_units, const R
 // the SMT chain kernel, in chunks of levels (bottom level first); every launch is its own profile entry of the same name
 static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa, const char* name, hipStream_t s) {
     const int n = (int)sa.n_levels, chunk = smt_chunk_levels(sa);
+    int piece = 0;
     for (int hi = n - 1; hi >= 0; hi -= chunk) {
-        ProfScope ps(c, s, name, sa.n_units);
-        const hipError_t e = launch_smt_levels(sa, hi, hi - chunk + 1 > 0 ? hi - chunk + 1 : 0, s);
-        if (e != hipSuccess) return e;
+        {
+            ProfScope ps(c, s, name, sa.n_units);
+            const hipError_t e = launch_smt_levels(sa, hi, hi - chunk + 1 > 0 ? hi - chunk + 1 : 0, s);
+            if (e != hipSuccess) return e;
+        }
+        if (c->ev_mid && sa.n_proc == 2 && ++piece == c->stagger_piece) (void)hipEventRecord(c->ev_mid, s);
     }
     return hipSuccess;
 }
@@ -556,10 +569,14 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         // the two halves of the check (S*B8 and R8 + h*8A) are independent: two kernels on two streams, then the equality
         hipStream_t sfix = c->exclusive ? c->s_ed : c->s_fix;
         HZ_HIP(hipStreamWaitEvent(sfix, c->ev_front, 0));
+#ifndef HZ_EXPERIMENT_SKIP_EDDSA   // timing experiments only (tools/variant.sh): what a step costs without one of its kernels
         { ProfScope ps(c, sfix, "eddsa_fix", n_units); HZ_HIP(launch_eddsa_fix(ea, sfix)); }
+#endif
         HZ_HIP(hipEventRecord(c->ev_fix, sfix));
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_front, 0));
+#ifndef HZ_EXPERIMENT_SKIP_EDDSA
         { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed)); }
+#endif
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_fix, 0));
         { ProfScope ps(c, c->s_ed, "eddsa_final", n_units); HZ_HIP(launch_eddsa_final(ea, c->s_ed)); }
         HZ_HIP(hipEventRecord(c->ev_ed, c->s_ed));
@@ -567,8 +584,10 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     {
         Hash4Args h4 = make_hash4_rtx(base, sc, n_units, lo.rtx);
         h4.u0 = u0; h4.ucnt = ucnt;
+#ifndef HZ_EXPERIMENT_SKIP_HASH4
         ProfScope ps(c, s, "hash4", n_units);
         HZ_HIP(launch_hash4(h4, s));
+#endif
     }
     SmtArgs sa;
     memset(&sa, 0, sizeof sa);
@@ -576,7 +595,9 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     sa.p[0] = make_proc(lo.rtx.p1, sib1, 0);
     sa.p[1] = make_proc(lo.rtx.p2, sib2, 1);
     sa.u0 = u0; sa.ucnt = ucnt;
+#ifndef HZ_EXPERIMENT_SKIP_SMT
     HZ_HIP(enqueue_smt_chain(c, sa, "smt", s));
+#endif
     RtxBackArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.base = base; ba.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; ba.scratch = sc; ba.err = err; ba.n_units = n_units; ba.L = (uint32_t)lo.p.L;
@@ -703,6 +724,12 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
     c->prof_used = 0;
     switch (lo.p.tmpl) {
         case T_ROLLUP_MAIN: {
+            static hz_ctx* g_last = nullptr;   // HZ_STAGGER experiment (single-threaded callers only)
+            if (c->ev_mid) {
+                if (g_last && g_last != c && g_last->ev_mid && g_last->mid_valid) HZ_HIP(hipStreamWaitEvent(s, g_last->ev_mid, 0));
+                g_last = c;
+                c->mid_valid = true;
+            }
             MainFrontArgs fa;
             memset(&fa, 0, sizeof fa);
             fa.tx_base = sec_ptr(c, lo.sec_tx); fa.fee_base = sec_ptr(c, lo.sec_fee); fa.glob_base = sec_ptr(c, lo.sec_glob);
@@ -989,6 +1016,45 @@ extern "C" hz_status hz_witness_read(hz_ctx* c, int32_t instance, uint64_t first
         hipLaunchKernelGGL(k_gather_virtual, dim3((unsigned)std::min<uint64_t>((g.count + 255) / 256, 4096)), dim3(256), 0, c->s_main, g);
         HZ_HIP(hipGetLastError());
         HZ_HIP(hipMemcpyAsync(out + done * 32, c->stage.p, g.count * 32, hipMemcpyDeviceToHost, c->s_main));
+        HZ_HIP(hipStreamSynchronize(c->s_main));
+    }
+    return HZ_OK;
+}
+
+// arbitrary elements of the per-instance witness (the circom-ordered view of formats.hip: hz_witness_read_sym)
+__global__ void k_gather_index(const GatherArgs a, const uint64_t* __restrict__ index) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.count; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = index[t];
+        uint32_t si = a.nsec - 1;
+        while (si > 0 && a.sec[si].vbase > v) si--;
+        const SecMap m = a.sec[si];
+        const uint64_t rel = v - m.vbase;
+        const uint64_t p = m.base + (rel / m.upi) * m.n_units + (uint64_t)a.inst * m.upi + rel % m.upi;
+        a.out[2 * t] = a.wit[2 * p];
+        a.out[2 * t + 1] = a.wit[2 * p + 1];
+    }
+}
+extern "C" hz_status hz_witness_gather(hz_ctx* c, int32_t instance, const uint64_t* index, uint64_t count, uint8_t* out) {
+    if (!c || !index || !out) return set_err(HZ_ERR_ARG, "hz_witness_gather: null argument");
+    const Layout& lo = c->lo;
+    if (instance < 0 || (uint32_t)instance >= lo.n_inst) return set_err(HZ_ERR_ARG, "hz_witness_gather: bad instance");
+    for (uint64_t i = 0; i < count; i++)
+        if (index[i] >= lo.per_instance) return set_err(HZ_ERR_ARG, "hz_witness_gather: index %llu beyond the witness", (unsigned long long)index[i]);
+    HZ_HIP(hipSetDevice(c->device));
+    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(count, 1), 1u << 21);
+    DevBuf didx, dout;
+    HZ_HIP(didx.alloc(chunk * 8));
+    HZ_HIP(dout.alloc(chunk * 32));
+    GatherArgs g;
+    memset(&g, 0, sizeof g);
+    g.wit = (const uint4*)c->wit.p; g.out = (uint4*)dout.p; g.inst = (uint32_t)instance; g.nsec = (uint32_t)lo.sections.size();
+    for (size_t i = 0; i < lo.sections.size() && i < 4; i++) g.sec[i] = SecMap{lo.sections[i].vbase, lo.sections[i].base, lo.sections[i].upi, lo.sections[i].n_units};
+    for (uint64_t done = 0; done < count; done += chunk) {
+        g.count = std::min<uint64_t>(chunk, count - done);
+        HZ_HIP(hipMemcpyAsync(didx.p, index + done, g.count * 8, hipMemcpyHostToDevice, c->s_main));
+        hipLaunchKernelGGL(k_gather_index, dim3((unsigned)std::min<uint64_t>((g.count + 255) / 256, 4096)), dim3(256), 0, c->s_main, g, (const uint64_t*)didx.p);
+        HZ_HIP(hipGetLastError());
+        HZ_HIP(hipMemcpyAsync(out + done * 32, dout.p, g.count * 32, hipMemcpyDeviceToHost, c->s_main));
         HZ_HIP(hipStreamSynchronize(c->s_main));
     }
     return HZ_OK;

@@ -5,6 +5,9 @@
 //   hz_witness_write_wtns   snarkjs .wtns: magic "wtns", version 2, section 1 = {n8 = 32, prime, nVars},
 //                           section 2 = nVars x 32-byte little-endian elements (what `snarkjs wtns calculate` emits)
 //   hz_symbols_write_sym    circom .sym lines "labelIdx,varIdx,componentIdx,name" for the stored signals
+//   hz_symmap_*             IMPORT of a circom .sym (the compiler's own numbering of the circuit): name join against the stored
+//                           signals -> the witness in circom's variable order (hz_witness_read_sym / hz_witness_write_wtns_sym),
+//                           the form the reference's r1cs / zkey consume
 // Together with hz_ctx_create / hz_witness_run they are the whole of the native witness binary
 // `./circuit input.json witness.json` (circuits_amd/csrc/cli/hz_witness.cpp).
 #include <stdio.h>
@@ -255,6 +258,121 @@ extern "C" hz_status hz_symbols_write_sym(const hz_ctx* ctx, const char* path) {
         if (st != HZ_OK) { fclose(f); return st; }
         // every stored signal is its own variable: label index = variable index; component ids are not modelled
         fprintf(f, "%llu,%llu,0,%s\n", (unsigned long long)s.index, (unsigned long long)s.index, s.name);
+    }
+    if (ferror(f)) { fclose(f); return set_err(HZ_ERR_ARG, "write to %s failed", path); }
+    if (fclose(f) != 0) return set_err(HZ_ERR_ARG, "close of %s failed", path);
+    return HZ_OK;
+}
+
+// ---- circom .sym import --------------------------------------------------------------------------------------
+// circom writes one line per signal LABEL: `labelIdx,varIdx,componentIdx,dotted.name`. varIdx is the signal's position in the
+// witness the r1cs / zkey refer to, or -1 when constraint reduction eliminated it; labels that circom wired together (a component
+// input and the signal it was connected to) share one varIdx. This library numbers the signals it stores in its own order
+// (include/hz_layout.h) and does not store linear signals a reducing compile eliminates, so its .wtns cannot be fed to a prover
+// as is. The import joins the two by NAME: variable v is resolved when ANY label of v is a stored signal. Variables none of
+// whose labels is stored are reported (hz_symmap_unresolved): such a circuit build keeps signals this layout drops, and its
+// witness cannot be produced from this one.
+struct hz_symmap {
+    std::vector<uint64_t> index;          // per variable: index in this library's per-instance witness, ~0 = unresolved
+    std::vector<std::string> first_label; // per unresolved variable (in variable order): one of its names
+    std::vector<uint64_t> unresolved;     // variable numbers
+};
+
+extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_t len, hz_symmap** out) {
+    if (!ctx || !text || !out) return set_err(HZ_ERR_ARG, "hz_symmap_create: null argument");
+    hz_symmap* m = new hz_symmap();
+    std::vector<std::string> label;   // one label per variable, kept until the variable resolves
+    const char* p = text;
+    const char* e = text + len;
+    uint64_t line_no = 0;
+    while (p < e) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+        const char* le = nl ? nl : e;
+        line_no++;
+        // labelIdx,varIdx,componentIdx,name
+        const char* q = p;
+        long long f[3] = {0, 0, 0};
+        bool ok = le > p;
+        for (int k = 0; k < 3 && ok; k++) {
+            char* end = nullptr;
+            f[k] = strtoll(q, &end, 10);
+            ok = end != q && end < le && *end == ',';
+            q = end + 1;
+        }
+        if (le > p && !(le - p == 1 && *p == '\r')) {
+            if (!ok) { delete m; return set_err(HZ_ERR_INPUT, ".sym line %llu: expected labelIdx,varIdx,componentIdx,name", (unsigned long long)line_no); }
+            const char* ne = le;
+            while (ne > q && (ne[-1] == '\r' || ne[-1] == ' ')) ne--;
+            const long long var = f[1];
+            if (var >= 0) {
+                if ((uint64_t)var >= (1ull << 40)) { delete m; return set_err(HZ_ERR_INPUT, ".sym line %llu: variable index out of range", (unsigned long long)line_no); }
+                if ((uint64_t)var >= m->index.size()) { m->index.resize((size_t)var + 1, ~0ull); label.resize((size_t)var + 1); }
+                if (m->index[(size_t)var] == ~0ull) {
+                    const std::string name(q, (size_t)(ne - q));
+                    uint64_t idx = 0;
+                    if (var == 0 && (name == "one" || name == "main.one")) idx = 0, m->index[0] = 0;
+                    else if (hz_symbol_lookup(ctx, name.c_str(), &idx)) m->index[(size_t)var] = idx;
+                    else if (label[(size_t)var].empty()) label[(size_t)var] = name;
+                }
+            }
+        }
+        p = nl ? nl + 1 : e;
+    }
+    if (!m->index.empty() && m->index[0] == ~0ull) m->index[0] = 0;   // variable 0 is the constant 1 whether or not the file names it
+    for (size_t v = 0; v < m->index.size(); v++)
+        if (m->index[v] == ~0ull) {
+            m->unresolved.push_back(v);
+            m->first_label.push_back(label[v].empty() ? std::string("(no label in the file)") : label[v]);
+        }
+    *out = m;
+    return HZ_OK;
+}
+extern "C" void hz_symmap_destroy(hz_symmap* m) { delete m; }
+extern "C" uint64_t hz_symmap_nvars(const hz_symmap* m) { return m ? m->index.size() : 0; }
+extern "C" uint64_t hz_symmap_unresolved(const hz_symmap* m, uint64_t i, uint64_t* var, const char** name) {
+    if (!m) return 0;
+    if (i < m->unresolved.size()) {
+        if (var) *var = m->unresolved[i];
+        if (name) *name = m->first_label[i].c_str();
+    }
+    return m->unresolved.size();
+}
+static hz_status symmap_usable(const hz_symmap* m, const char* who) {
+    if (!m) return set_err(HZ_ERR_ARG, "%s: null symbol map", who);
+    if (!m->unresolved.empty())
+        return set_err(HZ_ERR_INPUT, "%s: %zu of %zu variables of the .sym are not stored by this layout (first: variable %llu, %s)", who, m->unresolved.size(),
+                       m->index.size(), (unsigned long long)m->unresolved[0], m->first_label[0].c_str());
+    return HZ_OK;
+}
+extern "C" hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* m, int32_t instance, uint64_t first, uint64_t count, uint8_t* out) {
+    const hz_status st = symmap_usable(m, "hz_witness_read_sym");
+    if (st != HZ_OK) return st;
+    if (first > m->index.size() || count > m->index.size() - first) return set_err(HZ_ERR_ARG, "hz_witness_read_sym: range beyond the %zu variables", m->index.size());
+    return hz_witness_gather(ctx, instance, m->index.data() + first, count, out);
+}
+extern "C" hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const char* path) {
+    if (!ctx || !path) return set_err(HZ_ERR_ARG, "hz_witness_write_wtns_sym: null argument");
+    hz_status st = symmap_usable(m, "hz_witness_write_wtns_sym");
+    if (st != HZ_OK) return st;
+    const uint64_t n = m->index.size();
+    if (n > 0xFFFFFFFFull) return set_err(HZ_ERR_ARG, "hz_witness_write_wtns_sym: %llu variables do not fit the format's 32-bit count", (unsigned long long)n);
+    FILE* f = fopen(path, "wb");
+    if (!f) return set_err(HZ_ERR_ARG, "cannot open %s for writing", path);
+    auto u32 = [&](uint32_t v) { fwrite(&v, 4, 1, f); };
+    auto u64 = [&](uint64_t v) { fwrite(&v, 8, 1, f); };
+    fwrite("wtns", 1, 4, f);
+    u32(2); u32(2);
+    u32(1); u64(4 + 32 + 4);
+    u32(32);
+    fwrite(R_LIMBS, 8, 4, f);
+    u32((uint32_t)n);
+    u32(2); u64(n * 32);
+    std::vector<uint8_t> buf(CHUNK * 32);
+    for (uint64_t i = 0; i < n; i += CHUNK) {
+        const uint64_t c = n - i < CHUNK ? n - i : CHUNK;
+        st = hz_witness_gather(ctx, instance, m->index.data() + i, c, buf.data());
+        if (st != HZ_OK) { fclose(f); return st; }
+        if (fwrite(buf.data(), 32, c, f) != c) { fclose(f); return set_err(HZ_ERR_ARG, "short write to %s", path); }
     }
     if (ferror(f)) { fclose(f); return set_err(HZ_ERR_ARG, "write to %s failed", path); }
     if (fclose(f) != 0) return set_err(HZ_ERR_ARG, "close of %s failed", path);

@@ -56,7 +56,14 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HAS
 #ifndef HZ_SMT_WAVES
 #define HZ_SMT_WAVES 2
 #endif
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT_WAVES))) void k_smt(const SmtArgs a) {
+// Register budget: two wavefronts of this kernel per SIMD saturate the integer pipe; what they leave of the 512 registers decides
+// whether a store-bound wavefront of another kernel (the SHA-256 expansion: 72 registers) can sit beside them.
+#ifdef HZ_SMT_VGPRS
+#define HZ_SMT_VGPR_ATTR __attribute__((amdgpu_num_vgpr(HZ_SMT_VGPRS)))
+#else
+#define HZ_SMT_VGPR_ATTR
+#endif
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT_WAVES))) HZ_SMT_VGPR_ATTR void k_smt(const SmtArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
     const Fr* K3 = poseidon_consts_w<3>(lds);

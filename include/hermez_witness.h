@@ -195,6 +195,22 @@ hz_status hz_witness_write_json(hz_ctx* ctx, int32_t instance, const char* path)
 hz_status hz_witness_write_wtns(hz_ctx* ctx, int32_t instance, const char* path);
 hz_status hz_symbols_write_sym(const hz_ctx* ctx, const char* path);
 
+/* circom .sym import: the witness in the COMPILER's variable order. The reference's prover steps (snarkjs / rapidsnark on the
+ * r1cs + zkey of tools/helpers/actions.js:30-68,148-170) consume circom's numbering, which only the compiler's .sym records
+ * (`labelIdx,varIdx,componentIdx,name`; varIdx = -1 for eliminated signals; wired labels share a varIdx). hz_symmap_create joins
+ * it by name with the signals this library stores: a variable resolves when any of its labels is stored. hz_symmap_unresolved
+ * returns how many variables did not (and the i-th one's number and a label): a compile that keeps signals this layout drops
+ * cannot be served. hz_witness_read_sym / hz_witness_write_wtns_sym then deliver the witness in that order;
+ * hz_witness_gather reads arbitrary positions of this library's own per-instance numbering. */
+typedef struct hz_symmap hz_symmap;
+hz_status hz_symmap_create(const hz_ctx* ctx, const char* sym_text, size_t len, hz_symmap** out);
+void hz_symmap_destroy(hz_symmap* map);
+uint64_t hz_symmap_nvars(const hz_symmap* map);
+uint64_t hz_symmap_unresolved(const hz_symmap* map, uint64_t i, uint64_t* var, const char** name);
+hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instance, uint64_t first_var, uint64_t count, uint8_t* out);
+hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instance, const char* path);
+hz_status hz_witness_gather(hz_ctx* ctx, int32_t instance, const uint64_t* index, uint64_t count, uint8_t* out);
+
 /* symbols ------------------------------------------------------------------------------------ */
 uint64_t hz_symbol_count(const hz_ctx* ctx);
 hz_status hz_symbol_get(const hz_ctx* ctx, uint64_t i, hz_symbol* out);

@@ -506,3 +506,68 @@ def test_bulk_upload_matches_set_input(hz, batch):
     assert g.read_raw_bytes() == ref.read_raw_bytes()
     hz.host_free(pin)
     hz.host_free(pin2)
+
+
+def test_circom_sym_import_permutes_the_witness(hz, batch, tmp_path):
+    """a circom .sym (the compiler's own variable numbering, `labelIdx,varIdx,componentIdx,name`, -1 for
+    eliminated signals, wired labels sharing a variable) is joined by name with the stored signals and the witness is delivered
+    in THAT order -- what the reference's r1cs / zkey consume (tools/helpers/actions.js:148-170). The .sym here is hand-written:
+    the stored signals of RollupMain(8,16,3,4) in a seeded random variable order, plus the kinds of lines a real compile emits."""
+    import json
+    import os
+    import random
+    import subprocess
+    g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4)
+    inp = batch.get_input()
+    g.set_inputs(inp)
+    g.run()
+    n = g.symbol_count()
+    own = g.read(0, g.witness_len())
+    rng = random.Random(2026)
+    take = sorted(rng.sample(range(n), 5000))
+    names = [g.symbol(i) for i in take]                      # (name, own index)
+    var_of = list(range(1, len(names) + 1))
+    rng.shuffle(var_of)                                      # circom's variable number of each taken signal
+    lines, label = ["0,0,0,one"], 1
+    for (nm, _), v in zip(names, var_of):
+        if label % 7 == 0:                                   # a wired label that this layout does not store, same variable, listed FIRST
+            lines.append("%d,%d,3,%s" % (label, v, "main.someComponent[%d].in" % label))
+            label += 1
+        lines.append("%d,%d,2,%s" % (label, v, nm))
+        label += 1
+        if label % 11 == 0:                                  # a signal constraint reduction eliminated
+            lines.append("%d,-1,5,main.rollupTx[0].processor1.levels[3].oldProofHash.h.ark[%d].out[1]" % (label, label))
+            label += 1
+    rng.shuffle(lines)
+    text = "\n".join(lines) + "\n"
+    m = g.import_sym(text)
+    assert m.nvars() == len(names) + 1 and m.unresolved() == []
+    got = m.read()
+    assert got[0] == 1
+    for (nm, idx), v in zip(names, var_of):
+        assert got[v] == own[idx], nm
+    # .wtns in that order, through the ABI and through the native binary (--circom-sym)
+    w1 = str(tmp_path / "ordered.wtns")
+    m.write_wtns(w1)
+    assert _parse_wtns(w1) == got
+    spath, ipath, w2 = str(tmp_path / "circuit.sym"), str(tmp_path / "input.json"), str(tmp_path / "cli.wtns")
+    open(spath, "w").write(text)
+    json.dump({k: (str(v) if isinstance(v, int) else v) for k, v in inp.items()}, open(ipath, "w"), default=str)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "circuits_amd", "bin", "hz_witness")
+    subprocess.run([cli, "RollupMain(8,16,3,4)", ipath, w2, "--circom-sym", spath], check=True)
+    assert open(w2, "rb").read() == open(w1, "rb").read()
+    # a compile that keeps a signal this layout drops: reported by variable and name, and no witness is written
+    bad = text + "%d,%d,9,main.rollupTx[1].balanceUpdater.computeFee.mux256.notStoredHere\n" % (label, len(names) + 1)
+    mb = g.import_sym(bad)
+    assert mb.nvars() == len(names) + 2
+    assert mb.unresolved() == [(len(names) + 1, "main.rollupTx[1].balanceUpdater.computeFee.mux256.notStoredHere")]
+    from circuits_amd.capi import HzError
+    with pytest.raises(HzError) as e:
+        mb.read()
+    assert e.value.status == 4 and "notStoredHere" in str(e.value)
+    open(spath, "w").write(bad)
+    r = subprocess.run([cli, "RollupMain(8,16,3,4)", ipath, str(tmp_path / "no.wtns"), "--circom-sym", spath], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "notStoredHere" in r.stderr
+    with pytest.raises(HzError):
+        g.import_sym("1,2,x\n")

@@ -21,7 +21,7 @@ f = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
     with open(out + "/kernel_stats.csv", "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats -- %s   (round 1, MI355X)\n" % cmd)
+        o.write("# rocprofv3 --kernel-trace --stats -- %s   (round 2, MI355X)\n" % cmd)
         o.write("name,calls,total_duration_us,average_us,percentage\n")
         for r in rows:
             o.write("%s,%s,%.0f,%.1f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
@@ -41,9 +41,9 @@ if f:
                 g = max(x[0] for x in v)
                 d = [x[1] for x in sorted((y for y in v if y[0] == g), key=lambda y: y[2])]   # in time order
                 if d and sum(d) > 1000:
-                    # the profiled command enqueues 12 steps (1 checked + 1 warm-up + 4 timed + 3 latency + 3 exclusive): a kernel
+                    # the profiled command enqueues 13 steps (2 checked + 1 warm-up + 4 timed + 3 latency + 3 exclusive): a kernel
                     # launched k times per step has 3k exclusive dispatches
-                    k_per_step = max(1, int(round(len(d) / 12.0)))
+                    k_per_step = max(1, int(round(len(d) / 13.0)))
                     alone = d[-3 * k_per_step:]
                     o.write("%s,%d,%d,%.1f,%.1f\n" % (k, g, len(d), sum(d) / len(d), sum(alone) / len(alone)))
     print(open(out + "/kernel_stats.csv").read()[:2500])
@@ -98,7 +98,11 @@ if fetch or write:
             # grid that move different amounts: the mean over its largest-grid dispatches is what bench.py's per-launch mean compares with
             fg = [x[0] for x in fetch.get(k, []) if x[1] == g] or [0]
             wg = [x[0] for x in write.get(k, []) if x[1] == g] or [0]
-            kernels["k_" + k.split("<")[0].replace("k_", "")] = {"fetch_bytes": max(fv) * 1024 * f_corr, "write_bytes": max(wv) * 1024 * w_corr,
+            key = "k_" + k.split("<")[0].replace("k_", "")
+            if k.startswith("poseidon_batch_kernel<"):   # poseidon_batch_kernel<T, witness>: one entry per width and mode
+                targ = k[k.index("<") + 1:].rstrip(">").replace(" ", "").split(",")
+                key = "poseidon_t%s_%s" % (targ[0], "witness" if targ[1] in ("true", "1") else "digest")
+            kernels[key] = {"fetch_bytes": max(fv) * 1024 * f_corr, "write_bytes": max(wv) * 1024 * w_corr,
                                                                  "fetch_bytes_mean": sum(fg) / len(fg) * 1024 * f_corr, "write_bytes_mean": sum(wg) / len(wg) * 1024 * w_corr,
                                                                  "largest_grid_dispatches": max(len(fg), len(wg))}
     bpl = 32
