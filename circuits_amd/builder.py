@@ -451,7 +451,7 @@ class BatchBuilder:
                 t["amountF"] = fix2float(t.get("amount", 0))
         for i, t in enumerate(ordered):
             k = t.get("rqOffset", 0)
-            if k:
+            if k and "rqTxCompressedDataV2" not in t:   # explicit rq fields (what the signer committed to) are kept as given
                 j = i + k if k <= 3 else i - (8 - k)
                 if not (0 <= j < len(ordered)) or ordered[j].get("onChain"):
                     raise ValueError("rqOffset %d of tx %d does not point at an L2 tx of this batch" % (k, i))
@@ -477,6 +477,20 @@ class BatchBuilder:
             new_account = 1 if (on and from_idx == 0) else 0
             aux_from = 0
             aux_to = tx.get("auxToIdx", 0)
+            if not on and to_idx == 0 and from_idx and "auxToIdx" not in tx:
+                # transfer to ethAddr / to Bjj: the coordinator looks the receiver up (lowest idx with that address -- and key, when the
+                # address is the "any" address -- holding the token), as the reference's JS BatchBuilder does for its suites
+                to_eth = tx.get("toEthAddr", 0)
+                for cand in sorted(db.leaves):
+                    lf = db.leaves[cand]
+                    if lf["tokenID"] != tx.get("tokenID", 0):
+                        continue
+                    if to_eth != (1 << 160) - 1 and lf["ethAddr"] == to_eth:
+                        aux_to = cand
+                        break
+                    if to_eth == (1 << 160) - 1 and lf["ay"] == tx.get("toBjjAy", 0) and lf["sign"] == tx.get("toBjjSign", 0):
+                        aux_to = cand
+                        break
             zero_state = {"tokenID": 0, "nonce": 0, "sign": 0, "balance": 0, "ay": 0, "ethAddr": 0}
             st1, st2 = dict(zero_state), dict(zero_state)
             sib1, sib2 = [], []
@@ -604,7 +618,7 @@ class BatchBuilder:
             inp["amountF"].append(amount_f)
             inp["txCompressedDataV2"].append(0 if on else build_tx_compressed_data_v2(tx))
             inp["fromIdx"].append(from_idx); inp["auxFromIdx"].append(aux_from)
-            inp["toIdx"].append(to_idx); inp["auxToIdx"].append(tx.get("auxToIdx", 0))
+            inp["toIdx"].append(to_idx); inp["auxToIdx"].append(aux_to)
             inp["toBjjAy"].append(tx.get("toBjjAy", 0)); inp["toEthAddr"].append(tx.get("toEthAddr", 0))
             inp["maxNumBatch"].append(tx.get("maxNumBatch", 0)); inp["onChain"].append(on); inp["newAccount"].append(new_account)
             inp["rqOffset"].append(tx.get("rqOffset", 0)); inp["rqTxCompressedDataV2"].append(tx.get("rqTxCompressedDataV2", 0))
