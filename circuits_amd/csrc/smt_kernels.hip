@@ -56,6 +56,58 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HAS
 #ifndef HZ_SMT_WAVES
 #define HZ_SMT_WAVES 2
 #endif
+
+// The empty-subtree levels of a proof (smt_dev.h) are pure stores of a constant block; the levels that hash data are pure integer
+// arithmetic. Run one after the other -- or in different kernels: a store-bound grid gets few dispatch slots beside a resident
+// integer-bound one (tools/experiments/overlap_probe.py: fills beside Poseidon keep 10 % of their rate) -- they cost the sum of
+// their times. Inside ONE instruction stream the vector-memory port and the integer pipe do overlap: every S-box of a level that
+// hashes also stores a few signals of an empty level's block (wave-uniform cursor, scalar registers), so the constant blocks leave
+// in the shadow of the arithmetic. HZ_SMT_BG_STORES = 0: every level stores its own block (round-1 behaviour).
+#ifndef HZ_SMT_BG_STORES
+#define HZ_SMT_BG_STORES 1
+#endif
+struct BgZero {
+    uint8_t* base;            // section base
+    uint32_t n_units, unit;
+    uint32_t off0;            // signal offset of level 0's hash block of this chain (o.levels + LV_OLDHASH / LV_NEWHASH)
+    uint32_t j, j_end;        // empty levels still to store: [j, j_end), wave-uniform
+    uint32_t s;               // next signal of level j's block
+    uint32_t per;             // signals per S-box
+    // The constants come through the scalar cache like Poseidon's own (s_load + v_mov). Staging the block in LDS was measured and is
+    // slower (k_smt 22.4 -> 27.2 ms): LDS reads share the lgkmcnt counter with the scalar loads that stream the round constants.
+    __device__ __forceinline__ void one() {
+        Fc c;
+#pragma unroll
+        for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[s][q];
+        store_fr(base + ((size_t)(off0 + LV_SIZE * j + s) * n_units + unit) * 32, c);
+        if (++s == 243) { s = 0; j++; }
+    }
+    __device__ __forceinline__ void emit() {
+        for (uint32_t q = 0; q < per && j < j_end; q++) one();
+    }
+    __device__ __forceinline__ void flush() {
+        while (j < j_end) one();
+    }
+};
+struct SmtSboxSink {
+    static constexpr bool kCanon = WitSboxSink::kCanon;
+    WitSboxSink w;
+    BgZero* bg;
+    __device__ __forceinline__ void operator()(int k, const Fr& x2, const Fr& x4, const Fr& x5) const {
+        w(k, x2, x4, x5);
+        if (HZ_SMT_BG_STORES) bg->emit();
+    }
+};
+// max over the wavefront of a small non-negative integer (< 64), as a scalar
+__device__ __forceinline__ uint32_t wave_max_u6(uint32_t v) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int b = 5; b >= 0; b--) {
+        const uint32_t cand = r | (1u << b);
+        if (__any(v >= cand)) r = cand;
+    }
+    return r;
+}
 // Register budget: two wavefronts of this kernel per SIMD saturate the integer pipe; what they leave of the 512 registers decides
 // whether a store-bound wavefront of another kernel (the SHA-256 expansion: 72 registers) can sit beside them.
 #ifdef HZ_SMT_VGPRS
@@ -165,6 +217,20 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
         io.chk(P.cid_sm_final, last_sum, one);
     }
     const Fr mU = fr_add(m, U), OU = fr_add(O, U);
+    // Levels that are empty for STRUCTURAL reasons (child and sibling are zero whatever the hashes are): from the level thr_lane on.
+    // Old side: the child of level k is root(k+1) = h1old * s_a(k+1), zero from k = kx on (k = kl on when m = 0: update / nop / insert
+    // into an empty slot); new side: both switcher inputs vanish above kx (from kl on when m = 0). The siblings above the highest
+    // non-zero one are zero by inspection. thr_wave = the first level that is empty for every lane of the wavefront.
+    uint32_t thr_wave = (uint32_t)n;
+    if (HZ_SMT_BG_STORES) {
+        const bool m_zero = fr_is_zero(m);
+        const uint64_t nz = ~zmask & ((n < 64 ? (1ull << n) : 0ull) - 1ull);
+        const int hi_nz = nz ? 63 - __builtin_clzll(nz) : -1;
+        int thr_lane = m_zero ? kl : (new_side ? kx + 1 : kx);
+        if (thr_lane < hi_nz + 1) thr_lane = hi_nz + 1;
+        if (thr_lane > n) thr_lane = n;
+        thr_wave = wave_max_u6((uint32_t)thr_lane);
+    }
     // level chain, bottom-up. Both sides run the level hash through ONE inlined copy of the permutation (the kernel's
     // hot code): wavefronts of the old and the new side that share a CU then share its instruction-cache lines.
     // levels k_hi .. k_lo of the chain; the running root travels between chunks through the scratch slot of the final root
@@ -196,10 +262,25 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
             io.put_m(lv + LV_NEWSW_AUX, aux); io.put_m(lv + LV_AUX1, aux1); io.put_m(lv + LV_AUX2, aux2);
             io.put_m(lv + LV_NEWSW_L, swL); io.put_m(lv + LV_NEWSW_R, swR);
         }
-        WitSboxSink sk = io.sbox_sink(lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
         Fr h;
-        if (HZ_SMT_ZERO_FAST && __all(fr_is_zero(hin[0]) && fr_is_zero(hin[1]))) h = poseidon3_zero_level(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
-        else h = poseidon_hash<3>(hin, K3, sk);
+        if (HZ_SMT_BG_STORES && thr_wave > 0 && (uint32_t)k >= thr_wave) {
+            // structurally empty for the whole wavefront: its block is stored by one of the hashing levels (below), only the digest here
+#pragma unroll
+            for (int q = 0; q < 9; q++) h.v[q] = HZ_POSEIDON3_ZERO_HASH[q];
+        } else {
+            // hashing level k (< thr_wave) also stores the blocks of empty levels thr + [k E / H, (k+1) E / H), E = n - thr, H = thr
+            BgZero bg{a.base, a.n_units, i, o.levels + (new_side ? LV_NEWHASH : LV_OLDHASH), 0, 0, 0, 0};
+            if (HZ_SMT_BG_STORES && thr_wave > 0) {
+                const uint32_t E = (uint32_t)n - thr_wave;
+                bg.j = thr_wave + (uint32_t)k * E / thr_wave;
+                bg.j_end = thr_wave + ((uint32_t)k + 1) * E / thr_wave;
+                bg.per = ((bg.j_end - bg.j) * 243 + 80) / 81;
+            }
+            SmtSboxSink sk{io.sbox_sink(lv + (new_side ? LV_NEWHASH : LV_OLDHASH)), &bg};
+            if (HZ_SMT_ZERO_FAST && __all(fr_is_zero(hin[0]) && fr_is_zero(hin[1]))) h = poseidon3_zero_level(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
+            else h = poseidon_hash<3>(hin, K3, sk);
+            if (HZ_SMT_BG_STORES) bg.flush();
+        }
         if (!new_side) {
             // st_bot + st_new1 + st_upd ; st_top
             const Fr s_a = k < kl ? zero : k == kl ? mU : k <= kx ? m : zero;
@@ -225,12 +306,14 @@ hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
     hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), poseidon_lds_bytes<5>() + poseidon_lds_bytes<4>(), s, a);
     return hipGetLastError();
 }
-// A chain lane lives for all n_levels hashes (~20 ms at nLevels = 32) and the grid is twice what the device holds: launched as
-// one kernel, no workgroup slot turns over for tens of milliseconds and every other queue of the process (the other context's
-// front / signature / SHA kernels, even host-side launches) waits behind it. The chain is therefore launched in chunks of
-// `HZ_SMT_CHUNK` levels: slots turn over every few milliseconds and the queues interleave.
+// Round 1 launched the chain in chunks of 11 levels: a lane then spent its first ~18 levels in a pure store phase, the 4096-workgroup
+// grid is twice what the device holds, and as one kernel no workgroup slot turned over for tens of milliseconds -- the other
+// context's kernels waited behind it. With the empty-level blocks stored in the shadow of the hashing levels (BgZero above) the
+// store phase is gone and one launch is as good for the step (46.2 vs 46.1-46.8 ms) and better for the kernel itself (21.4 vs
+// 22.8 ms alone: no per-chunk prologue, no tail of a chunk waiting for its slowest wavefront). HZ_SMT_CHUNK < n_levels brings the
+// chunks back.
 #ifndef HZ_SMT_CHUNK
-#define HZ_SMT_CHUNK 11
+#define HZ_SMT_CHUNK 64
 #endif
 int smt_chunk_levels(const SmtArgs& a) {
     const uint64_t lanes = (uint64_t)((a.ucnt ? a.ucnt : a.n_units) + HZ_BLOCK - 1) / HZ_BLOCK * 2 * a.n_proc;
