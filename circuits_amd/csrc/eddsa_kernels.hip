@@ -316,7 +316,7 @@ __device__ __forceinline__ Fr ay_sign_2_ax_dev(const EdCtx& c, const UnitIO& io,
     return x;
 }
 
-__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out) {
+__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out, bool* on_curve) {
     const EdCtx c = K.with(io);
     const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
     const Fr R8x = sc.get(SC_ED_R8X), R8y = sc.get(SC_ED_R8Y), M = sc.get(SC_SIGL2HASH);
@@ -329,6 +329,10 @@ __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const S
     num2bits_strict_dev(io, o.h2bits, out.h_c, C_RTX_SIG_H_ALIAS);
     PtA A;
     A.x = x; A.y = Ay;
+    {
+        const Fr x2 = fr_sqr(x), y2 = fr_sqr(Ay);   // is the point the ladder starts from on the curve? (k_eddsa_pre's fast doubling chain)
+        *on_curve = fr_eq(fr_add(fr_mul(c.a, x2), y2), fr_add(c.one, fr_mul(fr_mul(c.d, x2), y2)));
+    }
     const PtA d1 = baby_add_dev(c, o.dbl1, A, A);
     const PtA d2 = baby_add_dev(c, o.dbl2, d1, d1);
     const PtA d3 = baby_add_dev(c, o.dbl3, d2, d2);
@@ -347,14 +351,190 @@ __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const S
     out.R8.x = R8x; out.R8.y = R8y;
 }
 
-// Lane li evaluates the signatures of units li, li + nl, li + 2 nl, ... (nl lanes): consecutive
-// lanes keep writing consecutive units. A slot past the end repeats the lane's first unit (same
-// values to the same addresses).
+// ---------------------------------------------------------------------------------------------------------------------------
+// h * 8A = the two SegmentMulAny of circomlib's EscalarMulAny(254): bits 0..147 from 8A, bits 148..253 from 2^148 * 8A. The second
+// segment's start is the END of the first one's doubling chain, so a signature used to be one 254-step dependent chain -- the longest
+// chain of a step and of a single batch's latency. But the doublings do not depend on the additions: k_eddsa_pre walks them alone,
+// 147 inversion-free projective doublings (8 products each) and one inversion, and the two segments then run as independent lanes of
+// k_eddsa_ladder: 148 and 106 steps instead of 254, twice the wavefronts. Values are field elements, so the affine point the
+// circuit reaches by 147 affine doublings is the same number however it is computed -- as long as the chain is regular: 8A lies on
+// the curve (projective twisted-Edwards doubling is then exception free) and is not the identity (replaced by Base8 by the circuit
+// itself). Off-curve keys (a witness that fails BabyCheck anyway) take the circuit's own affine doubling chain instead (ed_dbl_chain_affine).
+struct PtP { Fr X, Y, Z; };
+// dbl-2008-hwcd for a*x^2 + y^2 = 1 + d*x^2*y^2 without the T coordinate (doubling only): 3M + 4S + 1 small-constant product
+__device__ __forceinline__ PtP ed_dbl_proj(const EdK& K, const PtP& p) {
+    const Fr A = fr_sqr(p.X), B = fr_sqr(p.Y), C = fr_dbl(fr_sqr(p.Z)), D = fr_mul(K.a, A);
+    const Fr E = fr_sub(fr_sub(fr_sqr(fr_add(p.X, p.Y)), A), B), G = fr_add(D, B), F = fr_sub(G, C), H = fr_sub(D, B);
+    PtP r;
+    r.X = fr_mul(E, F); r.Y = fr_mul(G, H); r.Z = fr_mul(F, G);
+    return r;
+}
+// the circuit's own chain: e2m, then `count` Montgomery doublings with the 0-divisor convention (no signals, no checks: the
+// segment lanes store and check every one of these steps again)
+__device__ __noinline__ PtA ed_dbl_chain_affine(const EdK& K, const PtA& p0, int count) {
+    Fr den[2] = {fr_sub(K.one, p0.y), p0.x};
+    batch_inv<2>(den, 2);
+    PtA m;
+    m.x = fr_mul(fr_add(K.one, p0.y), den[0]);
+    m.y = fr_mul(m.x, den[1]);
+    const Fr A2 = fr_dbl(K.A);
+    for (int i = 0; i < count; i++) {
+        if (fr_is_zero(m.y)) {
+            // 2y = 0: the quotient is 0 by the 0-divisor convention, so x' = -A - 2x and y' = -y = 0 -- and it stays that way. This is
+            // the chain of every lane without a signature (L1 and padding transactions: all-zero key), no inversion needed.
+            m.x = fr_sub(fr_neg(K.A), fr_dbl(m.x));
+            m.y = fr_zero();
+            continue;
+        }
+        const Fr x2 = fr_sqr(m.x);
+        const Fr num = fr_add(fr_add(fr_add(fr_dbl(x2), x2), fr_mul(A2, m.x)), K.one);
+        const Fr lamda = fr_div(num, fr_dbl(m.y));
+        PtA o;
+        o.x = fr_sub(fr_sub(fr_sqr(lamda), K.A), fr_dbl(m.x));
+        o.y = fr_sub(fr_mul(lamda, fr_sub(m.x, o.x)), m.y);
+        m = o;
+    }
+    return m;
+}
+#ifndef HZ_ED_FORCE_AFFINE_PRE
+#define HZ_ED_FORCE_AFFINE_PRE 0   // test builds: every lane takes the affine chain (the path off-curve keys take)
+#endif
+// Off-curve start (the key of a lane without a signature: ay forced to 0 for AySign2Ax, the leaf's own ay for the verifier): the
+// curve equation cannot be used, but the circuit's affine doubling x' = l^2 - A - 2x, y' = l (x - x') - y, l = (3x^2 + 2Ax + 1) / (2y)
+// is a rational map: carried as (X : Y : Z) with x = X/Z, y = Y/Z it needs no inversion either (4S + 12M per step). A zero divisor
+// anywhere (the circuit's quotient is then 0 by convention, not a rational value) makes Z = 0 for good: then, and only then, the
+// affine chain is walked (its y = 0 case is a linear recurrence).
+__device__ __noinline__ PtA ed_dbl_chain_generic(const EdK& K, const PtA& p0, int count) {
+    Fr den[2] = {fr_sub(K.one, p0.y), p0.x};
+    batch_inv<2>(den, 2);
+    PtA m;
+    m.x = fr_mul(fr_add(K.one, p0.y), den[0]);
+    m.y = fr_mul(m.x, den[1]);
+    Fr X = m.x, Y = m.y, Z = K.one;
+    const Fr A2 = fr_dbl(K.A);
+#pragma unroll 1
+    for (int i = 0; i < count; i++) {
+        const Fr XX = fr_sqr(X), XZ = fr_mul(X, Z), ZZ = fr_sqr(Z);
+        const Fr N = fr_add(fr_add(fr_add(fr_dbl(XX), XX), fr_mul(A2, XZ)), ZZ);
+        const Fr D = fr_dbl(fr_mul(Y, Z));
+        const Fr D2 = fr_sqr(D), D3 = fr_mul(D2, D);
+        const Fr X3n = fr_sub(fr_mul(fr_sqr(N), Z), fr_mul(fr_add(fr_mul(K.A, Z), fr_dbl(X)), D2));
+        const Fr Yn = fr_sub(fr_mul(N, fr_sub(fr_mul(X, D2), X3n)), fr_mul(Y, D3));
+        X = fr_mul(X3n, D);
+        Y = Yn;
+        Z = fr_mul(D3, Z);
+    }
+    if (fr_is_zero(Z)) return ed_dbl_chain_affine(K, p0, count);
+    const Fr zi = fr_inv(Z);
+    PtA r;
+    r.x = fr_mul(X, zi);
+    r.y = fr_mul(Y, zi);
+    return r;
+}
+// 2^count * p0 in Montgomery affine coordinates (p0 Edwards affine)
+__device__ __forceinline__ PtA ed_dbl_chain(const EdK& K, const PtA& p0, int count, bool regular) {
+    if (HZ_ED_FORCE_AFFINE_PRE) return ed_dbl_chain_affine(K, p0, count);
+    if (!__all(regular)) {
+        if (!regular) return ed_dbl_chain_generic(K, p0, count);
+    }
+    PtP q{p0.x, p0.y, K.one};
+#pragma unroll 1
+    for (int i = 0; i < count; i++) q = ed_dbl_proj(K, q);
+    // Edwards (X/Z, Y/Z) -> Montgomery u = (Z + Y) / (Z - Y), v = u * Z / X
+    Fr den[2] = {fr_sub(q.Z, q.Y), q.X};
+    Fr inv[2] = {den[0], den[1]};
+    batch_inv<2>(inv, 2);
+    PtA m;
+    m.x = fr_mul(fr_add(q.Z, q.Y), inv[0]);
+    m.y = fr_mul(fr_mul(m.x, q.Z), inv[1]);
+    if (fr_is_zero(den[0]) || fr_is_zero(den[1])) return ed_dbl_chain_affine(K, p0, count);   // cannot happen for a regular chain
+    return m;
+}
+
 #ifndef HZ_ED_WAVES
 #define HZ_ED_WAVES 2
 #endif
+// lane = signature: everything before the scalar multiplication, and the start of its second segment
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_pre(const EddsaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    uint32_t* lds = lds_raw;
+    const Fr* K6 = poseidon_consts_w<6>(lds);
+    __syncthreads();
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n) return;
+    const uint32_t i = a.u0 + li;
+    EdK K;
+    K.one = fr_one();
+    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+    const Scratch sc{a.scratch, a.n_units, i};
+    EdSig sg;
+    bool on_curve = false;
+    ed_prologue(K, io, sc, a.ed, K6, sg, &on_curve);
+    sc.set(SC_ED_H, fr_from_canon(sg.h_c)); sc.set(SC_ED_ZP, sg.zp);
+    sc.set(SC_ED_P0X, sg.p0.x); sc.set(SC_ED_P0Y, sg.p0.y);
+    // 8A of an on-curve A is on the curve; when it is the identity the circuit substitutes Base8 (zp = 1): regular either way
+#ifndef HZ_EXPERIMENT_PRE_COUNT
+#define HZ_EXPERIMENT_PRE_COUNT 147   // timing experiments only
+#endif
+    const PtA d147 = ed_dbl_chain(K, sg.p0, HZ_EXPERIMENT_PRE_COUNT, on_curve);
+    sc.set(SC_ED_DBLX, d147.x); sc.set(SC_ED_DBLY, d147.y);
+}
+
+// lane = (segment, G signatures in lockstep). Lane li of a segment evaluates the signatures of units li, li + nl, li + 2 nl, ...
+// (nl lanes): consecutive lanes keep writing consecutive units. A slot past the end repeats the lane's first unit (same values to
+// the same addresses).
 template <int G>
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa(const EddsaArgs a) {
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_ladder(const EddsaArgs a) {
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t nl = (n + G - 1) / G;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= nl) return;
+    const uint32_t seg = blockIdx.y;
+    EdK K;
+    K.one = fr_one();
+    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EddsaOff& o = a.ed;
+    UnitIO io[G];
+    Fc h_c[G];
+    PtA p[G], dbl[G];
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        uint32_t ui = li + (uint32_t)g * nl;
+        if (ui >= n) ui = li;
+        const uint32_t i = a.u0 + ui;
+        io[g] = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+        const Scratch sc{a.scratch, a.n_units, i};
+        h_c[g] = fr_to_canon(sc.get(SC_ED_H));
+        if (seg == 0) {
+            p[g].x = sc.get(SC_ED_P0X); p[g].y = sc.get(SC_ED_P0Y);
+        } else {
+            // the doubling between the segments and the second segment's base point (escalarmulany.circom: doublers / m2e)
+            const EdCtx c = K.with(io[g]);
+            PtA d147;
+            d147.x = sc.get(SC_ED_DBLX); d147.y = sc.get(SC_ED_DBLY);
+            const MDbl dd = mont_dbl_dev(c, d147);
+            c.io.put_m(o.dblr, dd.x1_2); c.io.put_m(o.dblr + 1, dd.lamda); c.io.put_m(o.dblr + 2, dd.out.x); c.io.put_m(o.dblr + 3, dd.out.y);
+            p[g] = m2e_dev(c, dd.out);
+            c.io.put_m(o.m2e0, p[g].x); c.io.put_m(o.m2e0 + 1, p[g].y);
+        }
+    }
+    if (seg == 0) seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);
+    else seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, p, dbl);
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const Scratch sc{a.scratch, a.n_units, io[g].unit};
+        sc.set(seg == 0 ? SC_ED_S0X : SC_ED_S1X, p[g].x);
+        sc.set(seg == 0 ? SC_ED_S0Y : SC_ED_S1Y, p[g].y);
+    }
+}
+
+// The whole signature as ONE chain per lane (both segments back to back, no k_eddsa_pre): 8 % fewer instructions than the split form
+// (no projective doubling chain) and half the wavefronts. Throughput-sized launches use it -- the device is full anyway, and the split
+// form measured 50.3 ms per step against 46.0 -- the split form is for launches the device does not fill (a single batch: latency).
+template <int G>
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain(const EddsaArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
     const Fr* K6 = poseidon_consts_w<6>(lds);
@@ -369,8 +549,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     const EddsaOff& o = a.ed;
     UnitIO io[G];
     Fc h_c[G];
-    Fr enabled[G], zp[G];
-    PtA R8[G], p[G], q[G], dbl[G];
+    PtA p[G], q[G], dbl[G];
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         uint32_t ui = li + (uint32_t)g * nl;
@@ -379,10 +558,11 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         io[g] = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
         const Scratch sc{a.scratch, a.n_units, i};
         EdSig sg;
-        ed_prologue(K, io[g], sc, o, K6, sg);
-        h_c[g] = sg.h_c; enabled[g] = sg.enabled; zp[g] = sg.zp; R8[g] = sg.R8; p[g] = sg.p0;
+        bool on_curve;
+        ed_prologue(K, io[g], sc, o, K6, sg, &on_curve);
+        sc.set(SC_ED_ZP, sg.zp);
+        h_c[g] = sg.h_c; p[g] = sg.p0;
     }
-    // ---- mulAny = h * 8A: two SegmentMulAny (148 + 106 bits)
     seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);   // p <- segment 0 output
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
@@ -394,22 +574,10 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     }
     seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, q, dbl);  // q <- segment 1 output
 #pragma unroll 1
-    for (int g = 0; g < G; g++) {
-        const EdCtx c = K.with(io[g]);
-        const PtA sum = baby_add_dev(c, o.adders0, p[g], q[g]);
-        PtA any;
-        any.x = fr_mul(sum.x, fr_sub(c.one, zp[g]));
-        any.y = fr_add(sum.y, fr_mul(fr_sub(c.one, sum.y), zp[g]));
-        c.io.put_m(o.anyOut, any.x); c.io.put_m(o.anyOut + 1, any.y);
-        p[g] = baby_add_dev(c, o.addRight, R8[g], any);   // right side: R8 + h*8A
-    }
-    // the right-hand side goes to k_eddsa_final through the scratch buffer
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {
+    for (int g = 0; g < G; g++) {   // the sum, the zero-point substitution and R8 + h*8A belong to k_eddsa_final
         const Scratch sc{a.scratch, a.n_units, io[g].unit};
-        sc.set(SC_ED_RIGHTX, p[g].x); sc.set(SC_ED_RIGHTY, p[g].y);
+        sc.set(SC_ED_S0X, p[g].x); sc.set(SC_ED_S0Y, p[g].y); sc.set(SC_ED_S1X, q[g].x); sc.set(SC_ED_S1Y, q[g].y);
     }
-    (void)enabled;
 }
 
 // mulFix = S * B8 (two SegmentMulFix: 82 + 3 windows of the constant base) with the S decomposition and range check: it depends on
@@ -461,7 +629,25 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa_final(const EddsaArgs a) {
     const Scratch sc{a.scratch, a.n_units, i};
     const EddsaOff& o = a.ed;
     const Fr one = fr_one(), enabled = sc.get(SC_ED_ENABLED);
-    Fr d2[2] = {fr_sub(sc.get(SC_ED_RIGHTX), sc.get(SC_ED_LEFTX)), fr_sub(sc.get(SC_ED_RIGHTY), sc.get(SC_ED_LEFTY))};
+    PtA right;
+    {
+        // mulAny.out = segment 0 + segment 1, the zero-point substitution undone, R8 + h*8A (eddsaposeidon.circom)
+        EdK K;
+        K.one = one;
+        K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+        const EdCtx c = K.with(io);
+        PtA s0, s1, R8;
+        s0.x = sc.get(SC_ED_S0X); s0.y = sc.get(SC_ED_S0Y); s1.x = sc.get(SC_ED_S1X); s1.y = sc.get(SC_ED_S1Y);
+        R8.x = sc.get(SC_ED_R8X); R8.y = sc.get(SC_ED_R8Y);
+        const Fr zp = sc.get(SC_ED_ZP);
+        const PtA sum = baby_add_dev(c, o.adders0, s0, s1);
+        PtA any;
+        any.x = fr_mul(sum.x, fr_sub(one, zp));
+        any.y = fr_add(sum.y, fr_mul(fr_sub(one, sum.y), zp));
+        io.put_m(o.anyOut, any.x); io.put_m(o.anyOut + 1, any.y);
+        right = baby_add_dev(c, o.addRight, R8, any);
+    }
+    Fr d2[2] = {fr_sub(right.x, sc.get(SC_ED_LEFTX)), fr_sub(right.y, sc.get(SC_ED_LEFTY))};
     Fr di[2] = {d2[0], d2[1]};
     batch_inv<2>(di, 2);
     const Fr ex = is_zero_dev(io, o.eqCheckX, d2[0], di[0]);
@@ -474,9 +660,16 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa_final(const EddsaArgs a) {
 // wavefronts, each G times as long (latency). Few units (a single batch or a handful): the device is far from full and
 // latency is what counts; many units per launch: the integer pipe is the limit.
 template <int G>
+static hipError_t launch_eddsa_split(const EddsaArgs& a, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_eddsa_pre, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
+    const uint32_t nl = (n + G - 1) / G;
+    hipLaunchKernelGGL(k_eddsa_ladder<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK, 2), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+template <int G>
 static hipError_t launch_eddsa_g(const EddsaArgs& a, uint32_t n, hipStream_t s) {
     const uint32_t nl = (n + G - 1) / G;
-    hipLaunchKernelGGL(k_eddsa<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
+    hipLaunchKernelGGL(k_eddsa_chain<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
     return hipGetLastError();
 }
 template <int G>
@@ -490,7 +683,12 @@ hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
 #ifdef HZ_ED_G_FIXED
     return launch_eddsa_g<HZ_ED_G>(a, n, s);
 #else
-    if (n <= 8192) return launch_eddsa_g<1>(a, n, s);
+#ifndef HZ_ED_SPLIT_MAX
+#define HZ_ED_SPLIT_MAX 8192
+#endif
+    // a launch the device does not fill is latency bound: the two segments of every signature as independent lanes (148 / 106
+    // dependent steps instead of 254), one signature per lane
+    if (n <= HZ_ED_SPLIT_MAX) return launch_eddsa_split<1>(a, n, s);
     // Two signatures per lane. Four (one inversion shared by four ladder steps) issue fewer instructions but take 42.6 ms against
     // 28.5 ms per 65 536 signatures: since the SMT chain stores its empty-subtree levels from a table (25 ms per step instead of 42)
     // the ladder is the longest chain of a step, and its length, not its instruction count, sets the step: 1.27 vs 1.19 M tx/s

@@ -22,6 +22,9 @@ enum ScratchField {
     SC_ISEXIT, SC_OLDSTATEROOT, SC_OLDEXITROOT,
     SC_ED_ENABLED, SC_ED_SIGN, SC_ED_AYSIG, SC_ED_AY, SC_ED_S, SC_ED_R8X, SC_ED_R8Y,
     SC_ED_LEFTX, SC_ED_LEFTY, SC_ED_RIGHTX, SC_ED_RIGHTY,   // S*B8 (k_eddsa_fix) and R8 + h*8A (k_eddsa) for k_eddsa_final
+    // k_eddsa_pre -> the two segment lanes of k_eddsa_ladder -> k_eddsa_final: message hash, zero-point flag, 8A (or Base8), 2^147 * 8A
+    // (Montgomery form), the two segment outputs
+    SC_ED_H, SC_ED_ZP, SC_ED_P0X, SC_ED_P0Y, SC_ED_DBLX, SC_ED_DBLY, SC_ED_S0X, SC_ED_S0Y, SC_ED_S1X, SC_ED_S1Y,
     SC_ISAMTNULL,
     // written by the hash step
     SC_LEAF_P1OLD, SC_LEAF_P1NEW, SC_LEAF_P2OLD, SC_LEAF_P2NEW,
