@@ -226,6 +226,99 @@ __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const 
     }
 }
 
+// C ladder chains in lockstep that need not be the same segment: chain c walks bits e[c][e0[c] .. e0[c] + n[c]) with the signal
+// block oo[c] and the witness cursor io[c]. A chain that has run out of steps contributes the element 1 to the shared inversion.
+// Used with C = 2 G: both segments of G signatures (the second one starts from the precomputed 2^147 * 8A, k_eddsa_pre's chain), so
+// a lane's dependent chain is 147 steps instead of 2 x 127 and four steps share every inversion for the first 105 of them.
+template <int C>
+__device__ __noinline__ void seg_any_multi(const EdK& K, const UnitIO* const* io, const SegAnyOff* const* oo, const Fc* const* e, const int* e0, const int* n,
+                                           PtA* p, PtA* dbl) {
+    PtA dout[C], addIn[C];
+    Fr nx1_2[C], d_num[C];
+    int max_steps = 0;
+#pragma unroll 1
+    for (int c = 0; c < C; c++) {
+        const SegAnyOff& o = *oo[c];
+        const EdCtx ctx = K.with(*io[c]);
+        const PtA m = e2m_dev(ctx, p[c]);
+        ctx.io.put_m(o.e2m, m.x); ctx.io.put_m(o.e2m + 1, m.y);
+        const MDbl d = mont_dbl_dev(ctx, m);   // doubler_0
+        ctx.io.put_m(o.bits + BIT_DBL_X1_2, d.x1_2); ctx.io.put_m(o.bits + BIT_DBL_LAMDA, d.lamda);
+        ctx.io.put_m(o.bits + BIT_DBL_OUT0, d.out.x); ctx.io.put_m(o.bits + BIT_DBL_OUT1, d.out.y);
+        dout[c] = d.out;
+        addIn[c] = m;
+        if (n[c] - 1 > max_steps) max_steps = n[c] - 1;
+    }
+    const Fr A2 = fr_dbl(K.A);
+#pragma unroll 1
+    for (int i = 0; i < max_steps; i++) {
+        Fr inv[2 * C];
+        uint32_t zmask = 0;
+#pragma unroll 1
+        for (int c = 0; c < C; c++) {
+            const int steps = n[c] - 1;
+            Fr a_den = K.one, dd = K.one;
+            if (i < steps) {
+                a_den = fr_sub(addIn[c].x, dout[c].x);
+                if (fr_is_zero(a_den)) zmask |= 1u << (2 * c);
+                if (i + 1 < steps) {
+                    nx1_2[c] = fr_sqr(dout[c].x);
+                    d_num[c] = fr_add(fr_add(fr_add(fr_dbl(nx1_2[c]), nx1_2[c]), fr_mul(A2, dout[c].x)), K.one);
+                    dd = fr_dbl(dout[c].y);
+                    if (fr_is_zero(dd)) zmask |= 1u << (2 * c + 1);
+                }
+            }
+            inv[2 * c] = a_den;
+            inv[2 * c + 1] = dd;
+        }
+        batch_inv<2 * C>(inv, 2 * C);
+#pragma unroll 1
+        for (int c = 0; c < C; c++) {
+            const int steps = n[c] - 1;
+            if (i >= steps) continue;
+            const SegAnyOff& o = *oo[c];
+            const UnitIO& w = *io[c];
+            const uint32_t b = o.bits + BIT_N * i;
+            const Fr a_num = fr_sub(addIn[c].y, dout[c].y);
+            const Fr a_lamda = fr_mul(a_num, inv[2 * c]);
+            if ((zmask >> (2 * c)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), a_num);
+            PtA ao;
+            ao.x = fr_sub(fr_sub(fr_sub(fr_sqr(a_lamda), K.A), dout[c].x), addIn[c].x);
+            ao.y = fr_sub(fr_mul(a_lamda, fr_sub(dout[c].x, ao.x)), dout[c].y);
+            const uint32_t sel = c_bit(*e[c], e0[c] + i + 1);
+            const PtA so = sel ? ao : addIn[c];
+            w.put_m(b + BIT_ADD_LAMDA, a_lamda); w.put_m(b + BIT_ADD_OUT0, ao.x); w.put_m(b + BIT_ADD_OUT1, ao.y);
+            w.put_m(b + BIT_SEL_OUT0, so.x); w.put_m(b + BIT_SEL_OUT1, so.y);
+            addIn[c] = so;
+            if (i + 1 < steps) {
+                const Fr lamda = fr_mul(d_num[c], inv[2 * c + 1]);
+                if ((zmask >> (2 * c + 1)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), d_num[c]);
+                PtA no;
+                no.x = fr_sub(fr_sub(fr_sqr(lamda), K.A), fr_dbl(dout[c].x));
+                no.y = fr_sub(fr_mul(lamda, fr_sub(dout[c].x, no.x)), dout[c].y);
+                const uint32_t bn = b + BIT_N;
+                w.put_m(bn + BIT_DBL_X1_2, nx1_2[c]); w.put_m(bn + BIT_DBL_LAMDA, lamda); w.put_m(bn + BIT_DBL_OUT0, no.x); w.put_m(bn + BIT_DBL_OUT1, no.y);
+                dout[c] = no;
+            }
+        }
+    }
+#pragma unroll 1
+    for (int c = 0; c < C; c++) {
+        const SegAnyOff& o = *oo[c];
+        const EdCtx ctx = K.with(*io[c]);
+        dbl[c] = dout[c];
+        const PtA me = m2e_dev(ctx, addIn[c]);
+        ctx.io.put_m(o.m2e, me.x); ctx.io.put_m(o.m2e + 1, me.y);
+        PtA negp;
+        negp.x = fr_neg(p[c].x);
+        negp.y = p[c].y;
+        const PtA ea = baby_add_dev(ctx, o.eadder, me, negp);
+        const PtA r = c_bit(*e[c], e0[c]) ? me : ea;
+        ctx.io.put_m(o.lastSel, r.x); ctx.io.put_m(o.lastSel + 1, r.y);
+        p[c] = r;
+    }
+}
+
 // SegmentMulFix on the constant base for G signatures in lockstep: window tables from
 // HZ_BJJ_FIX_WIN; the G additions of one window share one inversion.
 __device__ __forceinline__ uint32_t fix_window_bits(const Fc& e, int e0, int nbits, int i) {
@@ -580,6 +673,62 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     }
 }
 
+// Both segments of G signatures in lockstep in one lane (seg_any_multi): 2 G chains share every inversion, 147 dependent steps.
+template <int G>
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain2(const EddsaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    uint32_t* lds = lds_raw;
+    const Fr* K6 = poseidon_consts_w<6>(lds);
+    __syncthreads();
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t nl = (n + G - 1) / G;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= nl) return;
+    EdK K;
+    K.one = fr_one();
+    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EddsaOff& o = a.ed;
+    UnitIO io[G];
+    Fc h_c[G];
+    PtA p[2 * G], dbl[2 * G];
+    const UnitIO* iop[2 * G];
+    const SegAnyOff* oo[2 * G];
+    const Fc* ep[2 * G];
+    int e0[2 * G], nn[2 * G];
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        uint32_t ui = li + (uint32_t)g * nl;
+        if (ui >= n) ui = li;
+        const uint32_t i = a.u0 + ui;
+        io[g] = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+        const Scratch sc{a.scratch, a.n_units, i};
+        EdSig sg;
+        bool on_curve;
+        ed_prologue(K, io[g], sc, o, K6, sg, &on_curve);
+        sc.set(SC_ED_ZP, sg.zp);
+        h_c[g] = sg.h_c;
+        p[2 * g] = sg.p0;
+        // the second segment's base point: 2^148 * 8A through the doubling chain alone, then the circuit's own doubler / m2e signals
+        const EdCtx c = K.with(io[g]);
+        const PtA d147 = ed_dbl_chain(K, sg.p0, 147, on_curve);
+        const MDbl dd = mont_dbl_dev(c, d147);
+        c.io.put_m(o.dblr, dd.x1_2); c.io.put_m(o.dblr + 1, dd.lamda); c.io.put_m(o.dblr + 2, dd.out.x); c.io.put_m(o.dblr + 3, dd.out.y);
+        p[2 * g + 1] = m2e_dev(c, dd.out);
+        c.io.put_m(o.m2e0, p[2 * g + 1].x); c.io.put_m(o.m2e0 + 1, p[2 * g + 1].y);
+    }
+#pragma unroll 1
+    for (int c = 0; c < 2 * G; c++) {
+        iop[c] = &io[c >> 1]; ep[c] = &h_c[c >> 1];
+        oo[c] = &o.seg[c & 1]; e0[c] = (c & 1) ? 148 : 0; nn[c] = (c & 1) ? 106 : 148;
+    }
+    seg_any_multi<2 * G>(K, iop, oo, ep, e0, nn, p, dbl);
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const Scratch sc{a.scratch, a.n_units, io[g].unit};
+        sc.set(SC_ED_S0X, p[2 * g].x); sc.set(SC_ED_S0Y, p[2 * g].y); sc.set(SC_ED_S1X, p[2 * g + 1].x); sc.set(SC_ED_S1Y, p[2 * g + 1].y);
+    }
+}
+
 // mulFix = S * B8 (two SegmentMulFix: 82 + 3 windows of the constant base) with the S decomposition and range check: it depends on
 // nothing but S, so it runs beside the variable-base ladder in its own kernel with its own signatures-per-lane (85 inversions
 // per lane: more signatures share each of them than in the 254-step ladder kernel).
@@ -666,10 +815,19 @@ static hipError_t launch_eddsa_split(const EddsaArgs& a, uint32_t n, hipStream_t
     hipLaunchKernelGGL(k_eddsa_ladder<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK, 2), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
+// 1: both segments of a lane's signatures in lockstep (k_eddsa_chain2: 147 dependent steps, four steps per inversion); 0: one after the
+// other (k_eddsa_chain). Measured at 65 536 signatures, G = 2: the kernel alone 23.9 vs 24.6 ms, the step 47.7-47.8 vs 47.9 ms on the
+// same box -- halving the inversions buys 3 %: a ladder step is as long as an inversion even without one (nine stored signals, each
+// a reduction of its own, and eight dependent products), and the lockstep form parks four chains' state in scratch (3.9 vs 2.8 KB per
+// lane). Kept as an option, not the default.
+#ifndef HZ_ED_MULTI
+#define HZ_ED_MULTI 0
+#endif
 template <int G>
 static hipError_t launch_eddsa_g(const EddsaArgs& a, uint32_t n, hipStream_t s) {
     const uint32_t nl = (n + G - 1) / G;
-    hipLaunchKernelGGL(k_eddsa_chain<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
+    if (HZ_ED_MULTI) hipLaunchKernelGGL(k_eddsa_chain2<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
+    else hipLaunchKernelGGL(k_eddsa_chain<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
     return hipGetLastError();
 }
 template <int G>
