@@ -62,12 +62,17 @@ struct hz_ctx {
     int stagger_piece = 0;
     bool mid_valid = false;
     hipStream_t s_fix = nullptr;   // the fixed-base half of the signature check
+    hipStream_t s_sha = nullptr;   // SHA-256 expansion groups behind the chain when HashInputs runs early on the fee stream
+    hipEvent_t ev_hash4 = nullptr, ev_tail = nullptr;
     ~hz_ctx() {
         if (s_ed) (void)hipStreamDestroy(s_ed);
         if (s_fee) (void)hipStreamDestroy(s_fee);
         if (s_main) (void)hipStreamDestroy(s_main);
         if (s_fix) (void)hipStreamDestroy(s_fix);
         if (s_copy) (void)hipStreamDestroy(s_copy);
+        if (s_sha) (void)hipStreamDestroy(s_sha);
+        for (hipEvent_t e : {ev_hash4, ev_tail})
+            if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_staged, ev_unpacked})
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_reset, ev_front, ev_ed, ev_fee, ev_fix, ev_user_in, ev_user_out, ev_inputs})
@@ -206,6 +211,9 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         if (e == hipSuccess) e = make_stream(&c->s_fix, ncu / 4, ncu * 3 / 8);       // fixed-base half
         if (e == hipSuccess) e = make_stream(&c->s_fee, ncu * 3 / 8, ncu / 2);       // fee-transaction chain
         if (e == hipSuccess) e = make_stream(&c->s_main, ncu / 2, ncu);              // front, hash-state, SMT chains, HashInputs
+        if (e == hipSuccess && lo.p.tmpl == T_ROLLUP_MAIN && !c->partitioned) e = hipStreamCreateWithFlags(&c->s_sha, hipStreamNonBlocking);
+        for (hipEvent_t* ev : {&c->ev_hash4, &c->ev_tail})
+            if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     }
     for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix, &c->ev_user_in, &c->ev_user_out, &c->ev_inputs})
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
@@ -555,7 +563,18 @@ static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa, const char* na
     return hipSuccess;
 }
 
-static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, uint32_t sib1, uint32_t sib2, hipStream_t s) {
+#ifndef HZ_EARLY_TAIL
+#define HZ_EARLY_TAIL 1
+#endif
+static HashInputsArgs make_hi(hz_ctx* c, bool is_main);
+
+// early_tail (RollupMain, whole batch): HashInputs does not wait for the SMT chains of every transaction. Its SHA-256 message needs
+// the data-availability bits (front kernel), the last fee transaction's root (fee chain, own stream from the start) and ONE value
+// of the chains: the LAST transaction's exit root. That transaction's four chains are evaluated first, as a launch of their own
+// (4 lanes per batch) on the fee stream right after the hash-state kernel, then the message, the sequential chain and the
+// expansion follow there while the main stream hashes the other 2047 transactions (which recomputes the last one's signals to the
+// same values). The 3.6 ms of one-wavefront chain latency and the expansion leave the end of the step.
+static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, uint32_t sib1, uint32_t sib2, hipStream_t s, bool early_tail = false) {
     const Layout& lo = c->lo;
     Fr* sc = (Fr*)c->sc_tx.p;
     ErrBuf* err = (ErrBuf*)c->err.p;
@@ -595,9 +614,6 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     sa.p[0] = make_proc(lo.rtx.p1, sib1, 0);
     sa.p[1] = make_proc(lo.rtx.p2, sib2, 1);
     sa.u0 = u0; sa.ucnt = ucnt;
-#ifndef HZ_EXPERIMENT_SKIP_SMT
-    HZ_HIP(enqueue_smt_chain(c, sa, "smt", s));
-#endif
     RtxBackArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.base = base; ba.glob_base = is_main ? sec_ptr(c, lo.sec_glob) : nullptr; ba.scratch = sc; ba.err = err; ba.n_units = n_units; ba.L = (uint32_t)lo.p.L;
@@ -612,6 +628,26 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     } else {
         ba.o_newStateRoot = lo.rtxi.o_newStateRoot; ba.o_newExitRoot = lo.rtxi.o_newExitRoot;
     }
+    if (early_tail) {
+        hipStream_t st = c->s_fee;   // the fee chain was enqueued on it before: newStateRoot is ready when these run
+        HZ_HIP(hipEventRecord(c->ev_hash4, s));
+        HZ_HIP(hipStreamWaitEvent(st, c->ev_hash4, 0));
+        SmtArgs sl = sa;
+        sl.u0 = (uint32_t)lo.p.nTx - 1; sl.ucnt = lo.n_inst; sl.ustride = (uint32_t)lo.p.nTx;
+        HZ_HIP(launch_smt_levels(sl, (int)sl.n_levels - 1, 0, st));
+        RtxBackArgs bl = ba;
+        bl.u0 = sl.u0; bl.ucnt = sl.ucnt; bl.ustride = sl.ustride;
+        HZ_HIP(launch_rtx_back(bl, st));
+        HZ_HIP(launch_da_mask(ba, st));
+        {
+            ProfScope ps(c, st, "hash_inputs", (uint64_t)lo.hi.sha.nblocks);
+            HZ_HIP(launch_hash_inputs(make_hi(c, true), st, c->exclusive ? nullptr : c->s_sha, c->ev_sha, 9));
+        }
+        HZ_HIP(hipEventRecord(c->ev_tail, st));
+    }
+#ifndef HZ_EXPERIMENT_SKIP_SMT
+    HZ_HIP(enqueue_smt_chain(c, sa, "smt", s));
+#endif
     { ProfScope ps(c, s, "rtx_back", n_units); HZ_HIP(launch_rtx_back(ba, s)); }
     return HZ_OK;   // the caller joins the signature stream (ev_ed) after whatever else it launches on `s`
 }
@@ -747,9 +783,12 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             fa.u0 = c->sh_first; fa.ucnt = c->sh_count;
             { ProfScope ps(c, s, "front", (uint64_t)fa.nTx * fa.B); HZ_HIP(launch_main_front(fa, s)); }
             HZ_HIP(hipEventRecord(c->ev_front, s));
-            st = enqueue_rtx_tail(c, fa.tx_base, lo.sections[lo.sec_tx].n_units, true, lo.mi.siblings1, lo.mi.siblings2, s);
+            const bool early = tail_now && !c->partitioned && HZ_EARLY_TAIL;   // CU-partitioned contexts keep the tail on the main stream
+            st = enqueue_rtx_tail(c, fa.tx_base, lo.sections[lo.sec_tx].n_units, true, lo.mi.siblings1, lo.mi.siblings2, s, early);
             if (st != HZ_OK) return st;
-            if (tail_now) {
+            if (early) {
+                HZ_HIP(hipStreamWaitEvent(s, c->ev_tail, 0));
+            } else if (tail_now) {
                 // HashInputs needs the roots and the data-availability bits, not the signatures: it runs beside the ladders
                 HZ_HIP(hipStreamWaitEvent(s, c->ev_fee, 0));
                 { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s, c->partitioned ? nullptr : c->s_fee, c->ev_sha, 9)); }

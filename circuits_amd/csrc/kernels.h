@@ -88,6 +88,7 @@ struct SmtProcDesc {
 
 struct SmtArgs {
     uint32_t u0, ucnt;   // unit range evaluated by this launch (multi-GPU shard); ucnt = 0 means all
+    uint32_t ustride;    // 0 / 1: units u0 .. u0+ucnt-1; k > 1: units u0, u0+k, ... (the last transaction of every batch: early HashInputs)
     uint8_t* base;
     Fr* scratch;
     ErrBuf* err;
@@ -100,6 +101,7 @@ struct SmtArgs {
 
 struct RtxBackArgs {
     uint32_t u0, ucnt;   // unit range evaluated by this launch (multi-GPU shard); ucnt = 0 means all
+    uint32_t ustride;    // as in SmtArgs
     uint8_t* base;
     uint8_t* glob_base;
     Fr* scratch;
@@ -197,6 +199,7 @@ hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
 int smt_chunk_levels(const SmtArgs& a);   // levels per launch (the chain is launched in chunks, smt_kernels.hip)
 hipError_t launch_smt_levels(const SmtArgs& a, int k_hi, int k_lo, hipStream_t s);
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
+hipError_t launch_da_mask(const RtxBackArgs& a, hipStream_t s);   // RollupMain phase H alone (amount bits of L1L2TxData times 1 - isAmountNullified), every unit
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s);         // AySign2Ax, message hash, variable-base ladder, R8 + h*8A
 hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s);     // S bits / range, S*B8 (independent of the above)
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s);   // the equality of the two sides

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
     __syncthreads();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
-    const uint32_t i = a.u0 + li;
+    const uint32_t i = a.u0 + li * (a.ustride > 1 ? a.ustride : 1u);
     const uint32_t chain = blockIdx.y, pi = chain >> 1;
     const bool new_side = chain & 1;
     const SmtProcDesc& P = a.p[pi];

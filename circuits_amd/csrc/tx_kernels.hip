@@ -144,7 +144,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRO
 __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
-    const uint32_t u = a.u0 + li;
+    const uint32_t u = a.u0 + li * (a.ustride > 1 ? a.ustride : 1u);
     const uint32_t b = u / a.upi, i = u % a.upi;
     const UnitIO io{a.base, a.n_units, u, b, i, a.err};
     const Scratch sc{a.scratch, a.n_units, u};
@@ -175,6 +175,21 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
     }
 }
 
+// RollupMain phase H alone (src/rollup-main.circom:456-459): the amount bits of L1L2TxData times (1 - isAmountNullified). Everything
+// it needs exists after the front kernel, and HashInputs needs it from every transaction: launched early so that the SHA-256 chain
+// does not have to wait for the SMT chains of 2048 transactions when it only depends on the last one's exit root (ctx.hip).
+__global__ __launch_bounds__(HZ_BLOCK) void k_da_mask(const RtxBackArgs a) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= a.n_units) return;
+    const UnitIO io{a.base, a.n_units, u, u / a.upi, u % a.upi, a.err};
+    const Scratch sc{a.scratch, a.n_units, u};
+    const Fc keep_c = fr_to_canon(fr_sub(fr_one(), sc.get(SC_ISAMTNULL)));
+    for (int j = 0; j < 40; j++) {
+        const Fc b = io.in_c(a.n2bAmount + (39 - j));
+        io.put_c(a.main_l1l2amt + j, b.v[0] ? keep_c : fc_zero());
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host launchers
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
@@ -193,6 +208,10 @@ hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s) {
 }
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_rtx_back, grid1(a.ucnt ? a.ucnt : a.n_units), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_da_mask(const RtxBackArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_da_mask, dim3((a.n_units + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
