@@ -634,9 +634,11 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         HZ_HIP(hipStreamWaitEvent(st, c->ev_hash4, 0));
         SmtArgs sl = sa;
         sl.u0 = (uint32_t)lo.p.nTx - 1; sl.ucnt = lo.n_inst; sl.ustride = (uint32_t)lo.p.nTx;
+        sl.p[0].sc_root_old = SC_EROOT_P1OLD; sl.p[0].sc_root_new = SC_EROOT_P1NEW; sl.p[1].sc_root_old = SC_EROOT_P2OLD; sl.p[1].sc_root_new = SC_EROOT_P2NEW;
         HZ_HIP(launch_smt_levels(sl, (int)sl.n_levels - 1, 0, st));
         RtxBackArgs bl = ba;
         bl.u0 = sl.u0; bl.ucnt = sl.ucnt; bl.ustride = sl.ustride;
+        bl.p[0] = sl.p[0]; bl.p[1] = sl.p[1];
         HZ_HIP(launch_rtx_back(bl, st));
         HZ_HIP(launch_da_mask(ba, st));
         {

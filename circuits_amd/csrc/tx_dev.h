@@ -30,6 +30,9 @@ enum ScratchField {
     SC_LEAF_P1OLD, SC_LEAF_P1NEW, SC_LEAF_P2OLD, SC_LEAF_P2NEW,
     // written by the smt step: levels[0].oldRoot / newRoot per processor
     SC_ROOT_P1OLD, SC_ROOT_P1NEW, SC_ROOT_P2OLD, SC_ROOT_P2NEW,
+    // the same for the early evaluation of the last transaction of a batch (ctx.hip early tail): the main chain may be launched in
+    // pieces that keep their running roots in the slots above
+    SC_EROOT_P1OLD, SC_EROOT_P1NEW, SC_EROOT_P2OLD, SC_EROOT_P2NEW,
     SC_COUNT
 };
 
