@@ -201,8 +201,16 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         const bool want = (p->flags & HZ_FLAG_LATENCY) != 0 || getenv("HZ_FORCE_LATENCY_SCHEDULING") != nullptr;
         c->partitioned = lo.p.tmpl == T_ROLLUP_MAIN && want && hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 64;
         const int ncu = c->partitioned ? prop.multiProcessorCount : 0;
+        // The variable-base ladder is the longest dependent chain of a step and runs on few wavefronts: its stream gets the highest
+        // priority, so its workgroups are dispatched ahead of the wide kernels' (a 32-batch step alone: 56.8 -> 47.9 ms; two contexts
+        // in flight: unchanged, 44 ms per step).
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         auto make_stream = [&](hipStream_t* st, int lo_cu, int hi_cu) {
-            if (!c->partitioned) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+            if (!c->partitioned) {
+                if (st == &c->s_ed && prio_greatest != prio_least) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest);
+                return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+            }
             std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
             for (int b = lo_cu; b < hi_cu; b++) mask[b >> 5] |= 1u << (b & 31);
             return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
@@ -211,7 +219,7 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         if (e == hipSuccess) e = make_stream(&c->s_fix, ncu / 4, ncu * 3 / 8);       // fixed-base half
         if (e == hipSuccess) e = make_stream(&c->s_fee, ncu * 3 / 8, ncu / 2);       // fee-transaction chain
         if (e == hipSuccess) e = make_stream(&c->s_main, ncu / 2, ncu);              // front, hash-state, SMT chains, HashInputs
-        if (e == hipSuccess && lo.p.tmpl == T_ROLLUP_MAIN && !c->partitioned) e = hipStreamCreateWithFlags(&c->s_sha, hipStreamNonBlocking);
+        if (e == hipSuccess && lo.p.tmpl == T_ROLLUP_MAIN && !c->partitioned) e = make_stream(&c->s_sha, 0, 0);
         for (hipEvent_t* ev : {&c->ev_hash4, &c->ev_tail})
             if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     }

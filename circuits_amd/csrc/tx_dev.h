@@ -186,6 +186,23 @@ struct RtxExt {
     Fr futV2[3], pastV2[4], futEth[3], pastEth[4], futAy[3], pastAy[4];
 };
 
+// The DecodeTx outputs RollupTx consumes, from the same bits decode_tx_dev reads, without its signals or checks: the front kernel
+// evaluates DecodeTx and the RollupTx front logic of one transaction in two lanes (k_main_front).
+template <class IN>
+__device__ __forceinline__ void decode_fields_dev(const UnitIO& io, const IN& in, RtxExt& x) {
+    const Fc d = io.in_c(in.txCompressedData);
+    x.fromIdx = fr_from_u64(c_bits64(d, 48, 48)); x.toIdx = fr_from_u64(c_bits64(d, 96, 48)); x.tokenID = fr_from_u64(c_bits64(d, 144, 32));
+    x.nonce = fr_from_u64(c_bits64(d, 176, 40)); x.userFee = fr_from_u64(c_bits64(d, 216, 8)); x.toBjjSign = fr_from_bit(c_bit(d, 224));
+    const uint64_t f40 = c_bits64(io.in_c(in.amountF), 0, 40);
+    Fr pe = fr_from_u64(((f40 >> 35) & 1) ? 10 : 1), p10 = fr_from_u64(10);   // decode_float_dev without its signals
+    for (int i = 1; i < 5; i++) {
+        p10 = fr_sqr(p10);
+        if ((f40 >> (35 + i)) & 1) pe = fr_mul(pe, p10);
+    }
+    x.amount = fr_mul(fr_from_u64(f40 & ((1ull << 35) - 1)), pe);
+    x.sigL2Hash = fr_zero();   // stays with the DecodeTx lane
+}
+
 // MultiMux3(1): stores s10,a210,a21,a20,a10,a1,a0,out
 __device__ __forceinline__ Fr mux3_dev(const UnitIO& io, const Mux3Off& o, const Fr* c, const Fr* s) {
     const Fr s10 = fr_mul(s[1], s[0]);
@@ -291,7 +308,7 @@ struct FrontOut {
 // accFeeIn / feePlanTokens are read through the pointers (Montgomery conversion on load).
 template <class IN, class FEE>
 __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const Scratch& sc, const RtxOff& o, const IN& in, const RtxExt& x,
-                                                       int Fn, const FEE& feeSrc) {
+                                                       int Fn, const FEE& feeSrc, bool own_sig = true) {
     const Fr one = fr_one(), zero = fr_zero();
     const Fr onChain = io.in_m(in.onChain), newAccount = io.in_m(in.newAccount);
     const Fr notOn = fr_sub(one, onChain);
@@ -532,7 +549,7 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
     sc.set(SC_ISEXIT, isExit); sc.set(SC_OLDSTATEROOT, x.oldStateRoot); sc.set(SC_OLDEXITROOT, x.oldExitRoot);
     sc.set(SC_ED_ENABLED, verifySignEnabled); sc.set(SC_ED_SIGN, signSig); sc.set(SC_ED_AYSIG, aySig); sc.set(SC_ED_AY, mx[MX_S1AY]);
     sc.set(SC_ED_S, io.in_m(in.s)); sc.set(SC_ED_R8X, io.in_m(in.r8x)); sc.set(SC_ED_R8Y, io.in_m(in.r8y));
-    sc.set(SC_SIGL2HASH, x.sigL2Hash);
+    if (own_sig) sc.set(SC_SIGL2HASH, x.sigL2Hash);   // else: the DecodeTx lane stores it
     sc.set(SC_ISAMTNULL, isAmountNullified);
     FrontOut r;
     r.isAmountNullified = isAmountNullified;

@@ -1,5 +1,5 @@
 // Kernels of the per-transaction path (SURVEY 8a' K2-K4 and the back/top step):
-//   k_main_front  lane = tx         RollupMain phase A/C checks + DecodeTx + RollupTx front
+//   k_main_front  lane = (tx, half) RollupMain phase A/C checks + DecodeTx | RollupTx front
 //   k_rtx_front   lane = instance   standalone RollupTx front
 //   k_dec_main    lane = instance   standalone DecodeTx
 //   k_hash4       lane = (tx, j)    HashState j in {old1, old2, new1, new2} + its SMTHash1
@@ -48,6 +48,9 @@ struct FeeSrcRtx {
 #ifndef HZ_FRONT_WAVES
 #define HZ_FRONT_WAVES 2
 #endif
+// Two lanes per transaction (blockIdx.y): 0 = RollupMain's boolean checks, DecodeTx and the im* checks on its outputs; 1 = the
+// RollupTx front logic, which takes the few DecodeTx outputs it consumes straight from the input bits (decode_fields_dev). The halves
+// share no signal; a single batch has 32 wavefronts per half and the kernel is the head of both of its critical paths.
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_main_front(const MainFrontArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     uint32_t* lds = lds_raw;
@@ -63,34 +66,37 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRO
     const MainTxInOff& m = a.mi;
     auto glob = [&](uint32_t sig) { return fr_from_canon(load_fr(a.glob_base + ((size_t)sig * a.B + b) * 32)); };
     const Fr one = fr_one();
-    // A (src/rollup-main.circom:207-219)
-    auto bool_chk = [&](int cid, const Fr& v) { io.chk_zero(cid, fr_mul(v, fr_sub(v, one))); };
-    if (i + 1 < a.nTx) bool_chk(C_MAIN_IMONCHAIN_BOOL, io.in_m(m.imOnChain));
-    bool_chk(C_MAIN_ONCHAIN_BOOL, io.in_m(m.onChain));
-    bool_chk(C_MAIN_NEWACCOUNT_BOOL, io.in_m(m.newAccount));
-    for (int j = 0; j < 256; j++) {
-        const Fc b = io.in_c(m.fromBjjCompressed + j);
-        uint32_t hi = 0;
-        for (int k = 1; k < 8; k++) hi |= b.v[k];
-        if (hi || b.v[0] > 1u) bool_chk(C_MAIN_BJJ_BOOL, fr_from_canon(b));
+    if (blockIdx.y == 0) {
+        // A (src/rollup-main.circom:207-219)
+        auto bool_chk = [&](int cid, const Fr& v) { io.chk_zero(cid, fr_mul(v, fr_sub(v, one))); };
+        if (i + 1 < a.nTx) bool_chk(C_MAIN_IMONCHAIN_BOOL, io.in_m(m.imOnChain));
+        bool_chk(C_MAIN_ONCHAIN_BOOL, io.in_m(m.onChain));
+        bool_chk(C_MAIN_NEWACCOUNT_BOOL, io.in_m(m.newAccount));
+        for (int j = 0; j < 256; j++) {
+            const Fc b = io.in_c(m.fromBjjCompressed + j);
+            uint32_t hi = 0;
+            for (int k = 1; k < 8; k++) hi |= b.v[k];
+            if (hi || b.v[0] > 1u) bool_chk(C_MAIN_BJJ_BOOL, fr_from_canon(b));
+        }
+        bool_chk(C_MAIN_ISOLD0_1_BOOL, io.in_m(m.isOld0_1));
+        bool_chk(C_MAIN_ISOLD0_2_BOOL, io.in_m(m.isOld0_2));
+        // B
+        const Fr previousOnChain = i == 0 ? one : io.in_m_u(m.imOnChain, u - 1);
+        const Fr inIdx = i == 0 ? glob(a.g.oldLastIdx) : io.in_m_u(m.imOutIdx, u - 1);
+        const DecResult d = decode_tx_dev(io, a.dec, m, (int)a.L, previousOnChain, inIdx, glob(a.g.globalChainID), glob(a.g.currentNumBatch), K7);
+        // C (:258-265)
+        io.chk(C_MAIN_IM_V2, d.v2, io.in_m(m.txCompressedDataV2));
+        if (i + 1 < a.nTx) {
+            io.chk(C_MAIN_IM_ONCHAIN, io.in_m(m.onChain), io.in_m(m.imOnChain));
+            io.chk(C_MAIN_IM_OUTIDX, d.outIdx, io.in_m(m.imOutIdx));
+        }
+        sc.set(SC_OUTIDX, d.outIdx);
+        sc.set(SC_SIGL2HASH, d.sigL2Hash);
+        return;
     }
-    bool_chk(C_MAIN_ISOLD0_1_BOOL, io.in_m(m.isOld0_1));
-    bool_chk(C_MAIN_ISOLD0_2_BOOL, io.in_m(m.isOld0_2));
-    // B
-    const Fr previousOnChain = i == 0 ? one : io.in_m_u(m.imOnChain, u - 1);
-    const Fr inIdx = i == 0 ? glob(a.g.oldLastIdx) : io.in_m_u(m.imOutIdx, u - 1);
-    const DecResult d = decode_tx_dev(io, a.dec, m, (int)a.L, previousOnChain, inIdx, glob(a.g.globalChainID), glob(a.g.currentNumBatch), K7);
-    // C (:258-265)
-    io.chk(C_MAIN_IM_V2, d.v2, io.in_m(m.txCompressedDataV2));
-    if (i + 1 < a.nTx) {
-        io.chk(C_MAIN_IM_ONCHAIN, io.in_m(m.onChain), io.in_m(m.imOnChain));
-        io.chk(C_MAIN_IM_OUTIDX, d.outIdx, io.in_m(m.imOutIdx));
-    }
-    sc.set(SC_OUTIDX, d.outIdx);
     // D: wiring (:269-379)
     RtxExt x;
-    x.fromIdx = d.fromIdx; x.toIdx = d.toIdx; x.toBjjSign = d.toBjjSign; x.amount = d.amount; x.tokenID = d.tokenID; x.nonce = d.nonce;
-    x.userFee = d.userFee; x.sigL2Hash = d.sigL2Hash;
+    decode_fields_dev(io, m, x);
     x.oldStateRoot = i == 0 ? glob(a.g.oldStateRoot) : io.in_m_u(m.imStateRoot, u - 1);
     x.oldExitRoot = i == 0 ? fr_zero() : io.in_m_u(m.imExitRoot, u - 1);
     for (int j = 0; j < 3; j++) {
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRO
         x.pastAy[j] = ok ? io.in_m_u(m.toBjjAy, u - j - 1) : fr_zero();
     }
     const FeeSrcMain fs{&io, a.fee_base, a.B * a.F, b * a.F, a.fi.feePlanTokens, a.fi.imFinalAccFee, m.imAccFeeOut, a.nTx, i};
-    rollup_tx_front_dev(io, sc, a.rtx, m, x, (int)a.F, fs);
+    rollup_tx_front_dev(io, sc, a.rtx, m, x, (int)a.F, fs, false);
 }
 
 
@@ -195,7 +201,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_da_mask(const RtxBackArgs a) {
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_main_front, grid1(a.ucnt ? a.ucnt : a.B * a.nTx), dim3(HZ_BLOCK), poseidon_lds_bytes<7>(), s, a);
+    dim3 g = grid1(a.ucnt ? a.ucnt : a.B * a.nTx);
+    g.y = 2;   // DecodeTx lane, RollupTx-front lane
+    hipLaunchKernelGGL(k_main_front, g, dim3(HZ_BLOCK), poseidon_lds_bytes<7>(), s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
