@@ -24,6 +24,7 @@ struct hz_ctx {
     Layout lo;
     int device = 0;
     DevBuf wit, sc_tx, sc_fee, err, msg, chain, stage;
+    DevBuf ed_side;   // the small-launch signature ladder's parked numerators (eddsa_side_bytes)
     std::vector<uint8_t> input_set;
     std::vector<uint8_t> host_stage;
     hipStream_t last_stream = nullptr;
@@ -181,6 +182,7 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     if (e == hipSuccess) e = hipMemset(c->wit.p, 0, lo.total * 32);
     if (e == hipSuccess) e = c->err.alloc(sizeof(ErrBuf));
     if (e == hipSuccess && lo.sec_tx >= 0) e = c->sc_tx.alloc((size_t)SC_COUNT * lo.sections[lo.sec_tx].n_units * sizeof(Fr));
+    if (e == hipSuccess && (lo.p.tmpl == T_ROLLUP_MAIN || lo.p.tmpl == T_ROLLUP_TX)) e = c->ed_side.alloc(eddsa_side_bytes(lo.sections[lo.sec_tx].n_units));
     if (e == hipSuccess && lo.sec_fee >= 0) e = c->sc_fee.alloc((size_t)SC_COUNT * lo.sections[lo.sec_fee].n_units * sizeof(Fr));
     if (e == hipSuccess && lo.sec_hi >= 0) {
         e = c->msg.alloc((size_t)lo.hi.sha.nblocks * 64 * lo.n_inst);
@@ -591,6 +593,7 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.upi = lo.sections[lo.sec_tx].upi; ea.ed = lo.rtx.ed;
     const uint32_t u0 = is_main ? c->sh_first : 0, ucnt = is_main ? c->sh_count : 0;
     ea.u0 = u0; ea.ucnt = ucnt;
+    ea.side = (uint32_t*)c->ed_side.p;   // sized for the whole section; a shard uses a prefix
     {
         // the signature ladders only need the front step: run them beside the hash/SMT chain
         // the two halves of the check (S*B8 and R8 + h*8A) are independent: two kernels on two streams, then the equality

@@ -74,6 +74,9 @@ __device__ Fr fr_sqrt_circom_dev(const Fr& n) {
 #ifndef HZ_ED_G
 #define HZ_ED_G 2   // signatures per lane (launches above 8192 signatures)
 #endif
+#ifndef HZ_ED_SPLIT_MAX
+#define HZ_ED_SPLIT_MAX 8192   // launches up to this many signatures: segments as lanes, no inversion per step (seg_any_proj)
+#endif
 
 struct EdCtx {
     UnitIO io;
@@ -224,6 +227,136 @@ __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const 
         c.io.put_m(o.lastSel, r.x); c.io.put_m(o.lastSel + 1, r.y);
         p[g] = r;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// SegmentMulAny(n) for ONE signature without an inversion per step (launches the device does not fill: a step of seg_any_lock is
+// 60 us of one wavefront, 42 of them the inversion). The circuit's recurrences are rational maps, so they are walked with
+// denominators carried along -- x = X / Z^2, y = Y / Z^3 for the doubling chain D_i and for the accumulator -- and every signal is
+// a numerator times a power of an inverse:
+//   doubler (lamda = (3x^2 + 2Ax + 1) / 2y):  Z' = 2YZ, N = 3X^2 + 2A X Z^2 + Z^4, lamda = N / Z', X' = N^2 - A Z'^2 - 8 X Y^2,
+//                                              Y' = N (4 X Y^2 - X') - 8 Y^4
+//   adder (lamda = (y2 - y1) / (x2 - x1)):     U1 = X1 Z2^2, U2 = X2 Z1^2, S1 = Y1 Z2^3, S2 = Y2 Z1^3, H = U2 - U1, R = S2 - S1,
+//                                              Z3 = H Z1 Z2, lamda = R / Z3, X3 = R^2 - A Z3^2 - (U1 + U2) H^2, Y3 = R (U1 H^2 - X3) - S1 H^3
+// Pass 1 walks the steps forward and parks the numerators, every adder's Z3 and the running product of the Z3 in `side` (8 field
+// elements per step, [step][field][limb][lane]); ONE inversion of (product of all Z3) * (last doubler Z) follows; pass 2 walks
+// backward, peels the inverses off (Montgomery's trick for the Z3; 1 / Z_i = (1 / Z_{i+1}) * 2 Y_i for the doubling chain) and
+// stores the signals; pass 3 copies the selector outputs forward (the selected adder outputs, already in the witness).
+// Any zero divisor of the circuit (x2 = x1, y = 0) makes the product zero: that signature is walked again by seg_any_lock<1>, with
+// the circuit's own 0-divisor convention and its constraint checks. Values are field elements either way: identical signals.
+enum { SD_R = 0, SD_X3, SD_Y3, SD_Z3, SD_P, SD_N, SD_XN, SD_YN, SD_FIELDS };
+struct SideBuf {
+    uint32_t* p;
+    uint32_t stride, lane;
+    __device__ __forceinline__ void put(int step, int f, const Fr& v) const {
+        uint32_t* q = p + (size_t)((step * SD_FIELDS + f) * 9) * stride + lane;
+#pragma unroll
+        for (int l = 0; l < 9; l++) q[(size_t)l * stride] = v.v[l];
+    }
+    __device__ __forceinline__ Fr get(int step, int f) const {
+        const uint32_t* q = p + (size_t)((step * SD_FIELDS + f) * 9) * stride + lane;
+        Fr r;
+#pragma unroll
+        for (int l = 0; l < 9; l++) r.v[l] = q[(size_t)l * stride];
+        return r;
+    }
+};
+template <int G> __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl);
+
+__device__ __noinline__ void seg_any_proj(const EdK& K, const UnitIO& io, const SegAnyOff& o, const Fc& e, int e0, int n, PtA* p, PtA* dbl, const SideBuf& sd) {
+    const EdCtx c = K.with(io);
+    const int steps = n - 1;
+    const PtA m = e2m_dev(c, *p);
+    io.put_m(o.e2m, m.x); io.put_m(o.e2m + 1, m.y);
+    const MDbl d0 = mont_dbl_dev(c, m);   // doubler_0
+    io.put_m(o.bits + BIT_DBL_X1_2, d0.x1_2); io.put_m(o.bits + BIT_DBL_LAMDA, d0.lamda);
+    io.put_m(o.bits + BIT_DBL_OUT0, d0.out.x); io.put_m(o.bits + BIT_DBL_OUT1, d0.out.y);
+    const Fr A2 = fr_dbl(K.A);
+    // ---- pass 1
+    Fr X1 = d0.out.x, Y1 = d0.out.y, Z1 = K.one;
+    Fr X2 = m.x, Y2 = m.y, Z2 = K.one, Z2s = K.one, Z2c = K.one;
+    Fr P = K.one;
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        const Fr Z1s = fr_sqr(Z1), Z1c = fr_mul(Z1s, Z1);
+        const Fr U1 = fr_mul(X1, Z2s), U2 = fr_mul(X2, Z1s), S1 = fr_mul(Y1, Z2c), S2 = fr_mul(Y2, Z1c);
+        const Fr H = fr_sub(U2, U1), R = fr_sub(S2, S1);
+        const Fr Z3 = fr_mul(H, fr_mul(Z1, Z2));
+        const Fr Hs = fr_sqr(H), Hc = fr_mul(Hs, H), Z3s = fr_sqr(Z3), U1Hs = fr_mul(U1, Hs);
+        const Fr X3 = fr_sub(fr_sub(fr_sqr(R), fr_mul(K.A, Z3s)), fr_mul(fr_add(U1, U2), Hs));
+        const Fr Y3 = fr_sub(fr_mul(R, fr_sub(U1Hs, X3)), fr_mul(S1, Hc));
+        P = fr_mul(P, Z3);
+        sd.put(i, SD_R, R); sd.put(i, SD_X3, X3); sd.put(i, SD_Y3, Y3); sd.put(i, SD_Z3, Z3); sd.put(i, SD_P, P);
+        if (i + 1 < steps) {
+            const Fr Ys = fr_sqr(Y1), XYs = fr_mul(X1, Ys), Y4 = fr_sqr(Ys), XX = fr_sqr(X1);
+            const Fr N = fr_add(fr_add(fr_add(fr_dbl(XX), XX), fr_mul(A2, fr_mul(X1, Z1s))), fr_sqr(Z1s));
+            const Fr Zn = fr_dbl(fr_mul(Y1, Z1));
+            const Fr XYs4 = fr_dbl(fr_dbl(XYs));
+            const Fr Xn = fr_sub(fr_sub(fr_sqr(N), fr_mul(K.A, fr_sqr(Zn))), fr_dbl(XYs4));
+            const Fr Yn = fr_sub(fr_mul(N, fr_sub(XYs4, Xn)), fr_dbl(fr_dbl(fr_dbl(Y4))));
+            sd.put(i, SD_N, N); sd.put(i, SD_XN, Xn); sd.put(i, SD_YN, Yn);
+            X1 = Xn; Y1 = Yn; Z1 = Zn;
+        }
+        if (c_bit(e, e0 + i + 1)) { X2 = X3; Y2 = Y3; Z2 = Z3; Z2s = Z3s; Z2c = fr_mul(Z3s, Z3); }
+    }
+    // ---- the one inversion: every adder's Z3 and the Z of the last doubler output (Z1 now)
+    const Fr total = fr_mul(P, Z1);
+    if (fr_is_zero(total)) {
+        seg_any_lock<1>(K, &io, o, &e, e0, n, p, dbl);
+        return;
+    }
+    const Fr tinv = fr_inv(total);
+    Fr iZ = fr_mul(tinv, P);      // 1 / Z of dout_{steps-1}
+    Fr Rr = fr_mul(tinv, Z1);     // 1 / (Z3_0 ... Z3_{steps-1})
+    // ---- pass 2
+    PtA fin = m, dlast = d0.out;
+    bool have_fin = false;
+#pragma unroll 1
+    for (int i = steps - 1; i >= 0; i--) {
+        const uint32_t b = o.bits + BIT_N * i;
+        {
+            const Fr iZ3 = i > 0 ? fr_mul(Rr, sd.get(i - 1, SD_P)) : Rr;
+            Rr = fr_mul(Rr, sd.get(i, SD_Z3));
+            const Fr t = fr_sqr(iZ3);
+            PtA ao;
+            ao.x = fr_mul(sd.get(i, SD_X3), t);
+            ao.y = fr_mul(sd.get(i, SD_Y3), fr_mul(t, iZ3));
+            io.put_m(b + BIT_ADD_LAMDA, fr_mul(sd.get(i, SD_R), iZ3)); io.put_m(b + BIT_ADD_OUT0, ao.x); io.put_m(b + BIT_ADD_OUT1, ao.y);
+            if (!have_fin && c_bit(e, e0 + i + 1)) { fin = ao; have_fin = true; }
+        }
+        if (i + 1 < steps) {   // doubler_{i+1}: iZ = 1 / Z of its output
+            const uint32_t bn = b + BIT_N;
+            const Fr t = fr_sqr(iZ);
+            PtA no;
+            no.x = fr_mul(sd.get(i, SD_XN), t);
+            no.y = fr_mul(sd.get(i, SD_YN), fr_mul(t, iZ));
+            io.put_m(bn + BIT_DBL_LAMDA, fr_mul(sd.get(i, SD_N), iZ)); io.put_m(bn + BIT_DBL_OUT0, no.x); io.put_m(bn + BIT_DBL_OUT1, no.y);
+            if (i + 2 < steps) io.put_m(bn + BIT_N + BIT_DBL_X1_2, fr_sqr(no.x));   // doubler_{i+2}.x1_2 = x_{i+1}^2
+            if (i + 2 == steps) dlast = no;
+            iZ = fr_mul(iZ, fr_dbl(i > 0 ? sd.get(i - 1, SD_YN) : d0.out.y));       // Z_{i+1} = 2 Y_i Z_i
+        }
+    }
+    if (steps > 1) io.put_m(o.bits + BIT_N + BIT_DBL_X1_2, fr_sqr(d0.out.x));
+    // ---- pass 3: selector outputs = the accumulator after each step
+    {
+        Fc cx = fr_to_canon(m.x), cy = fr_to_canon(m.y);
+#pragma unroll 1
+        for (int i = 0; i < steps; i++) {
+            const uint32_t b = o.bits + BIT_N * i;
+            if (c_bit(e, e0 + i + 1)) { cx = io.in_c(b + BIT_ADD_OUT0); cy = io.in_c(b + BIT_ADD_OUT1); }
+            io.put_c(b + BIT_SEL_OUT0, cx); io.put_c(b + BIT_SEL_OUT1, cy);
+        }
+    }
+    *dbl = dlast;
+    const PtA me = m2e_dev(c, fin);
+    io.put_m(o.m2e, me.x); io.put_m(o.m2e + 1, me.y);
+    PtA negp;
+    negp.x = fr_neg(p->x);
+    negp.y = p->y;
+    const PtA ea = baby_add_dev(c, o.eadder, me, negp);
+    const PtA r = c_bit(e, e0) ? me : ea;
+    io.put_m(o.lastSel, r.x); io.put_m(o.lastSel + 1, r.y);
+    *p = r;
 }
 
 // C ladder chains in lockstep that need not be the same segment: chain c walks bits e[c][e0[c] .. e0[c] + n[c]) with the signal
@@ -613,7 +746,11 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
             c.io.put_m(o.m2e0, p[g].x); c.io.put_m(o.m2e0 + 1, p[g].y);
         }
     }
-    if (seg == 0) seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);
+    if (G == 1 && a.side) {
+        const SideBuf sd{a.side, 2 * nl, seg * nl + li};
+        if (seg == 0) seg_any_proj(K, io[0], o.seg[0], h_c[0], 0, 148, p, dbl, sd);
+        else seg_any_proj(K, io[0], o.seg[1], h_c[0], 148, 106, p, dbl, sd);
+    } else if (seg == 0) seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);
     else seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, p, dbl);
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
@@ -836,14 +973,14 @@ static hipError_t launch_eddsa_fix_g(const EddsaArgs& a, uint32_t n, hipStream_t
     hipLaunchKernelGGL(k_eddsa_fix<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
+size_t eddsa_side_bytes(uint32_t n) {
+    return n <= HZ_ED_SPLIT_MAX ? (size_t)2 * n * 147 * SD_FIELDS * 9 * sizeof(uint32_t) : 0;
+}
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
 #ifdef HZ_ED_G_FIXED
     return launch_eddsa_g<HZ_ED_G>(a, n, s);
 #else
-#ifndef HZ_ED_SPLIT_MAX
-#define HZ_ED_SPLIT_MAX 8192
-#endif
     // a launch the device does not fill is latency bound: the two segments of every signature as independent lanes (148 / 106
     // dependent steps instead of 254), one signature per lane
     if (n <= HZ_ED_SPLIT_MAX) return launch_eddsa_split<1>(a, n, s);

@@ -122,7 +122,9 @@ struct EddsaArgs {
     ErrBuf* err;
     uint32_t n_units, upi;
     EddsaOff ed;
+    uint32_t* side;      // seg_any_proj's parked numerators (eddsa_side_bytes(n)); nullptr: the inversion-per-step ladder
 };
+size_t eddsa_side_bytes(uint32_t n_signatures);   // 0 when a launch of that size does not use the buffer
 
 // FeeTx (reference src/fee-tx.circom:26-112): front = IsZero/checker + hash-state inputs,
 // back = processor top + newStateRoot (+ RollupMain phase G check)
