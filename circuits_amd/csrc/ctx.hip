@@ -584,7 +584,8 @@ static HashInputsArgs make_hi(hz_ctx* c, bool is_main);
 // (4 lanes per batch) on the fee stream right after the hash-state kernel, then the message, the sequential chain and the
 // expansion follow there while the main stream hashes the other 2047 transactions (which recomputes the last one's signals to the
 // same values). The 3.6 ms of one-wavefront chain latency and the expansion leave the end of the step.
-static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, uint32_t sib1, uint32_t sib2, hipStream_t s, bool early_tail = false) {
+static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, uint32_t sib1, uint32_t sib2, hipStream_t s, bool early_tail = false,
+                                  bool early_prep = false) {
     const Layout& lo = c->lo;
     Fr* sc = (Fr*)c->sc_tx.p;
     ErrBuf* err = (ErrBuf*)c->err.p;
@@ -656,6 +657,15 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
             ProfScope ps(c, st, "hash_inputs", (uint64_t)lo.hi.sha.nblocks);
             HZ_HIP(launch_hash_inputs(make_hi(c, true), st, c->exclusive ? nullptr : c->s_sha, c->ev_sha, 9));
         }
+        HZ_HIP(hipEventRecord(c->ev_tail, st));
+    }
+    if (early_prep) {
+        // CU-partitioned contexts (a few batches, latency): the chain cannot start before the roots are known (they sit in the first
+        // block), but the rest of the message can be laid out while the SMT chains run
+        hipStream_t st = c->s_fee;
+        HZ_HIP(hipStreamWaitEvent(st, c->ev_front, 0));
+        HZ_HIP(launch_da_mask(ba, st));
+        HZ_HIP(launch_hi_prep_body(make_hi(c, true), st));
         HZ_HIP(hipEventRecord(c->ev_tail, st));
     }
 #ifndef HZ_EXPERIMENT_SKIP_SMT
@@ -797,14 +807,16 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             { ProfScope ps(c, s, "front", (uint64_t)fa.nTx * fa.B); HZ_HIP(launch_main_front(fa, s)); }
             HZ_HIP(hipEventRecord(c->ev_front, s));
             const bool early = tail_now && !c->partitioned && HZ_EARLY_TAIL;   // CU-partitioned contexts keep the tail on the main stream
-            st = enqueue_rtx_tail(c, fa.tx_base, lo.sections[lo.sec_tx].n_units, true, lo.mi.siblings1, lo.mi.siblings2, s, early);
+            const bool early_prep = tail_now && c->partitioned;
+            st = enqueue_rtx_tail(c, fa.tx_base, lo.sections[lo.sec_tx].n_units, true, lo.mi.siblings1, lo.mi.siblings2, s, early, early_prep);
             if (st != HZ_OK) return st;
             if (early) {
                 HZ_HIP(hipStreamWaitEvent(s, c->ev_tail, 0));
             } else if (tail_now) {
                 // HashInputs needs the roots and the data-availability bits, not the signatures: it runs beside the ladders
                 HZ_HIP(hipStreamWaitEvent(s, c->ev_fee, 0));
-                { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s, c->partitioned ? nullptr : c->s_fee, c->ev_sha, 9)); }
+                if (early_prep) HZ_HIP(hipStreamWaitEvent(s, c->ev_tail, 0));
+                { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s, c->partitioned ? nullptr : c->s_fee, c->ev_sha, 9, early_prep)); }
             }
             HZ_HIP(hipStreamWaitEvent(s, c->ev_ed, 0));   // join the signature stream
             break;

@@ -87,8 +87,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t L = a.L, nTx = a.nTx, maxL1 = a.maxL1, Fn = a.F, B = a.B;
     const uint32_t n_items = 1 + maxL1 + nTx + Fn;
-    if (gt >= n_items * B) return;
-    const uint32_t bt = gt / n_items, t = gt % n_items;   // batch, item
+    if (gt >= (a.prep_part == 2 ? 1u : n_items) * B) return;
+    const uint32_t bt = a.prep_part == 2 ? gt : gt / n_items, t = a.prep_part == 2 ? 0u : gt % n_items;   // batch, item
+    if (a.prep_part == 1 && t == 0) return;
     const uint32_t txU = B * nTx, feeU = B * Fn, tx0 = bt * nTx, fee0 = bt * Fn;
     uint32_t* msgw = reinterpret_cast<uint32_t*>(a.msg) + (size_t)bt * a.hi.sha.nblocks * 16;
     const HashInputsOff& o = a.hi;
@@ -230,6 +231,99 @@ __global__ __launch_bounds__(256) void k_sha_chain(const HashInputsArgs a) {
     }
     if (!active) return;
     if (blk1 < nb) {   // the next group's launch continues from here
+        for (int i = 0; i < 8; i++) chain[8 * blk1 + i] = hv[i];
+        return;
+    }
+    const Fc out = sha_digest_to_fr(hv);
+    if (a.is_main) store_fr(a.glob_base + ((size_t)a.g.hashGlobalInputs * a.B + bt) * 32, out);
+    else store_fr(a.hi_base + ((size_t)a.hi.out * a.B + bt) * 32, out);
+    if (a.is_main) {
+        uint4* q = reinterpret_cast<uint4*>(a.glob_base + ((size_t)a.g.one * a.B + bt) * 32);
+        q[0] = make_uint4(1u, 0u, 0u, 0u);
+        q[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// The same chain for launches of a few batches (a single batch: the chain is 766 dependent compressions of ONE lane and the tail of
+// the step's critical path). The message schedule does not depend on the chaining value: wavefronts 1-3 expand the next chunk's
+// blocks (one block per lane: W[0..63] + K) into LDS while lane l of wavefront 0 walks batch l's current chunk with the round
+// function alone -- 4.2 -> 2.6 ms per 766 blocks.
+#define HZ_SHAW_BATCH 8
+#define HZ_SHAW_ROW 65   // words per expanded block, odd: the lanes of wavefront 0 read the same word of different rows
+__global__ __launch_bounds__(256) void k_sha_chain_w(const HashInputsArgs a) {
+    __shared__ uint32_t wk[2][HZ_SHAW_BATCH * HZ_SHA_CHUNK * HZ_SHAW_ROW];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t bt0 = blockIdx.x * HZ_SHAW_BATCH;
+    const uint32_t nbt = min((uint32_t)HZ_SHAW_BATCH, a.B - bt0);
+    const int nb = a.hi.sha.nblocks;
+    const int blk0 = (int)a.blk0, blk1 = (int)a.blk1;
+    const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg);
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
+    auto expand = [&](int c0, int which) {
+        if (wave == 0) return;
+        for (uint32_t q = tid - 64; q < nbt * HZ_SHA_CHUNK; q += 192) {
+            const uint32_t l = q / HZ_SHA_CHUNK, j = q % HZ_SHA_CHUNK;
+            const int b = c0 + (int)j;
+            if (b >= blk1) continue;
+            const uint32_t* src = msgw + ((size_t)(bt0 + l) * nb + b) * 16;
+            uint32_t* dst = &wk[which][(l * HZ_SHA_CHUNK + j) * HZ_SHAW_ROW];
+            uint32_t w[64];
+            for (int t = 0; t < 16; t++) w[t] = src[t];
+            for (int t = 16; t < 64; t++) {
+                const uint32_t s0 = rotr32(w[t - 15], 7) ^ rotr32(w[t - 15], 18) ^ (w[t - 15] >> 3);
+                const uint32_t s1 = rotr32(w[t - 2], 17) ^ rotr32(w[t - 2], 19) ^ (w[t - 2] >> 10);
+                w[t] = s1 + w[t - 7] + s0 + w[t - 16];
+            }
+            for (int t = 0; t < 64; t++) dst[t] = w[t] + SHA_K[t];
+        }
+    };
+    if (wave == 0) {   // nothing to walk yet: wavefront 0 helps with the first chunk
+        for (uint32_t q = tid; q < nbt * HZ_SHA_CHUNK; q += 64) {
+            const uint32_t l = q / HZ_SHA_CHUNK, j = q % HZ_SHA_CHUNK;
+            const int b = blk0 + (int)j;
+            if (b >= blk1) continue;
+            const uint32_t* src = msgw + ((size_t)(bt0 + l) * nb + b) * 16;
+            uint32_t* dst = &wk[0][(l * HZ_SHA_CHUNK + j) * HZ_SHAW_ROW];
+            uint32_t w[64];
+            for (int t = 0; t < 16; t++) w[t] = src[t];
+            for (int t = 16; t < 64; t++) {
+                const uint32_t s0 = rotr32(w[t - 15], 7) ^ rotr32(w[t - 15], 18) ^ (w[t - 15] >> 3);
+                const uint32_t s1 = rotr32(w[t - 2], 17) ^ rotr32(w[t - 2], 19) ^ (w[t - 2] >> 10);
+                w[t] = s1 + w[t - 7] + s0 + w[t - 16];
+            }
+            for (int t = 0; t < 64; t++) dst[t] = w[t] + SHA_K[t];
+        }
+    }
+    __syncthreads();
+    const bool active = wave == 0 && lane < nbt;
+    const uint32_t bt = bt0 + lane;
+    uint32_t* chain = a.chain + (size_t)bt * (nb + 1) * 8;
+    uint32_t hv[8];
+    if (active)
+        for (int i = 0; i < 8; i++) hv[i] = blk0 == 0 ? SHA_H0[i] : chain[8 * blk0 + i];
+    int which = 0;
+    for (int c0 = blk0; c0 < blk1; c0 += HZ_SHA_CHUNK) {
+        if (c0 + HZ_SHA_CHUNK < blk1) expand(c0 + HZ_SHA_CHUNK, which ^ 1);
+        if (active) {
+            const int cnt = min(HZ_SHA_CHUNK, blk1 - c0);
+            for (int j = 0; j < cnt; j++) {
+                for (int i = 0; i < 8; i++) chain[8 * (c0 + j) + i] = hv[i];
+                const uint32_t* w = &wk[which][(lane * HZ_SHA_CHUNK + j) * HZ_SHAW_ROW];
+                uint32_t x0 = hv[0], x1 = hv[1], x2 = hv[2], x3 = hv[3], x4 = hv[4], x5 = hv[5], x6 = hv[6], x7 = hv[7];
+#pragma unroll 8
+                for (int t = 0; t < 64; t++) {
+                    const uint32_t t1 = x7 + (rotr32(x4, 6) ^ rotr32(x4, 11) ^ rotr32(x4, 25)) + ((x4 & x5) ^ (~x4 & x6)) + w[t];
+                    const uint32_t t2 = (rotr32(x0, 2) ^ rotr32(x0, 13) ^ rotr32(x0, 22)) + ((x0 & x1) ^ (x0 & x2) ^ (x1 & x2));
+                    x7 = x6; x6 = x5; x5 = x4; x4 = x3 + t1; x3 = x2; x2 = x1; x1 = x0; x0 = t1 + t2;
+                }
+                hv[0] += x0; hv[1] += x1; hv[2] += x2; hv[3] += x3; hv[4] += x4; hv[5] += x5; hv[6] += x6; hv[7] += x7;
+            }
+        }
+        __syncthreads();
+        which ^= 1;
+    }
+    if (!active) return;
+    if (blk1 < nb) {
         for (int i = 0; i < 8; i++) chain[8 * blk1 + i] = hv[i];
         return;
     }
@@ -483,12 +577,27 @@ hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff&
 #ifndef HZ_SHA_GROUPS
 #define HZ_SHA_GROUPS 8
 #endif
-hipError_t launch_hash_inputs(const HashInputsArgs& a0, hipStream_t s, hipStream_t side, hipEvent_t* ev, int n_ev) {
+hipError_t launch_hi_prep_body(const HashInputsArgs& a0, hipStream_t s) {
     HashInputsArgs a = a0;
-    const size_t msg_bytes = (size_t)a.hi.sha.nblocks * 64 * a.B;
-    hipError_t e = hipMemsetAsync(a.msg, 0, msg_bytes, s);
+    const hipError_t e = hipMemsetAsync(a.msg, 0, (size_t)a.hi.sha.nblocks * 64 * a.B, s);
     if (e != hipSuccess) return e;
+    a.prep_part = 1;
     hipLaunchKernelGGL(k_hi_prep, grid1((1 + a.maxL1 + a.nTx + a.F) * a.B), dim3(HZ_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_hash_inputs(const HashInputsArgs& a0, hipStream_t s, hipStream_t side, hipEvent_t* ev, int n_ev, bool body_done) {
+    HashInputsArgs a = a0;
+    hipError_t e = hipSuccess;
+    if (body_done) {
+        a.prep_part = 2;
+        hipLaunchKernelGGL(k_hi_prep, grid1(a.B), dim3(HZ_BLOCK), 0, s, a);
+    } else {
+        const size_t msg_bytes = (size_t)a.hi.sha.nblocks * 64 * a.B;
+        e = hipMemsetAsync(a.msg, 0, msg_bytes, s);
+        if (e != hipSuccess) return e;
+        a.prep_part = 0;
+        hipLaunchKernelGGL(k_hi_prep, grid1((1 + a.maxL1 + a.nTx + a.F) * a.B), dim3(HZ_BLOCK), 0, s, a);
+    }
 #if !defined(HZ_EXPERIMENT_NO_SHA)   // timing experiment only (wrong witness)
     const uint32_t nb = (uint32_t)a.hi.sha.nblocks;
     const bool piped = side && side != s && ev && n_ev >= 2 && nb >= 64;
@@ -497,7 +606,8 @@ hipError_t launch_hash_inputs(const HashInputsArgs& a0, hipStream_t s, hipStream
     for (uint32_t g = 0, b0 = 0; b0 < nb; g++, b0 += per) {
         a.blk0 = b0;
         a.blk1 = std::min(nb, b0 + per);
-        hipLaunchKernelGGL(k_sha_chain, dim3((a.B + 63) / 64), dim3(256), 0, s, a);
+        if (a.B <= 2 * HZ_SHAW_BATCH) hipLaunchKernelGGL(k_sha_chain_w, dim3((a.B + HZ_SHAW_BATCH - 1) / HZ_SHAW_BATCH), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_sha_chain, dim3((a.B + 63) / 64), dim3(256), 0, s, a);
         hipStream_t sx = s;
         if (piped) {
             if ((e = hipEventRecord(ev[g], s)) != hipSuccess) return e;

@@ -166,6 +166,7 @@ struct HashInputsArgs {
     uint8_t* msg;              // device byte buffer for the padded message (nblocks * 64)
     uint32_t* chain;           // device buffer: (nblocks + 1) * 8 chaining words
     uint32_t blk0, blk1;       // SHA-256 blocks handled by one k_sha_chain / k_sha_expand launch (set by launch_hash_inputs)
+    uint32_t prep_part;        // k_hi_prep: 0 = the whole message, 1 = everything but the header lane, 2 = the header lane alone
 };
 
 struct WithdrawArgs {
@@ -207,7 +208,9 @@ hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s);     // S bits / 
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s);   // the equality of the two sides
 hipError_t launch_fee_front(const FeeFrontArgs& a, hipStream_t s);
 hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s);
-hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s, hipStream_t side = nullptr, hipEvent_t* ev = nullptr, int n_ev = 0);
+hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s, hipStream_t side = nullptr, hipEvent_t* ev = nullptr, int n_ev = 0, bool body_done = false);
+// the part of the message that does not wait for the roots (the data-availability bits: front kernel + k_da_mask); launch_hash_inputs(body_done = true) follows
+hipError_t launch_hi_prep_body(const HashInputsArgs& a, hipStream_t s);
 hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff& hs, hipStream_t s);
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s);
 
