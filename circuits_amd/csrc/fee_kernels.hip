@@ -344,6 +344,9 @@ __global__ __launch_bounds__(256) void k_sha_chain_w(const HashInputsArgs a) {
 #ifndef HZ_SHA_PARTS
 #define HZ_SHA_PARTS 8
 #endif
+#ifndef HZ_SHA_COOP
+#define HZ_SHA_COOP 1   // bit rows of the SHA-256 witness stored cooperatively by half-wavefronts (sha_dev.h put_word_bits)
+#endif
 __global__ __launch_bounds__(HZ_BLOCK) void k_sha_expand(const HashInputsArgs a) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nb = (uint32_t)a.hi.sha.nblocks, nblk = a.blk1 - a.blk0;
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_sha_expand(const HashInputsArgs a)
     const uint32_t bt = gt % a.B, rest = gt / a.B;
     const uint32_t b = a.blk0 + rest % nblk, part = rest / nblk;
     const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg) + (size_t)bt * nb * 16;
-    const UnitIO hio{a.hi_base, a.B, bt, bt, 0, a.err};
+    UnitIO hio{a.hi_base, a.B, bt, bt, 0, a.err};
+    hio.coop32 = HZ_SHA_COOP && (a.B % 32u == 0u);   // a half-wavefront = 32 consecutive batches of one (block, part); the grid is a multiple of 32
     uint32_t hv[8], w16[16];
     for (int i = 0; i < 8; i++) hv[i] = a.chain[((size_t)bt * (nb + 1) + b) * 8 + i];
     for (int i = 0; i < 16; i++) w16[i] = msgw[16 * b + i];
@@ -476,7 +480,8 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw_sha(const WithdrawArgs a)
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     if (gt >= 2 * a.N) return;
     const uint32_t i = gt % a.N, blk = gt / a.N;   // consecutive lanes = consecutive instances: coalesced stores
-    const UnitIO io{a.base, a.N, i, i, 0, a.err};
+    UnitIO io{a.base, a.N, i, i, 0, a.err};
+    io.coop32 = HZ_SHA_COOP && (a.N % 32u == 0u);   // then every aligned half-wavefront is 32 consecutive instances of one block, all active
     const WithdrawOff& o = a.wd;
     const Fr zero = fr_zero();
     const Fc rootExit_c = io.in_c(o.rootExit), ethAddr_c = io.in_c(o.ethAddr), tokenID_c = io.in_c(o.tokenID), balance_c = io.in_c(o.balance),

@@ -17,6 +17,9 @@ struct UnitIO {
     uint32_t inst;      // instance id for the failure key
     uint32_t err_unit;  // unit id for the failure key
     ErrBuf* err;
+    // 1: the 32 lanes of this lane's aligned half-wavefront own 32 consecutive units and run in lockstep, so runs of bit signals may
+    // be stored cooperatively (put_word_bits in sha_dev.h). Set by the kernels that guarantee it, wave-uniform.
+    uint32_t coop32 = 0;
 
     __device__ __forceinline__ uint8_t* addr(uint32_t sig) const { return base + ((size_t)sig * n_units + unit) * 32; }
     __device__ __forceinline__ uint8_t* addr_u(uint32_t sig, uint32_t u) const { return base + ((size_t)sig * n_units + u) * 32; }

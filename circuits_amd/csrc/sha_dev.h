@@ -37,7 +37,30 @@ __device__ __forceinline__ void sha256_compress(uint32_t* hv, const uint32_t* w1
     hv[0] += a; hv[1] += b; hv[2] += c; hv[3] += d; hv[4] += e; hv[5] += f; hv[6] += g; hv[7] += h;
 }
 
+// n consecutive bit signals off .. off+n-1 of this lane's unit = the low n bits of v.
+// A bit is a 32-byte element (bit, 0, ..., 0); stored lane by lane (store_fr) every instruction writes 16 of every 32 bytes and the
+// second one of a pair nothing but zeros -- measured at 3.5-4.6 TB/s (tools/microbench/storebench.hip, pattern 4). When the 32
+// lanes of a half-wavefront own 32 consecutive units (io.coop32) the 1 KiB row of a signal is written as two fully contiguous
+// 512-byte instructions instead: lane L of the group carries the first or second 16 bytes of unit L/2 (then 16 + L/2), the bits
+// travel once per word through two lane permutes (pattern 5: 4.9-5.7 TB/s). Same bytes at the same addresses.
 __device__ __forceinline__ void put_word_bits(const UnitIO& io, uint32_t off, uint64_t v, int n) {
+    if (io.coop32) {
+        const uint32_t lane = __lane_id(), gl = lane & 31u;
+        const int src = (int)((lane & 32u) | (gl >> 1));
+        uint32_t loA = __shfl((uint32_t)v, src), loB = __shfl((uint32_t)v, src + 16), hiA = 0, hiB = 0;
+        if (n > 32) { hiA = __shfl((uint32_t)(v >> 32), src); hiB = __shfl((uint32_t)(v >> 32), src + 16); }
+        if (gl & 1u) loA = loB = hiA = hiB = 0u;   // odd lanes carry the upper half of an element: zeros
+        const uint64_t vA = ((uint64_t)hiA << 32) | loA, vB = ((uint64_t)hiB << 32) | loB;
+        uint8_t* p = io.addr(off) - (size_t)gl * 16;
+        const size_t row = (size_t)io.n_units * 32;
+        for (int k = 0; k < n; k++) {
+            uint4* q = reinterpret_cast<uint4*>(p);
+            q[0] = make_uint4((uint32_t)(vA >> k) & 1u, 0u, 0u, 0u);
+            q[32] = make_uint4((uint32_t)(vB >> k) & 1u, 0u, 0u, 0u);
+            p += row;
+        }
+        return;
+    }
     for (int k = 0; k < n; k++) io.put_bit(off + k, (uint32_t)((v >> k) & 1));
 }
 // Xor3: mid = b & c, out = a ^ b ^ c  (64 signals)

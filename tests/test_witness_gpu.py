@@ -105,6 +105,28 @@ def test_withdraw_bit_exact(hz, batch):
         assert g.get("main.hashGlobalInputs", k) == exp
 
 
+@pytest.mark.parametrize("n", [96, 33])
+def test_withdraw_half_wavefront_groups_bit_exact(hz, n):
+    """96 instances: a multiple of 32 that is not a multiple of 64 -- the SHA-256 bit rows are stored cooperatively by half-wavefronts
+    and one wavefront holds block 0 of the last instances next to block 1 of the first; 33: the lane-by-lane store path."""
+    from circuits_amd import builder as B
+    fx = B.ExitTreeFixture(64)
+    idxs = sorted(fx.exit_leaves)
+    g = hz.ctx("withdraw", nLevels=16, n_instances=n)
+    o = OracleCtx("withdraw", nLevels=16, n_instances=n)
+    exps = []
+    for k in range(n):
+        inp, exp = B.withdraw_input(fx, idxs[(k * 5) % len(idxs)], 16)
+        g.set_inputs(inp, instance=k)
+        o.set_inputs(inp, instance=k)
+        exps.append(exp)
+    g.run()
+    assert o.run() is None
+    _compare_chunked(g, o)
+    for k, exp in enumerate(exps):
+        assert g.get("main.hashGlobalInputs", k) == exp
+
+
 def test_withdraw_config5_at_size(hz):
     """BASELINE config 5 at its stated shape: Withdraw(nLevels = 32), 4 160 instances = 65 wavefronts with a ragged tail, exits drawn
     from an exit tree of 2^12 leaves (hashed on the device, f1), whole buffer vs the oracle; every instance's hashGlobalInputs vs
@@ -392,10 +414,12 @@ def test_command_line_input_then_witness(hz, tmp_path):
     assert w[g.lookup("main.hashGlobalInputs")] == int(json.load(open(os.path.join(d, "expected.json")))["hashGlobalInputs"])
 
 
-@pytest.mark.parametrize("shape,inst", [((5, 10, 2, 1), 1), ((70, 10, 3, 3), 3), ((130, 24, 65, 5), 2), ((1, 48, 1, 1), 1)])
+@pytest.mark.parametrize("shape,inst", [((5, 10, 2, 1), 1), ((70, 10, 3, 3), 3), ((130, 24, 65, 5), 2), ((1, 48, 1, 1), 1),
+                                        ((3, 10, 1, 1), 32), ((2, 10, 1, 1), 96)])
 def test_odd_shapes_bit_exact(hz, shape, inst):
     """Ragged sizes: transaction counts that are not a multiple of the wavefront, a shallow and the deepest tree (account indices start at 256, so nLevels >= 9), a single fee
-    slot, several instances per launch (instance b holds its own batch)."""
+    slot, several instances per launch (instance b holds its own batch). 32 and 96 instances: the SHA-256 bit rows of HashInputs are
+    then stored cooperatively by half-wavefronts (sha_dev.h put_word_bits), with wavefronts whose halves work on different blocks."""
     from circuits_amd import builder as B
     nTx, L, m1, F = shape
     g = hz.ctx("rollup-main", nTx=nTx, nLevels=L, maxL1Tx=m1, maxFeeTx=F, n_instances=inst)

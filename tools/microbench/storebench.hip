@@ -3,7 +3,8 @@
 // Patterns:  0 = two dwordx4 per lane at a 32-byte lane stride (store_fr as it is: every instruction half-fills its 64-byte sectors)
 //            1 = the same 2 KiB written as two fully contiguous 1 KiB instructions (lane stride 16 bytes)
 //            2 = pattern 0, but lanes paired through DPP so that each instruction is contiguous (what a transposed store_fr would do)
-//            3 = one dwordx4 + 16 B of zeros via a second instruction from the same lane pair (bit signals: value in dword 0 only)
+//            4 = a bit signal (bit, 0, .., 0) through store_fr;  3 = the same, each instruction 1 KiB contiguous (bit of element L/2 in lane L)
+//            5 = as 3 in half-wavefront groups: 512 contiguous bytes per group and instruction (sha_dev.h put_word_bits)
 // build: hipcc -O3 --offload-arch=gfx950 storebench.hip -o storebench ; run: storebench [units=65536] [signals=2048] [reps=5]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,6 +50,14 @@ __global__ __launch_bounds__(64) void k_store(uint8_t* base, uint32_t N, uint32_
             uint4* q = reinterpret_cast<uint4*>(row + lane * 16);
             q[0] = make_uint4((lane & 1) ? 0u : bA, 0u, 0u, 0u);
             q[64] = make_uint4((lane & 1) ? 0u : bB, 0u, 0u, 0u);
+        } else if constexpr (P == 5) {
+            // bit signal, half-wavefront groups: each instruction writes 512 contiguous bytes per group (sha_dev.h put_word_bits)
+            const uint32_t bit = v & 1u, gl = lane & 31u;
+            const int src = (int)((lane & 32u) | (gl >> 1));
+            const uint32_t bA = __shfl(bit, src), bB = __shfl(bit, src + 16);
+            uint4* q = reinterpret_cast<uint4*>(row + (lane & 32u) * 32 + gl * 16);
+            q[0] = make_uint4((gl & 1) ? 0u : bA, 0u, 0u, 0u);
+            q[32] = make_uint4((gl & 1) ? 0u : bB, 0u, 0u, 0u);
         } else if constexpr (P == 4) {
             // bit signal, store_fr as it is
             const uint32_t bit = v & 1u;
@@ -92,6 +101,7 @@ int main(int argc, char** argv) {
     run<2>(d, N, S, reps, "as 1, elements transposed across lanes with 16 bpermutes");
     run<4>(d, N, S, reps, "bit signal, store_fr");
     run<3>(d, N, S, reps, "bit signal, contiguous (2 bpermutes)");
+    run<5>(d, N, S, reps, "bit signal, 512 B contiguous per half-wavefront");
     hipFree(d);
     return 0;
 }
