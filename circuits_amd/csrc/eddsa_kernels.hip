@@ -148,8 +148,190 @@ __device__ __noinline__ PtA m2e_dev(const EdCtx& c, const PtA& p) {
 // doubler_{i+1} both depend only on D_{i+1} and acc_i, so one step needs 2 divisions per signature:
 // all 2G of them share one inversion.
 // in: p[g] (Edwards). out: p[g] <- segment output (Edwards), dbl[g] <- last doubler output (Montgomery).
-template <int G>
-__device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl) {
+// Scales (HZ_ED_SCALES, default): a field element v is carried as the integer v * R^k mod p, k = 1 the Montgomery form, k = 0 the
+// number itself -- which is what the witness stores. The product routine maps scales (j, k) to j + k - 1, sums need equal scales.
+// Every point of the ladder is a stored signal, and in the all-Montgomery form each store pays a reduction of its own (nine per
+// step and signature, against eight products). Here the points live in scale 0 and only what is squared keeps a scale-1 twin:
+//   inverses: the scale-0 divisors go through the Montgomery batch inversion as they are, which returns 1/v in scale 2;
+//   lamda[1] = num[0] * inv[2], lamda[0] = one reduction; x'[0] = lamda[0] * lamda[1] - A - ..., y'[0] = lamda[1] * (x - x')[0] - y[0]
+//   (scale 0 straight out of the product); the doubler's x1_2[0] = x[0] * x[1] needs x[1]: its x' is computed in scale 1 and reduced.
+// Three reductions per step instead of nine; the selector outputs are copies of scale-0 values. Same field elements, same signals.
+#ifndef HZ_ED_SCALES
+#define HZ_ED_SCALES 1
+#endif
+// scale-0 value in [0, 2p), normalised limbs -> the witness
+__device__ __forceinline__ Fr ed_put0(const UnitIO& w, uint32_t sig, const Fr& x) {
+    const Fr c = fr_cond_sub_p(x);
+    w.put_c(sig, fr_pack_canon(c));
+    return c;
+}
+__device__ __forceinline__ Fr fr_scale_up(const Fr& x) {   // scale k -> k + 1
+    Fr r2;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r2.v[i] = fr_r2(i);
+    return fr_mul(x, r2);
+}
+__device__ __forceinline__ Fr fr_limbs_u64(uint64_t x) {   // small integer in scale 0
+    Fr r = fr_zero();
+    r.v[0] = (uint32_t)x & HZ_M29; r.v[1] = (uint32_t)(x >> 29) & HZ_M29; r.v[2] = (uint32_t)(x >> 58);
+    return r;
+}
+// One inversion per ladder step for the XW wavefronts of a workgroup (HZ_ED_XW): Montgomery's trick across wavefronts. Every lane
+// multiplies its own divisors together as before; the products of lane l of the XW wavefronts meet in LDS, the wavefront whose turn
+// it is (they rotate) combines them, runs the ONE inversion, hands every wavefront the inverse of its own product back through LDS,
+// and each lane peels its divisors off. The others wait at the barrier and leave the issue slots of their SIMDs to whatever else is
+// resident. The inversion is about half of a ladder step's instructions (two signatures per lane); XW = 4 removes three quarters
+// of them for 9 products per step on the wavefront whose turn it is. Two barriers per step; two LDS regions (products in, inverses
+// out) so that a step's writes never meet the previous step's reads.
+template <int XW>
+__device__ __noinline__ Fr fr_inv_shared(const Fr& acc, uint32_t* xlds, int turn) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* A = xlds;
+    uint32_t* B = xlds + XW * 9 * 64;
+#pragma unroll
+    for (int l = 0; l < 9; l++) A[(wave * 9 + l) * 64 + lane] = acc.v[l];
+    __syncthreads();
+    if (wave == (uint32_t)turn % XW) {
+        Fr a[XW], pre[XW];
+#pragma unroll
+        for (int w = 0; w < XW; w++) {
+#pragma unroll
+            for (int l = 0; l < 9; l++) a[w].v[l] = A[(w * 9 + l) * 64 + lane];
+        }
+        pre[0] = a[0];
+#pragma unroll
+        for (int w = 1; w < XW; w++) pre[w] = fr_mul(pre[w - 1], a[w]);   // pre[w] = a[0] ... a[w]
+        Fr t = fr_inv(pre[XW - 1]);
+#pragma unroll
+        for (int w = XW - 1; w >= 0; w--) {
+            const Fr r = w > 0 ? fr_mul(t, pre[w - 1]) : t;
+            if (w > 0) t = fr_mul(t, a[w]);
+#pragma unroll
+            for (int l = 0; l < 9; l++) B[(w * 9 + l) * 64 + lane] = r.v[l];
+        }
+    }
+    __syncthreads();
+    Fr r;
+#pragma unroll
+    for (int l = 0; l < 9; l++) r.v[l] = B[(wave * 9 + l) * 64 + lane];
+    return r;
+}
+// batch_inv (gadgets_dev.h) with the inversion of the lane's product shared among the XW wavefronts of the workgroup
+template <int N, int XW>
+__device__ __forceinline__ void batch_inv_xw(Fr (&x)[N], int n, uint32_t* xlds, int turn) {
+    if constexpr (XW == 1) {
+        batch_inv<N>(x, n);
+    } else {
+        Fr pre[N];
+        Fr acc = fr_one();
+        for (int i = 0; i < n; i++) {
+            pre[i] = acc;
+            if (!fr_is_zero(x[i])) acc = fr_mul(acc, x[i]);
+        }
+        Fr inv = fr_inv_shared<XW>(acc, xlds, turn);
+        for (int i = n - 1; i >= 0; i--) {
+            if (fr_is_zero(x[i])) continue;
+            const Fr xi = x[i];
+            x[i] = fr_mul(inv, pre[i]);
+            inv = fr_mul(inv, xi);
+        }
+    }
+}
+#if HZ_ED_SCALES
+template <int G, int XW>
+__device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl, uint32_t* xlds) {
+    Fr dx0[G], dx1[G], dy0[G];   // doubler output D_{i+1}: x in scales 0 and 1, y in scale 0
+    PtA addIn[G];                // the accumulator, scale 0, canonical
+    Fr nx1_2[G], d_num[G];       // scale 0
+    const int steps = n - 1;
+    const Fr A0 = fr_limbs_u64(168698), one0 = fr_limbs_u64(1);
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const EdCtx c = K.with(io[g]);
+        const PtA m = e2m_dev(c, p[g]);
+        addIn[g].x = fr_canon_limbs(m.x); addIn[g].y = fr_canon_limbs(m.y);
+        c.io.put_c(o.e2m, fr_pack_canon(addIn[g].x)); c.io.put_c(o.e2m + 1, fr_pack_canon(addIn[g].y));
+        const MDbl d = mont_dbl_dev(c, m);   // doubler_0
+        c.io.put_m(o.bits + BIT_DBL_X1_2, d.x1_2); c.io.put_m(o.bits + BIT_DBL_LAMDA, d.lamda);
+        dx1[g] = d.out.x;
+        dx0[g] = fr_canon_limbs(d.out.x); dy0[g] = fr_canon_limbs(d.out.y);
+        c.io.put_c(o.bits + BIT_DBL_OUT0, fr_pack_canon(dx0[g])); c.io.put_c(o.bits + BIT_DBL_OUT1, fr_pack_canon(dy0[g]));
+    }
+    const Fr A2 = fr_dbl(K.A);
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        const bool more = i + 1 < steps;
+        const uint32_t b = o.bits + BIT_N * i;
+        Fr inv[2 * G];
+        uint32_t zmask = 0;
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            // adder_i: in1 = D_{i+1}, in2 = accumulator ; doubler_{i+1}: in = D_{i+1}
+            const Fr a_den = fr_sub(addIn[g].x, dx0[g]);
+            Fr dd = fr_zero();
+            if (more) {
+                nx1_2[g] = fr_mul(dx0[g], dx1[g]);
+                d_num[g] = fr_add(fr_add(fr_add(fr_dbl(nx1_2[g]), nx1_2[g]), fr_mul(A2, dx0[g])), one0);
+                dd = fr_dbl(dy0[g]);
+            }
+            inv[2 * g] = a_den;
+            inv[2 * g + 1] = dd;
+            if (fr_is_zero(a_den)) zmask |= 1u << (2 * g);
+            if (more && fr_is_zero(dd)) zmask |= 1u << (2 * g + 1);
+        }
+        batch_inv_xw<2 * G, XW>(inv, 2 * G, xlds, i);   // scale-0 divisors in, scale-2 inverses out
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const UnitIO& w = io[g];
+            const Fr a_num = fr_sub(addIn[g].y, dy0[g]);
+            const Fr a_l1 = fr_mul(a_num, inv[2 * g]);
+            const Fr a_l0 = fr_canon_limbs(a_l1);
+            if ((zmask >> (2 * g)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), fr_scale_up(a_num));
+            PtA ao;
+            ao.x = fr_sub(fr_sub(fr_sub(fr_mul(a_l0, a_l1), A0), dx0[g]), addIn[g].x);
+            ao.y = fr_sub(fr_mul(a_l1, fr_sub(dx0[g], ao.x)), dy0[g]);
+            w.put_c(b + BIT_ADD_LAMDA, fr_pack_canon(a_l0));
+            ao.x = ed_put0(w, b + BIT_ADD_OUT0, ao.x); ao.y = ed_put0(w, b + BIT_ADD_OUT1, ao.y);
+            const uint32_t sel = c_bit(e[g], e0 + i + 1);
+            const PtA so = sel ? ao : addIn[g];
+            w.put_c(b + BIT_SEL_OUT0, fr_pack_canon(so.x)); w.put_c(b + BIT_SEL_OUT1, fr_pack_canon(so.y));
+            addIn[g] = so;
+            if (more) {
+                const Fr l1 = fr_mul(d_num[g], inv[2 * g + 1]);
+                const Fr l0 = fr_canon_limbs(l1);
+                if ((zmask >> (2 * g + 1)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), fr_scale_up(d_num[g]));
+                const Fr nx1 = fr_sub(fr_sub(fr_sqr(l1), K.A), fr_dbl(dx1[g]));
+                const Fr nx0 = fr_canon_limbs(nx1);
+                const Fr ny0 = fr_sub(fr_mul(l1, fr_sub(dx0[g], nx0)), dy0[g]);
+                const uint32_t bn = b + BIT_N;
+                (void)ed_put0(w, bn + BIT_DBL_X1_2, nx1_2[g]);
+                w.put_c(bn + BIT_DBL_LAMDA, fr_pack_canon(l0)); w.put_c(bn + BIT_DBL_OUT0, fr_pack_canon(nx0));
+                dy0[g] = ed_put0(w, bn + BIT_DBL_OUT1, ny0);
+                dx1[g] = nx1; dx0[g] = nx0;
+            }
+        }
+    }
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const EdCtx c = K.with(io[g]);
+        dbl[g].x = dx1[g];
+        dbl[g].y = fr_scale_up(dy0[g]);
+        PtA acc;
+        acc.x = fr_scale_up(addIn[g].x); acc.y = fr_scale_up(addIn[g].y);
+        const PtA me = m2e_dev(c, acc);
+        c.io.put_m(o.m2e, me.x); c.io.put_m(o.m2e + 1, me.y);
+        PtA negp;
+        negp.x = fr_neg(p[g].x);
+        negp.y = p[g].y;
+        const PtA ea = baby_add_dev(c, o.eadder, me, negp);
+        const PtA r = c_bit(e[g], e0) ? me : ea;
+        c.io.put_m(o.lastSel, r.x); c.io.put_m(o.lastSel + 1, r.y);
+        p[g] = r;
+    }
+}
+#else
+template <int G, int XW>
+__device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl, uint32_t* xlds) {
     PtA dout[G], addIn[G];
     Fr nx1_2[G], d_num[G];
     const int steps = n - 1;
@@ -186,7 +368,7 @@ __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const 
             if (fr_is_zero(a_den)) zmask |= 1u << (2 * g);
             if (more && fr_is_zero(dd)) zmask |= 1u << (2 * g + 1);
         }
-        batch_inv<2 * G>(inv, 2 * G);
+        batch_inv_xw<2 * G, XW>(inv, 2 * G, xlds, i);
 #pragma unroll 1
         for (int g = 0; g < G; g++) {
             const UnitIO& w = io[g];
@@ -229,6 +411,8 @@ __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const 
     }
 }
 
+#endif   // HZ_ED_SCALES
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // SegmentMulAny(n) for ONE signature without an inversion per step (launches the device does not fill: a step of seg_any_lock is
 // 60 us of one wavefront, 42 of them the inversion). The circuit's recurrences are rational maps, so they are walked with
@@ -261,7 +445,7 @@ struct SideBuf {
         return r;
     }
 };
-template <int G> __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl);
+
 
 __device__ __noinline__ void seg_any_proj(const EdK& K, const UnitIO& io, const SegAnyOff& o, const Fc& e, int e0, int n, PtA* p, PtA* dbl, const SideBuf& sd) {
     const EdCtx c = K.with(io);
@@ -302,7 +486,7 @@ __device__ __noinline__ void seg_any_proj(const EdK& K, const UnitIO& io, const 
     // ---- the one inversion: every adder's Z3 and the Z of the last doubler output (Z1 now)
     const Fr total = fr_mul(P, Z1);
     if (fr_is_zero(total)) {
-        seg_any_lock<1>(K, &io, o, &e, e0, n, p, dbl);
+        seg_any_lock<1, 1>(K, &io, o, &e, e0, n, p, dbl, nullptr);
         return;
     }
     const Fr tinv = fr_inv(total);
@@ -464,6 +648,51 @@ __device__ __forceinline__ uint32_t fix_window_bits(const Fc& e, int e0, int nbi
 }
 template <int G>
 __device__ __noinline__ void seg_fix_lock(const EdK& K, const UnitIO* io, const SegFixOff& o, const Fc* e, int e0, int nbits, int win0, int seg, PtA* out) {
+#if HZ_ED_SCALES
+    // the chain in scale 0 (see seg_any_lock): window points from the plain table, one reduction per window (lamda) instead of five
+    PtA acc[G];
+    const Fr A0 = fr_limbs_u64(168698);
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        acc[g].x = ld_const(HZ_BJJ_FIX_DBLLAST0[2 * seg]);
+        acc[g].y = ld_const(HZ_BJJ_FIX_DBLLAST0[2 * seg + 1]);
+    }
+#pragma unroll 1
+    for (int i = 0; i < (int)o.nwin; i++) {
+        const uint32_t wb = o.windows + WIN_N * i;
+        Fr inv[G];
+        uint32_t zmask = 0;
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const uint32_t k = fix_window_bits(e[g], e0, nbits, i);
+            const Fr mx = ld_const(HZ_BJJ_FIX_WIN0[((win0 + i) * 8 + k) * 2]);
+            inv[g] = fr_sub(mx, acc[g].x);
+            if (fr_is_zero(inv[g])) zmask |= 1u << g;
+        }
+        batch_inv<G>(inv, G);   // scale-0 divisors in, scale-2 inverses out
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const UnitIO& w = io[g];
+            const uint32_t k = fix_window_bits(e[g], e0, nbits, i);
+            PtA mo;
+            mo.x = ld_const(HZ_BJJ_FIX_WIN0[((win0 + i) * 8 + k) * 2]);
+            mo.y = ld_const(HZ_BJJ_FIX_WIN0[((win0 + i) * 8 + k) * 2 + 1]);
+            w.put_bit(wb + WIN_S10, (k & 1) & ((k >> 1) & 1));
+            w.put_c(wb + WIN_MUX0, fr_pack_canon(mo.x)); w.put_c(wb + WIN_MUX1, fr_pack_canon(mo.y));
+            const Fr num = fr_sub(mo.y, acc[g].y);
+            const Fr l1 = fr_mul(num, inv[g]);
+            const Fr l0 = fr_canon_limbs(l1);
+            if ((zmask >> g) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), fr_scale_up(num));
+            PtA ao;
+            ao.x = fr_sub(fr_sub(fr_sub(fr_mul(l0, l1), A0), acc[g].x), mo.x);
+            ao.y = fr_sub(fr_mul(l1, fr_sub(acc[g].x, ao.x)), acc[g].y);
+            w.put_c(wb + WIN_ADD_LAMDA, fr_pack_canon(l0));
+            acc[g].x = ed_put0(w, wb + WIN_ADD_OUT0, ao.x); acc[g].y = ed_put0(w, wb + WIN_ADD_OUT1, ao.y);
+        }
+    }
+#pragma unroll 1
+    for (int g = 0; g < G; g++) { acc[g].x = fr_scale_up(acc[g].x); acc[g].y = fr_scale_up(acc[g].y); }
+#else
     PtA acc[G];
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
@@ -502,6 +731,7 @@ __device__ __noinline__ void seg_fix_lock(const EdK& K, const UnitIO* io, const 
             acc[g] = ao;
         }
     }
+#endif
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const EdCtx c = K.with(io[g]);
@@ -750,8 +980,8 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         const SideBuf sd{a.side, 2 * nl, seg * nl + li};
         if (seg == 0) seg_any_proj(K, io[0], o.seg[0], h_c[0], 0, 148, p, dbl, sd);
         else seg_any_proj(K, io[0], o.seg[1], h_c[0], 148, 106, p, dbl, sd);
-    } else if (seg == 0) seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);
-    else seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, p, dbl);
+    } else if (seg == 0) seg_any_lock<G, 1>(K, io, o.seg[0], h_c, 0, 148, p, dbl, nullptr);
+    else seg_any_lock<G, 1>(K, io, o.seg[1], h_c, 148, 106, p, dbl, nullptr);
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const Scratch sc{a.scratch, a.n_units, io[g].unit};
@@ -763,16 +993,20 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
 // The whole signature as ONE chain per lane (both segments back to back, no k_eddsa_pre): 8 % fewer instructions than the split form
 // (no projective doubling chain) and half the wavefronts. Throughput-sized launches use it -- the device is full anyway, and the split
 // form measured 50.3 ms per step against 46.0 -- the split form is for launches the device does not fill (a single batch: latency).
-template <int G>
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain(const EddsaArgs a) {
+template <int G, int XW>
+__global__ __launch_bounds__(HZ_BLOCK * XW) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain(const EddsaArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    __shared__ uint32_t xlds[XW > 1 ? 2 * XW * 9 * 64 : 1];   // fr_inv_shared: products in, inverses out
     uint32_t* lds = lds_raw;
     const Fr* K6 = poseidon_consts_w<6>(lds);
     __syncthreads();
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t nl = (n + G - 1) / G;
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= nl) return;
+    uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= nl) {
+        if (XW == 1) return;
+        li = nl - 1;   // the wavefronts of a workgroup walk the ladder together (barriers): a lane past the end repeats the last one
+    }
     EdK K;
     K.one = fr_one();
     K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
@@ -793,7 +1027,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         sc.set(SC_ED_ZP, sg.zp);
         h_c[g] = sg.h_c; p[g] = sg.p0;
     }
-    seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);   // p <- segment 0 output
+    seg_any_lock<G, XW>(K, io, o.seg[0], h_c, 0, 148, p, dbl, xlds);   // p <- segment 0 output
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const EdCtx c = K.with(io[g]);
@@ -802,7 +1036,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         q[g] = m2e_dev(c, dd.out);
         c.io.put_m(o.m2e0, q[g].x); c.io.put_m(o.m2e0 + 1, q[g].y);
     }
-    seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, q, dbl);  // q <- segment 1 output
+    seg_any_lock<G, XW>(K, io, o.seg[1], h_c, 148, 106, q, dbl, xlds);  // q <- segment 1 output
 #pragma unroll 1
     for (int g = 0; g < G; g++) {   // the sum, the zero-point substitution and R8 + h*8A belong to k_eddsa_final
         const Scratch sc{a.scratch, a.n_units, io[g].unit};
@@ -960,11 +1194,14 @@ static hipError_t launch_eddsa_split(const EddsaArgs& a, uint32_t n, hipStream_t
 #ifndef HZ_ED_MULTI
 #define HZ_ED_MULTI 0
 #endif
+#ifndef HZ_ED_XW
+#define HZ_ED_XW 1   // wavefronts of a workgroup that share the ladder's inversion (fr_inv_shared)
+#endif
 template <int G>
 static hipError_t launch_eddsa_g(const EddsaArgs& a, uint32_t n, hipStream_t s) {
     const uint32_t nl = (n + G - 1) / G;
     if (HZ_ED_MULTI) hipLaunchKernelGGL(k_eddsa_chain2<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
-    else hipLaunchKernelGGL(k_eddsa_chain<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
+    else hipLaunchKernelGGL((k_eddsa_chain<G, HZ_ED_XW>), dim3((nl + HZ_BLOCK * HZ_ED_XW - 1) / (HZ_BLOCK * HZ_ED_XW)), dim3(HZ_BLOCK * HZ_ED_XW), poseidon_lds_bytes<6>(), s, a);
     return hipGetLastError();
 }
 template <int G>
