@@ -425,8 +425,13 @@ def main():
     ctxs[0].set_profiling(False)
 
     def stage(k):   # the inputs of context k's NEXT step: the PCIe copies run beside the kernels of the step just enqueued
-        for b in range(Bp):
-            ctxs[k].stage(b, pin + slot(k, b) * pbytes, pbytes)
+        b = 0
+        while b < Bp:   # runs of batches that are contiguous in the pinned buffer go as one hz_inputs_stage_range (one copy)
+            e = b + 1
+            while e < Bp and slot(k, e) == slot(k, e - 1) + 1:
+                e += 1
+            ctxs[k].stage_range(b, e - b, pin + slot(k, b) * pbytes, pbytes)
+            b = e
 
     phase_ms = float(os.environ.get("HZ_BENCH_OFFSET_MS", "0"))   # experiment: start the contexts this far apart
 

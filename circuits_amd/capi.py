@@ -57,7 +57,7 @@ TEMPLATES = {"rollup-main": 0, "rollup-tx": 1, "decode-tx": 2, "fee-tx": 3, "has
 EXPORTS = [
     "hz_version", "hz_last_error", "hz_device_count", "hz_ctx_create", "hz_ctx_destroy", "hz_witness_len",
     "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_copy_instance_inputs", "hz_inputs_packed_bytes", "hz_input_packed_width",
-    "hz_input_packed_offset", "hz_host_alloc", "hz_host_free", "hz_inputs_upload", "hz_inputs_stage", "hz_clear_inputs", "hz_input_count", "hz_input_name",
+    "hz_input_packed_offset", "hz_host_alloc", "hz_host_free", "hz_inputs_upload", "hz_inputs_stage", "hz_inputs_stage_range", "hz_clear_inputs", "hz_input_count", "hz_input_name",
     "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
@@ -109,6 +109,7 @@ class Lib:
         c.hz_host_free.restype = None
         c.hz_inputs_upload.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_size_t, vp]
         c.hz_inputs_stage.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_size_t, vp]
+        c.hz_inputs_stage_range.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
         c.hz_input_count.argtypes = [vp]
         c.hz_input_name.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(u64)]
         c.hz_input_name.restype = ctypes.c_char_p
@@ -299,6 +300,10 @@ class Ctx:
     def stage(self, instance, packed_addr, nbytes, stream=None):
         """hz_inputs_stage: the H2D copy alone (pinned source); the next enqueue scatters the staged instances"""
         self.L._check(self.L.c.hz_inputs_stage(self.h, instance, packed_addr, nbytes, stream))
+
+    def stage_range(self, first, count, packed_addr, nbytes_each, stride=None, stream=None):
+        """hz_inputs_stage_range: `count` consecutive instances, one copy when the host buffers are contiguous"""
+        self.L._check(self.L.c.hz_inputs_stage_range(self.h, first, count, packed_addr, nbytes_each, nbytes_each if stride is None else stride, stream))
 
     def copy_instance_inputs(self, src, dst, stream=None):
         """Replicate the inputs of instance `src` onto instance `dst` on the device."""

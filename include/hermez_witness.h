@@ -157,6 +157,9 @@ hz_status hz_inputs_upload(hz_ctx* ctx, int32_t instance, const void* packed, si
  * its kernels. Called right after the enqueue of step N with the inputs of step N + 1, the PCIe transfer overlaps step N's
  * kernels, which still read the old inputs. All stage calls between two enqueues of a context must use the same stream. */
 hz_status hz_inputs_stage(hz_ctx* ctx, int32_t instance, const void* packed, size_t bytes, void* stream);
+/* The same for `count` consecutive instances, instance first + j from packed + j * stride. When the host buffers are contiguous
+ * (stride == bytes_each) the whole range crosses PCIe as one copy: what a serving loop calls once per step. */
+hz_status hz_inputs_stage_range(hz_ctx* ctx, int32_t first, int32_t count, const void* packed, size_t bytes_each, size_t stride, void* stream);
 /* enumerate the input signals the template expects */
 int32_t hz_input_count(const hz_ctx* ctx);
 const char* hz_input_name(const hz_ctx* ctx, int32_t i, uint64_t* flat_len);

@@ -528,8 +528,22 @@ def test_bulk_upload_matches_set_input(hz, batch):
     ref.set_inputs(bb2.get_input(), instance=2)
     ref.run()
     assert g.read_raw_bytes() == ref.read_raw_bytes()
+    # hz_inputs_stage_range: instances 0..2 from one contiguous pinned buffer (one copy), then 1..2 from a strided one
+    pin3 = hz.host_alloc(4 * total)
+    for j, pk in enumerate((pk2, packed, pk2)):
+        ctypes.memmove(pin3 + j * total, pk, total)
+    g.stage_range(0, 3, pin3, total)
+    g.run()
+    assert [g.get("main.hashGlobalInputs", j) for j in range(3)] == [bb2.get_hash_inputs(), bb.get_hash_inputs(), bb2.get_hash_inputs()]
+    ctypes.memmove(pin3 + 2 * total, packed, total)
+    g.stage_range(1, 2, pin3, total, stride=2 * total)   # instance 1 <- slot 0 (bb2), instance 2 <- slot 2 (bb)
+    g.run()
+    assert [g.get("main.hashGlobalInputs", j) for j in range(3)] == [bb2.get_hash_inputs(), bb2.get_hash_inputs(), bb.get_hash_inputs()]
+    with pytest.raises(HzError):
+        g.stage_range(n_inst - 1, 2, pin3, total)
     hz.host_free(pin)
     hz.host_free(pin2)
+    hz.host_free(pin3)
 
 
 def test_circom_sym_import_permutes_the_witness(hz, batch, tmp_path):
