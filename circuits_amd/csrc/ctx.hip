@@ -105,7 +105,7 @@ static const char* block_owner(const Layout& lo, int sec, const Block& b) {
     if (has(".sigVerifier.mulFix.") || has(".sigVerifier.snum2bits") || has(".sigVerifier.compConstant")) return "eddsa_fix";
     if (has(".sigVerifier.eqCheck")) return "eddsa_final";
     if (has(".getAx.") || has(".sigVerifier.")) return "eddsa";
-    if (has(".s3.out") || has(".s4.out") || has(".s5.out") || has("L1L2TxsData.amountF")) return "rtx_back";
+    if (has(".s3.out") || has(".s4.out") || has(".s5.out") || n == "main.hasherInputs.L1L2TxsData") return "rtx_back";
     return fee ? "fee_front" : "front";
 }
 static uint64_t owner_bytes(const hz_ctx* c, const char* owner) {
@@ -1187,7 +1187,7 @@ extern "C" hz_status hz_symbol_get(const hz_ctx* cc, uint64_t i, hz_symbol* out)
     const uint32_t u = (uint32_t)(rel / b.count), k = (uint32_t)(rel % b.count);
     std::string nm = ssub(b.name, "{u}", istr(u));
     if (b.kind == BK_POSEIDON) nm += poseidon_signame(b.t, (int)k);
-    else if (b.count > 1 || b.scalar_array) nm += "[" + istr(k) + "]";
+    else if (b.count > 1 || b.scalar_array) nm += "[" + istr(b.idx0 + u * b.ustride + k) + "]";   // slices keep circom's index (Block::idx0)
     c->sym_name = nm;
     out->name = c->sym_name.c_str();
     out->index = c->lo.virt(r.sec, b.off + k, u);

@@ -452,6 +452,10 @@ struct Block {
     uint8_t t = 0;      // Poseidon width for BK_POSEIDON
     int32_t max_units = -1;  // units for which the block is defined (-1 = all); e.g. im* arrays have nTx-1
     bool scalar_array = false;  // name gets "[k]" even if count == 1
+    // A block that holds a SLICE of one of the reference's arrays keeps circom's own index: element k of unit u is
+    // name[idx0 + u * ustride + k] (ustride != 0: the array belongs to a component above the units and the name has no "{u}",
+    // e.g. hasherInputs.L1L2TxsData[i * bitsL1L2TxData + j] of reference src/rollup-main.circom:451-462).
+    uint32_t idx0 = 0, ustride = 0;
 };
 
 struct InputDesc {
@@ -482,6 +486,13 @@ struct Section {
         blocks.push_back(b);
         n_sigs += count;
         return b.off;
+    }
+    // `count` elements that are name[idx0 ...] of the reference (see Block::idx0)
+    uint32_t add_slice(const std::string& name, uint32_t count, uint32_t idx0, uint32_t ustride = 0) {
+        const uint32_t off = add(name, count, -1, true);
+        blocks.back().idx0 = idx0;
+        blocks.back().ustride = ustride;
+        return off;
     }
     PoseidonOff add_poseidon(const std::string& name, int t) {
         Block b;
@@ -601,7 +612,7 @@ struct Layout {
                     } else if (b.count == 1 && !b.scalar_array) {
                         f(base, (int)si, b.off, u);
                     } else {
-                        for (uint32_t k = 0; k < b.count; k++) f(base + "[" + istr(k) + "]", (int)si, b.off + k, u);
+                        for (uint32_t k = 0; k < b.count; k++) f(base + "[" + istr(b.idx0 + u * b.ustride + k) + "]", (int)si, b.off + k, u);
                     }
                 }
             }
@@ -673,6 +684,8 @@ struct Layout {
             if (!suffix.empty()) return false;
             const bool is_array = b.count > 1 || b.scalar_array;
             if (is_array != has_k) continue;
+            if (b.ustride) { unit = k / b.ustride; k %= b.ustride; if ((uint64_t)unit >= units) return false; }
+            k -= b.idx0;
             if (k < 0 || (uint64_t)k >= b.count) return false;
             *out = virt(it->second.first, b.off + (uint32_t)k, (uint32_t)unit);
             return true;
@@ -777,7 +790,10 @@ inline void lay_decode(Section& s, const std::string& pre, int L, bool is_main, 
     o.selToIdx_s = s.add(pre + "selectToIdx.s");
     o.selToIdx_out = s.add(pre + "selectToIdx.out");
     o.n2bFinalToIdx = s.add(pre + "n2bFinalToIdx.out", (uint32_t)L);
-    o.l1l2Fee = s.add(pre + "L1L2TxData.fee", 8);  // L1L2TxData[2L+40 .. 2L+47], bit 7 first
+    // the fee bits of the data-availability output are products, n2bData.out[216 + i] * (1 - onChain) (src/decode-tx.circom:246):
+    // L1L2TxData[2L+40 .. 2L+47]. As `component main` the whole output array is stored as well (below) and owns the name; '#' marks
+    // a name of this layout that is not a circom label.
+    o.l1l2Fee = is_main ? s.add(pre + "L1L2TxData#fee", 8) : s.add_slice(pre + "L1L2TxData", 8, (uint32_t)(2 * L + 40));
     o.n2bToEthAddr = s.add(pre + "n2bToEthAddr.out", 160);
     o.n2bMaxNumBatch = s.add(pre + "n2bMaxNumBatch.out", 32);
     o.hashSig = s.add_poseidon(pre + "hashSig", 7);
@@ -1105,7 +1121,9 @@ inline void build_layout(const Params& p, Layout& lo) {
 #undef HZL_TXIN
             lay_decode(T, "main.decodeTx[{u}].", L, false, lo.dec);
             lay_rtx(T, "main.rollupTx[{u}].", L, F, true, lo.rtx);
-            lo.rtx.main_l1l2amt = T.add("main.hasherInputs.L1L2TxsData.amountF[{u}]", 40);
+            // hasherInputs.L1L2TxsData[i * bits + j] <== decodeTx[i].L1L2TxData[j] * (1 - rollupTx[i].isAmountNullified), j in [2L, 2L + 40)
+            // (src/rollup-main.circom:456-458): the only elements of that array that are products
+            lo.rtx.main_l1l2amt = T.add_slice("main.hasherInputs.L1L2TxsData", 40, (uint32_t)(2 * L), (uint32_t)(2 * L + 48));
             Section& Fs = lo.sections[2]; Fs.tag = "fee"; Fs.upi = (uint32_t)F;
             MainFeeInOff& f = lo.fi;
             f.feeIdxs = in1(Fs, 2, "feeIdxs", 1, F, -1, false);

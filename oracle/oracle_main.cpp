@@ -360,4 +360,13 @@ extern "C" uint64_t orc_symbol_count(void* h) {
     ((OrcCtx*)h)->lo.for_each_symbol([&](const std::string&, int, uint32_t, uint32_t) { n++; });
     return n;
 }
+// every stored signal's name, newline separated (Poseidon blocks as one "<component>.sigma*" line); returns the bytes needed
+extern "C" uint64_t orc_symbol_names(void* h, char* out, uint64_t cap) {
+    uint64_t n = 0;
+    ((OrcCtx*)h)->lo.for_each_symbol([&](const std::string& nm, int, uint32_t, uint32_t) {
+        if (out && n + nm.size() + 1 <= cap) { memcpy(out + n, nm.data(), nm.size()); out[n + nm.size()] = '\n'; }
+        n += nm.size() + 1;
+    }, false);
+    return n;
+}
 extern "C" const char* orc_constraint_name(int id) { return constraint_name(id); }

@@ -126,6 +126,16 @@ class OracleCtx:
     def get(self, name, instance=0):
         return self.read(self.lookup(name), 1, instance)[0]
 
+    def symbol_names(self):
+        """names of all stored signals of one instance (Poseidon blocks as '<component>.sigma*')"""
+        f = self.o.c.orc_symbol_names
+        f.restype = ctypes.c_uint64
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        n = f(self.h, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        f(self.h, buf, n)
+        return buf.raw[:n].decode().split("\n")[:-1]
+
     def unwritten(self):
         nm = ctypes.create_string_buffer(256)
         n = self.o.c.orc_unwritten(self.h, nm, 256)
