@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc; rm -rf $OUT; mkdir -p $OUT
 cd $R
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/valu -o run --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 "$@" > $OUT/bench_valu.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/valu -o run --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 "$@" > $OUT/bench_valu.log 2>&1
 tail -2 $OUT/bench_valu.log | cut -c1-300
 find $OUT -name "*.csv" | head
 python - <<'PY'
