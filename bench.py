@@ -377,7 +377,8 @@ def main():
     want_shard = args.shard_tx or (world > 1 and not args.no_shard)
     seeds = [] if args.shard_tx else [SEED + 1 + 1000 * rank + i for i in range(n_distinct)]
     # the ranks of one node build their batches at the same time: each takes its share of the host cores
-    build_workers = args.build_workers or max(1, min(64, ((os.cpu_count() or 2) - 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
+    n_build = len(seeds) + (1 if want_shard else 0)
+    build_workers = args.build_workers or max(1, min(n_build, 64, ((os.cpu_count() or 2) - 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     batches = build_packed_batches(seeds + ([SEED] if want_shard else []), nTx, lv, m1, F, n_acc, layout, build_workers)
     t_build = time.time() - t_build
     shared = batches.pop() if want_shard else None
