@@ -326,6 +326,7 @@ def main():
     ap.add_argument("--calibrate-copy", action="store_true",
                     help="profiling aid: one 1 GiB device-to-device tensor copy before the timed region, a known byte count that "
                          "calibrates the FETCH_SIZE / WRITE_SIZE counters of a rocprofv3 --pmc pass (tools/profile.sh)")
+    ap.add_argument("--shard-timeout", type=int, default=240, help="N > 1: seconds the tx-sharded secondary line may take before it is given up")
     ap.add_argument("--shard-tx", action="store_true", help="only the tx-sharded line (BASELINE config 4) as the main line")
     args = ap.parse_args()
 
@@ -556,7 +557,23 @@ def main():
                                   "+ unpack kernel + witness kernels + check; upload_* = hz_inputs_upload (copy + unpack) alone on the device"}
     # secondary lines: config 4 sharded (N > 1), config 5 withdraw, Poseidon-BN254/sec, CPU baseline
     if world > 1 and not args.no_shard:
-        sh = bench_sharded(args, L, D, shared[0], shared[1])
+        # The secondary line must never cost the main one: RCCL over xGMI has not run on any box this code was built on. A failure is
+        # recorded in the line; a collective that hangs is cut off by a watchdog that prints the main line and ends the rank.
+        import threading
+
+        def _give_up():
+            if rank == 0:
+                out["shard_tx"] = {"error": "tx-sharded pass did not finish within %d s" % args.shard_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(args.shard_timeout + (0 if rank == 0 else 15), _give_up)
+        wd.daemon = True
+        wd.start()
+        try:
+            sh = bench_sharded(args, L, D, shared[0], shared[1])
+        except Exception as e:   # noqa: BLE001 -- reported, not raised
+            sh = {"error": "%s: %s" % (type(e).__name__, e)}
+        wd.cancel()
         if rank == 0:
             out["shard_tx"] = sh
     if world == 1 and not args.no_withdraw:
