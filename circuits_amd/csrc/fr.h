@@ -416,6 +416,16 @@ HZ_HD Fr fr_cond_sub_p(const Fr& a) {
     for (int i = 0; i < 9; i++) r.v[i] = ge ? (uint32_t)d[i] : a.v[i];
     return r;
 }
+// The same for values that are almost always below p already -- a Montgomery product of reduced operands is < p (1 + p/R), i.e.
+// >= p for one lane in ~256, and a bare reduction yields exactly p or less: when no lane of the wavefront has a top limb that
+// reaches p's, nobody can be >= p and the 36-instruction subtract-and-select is skipped (wave-uniform branch; three of these per
+// Poseidon S-box were 12 % of its instructions).
+HZ_HD Fr fr_cond_sub_p_rare(const Fr& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_NO_RARE_SKIP)
+    if (!__any(a.v[8] >= fr_p29(8))) return a;
+#endif
+    return fr_cond_sub_p(a);
+}
 // Montgomery -> canonical, kept in 29-bit limbs (a usable multiplicand: x * canon(y) / R = xy/R^... see poseidon_sbox)
 HZ_HD Fr fr_canon_limbs(const Fr& a) {
     uint64_t t[18];
@@ -423,7 +433,7 @@ HZ_HD Fr fr_canon_limbs(const Fr& a) {
     for (int i = 0; i < 9; i++) t[i] = a.v[i];
 #pragma unroll
     for (int i = 9; i < 18; i++) t[i] = 0;
-    return fr_cond_sub_p(fr_reduce_cols(t));   // (a + m p)/R <= p
+    return fr_cond_sub_p_rare(fr_reduce_cols(t));   // (a + m p)/R <= p
 }
 // canonical value in 29-bit limbs (< p) -> 8 x u32
 HZ_HD Fc fr_pack_canon(const Fr& r) {

@@ -76,8 +76,8 @@ HZ_HD Fr poseidon_sbox(const Fr& x, int k, Sink& sink) {
     if constexpr (Sink::kCanon) {
         const Fr x2 = fr_sqr(x);
         const Fr in2 = fr_canon_limbs(x2);
-        const Fr in4 = fr_cond_sub_p(fr_mul(x2, in2));
-        const Fr out = fr_cond_sub_p(fr_mul(in4, x));
+        const Fr in4 = fr_cond_sub_p_rare(fr_mul(x2, in2));
+        const Fr out = fr_cond_sub_p_rare(fr_mul(in4, x));
         sink(k, in2, in4, out);
         return out;
     } else {
