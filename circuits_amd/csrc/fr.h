@@ -516,6 +516,44 @@ HZ_HD int32_t fr_divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, int32_t* t)
     t[0] = (int32_t)u; t[1] = (int32_t)v; t[2] = (int32_t)q; t[3] = (int32_t)r;
     return zeta;
 }
+// The same 30 division steps (plain delta = 1 form, eta = -delta), several per iteration: the zeros at the bottom of g are shifted
+// out together (count-trailing-zeros up to the steps that are left), and when g is odd the multiple w of f that cancels its
+// bottom min(eta + 1, steps left, 8) bits is added at once -- no sign flip of eta can happen inside those steps -- with
+// w = -g / f mod 2^8 from two Newton steps on f. About 10 iterations of ~35 instructions instead of 30 x 23; the lanes of a
+// wavefront finish at different iterations and wait for the slowest (SIMT loop). The transition matrix is the product of the same
+// division steps, so d, e, f, g come out as in the one-step-at-a-time form of this delta rule.
+HZ_HD int32_t fr_divsteps_30_var(int32_t eta, uint32_t f0, uint32_t g0, int32_t* t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+    int i = 30;
+    for (;;) {
+        const uint32_t sentinel = g | (0xffffffffu << i);   // i in 1..30
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int zeros = __ffs((int)sentinel) - 1;
+#else
+        const int zeros = __builtin_ctz(sentinel);
+#endif
+        g >>= zeros; u <<= zeros; v <<= zeros;
+        eta -= zeros;
+        i -= zeros;
+        if (i == 0) break;
+        if (eta < 0) {
+            eta = -eta;
+            uint32_t tmp = f; f = g; g = 0u - tmp;
+            tmp = u; u = q; q = 0u - tmp;
+            tmp = v; v = r; r = 0u - tmp;
+        }
+        int limit = eta + 1 > i ? i : eta + 1;
+        if (limit > 8) limit = 8;
+        const uint32_t m = 0xffffffffu >> (32 - limit);
+        uint32_t finv = f;                  // f * f = 1 mod 8: 3 bits
+        finv *= 2u - f * finv;              // 6 bits
+        finv *= 2u - f * finv;              // 12 bits
+        const uint32_t w = (0u - g * finv) & m;
+        g += f * w; q += u * w; r += v * w;
+    }
+    t[0] = (int32_t)u; t[1] = (int32_t)v; t[2] = (int32_t)q; t[3] = (int32_t)r;
+    return eta;
+}
 HZ_HD void fr_update_fg_30(Fr30& f, Fr30& g, const int32_t* t) {
     const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
     int64_t cf = u * f.v[0] + v * g.v[0];
@@ -592,6 +630,9 @@ HZ_HD Fr fr_from_limbs30(const int32_t* rr) {  // rr: 9 non-negative 30-bit limb
     return o;
 }
 // Montgomery-domain inverse: (aR)^-1 * R^3 / R = a^-1 R
+#ifndef HZ_INV_VAR
+#define HZ_INV_VAR 1   // 1: several division steps per iteration (fr_divsteps_30_var); 0: one at a time, half-delta rule
+#endif
 HZ_HD_HEAVY Fr fr_inv(HZ_HEAVY_ARG(Fr) a) {
     Fr30 d, e, f, g;
 #pragma unroll
@@ -599,15 +640,19 @@ HZ_HD_HEAVY Fr fr_inv(HZ_HEAVY_ARG(Fr) a) {
     e.v[0] = 1;
     fr_to_limbs30(a, g);
     int32_t zeta = -1;
+    // batches: the half-delta rule needs at most 600 division steps (20 batches), the plain delta = 1 rule of the several-at-a-time
+    // form at most 735 (25 batches); both leave as soon as every lane of the wavefront has g = 0 (random operands: 17..19 batches)
+    constexpr int kBatches = HZ_INV_VAR ? 25 : 20;
 #pragma unroll 1
-    for (int it = 0; it < 20; ++it) {
+    for (int it = 0; it < kBatches; ++it) {
         int32_t t[4];
-        zeta = fr_divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        if (HZ_INV_VAR) zeta = fr_divsteps_30_var(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        else zeta = fr_divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
         fr_update_de_30(d, e, t);
         fr_update_fg_30(f, g, t);
         // g = 0: f = +-1 and d = +-1/a already (the invariants d*a = f, e*a = g hold after every batch); 600 division steps are
         // the proven bound, random operands need 495..530 of them. Left when every lane of the wavefront is done (18 batches).
-        if (it >= 16) {
+        if (it >= 15) {
             uint32_t nz = 0;
 #pragma unroll
             for (int i = 0; i < 9; i++) nz |= (uint32_t)g.v[i];
