@@ -30,6 +30,7 @@ tools/microbench/instbench > $OUT/instbench.txt 2>&1
 tools/microbench/mulbench > $OUT/mulbench.txt 2>&1
 tools/microbench/invbench > $OUT/invbench.txt 2>&1
 python tools/microbench/run_mfmabench.py > $OUT/mfmabench.txt 2>&1
+( tools/microbench/storebench 1048576 256 5; tools/microbench/storebench 65536 2048 5 ) > $OUT/storebench.txt 2>&1
 ( python tools/experiments/overlap_probe.py 3; python tools/experiments/overlap_probe.py 5 ) > $OUT/overlap_probe.txt 2>/dev/null
 timeout 120 python tools/experiments/power_probe.py 2>/dev/null | python -c "
 import sys,re
