@@ -76,10 +76,12 @@ struct BgZero {
     // The constants come through the scalar cache like Poseidon's own (s_load + v_mov). Staging the block in LDS was measured and is
     // slower (k_smt 22.4 -> 27.2 ms): LDS reads share the lgkmcnt counter with the scalar loads that stream the round constants.
     __device__ __forceinline__ void one() {
+#ifndef HZ_EXPERIMENT_NO_BG_EMIT   // timing experiment only (wrong witness): the chain without its background stores
         Fc c;
 #pragma unroll
         for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[s][q];
         store_fr(base + ((size_t)(off0 + LV_SIZE * j + s) * n_units + unit) * 32, c);
+#endif
         if (++s == 243) { s = 0; j++; }
     }
     __device__ __forceinline__ void emit() {
