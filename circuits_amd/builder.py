@@ -360,9 +360,10 @@ def _device_dag_evaluator(device):
 
 
 class RollupDB:
-    def __init__(self, chain_id=1, device=None, dag_evaluator=None):
+    def __init__(self, chain_id=1, device=None, dag_evaluator=None, first_idx=256):
         """device=N: the Merkle / state hashing of every batch runs on GPU N (DagHasher); default: host hashing, one at a time.
-        Both produce identical trees and circuit inputs."""
+        Both produce identical trees and circuit inputs. first_idx: index of the first account created (the protocol reserves
+        0..255; a tree of nLevels = 8 -- BASELINE config 2 -- only has room below 256, the circuit itself has no such constant)."""
         self.chain_id = chain_id
         self.hasher = host()
         if device is not None or dag_evaluator is not None:
@@ -370,7 +371,7 @@ class RollupDB:
         self.lazy = isinstance(self.hasher, DagHasher)
         self.state = SMT(self.hasher)
         self.leaves = {}  # idx -> state dict
-        self.last_idx = 255
+        self.last_idx = first_idx - 1
         self.num_batch = 0
         self.exit_trees = {}
 
@@ -789,14 +790,14 @@ class ExitTreeFixture:
             self.exit_tree.rekey(hasher.resolve())
 
 
-def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, dag_evaluator=None):
+def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, dag_evaluator=None, first_idx=256):
     """Seeded synthetic batch following reference tools/generate-input.js:61-109 and
     tools/helpers/gen-inputs-utils.js: pre-populated accounts (token 1), then one batch of `max_l1` L1
     createAccountDeposit txs followed by signed L2 transfers of 20 % of the sender balance with
     userFee 176 (plus `exits` L2 exits), one fee token and one fee receiver."""
     import random
     rng = random.Random(seed)
-    db = RollupDB(chain_id=1, device=device, dag_evaluator=dag_evaluator)
+    db = RollupDB(chain_id=1, device=device, dag_evaluator=dag_evaluator, first_idx=first_idx)
     keys = [Account(seed * 1000 + i) for i in range(n_keys)]
     n_accounts = n_accounts if n_accounts is not None else max(2, min(4 * n_tx, 4096))
     owner = {}

@@ -268,3 +268,29 @@ def reference_l1_edge_scripts():
         (tx(**dict(fe, amountF=0)), 0, 0),                                     # no exit leaf
         (tx(**fe), 0, -100)]))
     return (3, 16, 2, 2), S
+
+
+def config2_batch():
+    """BASELINE config 2 at its literal shape: RollupTx(nLevels=8, maxFeeTx=16) -- the parameters of reference
+    test/rollup-tx.test.js:20-23 are (16, 16); BASELINE.json asks for nLevels = 8, whose tree only has room for indices below
+    256, so the accounts start at idx 2 (RollupDB(first_idx=2); 0 = null, 1 = exit). Two batches of 6: batch 1 creates three
+    accounts (createAccountDeposit), batch 2 holds an L1 deposit, a signed L2 transfer, a signed L2 exit, a second exit onto the
+    same exit leaf (update instead of insert), and two NOPs (padding). Returns (db, [bb1, bb2])."""
+    L, F = 8, 16
+    db = B.RollupDB(chain_id=1, first_idx=2)
+    acc = [B.Account(i + 11) for i in range(3)]
+    bb1 = db.build_batch(6, L, 4, F)
+    for a, amt in ((acc[0], 1000), (acc[1], 2000), (acc[2], 300)):
+        bb1.add_tx({"onChain": 1, "fromIdx": 0, "toIdx": 0, "tokenID": 1, "loadAmountF": B.fix2float(amt), "fromBjjCompressed": a.bjj_compressed,
+                    "fromEthAddr": a.eth_addr})
+    bb1.add_token(1)
+    bb1.build()   # idx 2, 3, 4
+    bb2 = db.build_batch(6, L, 4, F)
+    bb2.add_tx({"onChain": 1, "fromIdx": 3, "toIdx": 0, "tokenID": 1, "loadAmountF": B.fix2float(50), "fromEthAddr": acc[1].eth_addr})
+    bb2.add_tx({"fromIdx": 2, "toIdx": 4, "amount": 120, "tokenID": 1, "userFee": 126, "onChain": 0, "signer": acc[0]})
+    bb2.add_tx({"fromIdx": 3, "toIdx": 1, "amount": 70, "tokenID": 1, "userFee": 100, "onChain": 0, "signer": acc[1]})
+    bb2.add_tx({"fromIdx": 3, "toIdx": 1, "amount": 30, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": acc[1]})
+    bb2.add_token(1)
+    bb2.add_fee_idx(2)
+    bb2.build()
+    return db, [bb1, bb2]

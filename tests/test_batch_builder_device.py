@@ -33,6 +33,38 @@ def host_dag_evaluator(vals, job_in, job_out, seg_t, seg_first, seg_count):
     return None
 
 
+def oracle_dag_evaluator(vals, job_in, job_out, seg_t, seg_first, seg_count):
+    """the same walk with the ORACLE's Poseidon (oracle/poseidon_ref.cpp, dense form, 4 x 64-bit field): the recorded DAG
+    evaluated by code that shares nothing with the product's poseidon.h"""
+    from oracle_binding import Oracle
+    orc = Oracle()
+    for t, first, count in zip(seg_t, seg_first, seg_count):
+        rows = []
+        for j in range(int(first), int(first + count)):
+            rows.append([int.from_bytes(vals[32 * int(i):32 * int(i) + 32], "little") for i in job_in[j][:int(t) - 1]])
+        digests, _ = orc.poseidon_batch(int(t), rows)
+        for j, v in zip(range(int(first), int(first + count)), digests):
+            o = int(job_out[j])
+            vals[32 * o:32 * o + 32] = v.to_bytes(32, "little")
+    return None
+
+
+def _oracle_accepts(b, shape):
+    """f1 against the oracle (not against the product's own host Poseidon): the inputs the DAG builder produced drive the
+    ORACLE's RollupMain -- every constraint holds (the SMT processors recompute every root the builder supplied as
+    imStateRoot / imExitRoot / siblings from the oracle's own hashes), and the public hash is hashlib's."""
+    from oracle_binding import OracleCtx
+    o = OracleCtx("rollup-main", *shape)
+    inp = b.get_input()
+    o.set_inputs(inp)
+    assert o.run() is None
+    assert o.get("main.hashGlobalInputs") == b.get_hash_inputs()
+    n = shape[0]
+    assert o.get("main.rollupTx[%d].s4.out" % (n - 2)) == inp["imStateRoot"][n - 2]
+    assert o.get("main.rollupTx[%d].s5.out" % (n - 2)) == inp["imExitRoot"][n - 2]
+    return o
+
+
 def _same_batch(a, b):
     ia, ib = a.get_input(), b.get_input()
     assert ia.keys() == ib.keys()
@@ -91,6 +123,14 @@ def test_dag_builder_matches_eager_builder_on_every_scenario(monkeypatch):
     _check_scenarios(monkeypatch, evaluator=host_dag_evaluator)
 
 
+def test_dag_built_inputs_are_accepted_by_the_oracle():
+    """recorded DAG evaluated by the oracle's Poseidon, inputs fed to the oracle's RollupMain: no product arithmetic anywhere"""
+    shape = (48, 16, 8, 4)
+    lazy = B.synthetic_batch(*shape, exits=3, dag_evaluator=oracle_dag_evaluator)
+    _same_batch(B.synthetic_batch(*shape, exits=3), lazy)
+    _oracle_accepts(lazy, shape)
+
+
 def test_dag_levels_do_not_grow_with_the_number_of_transactions():
     segs = []
     for n in (16, 64):
@@ -129,6 +169,29 @@ def test_hip_poseidon_dag_rejects_bad_tables(hz):
     with pytest.raises(HzError):
         hz.poseidon_dag(vals, np.zeros((1, 6), dtype=np.uint32), np.zeros(1, dtype=np.uint32), np.array([9], dtype=np.uint32), np.array([0], dtype=np.uint64),
                         np.array([1], dtype=np.uint64))
+
+
+@pytest.mark.gpu
+def test_hip_dag_built_config3_inputs_are_accepted_by_the_oracle(hz):
+    """SURVEY 8f-1 parity against the ORACLE: BASELINE config 3 (256, 16, 128, 64) built with the Merkle hashing on the device
+    (hz_poseidon_dag) -> the oracle's RollupMain accepts the inputs (every root, sibling and state hash the device produced is
+    re-derived by the oracle's own Poseidon inside its SMT processors), same hashGlobalInputs; then HIP witness == oracle witness."""
+    shape = (256, 16, 128, 64)
+    b = B.synthetic_batch(*shape, exits=4, device=0)
+    assert b.db.lazy and b.db.hasher.stats["jobs"] > 256 * 2 * 10
+    o = _oracle_accepts(b, shape)
+    g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3])
+    g.set_inputs(b.get_input())
+    g.run()
+    assert g.get("main.hashGlobalInputs") == b.get_hash_inputs()
+    assert g.read_raw_bytes() == o.read_raw_bytes()
+    # and the withdrawal proofs of the exit tree the device hashed verify in the oracle's Withdraw
+    from oracle_binding import OracleCtx
+    idxs = sorted(b.exit_leaves)[:4]
+    w = OracleCtx("withdraw", nLevels=16, n_instances=len(idxs))
+    for k, idx in enumerate(idxs):
+        w.set_inputs(B.withdraw_input(b, idx, 16)[0], instance=k)
+    assert w.run() is None
 
 
 @pytest.mark.gpu

@@ -259,3 +259,20 @@ def test_oracle_fee_tx_and_hash_inputs_as_main_components():
     o.set_inputs(hin)
     assert o.run() is None
     assert o.get("main.hashInputsOut") == exp
+
+
+def test_oracle_rollup_tx_config2_literal_shape():
+    """BASELINE config 2 as written: rollup-tx.circom nLevels = 8 (maxFeeTx = 16 as in reference test/rollup-tx.test.js:20-23),
+    one witness per transaction: L1 createAccountDeposit, L1 deposit, signed L2 transfer, exit (insert, then update), NOP."""
+    import scenarios
+    _, bbs = scenarios.config2_batch()
+    for bb in bbs:
+        o = OracleCtx("rollup-tx", nLevels=8, maxFeeTx=16, n_instances=bb.nTx)
+        for i in range(bb.nTx):
+            o.set_inputs(bb.get_single_tx_input(i)[0], instance=i)
+        assert o.run() is None
+        assert o.unwritten()[0] == 0
+        for i in range(bb.nTx):
+            exp = bb.get_single_tx_input(i)[1]
+            assert o.get("main.newStateRoot", i) == exp["newStateRoot"] and o.get("main.newExitRoot", i) == exp["newExitRoot"]
+            assert o.read(o.lookup("main.accFeeOut[0]"), 16, i) == exp["accFeeOut"]

@@ -87,6 +87,41 @@ def test_rollup_tx_config2_bit_exact(hz, batch):
         assert g.read(g.lookup("main.accFeeOut[0]"), 4, i) == exp["accFeeOut"]
 
 
+def test_rollup_tx_config2_literal_shape_bit_exact(hz):
+    """BASELINE config 2 as written: RollupTx(nLevels = 8, maxFeeTx = 16), account indices below 256 (tests/scenarios.py
+    config2_batch): L1 createAccountDeposit / deposit, signed L2 transfer, exit (insert and update of the exit leaf), NOP --
+    the whole physical witness buffer against the oracle, and the roots / fee accumulators the builder expects."""
+    import scenarios
+    _, bbs = scenarios.config2_batch()
+    for bb in bbs:
+        n = bb.nTx
+        g = hz.ctx("rollup-tx", nLevels=8, maxFeeTx=16, n_instances=n)
+        o = OracleCtx("rollup-tx", nLevels=8, maxFeeTx=16, n_instances=n)
+        for i in range(n):
+            inp = bb.get_single_tx_input(i)[0]
+            g.set_inputs(inp, instance=i)
+            o.set_inputs(inp, instance=i)
+        g.run()
+        assert o.run() is None
+        assert g.witness_len() == o.witness_len()
+        _compare(g, o)
+        for i in range(n):
+            exp = bb.get_single_tx_input(i)[1]
+            assert g.get("main.newStateRoot", i) == exp["newStateRoot"]
+            assert g.get("main.newExitRoot", i) == exp["newExitRoot"]
+            assert g.read(g.lookup("main.accFeeOut[0]"), 16, i) == exp["accFeeOut"]
+    # one transaction alone (n_instances = 1: "one tx" of BASELINE.json), the signed L2 transfer
+    g = hz.ctx("rollup-tx", nLevels=8, maxFeeTx=16)
+    o = OracleCtx("rollup-tx", nLevels=8, maxFeeTx=16)
+    inp, exp = bbs[1].get_single_tx_input(1)
+    g.set_inputs(inp)
+    o.set_inputs(inp)
+    g.run()
+    assert o.run() is None
+    _compare(g, o)
+    assert g.get("main.newStateRoot") == exp["newStateRoot"]
+
+
 def test_withdraw_bit_exact(hz, batch):
     from circuits_amd import builder as B
     idxs = sorted(batch.exit_leaves)
