@@ -158,6 +158,31 @@ def cpu_baseline(n_tx, L, max_l1, F, workers):
                       % (n_tx, L, max_l1, F, workers, dt, os.cpu_count() or 0)}
 
 
+def node_host_line(args, packed_file, expected, Bp, inflight):
+    """The same loop driven from Node.js through the N-API addon (tests/node/bench_facade.js): the host the north star names.
+    Runs after this process has released its contexts (the witness buffers of B x inflight batches fill most of the HBM)."""
+    import shutil
+    import tempfile
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "circuits_amd", "node", "hermez_addon.node")
+    if node is None or not os.path.exists(addon):
+        return {"error": "node or the addon is not available"}
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump([str(e) for e in expected], f)
+        exp_file = f.name
+    try:
+        cmd = [node, os.path.join(ROOT, "tests", "node", "bench_facade.js"), packed_file] + [str(x) for x in (args.nTx, args.nLevels, args.maxL1Tx, args.maxFeeTx,
+               Bp, inflight, args.steps, args.warmup)] + [exp_file]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except (subprocess.TimeoutExpired, ValueError) as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        os.unlink(exp_file)
+
+
 def bench_sharded(args, L, D, packed, expected):
     """BASELINE config 4: ONE batch sharded by transaction index over the ranks (circuits_amd/multigpu.py): one all_gather of the
     160-byte data-availability records, FeeTx + HashInputs on rank 0. Returns the result object (rank 0) or None."""
@@ -322,6 +347,7 @@ def main():
     ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon-BN254/sec secondary metric")
     ap.add_argument("--no-withdraw", action="store_true", help="skip the config-5 (withdraw) secondary line")
     ap.add_argument("--no-e2e", action="store_true", help="skip the upload-inclusive run (value_e2e)")
+    ap.add_argument("--no-node", action="store_true", help="skip value_node (the same loop driven from Node.js through the N-API addon)")
     ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the tx-sharded (config 4, strong scaling) secondary line")
     ap.add_argument("--calibrate-copy", action="store_true",
                     help="profiling aid: one 1 GiB device-to-device tensor copy before the timed region, a known byte count that "
@@ -402,6 +428,12 @@ def main():
         ctypes.memmove(pin + i * pbytes, pk, pbytes)
     expected = [b[1] for b in batches]
     del batches
+    packed_file = None
+    if rank == 0 and world == 1 and not args.no_node and not args.no_e2e:
+        import tempfile
+        fd, packed_file = tempfile.mkstemp(suffix=".packed", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        with os.fdopen(fd, "wb") as f:
+            f.write(ctypes.string_at(pin, pbytes * n_distinct))
     ctxs, streams = [], []
     for k in range(inflight):
         c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=Bp,
@@ -505,6 +537,12 @@ def main():
     del ctxs, c
     L.host_free(pin)
     torch.cuda.empty_cache()
+    node_line = None
+    if packed_file is not None:
+        try:
+            node_line = node_host_line(args, packed_file, expected, Bp, inflight)
+        finally:
+            os.unlink(packed_file)
 
     out = None
     if rank == 0:
@@ -549,6 +587,11 @@ def main():
             "kernels_ms": {k: round(v[0], 3) for k, v in acc.items()},
             "kernels_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in acc.items() if v[0] > 0},
         }
+        if node_line is not None:
+            if "value_node" in node_line:
+                out["value_node"] = round(node_line["value_node"], 1)
+                node_line["ratio_to_value_e2e"] = round(node_line["value_node"] / (total_tx / dt_e2e), 4) if dt_e2e else None
+            out["node_host"] = node_line
         if dt_e2e is not None:
             out["value_e2e"] = round(total_tx / dt_e2e, 1)
             out["e2e"] = {"ms_per_step": round(dt_e2e / args.steps * 1e3, 3), "ratio_to_value": round(dt / dt_e2e, 4), "packed_input_bytes_per_batch": pbytes,

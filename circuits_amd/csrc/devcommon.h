@@ -76,6 +76,15 @@ __device__ __forceinline__ Fc load_fr(const void* p) {
 #endif
 typedef uint32_t hz_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_fr(void* p, const Fc& r) {
+#ifdef HZ_EXPERIMENT_SPLIT_STORES   // timing experiment only (WRONG placement): each store instruction of a wavefront writes 1 KB of full lines
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint8_t* row = reinterpret_cast<uint8_t*>(p) - (size_t)lane * 32;
+        *reinterpret_cast<uint4*>(row + lane * 16) = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+        *reinterpret_cast<uint4*>(row + 1024 + lane * 16) = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+        return;
+    }
+#endif
 #if HZ_NT_STORES
     hz_u32x4* q = reinterpret_cast<hz_u32x4*>(p);
     hz_u32x4 a = {r.v[0], r.v[1], r.v[2], r.v[3]}, b = {r.v[4], r.v[5], r.v[6], r.v[7]};
@@ -111,11 +120,24 @@ struct WitOut {
 };
 
 // Poseidon S-box sink that stores the three product signals of S-box k at sig0 + 3k + {0,1,2}.
+#ifndef HZ_SINK_EARLY
+#define HZ_SINK_EARLY 0
+#endif
 struct WitSboxSink {
     static constexpr bool kCanon = HZ_POSEIDON_CANON_SBOX != 0;   // the S-box hands over canonical values (29-bit limbs, < p)
+    static constexpr bool kEarly = kCanon && HZ_SINK_EARLY != 0;   // one signal at a time, right after its product (poseidon_sbox)
     WitOut w;
     uint32_t sig0;
+    __device__ __forceinline__ void put(int k, int j, const Fr& v) const {
+#ifndef HZ_EXPERIMENT_NO_SINK_STORES
+        w.put_canon(sig0 + 3 * k + j, fr_pack_canon(v));
+#endif
+    }
     __device__ __forceinline__ void operator()(int k, const Fr& x2, const Fr& x4, const Fr& x5) const {
+#ifdef HZ_EXPERIMENT_NO_SINK_STORES   // timing experiment only (wrong witness): the arithmetic without its stores
+        asm volatile("" :: "v"(x2.v[0]), "v"(x4.v[0]), "v"(x5.v[0]));
+        return;
+#endif
         if constexpr (kCanon) {
             w.put_canon(sig0 + 3 * k + 0, fr_pack_canon(x2));
             w.put_canon(sig0 + 3 * k + 1, fr_pack_canon(x4));

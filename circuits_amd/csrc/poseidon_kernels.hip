@@ -43,7 +43,10 @@ static hipError_t launch_poseidon(size_t n, const void* d_in, void* d_out, void*
     const int block = 256;
     size_t blocks = (n + block - 1) / block;
     if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 blocks per CU
-    const size_t lds = poseidon_lds_bytes<T>();
+    size_t lds = poseidon_lds_bytes<T>();
+#ifdef HZ_EXPERIMENT_LDS_PAD   // occupancy experiment: a dynamic LDS reservation limits the workgroups per CU
+    if (const char* e = getenv("HZ_POSEIDON_LDS_PAD")) lds += (size_t)atol(e);
+#endif
     if (d_wit)
         hipLaunchKernelGGL((poseidon_batch_kernel<T, true>), dim3((unsigned)blocks), dim3(block), lds, s,
                            (const uint8_t*)d_in, (uint8_t*)d_out, (uint8_t*)d_wit, n);

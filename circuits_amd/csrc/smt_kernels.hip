@@ -76,16 +76,29 @@ struct BgZero {
     // The constants come through the scalar cache like Poseidon's own (s_load + v_mov). Staging the block in LDS was measured and is
     // slower (k_smt 22.4 -> 27.2 ms): LDS reads share the lgkmcnt counter with the scalar loads that stream the round constants.
     __device__ __forceinline__ void one() {
-#ifndef HZ_EXPERIMENT_NO_BG_EMIT   // timing experiment only (wrong witness): the chain without its background stores
+#ifndef HZ_EXPERIMENT_NO_BG_EMIT   // timing experiments only (wrong witness): the chain without its background stores / loads
         Fc c;
+#ifdef HZ_EXPERIMENT_BG_NOLOAD
+#pragma unroll
+        for (int q = 0; q < 8; q++) c.v[q] = s + q;
+#else
 #pragma unroll
         for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[s][q];
+#endif
+#ifdef HZ_EXPERIMENT_BG_NOSTORE
+#pragma unroll
+        for (int q = 0; q < 8; q++) asm volatile("" :: "s"(c.v[q]));
+#else
         store_fr(base + ((size_t)(off0 + LV_SIZE * j + s) * n_units + unit) * 32, c);
+#endif
 #endif
         if (++s == 243) { s = 0; j++; }
     }
     __device__ __forceinline__ void emit() {
         for (uint32_t q = 0; q < per && j < j_end; q++) one();
+    }
+    __device__ __forceinline__ void emit3() {   // a third of an S-box's share (the sink is called after each of its three products)
+        for (uint32_t q = 0; 3 * q < per + 2 && j < j_end; q++) one();
     }
     __device__ __forceinline__ void flush() {
         while (j < j_end) one();
@@ -93,8 +106,13 @@ struct BgZero {
 };
 struct SmtSboxSink {
     static constexpr bool kCanon = WitSboxSink::kCanon;
+    static constexpr bool kEarly = WitSboxSink::kEarly;
     WitSboxSink w;
     BgZero* bg;
+    __device__ __forceinline__ void put(int k, int j, const Fr& v) const {
+        w.put(k, j, v);
+        if (HZ_SMT_BG_STORES) bg->emit3();
+    }
     __device__ __forceinline__ void operator()(int k, const Fr& x2, const Fr& x4, const Fr& x5) const {
         w(k, x2, x4, x5);
         if (HZ_SMT_BG_STORES) bg->emit();

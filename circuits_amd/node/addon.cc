@@ -38,6 +38,30 @@ struct Api {
     decltype(&hz_symbol_get) symbol_get;
     decltype(&hz_symbol_lookup) symbol_lookup;
     decltype(&hz_constraint_name) constraint_name;
+    // the batched path (what bench.py measures): packed inputs from pinned memory, staged uploads, enqueue / check
+    decltype(&hz_inputs_packed_bytes) inputs_packed_bytes;
+    decltype(&hz_input_packed_width) input_packed_width;
+    decltype(&hz_input_packed_offset) input_packed_offset;
+    decltype(&hz_host_alloc) host_alloc;
+    decltype(&hz_host_free) host_free;
+    decltype(&hz_inputs_upload) inputs_upload;
+    decltype(&hz_inputs_stage) inputs_stage;
+    decltype(&hz_inputs_stage_range) inputs_stage_range;
+    decltype(&hz_witness_enqueue) witness_enqueue;
+    decltype(&hz_witness_check) witness_check;
+    decltype(&hz_witness_total) witness_total;
+    decltype(&hz_witness_read_raw) witness_read_raw;
+    decltype(&hz_witness_dev_ptr) witness_dev_ptr;
+    decltype(&hz_set_inputs_json) set_inputs_json;
+    decltype(&hz_witness_write_json) witness_write_json;
+    decltype(&hz_witness_write_wtns) witness_write_wtns;
+    decltype(&hz_symbols_write_sym) symbols_write_sym;
+    decltype(&hz_symmap_create) symmap_create;
+    decltype(&hz_symmap_destroy) symmap_destroy;
+    decltype(&hz_symmap_nvars) symmap_nvars;
+    decltype(&hz_symmap_unresolved) symmap_unresolved;
+    decltype(&hz_witness_write_wtns_sym) witness_write_wtns_sym;
+    decltype(&hz_poseidon_batch) poseidon_batch;
 } api;
 
 static bool load_api(std::string& err) {
@@ -55,6 +79,10 @@ static bool load_api(std::string& err) {
     SYM(version) SYM(last_error) SYM(device_count) SYM(ctx_create) SYM(ctx_destroy) SYM(witness_len) SYM(constraint_estimate) SYM(set_input)
     SYM(clear_inputs) SYM(input_count) SYM(input_name) SYM(witness_run) SYM(witness_read) SYM(symbol_count) SYM(symbol_get) SYM(symbol_lookup)
     SYM(constraint_name)
+    SYM(inputs_packed_bytes) SYM(input_packed_width) SYM(input_packed_offset) SYM(host_alloc) SYM(host_free) SYM(inputs_upload) SYM(inputs_stage)
+    SYM(inputs_stage_range) SYM(witness_enqueue) SYM(witness_check) SYM(witness_total) SYM(witness_read_raw) SYM(witness_dev_ptr)
+    SYM(set_inputs_json) SYM(witness_write_json) SYM(witness_write_wtns) SYM(symbols_write_sym) SYM(symmap_create) SYM(symmap_destroy)
+    SYM(symmap_nvars) SYM(symmap_unresolved) SYM(witness_write_wtns_sym) SYM(poseidon_batch)
 #undef SYM
     return true;
 }
@@ -71,18 +99,18 @@ static hz_ctx* get_ctx(napi_env env, napi_value v) {
 }
 static void finalize_ctx(napi_env, void* data, void*) { if (data && api.ctx_destroy) api.ctx_destroy((hz_ctx*)data); }
 
-// create(templateId, nTx, nLevels, maxL1Tx, maxFeeTx, nInstances) -> handle
+// create(templateId, nTx, nLevels, maxL1Tx, maxFeeTx, nInstances = 1, flags = 0, device = 0) -> handle
 static napi_value Create(napi_env env, napi_callback_info info) {
     std::string err;
     if (!load_api(err)) { napi_throw_error(env, nullptr, err.c_str()); return nullptr; }
-    size_t argc = 6;
-    napi_value argv[6];
+    size_t argc = 8;
+    napi_value argv[8];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-    int32_t a[6] = {0, 0, 0, 0, 0, 1};
-    for (size_t i = 0; i < argc && i < 6; i++) napi_get_value_int32(env, argv[i], &a[i]);
+    int32_t a[8] = {0, 0, 0, 0, 0, 1, 0, 0};
+    for (size_t i = 0; i < argc && i < 8; i++) napi_get_value_int32(env, argv[i], &a[i]);
     hz_params p;
     memset(&p, 0, sizeof p);
-    p.template_id = a[0]; p.nTx = a[1]; p.nLevels = a[2]; p.maxL1Tx = a[3]; p.maxFeeTx = a[4]; p.n_instances = a[5]; p.device = 0;
+    p.template_id = a[0]; p.nTx = a[1]; p.nLevels = a[2]; p.maxL1Tx = a[3]; p.maxFeeTx = a[4]; p.n_instances = a[5]; p.flags = a[6]; p.device = a[7];
     hz_ctx* c = nullptr;
     if (api.ctx_create(&p, &c) != HZ_OK) return throw_hz(env, "hz_ctx_create");
     napi_value ext;
@@ -288,11 +316,267 @@ static napi_value Version(napi_env env, napi_callback_info) {
     return v;
 }
 
+
+// ---- the batched path ------------------------------------------------------------------------------------------------------------
+// What the measured loop of bench.py does, for a Node host (reference tools/helpers/actions.js:132-146 runs one witness binary per
+// batch; a serving process keeps contexts of many instances resident): packed inputs in pinned memory -> stageRange (async H2D)
+// -> enqueue (kernels, asynchronous) -> check (Promise, waits on the libuv pool) -> the witness stays in HBM (devPtr) or goes to a
+// .wtns file (writeWtns).
+static bool get_args(napi_env env, napi_callback_info info, size_t want, napi_value* argv, size_t* got = nullptr) {
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok) { napi_throw_error(env, nullptr, "bad arguments"); return false; }
+    for (size_t i = argc; i < want; i++) napi_get_undefined(env, &argv[i]);
+    if (got) *got = argc;
+    return true;
+}
+static double num(napi_env env, napi_value v, double dflt = 0) {
+    double d = dflt;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) == napi_ok && t == napi_number) napi_get_value_double(env, v, &d);
+    return d;
+}
+// bytes of an ArrayBuffer / Buffer / TypedArray argument
+static bool get_bytes(napi_env env, napi_value v, uint8_t** data, size_t* len) {
+    bool is = false;
+    void* p = nullptr;
+    if (napi_is_arraybuffer(env, v, &is) == napi_ok && is) { if (napi_get_arraybuffer_info(env, v, &p, len) != napi_ok) return false; *data = (uint8_t*)p; return true; }
+    if (napi_is_buffer(env, v, &is) == napi_ok && is) { if (napi_get_buffer_info(env, v, &p, len) != napi_ok) return false; *data = (uint8_t*)p; return true; }
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type tt; size_t n; napi_value ab; size_t off;
+        if (napi_get_typedarray_info(env, v, &tt, &n, &p, &ab, &off) != napi_ok) return false;
+        static const size_t w[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+        *data = (uint8_t*)p; *len = n * w[tt];
+        return true;
+    }
+    napi_throw_error(env, nullptr, "expected an ArrayBuffer, Buffer or TypedArray");
+    return false;
+}
+// packedLayout(handle) -> { bytes, inputs: [{ name, length, offset, width }] }
+static napi_value PackedLayout(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    napi_value o, arr, v;
+    napi_create_object(env, &o);
+    napi_create_double(env, (double)api.inputs_packed_bytes(c), &v); napi_set_named_property(env, o, "bytes", v);
+    const int32_t n = api.input_count(c);
+    napi_create_array_with_length(env, n, &arr);
+    for (int32_t i = 0; i < n; i++) {
+        uint64_t len = 0;
+        const char* nm = api.input_name(c, i, &len);
+        napi_value e;
+        napi_create_object(env, &e);
+        napi_create_string_utf8(env, nm, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, e, "name", v);
+        napi_create_double(env, (double)len, &v); napi_set_named_property(env, e, "length", v);
+        napi_create_double(env, (double)api.input_packed_offset(c, i), &v); napi_set_named_property(env, e, "offset", v);
+        napi_create_int32(env, api.input_packed_width(c, i), &v); napi_set_named_property(env, e, "width", v);
+        napi_set_element(env, arr, i, e);
+    }
+    napi_set_named_property(env, o, "inputs", arr);
+    return o;
+}
+static void finalize_pinned(napi_env, void* data, void*) { if (data && api.host_free) api.host_free(data); }
+// hostAlloc(bytes) -> ArrayBuffer over pinned host memory (freed with the ArrayBuffer)
+static napi_value HostAlloc(napi_env env, napi_callback_info info) {
+    std::string err;
+    if (!load_api(err)) { napi_throw_error(env, nullptr, err.c_str()); return nullptr; }
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    const size_t bytes = (size_t)num(env, argv[0]);
+    void* p = bytes ? api.host_alloc(bytes) : nullptr;
+    if (!p) return throw_hz(env, "hz_host_alloc");
+    napi_value ab;
+    if (napi_create_external_arraybuffer(env, p, bytes, finalize_pinned, nullptr, &ab) != napi_ok) { api.host_free(p); napi_throw_error(env, nullptr, "external ArrayBuffer"); return nullptr; }
+    return ab;
+}
+// upload(handle, instance, bytes, byteOffset = 0): packed inputs of one instance, copy + scatter on the context's stream
+static napi_value Upload(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    uint8_t* data; size_t len;
+    if (!c || !get_bytes(env, argv[2], &data, &len)) return nullptr;
+    const size_t off = (size_t)num(env, argv[3]), each = (size_t)api.inputs_packed_bytes(c);
+    if (off + each > len) { napi_throw_error(env, nullptr, "upload: buffer too small"); return nullptr; }
+    if (api.inputs_upload(c, (int32_t)num(env, argv[1]), data + off, each, nullptr) != HZ_OK) return throw_hz(env, "hz_inputs_upload");
+    return nullptr;
+}
+// stageRange(handle, first, count, bytes, byteOffset = 0, stride = packed bytes): the next step's inputs, asynchronous H2D
+static napi_value StageRange(napi_env env, napi_callback_info info) {
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    uint8_t* data; size_t len;
+    if (!c || !get_bytes(env, argv[3], &data, &len)) return nullptr;
+    const int32_t first = (int32_t)num(env, argv[1]), count = (int32_t)num(env, argv[2]);
+    const size_t each = (size_t)api.inputs_packed_bytes(c), off = (size_t)num(env, argv[4]), stride = (size_t)num(env, argv[5], (double)each);
+    if (count < 0 || off + (count ? (size_t)(count - 1) * stride + each : 0) > len) { napi_throw_error(env, nullptr, "stageRange: buffer too small"); return nullptr; }
+    if (api.inputs_stage_range(c, first, count, data + off, each, stride, nullptr) != HZ_OK) return throw_hz(env, "hz_inputs_stage_range");
+    return nullptr;
+}
+// enqueue(handle): the kernels of one step on the context's stream; returns at once
+static napi_value Enqueue(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    if (api.witness_enqueue(c, nullptr) != HZ_OK) return throw_hz(env, "hz_witness_enqueue");
+    return nullptr;
+}
+// check(handle) -> Promise<null | failure record> (same shape as run): waits for the step on the libuv pool
+static void check_execute(napi_env, void* data) {
+    RunWork* w = (RunWork*)data;
+    memset(&w->err, 0, sizeof w->err);
+    w->st = api.witness_check(w->ctx, &w->err);
+    if (w->st != HZ_OK) w->msg = api.last_error();
+}
+static napi_value Check(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    RunWork* w = new RunWork();
+    w->ctx = c;
+    napi_value promise, name;
+    NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
+    NAPI_OK(napi_create_string_utf8(env, "hz_witness_check", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(napi_create_async_work(env, nullptr, name, check_execute, run_complete, w, &w->work));
+    NAPI_OK(napi_queue_async_work(env, w->work));
+    return promise;
+}
+// devPtr(handle) -> BigInt device address of the physical witness buffer (for a prover in the same process); witnessTotal -> elements
+static napi_value DevPtr(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    napi_value v;
+    NAPI_OK(napi_create_bigint_uint64(env, (uint64_t)(uintptr_t)api.witness_dev_ptr(c), &v));
+    return v;
+}
+static napi_value WitnessTotal(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    napi_value v;
+    NAPI_OK(napi_create_double(env, (double)api.witness_total(c), &v));
+    return v;
+}
+// readRaw(handle, first, count) -> Buffer: the physical (signal-major) buffer
+static napi_value ReadRaw(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    const uint64_t first = (uint64_t)num(env, argv[1]), count = (uint64_t)num(env, argv[2]);
+    void* data = nullptr;
+    napi_value buf;
+    NAPI_OK(napi_create_buffer(env, (size_t)count * 32, &data, &buf));
+    if (api.witness_read_raw(c, first, count, (uint8_t*)data) != HZ_OK) return throw_hz(env, "hz_witness_read_raw");
+    return buf;
+}
+static bool get_str(napi_env env, napi_value v, std::string& out) {
+    size_t n = 0;
+    if (napi_get_value_string_utf8(env, v, nullptr, 0, &n) != napi_ok) return false;
+    out.resize(n);
+    return napi_get_value_string_utf8(env, v, &out[0], n + 1, &n) == napi_ok;
+}
+// setInputsJson(handle, instance, text): the input.json of the reference's tools (tools/generate-input.js:109)
+static napi_value SetInputsJson(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    std::string text;
+    if (!c || !get_str(env, argv[2], text)) return nullptr;
+    if (api.set_inputs_json(c, (int32_t)num(env, argv[1]), text.c_str(), text.size()) != HZ_OK) return throw_hz(env, "hz_set_inputs_json");
+    return nullptr;
+}
+// writeWtns(handle, instance, path[, symText]) / writeJson(handle, instance, path) / writeSym(handle, path)
+static napi_value WriteWtns(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    size_t got = 0;
+    if (!get_args(env, info, 4, argv, &got)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    std::string path, sym;
+    if (!c || !get_str(env, argv[2], path)) return nullptr;
+    const int32_t inst = (int32_t)num(env, argv[1]);
+    napi_valuetype t = napi_undefined;
+    napi_typeof(env, argv[3], &t);
+    if (got >= 4 && t == napi_string) {
+        if (!get_str(env, argv[3], sym)) return nullptr;
+        hz_symmap* m = nullptr;
+        if (api.symmap_create(c, sym.c_str(), sym.size(), &m) != HZ_OK) return throw_hz(env, "hz_symmap_create");
+        uint64_t var = 0; const char* nm = nullptr;
+        const uint64_t miss = api.symmap_unresolved(m, 0, &var, &nm);
+        if (miss) {
+            std::string e = "circom .sym: " + std::to_string(miss) + " variables are not stored by this layout (first: " + (nm ? nm : "?") + ")";
+            api.symmap_destroy(m);
+            napi_throw_error(env, nullptr, e.c_str());
+            return nullptr;
+        }
+        const hz_status st = api.witness_write_wtns_sym(c, m, inst, path.c_str());
+        api.symmap_destroy(m);
+        if (st != HZ_OK) return throw_hz(env, "hz_witness_write_wtns_sym");
+        return nullptr;
+    }
+    if (api.witness_write_wtns(c, inst, path.c_str()) != HZ_OK) return throw_hz(env, "hz_witness_write_wtns");
+    return nullptr;
+}
+static napi_value WriteJson(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    std::string path;
+    if (!c || !get_str(env, argv[2], path)) return nullptr;
+    if (api.witness_write_json(c, (int32_t)num(env, argv[1]), path.c_str()) != HZ_OK) return throw_hz(env, "hz_witness_write_json");
+    return nullptr;
+}
+static napi_value WriteSym(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    std::string path;
+    if (!c || !get_str(env, argv[1], path)) return nullptr;
+    if (api.symbols_write_sym(c, path.c_str()) != HZ_OK) return throw_hz(env, "hz_symbols_write_sym");
+    return nullptr;
+}
+// poseidonBatch(t, inputs: Buffer of n*(t-1) elements, withWitness = false, device = 0) -> { out: Buffer, witness: Buffer | null }
+static napi_value PoseidonBatch(napi_env env, napi_callback_info info) {
+    std::string err;
+    if (!load_api(err)) { napi_throw_error(env, nullptr, err.c_str()); return nullptr; }
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return nullptr;
+    const int32_t t = (int32_t)num(env, argv[0]);
+    uint8_t* in; size_t len;
+    if (!get_bytes(env, argv[1], &in, &len)) return nullptr;
+    if (t < 2 || t > 7 || len % (32 * (size_t)(t - 1))) { napi_throw_error(env, nullptr, "poseidonBatch: t in 2..7, inputs a multiple of 32*(t-1) bytes"); return nullptr; }
+    bool wit = false;
+    napi_get_value_bool(env, argv[2], &wit);
+    const size_t n = len / (32 * (size_t)(t - 1));
+    static const int rp[] = {56, 57, 56, 60, 60, 63};
+    const size_t nsbox = 8 * (size_t)t + rp[t - 2];
+    void *po = nullptr, *pw = nullptr;
+    napi_value out, w, o;
+    NAPI_OK(napi_create_buffer(env, 32 * n, &po, &out));
+    if (wit) NAPI_OK(napi_create_buffer(env, 96 * nsbox * n, &pw, &w));
+    else napi_get_null(env, &w);
+    if (api.poseidon_batch((int32_t)num(env, argv[3]), t, n, in, (uint8_t*)po, (uint8_t*)pw) != HZ_OK) return throw_hz(env, "hz_poseidon_batch");
+    napi_create_object(env, &o);
+    napi_set_named_property(env, o, "out", out);
+    napi_set_named_property(env, o, "witness", w);
+    return o;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
     const struct { const char* name; napi_callback fn; } fns[] = {
         {"create", Create}, {"setInput", SetInput}, {"clearInputs", ClearInputs}, {"run", Run}, {"witnessLen", WitnessLen},
         {"constraintEstimate", ConstraintEstimate}, {"read", Read}, {"lookup", Lookup}, {"inputNames", InputNames},
-        {"symbolCount", SymbolCount}, {"symbolGet", SymbolGet}, {"deviceCount", DeviceCount}, {"version", Version}};
+        {"symbolCount", SymbolCount}, {"symbolGet", SymbolGet}, {"deviceCount", DeviceCount}, {"version", Version},
+        {"packedLayout", PackedLayout}, {"hostAlloc", HostAlloc}, {"upload", Upload}, {"stageRange", StageRange}, {"enqueue", Enqueue},
+        {"check", Check}, {"devPtr", DevPtr}, {"witnessTotal", WitnessTotal}, {"readRaw", ReadRaw}, {"setInputsJson", SetInputsJson},
+        {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}};
     for (const auto& f : fns) {
         napi_value fn;
         napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn);

@@ -38,6 +38,8 @@ const TEMPLATES = {
     Mux256: [13, []],
     BitsCompressed2AySign: [14, []],
     AySign2Ax: [15, []],
+    SMTProcessor: [16, ["nLevels"]],
+    SMTVerifier: [17, ["nLevels"]],
 };
 
 function parseMain(spec) {
@@ -78,51 +80,136 @@ function unpackFr(buf, i) {
     return x;
 }
 
+function constraintError(fail) {
+    const e = new Error(`Constraint doesn't match ${unpackFr(fail.lhs, 0)} != ${unpackFr(fail.rhs, 0)} (${fail.constraintName}, instance ${fail.instance}, unit ${fail.unit})`);
+    e.constraint = fail;
+    return e;
+}
+// circom_tester's second argument: `true`, or an options object whose sanityCheck defaults to on (every reference call passes a
+// truthy value, test/helpers/helpers.js:142,149); only an explicit false / { sanityCheck: false } turns the constraint asserts off
+function wantsSanityCheck(arg) {
+    if (arg === false) return false;
+    if (arg !== null && typeof arg === "object" && arg.sanityCheck === false) return false;
+    return true;
+}
+
 class Circuit {
+    /** opts.nInstances: independent instances of the main component evaluated by one run (default 1 = the reference's shape);
+     *  opts.flags: 2 = HZ_FLAG_LATENCY (one request at a time); opts.device: HIP device ordinal */
     constructor(main, opts) {
         this.main = main;
         this.opts = opts || {};
         const p = main.params;
-        this.handle = addon.create(main.id, p.nTx, p.nLevels, p.maxL1Tx, p.maxFeeTx, 1);
+        this.nInstances = Math.max(1, this.opts.nInstances | 0);
+        this.handle = addon.create(main.id, p.nTx, p.nLevels, p.maxL1Tx, p.maxFeeTx, this.nInstances, this.opts.flags | 0, this.opts.device | 0);
         this.nVars = addon.witnessLen(this.handle);
         this.inputs = {};
         for (const d of addon.inputNames(this.handle)) this.inputs[d.name] = d.length;
         this._busy = Promise.resolve();
     }
-
-    /** input: { signalName: Number | BigInt | decimal string | nested arrays } -> Array<BigInt>, w[0] === 1n */
-    calculateWitness(input, sanityCheck) {
+    _serial(fn) {
         // one in-flight call per Circuit (the reference's tests await every call serially)
-        const run = this._busy.then(() => this._calculate(input, false));
+        const run = this._busy.then(fn);
         this._busy = run.catch(() => {});
         return run;
+    }
+
+    /** input: { signalName: Number | BigInt | decimal string | nested arrays } -> Array<BigInt>, w[0] === 1n.
+     *  sanityCheck (circom_tester's second argument): constraint asserts on unless explicitly false -- then a violated
+     *  constraint does not reject and the (complete) witness is returned as computed. */
+    calculateWitness(input, sanityCheck) {
+        return this._serial(() => this._calculate(input, false, wantsSanityCheck(sanityCheck)));
     }
     /** same, but returns the witness as a Buffer of 32-byte little-endian elements (snarkjs .wtns body) */
-    calculateWitnessBin(input) {
-        const run = this._busy.then(() => this._calculate(input, true));
-        this._busy = run.catch(() => {});
-        return run;
+    calculateWitnessBin(input, sanityCheck) {
+        return this._serial(() => this._calculate(input, true, wantsSanityCheck(sanityCheck)));
     }
-    async _calculate(input, bin) {
-        addon.clearInputs(this.handle);
+    _setInputs(instance, input) {
         for (const key of Object.keys(input)) {
             if (!(key in this.inputs)) throw new Error(`Signal not found: ${key}`);
             const flat = flatten(input[key], []);
             if (flat.length !== this.inputs[key]) throw new Error(`Signal ${key}: expected ${this.inputs[key]} values, got ${flat.length}`);
-            addon.setInput(this.handle, 0, key, packFr(flat));
+            addon.setInput(this.handle, instance, key, packFr(flat));
         }
+    }
+    async _calculate(input, bin, sanity) {
+        addon.clearInputs(this.handle);
+        this._setInputs(0, input);
         const fail = await addon.run(this.handle);
-        if (fail) {
-            const e = new Error(`Constraint doesn't match ${unpackFr(fail.lhs, 0)} != ${unpackFr(fail.rhs, 0)} (${fail.constraintName}, unit ${fail.unit})`);
-            e.constraint = fail;
-            throw e;
-        }
+        if (fail && sanity) throw constraintError(fail);
         const buf = addon.read(this.handle, 0, 0, this.nVars);
         if (bin) return buf;
         const w = new Array(this.nVars);
         for (let i = 0; i < this.nVars; i++) w[i] = unpackFr(buf, i);
         return w;
     }
+
+    // ---- many instances per run: the path the benchmark measures (bench.py), for a Node host ---------------------------------
+    /** inputs: one input object per instance (nInstances of them). Resolves to a reader { get(instance, name), bin(instance) }:
+     *  a 2048-transaction RollupMain witness is 120 M elements -- it stays on the device (devPtr) unless asked for. */
+    calculateWitnessBatch(inputs, sanityCheck) {
+        return this._serial(async () => {
+            if (!Array.isArray(inputs) || inputs.length !== this.nInstances) throw new Error(`expected ${this.nInstances} input objects`);
+            addon.clearInputs(this.handle);
+            inputs.forEach((inp, k) => this._setInputs(k, inp));
+            const fail = await addon.run(this.handle);
+            if (fail && wantsSanityCheck(sanityCheck)) throw constraintError(fail);
+            return this.reader();
+        });
+    }
+    reader() {
+        return {
+            get: (instance, name) => unpackFr(addon.read(this.handle, instance, this._index(name), 1), 0),
+            bin: (instance) => addon.read(this.handle, instance, 0, this.nVars),
+        };
+    }
+    /** { bytes, inputs: [{ name, length, offset, width }] }: the packed input buffer of ONE instance (include/hermez_witness.h,
+     *  hz_inputs_upload): every input signal at its offset, elements of `width` bytes (32, or 1 for bit-valued signals) */
+    packedLayout() {
+        if (!this._layout) this._layout = addon.packedLayout(this.handle);
+        return this._layout;
+    }
+    /** pinned host memory as an ArrayBuffer: the source of asynchronous uploads */
+    hostAlloc(bytes) { return addon.hostAlloc(bytes); }
+    /** marshal one input object into the packed layout at `byteOffset` of `target` (ArrayBuffer | Buffer | Uint8Array) */
+    packInput(input, target, byteOffset) {
+        const lay = this.packedLayout();
+        const u8 = target instanceof ArrayBuffer ? new Uint8Array(target) : new Uint8Array(target.buffer, target.byteOffset, target.byteLength);
+        const base = byteOffset | 0;
+        if (base + lay.bytes > u8.length) throw new Error("packInput: target too small");
+        const seen = new Set();
+        for (const key of Object.keys(input)) {
+            if (!(key in this.inputs)) throw new Error(`Signal not found: ${key}`);
+            seen.add(key);
+        }
+        for (const d of lay.inputs) {
+            if (!seen.has(d.name)) throw new Error(`Not all inputs have been set (${d.name})`);
+            const flat = flatten(input[d.name], []);
+            if (flat.length !== d.length) throw new Error(`Signal ${d.name}: expected ${d.length} values, got ${flat.length}`);
+            if (d.width === 1) {
+                for (let i = 0; i < flat.length; i++) u8[base + d.offset + i] = Number(toFr(flat[i]) & 1n);
+            } else {
+                const b = packFr(flat);
+                u8.set(b, base + d.offset);
+            }
+        }
+    }
+    upload(instance, buf, byteOffset) { addon.upload(this.handle, instance, buf, byteOffset || 0); }
+    stageRange(first, count, buf, byteOffset, stride) { addon.stageRange(this.handle, first, count, buf, byteOffset || 0, stride || this.packedLayout().bytes); }
+    /** the kernels of one step, asynchronous; check() resolves when they are done and rejects on the first violated constraint */
+    enqueue() { addon.enqueue(this.handle); }
+    async check(sanityCheck) {
+        const fail = await addon.check(this.handle);
+        if (fail && wantsSanityCheck(sanityCheck)) throw constraintError(fail);
+    }
+    devPtr() { return addon.devPtr(this.handle); }
+    witnessTotal() { return addon.witnessTotal(this.handle); }
+    readRaw(first, count) { return addon.readRaw(this.handle, first, count); }
+    setInputsJson(text, instance) { addon.setInputsJson(this.handle, instance | 0, text); }
+    /** snarkjs .wtns of one instance; with `symText` (a circom .sym) in the compiler's variable order */
+    writeWtns(file, instance, symText) { if (symText) addon.writeWtns(this.handle, instance | 0, file, symText); else addon.writeWtns(this.handle, instance | 0, file); }
+    writeJson(file, instance) { addon.writeJson(this.handle, instance | 0, file); }
+    writeSym(file) { addon.writeSym(this.handle, file); }
 
     _index(name) {
         const idx = addon.lookup(this.handle, name);
@@ -158,4 +245,15 @@ async function tester(circomPathOrSpec, opts) {
     return new Circuit(parseMain(circomPathOrSpec), opts);
 }
 
-module.exports = { tester, Circuit, parseMain, deviceCount: addon.deviceCount, version: addon.version, R };
+/** n Poseidon permutations of width t on the device: rows of t-1 inputs -> digests (BigInt[]); with `witness` also the S-box
+ *  signals as a Buffer of [3*(8t+RP)][n] elements (circomlib Poseidon(nInputs), reference src/lib/hash-state.circom:32) */
+function poseidonBatch(t, rows, witness, device) {
+    const flat = flatten(rows, []);
+    const r = addon.poseidonBatch(t, packFr(flat), !!witness, device | 0);
+    const n = r.out.length / 32;
+    const out = new Array(n);
+    for (let i = 0; i < n; i++) out[i] = unpackFr(r.out, i);
+    return witness ? { out, witness: r.witness } : out;
+}
+
+module.exports = { tester, Circuit, parseMain, poseidonBatch, hostAlloc: addon.hostAlloc, deviceCount: addon.deviceCount, version: addon.version, R };

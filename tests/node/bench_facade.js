@@ -1,0 +1,57 @@
+"use strict";
+// The measured loop of bench.py from a Node.js host (VERDICT r2 item 4): RollupMain contexts of B instances, `inflight` of them,
+// every step = stageRange (packed inputs of the step's B batches from pinned memory, asynchronous H2D) + enqueue + check, through
+// the N-API addon. Inputs: a file of `n` packed batches written by bench.py (circuits_amd/batchgen.py built them).
+// usage: node bench_facade.js <packed.bin> <nTx> <nLevels> <maxL1Tx> <maxFeeTx> <B> <inflight> <steps> <warmup> <expected.json>
+const fs = require("fs");
+const path = require("path");
+const { tester } = require(path.join(__dirname, "..", "..", "circuits_amd", "node", "index.js"));
+
+async function main() {
+    const [file, nTx, L, m1, F, B, inflight, steps, warmup] = process.argv.slice(2, 11).map((x, i) => (i === 0 ? x : Number(x)));
+    const expected = process.argv[11] ? JSON.parse(fs.readFileSync(process.argv[11], "utf8")) : null;
+    const ctxs = [];
+    for (let k = 0; k < inflight; k++) ctxs.push(await tester(`component main = RollupMain(${nTx}, ${L}, ${m1}, ${F});`, { nInstances: B }));
+    const each = ctxs[0].packedLayout().bytes;
+    const size = fs.statSync(file).size;
+    const nDistinct = Math.floor(size / each);
+    if (nDistinct < 1) throw new Error("packed file too small");
+    // pinned copy of the packed batches, laid out so that every context's B batches are contiguous (one copy per stageRange)
+    const pin = ctxs[0].hostAlloc(each * B * inflight);
+    const u8 = new Uint8Array(pin);
+    const fd = fs.openSync(file, "r");
+    for (let k = 0; k < inflight; k++) for (let b = 0; b < B; b++) fs.readSync(fd, u8, (k * B + b) * each, each, ((k * B + b) % nDistinct) * each);
+    fs.closeSync(fd);
+    const stage = (k) => ctxs[k].stageRange(0, B, pin, k * B * each, each);
+    // first pass: inputs in, one checked step per context, public outputs against the builder's values
+    for (let k = 0; k < inflight; k++) { stage(k); ctxs[k].enqueue(); await ctxs[k].check(true); }
+    if (expected) {
+        for (let k = 0; k < inflight; k++) {
+            const rd = ctxs[k].reader();
+            for (const b of [0, B - 1]) {
+                const want = expected[(k * B + b) % nDistinct];
+                if (rd.get(b, "main.hashGlobalInputs").toString() !== want) throw new Error(`hashGlobalInputs mismatch (context ${k}, batch ${b})`);
+            }
+        }
+    }
+    const run = async (n) => {
+        const pending = new Array(inflight).fill(null);
+        for (let i = 0; i < n; i++) {
+            const k = i % inflight;
+            if (pending[k]) await pending[k];
+            ctxs[k].enqueue();        // scatters what was staged for this step, then the kernels
+            stage(k);                 // the NEXT step's inputs cross PCIe beside this step's kernels
+            pending[k] = ctxs[k].check(true);
+        }
+        await Promise.all(pending.filter((p) => p));
+    };
+    for (let k = 0; k < inflight; k++) stage(k);
+    await run(Math.max(inflight, warmup));
+    const t0 = process.hrtime.bigint();
+    await run(steps);
+    const dt = Number(process.hrtime.bigint() - t0) / 1e9;
+    for (let k = 0; k < inflight; k++) { ctxs[k].enqueue(); await ctxs[k].check(true); }   // drain the last staged inputs
+    console.log(JSON.stringify({ value_node: nTx * B * steps / dt, ms_per_step: dt / steps * 1e3, steps, batches_per_launch: B, contexts_in_flight: inflight,
+        distinct_batches: Math.min(nDistinct, B * inflight), host: "node " + process.version + " over N-API (circuits_amd/node)", uploads: "inside the timed region (stageRange per step)" }));
+}
+main().catch((e) => { console.error(e); process.exit(1); });

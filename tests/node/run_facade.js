@@ -58,6 +58,73 @@ async function main() {
         const fa = await tester("component main = FeeAccumulator(4);");
         await fa.assertOut(await fa.calculateWitness({ tokenID: 3, fee2Charge: 7, feePlanTokenID: [1, 3, 3, 4], accFeeIn: [10, 20, 30, 40] }, true), { accFeeOut: [10, 27, 30, 40] });
     }
-    console.log("node facade: ok");
+    // every `component main` of the reference's 16 suites through N-API (inputs from the builder / the suites' literals,
+    // expected outputs from the CPU oracle: tests/golden/gen_node_fixture.py)
+    let nCases = 0;
+    for (const m of fx.mains) {
+        const circuit = await tester(m.spec, { reduceConstraints: false });
+        for (const c of m.cases) {
+            if (c.fail !== undefined) {
+                await assert.rejects(circuit.calculateWitness(c.input, true), (e) => e.message.includes("Constraint doesn't match") && e.message.includes(c.fail), `${m.spec} must fail with ${c.fail}`);
+                // circom_tester's sanityCheck = false: no assert, the witness comes back as computed
+                const w = await circuit.calculateWitness(c.input, { sanityCheck: false });
+                assert.strictEqual(w[0], 1n);
+            } else {
+                const w = await circuit.calculateWitness(c.input, { logOutput: false });
+                assert.strictEqual(w[0], 1n);
+                await circuit.assertOut(w, c.out);
+            }
+            nCases++;
+        }
+    }
+    // calculateWitnessBin = the body of a .wtns file; writeWtns writes the same elements
+    {
+        const circuit = await tester("component main = HashState();");
+        const bin = await circuit.calculateWitnessBin(fx.hashState.input, true);
+        assert.strictEqual(bin.length, 32 * circuit.nVars);
+        const os = require("os");
+        const file = path.join(os.tmpdir(), `hz_facade_${process.pid}.wtns`);
+        circuit.writeWtns(file, 0);
+        const f = fs.readFileSync(file);
+        fs.unlinkSync(file);
+        assert.strictEqual(f.slice(0, 4).toString(), "wtns");
+        assert.ok(f.slice(f.length - bin.length).equals(bin), ".wtns data section != calculateWitnessBin");
+        // Poseidon batch through N-API: HashState's digest is Poseidon(4) of its packed inputs
+        const { poseidonBatch } = require(path.join(__dirname, "..", "..", "circuits_amd", "node", "index.js"));
+        const d = poseidonBatch(5, [fx.hashState.poseidonInputs, fx.hashState.poseidonInputs]);
+        assert.strictEqual(d[0].toString(), fx.hashState.out);
+        assert.strictEqual(d[1].toString(), fx.hashState.out);
+        const dw = poseidonBatch(5, [fx.hashState.poseidonInputs], true);
+        assert.strictEqual(dw.witness.length, 96 * (8 * 5 + 60));
+    }
+    // many instances per run: (a) by signal name, (b) the measured path -- packed inputs in pinned memory, staged upload, enqueue, check
+    {
+        const p = fx.rollupMain.params;
+        const many = fx.rollupMainMany;
+        const circuit = await tester(`component main = RollupMain(${p.nTx}, ${p.nLevels}, ${p.maxL1Tx}, ${p.maxFeeTx});`, { nInstances: many.length });
+        const r = await circuit.calculateWitnessBatch(many.map((b) => b.input), true);
+        many.forEach((b, k) => assert.strictEqual(r.get(k, "main.hashGlobalInputs").toString(), b.hashGlobalInputs));
+        const lay = circuit.packedLayout();
+        assert.ok(lay.bytes > 0 && lay.inputs.length === Object.keys(many[0].input).length);
+        const pin = circuit.hostAlloc(lay.bytes * many.length);
+        // reversed order, so that the staged inputs differ from what the context holds
+        many.forEach((b, k) => circuit.packInput(many[many.length - 1 - k].input, pin, k * lay.bytes));
+        circuit.stageRange(0, many.length, pin, 0, lay.bytes);
+        circuit.enqueue();
+        await circuit.check(true);
+        const rd = circuit.reader();
+        many.forEach((b, k) => assert.strictEqual(rd.get(k, "main.hashGlobalInputs").toString(), many[many.length - 1 - k].hashGlobalInputs));
+        assert.ok(circuit.devPtr() > 0n);
+        assert.ok(circuit.witnessTotal() > circuit.nVars);
+        // a tampered batch among the staged ones rejects with the instance in the record
+        const bad = JSON.parse(JSON.stringify(many[1].input));
+        bad.imStateRoot[2] = (BigInt(bad.imStateRoot[2]) + 1n).toString();
+        circuit.packInput(bad, pin, 2 * lay.bytes);
+        circuit.stageRange(2, 1, pin, 2 * lay.bytes, lay.bytes);
+        circuit.enqueue();
+        await assert.rejects(circuit.check(true), (e) => /Constraint doesn't match/.test(e.message) && e.constraint.instance === 2);
+        await assert.rejects(async () => circuit.packInput(Object.assign({ nope: 1 }, many[0].input), pin, 0), /Signal not found/);
+    }
+    console.log(`node facade: ok (${nCases} cases over ${fx.mains.length} mains + batched path)`);
 }
 main().catch((e) => { console.error(e); process.exit(1); });
