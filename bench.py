@@ -57,10 +57,20 @@ class Dist:
         import torch
         self.torch = torch
         torch.cuda.set_device(self.local)
-        if self.world > 1:
+        # HZ_BENCH_FORCE_COLLECTIVE=1 (test hook): a process group even at world size 1, so that the RCCL calls of the sharded
+        # pass (all_gather_into_tensor / broadcast on the pass's stream) run on a box with one GPU
+        self.force = self.world == 1 and os.environ.get("HZ_BENCH_FORCE_COLLECTIVE") == "1"
+        if self.world > 1 or self.force:
             import torch.distributed as dist
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group(self.backend)
+            if self.force:
+                s = socket.socket()
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+                s.close()
+                dist.init_process_group(self.backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+            else:
+                dist.init_process_group(self.backend)
             self.dist = dist
 
     def barrier(self):
@@ -84,7 +94,7 @@ class Dist:
         return self.max_over_ranks(time.perf_counter() - t0)
 
     def close(self):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.destroy_process_group()
 
 
@@ -143,7 +153,7 @@ def cpu_baseline(n_tx, L, max_l1, F, workers):
     """The CPU oracle (restated CPU path, kind "port") on a bounded sample of the same workload: `workers` processes, one batch
     of `n_tx` transactions each, started together (tests/cpu_baseline_worker.py); value = all their transactions / the slowest run."""
     script = os.path.join(ROOT, "tests", "cpu_baseline_worker.py")
-    start = time.time() + 6.0 + 0.012 * n_tx   # every worker has built its batch by then
+    start = time.time() + 10.0 + 0.014 * n_tx + 0.05 * workers   # every worker has built its batch by then
     procs = [subprocess.Popen([sys.executable, script, str(n_tx), str(L), str(max_l1), str(F), repr(start)], stdout=subprocess.PIPE, text=True)
              for _ in range(workers)]
     outs = [p.communicate()[0].split() for p in procs]
@@ -197,7 +207,7 @@ def bench_sharded(args, L, D, packed, expected):
         return torch.zeros(n, dtype=torch.uint8, device="cuda")
 
     def all_gather(recv, send):
-        if D.world == 1:
+        if D.world == 1 and not D.force:
             with torch.cuda.stream(stream):
                 recv.copy_(send)
         elif D.backend == "gloo":   # test hook (CPU collectives): through the host, blocking -- "send complete, recv filled" on return
@@ -211,7 +221,21 @@ def bench_sharded(args, L, D, packed, expected):
             with torch.cuda.stream(stream):   # RCCL enqueues on the current stream: ordered with the export / import kernels
                 D.dist.all_gather_into_tensor(recv, send)
 
-    sb = ShardedBatch(c, L, nTx, D.rank, D.world, alloc, all_gather)
+    def broadcast(buf):
+        if D.world == 1 and not D.force:
+            return
+        if D.backend == "gloo":   # test hook (CPU collectives): through the host, blocking
+            stream.synchronize()
+            h = buf.cpu()
+            D.dist.broadcast(h, src=0)
+            if D.rank != 0:
+                buf.copy_(h)
+            torch.cuda.synchronize()
+        else:
+            with torch.cuda.stream(stream):
+                D.dist.broadcast(buf, src=0)
+
+    sb = ShardedBatch(c, L, nTx, D.rank, D.world, alloc, all_gather, broadcast, force_split=D.force)
     sb.step(stream.cuda_stream)
     if D.rank == 0 and not args.no_verify:
         assert c.get("main.hashGlobalInputs") == expected, "hashGlobalInputs mismatch (sharded)"
@@ -223,7 +247,9 @@ def bench_sharded(args, L, D, packed, expected):
     if D.rank == 0:
         abytes = algorithmic_bytes_per_tx(lv, F) * nTx
         res = {"value": round(nTx * steps / dt, 1), "unit": "tx-witnesses/s", "scaling": "strong", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
-               "parallelism": "tx-shard%d" % D.world, "collective": "one all_gather of %d B per step (%s)" % (sb.slot * D.world, D.backend),
+               "parallelism": "tx-shard%d" % D.world,
+               "collective": "one all_gather of %d B%s per step (%s)" % (sb.slot * D.world, " + one broadcast of %d B (SHA-256 blocks split over the ranks)" % c.sha_state_bytes()
+                                                                          if sb.split_tail else "", D.backend),
                "transactions_per_rank": sb.count,
                "whole_pass_GBs": round(abytes / (dt / steps) / 1e9, 2)}
     del sb, c
@@ -328,8 +354,10 @@ def main():
     ap.add_argument("--maxFeeTx", type=int, default=64)
     ap.add_argument("--accounts", type=int, default=0, help="accounts in the synthetic state before the batch (default 4 * nTx, the reference recipe)")
     ap.add_argument("--inflight", type=int, default=2, help="contexts in flight (each with its own witness buffers and streams): the fee/SHA tail of one step overlaps the next step's kernels")
-    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = min(16, logical CPUs); 64 processes were measured slower in total: 867 vs 956 tx/s)")
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="nTx of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = every logical CPU the host's free memory allows: a RollupMain(2048, 32, ..) oracle holds a 3.9 GB witness)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="nTx of the CPU-baseline sample (0 = skip; default: the headline shape, one batch per process)")
+    ap.add_argument("--no-deep-state", action="store_true", help="skip the deep_state line (the same step on a state of 2^20 accounts)")
+    ap.add_argument("--deep-accounts-log2", type=int, default=20)
     ap.add_argument("--batches-per-launch", type=int, default=32,
                     help="independent batches evaluated by ONE set of kernel launches (context with n_instances = B): more wavefronts per launch")
     ap.add_argument("--distinct-batches", type=int, default=0,
@@ -534,6 +562,62 @@ def main():
     torch.cuda.synchronize()
     upload_ms = e0.elapsed_time(e1) / Bp
     witness_bytes = ctxs[0].witness_len() * 32
+    deep = None
+    if world == 1 and not args.no_deep_state and n_acc < (1 << args.deep_accounts_log2):
+        # The same step on a DEEP state: 2^20 accounts instead of 4 * nTx. The proofs then reach their leaves at level ~21 instead
+        # of ~14: seven more levels of every chain hash data instead of storing the empty-subtree block -- the sparsity of the
+        # reference recipe's state is what the headline rides on. The pre-state is shared (one DenseState
+        # hashed on the device, builder.py), every batch brings its own transactions; 8 different batches fill the resident
+        # instances round-robin.
+        import tempfile
+        from circuits_amd import builder as B
+        t_deep = time.time()
+        kk = args.deep_accounts_log2
+        base = B.DenseState.build(kk, seed=SEED ^ 0xD33F, hash_rows=lambda t, n, data: L.poseidon_batch_bytes(t, n, data, device=local))
+        fd, base_path = tempfile.mkstemp(suffix=".npz", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        os.close(fd)
+        base.save(base_path)
+        t_base = time.time() - t_deep
+        n_deep = min(8, n_res)
+        try:
+            dbatches = build_packed_batches([SEED + 77000 + i for i in range(n_deep)], nTx, lv, m1, F, 0, layout, min(n_deep, build_workers), base_path=base_path)
+        finally:
+            os.unlink(base_path)
+        del base
+        t_deep = time.time() - t_deep
+        dpin = L.host_alloc(pbytes * n_deep)
+        for i, (pk, _, _) in enumerate(dbatches):
+            ctypes.memmove(dpin + i * pbytes, pk, pbytes)
+        dexp = [b[1] for b in dbatches]
+        del dbatches
+        for k in range(inflight):
+            for b in range(Bp):
+                ctxs[k].upload(b, dpin + ((k * Bp + b) % n_deep) * pbytes, pbytes, streams[k].cuda_stream)
+        for k in range(inflight):
+            ctxs[k].enqueue(streams[k].cuda_stream)
+            ctxs[k].check()
+            for b in range(Bp):
+                assert ctxs[k].get("main.hashGlobalInputs", b) == dexp[(k * Bp + b) % n_deep], "hashGlobalInputs mismatch (deep state, context %d, batch %d)" % (k, b)
+        dsteps = max(4, args.steps // 2)
+        run_steps(max(1, args.warmup))
+        ddt = D.timed(lambda: run_steps(dsteps))
+        ctxs[0].set_profiling(True, exclusive=True)
+        dacc = {}
+        for _ in range(2):
+            ctxs[0].enqueue(streams[0].cuda_stream)
+            ctxs[0].check()
+            for name, ms, by, units in ctxs[0].profile():
+                a = dacc.setdefault(name, [0.0, by])
+                a[0] += ms / 2
+        ctxs[0].set_profiling(False)
+        L.host_free(dpin)
+        deep = {"state_accounts": 1 << kk, "value": round(nTx * Bp * dsteps / ddt, 1), "unit": "tx-witnesses/s", "steps": dsteps, "ms_per_step": round(ddt / dsteps * 1e3, 3),
+                "distinct_batches": n_deep, "kernels_ms": {k: round(v[0], 3) for k, v in dacc.items()},
+                "k_smt": {"launch_ms": round(dacc["smt"][0], 3), "achieved_GBs": round(dacc["smt"][1] / (dacc["smt"][0] * 1e-3) / 1e9, 2),
+                          "frac": round(dacc["smt"][1] / (dacc["smt"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                "state_build_s": round(t_base, 1), "batch_build_s": round(t_deep, 1),
+                "note": "same step, same shape; the pre-populated state (builder.DenseState, hashed on the device) is shared by the batches, "
+                        "each of which has its own L1 keys, transactions and signatures"}
     del ctxs, c
     L.host_free(pin)
     torch.cuda.empty_cache()
@@ -592,6 +676,9 @@ def main():
                 out["value_node"] = round(node_line["value_node"], 1)
                 node_line["ratio_to_value_e2e"] = round(node_line["value_node"] / (total_tx / dt_e2e), 4) if dt_e2e else None
             out["node_host"] = node_line
+        if deep is not None:
+            deep["ratio_to_value"] = round(deep["value"] / value, 4)
+            out["deep_state"] = deep
         if dt_e2e is not None:
             out["value_e2e"] = round(total_tx / dt_e2e, 1)
             out["e2e"] = {"ms_per_step": round(dt_e2e / args.steps * 1e3, 3), "ratio_to_value": round(dt / dt_e2e, 4), "packed_input_bytes_per_batch": pbytes,
@@ -620,13 +707,21 @@ def main():
         if rank == 0:
             out["shard_tx"] = sh
     if world == 1 and not args.no_withdraw:
-        out["withdraw"] = bench_withdraw(args, L, D, launches=max(1, (1 << 18) // args.withdraw_per_launch), steps=2)
+        out["withdraw"] = bench_withdraw(args, L, D, launches=max(1, args.withdraw_total // args.withdraw_per_launch), steps=2)
     if rank == 0:
         if world == 1 and not args.no_poseidon:
             out["poseidon_bn254"] = poseidon_rates(L, torch)
         if world == 1 and args.cpu_sample > 0:
-            workers = args.cpu_workers if args.cpu_workers > 0 else max(1, min(16, (os.cpu_count() or 1)))
-            out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, nTx), lv, min(m1, max(1, args.cpu_sample // 8)), F, workers)
+            n_cpu = min(args.cpu_sample, nTx)
+            workers = args.cpu_workers
+            if workers <= 0:   # all logical CPUs, as far as memory goes (oracle witness + the Python builder per process)
+                per_proc = 32 * 60000 * n_cpu * 1.15 + (1 << 30)
+                try:
+                    avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+                except (OSError, IndexError):
+                    avail = 64 << 30
+                workers = max(1, min(os.cpu_count() or 1, int(avail * 0.6 // per_proc)))
+            out["cpu_baseline"] = cpu_baseline(n_cpu, lv, min(m1, max(1, n_cpu // 8)), F, workers)
         print(json.dumps(out))
     D.close()
 

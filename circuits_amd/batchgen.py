@@ -11,21 +11,29 @@ import sys
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_BASE = {}
+
+
 def _one(task):
-    seed, n_tx, n_levels, max_l1, max_fee, n_accounts, layout = task
+    seed, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, base_path = task
     if _ROOT not in sys.path:
         sys.path.insert(0, _ROOT)
     from circuits_amd import builder as B
     from circuits_amd.capi import pack_inputs
-    bb = B.synthetic_batch(n_tx, n_levels, max_l1, max_fee, n_accounts=n_accounts, seed=seed)
+    if base_path:   # a shared pre-populated state (builder.DenseState, built once by the parent): the batch brings its own transactions
+        if base_path not in _BASE:
+            _BASE[base_path] = B.DenseState.load(base_path)
+        bb = B.synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=seed, base=_BASE[base_path])
+    else:
+        bb = B.synthetic_batch(n_tx, n_levels, max_l1, max_fee, n_accounts=n_accounts, seed=seed)
     inp = bb.get_input()
     return pack_inputs(layout, inp), bb.get_hash_inputs(), sum(1 for x in inp["onChain"] if not x)
 
 
-def build_packed_batches(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, workers=0):
+def build_packed_batches(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, workers=0, base_path=None):
     """one batch per seed: [(packed bytes, expected hashGlobalInputs, signed L2 transactions)]"""
     import multiprocessing as mp
-    tasks = [(s, n_tx, n_levels, max_l1, max_fee, n_accounts, layout) for s in seeds]
+    tasks = [(s, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, base_path) for s in seeds]
     n = len(tasks)
     workers = workers or max(1, min(n, (os.cpu_count() or 2) - 2, 64))
     if workers == 1:

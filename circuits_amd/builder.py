@@ -173,12 +173,139 @@ class DagHasher:
         return lambda x: x if x >= 0 else out[-x - 1]
 
 
+class DenseState:
+    """A pre-populated state of N = 2^k accounts (idx first_idx .. first_idx + N - 1) whose tree is held as arrays instead of a
+    dictionary of nodes: with consecutive keys every residue class modulo 2^k holds exactly one key, so the circomlib tree (key bits
+    LSB first, a leaf at the shallowest level where it is alone) is the perfect binary tree of depth k -- node (d, p) covers the
+    keys = p (mod 2^d), its children are (d + 1, p) and (d + 1, p + 2^d), the leaves sit at depth k. Built bottom-up, one batched
+    Poseidon call per level (`hash_rows(t, n, bytes) -> bytes`: the device through hz_poseidon_batch, or the host one hash at a
+    time), 3 N hashes in all; what bench.py's `deep_state` line uses for 2^20 accounts (the proofs then hash ~21 levels instead of
+    ~14). The accounts follow synthetic_batch's recipe (token 1, one of `n_keys` keys, float40 balance below 2^95), drawn with numpy
+    from `seed`. The object is read-only: updates live in the SMT's own node dictionary / RollupDB.leaves on top of it."""
+
+    def __init__(self, k, first_idx, seed, n_keys, key_idx, mant, expo, levels, value):
+        self.k, self.first_idx, self.seed, self.n_keys = k, first_idx, seed, n_keys
+        self.N = 1 << k
+        self.key_idx, self.mant, self.expo, self.levels, self.value = key_idx, mant, expo, levels, value
+        self._keys = None
+
+    @property
+    def root(self):
+        return int.from_bytes(self.levels[0][0].tobytes(), "little")
+
+    def keys(self):
+        if self._keys is None:
+            self._keys = [Account(self.seed * 1000 + i) for i in range(self.n_keys)]
+        return self._keys
+
+    def key_of(self, p):
+        """the key (account index) whose residue modulo 2^k is p"""
+        r = (p - self.first_idx) % self.N
+        return self.first_idx + r
+
+    def has(self, idx):
+        return self.first_idx <= idx < self.first_idx + self.N
+
+    def state(self, idx):
+        j = idx - self.first_idx
+        a = self.keys()[int(self.key_idx[j])]
+        return {"tokenID": 1, "nonce": 0, "sign": a.sign, "balance": int(self.mant[j]) * 10 ** int(self.expo[j]), "ay": a.ay, "ethAddr": a.eth_addr}
+
+    def hash_at(self, depth, prefix):
+        return int.from_bytes(self.levels[depth][prefix].tobytes(), "little")
+
+    def node(self, depth, prefix):
+        """the base tree's node at (depth, prefix) in SMT.nodes form"""
+        if depth == self.k:
+            return ("leaf", self.key_of(prefix), int.from_bytes(self.value[(self.key_of(prefix) - self.first_idx)].tobytes(), "little"))
+        lv = self.levels[depth + 1]
+        return ("mid", int.from_bytes(lv[prefix].tobytes(), "little"), int.from_bytes(lv[prefix + (1 << depth)].tobytes(), "little"))
+
+    @staticmethod
+    def build(k, seed=0x48455A31, first_idx=256, n_keys=8, hash_rows=None):
+        import numpy as np
+        N = 1 << k
+        if hash_rows is None:
+            h = host()
+
+            def hash_rows(t, n, data):   # host fallback: one hash at a time (tests; a million accounts want the device)
+                out = bytearray(32 * n)
+                w = t - 1
+                for i in range(n):
+                    xs = [int.from_bytes(data[32 * (w * i + j):32 * (w * i + j + 1)], "little") for j in range(w)]
+                    out[32 * i:32 * i + 32] = h.poseidon(xs).to_bytes(32, "little")
+                return bytes(out)
+        rng = np.random.default_rng(seed)
+        keys = [Account(seed * 1000 + i) for i in range(n_keys)]
+        key_idx = rng.integers(0, n_keys, size=N, dtype=np.uint8)
+        mant = rng.integers(1, 1 << 35, size=N, dtype=np.uint64)
+        expo = rng.integers(0, 19, size=N, dtype=np.uint8)
+
+        def col(vals):   # [N] python ints -> [N, 32] uint8 little-endian
+            return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32)
+        e0_k = col([1 + (a.sign << 72) for a in keys])
+        ay_k = col([a.ay for a in keys])
+        eth_k = col([a.eth_addr for a in keys])
+        bal = col([int(m) * 10 ** int(e) for m, e in zip(mant.tolist(), expo.tolist())])
+        rows = np.stack([e0_k[key_idx], bal, ay_k[key_idx], eth_k[key_idx]], axis=1)            # [N, 4, 32]
+        value = np.frombuffer(hash_rows(5, N, rows.tobytes()), dtype=np.uint8).reshape(N, 32)   # state hash of account j
+        # leaves at depth k, indexed by residue p: the account j = (p - first_idx) mod N
+        p = np.arange(N, dtype=np.int64)
+        j = (p - first_idx) % N
+        keycol = np.zeros((N, 32), dtype=np.uint8)
+        kk = (first_idx + j).astype(np.uint64)
+        for b in range(8):
+            keycol[:, b] = ((kk >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.uint8)
+        one = np.zeros((N, 32), dtype=np.uint8)
+        one[:, 0] = 1
+        rows = np.stack([keycol, value[j], one], axis=1)
+        levels = [None] * (k + 1)
+        levels[k] = np.frombuffer(hash_rows(4, N, rows.tobytes()), dtype=np.uint8).reshape(N, 32)
+        for d in range(k - 1, -1, -1):
+            n = 1 << d
+            rows = np.stack([levels[d + 1][:n], levels[d + 1][n:2 * n]], axis=1)
+            levels[d] = np.frombuffer(hash_rows(3, n, rows.tobytes()), dtype=np.uint8).reshape(n, 32)
+        return DenseState(k, first_idx, seed, n_keys, key_idx, mant, expo, levels, value)
+
+    def save(self, path):
+        import numpy as np
+        arrs = {"meta": np.array([self.k, self.first_idx, self.seed, self.n_keys], dtype=np.int64), "key_idx": self.key_idx, "mant": self.mant,
+                "expo": self.expo, "value": self.value}
+        for d, lv in enumerate(self.levels):
+            arrs["lv%d" % d] = lv
+        np.savez(path, **arrs)
+
+    @staticmethod
+    def load(path):
+        import numpy as np
+        z = np.load(path)
+        k, first_idx, seed, n_keys = (int(x) for x in z["meta"])
+        return DenseState(k, first_idx, seed, n_keys, z["key_idx"], z["mant"], z["expo"], [z["lv%d" % d] for d in range(k + 1)], z["value"])
+
+
+class _BaseLeaves(dict):
+    """RollupDB.leaves over a DenseState: accounts that have not been written yet come from the base"""
+
+    def __init__(self, base):
+        super().__init__()
+        self.base = base
+
+    def __missing__(self, idx):
+        if not self.base.has(idx):
+            raise KeyError(idx)
+        return self.base.state(idx)
+
+    def __contains__(self, idx):
+        return dict.__contains__(self, idx) or self.base.has(idx)
+
+
 class SMT:
-    def __init__(self, hasher=None):
+    def __init__(self, hasher=None, base=None):
         self.h = hasher or host()
         self.lazy = isinstance(self.h, DagHasher)
         self.fresh = []   # lazy mode: node ids created since the last rekey()
-        self.root = 0
+        self.base = base  # DenseState: the nodes nobody has rewritten yet (found by position, not by hash)
+        self.root = base.root if base is not None else 0
         self.nodes = {}  # hash -> ("leaf", key, value) | ("mid", left, right)
 
     def _put(self, k, node):
@@ -206,7 +333,15 @@ class SMT:
         while True:
             if node == 0:
                 return {"found": False, "siblings": sib, "notFoundKey": key, "notFoundValue": 0, "isOld0": True}
-            n = self.nodes[node]
+            n = self.nodes.get(node)
+            if n is None:   # a node of the pre-populated tree that no update has replaced: known by its position on the path
+                if self.base is None:
+                    raise KeyError(node)
+                # below depth k only a base LEAF can appear (pushed down by the insertion of a key of the same residue class)
+                d = min(lvl, self.base.k)
+                if self.base.hash_at(d, key & ((1 << d) - 1)) != node:
+                    raise KeyError(node)
+                n = self.base.node(d, key & ((1 << d) - 1))
             if n[0] == "leaf":
                 if n[1] == key:
                     return {"found": True, "siblings": sib, "foundValue": n[2], "isOld0": False}
@@ -360,7 +495,7 @@ def _device_dag_evaluator(device):
 
 
 class RollupDB:
-    def __init__(self, chain_id=1, device=None, dag_evaluator=None, first_idx=256):
+    def __init__(self, chain_id=1, device=None, dag_evaluator=None, first_idx=256, base=None):
         """device=N: the Merkle / state hashing of every batch runs on GPU N (DagHasher); default: host hashing, one at a time.
         Both produce identical trees and circuit inputs. first_idx: index of the first account created (the protocol reserves
         0..255; a tree of nLevels = 8 -- BASELINE config 2 -- only has room below 256, the circuit itself has no such constant)."""
@@ -369,9 +504,9 @@ class RollupDB:
         if device is not None or dag_evaluator is not None:
             self.hasher = DagHasher(dag_evaluator or _device_dag_evaluator(device))
         self.lazy = isinstance(self.hasher, DagHasher)
-        self.state = SMT(self.hasher)
-        self.leaves = {}  # idx -> state dict
-        self.last_idx = first_idx - 1
+        self.state = SMT(self.hasher, base)
+        self.leaves = {} if base is None else _BaseLeaves(base)  # idx -> state dict
+        self.last_idx = first_idx - 1 if base is None else base.first_idx + base.N - 1
         self.num_batch = 0
         self.exit_trees = {}
 
@@ -790,13 +925,16 @@ class ExitTreeFixture:
             self.exit_tree.rekey(hasher.resolve())
 
 
-def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, dag_evaluator=None, first_idx=256):
+def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, dag_evaluator=None, first_idx=256,
+                    base=None):
     """Seeded synthetic batch following reference tools/generate-input.js:61-109 and
     tools/helpers/gen-inputs-utils.js: pre-populated accounts (token 1), then one batch of `max_l1` L1
     createAccountDeposit txs followed by signed L2 transfers of 20 % of the sender balance with
     userFee 176 (plus `exits` L2 exits), one fee token and one fee receiver."""
     import random
     rng = random.Random(seed)
+    if base is not None:
+        return _synthetic_batch_on_base(rng, base, n_tx, n_levels, max_l1, max_fee, seed, n_keys, exits, device, dag_evaluator)
     db = RollupDB(chain_id=1, device=device, dag_evaluator=dag_evaluator, first_idx=first_idx)
     keys = [Account(seed * 1000 + i) for i in range(n_keys)]
     n_accounts = n_accounts if n_accounts is not None else max(2, min(4 * n_tx, 4096))
@@ -836,5 +974,39 @@ def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts
             tmp[frm] = (nb + amount, nonce + 1)
     bb.add_token(1)
     bb.add_fee_idx(idxs[rng.randrange(len(idxs))])
+    bb.build()
+    return bb
+
+
+def _synthetic_batch_on_base(rng, base, n_tx, n_levels, max_l1, max_fee, seed, n_keys, exits, device, dag_evaluator):
+    """synthetic_batch's recipe on a shared pre-populated DenseState: the batch's own L1 keys and transactions come from `seed`,
+    senders and receivers are drawn from the base's N accounts (their keys are the base's)."""
+    db = RollupDB(chain_id=1, device=device, dag_evaluator=dag_evaluator, base=base)
+    keys = [Account(seed * 1000 + i) for i in range(n_keys)]
+    bkeys = base.keys()
+    bb = db.build_batch(n_tx, n_levels, max_l1, max_fee)
+    n_l1 = min(max_l1, n_tx)
+    for _ in range(n_l1):
+        a = keys[rng.randrange(n_keys)]
+        bb.add_tx({"fromIdx": 0, "loadAmountF": floor_fix2float(rng.randrange(1 << 96)), "tokenID": 1, "fromBjjCompressed": a.bjj_compressed,
+                   "fromEthAddr": a.eth_addr, "toIdx": 0, "onChain": 1})
+    tmp = {}
+    pick = lambda: base.first_idx + rng.randrange(base.N)   # noqa: E731
+    for t in range(n_tx - n_l1):
+        frm, to = pick(), pick()
+        bal, nonce = tmp.get(frm, (db.leaves[frm]["balance"], db.leaves[frm]["nonce"]))
+        amount = float2fix(floor_fix2float(bal * 20 // 100))
+        is_exit = t < exits
+        bb.add_tx({"fromIdx": frm, "toIdx": EXIT_IDX if is_exit else to, "amount": amount, "tokenID": 1, "userFee": 176, "nonce": nonce, "onChain": 0,
+                   "signer": bkeys[int(base.key_idx[frm - base.first_idx])]})
+        nb = bal - amount - compute_fee(amount, 176)
+        tmp[frm] = (nb, nonce + 1)
+        if not is_exit and to != frm:
+            tb, tn = tmp.get(to, (db.leaves[to]["balance"], db.leaves[to]["nonce"]))
+            tmp[to] = (tb + amount, tn)
+        elif not is_exit and to == frm:
+            tmp[frm] = (nb + amount, nonce + 1)
+    bb.add_token(1)
+    bb.add_fee_idx(pick())
     bb.build()
     return bb

@@ -61,6 +61,7 @@ EXPORTS = [
     "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
+    "hz_witness_enqueue_tail_chain", "hz_sha_blocks", "hz_sha_state_bytes", "hz_sha_export", "hz_sha_expand",
     "hz_symmap_create", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
     "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym", "hz_fr_ops", "hz_poseidon_dag",
@@ -143,6 +144,12 @@ class Lib:
         c.hz_da_export.argtypes = [vp, vp, vp]
         c.hz_da_import.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
         c.hz_witness_enqueue_tail.argtypes = [vp, vp]
+        c.hz_witness_enqueue_tail_chain.argtypes = [vp, vp]
+        for f in ("hz_sha_blocks", "hz_sha_state_bytes"):
+            getattr(c, f).argtypes = [vp]
+            getattr(c, f).restype = u64
+        c.hz_sha_export.argtypes = [vp, vp, vp]
+        c.hz_sha_expand.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
         c.hz_ctx_set_profiling.argtypes = [vp, ctypes.c_int32]
         c.hz_profile_count.argtypes = [vp]
         c.hz_profile_get.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(u64), ctypes.POINTER(u64)]
@@ -166,6 +173,13 @@ class Lib:
         wit = ctypes.create_string_buffer(96 * nsbox * max(n, 1)) if witness else None
         self._check(self.c.hz_poseidon_batch(device, t, n, flat, out, wit))
         return fr_from_bytes(out.raw[:32 * n]), (wit.raw if witness else None)
+
+    def poseidon_batch_bytes(self, t, n, in_bytes, device=0):
+        """n permutations from a bytes-like of n * (t-1) canonical 32-byte elements -> bytes of n digests (no per-element Python)"""
+        out = ctypes.create_string_buffer(32 * max(n, 1))
+        buf = (ctypes.c_char * len(in_bytes)).from_buffer_copy(in_bytes) if not isinstance(in_bytes, bytes) else in_bytes
+        self._check(self.c.hz_poseidon_batch(device, t, n, buf, out, None))
+        return out.raw[:32 * n]
 
     def poseidon_batch_dev(self, t, n, d_in, d_out, d_wit=None, stream=None):
         self._check(self.c.hz_poseidon_batch_dev(t, n, d_in, d_out, d_wit, stream))
@@ -368,6 +382,21 @@ class Ctx:
 
     def enqueue_tail(self, stream=None):
         self.L._check(self.L.c.hz_witness_enqueue_tail(self.h, stream))
+
+    def enqueue_tail_chain(self, stream=None):
+        self.L._check(self.L.c.hz_witness_enqueue_tail_chain(self.h, stream))
+
+    def sha_blocks(self):
+        return self.L.c.hz_sha_blocks(self.h)
+
+    def sha_state_bytes(self):
+        return self.L.c.hz_sha_state_bytes(self.h)
+
+    def sha_export(self, d_buf, stream=None):
+        self.L._check(self.L.c.hz_sha_export(self.h, d_buf, stream))
+
+    def sha_expand(self, first, count, d_buf=None, stream=None):
+        self.L._check(self.L.c.hz_sha_expand(self.h, first, count, d_buf, stream))
 
     def set_profiling(self, on=True, exclusive=False):
         self.L._check(self.L.c.hz_ctx_set_profiling(self.h, (2 if exclusive else 1) if on else 0))

@@ -47,6 +47,7 @@ struct hz_ctx {
     // kernels of the staged instances run at the head of the next enqueue
     std::vector<uint8_t> staged;
     bool any_staged = false;
+    hipStream_t stage_stream = nullptr;     // the stream of the stage calls since the last enqueue (ev_staged is recorded on it)
     hipStream_t s_copy = nullptr;
     hipEvent_t ev_staged = nullptr, ev_unpacked = nullptr;
     // independent chains of one batch run concurrently: the EdDSA ladders and the fee transactions on
@@ -57,11 +58,6 @@ struct hz_ctx {
     hipStream_t s_ed = nullptr, s_fee = nullptr, s_main = nullptr;   // s_main replaces a NULL caller stream
     hipEvent_t ev_reset = nullptr, ev_front = nullptr, ev_ed = nullptr, ev_fee = nullptr, ev_fix = nullptr;
     hipEvent_t ev_sha[9] = {};   // HashInputs: chain group g done (0..7), expansion done (8)
-    // HZ_STAGGER=n (experiment): a RollupMain step does not start before the context enqueued just before it (another one) has
-    // finished the n-th piece of its SMT chain: two contexts in flight then run half a step apart instead of in lock-step
-    hipEvent_t ev_mid = nullptr;
-    int stagger_piece = 0;
-    bool mid_valid = false;
     hipStream_t s_fix = nullptr;   // the fixed-base half of the signature check
     hipStream_t s_sha = nullptr;   // SHA-256 expansion groups behind the chain when HashInputs runs early on the fee stream
     hipEvent_t ev_hash4 = nullptr, ev_tail = nullptr;
@@ -227,10 +223,6 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     }
     for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix, &c->ev_user_in, &c->ev_user_out, &c->ev_inputs})
         if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
-    if (lo.p.tmpl == T_ROLLUP_MAIN && getenv("HZ_STAGGER") && atoi(getenv("HZ_STAGGER")) > 0 && e == hipSuccess) {
-        c->stagger_piece = atoi(getenv("HZ_STAGGER"));
-        e = hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming);
-    }
     if (lo.sec_hi >= 0)
         for (hipEvent_t& ev : c->ev_sha)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
@@ -511,6 +503,9 @@ extern "C" hz_status hz_inputs_stage(hz_ctx* c, int32_t instance, const void* pa
         c->staged.assign(c->lo.n_inst, 0);
     }
     hipStream_t s = stream ? (hipStream_t)stream : c->s_copy;
+    if (c->any_staged && c->stage_stream != s)   // ev_staged is one event: a second stream's copies would not be covered by it
+        return set_err(HZ_ERR_ARG, "hz_inputs_stage: all stage calls between two enqueues of a context must use the same stream");
+    c->stage_stream = s;
     HZ_HIP(hipStreamWaitEvent(s, c->ev_unpacked, 0));   // the slot's previous content has been scattered
     HZ_HIP(hipMemcpyAsync(slot, packed, bytes, hipMemcpyHostToDevice, s));
     HZ_HIP(hipEventRecord(c->ev_staged, s));   // all stage calls between two enqueues use one stream: the last record covers them
@@ -589,32 +584,21 @@ static Hash4Args make_hash4_rtx(uint8_t* base, Fr* sc, uint32_t n_units, const R
     return h;
 }
 
-// the SMT chain kernel, in chunks of levels (bottom level first); every launch is its own profile entry of the same name
+// the SMT chain kernel: one launch, one profile entry
 static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa, const char* name, hipStream_t s) {
-    const int n = (int)sa.n_levels, chunk = smt_chunk_levels(sa);
-    int piece = 0;
-    for (int hi = n - 1; hi >= 0; hi -= chunk) {
-        {
-            ProfScope ps(c, s, name, sa.n_units);
-            const hipError_t e = launch_smt_levels(sa, hi, hi - chunk + 1 > 0 ? hi - chunk + 1 : 0, s);
-            if (e != hipSuccess) return e;
-        }
-        if (c->ev_mid && sa.n_proc == 2 && ++piece == c->stagger_piece) (void)hipEventRecord(c->ev_mid, s);
-    }
-    return hipSuccess;
+    ProfScope ps(c, s, name, sa.n_units);
+    return launch_smt(sa, s);
 }
 
-#ifndef HZ_EARLY_TAIL
-#define HZ_EARLY_TAIL 1
-#endif
 static HashInputsArgs make_hi(hz_ctx* c, bool is_main);
 
 // early_tail (RollupMain, whole batch): HashInputs does not wait for the SMT chains of every transaction. Its SHA-256 message needs
 // the data-availability bits (front kernel), the last fee transaction's root (fee chain, own stream from the start) and ONE value
 // of the chains: the LAST transaction's exit root. That transaction's four chains are evaluated first, as a launch of their own
 // (4 lanes per batch) on the fee stream right after the hash-state kernel, then the message, the sequential chain and the
-// expansion follow there while the main stream hashes the other 2047 transactions (which recomputes the last one's signals to the
-// same values). The 3.6 ms of one-wavefront chain latency and the expansion leave the end of the step.
+// expansion follow there while the main stream hashes the other 2047 transactions of every batch (its chain and back kernels leave
+// the last one out: `skip_mod`, so no signal is written twice and a failing constraint of that transaction is recorded once).
+// The 3.6 ms of one-wavefront chain latency and the expansion leave the end of the step.
 static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, uint32_t sib1, uint32_t sib2, hipStream_t s, bool early_tail = false,
                                   bool early_prep = false) {
     const Layout& lo = c->lo;
@@ -631,14 +615,10 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         // the two halves of the check (S*B8 and R8 + h*8A) are independent: two kernels on two streams, then the equality
         hipStream_t sfix = c->exclusive ? c->s_ed : c->s_fix;
         HZ_HIP(hipStreamWaitEvent(sfix, c->ev_front, 0));
-#ifndef HZ_EXPERIMENT_SKIP_EDDSA   // timing experiments only (tools/variant.sh): what a step costs without one of its kernels
         { ProfScope ps(c, sfix, "eddsa_fix", n_units); HZ_HIP(launch_eddsa_fix(ea, sfix)); }
-#endif
         HZ_HIP(hipEventRecord(c->ev_fix, sfix));
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_front, 0));
-#ifndef HZ_EXPERIMENT_SKIP_EDDSA
         { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed)); }
-#endif
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_fix, 0));
         { ProfScope ps(c, c->s_ed, "eddsa_final", n_units); HZ_HIP(launch_eddsa_final(ea, c->s_ed)); }
         HZ_HIP(hipEventRecord(c->ev_ed, c->s_ed));
@@ -646,10 +626,8 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     {
         Hash4Args h4 = make_hash4_rtx(base, sc, n_units, lo.rtx);
         h4.u0 = u0; h4.ucnt = ucnt;
-#ifndef HZ_EXPERIMENT_SKIP_HASH4
         ProfScope ps(c, s, "hash4", n_units);
         HZ_HIP(launch_hash4(h4, s));
-#endif
     }
     SmtArgs sa;
     memset(&sa, 0, sizeof sa);
@@ -678,12 +656,16 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         SmtArgs sl = sa;
         sl.u0 = (uint32_t)lo.p.nTx - 1; sl.ucnt = lo.n_inst; sl.ustride = (uint32_t)lo.p.nTx;
         sl.p[0].sc_root_old = SC_EROOT_P1OLD; sl.p[0].sc_root_new = SC_EROOT_P1NEW; sl.p[1].sc_root_old = SC_EROOT_P2OLD; sl.p[1].sc_root_new = SC_EROOT_P2NEW;
-        HZ_HIP(launch_smt_levels(sl, (int)sl.n_levels - 1, 0, st));
+        HZ_HIP(launch_smt(sl, st));
         RtxBackArgs bl = ba;
         bl.u0 = sl.u0; bl.ucnt = sl.ucnt; bl.ustride = sl.ustride;
         bl.p[0] = sl.p[0]; bl.p[1] = sl.p[1];
+        bl.skip_h = 1;
         HZ_HIP(launch_rtx_back(bl, st));
         HZ_HIP(launch_da_mask(ba, st));
+        // the main stream leaves these units (and phase H of every unit: k_da_mask has it) to the launches above
+        sa.skip_mod = ba.skip_mod = (uint32_t)lo.p.nTx;
+        ba.skip_h = 1;
         {
             ProfScope ps(c, st, "hash_inputs", (uint64_t)lo.hi.sha.nblocks);
             HZ_HIP(launch_hash_inputs(make_hi(c, true), st, c->exclusive ? nullptr : c->s_sha, c->ev_sha, 9));
@@ -696,12 +678,11 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         hipStream_t st = c->s_fee;
         HZ_HIP(hipStreamWaitEvent(st, c->ev_front, 0));
         HZ_HIP(launch_da_mask(ba, st));
+        ba.skip_h = 1;
         HZ_HIP(launch_hi_prep_body(make_hi(c, true), st));
         HZ_HIP(hipEventRecord(c->ev_tail, st));
     }
-#ifndef HZ_EXPERIMENT_SKIP_SMT
     HZ_HIP(enqueue_smt_chain(c, sa, "smt", s));
-#endif
     { ProfScope ps(c, s, "rtx_back", n_units); HZ_HIP(launch_rtx_back(ba, s)); }
     return HZ_OK;   // the caller joins the signature stream (ev_ed) after whatever else it launches on `s`
 }
@@ -816,12 +797,6 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
     c->prof_used = 0;
     switch (lo.p.tmpl) {
         case T_ROLLUP_MAIN: {
-            static hz_ctx* g_last = nullptr;   // HZ_STAGGER experiment (single-threaded callers only)
-            if (c->ev_mid) {
-                if (g_last && g_last != c && g_last->ev_mid && g_last->mid_valid) HZ_HIP(hipStreamWaitEvent(s, g_last->ev_mid, 0));
-                g_last = c;
-                c->mid_valid = true;
-            }
             MainFrontArgs fa;
             memset(&fa, 0, sizeof fa);
             fa.tx_base = sec_ptr(c, lo.sec_tx); fa.fee_base = sec_ptr(c, lo.sec_fee); fa.glob_base = sec_ptr(c, lo.sec_glob);
@@ -839,7 +814,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             fa.u0 = c->sh_first; fa.ucnt = c->sh_count;
             { ProfScope ps(c, s, "front", (uint64_t)fa.nTx * fa.B); HZ_HIP(launch_main_front(fa, s)); }
             HZ_HIP(hipEventRecord(c->ev_front, s));
-            const bool early = tail_now && !c->partitioned && HZ_EARLY_TAIL;   // CU-partitioned contexts keep the tail on the main stream
+            const bool early = tail_now && !c->partitioned;   // CU-partitioned contexts keep the tail on the main stream
             const bool early_prep = tail_now && c->partitioned;
             st = enqueue_rtx_tail(c, fa.tx_base, lo.sections[lo.sec_tx].n_units, true, lo.mi.siblings1, lo.mi.siblings2, s, early, early_prep);
             if (st != HZ_OK) return st;
@@ -1042,6 +1017,52 @@ extern "C" hz_status hz_witness_enqueue_tail(hz_ctx* c, void* stream) {
     hz_status st = enqueue_fee(c, sec_ptr(c, lo.sec_fee), lo.sections[lo.sec_fee].n_units, true, s);
     if (st != HZ_OK) return st;
     { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s, c->s_fee, c->ev_sha, 9)); }
+    c->last_stream = s;
+    c->enqueued = true;
+    return HZ_OK;
+}
+
+extern "C" hz_status hz_witness_enqueue_tail_chain(hz_ctx* c, void* stream) {
+    if (!c || c->lo.p.tmpl != T_ROLLUP_MAIN) return set_err(HZ_ERR_ARG, "hz_witness_enqueue_tail_chain: RollupMain contexts only");
+    HZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    const Layout& lo = c->lo;
+    hz_status st = enqueue_fee(c, sec_ptr(c, lo.sec_fee), lo.sections[lo.sec_fee].n_units, true, s);
+    if (st != HZ_OK) return st;
+    { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hi_chain_only(make_hi(c, true), s)); }
+    c->last_stream = s;
+    c->enqueued = true;
+    return HZ_OK;
+}
+extern "C" uint64_t hz_sha_blocks(const hz_ctx* c) { return (c && c->lo.sec_hi >= 0) ? (uint64_t)c->lo.hi.sha.nblocks : 0; }
+extern "C" uint64_t hz_sha_state_bytes(const hz_ctx* c) {
+    return (c && c->lo.sec_hi >= 0) ? ((uint64_t)c->lo.hi.sha.nblocks * 64 + ((uint64_t)c->lo.hi.sha.nblocks + 1) * 32) * c->lo.n_inst : 0;
+}
+extern "C" hz_status hz_sha_export(hz_ctx* c, void* d_buf, void* stream) {
+    if (!c || !d_buf || c->lo.sec_hi < 0) return set_err(HZ_ERR_ARG, "hz_sha_export: needs a context with a HashInputs section and a buffer");
+    HZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    const size_t mb = (size_t)c->lo.hi.sha.nblocks * 64 * c->lo.n_inst, cb = ((size_t)c->lo.hi.sha.nblocks + 1) * 32 * c->lo.n_inst;
+    HZ_HIP(hipMemcpyAsync(d_buf, c->msg.p, mb, hipMemcpyDeviceToDevice, s));
+    HZ_HIP(hipMemcpyAsync((uint8_t*)d_buf + mb, c->chain.p, cb, hipMemcpyDeviceToDevice, s));
+    return HZ_OK;
+}
+extern "C" hz_status hz_sha_expand(hz_ctx* c, int32_t first, int32_t count, const void* d_buf, void* stream) {
+    if (!c || c->lo.sec_hi < 0) return set_err(HZ_ERR_ARG, "hz_sha_expand: needs a context with a HashInputs section");
+    const int64_t nb = c->lo.hi.sha.nblocks;
+    if (first < 0 || count < 0 || (int64_t)first + count > nb) return set_err(HZ_ERR_ARG, "hz_sha_expand: blocks %d..%d out of range (%lld blocks)", first, first + count - 1, (long long)nb);
+    HZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
+    if (d_buf) {
+        const size_t mb = (size_t)nb * 64 * c->lo.n_inst, cb = ((size_t)nb + 1) * 32 * c->lo.n_inst;
+        HZ_HIP(hipMemcpyAsync(c->msg.p, d_buf, mb, hipMemcpyDeviceToDevice, s));
+        HZ_HIP(hipMemcpyAsync(c->chain.p, (const uint8_t*)d_buf + mb, cb, hipMemcpyDeviceToDevice, s));
+    }
+    if (!c->enqueued) {   // a rank with an empty transaction shard has not reset its failure record this step
+        HZ_HIP(hipMemsetAsync(c->err.p, 0xFF, 16, s));
+        HZ_HIP(hipMemsetAsync((uint8_t*)c->err.p + 16, 0, 8, s));
+    }
+    HZ_HIP(launch_sha_expand_range(make_hi(c, true), (uint32_t)first, (uint32_t)count, s));
     c->last_stream = s;
     c->enqueued = true;
     return HZ_OK;

@@ -21,43 +21,20 @@ HZ_PC(2) HZ_PC(3) HZ_PC(4) HZ_PC(5) HZ_PC(6) HZ_PC(7)
 #undef HZ_PC
 // the block for sinks that store the S-box witness (canonical S-box outputs, poseidon.h)
 template <int T> __device__ __forceinline__ const Fr* poseidon_k_global_w();
-#if HZ_POSEIDON_CANON_SBOX
 #define HZ_PC(T) \
     template <> __device__ __forceinline__ const Fr* poseidon_k_global_w<T>() { return reinterpret_cast<const Fr*>(&HZ_POSEIDON_KW_T##T[0][0]); }
-#else
-#define HZ_PC(T) \
-    template <> __device__ __forceinline__ const Fr* poseidon_k_global_w<T>() { return reinterpret_cast<const Fr*>(&HZ_POSEIDON_K_T##T[0][0]); }
-#endif
 HZ_PC(2) HZ_PC(3) HZ_PC(4) HZ_PC(5) HZ_PC(6) HZ_PC(7)
 #undef HZ_PC
 
-// Where the kernels read the Poseidon constants from. Every lane of a wavefront needs the same
-// constant at the same time, so the block is either read straight from device memory through the
-// scalar cache (s_load into SGPRs, which v_mad_u64_u32 takes as an operand: no VGPRs, no LDS), or
-// staged once per workgroup into LDS and read as broadcasts (HZ_POSEIDON_LDS = 1).
-#ifndef HZ_POSEIDON_LDS
-#define HZ_POSEIDON_LDS 0
-#endif
-template <int T> constexpr size_t poseidon_lds_bytes() { return HZ_POSEIDON_LDS ? (size_t)poseidon_const_frs<T>() * sizeof(Fr) : 0; }
-
-// Returns the width-T constant block; in LDS mode the whole block cooperates in copying it to
-// `lds` (advanced past the block) and the caller must __syncthreads() before the first use.
+// Where the kernels read the Poseidon constants from: every lane of a wavefront needs the same constant at the same time, so the
+// block is read straight from device memory through the scalar cache (s_load into SGPRs, which v_mad_u64_u32 takes as an
+// operand: no VGPRs, no LDS). Staging the block in LDS (north star) was measured in rounds 1-2 and was slower: LDS reads share the
+// lgkmcnt counter with the scalar loads, and the reservation held k_hash4 to three workgroups per CU.
 template <int T, bool W = false>
-__device__ __forceinline__ const Fr* poseidon_consts(uint32_t*& lds) {
-#if HZ_POSEIDON_LDS
-    constexpr int NW = poseidon_const_frs<T>() * 9;  // 32-bit words (an Fr is 9 limbs)
-    const uint32_t* g = reinterpret_cast<const uint32_t*>(W ? poseidon_k_global_w<T>() : poseidon_k_global<T>());
-    uint32_t* d = lds;
-    for (int i = threadIdx.x; i < NW; i += blockDim.x) d[i] = g[i];
-    lds += NW;
-    return reinterpret_cast<const Fr*>(d);
-#else
-    return W ? poseidon_k_global_w<T>() : poseidon_k_global<T>();
-#endif
-}
+__device__ __forceinline__ const Fr* poseidon_consts() { return W ? poseidon_k_global_w<T>() : poseidon_k_global<T>(); }
 // the block for a sink that stores the S-box witness (every witness kernel)
 template <int T>
-__device__ __forceinline__ const Fr* poseidon_consts_w(uint32_t*& lds) { return poseidon_consts<T, true>(lds); }
+__device__ __forceinline__ const Fr* poseidon_consts_w() { return poseidon_consts<T, true>(); }
 
 // ---- 32-byte element I/O (canonical form) ------------------------------------------------------
 __device__ __forceinline__ Fc load_fr(const void* p) {
@@ -68,33 +45,13 @@ __device__ __forceinline__ Fc load_fr(const void* p) {
     r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
     return r;
 }
-// witness elements are written once and (with few exceptions) never read again by the device. Marking the stores non-temporal
-// (HZ_NT_STORES=1) was measured and is much SLOWER (k_smt 24 -> 37 ms, withdraw 1.90 -> 0.78 M/s): a lane writes 32 bytes, the
-// wavefront's 2 KB per signal are combined in L2, which streaming stores bypass.
-#ifndef HZ_NT_STORES
-#define HZ_NT_STORES 0
-#endif
-typedef uint32_t hz_u32x4 __attribute__((ext_vector_type(4)));
+// witness elements are written once and (with few exceptions) never read again by the device. Non-temporal stores were measured and
+// are much SLOWER (k_smt 24 -> 37 ms, withdraw 1.90 -> 0.78 M/s; tools/microbench/mixbench.hip: 1.9 TB/s whatever the mix): a lane
+// writes 32 bytes, the wavefront's 2 KB per signal are combined in L2, which streaming stores bypass.
 __device__ __forceinline__ void store_fr(void* p, const Fc& r) {
-#ifdef HZ_EXPERIMENT_SPLIT_STORES   // timing experiment only (WRONG placement): each store instruction of a wavefront writes 1 KB of full lines
-    {
-        const uint32_t lane = threadIdx.x & 63u;
-        uint8_t* row = reinterpret_cast<uint8_t*>(p) - (size_t)lane * 32;
-        *reinterpret_cast<uint4*>(row + lane * 16) = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-        *reinterpret_cast<uint4*>(row + 1024 + lane * 16) = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-        return;
-    }
-#endif
-#if HZ_NT_STORES
-    hz_u32x4* q = reinterpret_cast<hz_u32x4*>(p);
-    hz_u32x4 a = {r.v[0], r.v[1], r.v[2], r.v[3]}, b = {r.v[4], r.v[5], r.v[6], r.v[7]};
-    __builtin_nontemporal_store(a, q);
-    __builtin_nontemporal_store(b, q + 1);
-#else
     uint4* q = reinterpret_cast<uint4*>(p);
     q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
     q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-#endif
 }
 
 // ---- witness writer ---------------------------------------------------------------------------
@@ -120,33 +77,14 @@ struct WitOut {
 };
 
 // Poseidon S-box sink that stores the three product signals of S-box k at sig0 + 3k + {0,1,2}.
-#ifndef HZ_SINK_EARLY
-#define HZ_SINK_EARLY 0
-#endif
 struct WitSboxSink {
-    static constexpr bool kCanon = HZ_POSEIDON_CANON_SBOX != 0;   // the S-box hands over canonical values (29-bit limbs, < p)
-    static constexpr bool kEarly = kCanon && HZ_SINK_EARLY != 0;   // one signal at a time, right after its product (poseidon_sbox)
+    static constexpr bool kCanon = true;   // the S-box hands over canonical values (29-bit limbs, < p)
     WitOut w;
     uint32_t sig0;
-    __device__ __forceinline__ void put(int k, int j, const Fr& v) const {
-#ifndef HZ_EXPERIMENT_NO_SINK_STORES
-        w.put_canon(sig0 + 3 * k + j, fr_pack_canon(v));
-#endif
-    }
     __device__ __forceinline__ void operator()(int k, const Fr& x2, const Fr& x4, const Fr& x5) const {
-#ifdef HZ_EXPERIMENT_NO_SINK_STORES   // timing experiment only (wrong witness): the arithmetic without its stores
-        asm volatile("" :: "v"(x2.v[0]), "v"(x4.v[0]), "v"(x5.v[0]));
-        return;
-#endif
-        if constexpr (kCanon) {
-            w.put_canon(sig0 + 3 * k + 0, fr_pack_canon(x2));
-            w.put_canon(sig0 + 3 * k + 1, fr_pack_canon(x4));
-            w.put_canon(sig0 + 3 * k + 2, fr_pack_canon(x5));
-        } else {
-            w.put_mont(sig0 + 3 * k + 0, x2);
-            w.put_mont(sig0 + 3 * k + 1, x4);
-            w.put_mont(sig0 + 3 * k + 2, x5);
-        }
+        w.put_canon(sig0 + 3 * k + 0, fr_pack_canon(x2));
+        w.put_canon(sig0 + 3 * k + 1, fr_pack_canon(x4));
+        w.put_canon(sig0 + 3 * k + 2, fr_pack_canon(x5));
     }
 };
 

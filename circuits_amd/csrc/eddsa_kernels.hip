@@ -156,9 +156,6 @@ __device__ __noinline__ PtA m2e_dev(const EdCtx& c, const PtA& p) {
 //   lamda[1] = num[0] * inv[2], lamda[0] = one reduction; x'[0] = lamda[0] * lamda[1] - A - ..., y'[0] = lamda[1] * (x - x')[0] - y[0]
 //   (scale 0 straight out of the product); the doubler's x1_2[0] = x[0] * x[1] needs x[1]: its x' is computed in scale 1 and reduced.
 // Three reductions per step instead of nine; the selector outputs are copies of scale-0 values. Same field elements, same signals.
-#ifndef HZ_ED_SCALES
-#define HZ_ED_SCALES 1
-#endif
 // scale-0 value in [0, 2p), normalised limbs -> the witness
 __device__ __forceinline__ Fr ed_put0(const UnitIO& w, uint32_t sig, const Fr& x) {
     const Fr c = fr_cond_sub_p(x);
@@ -176,70 +173,8 @@ __device__ __forceinline__ Fr fr_limbs_u64(uint64_t x) {   // small integer in s
     r.v[0] = (uint32_t)x & HZ_M29; r.v[1] = (uint32_t)(x >> 29) & HZ_M29; r.v[2] = (uint32_t)(x >> 58);
     return r;
 }
-// One inversion per ladder step for the XW wavefronts of a workgroup (HZ_ED_XW): Montgomery's trick across wavefronts. Every lane
-// multiplies its own divisors together as before; the products of lane l of the XW wavefronts meet in LDS, the wavefront whose turn
-// it is (they rotate) combines them, runs the ONE inversion, hands every wavefront the inverse of its own product back through LDS,
-// and each lane peels its divisors off. The others wait at the barrier and leave the issue slots of their SIMDs to whatever else is
-// resident. The inversion is about half of a ladder step's instructions (two signatures per lane); XW = 4 removes three quarters
-// of them for 9 products per step on the wavefront whose turn it is. Two barriers per step; two LDS regions (products in, inverses
-// out) so that a step's writes never meet the previous step's reads.
-template <int XW>
-__device__ __noinline__ Fr fr_inv_shared(const Fr& acc, uint32_t* xlds, int turn) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* A = xlds;
-    uint32_t* B = xlds + XW * 9 * 64;
-#pragma unroll
-    for (int l = 0; l < 9; l++) A[(wave * 9 + l) * 64 + lane] = acc.v[l];
-    __syncthreads();
-    if (wave == (uint32_t)turn % XW) {
-        Fr a[XW], pre[XW];
-#pragma unroll
-        for (int w = 0; w < XW; w++) {
-#pragma unroll
-            for (int l = 0; l < 9; l++) a[w].v[l] = A[(w * 9 + l) * 64 + lane];
-        }
-        pre[0] = a[0];
-#pragma unroll
-        for (int w = 1; w < XW; w++) pre[w] = fr_mul(pre[w - 1], a[w]);   // pre[w] = a[0] ... a[w]
-        Fr t = fr_inv(pre[XW - 1]);
-#pragma unroll
-        for (int w = XW - 1; w >= 0; w--) {
-            const Fr r = w > 0 ? fr_mul(t, pre[w - 1]) : t;
-            if (w > 0) t = fr_mul(t, a[w]);
-#pragma unroll
-            for (int l = 0; l < 9; l++) B[(w * 9 + l) * 64 + lane] = r.v[l];
-        }
-    }
-    __syncthreads();
-    Fr r;
-#pragma unroll
-    for (int l = 0; l < 9; l++) r.v[l] = B[(wave * 9 + l) * 64 + lane];
-    return r;
-}
-// batch_inv (gadgets_dev.h) with the inversion of the lane's product shared among the XW wavefronts of the workgroup
-template <int N, int XW>
-__device__ __forceinline__ void batch_inv_xw(Fr (&x)[N], int n, uint32_t* xlds, int turn) {
-    if constexpr (XW == 1) {
-        batch_inv<N>(x, n);
-    } else {
-        Fr pre[N];
-        Fr acc = fr_one();
-        for (int i = 0; i < n; i++) {
-            pre[i] = acc;
-            if (!fr_is_zero(x[i])) acc = fr_mul(acc, x[i]);
-        }
-        Fr inv = fr_inv_shared<XW>(acc, xlds, turn);
-        for (int i = n - 1; i >= 0; i--) {
-            if (fr_is_zero(x[i])) continue;
-            const Fr xi = x[i];
-            x[i] = fr_mul(inv, pre[i]);
-            inv = fr_mul(inv, xi);
-        }
-    }
-}
-#if HZ_ED_SCALES
-template <int G, int XW>
-__device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl, uint32_t* xlds) {
+template <int G>
+__device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl) {
     Fr dx0[G], dx1[G], dy0[G];   // doubler output D_{i+1}: x in scales 0 and 1, y in scale 0
     PtA addIn[G];                // the accumulator, scale 0, canonical
     Fr nx1_2[G], d_num[G];       // scale 0
@@ -279,7 +214,7 @@ __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const 
             if (fr_is_zero(a_den)) zmask |= 1u << (2 * g);
             if (more && fr_is_zero(dd)) zmask |= 1u << (2 * g + 1);
         }
-        batch_inv_xw<2 * G, XW>(inv, 2 * G, xlds, i);   // scale-0 divisors in, scale-2 inverses out
+        batch_inv<2 * G>(inv, 2 * G);   // scale-0 divisors in, scale-2 inverses out
 #pragma unroll 1
         for (int g = 0; g < G; g++) {
             const UnitIO& w = io[g];
@@ -329,89 +264,6 @@ __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const 
         p[g] = r;
     }
 }
-#else
-template <int G, int XW>
-__device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl, uint32_t* xlds) {
-    PtA dout[G], addIn[G];
-    Fr nx1_2[G], d_num[G];
-    const int steps = n - 1;
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {
-        const EdCtx c = K.with(io[g]);
-        const PtA m = e2m_dev(c, p[g]);
-        c.io.put_m(o.e2m, m.x); c.io.put_m(o.e2m + 1, m.y);
-        const MDbl d = mont_dbl_dev(c, m);   // doubler_0
-        c.io.put_m(o.bits + BIT_DBL_X1_2, d.x1_2); c.io.put_m(o.bits + BIT_DBL_LAMDA, d.lamda);
-        c.io.put_m(o.bits + BIT_DBL_OUT0, d.out.x); c.io.put_m(o.bits + BIT_DBL_OUT1, d.out.y);
-        dout[g] = d.out;
-        addIn[g] = m;
-    }
-    const Fr A2 = fr_dbl(K.A);
-#pragma unroll 1
-    for (int i = 0; i < steps; i++) {
-        const bool more = i + 1 < steps;
-        const uint32_t b = o.bits + BIT_N * i;
-        Fr inv[2 * G];
-        uint32_t zmask = 0;
-#pragma unroll 1
-        for (int g = 0; g < G; g++) {
-            // adder_i: in1 = dout, in2 = addIn ; doubler_{i+1}: in = dout
-            const Fr a_den = fr_sub(addIn[g].x, dout[g].x);
-            Fr dd = fr_zero();
-            if (more) {
-                nx1_2[g] = fr_sqr(dout[g].x);
-                d_num[g] = fr_add(fr_add(fr_add(fr_dbl(nx1_2[g]), nx1_2[g]), fr_mul(A2, dout[g].x)), K.one);
-                dd = fr_dbl(dout[g].y);
-            }
-            inv[2 * g] = a_den;
-            inv[2 * g + 1] = dd;
-            if (fr_is_zero(a_den)) zmask |= 1u << (2 * g);
-            if (more && fr_is_zero(dd)) zmask |= 1u << (2 * g + 1);
-        }
-        batch_inv_xw<2 * G, XW>(inv, 2 * G, xlds, i);
-#pragma unroll 1
-        for (int g = 0; g < G; g++) {
-            const UnitIO& w = io[g];
-            const Fr a_num = fr_sub(addIn[g].y, dout[g].y);
-            const Fr a_lamda = fr_mul(a_num, inv[2 * g]);
-            if ((zmask >> (2 * g)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), a_num);
-            PtA ao;
-            ao.x = fr_sub(fr_sub(fr_sub(fr_sqr(a_lamda), K.A), dout[g].x), addIn[g].x);
-            ao.y = fr_sub(fr_mul(a_lamda, fr_sub(dout[g].x, ao.x)), dout[g].y);
-            const uint32_t sel = c_bit(e[g], e0 + i + 1);
-            const PtA so = sel ? ao : addIn[g];
-            w.put_m(b + BIT_ADD_LAMDA, a_lamda); w.put_m(b + BIT_ADD_OUT0, ao.x); w.put_m(b + BIT_ADD_OUT1, ao.y);
-            w.put_m(b + BIT_SEL_OUT0, so.x); w.put_m(b + BIT_SEL_OUT1, so.y);
-            addIn[g] = so;
-            if (more) {
-                const Fr lamda = fr_mul(d_num[g], inv[2 * g + 1]);
-                if ((zmask >> (2 * g + 1)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), d_num[g]);
-                PtA no;
-                no.x = fr_sub(fr_sub(fr_sqr(lamda), K.A), fr_dbl(dout[g].x));
-                no.y = fr_sub(fr_mul(lamda, fr_sub(dout[g].x, no.x)), dout[g].y);
-                const uint32_t bn = b + BIT_N;
-                w.put_m(bn + BIT_DBL_X1_2, nx1_2[g]); w.put_m(bn + BIT_DBL_LAMDA, lamda); w.put_m(bn + BIT_DBL_OUT0, no.x); w.put_m(bn + BIT_DBL_OUT1, no.y);
-                dout[g] = no;
-            }
-        }
-    }
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {
-        const EdCtx c = K.with(io[g]);
-        dbl[g] = dout[g];
-        const PtA me = m2e_dev(c, addIn[g]);
-        c.io.put_m(o.m2e, me.x); c.io.put_m(o.m2e + 1, me.y);
-        PtA negp;
-        negp.x = fr_neg(p[g].x);
-        negp.y = p[g].y;
-        const PtA ea = baby_add_dev(c, o.eadder, me, negp);
-        const PtA r = c_bit(e[g], e0) ? me : ea;
-        c.io.put_m(o.lastSel, r.x); c.io.put_m(o.lastSel + 1, r.y);
-        p[g] = r;
-    }
-}
-
-#endif   // HZ_ED_SCALES
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // SegmentMulAny(n) for ONE signature without an inversion per step (launches the device does not fill: a step of seg_any_lock is
@@ -486,7 +338,7 @@ __device__ __noinline__ void seg_any_proj(const EdK& K, const UnitIO& io, const 
     // ---- the one inversion: every adder's Z3 and the Z of the last doubler output (Z1 now)
     const Fr total = fr_mul(P, Z1);
     if (fr_is_zero(total)) {
-        seg_any_lock<1, 1>(K, &io, o, &e, e0, n, p, dbl, nullptr);
+        seg_any_lock<1>(K, &io, o, &e, e0, n, p, dbl);
         return;
     }
     const Fr tinv = fr_inv(total);
@@ -543,99 +395,6 @@ __device__ __noinline__ void seg_any_proj(const EdK& K, const UnitIO& io, const 
     *p = r;
 }
 
-// C ladder chains in lockstep that need not be the same segment: chain c walks bits e[c][e0[c] .. e0[c] + n[c]) with the signal
-// block oo[c] and the witness cursor io[c]. A chain that has run out of steps contributes the element 1 to the shared inversion.
-// Used with C = 2 G: both segments of G signatures (the second one starts from the precomputed 2^147 * 8A, k_eddsa_pre's chain), so
-// a lane's dependent chain is 147 steps instead of 2 x 127 and four steps share every inversion for the first 105 of them.
-template <int C>
-__device__ __noinline__ void seg_any_multi(const EdK& K, const UnitIO* const* io, const SegAnyOff* const* oo, const Fc* const* e, const int* e0, const int* n,
-                                           PtA* p, PtA* dbl) {
-    PtA dout[C], addIn[C];
-    Fr nx1_2[C], d_num[C];
-    int max_steps = 0;
-#pragma unroll 1
-    for (int c = 0; c < C; c++) {
-        const SegAnyOff& o = *oo[c];
-        const EdCtx ctx = K.with(*io[c]);
-        const PtA m = e2m_dev(ctx, p[c]);
-        ctx.io.put_m(o.e2m, m.x); ctx.io.put_m(o.e2m + 1, m.y);
-        const MDbl d = mont_dbl_dev(ctx, m);   // doubler_0
-        ctx.io.put_m(o.bits + BIT_DBL_X1_2, d.x1_2); ctx.io.put_m(o.bits + BIT_DBL_LAMDA, d.lamda);
-        ctx.io.put_m(o.bits + BIT_DBL_OUT0, d.out.x); ctx.io.put_m(o.bits + BIT_DBL_OUT1, d.out.y);
-        dout[c] = d.out;
-        addIn[c] = m;
-        if (n[c] - 1 > max_steps) max_steps = n[c] - 1;
-    }
-    const Fr A2 = fr_dbl(K.A);
-#pragma unroll 1
-    for (int i = 0; i < max_steps; i++) {
-        Fr inv[2 * C];
-        uint32_t zmask = 0;
-#pragma unroll 1
-        for (int c = 0; c < C; c++) {
-            const int steps = n[c] - 1;
-            Fr a_den = K.one, dd = K.one;
-            if (i < steps) {
-                a_den = fr_sub(addIn[c].x, dout[c].x);
-                if (fr_is_zero(a_den)) zmask |= 1u << (2 * c);
-                if (i + 1 < steps) {
-                    nx1_2[c] = fr_sqr(dout[c].x);
-                    d_num[c] = fr_add(fr_add(fr_add(fr_dbl(nx1_2[c]), nx1_2[c]), fr_mul(A2, dout[c].x)), K.one);
-                    dd = fr_dbl(dout[c].y);
-                    if (fr_is_zero(dd)) zmask |= 1u << (2 * c + 1);
-                }
-            }
-            inv[2 * c] = a_den;
-            inv[2 * c + 1] = dd;
-        }
-        batch_inv<2 * C>(inv, 2 * C);
-#pragma unroll 1
-        for (int c = 0; c < C; c++) {
-            const int steps = n[c] - 1;
-            if (i >= steps) continue;
-            const SegAnyOff& o = *oo[c];
-            const UnitIO& w = *io[c];
-            const uint32_t b = o.bits + BIT_N * i;
-            const Fr a_num = fr_sub(addIn[c].y, dout[c].y);
-            const Fr a_lamda = fr_mul(a_num, inv[2 * c]);
-            if ((zmask >> (2 * c)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), a_num);
-            PtA ao;
-            ao.x = fr_sub(fr_sub(fr_sub(fr_sqr(a_lamda), K.A), dout[c].x), addIn[c].x);
-            ao.y = fr_sub(fr_mul(a_lamda, fr_sub(dout[c].x, ao.x)), dout[c].y);
-            const uint32_t sel = c_bit(*e[c], e0[c] + i + 1);
-            const PtA so = sel ? ao : addIn[c];
-            w.put_m(b + BIT_ADD_LAMDA, a_lamda); w.put_m(b + BIT_ADD_OUT0, ao.x); w.put_m(b + BIT_ADD_OUT1, ao.y);
-            w.put_m(b + BIT_SEL_OUT0, so.x); w.put_m(b + BIT_SEL_OUT1, so.y);
-            addIn[c] = so;
-            if (i + 1 < steps) {
-                const Fr lamda = fr_mul(d_num[c], inv[2 * c + 1]);
-                if ((zmask >> (2 * c + 1)) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), d_num[c]);
-                PtA no;
-                no.x = fr_sub(fr_sub(fr_sqr(lamda), K.A), fr_dbl(dout[c].x));
-                no.y = fr_sub(fr_mul(lamda, fr_sub(dout[c].x, no.x)), dout[c].y);
-                const uint32_t bn = b + BIT_N;
-                w.put_m(bn + BIT_DBL_X1_2, nx1_2[c]); w.put_m(bn + BIT_DBL_LAMDA, lamda); w.put_m(bn + BIT_DBL_OUT0, no.x); w.put_m(bn + BIT_DBL_OUT1, no.y);
-                dout[c] = no;
-            }
-        }
-    }
-#pragma unroll 1
-    for (int c = 0; c < C; c++) {
-        const SegAnyOff& o = *oo[c];
-        const EdCtx ctx = K.with(*io[c]);
-        dbl[c] = dout[c];
-        const PtA me = m2e_dev(ctx, addIn[c]);
-        ctx.io.put_m(o.m2e, me.x); ctx.io.put_m(o.m2e + 1, me.y);
-        PtA negp;
-        negp.x = fr_neg(p[c].x);
-        negp.y = p[c].y;
-        const PtA ea = baby_add_dev(ctx, o.eadder, me, negp);
-        const PtA r = c_bit(*e[c], e0[c]) ? me : ea;
-        ctx.io.put_m(o.lastSel, r.x); ctx.io.put_m(o.lastSel + 1, r.y);
-        p[c] = r;
-    }
-}
-
 // SegmentMulFix on the constant base for G signatures in lockstep: window tables from
 // HZ_BJJ_FIX_WIN; the G additions of one window share one inversion.
 __device__ __forceinline__ uint32_t fix_window_bits(const Fc& e, int e0, int nbits, int i) {
@@ -648,7 +407,6 @@ __device__ __forceinline__ uint32_t fix_window_bits(const Fc& e, int e0, int nbi
 }
 template <int G>
 __device__ __noinline__ void seg_fix_lock(const EdK& K, const UnitIO* io, const SegFixOff& o, const Fc* e, int e0, int nbits, int win0, int seg, PtA* out) {
-#if HZ_ED_SCALES
     // the chain in scale 0 (see seg_any_lock): window points from the plain table, one reduction per window (lamda) instead of five
     PtA acc[G];
     const Fr A0 = fr_limbs_u64(168698);
@@ -692,46 +450,6 @@ __device__ __noinline__ void seg_fix_lock(const EdK& K, const UnitIO* io, const 
     }
 #pragma unroll 1
     for (int g = 0; g < G; g++) { acc[g].x = fr_scale_up(acc[g].x); acc[g].y = fr_scale_up(acc[g].y); }
-#else
-    PtA acc[G];
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {
-        acc[g].x = ld_const(HZ_BJJ_FIX_DBLLAST[2 * seg]);
-        acc[g].y = ld_const(HZ_BJJ_FIX_DBLLAST[2 * seg + 1]);
-    }
-#pragma unroll 1
-    for (int i = 0; i < (int)o.nwin; i++) {
-        const uint32_t wb = o.windows + WIN_N * i;
-        Fr inv[G];
-        uint32_t zmask = 0;
-#pragma unroll 1
-        for (int g = 0; g < G; g++) {
-            const uint32_t k = fix_window_bits(e[g], e0, nbits, i);
-            const Fr mx = ld_const(HZ_BJJ_FIX_WIN[((win0 + i) * 8 + k) * 2]);
-            inv[g] = fr_sub(mx, acc[g].x);
-            if (fr_is_zero(inv[g])) zmask |= 1u << g;
-        }
-        batch_inv<G>(inv, G);
-#pragma unroll 1
-        for (int g = 0; g < G; g++) {
-            const UnitIO& w = io[g];
-            const uint32_t k = fix_window_bits(e[g], e0, nbits, i);
-            PtA mo;
-            mo.x = ld_const(HZ_BJJ_FIX_WIN[((win0 + i) * 8 + k) * 2]);
-            mo.y = ld_const(HZ_BJJ_FIX_WIN[((win0 + i) * 8 + k) * 2 + 1]);
-            w.put_bit(wb + WIN_S10, (k & 1) & ((k >> 1) & 1));
-            w.put_m(wb + WIN_MUX0, mo.x); w.put_m(wb + WIN_MUX1, mo.y);
-            const Fr num = fr_sub(mo.y, acc[g].y);
-            const Fr lamda = fr_mul(num, inv[g]);
-            if ((zmask >> g) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), num);
-            PtA ao;
-            ao.x = fr_sub(fr_sub(fr_sub(fr_sqr(lamda), K.A), acc[g].x), mo.x);
-            ao.y = fr_sub(fr_mul(lamda, fr_sub(acc[g].x, ao.x)), acc[g].y);
-            w.put_m(wb + WIN_ADD_LAMDA, lamda); w.put_m(wb + WIN_ADD_OUT0, ao.x); w.put_m(wb + WIN_ADD_OUT1, ao.y);
-            acc[g] = ao;
-        }
-    }
-#endif
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const EdCtx c = K.with(io[g]);
@@ -912,10 +630,7 @@ __device__ __forceinline__ PtA ed_dbl_chain(const EdK& K, const PtA& p0, int cou
 #endif
 // lane = signature: everything before the scalar multiplication, and the start of its second segment
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_pre(const EddsaArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K6 = poseidon_consts_w<6>(lds);
-    __syncthreads();
+    const Fr* K6 = poseidon_consts_w<6>();
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
@@ -931,10 +646,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     sc.set(SC_ED_H, fr_from_canon(sg.h_c)); sc.set(SC_ED_ZP, sg.zp);
     sc.set(SC_ED_P0X, sg.p0.x); sc.set(SC_ED_P0Y, sg.p0.y);
     // 8A of an on-curve A is on the curve; when it is the identity the circuit substitutes Base8 (zp = 1): regular either way
-#ifndef HZ_EXPERIMENT_PRE_COUNT
-#define HZ_EXPERIMENT_PRE_COUNT 147   // timing experiments only
-#endif
-    const PtA d147 = ed_dbl_chain(K, sg.p0, HZ_EXPERIMENT_PRE_COUNT, on_curve);
+    const PtA d147 = ed_dbl_chain(K, sg.p0, 147, on_curve);
     sc.set(SC_ED_DBLX, d147.x); sc.set(SC_ED_DBLY, d147.y);
 }
 
@@ -980,8 +692,8 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         const SideBuf sd{a.side, 2 * nl, seg * nl + li};
         if (seg == 0) seg_any_proj(K, io[0], o.seg[0], h_c[0], 0, 148, p, dbl, sd);
         else seg_any_proj(K, io[0], o.seg[1], h_c[0], 148, 106, p, dbl, sd);
-    } else if (seg == 0) seg_any_lock<G, 1>(K, io, o.seg[0], h_c, 0, 148, p, dbl, nullptr);
-    else seg_any_lock<G, 1>(K, io, o.seg[1], h_c, 148, 106, p, dbl, nullptr);
+    } else if (seg == 0) seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);
+    else seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, p, dbl);
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const Scratch sc{a.scratch, a.n_units, io[g].unit};
@@ -993,20 +705,13 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
 // The whole signature as ONE chain per lane (both segments back to back, no k_eddsa_pre): 8 % fewer instructions than the split form
 // (no projective doubling chain) and half the wavefronts. Throughput-sized launches use it -- the device is full anyway, and the split
 // form measured 50.3 ms per step against 46.0 -- the split form is for launches the device does not fill (a single batch: latency).
-template <int G, int XW>
-__global__ __launch_bounds__(HZ_BLOCK * XW) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain(const EddsaArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    __shared__ uint32_t xlds[XW > 1 ? 2 * XW * 9 * 64 : 1];   // fr_inv_shared: products in, inverses out
-    uint32_t* lds = lds_raw;
-    const Fr* K6 = poseidon_consts_w<6>(lds);
-    __syncthreads();
+template <int G>
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain(const EddsaArgs a) {
+    const Fr* K6 = poseidon_consts_w<6>();
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t nl = (n + G - 1) / G;
     uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= nl) {
-        if (XW == 1) return;
-        li = nl - 1;   // the wavefronts of a workgroup walk the ladder together (barriers): a lane past the end repeats the last one
-    }
+    if (li >= nl) return;
     EdK K;
     K.one = fr_one();
     K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
@@ -1027,7 +732,7 @@ __global__ __launch_bounds__(HZ_BLOCK * XW) __attribute__((amdgpu_waves_per_eu(H
         sc.set(SC_ED_ZP, sg.zp);
         h_c[g] = sg.h_c; p[g] = sg.p0;
     }
-    seg_any_lock<G, XW>(K, io, o.seg[0], h_c, 0, 148, p, dbl, xlds);   // p <- segment 0 output
+    seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);   // p <- segment 0 output
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const EdCtx c = K.with(io[g]);
@@ -1036,67 +741,11 @@ __global__ __launch_bounds__(HZ_BLOCK * XW) __attribute__((amdgpu_waves_per_eu(H
         q[g] = m2e_dev(c, dd.out);
         c.io.put_m(o.m2e0, q[g].x); c.io.put_m(o.m2e0 + 1, q[g].y);
     }
-    seg_any_lock<G, XW>(K, io, o.seg[1], h_c, 148, 106, q, dbl, xlds);  // q <- segment 1 output
+    seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, q, dbl);  // q <- segment 1 output
 #pragma unroll 1
     for (int g = 0; g < G; g++) {   // the sum, the zero-point substitution and R8 + h*8A belong to k_eddsa_final
         const Scratch sc{a.scratch, a.n_units, io[g].unit};
         sc.set(SC_ED_S0X, p[g].x); sc.set(SC_ED_S0Y, p[g].y); sc.set(SC_ED_S1X, q[g].x); sc.set(SC_ED_S1Y, q[g].y);
-    }
-}
-
-// Both segments of G signatures in lockstep in one lane (seg_any_multi): 2 G chains share every inversion, 147 dependent steps.
-template <int G>
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain2(const EddsaArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K6 = poseidon_consts_w<6>(lds);
-    __syncthreads();
-    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
-    const uint32_t nl = (n + G - 1) / G;
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= nl) return;
-    EdK K;
-    K.one = fr_one();
-    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
-    const EddsaOff& o = a.ed;
-    UnitIO io[G];
-    Fc h_c[G];
-    PtA p[2 * G], dbl[2 * G];
-    const UnitIO* iop[2 * G];
-    const SegAnyOff* oo[2 * G];
-    const Fc* ep[2 * G];
-    int e0[2 * G], nn[2 * G];
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {
-        uint32_t ui = li + (uint32_t)g * nl;
-        if (ui >= n) ui = li;
-        const uint32_t i = a.u0 + ui;
-        io[g] = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
-        const Scratch sc{a.scratch, a.n_units, i};
-        EdSig sg;
-        bool on_curve;
-        ed_prologue(K, io[g], sc, o, K6, sg, &on_curve);
-        sc.set(SC_ED_ZP, sg.zp);
-        h_c[g] = sg.h_c;
-        p[2 * g] = sg.p0;
-        // the second segment's base point: 2^148 * 8A through the doubling chain alone, then the circuit's own doubler / m2e signals
-        const EdCtx c = K.with(io[g]);
-        const PtA d147 = ed_dbl_chain(K, sg.p0, 147, on_curve);
-        const MDbl dd = mont_dbl_dev(c, d147);
-        c.io.put_m(o.dblr, dd.x1_2); c.io.put_m(o.dblr + 1, dd.lamda); c.io.put_m(o.dblr + 2, dd.out.x); c.io.put_m(o.dblr + 3, dd.out.y);
-        p[2 * g + 1] = m2e_dev(c, dd.out);
-        c.io.put_m(o.m2e0, p[2 * g + 1].x); c.io.put_m(o.m2e0 + 1, p[2 * g + 1].y);
-    }
-#pragma unroll 1
-    for (int c = 0; c < 2 * G; c++) {
-        iop[c] = &io[c >> 1]; ep[c] = &h_c[c >> 1];
-        oo[c] = &o.seg[c & 1]; e0[c] = (c & 1) ? 148 : 0; nn[c] = (c & 1) ? 106 : 148;
-    }
-    seg_any_multi<2 * G>(K, iop, oo, ep, e0, nn, p, dbl);
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {
-        const Scratch sc{a.scratch, a.n_units, io[g].unit};
-        sc.set(SC_ED_S0X, p[2 * g].x); sc.set(SC_ED_S0Y, p[2 * g].y); sc.set(SC_ED_S1X, p[2 * g + 1].x); sc.set(SC_ED_S1Y, p[2 * g + 1].y);
     }
 }
 
@@ -1181,27 +830,15 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa_final(const EddsaArgs a) {
 // latency is what counts; many units per launch: the integer pipe is the limit.
 template <int G>
 static hipError_t launch_eddsa_split(const EddsaArgs& a, uint32_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_eddsa_pre, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
+    hipLaunchKernelGGL(k_eddsa_pre, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
     const uint32_t nl = (n + G - 1) / G;
     hipLaunchKernelGGL(k_eddsa_ladder<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK, 2), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
-// 1: both segments of a lane's signatures in lockstep (k_eddsa_chain2: 147 dependent steps, four steps per inversion); 0: one after the
-// other (k_eddsa_chain). Measured at 65 536 signatures, G = 2: the kernel alone 23.9 vs 24.6 ms, the step 47.7-47.8 vs 47.9 ms on the
-// same box -- halving the inversions buys 3 %: a ladder step is as long as an inversion even without one (nine stored signals, each
-// a reduction of its own, and eight dependent products), and the lockstep form parks four chains' state in scratch (3.9 vs 2.8 KB per
-// lane). Kept as an option, not the default.
-#ifndef HZ_ED_MULTI
-#define HZ_ED_MULTI 0
-#endif
-#ifndef HZ_ED_XW
-#define HZ_ED_XW 1   // wavefronts of a workgroup that share the ladder's inversion (fr_inv_shared)
-#endif
 template <int G>
 static hipError_t launch_eddsa_g(const EddsaArgs& a, uint32_t n, hipStream_t s) {
     const uint32_t nl = (n + G - 1) / G;
-    if (HZ_ED_MULTI) hipLaunchKernelGGL(k_eddsa_chain2<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), poseidon_lds_bytes<6>(), s, a);
-    else hipLaunchKernelGGL((k_eddsa_chain<G, HZ_ED_XW>), dim3((nl + HZ_BLOCK * HZ_ED_XW - 1) / (HZ_BLOCK * HZ_ED_XW)), dim3(HZ_BLOCK * HZ_ED_XW), poseidon_lds_bytes<6>(), s, a);
+    hipLaunchKernelGGL(k_eddsa_chain<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 template <int G>
@@ -1215,9 +852,6 @@ size_t eddsa_side_bytes(uint32_t n) {
 }
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
-#ifdef HZ_ED_G_FIXED
-    return launch_eddsa_g<HZ_ED_G>(a, n, s);
-#else
     // a launch the device does not fill is latency bound: the two segments of every signature as independent lanes (148 / 106
     // dependent steps instead of 254), one signature per lane
     if (n <= HZ_ED_SPLIT_MAX) return launch_eddsa_split<1>(a, n, s);
@@ -1226,16 +860,11 @@ hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
     // the ladder is the longest chain of a step, and its length, not its instruction count, sets the step: 1.27 vs 1.19 M tx/s
     // (one per lane: 20.8 ms, 1.23 M tx/s).
     return launch_eddsa_g<HZ_ED_G>(a, n, s);
-#endif
 }
 hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
-#ifdef HZ_ED_GF_FIXED
-    return launch_eddsa_fix_g<HZ_ED_GF_FIXED>(a, n, s);
-#else
     if (n <= 8192) return launch_eddsa_fix_g<1>(a, n, s);
     return launch_eddsa_fix_g<4>(a, n, s);   // 9.2 ms per 65 536 signatures (eight per lane: 14.1 ms, same step time)
-#endif
 }
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;

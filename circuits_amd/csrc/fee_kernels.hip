@@ -60,10 +60,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_fee_back(const FeeBackArgs a) {
 // ---- HashState as main component ------------------------------------------------------------------
 struct HsMainArgs { uint8_t* base; uint32_t N; HashStateOff hs; };
 __global__ __launch_bounds__(HZ_BLOCK) void k_hash_state_main(const HsMainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K5 = poseidon_consts_w<5>(lds);
-    __syncthreads();
+    const Fr* K5 = poseidon_consts_w<5>();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, nullptr};
@@ -364,12 +361,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_sha_expand(const HashInputsArgs a)
 
 // ---- Withdraw: lane = instance -----------------------------------------------------------------------
 __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K5 = poseidon_consts_w<5>(lds);
-    const Fr* K4 = poseidon_consts_w<4>(lds);
-    const Fr* K3 = poseidon_consts_w<3>(lds);
-    __syncthreads();
+    const Fr* K5 = poseidon_consts_w<5>();
+    const Fr* K4 = poseidon_consts_w<4>();
+    const Fr* K3 = poseidon_consts_w<3>();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
@@ -451,7 +445,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
         h2[1] = sel ? child : sib;
         WitSboxSink sk = io.sbox_sink(lv + VL_HASH);
         Fr ph;
-        if (HZ_SMT_ZERO_FAST && __all(fr_is_zero(h2[0]) && fr_is_zero(h2[1]))) ph = poseidon3_zero_level(io, lv + VL_HASH);   // empty subtree (smt_dev.h)
+        if (__all(fr_is_zero(h2[0]) && fr_is_zero(h2[1]))) ph = poseidon3_zero_level(io, lv + VL_HASH);   // empty subtree (smt_dev.h)
         else ph = poseidon_hash<3>(h2, K3, sk);
         const Fr a0 = ((topmask >> k) & 1) ? ph : zero;
         const Fr root = ((inewmask >> k) & 1) ? fr_add(a0, h1new) : a0;
@@ -573,7 +567,7 @@ hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s) {
 }
 hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff& hs, hipStream_t s) {
     HsMainArgs a{base, N, hs};
-    hipLaunchKernelGGL(k_hash_state_main, grid1(N), dim3(HZ_BLOCK), poseidon_lds_bytes<5>(), s, a);
+    hipLaunchKernelGGL(k_hash_state_main, grid1(N), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 // The chain is sequential, the expansion (a 0.7 GB store stream per batch) is not: the blocks are split into groups, group g's
@@ -603,7 +597,6 @@ hipError_t launch_hash_inputs(const HashInputsArgs& a0, hipStream_t s, hipStream
         a.prep_part = 0;
         hipLaunchKernelGGL(k_hi_prep, grid1((1 + a.maxL1 + a.nTx + a.F) * a.B), dim3(HZ_BLOCK), 0, s, a);
     }
-#if !defined(HZ_EXPERIMENT_NO_SHA)   // timing experiment only (wrong witness)
     const uint32_t nb = (uint32_t)a.hi.sha.nblocks;
     const bool piped = side && side != s && ev && n_ev >= 2 && nb >= 64;
     const uint32_t groups = piped ? (uint32_t)std::min<int>(HZ_SHA_GROUPS, n_ev - 1) : 1u;
@@ -625,7 +618,26 @@ hipError_t launch_hash_inputs(const HashInputsArgs& a0, hipStream_t s, hipStream
         if ((e = hipEventRecord(ev[n_ev - 1], side)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(s, ev[n_ev - 1], 0)) != hipSuccess) return e;
     }
-#endif
+    return hipGetLastError();
+}
+hipError_t launch_hi_chain_only(const HashInputsArgs& a0, hipStream_t s) {
+    HashInputsArgs a = a0;
+    hipError_t e = hipMemsetAsync(a.msg, 0, (size_t)a.hi.sha.nblocks * 64 * a.B, s);
+    if (e != hipSuccess) return e;
+    a.prep_part = 0;
+    hipLaunchKernelGGL(k_hi_prep, grid1((1 + a.maxL1 + a.nTx + a.F) * a.B), dim3(HZ_BLOCK), 0, s, a);
+    a.blk0 = 0;
+    a.blk1 = (uint32_t)a.hi.sha.nblocks;
+    if (a.B <= 2 * HZ_SHAW_BATCH) hipLaunchKernelGGL(k_sha_chain_w, dim3((a.B + HZ_SHAW_BATCH - 1) / HZ_SHAW_BATCH), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_sha_chain, dim3((a.B + 63) / 64), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_sha_expand_range(const HashInputsArgs& a0, uint32_t first, uint32_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    HashInputsArgs a = a0;
+    a.blk0 = first;
+    a.blk1 = first + count;
+    hipLaunchKernelGGL(k_sha_expand, grid1(count * a.B * HZ_SHA_PARTS), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_da_export(const DaArgs& a, hipStream_t s) {
@@ -638,7 +650,7 @@ hipError_t launch_da_import(const DaArgs& a, hipStream_t s) {
 }
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_withdraw, grid1(a.N), dim3(HZ_BLOCK),
-                       poseidon_lds_bytes<5>() + poseidon_lds_bytes<4>() + poseidon_lds_bytes<3>(), s, a);
+                       0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_withdraw_sha(const WithdrawArgs& a, hipStream_t s) {

@@ -12,6 +12,7 @@
 // `./circuit input.json witness.json` (circuits_amd/csrc/cli/hz_witness.cpp).
 #include <stdio.h>
 #include <string.h>
+#include <new>
 #include <string>
 #include <vector>
 #include "hostutil.h"
@@ -280,11 +281,15 @@ struct hz_symmap {
 
 extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_t len, hz_symmap** out) {
     if (!ctx || !text || !out) return set_err(HZ_ERR_ARG, "hz_symmap_create: null argument");
+    try {
     hz_symmap* m = new hz_symmap();
     std::vector<std::string> label;   // one label per variable, kept until the variable resolves
     const char* p = text;
     const char* e = text + len;
     uint64_t line_no = 0;
+    uint64_t n_lines = 1;
+    for (const char* c = text; c < e; c++) n_lines += *c == '\n';
+    const uint64_t var_cap = std::min<uint64_t>(n_lines, 8 * hz_witness_len(ctx) + 1024);
     while (p < e) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
         const char* le = nl ? nl : e;
@@ -294,10 +299,16 @@ extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_
         long long f[3] = {0, 0, 0};
         bool ok = le > p;
         for (int k = 0; k < 3 && ok; k++) {
-            char* end = nullptr;
-            f[k] = strtoll(q, &end, 10);
-            ok = end != q && end < le && *end == ',';
-            q = end + 1;
+            // bounded parse: the text need not be NUL-terminated (strtoll could run past `e`), and a field is at most 18 digits
+            const char* d = q;
+            const bool neg = d < le && *d == '-';
+            if (neg) d++;
+            long long v = 0;
+            int nd = 0;
+            while (d < le && *d >= '0' && *d <= '9' && nd < 19) { v = v * 10 + (*d - '0'); d++; nd++; }
+            ok = nd > 0 && nd < 19 && d < le && *d == ',';
+            f[k] = neg ? -v : v;
+            q = d + 1;
         }
         if (le > p && !(le - p == 1 && *p == '\r')) {
             if (!ok) { delete m; return set_err(HZ_ERR_INPUT, ".sym line %llu: expected labelIdx,varIdx,componentIdx,name", (unsigned long long)line_no); }
@@ -305,7 +316,9 @@ extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_
             while (ne > q && (ne[-1] == '\r' || ne[-1] == ' ')) ne--;
             const long long var = f[1];
             if (var >= 0) {
-                if ((uint64_t)var >= (1ull << 40)) { delete m; return set_err(HZ_ERR_INPUT, ".sym line %llu: variable index out of range", (unsigned long long)line_no); }
+                // a compile of this template cannot have more variables than the file has lines (every variable has a label), nor
+                // more than a few times the signals this layout stores: a stray huge index must not become a huge allocation
+                if ((uint64_t)var >= var_cap) { delete m; return set_err(HZ_ERR_INPUT, ".sym line %llu: variable index %lld out of range (cap %llu)", (unsigned long long)line_no, var, (unsigned long long)var_cap); }
                 if ((uint64_t)var >= m->index.size()) { m->index.resize((size_t)var + 1, ~0ull); label.resize((size_t)var + 1); }
                 if (m->index[(size_t)var] == ~0ull) {
                     const std::string name(q, (size_t)(ne - q));
@@ -326,6 +339,9 @@ extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_
         }
     *out = m;
     return HZ_OK;
+    } catch (const std::bad_alloc&) {   // nothing may unwind through the C ABI
+        return set_err(HZ_ERR_INPUT, "hz_symmap_create: out of memory while reading the .sym");
+    }
 }
 extern "C" void hz_symmap_destroy(hz_symmap* m) { delete m; }
 extern "C" uint64_t hz_symmap_nvars(const hz_symmap* m) { return m ? m->index.size() : 0; }

@@ -208,7 +208,6 @@ HZ_HD bool fr_eq(const Fr& a, const Fr& b) { return fr_is_zero(fr_sub(a, b)); }
 // there are no separate carry additions and no 18 live column sums (measured, tools/microbench/mulbench.hip variant 4: -12 %
 // latency of a dependent product, +1 % throughput against reducing row by row). The empty asm keeps the compiler from
 // re-associating the carry back into independent partial sums joined by 64-bit additions.
-#ifndef HZ_FR_ROWWISE
 HZ_HD Fr fr_reduce_cols(uint64_t* t) {
     uint32_t m[9];
     Fr r;
@@ -239,25 +238,6 @@ HZ_HD Fr fr_reduce_cols(uint64_t* t) {
     r.v[8] = (uint32_t)(acc + t[17]);
     return r;
 }
-#else
-HZ_HD Fr fr_reduce_cols(uint64_t* t) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        const uint32_t m = ((uint32_t)t[i] * HZ_INV29) & HZ_M29;
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[i + j] += (uint64_t)m * fr_p29(j);
-        t[i + 1] += t[i] >> 29;
-    }
-    Fr r;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        r.v[k] = (uint32_t)t[9 + k] & HZ_M29;
-        t[10 + k] += t[9 + k] >> 29;
-    }
-    r.v[8] = (uint32_t)t[17];
-    return r;
-}
-#endif
 // Montgomery product a*b/R mod p; inputs normalised with value < 2^257, output < 1.03 p, normalised.
 HZ_HD_HEAVY Fr fr_mul(HZ_HEAVY_ARG(Fr) a, HZ_HEAVY_ARG(Fr) b) {
     uint64_t t[18];
@@ -421,7 +401,7 @@ HZ_HD Fr fr_cond_sub_p(const Fr& a) {
 // reaches p's, nobody can be >= p and the 36-instruction subtract-and-select is skipped (wave-uniform branch; three of these per
 // Poseidon S-box were 12 % of its instructions).
 HZ_HD Fr fr_cond_sub_p_rare(const Fr& a) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_NO_RARE_SKIP)
+#if defined(__HIP_DEVICE_COMPILE__)
     if (!__any(a.v[8] >= fr_p29(8))) return a;
 #endif
     return fr_cond_sub_p(a);
@@ -494,29 +474,7 @@ HZ_HD constexpr int32_t fr_p30(int i) {
 }
 #define HZ_P_INV30 0x10000001u  // p^-1 mod 2^30
 
-HZ_HD int32_t fr_divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, int32_t* t) {
-    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
-#pragma unroll 1
-    for (int i = 0; i < 30; ++i) {
-        uint32_t mask1 = (uint32_t)(zeta >> 31);
-        const uint32_t mask2 = 0u - (g & 1u);
-        const uint32_t x = (f ^ mask1) - mask1, y = (u ^ mask1) - mask1, z = (v ^ mask1) - mask1;
-        g += x & mask2;
-        q += y & mask2;
-        r += z & mask2;
-        mask1 &= mask2;
-        zeta = (int32_t)(((uint32_t)zeta ^ mask1) - 1u);
-        f += g & mask1;
-        u += q & mask1;
-        v += r & mask1;
-        g >>= 1;
-        u <<= 1;
-        v <<= 1;
-    }
-    t[0] = (int32_t)u; t[1] = (int32_t)v; t[2] = (int32_t)q; t[3] = (int32_t)r;
-    return zeta;
-}
-// The same 30 division steps (plain delta = 1 form, eta = -delta), several per iteration: the zeros at the bottom of g are shifted
+// 30 division steps (plain delta = 1 form, eta = -delta), several per iteration: the zeros at the bottom of g are shifted
 // out together (count-trailing-zeros up to the steps that are left), and when g is odd the multiple w of f that cancels its
 // bottom min(eta + 1, steps left, 8) bits is added at once -- no sign flip of eta can happen inside those steps -- with
 // w = -g / f mod 2^8 from two Newton steps on f. About 10 iterations of ~35 instructions instead of 30 x 23; the lanes of a
@@ -630,9 +588,6 @@ HZ_HD Fr fr_from_limbs30(const int32_t* rr) {  // rr: 9 non-negative 30-bit limb
     return o;
 }
 // Montgomery-domain inverse: (aR)^-1 * R^3 / R = a^-1 R
-#ifndef HZ_INV_VAR
-#define HZ_INV_VAR 1   // 1: several division steps per iteration (fr_divsteps_30_var); 0: one at a time, half-delta rule
-#endif
 HZ_HD_HEAVY Fr fr_inv(HZ_HEAVY_ARG(Fr) a) {
     Fr30 d, e, f, g;
 #pragma unroll
@@ -640,14 +595,14 @@ HZ_HD_HEAVY Fr fr_inv(HZ_HEAVY_ARG(Fr) a) {
     e.v[0] = 1;
     fr_to_limbs30(a, g);
     int32_t zeta = -1;
-    // batches: the half-delta rule needs at most 600 division steps (20 batches), the plain delta = 1 rule of the several-at-a-time
-    // form at most 735 (25 batches); both leave as soon as every lane of the wavefront has g = 0 (random operands: 17..19 batches)
-    constexpr int kBatches = HZ_INV_VAR ? 25 : 20;
+    // batches: the plain delta = 1 rule needs at most 735 division steps (25 batches); the loop leaves as soon as every lane of the
+    // wavefront has g = 0 (random operands: 17..19 batches). (The one-step-at-a-time half-delta form of round 1 -- 20 batches of
+    // 30 x 23 instructions -- gave the same inverses on 20 000 operands and 1.89 instead of 2.25 G inversions/s.)
+    constexpr int kBatches = 25;
 #pragma unroll 1
     for (int it = 0; it < kBatches; ++it) {
         int32_t t[4];
-        if (HZ_INV_VAR) zeta = fr_divsteps_30_var(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
-        else zeta = fr_divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        zeta = fr_divsteps_30_var(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
         fr_update_de_30(d, e, t);
         fr_update_fg_30(f, g, t);
         // g = 0: f = +-1 and d = +-1/a already (the invariants d*a = f, e*a = g hold after every batch); 600 division steps are

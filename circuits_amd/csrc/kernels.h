@@ -95,7 +95,7 @@ struct SmtArgs {
     uint32_t n_units, n_levels;   // n_levels = L + 1
     uint32_t n_proc;
     uint32_t upi;
-    uint32_t k_hi, k_lo;          // levels evaluated by this launch, k_hi down to k_lo (launch_smt chunks the chain)
+    uint32_t skip_mod;            // != 0: units u with u % skip_mod == skip_mod - 1 belong to another launch of the step (early tail)
     SmtProcDesc p[2];
 };
 
@@ -107,6 +107,8 @@ struct RtxBackArgs {
     Fr* scratch;
     ErrBuf* err;
     uint32_t n_units, L, is_main, upi, B;
+    uint32_t skip_mod;   // as in SmtArgs
+    uint32_t skip_h;     // != 0: phase H (data-availability amount masking) is k_da_mask's this step
     SmtProcDesc p[2];
     uint32_t s3, s4, s5;
     // main: integrity checks + data-availability masking
@@ -199,8 +201,7 @@ hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s);
 hipError_t launch_gadget(int tmpl, const GadgetArgs& a, hipStream_t s);
 hipError_t launch_ay_sign_2_ax_main(const GadgetArgs& a, const EddsaOff& o, hipStream_t s);   // eddsa_kernels.hip (shares the curve code)
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
-int smt_chunk_levels(const SmtArgs& a);   // levels per launch (the chain is launched in chunks, smt_kernels.hip)
-hipError_t launch_smt_levels(const SmtArgs& a, int k_hi, int k_lo, hipStream_t s);
+hipError_t launch_smt(const SmtArgs& a, hipStream_t s);
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
 hipError_t launch_da_mask(const RtxBackArgs& a, hipStream_t s);   // RollupMain phase H alone (amount bits of L1L2TxData times 1 - isAmountNullified), every unit
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s);         // AySign2Ax, message hash, variable-base ladder, R8 + h*8A
@@ -211,6 +212,10 @@ hipError_t launch_fee_back(const FeeBackArgs& a, hipStream_t s);
 hipError_t launch_hash_inputs(const HashInputsArgs& a, hipStream_t s, hipStream_t side = nullptr, hipEvent_t* ev = nullptr, int n_ev = 0, bool body_done = false);
 // the part of the message that does not wait for the roots (the data-availability bits: front kernel + k_da_mask); launch_hash_inputs(body_done = true) follows
 hipError_t launch_hi_prep_body(const HashInputsArgs& a, hipStream_t s);
+// tx-sharded batches (multi-GPU): the message and the sequential chain alone (rank 0), then the bit-level witness of a range of
+// blocks on whichever rank holds the message blocks and chaining values (hz_sha_export / hz_sha_expand)
+hipError_t launch_hi_chain_only(const HashInputsArgs& a, hipStream_t s);
+hipError_t launch_sha_expand_range(const HashInputsArgs& a, uint32_t first, uint32_t count, hipStream_t s);
 hipError_t launch_hash_state_main(uint8_t* base, uint32_t N, const HashStateOff& hs, hipStream_t s);
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s);
 

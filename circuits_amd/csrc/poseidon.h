@@ -53,9 +53,6 @@ HZ_HD constexpr int poseidon_nsbox_rt(int t) {
     return 8 * t + (t == 2 ? 56 : t == 3 ? 57 : t == 4 ? 56 : t == 5 ? 60 : t == 6 ? 60 : 63);
 }
 
-#ifndef HZ_POSEIDON_CANON_SBOX
-#define HZ_POSEIDON_CANON_SBOX 1
-#endif
 struct NoSink {
     static constexpr bool kCanon = false;   // digest only: Montgomery form throughout, constant block HZ_POSEIDON_K_T*
     HZ_HD void operator()(int, const Fr&, const Fr&, const Fr&) const {}
@@ -71,21 +68,14 @@ struct NoSink {
 // i.e. three products and four reductions instead of three and six (-20 % of the multiply-accumulates of an S-box). The S-box
 // then returns a CANONICAL value; the constants that multiply S-box outputs carry the missing factor R (block HZ_POSEIDON_KW_T*,
 // tools/gen_constants.py), so every linear layer lands in Montgomery form again and nothing else changes.
-// A sink may ask for its three signals one at a time, each right after the product that makes it (Sink::kEarly, put(k, j, v)):
-// the stores of a witness sink then leave between the products instead of six in a row at the end of the S-box.
-template <class Sink, class = void> struct SinkEarly { static constexpr bool value = false; };
-template <class Sink> struct SinkEarly<Sink, decltype((void)Sink::kEarly)> { static constexpr bool value = Sink::kEarly; };
 template <class Sink>
 HZ_HD Fr poseidon_sbox(const Fr& x, int k, Sink& sink) {
     if constexpr (Sink::kCanon) {
         const Fr x2 = fr_sqr(x);
         const Fr in2 = fr_canon_limbs(x2);
-        if constexpr (SinkEarly<Sink>::value) sink.put(k, 0, in2);
         const Fr in4 = fr_cond_sub_p_rare(fr_mul(x2, in2));
-        if constexpr (SinkEarly<Sink>::value) sink.put(k, 1, in4);
         const Fr out = fr_cond_sub_p_rare(fr_mul(in4, x));
-        if constexpr (SinkEarly<Sink>::value) sink.put(k, 2, out);
-        else sink(k, in2, in4, out);
+        sink(k, in2, in4, out);
         return out;
     } else {
         const Fr x2 = fr_sqr(x);
@@ -147,136 +137,14 @@ HZ_HD void poseidon_sbox_layer(Fr (&st)[T], int k, Sink& sink) {
     for (int j = 0; j < T; j++) poseidon_rotate_in<T>(st, poseidon_sbox(st[0], k + j, sink));
 }
 
-// ---- compact form (HZ_POSEIDON_COMPACT, default) -------------------------------------------------------------------------------
-// The same permutation with ONE copy of the full-round S-box layer, ONE copy of the partial-round S-box and ONE copy of the mix:
-// the eight full rounds are one rolled loop whose linear layer takes its constants (and how many lanes receive one, how many rows
-// are needed) from wave-uniform values, the partial rounds are one rolled loop over single rounds that alternates between the two
-// halves of a pair. The straight-line form below has seven inlined S-box bodies and five mixes per permutation: 98 KB of code for
-// t = 3 with the witness sink, 181 KB for k_smt -- against an instruction cache of 64 KB shared by two compute units. Same
-// arithmetic in the same order, same constants block.
-#ifndef HZ_POSEIDON_COMPACT
-#define HZ_POSEIDON_COMPACT 1
-#endif
-
-// row . st + (use ? *addend : 0), one reduction; `addend` must point at readable memory even when `use` is 0 (mask, no branch:
-// the constants arrive through scalar loads, the mask is scalar arithmetic)
-template <int N>
-HZ_HD Fr poseidon_row_masked(const Fr* row, const Fr* st, const Fr* addend, uint32_t use_mask) {
-    static_assert(N <= 6, "one reduction");
-    uint64_t t[18];
-#pragma unroll
-    for (int k = 0; k < 17; k++) {
-        uint64_t acc = k < 9 ? (uint64_t)(addend->v[k] & use_mask) : 0;
-#pragma unroll
-        for (int n = 0; n < N; n++) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const int j = k - i;
-                if (j < 0 || j > 8) continue;
-                acc += (uint64_t)row[n].v[i] * st[n].v[j];
-            }
-        }
-        t[k] = acc;
-    }
-    t[17] = 0;
-    return fr_reduce_cols(t);
-}
-
-template <int T, class Sink>
-HZ_HD Fr poseidon_hash_compact(const Fr* in, const Fr* K, Sink& sink) {
-    constexpr int RP = PoseidonCfg<T>::RP;
-    const Fr* M = K + poseidon_k_m<T>();
-    Fr st[T];
-    st[0] = K[0];
-#pragma unroll
-    for (int j = 1; j < T; j++) st[j] = fr_add(in[j - 1], K[j]);
-    int k = 0;
-#pragma unroll 1
-    for (int fr = 0; fr < 8; fr++) {
-        poseidon_sbox_layer<T>(st, k, sink);
-        k += T;
-        // the linear layer after full round fr: constants for every lane (rounds 0-2, 4-6), for lane 0 only (round 3: the first
-        // partial round's), none and only row 0 (round 7: the digest)
-        const Fr* Cn = fr < 3 ? K + T * (fr + 1) : fr == 3 ? K + poseidon_k_e0<T>() : fr < 7 ? K + poseidon_k_tail<T>() + T * (fr - 4) : K;
-        const int nc = (fr == 3) ? 1 : (fr == 7) ? 0 : T;
-        const int rows = (fr == 7) ? 1 : T;
-        {
-            Fr o[T];
-#pragma unroll
-            for (int i = 0; i < T; i++) o[i] = st[i];
-#pragma unroll 1
-            for (int i = 0; i < rows; i++) {
-                const bool use = i < nc;
-                if constexpr (T <= 6) {
-                    poseidon_rotate_in<T>(o, poseidon_row_masked<T>(M + i * T, st, Cn + (use ? i : 0), use ? 0xffffffffu : 0u));
-                } else {
-                    const Fr lo = poseidon_row_masked<4>(M + i * T, st, Cn + (use ? i : 0), use ? 0xffffffffu : 0u);
-                    poseidon_rotate_in<T>(o, fr_add(lo, fr_dot<T - 4>(M + i * T + 4, st + 4)));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < T; i++) st[i] = o[i];
-        }
-        if (fr != 3) continue;
-        // partial rounds, one per iteration: even rounds are the first half of a pair (row A, keep yA), odd rounds the second
-        // (row B with beta * yA, lanes 1.. updated once per pair), a last unpaired round when RP is odd -- see the pair form below
-        const Fr* S = K + poseidon_k_part<T>();
-        Fr x = st[0], yA = st[0];
-#pragma unroll 1
-        for (int r = 0; r < RP; r++) {
-            Fr v[T + 1];
-            v[0] = poseidon_sbox(x, k, sink);
-            k += 1;
-#pragma unroll
-            for (int j = 1; j < T; j++) v[j] = st[j];
-            if ((r & 1) == 0) {
-                if ((RP & 1) && r == RP - 1) {
-                    x = poseidon_row<T>(S, v, S + 2 * T - 1);
-#pragma unroll
-                    for (int j = 1; j < T; j++) st[j] = fr_muladd(S[T + j - 1], v[0], st[j]);
-                } else {
-                    x = poseidon_row<T>(S, v, S + T);
-                    yA = v[0];
-                }
-            } else {
-                v[T] = yA;
-                x = poseidon_row<T + 1>(S + T + 1, v, S + 2 * T + 2);
-                const Fr* CA = S + 2 * T + 3;
-#pragma unroll
-                for (int j = 1; j < T; j++) st[j] = fr_cond_sub_4p(fr_muladd2(CA[j - 1], yA, CA[T - 1 + j - 1], v[0], st[j]));
-                S += 4 * T + 1;
-            }
-        }
-        st[0] = x;
-        {
-            Fr o[T - 1];
-#pragma unroll
-            for (int i = 0; i + 1 < T; i++) o[i] = st[i + 1];
-#pragma unroll 1
-            for (int i = 0; i + 1 < T; i++)
-                poseidon_rotate_in<T - 1>(o, poseidon_row<T - 1>(K + poseidon_k_dense<T>() + i * (T - 1), st + 1, K + poseidon_k_cf<T>() + i));
-#pragma unroll
-            for (int i = 1; i < T; i++) st[i] = o[i - 1];
-        }
-    }
-    return st[T - 1];   // round 7 computed row 0 only and rotated it in last
-}
-
-template <int T, class Sink>
-HZ_HD Fr poseidon_hash_straight(const Fr* in, const Fr* K, Sink& sink);
-
 // Full permutation; `in` are the T-1 inputs (Montgomery), K the constant block (layout above) in the form the sink asks for:
 // poseidon_consts<T>() for a digest-only sink, poseidon_consts_w<T>() for Sink::kCanon. The digest is in Montgomery form.
 // S-box k is numbered in evaluation order: 4 full rounds (T each), R_P partial, 4 full rounds.
+// (A rolled form with one S-box body for the full rounds and one for the partial rounds -- half the code, 48 KB instead of 98 KB for
+// t = 3 with the witness sink -- was measured in round 3: the instruction cache was never the limit (0.1 % misses), k_smt unchanged,
+// Poseidon t = 3 with witness 250 instead of 256 M/s. Not kept.)
 template <int T, class Sink>
 HZ_HD Fr poseidon_hash(const Fr* in, const Fr* K, Sink& sink) {
-    if constexpr (HZ_POSEIDON_COMPACT != 0) return poseidon_hash_compact<T>(in, K, sink);
-    else return poseidon_hash_straight<T>(in, K, sink);
-}
-
-// ---- straight-line form ------------------------------------------------------------------------------------------------------
-template <int T, class Sink>
-HZ_HD Fr poseidon_hash_straight(const Fr* in, const Fr* K, Sink& sink) {
     constexpr int RP = PoseidonCfg<T>::RP;
     const Fr* M = K + poseidon_k_m<T>();
     Fr st[T];

@@ -16,10 +16,7 @@ namespace hz {
 template <int T, bool WIT>
 __global__ __launch_bounds__(256) void poseidon_batch_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                               uint8_t* __restrict__ wit, size_t n) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K = poseidon_consts<T, WIT>(lds);   // the witness sink takes canonical S-box outputs: its own constant block
-    __syncthreads();
+    const Fr* K = poseidon_consts<T, WIT>();   // the witness sink takes canonical S-box outputs: its own constant block
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         Fr x[T - 1];
@@ -43,15 +40,11 @@ static hipError_t launch_poseidon(size_t n, const void* d_in, void* d_out, void*
     const int block = 256;
     size_t blocks = (n + block - 1) / block;
     if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 blocks per CU
-    size_t lds = poseidon_lds_bytes<T>();
-#ifdef HZ_EXPERIMENT_LDS_PAD   // occupancy experiment: a dynamic LDS reservation limits the workgroups per CU
-    if (const char* e = getenv("HZ_POSEIDON_LDS_PAD")) lds += (size_t)atol(e);
-#endif
     if (d_wit)
-        hipLaunchKernelGGL((poseidon_batch_kernel<T, true>), dim3((unsigned)blocks), dim3(block), lds, s,
+        hipLaunchKernelGGL((poseidon_batch_kernel<T, true>), dim3((unsigned)blocks), dim3(block), 0, s,
                            (const uint8_t*)d_in, (uint8_t*)d_out, (uint8_t*)d_wit, n);
     else
-        hipLaunchKernelGGL((poseidon_batch_kernel<T, false>), dim3((unsigned)blocks), dim3(block), lds, s,
+        hipLaunchKernelGGL((poseidon_batch_kernel<T, false>), dim3((unsigned)blocks), dim3(block), 0, s,
                            (const uint8_t*)d_in, (uint8_t*)d_out, (uint8_t*)nullptr, n);
     return hipGetLastError();
 }
@@ -62,10 +55,7 @@ static hipError_t launch_poseidon(size_t n, const void* d_in, void* d_out, void*
 template <int T>
 __global__ __launch_bounds__(256) void poseidon_dag_kernel(uint8_t* __restrict__ vals, const uint32_t* __restrict__ job_in,
                                                             const uint32_t* __restrict__ job_out, size_t first, size_t count) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K = poseidon_consts<T>(lds);
-    __syncthreads();
+    const Fr* K = poseidon_consts<T>();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const size_t job = first + i;
@@ -81,7 +71,7 @@ template <int T>
 static hipError_t launch_poseidon_dag(uint8_t* vals, const uint32_t* job_in, const uint32_t* job_out, size_t first, size_t count, hipStream_t s) {
     if (count == 0) return hipSuccess;
     // one wavefront per workgroup: a level of a 2048-transaction batch is a few thousand jobs, which should spread over all CUs
-    hipLaunchKernelGGL(poseidon_dag_kernel<T>, dim3((unsigned)((count + 63) / 64)), dim3(64), poseidon_lds_bytes<T>(), s, vals, job_in, job_out, first, count);
+    hipLaunchKernelGGL(poseidon_dag_kernel<T>, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, s, vals, job_in, job_out, first, count);
     return hipGetLastError();
 }
 

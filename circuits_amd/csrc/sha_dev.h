@@ -43,8 +43,15 @@ __device__ __forceinline__ void sha256_compress(uint32_t* hv, const uint32_t* w1
 // lanes of a half-wavefront own 32 consecutive units (io.coop32) the 1 KiB row of a signal is written as two fully contiguous
 // 512-byte instructions instead: lane L of the group carries the first or second 16 bytes of unit L/2 (then 16 + L/2), the bits
 // travel once per word through two lane permutes (pattern 5: 4.9-5.7 TB/s). Same bytes at the same addresses.
+// INVARIANT of the cooperative path: all 32 lanes of the aligned half-wavefront are active, converged, and call with the same `off`
+// and `n` (they store for each other). The SHA-256 kernels guarantee it by construction: unit counts that are multiples of 32,
+// lane order (part, block, batch), HZ_BLOCK a multiple of 64, no per-lane branch around a bit store. A half-wavefront that is not
+// whole (a future data-dependent branch, an early return) takes the lane-by-lane path instead of corrupting its neighbours' rows.
+static_assert(HZ_BLOCK % 64 == 0, "put_word_bits: half-wavefront groups need whole wavefronts");
 __device__ __forceinline__ void put_word_bits(const UnitIO& io, uint32_t off, uint64_t v, int n) {
-    if (io.coop32) {
+    const unsigned long long act = __ballot(1);
+    const bool whole = (__lane_id() & 32u) ? (act >> 32) == 0xffffffffull : (act & 0xffffffffull) == 0xffffffffull;
+    if (io.coop32 && whole) {
         const uint32_t lane = __lane_id(), gl = lane & 31u;
         const int src = (int)((lane & 32u) | (gl >> 1));
         uint32_t loA = __shfl((uint32_t)v, src), loB = __shfl((uint32_t)v, src + 16), hiA = 0, hiB = 0;

@@ -43,11 +43,7 @@ __device__ __forceinline__ Fr smt_top_dev(const UnitIO& io, const Scratch& sc, c
 // table -- the level is then bound by its HBM stores instead of 160 k integer instructions. Same bytes, same values.
 // (Writing the block as fully contiguous 1 KB stores -- lane l the 16-byte piece l of the wavefront's 2 KB per signal -- instead
 // of 16 bytes at a 32-byte stride per lane was measured: no difference, L2 combines the halves either way.)
-#ifndef HZ_SMT_ZERO_FAST
-#define HZ_SMT_ZERO_FAST 1
-#endif
 __device__ __forceinline__ Fr poseidon3_zero_level(const UnitIO& io, uint32_t sig0) {
-#if !defined(HZ_EXPERIMENT_NO_ZERO_STORES)   // timing experiment only (wrong witness): what the step costs without these stores
 #pragma unroll 3
     for (int s = 0; s < 243; s++) {
         Fc c;
@@ -55,7 +51,6 @@ __device__ __forceinline__ Fr poseidon3_zero_level(const UnitIO& io, uint32_t si
         for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[s][q];
         store_fr(io.addr(sig0 + s), c);
     }
-#endif
     Fr h;
 #pragma unroll
     for (int i = 0; i < 9; i++) h.v[i] = HZ_POSEIDON3_ZERO_HASH[i];

@@ -15,15 +15,9 @@ namespace hz {
 // HashState x4 + SMTHash1 x4 (reference src/rollup-tx.circom:297-312,517-532 and the hash1Old /
 // hash1New components of circomlib's SMTProcessor). blockIdx.y = j.
 
-#ifndef HZ_HASH4_WAVES
-#define HZ_HASH4_WAVES 2
-#endif
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HASH4_WAVES))) void k_hash4(const Hash4Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K5 = poseidon_consts_w<5>(lds);
-    const Fr* K4 = poseidon_consts_w<4>(lds);
-    __syncthreads();
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_hash4(const Hash4Args a) {
+    const Fr* K5 = poseidon_consts_w<5>();
+    const Fr* K4 = poseidon_consts_w<4>();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
     const uint32_t i = a.u0 + li;
@@ -53,19 +47,15 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_HAS
 // The old-side lane also writes enabled, n2bOld, SMTLevIns; the new-side lane n2bNew, xors, sm.
 
 
-#ifndef HZ_SMT_WAVES
-#define HZ_SMT_WAVES 2
-#endif
-
 // The empty-subtree levels of a proof (smt_dev.h) are pure stores of a constant block; the levels that hash data are pure integer
 // arithmetic. Run one after the other -- or in different kernels: a store-bound grid gets few dispatch slots beside a resident
 // integer-bound one (tools/experiments/overlap_probe.py: fills beside Poseidon keep 10 % of their rate) -- they cost the sum of
 // their times. Inside ONE instruction stream the vector-memory port and the integer pipe do overlap: every S-box of a level that
 // hashes also stores a few signals of an empty level's block (wave-uniform cursor, scalar registers), so the constant blocks leave
-// in the shadow of the arithmetic. HZ_SMT_BG_STORES = 0: every level stores its own block (round-1 behaviour).
-#ifndef HZ_SMT_BG_STORES
-#define HZ_SMT_BG_STORES 1
-#endif
+// in the shadow of the arithmetic. (Round 3 attribution, timing-only builds: the chain without any store 15.7 ms, with the S-box
+// stores 18.1, with these background stores 21.5 -- and 21.5 whether their constants are loaded or not, whether they leave spread
+// after each product or in one burst, at two or three wavefronts per SIMD: tools/microbench/mixbench.hip shows the same
+// max(integer, store) x 1.2 for any kernel that mixes v_mad_u64_u32 and stores at this ratio.)
 struct BgZero {
     uint8_t* base;            // section base
     uint32_t n_units, unit;
@@ -76,29 +66,14 @@ struct BgZero {
     // The constants come through the scalar cache like Poseidon's own (s_load + v_mov). Staging the block in LDS was measured and is
     // slower (k_smt 22.4 -> 27.2 ms): LDS reads share the lgkmcnt counter with the scalar loads that stream the round constants.
     __device__ __forceinline__ void one() {
-#ifndef HZ_EXPERIMENT_NO_BG_EMIT   // timing experiments only (wrong witness): the chain without its background stores / loads
         Fc c;
-#ifdef HZ_EXPERIMENT_BG_NOLOAD
-#pragma unroll
-        for (int q = 0; q < 8; q++) c.v[q] = s + q;
-#else
 #pragma unroll
         for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[s][q];
-#endif
-#ifdef HZ_EXPERIMENT_BG_NOSTORE
-#pragma unroll
-        for (int q = 0; q < 8; q++) asm volatile("" :: "s"(c.v[q]));
-#else
         store_fr(base + ((size_t)(off0 + LV_SIZE * j + s) * n_units + unit) * 32, c);
-#endif
-#endif
         if (++s == 243) { s = 0; j++; }
     }
     __device__ __forceinline__ void emit() {
         for (uint32_t q = 0; q < per && j < j_end; q++) one();
-    }
-    __device__ __forceinline__ void emit3() {   // a third of an S-box's share (the sink is called after each of its three products)
-        for (uint32_t q = 0; 3 * q < per + 2 && j < j_end; q++) one();
     }
     __device__ __forceinline__ void flush() {
         while (j < j_end) one();
@@ -106,16 +81,11 @@ struct BgZero {
 };
 struct SmtSboxSink {
     static constexpr bool kCanon = WitSboxSink::kCanon;
-    static constexpr bool kEarly = WitSboxSink::kEarly;
     WitSboxSink w;
     BgZero* bg;
-    __device__ __forceinline__ void put(int k, int j, const Fr& v) const {
-        w.put(k, j, v);
-        if (HZ_SMT_BG_STORES) bg->emit3();
-    }
     __device__ __forceinline__ void operator()(int k, const Fr& x2, const Fr& x4, const Fr& x5) const {
         w(k, x2, x4, x5);
-        if (HZ_SMT_BG_STORES) bg->emit();
+        bg->emit();
     }
 };
 // max over the wavefront of a small non-negative integer (< 64), as a scalar
@@ -128,21 +98,14 @@ __device__ __forceinline__ uint32_t wave_max_u6(uint32_t v) {
     }
     return r;
 }
-// Register budget: two wavefronts of this kernel per SIMD saturate the integer pipe; what they leave of the 512 registers decides
-// whether a store-bound wavefront of another kernel (the SHA-256 expansion: 72 registers) can sit beside them.
-#ifdef HZ_SMT_VGPRS
-#define HZ_SMT_VGPR_ATTR __attribute__((amdgpu_num_vgpr(HZ_SMT_VGPRS)))
-#else
-#define HZ_SMT_VGPR_ATTR
-#endif
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT_WAVES))) HZ_SMT_VGPR_ATTR void k_smt(const SmtArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K3 = poseidon_consts_w<3>(lds);
-    __syncthreads();
+// Two wavefronts of this kernel per SIMD saturate the integer pipe (three, with the register budget that implies: no faster).
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_smt(const SmtArgs a) {
+    const Fr* K3 = poseidon_consts_w<3>();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
     const uint32_t i = a.u0 + li * (a.ustride > 1 ? a.ustride : 1u);
+    // the units another launch of this step evaluates (the last transaction of every batch: the early HashInputs chain, ctx.hip)
+    if (a.skip_mod && i % a.skip_mod == a.skip_mod - 1) return;
     const uint32_t chain = blockIdx.y, pi = chain >> 1;
     const bool new_side = chain & 1;
     const SmtProcDesc& P = a.p[pi];
@@ -178,10 +141,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
         }
         if (!done) levmask |= 1ull;
     }
-    const bool first = a.k_hi + 1 == a.n_levels;   // the chunk that holds the bottom level also writes the per-processor signals
-    if (!first) {
-        // nothing: bit decompositions, IsZero witnesses and the state machine belong to the first chunk
-    } else if (!new_side) {
+    if (!new_side) {
         if (o.fnc != ~0u) { io.put_m(o.fnc, fnc0); io.put_m(o.fnc + 1, fnc1); }
         io.put_m(o.enabled, enabled);
         num2bits_strict_dev(io, o.n2bOld, oldKey_c, P.cid_alias_old);
@@ -217,7 +177,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
     const Fr O = fr_mul(A2, isOld0);
     const Fr U = fr_sub(enabled, A2);
     const Fr m = fr_sub(A2, O);
-    if (new_side && first) {
+    if (new_side) {
         Fr p_na = fr_sub(one, enabled), p_new1 = zero, p_old0 = zero, p_upd = zero;
         Fr last_sum = zero;
         for (int k = 0; k < n; k++) {
@@ -242,7 +202,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
     // into an empty slot); new side: both switcher inputs vanish above kx (from kl on when m = 0). The siblings above the highest
     // non-zero one are zero by inspection. thr_wave = the first level that is empty for every lane of the wavefront.
     uint32_t thr_wave = (uint32_t)n;
-    if (HZ_SMT_BG_STORES) {
+    {
         const bool m_zero = fr_is_zero(m);
         const uint64_t nz = ~zmask & ((n < 64 ? (1ull << n) : 0ull) - 1ull);
         const int hi_nz = nz ? 63 - __builtin_clzll(nz) : -1;
@@ -253,10 +213,9 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
     }
     // level chain, bottom-up. Both sides run the level hash through ONE inlined copy of the permutation (the kernel's
     // hot code): wavefronts of the old and the new side that share a CU then share its instruction-cache lines.
-    // levels k_hi .. k_lo of the chain; the running root travels between chunks through the scratch slot of the final root
     const int root_slot = new_side ? P.sc_root_new : P.sc_root_old;
-    Fr child = first ? zero : sc.get(root_slot);
-    for (int k = (int)a.k_hi; k >= (int)a.k_lo; k--) {
+    Fr child = zero;
+    for (int k = n - 1; k >= 0; k--) {
         const uint32_t lv = o.levels + LV_SIZE * k;
         const uint32_t sel = c_bit(newKey_c, k);
         const Fr sib = io.in_m(P.siblings + k);
@@ -283,23 +242,23 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SMT
             io.put_m(lv + LV_NEWSW_L, swL); io.put_m(lv + LV_NEWSW_R, swR);
         }
         Fr h;
-        if (HZ_SMT_BG_STORES && thr_wave > 0 && (uint32_t)k >= thr_wave) {
+        if (thr_wave > 0 && (uint32_t)k >= thr_wave) {
             // structurally empty for the whole wavefront: its block is stored by one of the hashing levels (below), only the digest here
 #pragma unroll
             for (int q = 0; q < 9; q++) h.v[q] = HZ_POSEIDON3_ZERO_HASH[q];
         } else {
             // hashing level k (< thr_wave) also stores the blocks of empty levels thr + [k E / H, (k+1) E / H), E = n - thr, H = thr
             BgZero bg{a.base, a.n_units, i, o.levels + (new_side ? LV_NEWHASH : LV_OLDHASH), 0, 0, 0, 0};
-            if (HZ_SMT_BG_STORES && thr_wave > 0) {
+            if (thr_wave > 0) {
                 const uint32_t E = (uint32_t)n - thr_wave;
                 bg.j = thr_wave + (uint32_t)k * E / thr_wave;
                 bg.j_end = thr_wave + ((uint32_t)k + 1) * E / thr_wave;
                 bg.per = ((bg.j_end - bg.j) * 243 + 80) / 81;
             }
             SmtSboxSink sk{io.sbox_sink(lv + (new_side ? LV_NEWHASH : LV_OLDHASH)), &bg};
-            if (HZ_SMT_ZERO_FAST && __all(fr_is_zero(hin[0]) && fr_is_zero(hin[1]))) h = poseidon3_zero_level(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
+            if (__all(fr_is_zero(hin[0]) && fr_is_zero(hin[1]))) h = poseidon3_zero_level(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
             else h = poseidon_hash<3>(hin, K3, sk);
-            if (HZ_SMT_BG_STORES) bg.flush();
+            bg.flush();
         }
         if (!new_side) {
             // st_bot + st_new1 + st_upd ; st_top
@@ -323,29 +282,16 @@ static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
     dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
     g.y = a.n_jobs;
-    hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), poseidon_lds_bytes<5>() + poseidon_lds_bytes<4>(), s, a);
+    hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
-// Round 1 launched the chain in chunks of 11 levels: a lane then spent its first ~18 levels in a pure store phase, the 4096-workgroup
-// grid is twice what the device holds, and as one kernel no workgroup slot turned over for tens of milliseconds -- the other
-// context's kernels waited behind it. With the empty-level blocks stored in the shadow of the hashing levels (BgZero above) the
-// store phase is gone and one launch is as good for the step (46.2 vs 46.1-46.8 ms) and better for the kernel itself (21.4 vs
-// 22.8 ms alone: no per-chunk prologue, no tail of a chunk waiting for its slowest wavefront). HZ_SMT_CHUNK < n_levels brings the
-// chunks back.
-#ifndef HZ_SMT_CHUNK
-#define HZ_SMT_CHUNK 64
-#endif
-int smt_chunk_levels(const SmtArgs& a) {
-    const uint64_t lanes = (uint64_t)((a.ucnt ? a.ucnt : a.n_units) + HZ_BLOCK - 1) / HZ_BLOCK * 2 * a.n_proc;
-    return lanes <= 2048 ? (int)a.n_levels : HZ_SMT_CHUNK;   // a launch the device holds at once (a single batch) is latency bound: one kernel
-}
-hipError_t launch_smt_levels(const SmtArgs& a0, int k_hi, int k_lo, hipStream_t s) {
-    SmtArgs a = a0;
+// One launch for the whole chain (round 1 launched it in chunks of 11 levels so that workgroup slots turned over during its store
+// phase; with the empty-level blocks stored in the shadow of the hashing levels one launch is as good for the step and better for
+// the kernel itself: no per-chunk prologue, no tail of a chunk waiting for its slowest wavefront).
+hipError_t launch_smt(const SmtArgs& a, hipStream_t s) {
     dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
     g.y = 2 * a.n_proc;
-    a.k_hi = (uint32_t)k_hi;
-    a.k_lo = (uint32_t)k_lo;
-    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), poseidon_lds_bytes<3>(), s, a);
+    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

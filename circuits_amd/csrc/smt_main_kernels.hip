@@ -11,10 +11,7 @@
 namespace hz {
 
 __global__ __launch_bounds__(HZ_BLOCK) void k_smtproc_front(const SmtMainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K4 = poseidon_consts_w<4>(lds);
-    __syncthreads();
+    const Fr* K4 = poseidon_consts_w<4>();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
@@ -44,11 +41,8 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smtproc_back(const SmtMainArgs a) 
 // SMTVerifier(n) with arbitrary field inputs: the state machine is evaluated in the field (smtverifiersm.circom), levIns from the
 // zero pattern of the siblings (IsZero outputs are bits).
 __global__ __launch_bounds__(HZ_BLOCK) void k_smtver_main(const SmtMainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K4 = poseidon_consts_w<4>(lds);
-    const Fr* K3 = poseidon_consts_w<3>(lds);
-    __syncthreads();
+    const Fr* K4 = poseidon_consts_w<4>();
+    const Fr* K3 = poseidon_consts_w<3>();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
@@ -144,7 +138,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smtver_main(const SmtMainArgs a) {
 
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 hipError_t launch_smtproc_front(const SmtMainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_smtproc_front, grid1(a.N), dim3(HZ_BLOCK), poseidon_lds_bytes<4>(), s, a);
+    hipLaunchKernelGGL(k_smtproc_front, grid1(a.N), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_smtproc_back(const SmtMainArgs& a, hipStream_t s) {
@@ -152,7 +146,7 @@ hipError_t launch_smtproc_back(const SmtMainArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_smtver_main(const SmtMainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_smtver_main, grid1(a.N), dim3(HZ_BLOCK), poseidon_lds_bytes<4>() + poseidon_lds_bytes<3>(), s, a);
+    hipLaunchKernelGGL(k_smtver_main, grid1(a.N), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

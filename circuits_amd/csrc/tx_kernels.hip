@@ -45,17 +45,11 @@ struct FeeSrcRtx {
 };
 
 
-#ifndef HZ_FRONT_WAVES
-#define HZ_FRONT_WAVES 2
-#endif
 // Two lanes per transaction (blockIdx.y): 0 = RollupMain's boolean checks, DecodeTx and the im* checks on its outputs; 1 = the
 // RollupTx front logic, which takes the few DecodeTx outputs it consumes straight from the input bits (decode_fields_dev). The halves
 // share no signal; a single batch has 32 wavefronts per half and the kernel is the head of both of its critical paths.
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_main_front(const MainFrontArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K7 = poseidon_consts_w<7>(lds);
-    __syncthreads();
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_main_front(const MainFrontArgs a) {
+    const Fr* K7 = poseidon_consts_w<7>();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_units = a.B * a.nTx;
     if (li >= (a.ucnt ? a.ucnt : n_units)) return;
@@ -116,7 +110,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRO
 }
 
 
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_rtx_front(const RtxFrontArgs a) {
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_rtx_front(const RtxFrontArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
@@ -134,11 +128,8 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRO
     io.put_m(r.o_isAmountNullified, fo.isAmountNullified);
 }
 
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_dec_main(const DecMainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
-    uint32_t* lds = lds_raw;
-    const Fr* K7 = poseidon_consts_w<7>(lds);
-    __syncthreads();
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_dec_main(const DecMainArgs a) {
+    const Fr* K7 = poseidon_consts_w<7>();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
@@ -151,6 +142,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
     const uint32_t u = a.u0 + li * (a.ustride > 1 ? a.ustride : 1u);
+    if (a.skip_mod && u % a.skip_mod == a.skip_mod - 1) return;   // evaluated by the early-tail launch of this step (ctx.hip)
     const uint32_t b = u / a.upi, i = u % a.upi;
     const UnitIO io{a.base, a.n_units, u, b, i, a.err};
     const Scratch sc{a.scratch, a.n_units, u};
@@ -169,7 +161,8 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
         } else {
             io.chk(C_MAIN_IM_INITFEEROOT, newStateRoot, fr_from_canon(load_fr(a.glob_base + ((size_t)a.g_initfeeroot * a.B + b) * 32)));
         }
-        // H (:456-459): amountF bits of L1L2TxData times (1 - isAmountNullified)
+        // H (:456-459): amountF bits of L1L2TxData times (1 - isAmountNullified) -- unless k_da_mask has it this step
+        if (a.skip_h) return;
         const Fc keep_c = fr_to_canon(fr_sub(fr_one(), sc.get(SC_ISAMTNULL)));
         for (int j = 0; j < 40; j++) {
             // L1L2TxData[2L + 40 - 1 - k] = n2bAmount.out[k]
@@ -203,7 +196,7 @@ static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
     dim3 g = grid1(a.ucnt ? a.ucnt : a.B * a.nTx);
     g.y = 2;   // DecodeTx lane, RollupTx-front lane
-    hipLaunchKernelGGL(k_main_front, g, dim3(HZ_BLOCK), poseidon_lds_bytes<7>(), s, a);
+    hipLaunchKernelGGL(k_main_front, g, dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
@@ -211,7 +204,7 @@ hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_main, grid1(a.N), dim3(HZ_BLOCK), poseidon_lds_bytes<7>(), s, a);
+    hipLaunchKernelGGL(k_dec_main, grid1(a.N), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s) {

@@ -569,6 +569,94 @@ static napi_value PoseidonBatch(napi_env env, napi_callback_info info) {
     return o;
 }
 
+// step(handle, bytes | null, byteOffset, first, count, stride) -> Promise<null | failure record of the PREVIOUS step>
+// One iteration of a serving loop as ONE work item on the libuv pool: wait for and check the step enqueued before (if any), enqueue
+// the next one (which scatters the inputs staged for it), stage the inputs of the one after (asynchronous H2D beside the kernels).
+// A context driven this way never bounces between the JS thread and the pool inside an iteration, and two contexts are two
+// independent promise chains on two pool threads (tests/node/bench_facade.js).
+struct StepWork {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref keep;          // the staged ArrayBuffer stays alive until the copy has been issued
+    hz_ctx* ctx;
+    uint8_t* data;
+    size_t each, stride;
+    int32_t first, count;
+    bool had_prev;
+    hz_status st;
+    hz_error err;
+    std::string msg;
+};
+static void step_execute(napi_env, void* data) {
+    StepWork* w = (StepWork*)data;
+    memset(&w->err, 0, sizeof w->err);
+    w->st = HZ_OK;
+    if (w->had_prev) {
+        w->st = api.witness_check(w->ctx, &w->err);
+        if (w->st != HZ_OK && w->st != HZ_ERR_CONSTRAINT) { w->msg = api.last_error(); return; }
+    }
+    hz_status e = api.witness_enqueue(w->ctx, nullptr);
+    if (e == HZ_OK && w->data && w->count > 0) e = api.inputs_stage_range(w->ctx, w->first, w->count, w->data, w->each, w->stride, nullptr);
+    if (e != HZ_OK) { w->st = e; w->msg = api.last_error(); }
+}
+static void step_complete(napi_env env, napi_status, void* data) {
+    StepWork* w = (StepWork*)data;
+    napi_value result;
+    if (w->st == HZ_OK) {
+        napi_get_null(env, &result);
+        napi_resolve_deferred(env, w->deferred, result);
+    } else if (w->st == HZ_ERR_CONSTRAINT) {
+        napi_create_object(env, &result);
+        napi_value v;
+        napi_create_int32(env, w->err.instance, &v); napi_set_named_property(env, result, "instance", v);
+        napi_create_int32(env, w->err.unit, &v); napi_set_named_property(env, result, "unit", v);
+        napi_create_int32(env, w->err.constraint_id, &v); napi_set_named_property(env, result, "constraintId", v);
+        napi_create_string_utf8(env, api.constraint_name(w->err.constraint_id), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, result, "constraintName", v);
+        void* p;
+        napi_create_buffer_copy(env, 32, w->err.lhs, &p, &v); napi_set_named_property(env, result, "lhs", v);
+        napi_create_buffer_copy(env, 32, w->err.rhs, &p, &v); napi_set_named_property(env, result, "rhs", v);
+        napi_resolve_deferred(env, w->deferred, result);
+    } else {
+        napi_value msg, e;
+        napi_create_string_utf8(env, w->msg.c_str(), NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &e);
+        napi_reject_deferred(env, w->deferred, e);
+    }
+    if (w->keep) napi_delete_reference(env, w->keep);
+    napi_delete_async_work(env, w->work);
+    delete w;
+}
+static napi_value Step(napi_env env, napi_callback_info info) {
+    napi_value argv[7];
+    if (!get_args(env, info, 7, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    StepWork* w = new StepWork();
+    w->ctx = c; w->keep = nullptr; w->data = nullptr; w->count = 0; w->first = 0;
+    w->each = (size_t)api.inputs_packed_bytes(c);
+    napi_valuetype t = napi_undefined;
+    napi_typeof(env, argv[1], &t);
+    if (t == napi_object) {
+        uint8_t* data; size_t len;
+        if (!get_bytes(env, argv[1], &data, &len)) { delete w; return nullptr; }
+        const size_t off = (size_t)num(env, argv[2]);
+        w->first = (int32_t)num(env, argv[3]); w->count = (int32_t)num(env, argv[4]);
+        w->stride = (size_t)num(env, argv[5], (double)w->each);
+        if (w->count < 0 || off + (w->count ? (size_t)(w->count - 1) * w->stride + w->each : 0) > len) { delete w; napi_throw_error(env, nullptr, "step: buffer too small"); return nullptr; }
+        w->data = data + off;
+        napi_create_reference(env, argv[1], 1, &w->keep);
+    }
+    bool prev = false;
+    napi_get_value_bool(env, argv[6], &prev);
+    w->had_prev = prev;
+    napi_value promise, name;
+    NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
+    NAPI_OK(napi_create_string_utf8(env, "hz_step", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(napi_create_async_work(env, nullptr, name, step_execute, step_complete, w, &w->work));
+    NAPI_OK(napi_queue_async_work(env, w->work));
+    return promise;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
     const struct { const char* name; napi_callback fn; } fns[] = {
         {"create", Create}, {"setInput", SetInput}, {"clearInputs", ClearInputs}, {"run", Run}, {"witnessLen", WitnessLen},
@@ -576,7 +664,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"symbolCount", SymbolCount}, {"symbolGet", SymbolGet}, {"deviceCount", DeviceCount}, {"version", Version},
         {"packedLayout", PackedLayout}, {"hostAlloc", HostAlloc}, {"upload", Upload}, {"stageRange", StageRange}, {"enqueue", Enqueue},
         {"check", Check}, {"devPtr", DevPtr}, {"witnessTotal", WitnessTotal}, {"readRaw", ReadRaw}, {"setInputsJson", SetInputsJson},
-        {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}};
+        {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}, {"step", Step}};
     for (const auto& f : fns) {
         napi_value fn;
         napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn);

@@ -197,9 +197,19 @@ class Circuit {
     upload(instance, buf, byteOffset) { addon.upload(this.handle, instance, buf, byteOffset || 0); }
     stageRange(first, count, buf, byteOffset, stride) { addon.stageRange(this.handle, first, count, buf, byteOffset || 0, stride || this.packedLayout().bytes); }
     /** the kernels of one step, asynchronous; check() resolves when they are done and rejects on the first violated constraint */
-    enqueue() { addon.enqueue(this.handle); }
+    enqueue() { this._inFlight = true; addon.enqueue(this.handle); }
     async check(sanityCheck) {
+        this._inFlight = false;
         const fail = await addon.check(this.handle);
+        if (fail && wantsSanityCheck(sanityCheck)) throw constraintError(fail);
+    }
+    /** One iteration of a serving loop in one hop to the thread pool: check the previous step of this circuit (if one is in flight),
+     *  enqueue the next, stage the inputs of the one after from `buf` (omit buf: nothing staged). Resolves when the enqueue has
+     *  been issued; rejects if the PREVIOUS step violated a constraint. Finish a loop with check(). */
+    async step(buf, byteOffset, first, count, stride, sanityCheck) {
+        const hadPrev = !!this._inFlight;
+        this._inFlight = true;
+        const fail = await addon.step(this.handle, buf || null, byteOffset || 0, first | 0, buf ? count | 0 : 0, stride || this.packedLayout().bytes, hadPrev);
         if (fail && wantsSanityCheck(sanityCheck)) throw constraintError(fail);
     }
     devPtr() { return addon.devPtr(this.handle); }

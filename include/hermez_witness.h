@@ -262,6 +262,20 @@ uint64_t hz_da_record_bytes(const hz_ctx* ctx);
 hz_status hz_da_export(hz_ctx* ctx, void* d_buf, void* stream);
 hz_status hz_da_import(hz_ctx* ctx, int32_t first, int32_t count, const void* d_buf, void* stream);
 hz_status hz_witness_enqueue_tail(hz_ctx* ctx, void* stream);
+/* The tail split over the ranks (SURVEY 8e "or scatter blocks back: 766 / 8"): the SHA-256 chain of HashInputs is sequential (rank 0),
+ * the bit-level witness of its blocks -- 0.73 GB of the 0.76 GB the tail writes at (2048, 32) -- is independent per block given the
+ * message block and the chaining value that enters it:
+ *   hz_witness_enqueue_tail_chain   rank 0, after the imports: FeeTx, the message, the chain, the public output; no block witness
+ *   hz_sha_blocks / hz_sha_state_bytes   number of blocks; bytes of (message blocks, chaining values): 96 B per block + 32
+ *   hz_sha_export                   rank 0: that state into a device buffer (ONE broadcast, 73 KB at 766 blocks)
+ *   hz_sha_expand                   any rank: take the state from the buffer (NULL on the rank that computed it) and write the
+ *                                   witness of blocks [first, first + count) into this context's HashInputs section
+ * Block ranges: hz_shard_range(hz_sha_blocks(ctx), world, rank, ...). The witness stays sharded: rank r holds its blocks' signals. */
+hz_status hz_witness_enqueue_tail_chain(hz_ctx* ctx, void* stream);
+uint64_t hz_sha_blocks(const hz_ctx* ctx);
+uint64_t hz_sha_state_bytes(const hz_ctx* ctx);
+hz_status hz_sha_export(hz_ctx* ctx, void* d_buf, void* stream);
+hz_status hz_sha_expand(hz_ctx* ctx, int32_t first, int32_t count, const void* d_buf, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,16 +34,18 @@ async function main() {
             }
         }
     }
+    // every context is its own chain of step() calls (check previous -> enqueue -> stage next, one work item on the libuv pool each):
+    // the contexts in flight advance independently, the JS thread only chains promises
     const run = async (n) => {
-        const pending = new Array(inflight).fill(null);
-        for (let i = 0; i < n; i++) {
-            const k = i % inflight;
-            if (pending[k]) await pending[k];
-            ctxs[k].enqueue();        // scatters what was staged for this step, then the kernels
-            stage(k);                 // the NEXT step's inputs cross PCIe beside this step's kernels
-            pending[k] = ctxs[k].check(true);
+        const chains = [];
+        for (let k = 0; k < inflight; k++) {
+            const mine = Math.floor(n / inflight) + (k < n % inflight ? 1 : 0);
+            chains.push((async () => {
+                for (let i = 0; i < mine; i++) await ctxs[k].step(pin, k * B * each, 0, B, each, true);
+                if (mine) await ctxs[k].check(true);
+            })());
         }
-        await Promise.all(pending.filter((p) => p));
+        await Promise.all(chains);
     };
     for (let k = 0; k < inflight; k++) stage(k);
     await run(Math.max(inflight, warmup));

@@ -115,6 +115,12 @@ async function main() {
         const rd = circuit.reader();
         many.forEach((b, k) => assert.strictEqual(rd.get(k, "main.hashGlobalInputs").toString(), many[many.length - 1 - k].hashGlobalInputs));
         assert.ok(circuit.devPtr() > 0n);
+        // the serving-loop form: step() = check the previous step, enqueue, stage the next inputs, in one hop to the pool
+        many.forEach((b, k) => circuit.packInput(b.input, pin, k * lay.bytes));
+        await circuit.step(pin, 0, 0, many.length, lay.bytes, true);   // enqueues on the reversed inputs, stages the straight ones
+        await circuit.step(null, 0, 0, 0, 0, true);                    // checks that step, enqueues on the straight inputs
+        await circuit.check(true);
+        many.forEach((b, k) => assert.strictEqual(circuit.reader().get(k, "main.hashGlobalInputs").toString(), b.hashGlobalInputs));
         assert.ok(circuit.witnessTotal() > circuit.nVars);
         // a tampered batch among the staged ones rejects with the instance in the record
         const bad = JSON.parse(JSON.stringify(many[1].input));

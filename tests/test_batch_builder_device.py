@@ -131,6 +131,51 @@ def test_dag_built_inputs_are_accepted_by_the_oracle():
     _oracle_accepts(lazy, shape)
 
 
+def _dict_tree_batch(base, bb, shape):
+    """the same transactions on a dictionary tree that holds the base's accounts inserted one by one"""
+    db = B.RollupDB(chain_id=1)
+    for idx in range(base.first_idx, base.first_idx + base.N):
+        db.last_idx = idx
+        st = base.state(idx)
+        db.state.insert(idx, db.hash_state(st))
+        db.leaves[idx] = st
+    b2 = db.build_batch(*shape)
+    for t in bb.txs:
+        b2.add_tx({k: v for k, v in t.items() if k not in ("amountF", "rqTxCompressedDataV2")})
+    b2.add_token(1)
+    b2.add_fee_idx(bb.fee_idxs[0])
+    return b2.build()
+
+
+def _check_dense_state(base):
+    """DenseState (the pre-populated tree of 2^k accounts held as per-level arrays, bench.py's deep_state) against the dictionary
+    tree: same root, same proofs, and batches built on it have byte-identical inputs -- which the ORACLE's RollupMain accepts."""
+    smt = B.SMT()
+    for idx in range(base.first_idx, base.first_idx + base.N):
+        smt.insert(idx, B.hash_state(base.state(idx)))
+    assert smt.root == base.root
+    via_base = B.SMT(base=base)
+    for idx in (base.first_idx, base.first_idx + 1, base.first_idx + base.N - 1, base.first_idx + base.N, 3):
+        assert smt.find(idx) == via_base.find(idx), idx
+    shape = (16, 16, 4, 4)
+    for seed in (5, 6):
+        bb = B.synthetic_batch(*shape, seed=seed, exits=2, base=base)
+        ref = _dict_tree_batch(base, bb, shape)
+        assert ref.get_input() == bb.get_input() and ref.get_hash_inputs() == bb.get_hash_inputs()
+        _oracle_accepts(bb, shape)
+
+
+def test_dense_state_matches_the_dictionary_tree(tmp_path):
+    base = B.DenseState.build(7, seed=77)
+    _check_dense_state(base)
+    base.save(str(tmp_path / "base.npz"))
+    again = B.DenseState.load(str(tmp_path / "base.npz"))
+    assert again.root == base.root and again.state(300) == base.state(300)
+    # new accounts that fall into an occupied residue class push a base leaf below depth k: still found
+    bb = B.synthetic_batch(40, 16, 32, 2, seed=9, base=again)
+    _oracle_accepts(bb, (40, 16, 32, 2))
+
+
 def test_dag_levels_do_not_grow_with_the_number_of_transactions():
     segs = []
     for n in (16, 64):
@@ -156,6 +201,25 @@ def test_hip_dag_builder_matches_eager_builder_on_the_synthetic_batch(hz):
 @pytest.mark.gpu
 def test_hip_dag_builder_matches_eager_builder_on_every_scenario(hz, monkeypatch):
     _check_scenarios(monkeypatch, device=0)
+
+
+@pytest.mark.gpu
+def test_hip_dense_state_built_on_the_device(hz):
+    """the per-level batched hashing of DenseState.build through hz_poseidon_batch: same tree as the host-hashed one, at 2^7 accounts
+    (full check against the dictionary tree) and the same root at 2^12"""
+    dev = lambda t, n, data: hz.poseidon_batch_bytes(t, n, data)   # noqa: E731
+    base = B.DenseState.build(7, seed=77, hash_rows=dev)
+    assert base.root == B.DenseState.build(7, seed=77).root
+    _check_dense_state(base)
+    big = B.DenseState.build(12, seed=3, hash_rows=dev)
+    smt = B.SMT()
+    for idx in range(big.first_idx, big.first_idx + big.N, 97):   # a sample of the proofs against the oracle's verifier
+        f = B.SMT(base=big).find(idx)
+        assert f["found"] and f["foundValue"] == B.hash_state(big.state(idx))
+    from oracle_binding import OracleCtx
+    bb = B.synthetic_batch(32, 16, 4, 4, seed=11, exits=1, base=big)
+    _oracle_accepts(bb, (32, 16, 4, 4))
+    del smt
 
 
 @pytest.mark.gpu

@@ -80,6 +80,24 @@ def _worker(rank, world, port, n_tx, out):
         def enqueue_tail(self, stream=None):
             self.log.append("tail")
 
+        def enqueue_tail_chain(self, stream=None):
+            self.log.append("tail_chain")
+
+        def sha_blocks(self):
+            return 11
+
+        def sha_state_bytes(self):
+            return 11 * 64 + 12 * 32
+
+        def sha_export(self, ptr, stream=None):
+            self.log.append("sha_export")
+            self.sha.t[:] = 7   # recognisable state
+
+        def sha_expand(self, first, count, ptr, stream=None):
+            assert (ptr is None) == (rank == 0)
+            assert int(self.sha.t[0]) == 7 and int(self.sha.t[-1]) == 7   # the broadcast arrived before the expansion
+            self.log.append(("sha_expand", first, count))
+
         def check(self):
             self.log.append("check")
 
@@ -96,14 +114,19 @@ def _worker(rank, world, port, n_tx, out):
         dist.all_gather(parts, send.t)
         recv.t.copy_(torch.cat(parts))
 
-    sb = ShardedBatch(ctx, lib(), n_tx, rank, world, alloc, all_gather)
-    ctx.send, ctx.recv = sb.send, sb.recv
+    def broadcast(buf):
+        dist.broadcast(buf.t, src=0)
+
+    sb = ShardedBatch(ctx, lib(), n_tx, rank, world, alloc, all_gather, broadcast)
+    ctx.send, ctx.recv, ctx.sha = sb.send, sb.recv, sb.sha
     sb.step(1)   # the fake context ignores the stream handle
     ok = ctx.log[0] == "enqueue" and ctx.log[1] == "export" and ctx.log[-1] == "check"
+    # the SHA-256 blocks are split over the ranks: 11 blocks -> 6 + 5
+    ok = ok and ctx.log[-2] == ("sha_expand", 0, 6) if rank == 0 else ok and ctx.log[-2] == ("sha_expand", 6, 5)
     if rank == 0:
-        ok = ok and ctx.log[-2] == "tail" and len(ctx.imported) == n_tx - sb.count and ctx.tail
+        ok = ok and ctx.log[-4:-2] == ["tail_chain", "sha_export"] and "tail" not in ctx.log and len(ctx.imported) == n_tx - sb.count and ctx.tail
     else:
-        ok = ok and "tail" not in ctx.log and not ctx.tail
+        ok = ok and "tail" not in ctx.log and "tail_chain" not in ctx.log and not ctx.tail
     res = torch.tensor([1 if ok else 0])
     dist.all_reduce(res, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -171,6 +194,96 @@ def test_sharded_batch_on_one_gpu_matches_oracle(hz):
     # fee-tx and hash-inputs sections on rank 0
     fee0 = ctxs[0].lookup("main.feeTx[0].feeIdxIsZero.inv")
     assert gb[0][32 * fee0:] == ob[32 * fee0:]
+
+
+@pytest.mark.gpu
+def test_sharded_batch_split_sha_tail_matches_oracle(hz):
+    """The tail split over the ranks (SURVEY 8e "scatter blocks back"): rank 0 runs FeeTx, the message and the sequential SHA-256
+    chain, its (message, chaining values) reach the other rank through the broadcast, and each rank writes the bit-level witness of
+    its own range of blocks. Two contexts stand in for two ranks; rank 0's public output is the builder's, and every byte of the
+    HashInputs section matches the oracle on the rank that owns it -- the blocks a rank does not own it must not have written."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleCtx
+    from circuits_amd import builder as B
+    from circuits_amd.multigpu import ShardedBatch
+    shape = (24, 16, 6, 4)
+    n_tx = shape[0]
+    bb = B.synthetic_batch(*shape, n_accounts=10, exits=2, seed=31)
+    inp = bb.get_input()
+    world = 2
+    ctxs = [hz.ctx("rollup-main", nTx=n_tx, nLevels=16, maxL1Tx=6, maxFeeTx=4) for _ in range(world)]
+    for c in ctxs:
+        c.set_inputs(inp)
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    mailbox, shabox = {}, {}
+
+    def alloc(n):
+        return torch.zeros(n, dtype=torch.uint8, device="cuda")
+
+    sbs = []
+    for r in range(world):
+        def all_gather(recv, send, r=r):
+            with torch.cuda.stream(streams[r]):
+                mailbox[r] = send.clone()
+                if r == 0:
+                    streams[0].wait_stream(streams[1])
+                    recv.copy_(torch.cat([mailbox[k] for k in range(world)]))
+
+        def broadcast(buf, r=r):
+            with torch.cuda.stream(streams[r]):
+                if r == 0:
+                    shabox[0] = buf.clone()
+                else:
+                    streams[r].wait_stream(streams[0])
+                    buf.copy_(shabox[0])
+        sbs.append(ShardedBatch(ctxs[r], hz, n_tx, r, world, alloc, all_gather, broadcast))
+    # single-process stand-in: rank 1's first half (its transactions, its export), then rank 0's whole step, then rank 1's expansion
+    c1, s1 = ctxs[1], streams[1].cuda_stream
+    c1.enqueue(s1)
+    c1.da_export(sbs[1].send.data_ptr(), s1)
+    sbs[1].all_gather(sbs[1].recv, sbs[1].send)
+    sbs[0].step(streams[0].cuda_stream)
+    sbs[1].broadcast(sbs[1].sha)
+    c1.sha_expand(sbs[1].blocks[0], sbs[1].blocks[1], sbs[1].sha.data_ptr(), s1)
+    c1.check()
+    assert ctxs[0].get("main.hashGlobalInputs") == bb.get_hash_inputs()
+    o = OracleCtx("rollup-main", *shape)
+    o.set_inputs(inp)
+    assert o.run() is None
+    ob = o.read_raw_bytes()
+    gb = [c.read_raw_bytes() for c in ctxs]
+    nb = ctxs[0].sha_blocks()
+    assert sbs[0].blocks[1] + sbs[1].blocks[1] == nb and sbs[1].blocks[0] == sbs[0].blocks[1] and nb >= 8
+    # block b's witness = sha256compression[b * per_block .. (b + 1) * per_block) (one flat array in the symbol table)
+    names = [n for n in o.symbol_names() if ".inputsHasher.sha256compression[" in n]
+    first = o.lookup("main.hasherInputs.inputsHasher.sha256compression[0]")
+    assert len(names) % nb == 0
+    per_block = len(names) // nb
+    for blk in range(nb):
+        owner = 0 if blk < sbs[0].blocks[1] else 1
+        lo_i, hi_i = first + blk * per_block, first + (blk + 1) * per_block
+        assert gb[owner][32 * lo_i:32 * hi_i] == ob[32 * lo_i:32 * hi_i], (blk, owner)
+        assert gb[1 - owner][32 * lo_i:32 * hi_i] != ob[32 * lo_i:32 * hi_i], "block %d also written by rank %d" % (blk, 1 - owner)
+
+
+@pytest.mark.gpu
+def test_bench_sharded_pass_through_rccl_on_one_gpu(hz):
+    """the RCCL calls of the sharded pass -- all_gather_into_tensor and broadcast enqueued on the pass's own
+    stream between the export / import / expansion kernels -- executed for real: a process group of backend nccl with world size 1
+    (HZ_BENCH_FORCE_COLLECTIVE=1). The pass must reproduce the builder's hashGlobalInputs (bench.py asserts it)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HZ_BENCH_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HZ_BENCH_BACKEND", "HZ_BENCH_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--shard-tx", "--nTx", "40", "--nLevels", "16", "--maxL1Tx", "8", "--maxFeeTx", "4",
+           "--steps", "4", "--warmup", "1", "--cpu-sample", "0", "--build-workers", "1"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["value"] > 0
+    assert "nccl" in line["config"]["collective"] and "broadcast" in line["config"]["collective"]
 
 
 @pytest.mark.gpu

@@ -125,17 +125,12 @@ def test_canonical_sbox_form_matches_the_montgomery_form(tmp_path):
     assert r.stdout.count("mismatches=0") == 6
 
 
-def test_inversion_forms_agree_on_the_host(tmp_path):
-    """fr.h has two division-step routines behind fr_inv: one step at a time (half-delta rule) and several per iteration (plain
-    delta rule, HZ_INV_VAR = 1, the default). Host build of both: a * inv(a) = 1 on 20 000 operands (random, powers of two, p - 1),
-    inv(0) = 0, and the same canonical inverses (checksum)."""
+def test_inversion_on_the_host(tmp_path):
+    """fr_inv (division steps, several per iteration) over the product header on the host: a * inv(a) = 1 on 20 000 operands (random,
+    powers of two, p - 1), inv(0) = 0, and the Fermat inverse gives the same canonical value."""
     import subprocess
     src = os.path.join(os.path.dirname(__file__), "native", "inv_check.cpp")
-    outs = []
-    for v in (0, 1):
-        exe = str(tmp_path / ("inv_check_%d" % v))
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-DHZ_INV_VAR=%d" % v, src, "-o", exe])
-        r = subprocess.run([exe], capture_output=True, text=True)
-        assert r.returncode == 0 and "mismatches=0" in r.stdout, r.stdout + r.stderr
-        outs.append(r.stdout.split("checksum=")[1].strip())
-    assert outs[0] == outs[1]
+    exe = str(tmp_path / "inv_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "mismatches=0" in r.stdout, r.stdout + r.stderr

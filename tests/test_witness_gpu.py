@@ -221,6 +221,42 @@ def test_constraint_failures_match_oracle(hz, batch):
         assert (e.value.instance, e.value.unit, e.value.constraint_id, e.value.lhs, e.value.rhs) == (r[0], r[1], r[2], r[4], r[5])
 
 
+def test_failure_in_the_last_transaction_of_a_batch(hz):
+    """The last transaction of every batch is evaluated by the early HashInputs chain's own launches (ctx.hip early tail), the main
+    stream's chain leaves it out: a constraint that fails there is reported once, with the oracle's operands, for the right batch --
+    and the whole witness is still the oracle's (nothing is written twice, nothing is left unwritten)."""
+    from circuits_amd import builder as B
+    from circuits_amd import ConstraintError
+    shape = (8, 16, 3, 4)
+    bbs = [B.synthetic_batch(*shape, n_accounts=6 + k, exits=1, seed=500 + k) for k in range(3)]
+    g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4, n_instances=3)
+    o = OracleCtx("rollup-main", *shape, n_instances=3)
+    for k, bb in enumerate(bbs):
+        g.set_inputs(bb.get_input(), instance=k)
+        o.set_inputs(bb.get_input(), instance=k)
+    g.run()
+    assert o.run() is None
+    _compare(g, o)
+    last = shape[0] - 1
+    for field in ("siblings1", "ay1", "balance2"):
+        bad = dict(bbs[1].get_input())
+        bad[field] = [list(x) if isinstance(x, list) else x for x in bad[field]]
+        if isinstance(bad[field][last], list):
+            bad[field][last][0] = (bad[field][last][0] + 1) % P
+        else:
+            bad[field][last] = (bad[field][last] + 1) % P
+        g.set_inputs(bad, instance=1)
+        o.set_inputs(bad, instance=1)
+        r = o.run()
+        assert r is not None and r[0] == 1 and r[1] == last, r
+        with pytest.raises(ConstraintError) as e:
+            g.run()
+        assert (e.value.instance, e.value.unit, e.value.constraint_id, e.value.lhs, e.value.rhs) == (r[0], r[1], r[2], r[4], r[5])
+        _compare(g, o)   # a failing witness is still complete and identical
+    g.set_inputs(bbs[1].get_input(), instance=1)
+    g.run()
+
+
 def test_input_errors(hz, batch):
     from circuits_amd import HzError
     g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4)
