@@ -149,6 +149,36 @@ def measured_traffic(kernel, bpl):
         return None
 
 
+def host_limits():
+    """(CPUs this process may really use, bytes of memory it may still take): the cgroup's quota when there is one -- a container
+    that shows 256 logical CPUs and 3 TB can be held to 16 CPUs' worth of time and 300 GiB (the GPU boxes of this project are)."""
+    cpus = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cpus = max(1, min(cpus, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        cpus = min(cpus, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        mem = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+    except (OSError, IndexError):
+        mem = 32 << 30
+    try:
+        mx = open("/sys/fs/cgroup/memory.max").read().strip()
+        if mx != "max":
+            mem = min(mem, int(mx) - int(open("/sys/fs/cgroup/memory.current").read()))
+    except (OSError, ValueError):
+        try:
+            mem = min(mem, int(open("/sys/fs/cgroup/memory/memory.limit_in_bytes").read()) - int(open("/sys/fs/cgroup/memory/memory.usage_in_bytes").read()))
+        except (OSError, ValueError):
+            pass
+    return cpus, max(mem, 1 << 30)
+
+
 def cpu_baseline(n_tx, L, max_l1, F, workers):
     """The CPU oracle (restated CPU path, kind "port") on a bounded sample of the same workload: `workers` processes, one batch
     of `n_tx` transactions each, started together (tests/cpu_baseline_worker.py); value = all their transactions / the slowest run."""
@@ -164,8 +194,9 @@ def cpu_baseline(n_tx, L, max_l1, F, workers):
     dt = max(times) + late   # a late starter only makes the denominator larger
     return {"value": round(workers * n_tx / dt, 2), "unit": "tx-witnesses/s", "cores": workers, "kind": "port",
             "per_core": round(n_tx / (sum(times) / len(times)), 2),
-            "sample": "RollupMain(nTx=%d,nLevels=%d,maxL1Tx=%d,maxFeeTx=%d): %d processes x one batch, %.1f s, host has %d logical CPUs"
-                      % (n_tx, L, max_l1, F, workers, dt, os.cpu_count() or 0)}
+            "sample": "RollupMain(nTx=%d,nLevels=%d,maxL1Tx=%d,maxFeeTx=%d): %d processes x one batch, %.1f s; the host shows %d logical CPUs, "
+                      "this process may use %d (cgroup quota / affinity) and %.0f GB of memory"
+                      % (n_tx, L, max_l1, F, workers, dt, os.cpu_count() or 0, host_limits()[0], host_limits()[1] / 1e9)}
 
 
 def node_host_line(args, packed_file, expected, Bp, inflight):
@@ -354,7 +385,7 @@ def main():
     ap.add_argument("--maxFeeTx", type=int, default=64)
     ap.add_argument("--accounts", type=int, default=0, help="accounts in the synthetic state before the batch (default 4 * nTx, the reference recipe)")
     ap.add_argument("--inflight", type=int, default=2, help="contexts in flight (each with its own witness buffers and streams): the fee/SHA tail of one step overlaps the next step's kernels")
-    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = every logical CPU the host's free memory allows: a RollupMain(2048, 32, ..) oracle holds a 3.9 GB witness)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = every CPU this process may use -- cgroup quota, affinity -- as far as a third of its memory allows: a RollupMain(2048, 32, ..) oracle holds a 3.9 GB witness)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="nTx of the CPU-baseline sample (0 = skip; default: the headline shape, one batch per process)")
     ap.add_argument("--no-deep-state", action="store_true", help="skip the deep_state line (the same step on a state of 2^20 accounts)")
     ap.add_argument("--deep-accounts-log2", type=int, default=20)
@@ -433,7 +464,8 @@ def main():
     seeds = [] if args.shard_tx else [SEED + 1 + 1000 * rank + i for i in range(n_distinct)]
     # the ranks of one node build their batches at the same time: each takes its share of the host cores
     n_build = len(seeds) + (1 if want_shard else 0)
-    build_workers = args.build_workers or max(1, min(n_build, 64, ((os.cpu_count() or 2) - 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
+    build_workers = args.build_workers or max(1, min(n_build, 64, ((os.cpu_count() or 2) - 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))),
+                                                   int(host_limits()[1] // 4 // (3 << 30)) or 1))
     batches = build_packed_batches(seeds + ([SEED] if want_shard else []), nTx, lv, m1, F, n_acc, layout, build_workers)
     t_build = time.time() - t_build
     shared = batches.pop() if want_shard else None
@@ -714,13 +746,10 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             n_cpu = min(args.cpu_sample, nTx)
             workers = args.cpu_workers
-            if workers <= 0:   # all logical CPUs, as far as memory goes (oracle witness + the Python builder per process)
+            if workers <= 0:   # every CPU this process may use, as far as a third of its memory goes (oracle witness + builder per process)
                 per_proc = 32 * 60000 * n_cpu * 1.15 + (1 << 30)
-                try:
-                    avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
-                except (OSError, IndexError):
-                    avail = 64 << 30
-                workers = max(1, min(os.cpu_count() or 1, int(avail * 0.6 // per_proc)))
+                cpus, mem = host_limits()
+                workers = max(1, min(cpus, int(mem // 3 // per_proc)))
             out["cpu_baseline"] = cpu_baseline(n_cpu, lv, min(m1, max(1, n_cpu // 8)), F, workers)
         print(json.dumps(out))
     D.close()

@@ -37,9 +37,15 @@ template <int T>
 __device__ __forceinline__ const Fr* poseidon_consts_w() { return poseidon_consts<T, true>(); }
 
 // ---- 32-byte element I/O (canonical form) ------------------------------------------------------
+// Witness elements always live in device memory: the pointer is cast to the global address space explicitly, so that the access is a
+// global_load / global_store even where the pointer reached the code through a by-reference argument of an out-of-line function
+// (a generic pointer compiles to flat_*: same memory, but flat operations also count against lgkmcnt, the counter LDS reads and
+// the scalar constant loads wait on).
+typedef uint32_t hz_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) hz_u32x4 hz_g_u32x4;
 __device__ __forceinline__ Fc load_fr(const void* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    const uint4 a = q[0], b = q[1];
+    const hz_g_u32x4* q = (const hz_g_u32x4*)p;
+    const hz_u32x4 a = q[0], b = q[1];
     Fc r;
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
     r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
@@ -49,9 +55,10 @@ __device__ __forceinline__ Fc load_fr(const void* p) {
 // are much SLOWER (k_smt 24 -> 37 ms, withdraw 1.90 -> 0.78 M/s; tools/microbench/mixbench.hip: 1.9 TB/s whatever the mix): a lane
 // writes 32 bytes, the wavefront's 2 KB per signal are combined in L2, which streaming stores bypass.
 __device__ __forceinline__ void store_fr(void* p, const Fc& r) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+    hz_g_u32x4* q = (hz_g_u32x4*)p;
+    const hz_u32x4 a = {r.v[0], r.v[1], r.v[2], r.v[3]}, b = {r.v[4], r.v[5], r.v[6], r.v[7]};
+    q[0] = a;
+    q[1] = b;
 }
 
 // ---- witness writer ---------------------------------------------------------------------------

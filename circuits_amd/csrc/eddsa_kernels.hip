@@ -266,6 +266,164 @@ __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The same ladder with the per-signature state parked in LDS between a signature's turns (throughput launches, k_eddsa_chain<G>).
+// seg_any_lock keeps its state in arrays indexed by g: with G = 2 the compiler puts them in scratch memory, and every turn of a
+// signature loads and stores its nine field elements through the vector-memory path -- round 2's counters: 23 GB of traffic for
+// 9.4 GB of signals, and a full memory latency in front of every turn of a kernel that is one long dependent chain on 512
+// wavefronts. One wavefront per workgroup, slot s limb l of lane L at st[(s * 9 + l) * 64 + L] (conflict-free 256-byte rows);
+// nothing else of a step uses LDS.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;   // an LDS pointer the compiler can prove is one: ds_read / ds_write, not flat_*
+struct LaneLds {
+    lds_u32* p;   // st + lane
+    __device__ __forceinline__ Fr get(int slot) const {
+        Fr r;
+#pragma unroll
+        for (int l = 0; l < 9; l++) r.v[l] = p[(slot * 9 + l) * 64];
+        return r;
+    }
+    __device__ __forceinline__ void put(int slot, const Fr& v) const {
+#pragma unroll
+        for (int l = 0; l < 9; l++) p[(slot * 9 + l) * 64] = v.v[l];
+    }
+};
+// Slots: six per signature (the doubling chain's point in scales 0 / 1, the accumulator, the next doubler's numerator), the 2 G - 1
+// prefix products of the step's shared inversion, and the ladder bits of the G signatures (8 words each): 17 slots = 38 KB at G = 2,
+// i.e. four such wavefronts per CU -- the ladders of BOTH contexts in flight are resident at once (at 24 slots / 54 KB only two per
+// CU fit, the second context's ladder queued behind the first one's and the step got 5 % longer although the kernel alone was
+// 12 % shorter).
+enum { LS_DX0 = 0, LS_DX1, LS_DY0, LS_AX, LS_AY, LS_DNUM, LS_PER_G };
+template <int G> constexpr int ls_pre0() { return G * LS_PER_G; }                 // pre[1 .. 2G-1] (pre[0] = 1 is not stored)
+template <int G> constexpr int ls_h0() { return G * LS_PER_G + 2 * G - 1; }       // word w of signature g's bits at dword g * 8 + w of this region
+template <int G> constexpr int ls_slots() { return ls_h0<G>() + (8 * G + 8) / 9; }
+__device__ __forceinline__ uint32_t ls_hbit(const LaneLds& L, int h0, int g, int bit) {
+    const int d = g * 8 + (bit >> 5);
+    return (L.p[(h0 * 9 + d) * 64] >> (bit & 31)) & 1u;
+}
+__device__ __forceinline__ void ls_hput(const LaneLds& L, int h0, int g, const Fc& h) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) L.p[(h0 * 9 + g * 8 + q) * 64] = h.v[q];
+}
+
+// start of a segment for signature g: e2m, doubler_0 (as the head of seg_any_lock)
+__device__ __noinline__ void seg_lds_init(const EdK& K, const UnitIO& io, const SegAnyOff& o, const PtA& p, const LaneLds& L, int g) {
+    const EdCtx c = K.with(io);
+    const PtA m = e2m_dev(c, p);
+    const Fr ax = fr_canon_limbs(m.x), ay = fr_canon_limbs(m.y);
+    L.put(g * LS_PER_G + LS_AX, ax); L.put(g * LS_PER_G + LS_AY, ay);
+    c.io.put_c(o.e2m, fr_pack_canon(ax)); c.io.put_c(o.e2m + 1, fr_pack_canon(ay));
+    const MDbl d = mont_dbl_dev(c, m);   // doubler_0
+    c.io.put_m(o.bits + BIT_DBL_X1_2, d.x1_2); c.io.put_m(o.bits + BIT_DBL_LAMDA, d.lamda);
+    const Fr dx0 = fr_canon_limbs(d.out.x), dy0 = fr_canon_limbs(d.out.y);
+    L.put(g * LS_PER_G + LS_DX1, d.out.x); L.put(g * LS_PER_G + LS_DX0, dx0); L.put(g * LS_PER_G + LS_DY0, dy0);
+    c.io.put_c(o.bits + BIT_DBL_OUT0, fr_pack_canon(dx0)); c.io.put_c(o.bits + BIT_DBL_OUT1, fr_pack_canon(dy0));
+}
+// the steps of a segment for the G signatures of a lane in lockstep (the loop of seg_any_lock, state in LDS); `mk_io(g)` gives
+// signature g's witness cursor. One inversion per step for the 2 G divisors (adder and next doubler of every signature): forward
+// pass = prefix products (parked), backward pass = each signature's two inverses peeled off and USED at once -- the divisors are
+// recomputed from the state (a subtraction, a doubling) instead of being parked, the inverses never leave the registers.
+template <int G, class MkIo>
+__device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, const SegAnyOff& o, int e0, int n, const LaneLds& L) {
+    const int steps = n - 1;
+    const Fr A0 = fr_limbs_u64(168698), one0 = fr_limbs_u64(1);
+    const Fr A2 = fr_dbl(K.A);
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        const bool more = i + 1 < steps;
+        const uint32_t b = o.bits + BIT_N * i;
+        Fr acc = fr_one();
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const int s0 = g * LS_PER_G;
+            const Fr dx0 = L.get(s0 + LS_DX0);
+            const Fr a_den = fr_sub(L.get(s0 + LS_AX), dx0);
+            if (g > 0) L.put(ls_pre0<G>() + 2 * g - 1, acc);          // pre[2g]
+            if (!fr_is_zero(a_den)) acc = fr_mul(acc, a_den);
+            L.put(ls_pre0<G>() + 2 * g, acc);                          // pre[2g + 1]
+            if (more) {
+                const UnitIO w = mk_io(g);
+                const Fr nx1_2 = fr_mul(dx0, L.get(s0 + LS_DX1));
+                (void)ed_put0(w, b + BIT_N + BIT_DBL_X1_2, nx1_2);     // doubler_{i+1}.x1_2
+                L.put(s0 + LS_DNUM, fr_add(fr_add(fr_add(fr_dbl(nx1_2), nx1_2), fr_mul(A2, dx0)), one0));
+                const Fr dd = fr_dbl(L.get(s0 + LS_DY0));
+                if (!fr_is_zero(dd)) acc = fr_mul(acc, dd);
+            }
+        }
+        Fr inv = fr_inv(acc);   // scale-0 divisors in, scale-2 inverses out
+#pragma unroll 1
+        for (int g = G - 1; g >= 0; g--) {
+            const int s0 = g * LS_PER_G;
+            const UnitIO w = mk_io(g);
+            const Fr dx0 = L.get(s0 + LS_DX0), dy0 = L.get(s0 + LS_DY0);
+            PtA addIn;
+            addIn.x = L.get(s0 + LS_AX); addIn.y = L.get(s0 + LS_AY);
+            // divisor 2g + 1 (the next doubler's 2y), then divisor 2g (the adder's x2 - x1): batch_inv's backward pass
+            Fr inv_dd = fr_zero();
+            bool dd_zero = true;
+            if (more) {
+                const Fr dd = fr_dbl(dy0);
+                dd_zero = fr_is_zero(dd);
+                if (!dd_zero) {
+                    inv_dd = fr_mul(inv, L.get(ls_pre0<G>() + 2 * g));
+                    inv = fr_mul(inv, dd);
+                }
+            }
+            const Fr a_den = fr_sub(addIn.x, dx0);
+            const bool a_zero = fr_is_zero(a_den);
+            Fr inv_a = fr_zero();
+            if (!a_zero) {
+                inv_a = g > 0 ? fr_mul(inv, L.get(ls_pre0<G>() + 2 * g - 1)) : inv;
+                if (g > 0) inv = fr_mul(inv, a_den);
+            }
+            const Fr a_num = fr_sub(addIn.y, dy0);
+            const Fr a_l1 = fr_mul(a_num, inv_a);
+            const Fr a_l0 = fr_canon_limbs(a_l1);
+            if (a_zero) w.chk(C_RTX_SIG_EC, fr_zero(), fr_scale_up(a_num));
+            PtA ao;
+            ao.x = fr_sub(fr_sub(fr_sub(fr_mul(a_l0, a_l1), A0), dx0), addIn.x);
+            ao.y = fr_sub(fr_mul(a_l1, fr_sub(dx0, ao.x)), dy0);
+            w.put_c(b + BIT_ADD_LAMDA, fr_pack_canon(a_l0));
+            ao.x = ed_put0(w, b + BIT_ADD_OUT0, ao.x); ao.y = ed_put0(w, b + BIT_ADD_OUT1, ao.y);
+            const uint32_t sel = ls_hbit(L, ls_h0<G>(), g, e0 + i + 1);
+            const PtA so = sel ? ao : addIn;
+            w.put_c(b + BIT_SEL_OUT0, fr_pack_canon(so.x)); w.put_c(b + BIT_SEL_OUT1, fr_pack_canon(so.y));
+            L.put(s0 + LS_AX, so.x); L.put(s0 + LS_AY, so.y);
+            if (more) {
+                const Fr d_num = L.get(s0 + LS_DNUM);
+                const Fr l1 = fr_mul(d_num, inv_dd);
+                const Fr l0 = fr_canon_limbs(l1);
+                if (dd_zero) w.chk(C_RTX_SIG_EC, fr_zero(), fr_scale_up(d_num));
+                const Fr nx1 = fr_sub(fr_sub(fr_sqr(l1), K.A), fr_dbl(L.get(s0 + LS_DX1)));
+                const Fr nx0 = fr_canon_limbs(nx1);
+                const Fr ny0 = fr_sub(fr_mul(l1, fr_sub(dx0, nx0)), dy0);
+                const uint32_t bn = b + BIT_N;
+                w.put_c(bn + BIT_DBL_LAMDA, fr_pack_canon(l0)); w.put_c(bn + BIT_DBL_OUT0, fr_pack_canon(nx0));
+                L.put(s0 + LS_DY0, ed_put0(w, bn + BIT_DBL_OUT1, ny0));
+                L.put(s0 + LS_DX1, nx1); L.put(s0 + LS_DX0, nx0);
+            }
+        }
+    }
+}
+// end of a segment for signature g (the tail of seg_any_lock): p = the segment's start point (Edwards); returns its output and
+// the last doubler output (Montgomery form)
+__device__ __noinline__ PtA seg_lds_fin(const EdK& K, const UnitIO& io, const SegAnyOff& o, uint32_t bit0, const PtA& p, const LaneLds& L, int g, PtA* dbl) {
+    const EdCtx c = K.with(io);
+    const int s0 = g * LS_PER_G;
+    dbl->x = L.get(s0 + LS_DX1);
+    dbl->y = fr_scale_up(L.get(s0 + LS_DY0));
+    PtA acc;
+    acc.x = fr_scale_up(L.get(s0 + LS_AX)); acc.y = fr_scale_up(L.get(s0 + LS_AY));
+    const PtA me = m2e_dev(c, acc);
+    c.io.put_m(o.m2e, me.x); c.io.put_m(o.m2e + 1, me.y);
+    PtA negp;
+    negp.x = fr_neg(p.x);
+    negp.y = p.y;
+    const PtA ea = baby_add_dev(c, o.eadder, me, negp);
+    const PtA r = bit0 ? me : ea;
+    c.io.put_m(o.lastSel, r.x); c.io.put_m(o.lastSel + 1, r.y);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // SegmentMulAny(n) for ONE signature without an inversion per step (launches the device does not fill: a step of seg_any_lock is
 // 60 us of one wavefront, 42 of them the inversion). The circuit's recurrences are rational maps, so they are walked with
 // denominators carried along -- x = X / Z^2, y = Y / Z^3 for the doubling chain D_i and for the accumulator -- and every signal is
@@ -705,47 +863,73 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
 // The whole signature as ONE chain per lane (both segments back to back, no k_eddsa_pre): 8 % fewer instructions than the split form
 // (no projective doubling chain) and half the wavefronts. Throughput-sized launches use it -- the device is full anyway, and the split
 // form measured 50.3 ms per step against 46.0 -- the split form is for launches the device does not fill (a single batch: latency).
+// The G signatures of a lane take turns; whatever a signature carries from one turn to the next lives in LDS (LaneLds above), what
+// it carries from one segment to the next in the inter-kernel scratch (its start points, its segment outputs).
 template <int G>
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain(const EddsaArgs a) {
+    __shared__ uint32_t st[ls_slots<G>() * 9 * HZ_BLOCK];
+    static_assert(HZ_BLOCK == 64, "LaneLds: one wavefront per workgroup");
     const Fr* K6 = poseidon_consts_w<6>();
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t nl = (n + G - 1) / G;
-    uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= nl) return;
+    const LaneLds L{(lds_u32*)(st + threadIdx.x)};
     EdK K;
     K.one = fr_one();
     K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
     const EddsaOff& o = a.ed;
-    UnitIO io[G];
-    Fc h_c[G];
-    PtA p[G], q[G], dbl[G];
+    // (the base pointer goes through an explicit global-address-space cast: captured in the lambda it would otherwise be a generic
+    // pointer, and flat_store counts against lgkmcnt -- the counter the LDS reads of the ladder wait on)
+    typedef __attribute__((address_space(1))) uint8_t gl_u8;
+    uint8_t* const wbase = (uint8_t*)(gl_u8*)a.base;
+    const uint32_t n_units = a.n_units, upi = a.upi, u0 = a.u0;
+    ErrBuf* const errp = a.err;
+    auto mk_io = [=](int g) {
+        uint32_t ui = li + (uint32_t)g * nl;
+        if (ui >= n) ui = li;   // a slot past the end repeats the lane's first unit (same values to the same addresses)
+        const uint32_t i = u0 + ui;
+        return UnitIO{wbase, n_units, i, i / upi, i % upi, errp};
+    };
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
-        uint32_t ui = li + (uint32_t)g * nl;
-        if (ui >= n) ui = li;
-        const uint32_t i = a.u0 + ui;
-        io[g] = UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
-        const Scratch sc{a.scratch, a.n_units, i};
+        const UnitIO io = mk_io(g);
+        const Scratch sc{a.scratch, a.n_units, io.unit};
         EdSig sg;
         bool on_curve;
-        ed_prologue(K, io[g], sc, o, K6, sg, &on_curve);
+        ed_prologue(K, io, sc, o, K6, sg, &on_curve);
         sc.set(SC_ED_ZP, sg.zp);
-        h_c[g] = sg.h_c; p[g] = sg.p0;
+        sc.set(SC_ED_P0X, sg.p0.x); sc.set(SC_ED_P0Y, sg.p0.y);
+        ls_hput(L, ls_h0<G>(), g, sg.h_c);   // the 254 ladder bits as plain 32-bit words
+        seg_lds_init(K, io, o.seg[0], sg.p0, L, g);
     }
-    seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);   // p <- segment 0 output
+    seg_lds_steps<G>(K, mk_io, o.seg[0], 0, 148, L);
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
-        const EdCtx c = K.with(io[g]);
-        const MDbl dd = mont_dbl_dev(c, dbl[g]);
+        const UnitIO io = mk_io(g);
+        const Scratch sc{a.scratch, a.n_units, io.unit};
+        PtA p0, dbl;
+        p0.x = sc.get(SC_ED_P0X); p0.y = sc.get(SC_ED_P0Y);
+        const PtA r = seg_lds_fin(K, io, o.seg[0], ls_hbit(L, ls_h0<G>(), g, 0), p0, L, g, &dbl);
+        sc.set(SC_ED_S0X, r.x); sc.set(SC_ED_S0Y, r.y);
+        // the doubling between the segments and the second segment's base point (escalarmulany.circom: doublers / m2e)
+        const EdCtx c = K.with(io);
+        const MDbl dd = mont_dbl_dev(c, dbl);
         c.io.put_m(o.dblr, dd.x1_2); c.io.put_m(o.dblr + 1, dd.lamda); c.io.put_m(o.dblr + 2, dd.out.x); c.io.put_m(o.dblr + 3, dd.out.y);
-        q[g] = m2e_dev(c, dd.out);
-        c.io.put_m(o.m2e0, q[g].x); c.io.put_m(o.m2e0 + 1, q[g].y);
+        const PtA q = m2e_dev(c, dd.out);
+        c.io.put_m(o.m2e0, q.x); c.io.put_m(o.m2e0 + 1, q.y);
+        sc.set(SC_ED_DBLX, q.x); sc.set(SC_ED_DBLY, q.y);   // (the split form keeps 2^147 * 8A here; this form the second start point)
+        seg_lds_init(K, io, o.seg[1], q, L, g);
     }
-    seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, q, dbl);  // q <- segment 1 output
+    seg_lds_steps<G>(K, mk_io, o.seg[1], 148, 106, L);
 #pragma unroll 1
     for (int g = 0; g < G; g++) {   // the sum, the zero-point substitution and R8 + h*8A belong to k_eddsa_final
-        const Scratch sc{a.scratch, a.n_units, io[g].unit};
-        sc.set(SC_ED_S0X, p[g].x); sc.set(SC_ED_S0Y, p[g].y); sc.set(SC_ED_S1X, q[g].x); sc.set(SC_ED_S1Y, q[g].y);
+        const UnitIO io = mk_io(g);
+        const Scratch sc{a.scratch, a.n_units, io.unit};
+        PtA q, dbl;
+        q.x = sc.get(SC_ED_DBLX); q.y = sc.get(SC_ED_DBLY);
+        const PtA r = seg_lds_fin(K, io, o.seg[1], ls_hbit(L, ls_h0<G>(), g, 148), q, L, g, &dbl);
+        sc.set(SC_ED_S1X, r.x); sc.set(SC_ED_S1Y, r.y);
     }
 }
 

@@ -51,8 +51,20 @@ struct Scratch {
     Fr* p;
     uint32_t n_units;
     uint32_t unit;
-    __device__ __forceinline__ Fr get(uint32_t f) const { return p[(size_t)f * n_units + unit]; }
-    __device__ __forceinline__ void set(uint32_t f, const Fr& v) const { p[(size_t)f * n_units + unit] = v; }
+    // explicit global address space, like load_fr / store_fr (devcommon.h)
+    typedef __attribute__((address_space(1))) uint32_t g_u32;
+    __device__ __forceinline__ Fr get(uint32_t f) const {
+        const g_u32* q = (const g_u32*)(p + ((size_t)f * n_units + unit));
+        Fr r;
+#pragma unroll
+        for (int l = 0; l < 9; l++) r.v[l] = q[l];
+        return r;
+    }
+    __device__ __forceinline__ void set(uint32_t f, const Fr& v) const {
+        g_u32* q = (g_u32*)(p + ((size_t)f * n_units + unit));
+#pragma unroll
+        for (int l = 0; l < 9; l++) q[l] = v.v[l];
+    }
 };
 
 // ---- canonical-integer helpers ---------------------------------------------------------------------
