@@ -291,10 +291,18 @@ struct LaneLds {
 // i.e. four such wavefronts per CU -- the ladders of BOTH contexts in flight are resident at once (at 24 slots / 54 KB only two per
 // CU fit, the second context's ladder queued behind the first one's and the step got 5 % longer although the kernel alone was
 // 12 % shorter).
-enum { LS_DX0 = 0, LS_DX1, LS_DY0, LS_AX, LS_AY, LS_DNUM, LS_PER_G };
-template <int G> constexpr int ls_pre0() { return G * LS_PER_G; }                 // pre[1 .. 2G-1] (pre[0] = 1 is not stored)
-template <int G> constexpr int ls_h0() { return G * LS_PER_G + 2 * G - 1; }       // word w of signature g's bits at dword g * 8 + w of this region
+enum { LS_DX1 = 0, LS_DY0, LS_AX, LS_AY, LS_DNUM, LS_DX0, LS_PER_G_MAX };
+// G <= 3 parks the doubling chain's x in both scales; G = 4 recomputes the scale-0 twin (one reduction, three times a step) to
+// stay within two wavefronts per CU (31 slots = 70 KB)
+template <int G> constexpr bool ls_keep_dx0() { return G <= 3; }
+template <int G> constexpr int ls_per_g() { return ls_keep_dx0<G>() ? LS_PER_G_MAX : LS_PER_G_MAX - 1; }
+template <int G> constexpr int ls_pre0() { return G * ls_per_g<G>(); }                 // pre[1 .. 2G-1] (pre[0] = 1 is not stored)
+template <int G> constexpr int ls_h0() { return G * ls_per_g<G>() + 2 * G - 1; }       // word w of signature g's bits at dword g * 8 + w of this region
 template <int G> constexpr int ls_slots() { return ls_h0<G>() + (8 * G + 8) / 9; }
+template <int G> __device__ __forceinline__ Fr ls_dx0(const LaneLds& L, int s0) {
+    if constexpr (ls_keep_dx0<G>()) return L.get(s0 + LS_DX0);
+    else return fr_canon_limbs(L.get(s0 + LS_DX1));
+}
 __device__ __forceinline__ uint32_t ls_hbit(const LaneLds& L, int h0, int g, int bit) {
     const int d = g * 8 + (bit >> 5);
     return (L.p[(h0 * 9 + d) * 64] >> (bit & 31)) & 1u;
@@ -305,7 +313,9 @@ __device__ __forceinline__ void ls_hput(const LaneLds& L, int h0, int g, const F
 }
 
 // start of a segment for signature g: e2m, doubler_0 (as the head of seg_any_lock)
+template <int G>
 __device__ __noinline__ void seg_lds_init(const EdK& K, const UnitIO& io, const SegAnyOff& o, const PtA& p, const LaneLds& L, int g) {
+    constexpr int LS_PER_G = ls_per_g<G>();
     const EdCtx c = K.with(io);
     const PtA m = e2m_dev(c, p);
     const Fr ax = fr_canon_limbs(m.x), ay = fr_canon_limbs(m.y);
@@ -314,7 +324,8 @@ __device__ __noinline__ void seg_lds_init(const EdK& K, const UnitIO& io, const 
     const MDbl d = mont_dbl_dev(c, m);   // doubler_0
     c.io.put_m(o.bits + BIT_DBL_X1_2, d.x1_2); c.io.put_m(o.bits + BIT_DBL_LAMDA, d.lamda);
     const Fr dx0 = fr_canon_limbs(d.out.x), dy0 = fr_canon_limbs(d.out.y);
-    L.put(g * LS_PER_G + LS_DX1, d.out.x); L.put(g * LS_PER_G + LS_DX0, dx0); L.put(g * LS_PER_G + LS_DY0, dy0);
+    L.put(g * LS_PER_G + LS_DX1, d.out.x); L.put(g * LS_PER_G + LS_DY0, dy0);
+    if constexpr (ls_keep_dx0<G>()) L.put(g * LS_PER_G + LS_DX0, dx0);
     c.io.put_c(o.bits + BIT_DBL_OUT0, fr_pack_canon(dx0)); c.io.put_c(o.bits + BIT_DBL_OUT1, fr_pack_canon(dy0));
 }
 // the steps of a segment for the G signatures of a lane in lockstep (the loop of seg_any_lock, state in LDS); `mk_io(g)` gives
@@ -323,6 +334,7 @@ __device__ __noinline__ void seg_lds_init(const EdK& K, const UnitIO& io, const 
 // recomputed from the state (a subtraction, a doubling) instead of being parked, the inverses never leave the registers.
 template <int G, class MkIo>
 __device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, const SegAnyOff& o, int e0, int n, const LaneLds& L) {
+    constexpr int LS_PER_G = ls_per_g<G>();
     const int steps = n - 1;
     const Fr A0 = fr_limbs_u64(168698), one0 = fr_limbs_u64(1);
     const Fr A2 = fr_dbl(K.A);
@@ -334,7 +346,7 @@ __device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, c
 #pragma unroll 1
         for (int g = 0; g < G; g++) {
             const int s0 = g * LS_PER_G;
-            const Fr dx0 = L.get(s0 + LS_DX0);
+            const Fr dx0 = ls_dx0<G>(L, s0);
             const Fr a_den = fr_sub(L.get(s0 + LS_AX), dx0);
             if (g > 0) L.put(ls_pre0<G>() + 2 * g - 1, acc);          // pre[2g]
             if (!fr_is_zero(a_den)) acc = fr_mul(acc, a_den);
@@ -353,7 +365,7 @@ __device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, c
         for (int g = G - 1; g >= 0; g--) {
             const int s0 = g * LS_PER_G;
             const UnitIO w = mk_io(g);
-            const Fr dx0 = L.get(s0 + LS_DX0), dy0 = L.get(s0 + LS_DY0);
+            const Fr dx0 = ls_dx0<G>(L, s0), dy0 = L.get(s0 + LS_DY0);
             PtA addIn;
             addIn.x = L.get(s0 + LS_AX); addIn.y = L.get(s0 + LS_AY);
             // divisor 2g + 1 (the next doubler's 2y), then divisor 2g (the adder's x2 - x1): batch_inv's backward pass
@@ -398,16 +410,18 @@ __device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, c
                 const uint32_t bn = b + BIT_N;
                 w.put_c(bn + BIT_DBL_LAMDA, fr_pack_canon(l0)); w.put_c(bn + BIT_DBL_OUT0, fr_pack_canon(nx0));
                 L.put(s0 + LS_DY0, ed_put0(w, bn + BIT_DBL_OUT1, ny0));
-                L.put(s0 + LS_DX1, nx1); L.put(s0 + LS_DX0, nx0);
+                L.put(s0 + LS_DX1, nx1);
+                if constexpr (ls_keep_dx0<G>()) L.put(s0 + LS_DX0, nx0);
             }
         }
     }
 }
 // end of a segment for signature g (the tail of seg_any_lock): p = the segment's start point (Edwards); returns its output and
 // the last doubler output (Montgomery form)
+template <int G>
 __device__ __noinline__ PtA seg_lds_fin(const EdK& K, const UnitIO& io, const SegAnyOff& o, uint32_t bit0, const PtA& p, const LaneLds& L, int g, PtA* dbl) {
     const EdCtx c = K.with(io);
-    const int s0 = g * LS_PER_G;
+    const int s0 = g * ls_per_g<G>();
     dbl->x = L.get(s0 + LS_DX1);
     dbl->y = fr_scale_up(L.get(s0 + LS_DY0));
     PtA acc;
@@ -867,7 +881,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
 // it carries from one segment to the next in the inter-kernel scratch (its start points, its segment outputs).
 template <int G>
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain(const EddsaArgs a) {
-    __shared__ uint32_t st[ls_slots<G>() * 9 * HZ_BLOCK];
+    extern __shared__ __attribute__((aligned(16))) uint32_t st[];   // ls_slots<G>() * 9 * 64 words (launch_eddsa_g)
     static_assert(HZ_BLOCK == 64, "LaneLds: one wavefront per workgroup");
     const Fr* K6 = poseidon_consts_w<6>();
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
@@ -901,7 +915,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         sc.set(SC_ED_ZP, sg.zp);
         sc.set(SC_ED_P0X, sg.p0.x); sc.set(SC_ED_P0Y, sg.p0.y);
         ls_hput(L, ls_h0<G>(), g, sg.h_c);   // the 254 ladder bits as plain 32-bit words
-        seg_lds_init(K, io, o.seg[0], sg.p0, L, g);
+        seg_lds_init<G>(K, io, o.seg[0], sg.p0, L, g);
     }
     seg_lds_steps<G>(K, mk_io, o.seg[0], 0, 148, L);
 #pragma unroll 1
@@ -910,7 +924,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         const Scratch sc{a.scratch, a.n_units, io.unit};
         PtA p0, dbl;
         p0.x = sc.get(SC_ED_P0X); p0.y = sc.get(SC_ED_P0Y);
-        const PtA r = seg_lds_fin(K, io, o.seg[0], ls_hbit(L, ls_h0<G>(), g, 0), p0, L, g, &dbl);
+        const PtA r = seg_lds_fin<G>(K, io, o.seg[0], ls_hbit(L, ls_h0<G>(), g, 0), p0, L, g, &dbl);
         sc.set(SC_ED_S0X, r.x); sc.set(SC_ED_S0Y, r.y);
         // the doubling between the segments and the second segment's base point (escalarmulany.circom: doublers / m2e)
         const EdCtx c = K.with(io);
@@ -919,7 +933,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         const PtA q = m2e_dev(c, dd.out);
         c.io.put_m(o.m2e0, q.x); c.io.put_m(o.m2e0 + 1, q.y);
         sc.set(SC_ED_DBLX, q.x); sc.set(SC_ED_DBLY, q.y);   // (the split form keeps 2^147 * 8A here; this form the second start point)
-        seg_lds_init(K, io, o.seg[1], q, L, g);
+        seg_lds_init<G>(K, io, o.seg[1], q, L, g);
     }
     seg_lds_steps<G>(K, mk_io, o.seg[1], 148, 106, L);
 #pragma unroll 1
@@ -928,7 +942,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
         const Scratch sc{a.scratch, a.n_units, io.unit};
         PtA q, dbl;
         q.x = sc.get(SC_ED_DBLX); q.y = sc.get(SC_ED_DBLY);
-        const PtA r = seg_lds_fin(K, io, o.seg[1], ls_hbit(L, ls_h0<G>(), g, 148), q, L, g, &dbl);
+        const PtA r = seg_lds_fin<G>(K, io, o.seg[1], ls_hbit(L, ls_h0<G>(), g, 148), q, L, g, &dbl);
         sc.set(SC_ED_S1X, r.x); sc.set(SC_ED_S1Y, r.y);
     }
 }
@@ -1022,7 +1036,12 @@ static hipError_t launch_eddsa_split(const EddsaArgs& a, uint32_t n, hipStream_t
 template <int G>
 static hipError_t launch_eddsa_g(const EddsaArgs& a, uint32_t n, hipStream_t s) {
     const uint32_t nl = (n + G - 1) / G;
-    hipLaunchKernelGGL(k_eddsa_chain<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
+    constexpr size_t lds = (size_t)ls_slots<G>() * 9 * HZ_BLOCK * sizeof(uint32_t);
+    if (lds > 64 * 1024) {   // beyond the default limit of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eddsa_chain<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (once != hipSuccess) return once;
+    }
+    hipLaunchKernelGGL(k_eddsa_chain<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), lds, s, a);
     return hipGetLastError();
 }
 template <int G>

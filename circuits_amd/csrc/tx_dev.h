@@ -251,6 +251,43 @@ __device__ __forceinline__ Fr mux4_var_dev(const UnitIO& io, uint32_t b, const F
     return out;
 }
 
+__device__ __forceinline__ Fr compute_fee_tail_dev(const UnitIO& io, const ComputeFeeOff& o, const Fc& feeSel_c, const Fr& amount, const Fr& factor);
+// value 1 in either representative of [0, 2p) (Montgomery form)
+__device__ __forceinline__ bool fr_is_one_m(const Fr& a) {
+    uint32_t d0 = 0, d1 = 0;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        d0 |= a.v[i] ^ fr_r1(i);
+        const int32_t x = (int32_t)fr_r1(i) + (int32_t)fr_p29(i) + c;   // R mod p + p, limb by limb
+        d1 |= a.v[i] ^ (i < 8 ? (uint32_t)(x & (int32_t)HZ_M29) : (uint32_t)x);
+        c = x >> 29;
+    }
+    return d0 == 0 || d1 == 0;
+}
+// The 15 product terms of a MultiMux4 whose selectors are bits (s_i = b_i * a with a = 1: t[i] in {0, 1}): a product of selectors is
+// 1 exactly when all its bits are set, so every term is either its coefficient or 0 -- additions only (mux4_var_dev multiplies).
+// Same signals, same values. `sel` = the four selector bits.
+__device__ __forceinline__ Fr mux4_bits_dev(const UnitIO& io, uint32_t b, const Fr* c, uint32_t sel) {
+    const Fr zero = fr_zero(), one = fr_one();
+    // out = (a3210 + ... + a30 + a3) * s3 + (a210 + ... + a0 + c0); a term = its coefficient times the product of the selectors
+    // BELOW bit 3 (a3210 = coef * s2 s1 s0, a32 = coef * s2, ...), so the low three bits decide it
+    auto term = [&](int mask) { return ((sel & (mask & 7)) == (uint32_t)(mask & 7)) ? mux4_coef(c, mask) : zero; };
+    auto prod = [&](int mask) { return ((sel & mask) == (uint32_t)mask) ? one : zero; };
+    const Fr h3210 = term(15), h321 = term(14), h320 = term(13), h310 = term(11), h32 = term(12), h31 = term(10), h30 = term(9);
+    const Fr a210 = term(7), a21 = term(6), a20 = term(5), a10 = term(3), a2 = term(4), a1 = term(2), a0 = term(1);
+    const Fr a3 = mux4_coef(c, 8);
+    const Fr hi = fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(h3210, h321), h320), h310), h32), h31), h30), a3);
+    const Fr lo = fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(fr_add(a210, a21), a20), a10), a2), a1), a0), c[0]);
+    const Fr out = (sel & 8u) ? fr_add(hi, lo) : lo;
+    io.put_m(b + MX4_S10, prod(3)); io.put_m(b + MX4_S20, prod(5)); io.put_m(b + MX4_S21, prod(6)); io.put_m(b + MX4_S210, prod(7));
+    io.put_m(b + MX4V_A3210, h3210); io.put_m(b + MX4V_A321, h321); io.put_m(b + MX4V_A320, h320); io.put_m(b + MX4V_A310, h310);
+    io.put_m(b + MX4V_A32, h32); io.put_m(b + MX4V_A31, h31); io.put_m(b + MX4V_A30, h30);
+    io.put_m(b + MX4V_A210, a210); io.put_m(b + MX4V_A21, a21); io.put_m(b + MX4V_A20, a20); io.put_m(b + MX4V_A10, a10);
+    io.put_m(b + MX4V_A2, a2); io.put_m(b + MX4V_A1, a1); io.put_m(b + MX4V_A0, a0); io.put_m(b + MX4V_OUT, out);
+    return out;
+}
+
 // ComputeFee (src/compute-fee.circom:12-94) incl. Mux256 (src/lib/mux256.circom)
 __device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFeeOff& o, const Fc& feeSel_c, const Fr& amount, const Fr& applyFee) {
     const Fr one = fr_one();
@@ -261,6 +298,27 @@ __device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFee
     for (int i = 0; i < 8; i++) {
         s[i] = c_bit(feeSel_c, i) ? applyFee : fr_zero();
         io.put_c(o.muxS + i, c_bit(feeSel_c, i) ? applyFee_c : fc_zero());
+    }
+    // applyFee is 0 or 1 in every witness RollupTx produces ((1 - onChain) * (1 - nop)); as a main component it is an input and
+    // may be anything. When it is a bit on every lane of the wavefront the selectors are bits and the 16 + 1 multiplexers need no
+    // field product at all: the selected table entry IS the first level's output (256 + 256 products and as many conversions of
+    // table entries otherwise: a quarter of the front kernel's instructions).
+    const bool ap1 = fr_is_one_m(applyFee);
+    if (__all(ap1 || fr_is_zero(applyFee))) {
+        const uint32_t selbits = ap1 ? (uint32_t)c_bits64(feeSel_c, 0, 8) : 0u;
+        const uint32_t lo4 = selbits & 15u;
+        const Fr s10 = ((lo4 & 3u) == 3u) ? one : fr_zero(), s20 = ((lo4 & 5u) == 5u) ? one : fr_zero(), s21 = ((lo4 & 6u) == 6u) ? one : fr_zero(),
+                 s210 = ((lo4 & 7u) == 7u) ? one : fr_zero();
+        Fr lvl1[16];
+#pragma unroll 1
+        for (int m = 0; m < 16; m++) {
+            lvl1[m] = fr_from_u64(HZ_FEE_TABLE[16 * m + lo4]);   // Mux4 with constant inputs and bit selectors: the selected entry
+            const uint32_t b = o.mux1 + MX4C_N * m;
+            io.put_m(b + MX4_S10, s10); io.put_m(b + MX4_S20, s20); io.put_m(b + MX4_S21, s21); io.put_m(b + MX4_S210, s210);
+            io.put_m(b + MX4_OUT_C, lvl1[m]);
+        }
+        const Fr factor = mux4_bits_dev(io, o.mux2, lvl1, selbits >> 4);
+        return compute_fee_tail_dev(io, o, feeSel_c, amount, factor);
     }
     const Fr s10 = fr_mul(s[1], s[0]), s20 = fr_mul(s[2], s[0]), s21 = fr_mul(s[2], s[1]), s210 = fr_mul(s21, s[0]);
     const Fr sp[16] = {one, s[0], s[1], s10, s[2], s20, s21, s210, s[3], fr_zero(), fr_zero(), fr_zero(), fr_zero(), fr_zero(), fr_zero(), fr_zero()};
@@ -282,6 +340,9 @@ __device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFee
     }
     // second level: selectors s[4..7], signal inputs: every product term is stored
     const Fr factor = mux4_var_dev(io, o.mux2, lvl1, s + 4);
+    return compute_fee_tail_dev(io, o, feeSel_c, amount, factor);
+}
+__device__ __forceinline__ Fr compute_fee_tail_dev(const UnitIO& io, const ComputeFeeOff& o, const Fc& feeSel_c, const Fr& amount, const Fr& factor) {
     const Fr notShifted = fr_mul(factor, amount);
     const Fc ns_c = fr_to_canon(notShifted);
     io.put_c(o.feeOutNotShifted, ns_c);
@@ -512,7 +573,7 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
     const Fr isP2Nop = fr_sub(one, ez);
     // ---- H: FeeAccumulator (batched inverses of tokenID - feePlanTokenID[i])
     {
-        Fr selIn = zero;
+        bool sel_in = false;
         for (int base = 0; base < Fn; base += 16) {
             const int n = (Fn - base) < 16 ? (Fn - base) : 16;
             Fr dz[16], dzi[16];
@@ -520,14 +581,17 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
             batch_inv<16>(dzi, n);
             for (int i = 0; i < n; i++) {
                 const uint32_t b = o.feeAcc + FA_N * (base + i);
-                const Fr eq = is_zero_dev(io, b + FA_ISZ_INV, dz[i], dzi[i]);
-                const Fr selOut = fr_sub(one, fr_mul(fr_sub(one, eq), fr_sub(one, selIn)));
-                const Fr ms = fr_mul(eq, fr_sub(one, selIn));
+                // IsEqual's output and the running "already selected" flag are bits whatever the inputs are: the chain
+                // selOut = 1 - (1 - eq)(1 - selIn), s = eq (1 - selIn), out = fee2Charge * s + accIn is logic plus one selection
+                const bool eq = fr_is_zero(dz[i]);
+                (void)is_zero_dev(io, b + FA_ISZ_INV, dz[i], dzi[i]);
+                const bool ms = eq && !sel_in;
+                const bool sel_out = eq || sel_in;
                 const Fr accIn = feeSrc.acc(base + i);
-                const Fr out = fr_add(fr_mul(fee2Charge, ms), accIn);   // (accIn + fee - accIn)*s + accIn
-                io.put_m(b + FA_SELOUT, selOut); io.put_m(b + FA_MUX_S, ms); io.put_m(b + FA_MUX_OUT, out);
+                const Fr out = ms ? fr_add(fee2Charge, accIn) : accIn;   // (accIn + fee - accIn)*s + accIn
+                io.put_bit(b + FA_SELOUT, sel_out ? 1u : 0u); io.put_bit(b + FA_MUX_S, ms ? 1u : 0u); io.put_m(b + FA_MUX_OUT, out);
                 feeSrc.out(io, base + i, out);
-                selIn = selOut;
+                sel_in = sel_out;
             }
         }
     }

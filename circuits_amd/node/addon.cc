@@ -445,6 +445,30 @@ static napi_value Check(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_queue_async_work(env, w->work));
     return promise;
 }
+// checkSync(handle) -> null | failure record: hz_witness_check on the calling (JS) thread. Blocks the event loop for as long as the
+// step takes: for command-line tools and measurements, not for servers.
+static napi_value CheckSync(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    hz_error err;
+    memset(&err, 0, sizeof err);
+    const hz_status st = api.witness_check(c, &err);
+    napi_value result;
+    if (st == HZ_OK) { napi_get_null(env, &result); return result; }
+    if (st != HZ_ERR_CONSTRAINT) return throw_hz(env, "hz_witness_check");
+    napi_create_object(env, &result);
+    napi_value v;
+    napi_create_int32(env, err.instance, &v); napi_set_named_property(env, result, "instance", v);
+    napi_create_int32(env, err.unit, &v); napi_set_named_property(env, result, "unit", v);
+    napi_create_int32(env, err.constraint_id, &v); napi_set_named_property(env, result, "constraintId", v);
+    napi_create_string_utf8(env, api.constraint_name(err.constraint_id), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, result, "constraintName", v);
+    void* p;
+    napi_create_buffer_copy(env, 32, err.lhs, &p, &v); napi_set_named_property(env, result, "lhs", v);
+    napi_create_buffer_copy(env, 32, err.rhs, &p, &v); napi_set_named_property(env, result, "rhs", v);
+    return result;
+}
 // devPtr(handle) -> BigInt device address of the physical witness buffer (for a prover in the same process); witnessTotal -> elements
 static napi_value DevPtr(napi_env env, napi_callback_info info) {
     napi_value argv[1];
@@ -664,7 +688,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"symbolCount", SymbolCount}, {"symbolGet", SymbolGet}, {"deviceCount", DeviceCount}, {"version", Version},
         {"packedLayout", PackedLayout}, {"hostAlloc", HostAlloc}, {"upload", Upload}, {"stageRange", StageRange}, {"enqueue", Enqueue},
         {"check", Check}, {"devPtr", DevPtr}, {"witnessTotal", WitnessTotal}, {"readRaw", ReadRaw}, {"setInputsJson", SetInputsJson},
-        {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}, {"step", Step}};
+        {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}, {"step", Step}, {"checkSync", CheckSync}};
     for (const auto& f : fns) {
         napi_value fn;
         napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn);

@@ -36,7 +36,21 @@ async function main() {
     }
     // every context is its own chain of step() calls (check previous -> enqueue -> stage next, one work item on the libuv pool each):
     // the contexts in flight advance independently, the JS thread only chains promises
+    const mode = process.env.HZ_NODE_MODE || "step";
+    const runSync = (n, withStage) => {   // the Python loop verbatim, on the JS thread (HZ_NODE_MODE = sync | nostage: experiments)
+        const pending = new Array(inflight).fill(false);
+        for (let i = 0; i < n; i++) {
+            const k = i % inflight;
+            if (pending[k]) ctxs[k].checkSync(true);
+            ctxs[k].enqueue();
+            if (withStage) stage(k);
+            pending[k] = true;
+        }
+        for (let k = 0; k < inflight; k++) if (pending[k]) ctxs[k].checkSync(true);
+    };
     const run = async (n) => {
+        if (mode === "sync") return runSync(n, true);
+        if (mode === "nostage") return runSync(n, false);
         const chains = [];
         for (let k = 0; k < inflight; k++) {
             const mine = Math.floor(n / inflight) + (k < n % inflight ? 1 : 0);
@@ -54,6 +68,6 @@ async function main() {
     const dt = Number(process.hrtime.bigint() - t0) / 1e9;
     for (let k = 0; k < inflight; k++) { ctxs[k].enqueue(); await ctxs[k].check(true); }   // drain the last staged inputs
     console.log(JSON.stringify({ value_node: nTx * B * steps / dt, ms_per_step: dt / steps * 1e3, steps, batches_per_launch: B, contexts_in_flight: inflight,
-        distinct_batches: Math.min(nDistinct, B * inflight), host: "node " + process.version + " over N-API (circuits_amd/node)", uploads: "inside the timed region (stageRange per step)" }));
+        distinct_batches: Math.min(nDistinct, B * inflight), mode, host: "node " + process.version + " over N-API (circuits_amd/node)", uploads: "inside the timed region (stageRange per step)" }));
 }
 main().catch((e) => { console.error(e); process.exit(1); });
