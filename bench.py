@@ -135,7 +135,7 @@ def poseidon_rates(L, torch):
 
 def measured_traffic(kernel, bpl):
     """HBM bytes of one launch of `kernel` (mean over its launches of the transaction grid) from the committed rocprofv3 PMC passes
-    (profiles/r02_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
+    (profiles/r03_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
     this configuration."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_counters.json")))

@@ -25,7 +25,7 @@ def _one(task):
             _BASE[base_path] = B.DenseState.load(base_path)
         bb = B.synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=seed, base=_BASE[base_path])
     else:
-        bb = B.synthetic_batch(n_tx, n_levels, max_l1, max_fee, n_accounts=n_accounts, seed=seed)
+        bb = B.synthetic_batch(n_tx, n_levels, max_l1, max_fee, n_accounts=n_accounts, seed=seed, dense=True)
     inp = bb.get_input()
     return pack_inputs(layout, inp), bb.get_hash_inputs(), sum(1 for x in inp["onChain"] if not x)
 

@@ -39,6 +39,12 @@ class Host:
         self.c.hzb_poseidon(len(xs), buf, self._o)
         return int.from_bytes(self._o.raw, "little")
 
+    def poseidon_many(self, t, n, data):
+        """n hashes of t - 1 inputs each from a bytes-like of canonical 32-byte elements -> bytes of n digests (one call)"""
+        out = ctypes.create_string_buffer(32 * max(n, 1))
+        self.c.hzb_poseidon_many(ctypes.c_int(t - 1), ctypes.c_uint64(n), bytes(data), out)
+        return out.raw[:32 * n]
+
     def bjj_mul(self, pt, k):
         b = lambda v: int(v).to_bytes(32, "little")  # noqa: E731
         self.c.hzb_bjj_mul(b(pt[0]), b(pt[1]), b(k % (1 << 256)), self._ox, self._oy)
@@ -226,15 +232,7 @@ class DenseState:
         import numpy as np
         N = 1 << k
         if hash_rows is None:
-            h = host()
-
-            def hash_rows(t, n, data):   # host fallback: one hash at a time (tests; a million accounts want the device)
-                out = bytearray(32 * n)
-                w = t - 1
-                for i in range(n):
-                    xs = [int.from_bytes(data[32 * (w * i + j):32 * (w * i + j + 1)], "little") for j in range(w)]
-                    out[32 * i:32 * i + 32] = h.poseidon(xs).to_bytes(32, "little")
-                return bytes(out)
+            hash_rows = host().poseidon_many   # the host library, one call per level (a million accounts want the device)
         rng = np.random.default_rng(seed)
         keys = [Account(seed * 1000 + i) for i in range(n_keys)]
         key_idx = rng.integers(0, n_keys, size=N, dtype=np.uint8)
@@ -926,13 +924,18 @@ class ExitTreeFixture:
 
 
 def synthetic_batch(n_tx, n_levels, max_l1, max_fee, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, dag_evaluator=None, first_idx=256,
-                    base=None):
+                    base=None, dense=False):
     """Seeded synthetic batch following reference tools/generate-input.js:61-109 and
     tools/helpers/gen-inputs-utils.js: pre-populated accounts (token 1), then one batch of `max_l1` L1
     createAccountDeposit txs followed by signed L2 transfers of 20 % of the sender balance with
     userFee 176 (plus `exits` L2 exits), one fee token and one fee receiver."""
     import random
     rng = random.Random(seed)
+    if base is None and dense and n_accounts and n_accounts >= 16 and n_accounts & (n_accounts - 1) == 0:
+        # the same pre-populated state built in bulk (DenseState: 3 hashes per account, one library call per tree level) instead of
+        # account by account (a path of ~log2(n) hashes per insertion): same tree shape, 5x fewer hashes -- what bench.py's
+        # batch builders use (8192 accounts per batch)
+        base = DenseState.build(n_accounts.bit_length() - 1, seed=seed, first_idx=first_idx, n_keys=n_keys)
     if base is not None:
         return _synthetic_batch_on_base(rng, base, n_tx, n_levels, max_l1, max_fee, seed, n_keys, exits, device, dag_evaluator)
     db = RollupDB(chain_id=1, device=device, dag_evaluator=dag_evaluator, first_idx=first_idx)

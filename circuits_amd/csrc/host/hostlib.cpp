@@ -1,20 +1,122 @@
 // libhz_host.so -- host-side arithmetic for the batch builder (the counterpart of the JS
 // @hermeznetwork/commonjs BatchBuilder/RollupDB the reference's tests and tools call at
 // test/helpers/helpers.js:46,148 and tools/generate-input.js:70-107). It is caller-side code: it
-// prepares circuit INPUTS (state tree, signatures); it never computes a witness. It reuses the
-// product's own field/Poseidon headers compiled for the host, and nothing from oracle/.
+// prepares circuit INPUTS (state tree, signatures); it never computes a witness, and it uses nothing from oracle/.
+//
+// Hashing and curve arithmetic run on a 4 x 64-bit Montgomery field (hostfield.h: what an x86-64 core multiplies natively); the
+// permutation is the textbook one
+// (Ark, S-box, Mix per round, circomlib 0.5.2 poseidon.circom) on the plain parameters of gen/poseidon_consts_host.inc. The
+// device-form routines stay reachable for the self tests (hzb_fr_inv, hzb_poseidon_dev9: same digests).
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 #include "../babyjub.h"
 #include "../poseidon.h"
+#include "hostfield.h"
 
 namespace hz {
 #define HZ_CONST_ARR static const
 #include "../gen/poseidon_consts.inc"
 #undef HZ_CONST_ARR
 }  // namespace hz
+#include "../gen/poseidon_consts_host.inc"
 using namespace hz;
+using hzh::F;
 
+// ---- Poseidon on the host field -----------------------------------------------------------------------------------------------
+struct HostTab {
+    int t, rp;
+    std::vector<F> C, M;
+};
+static HostTab make_tab(int t, int rp, const uint64_t (*c)[4], const uint64_t (*m)[4]) {
+    HostTab tab;
+    tab.t = t; tab.rp = rp;
+    for (int i = 0; i < t * (8 + rp); i++) tab.C.push_back(hzh::f_from_words(c[i]));
+    for (int i = 0; i < t * t; i++) tab.M.push_back(hzh::f_from_words(m[i]));
+    return tab;
+}
+static const HostTab& host_tab(int t) {
+    static const HostTab tabs[6] = {
+        make_tab(2, HZ_POSEIDON_RP_T2, HZ_POSEIDON_HC_T2, HZ_POSEIDON_HM_T2), make_tab(3, HZ_POSEIDON_RP_T3, HZ_POSEIDON_HC_T3, HZ_POSEIDON_HM_T3),
+        make_tab(4, HZ_POSEIDON_RP_T4, HZ_POSEIDON_HC_T4, HZ_POSEIDON_HM_T4), make_tab(5, HZ_POSEIDON_RP_T5, HZ_POSEIDON_HC_T5, HZ_POSEIDON_HM_T5),
+        make_tab(6, HZ_POSEIDON_RP_T6, HZ_POSEIDON_HC_T6, HZ_POSEIDON_HM_T6), make_tab(7, HZ_POSEIDON_RP_T7, HZ_POSEIDON_HC_T7, HZ_POSEIDON_HM_T7)};
+    return tabs[t - 2];
+}
+static F host_poseidon(const F* in, int n_in) {
+    const int t = n_in + 1;
+    const HostTab& tab = host_tab(t);
+    F st[7], nx[7];
+    st[0] = hzh::f_zero();
+    for (int j = 1; j < t; j++) st[j] = in[j - 1];
+    const int nr = 8 + tab.rp;
+    for (int r = 0; r < nr; r++) {
+        for (int j = 0; j < t; j++) st[j] = hzh::f_add(st[j], tab.C[(size_t)t * r + j]);
+        const int ns = (r < 4 || r >= 4 + tab.rp) ? t : 1;
+        for (int j = 0; j < ns; j++) {
+            const F x2 = hzh::f_sqr(st[j]), x4 = hzh::f_sqr(x2);
+            st[j] = hzh::f_mul(x4, st[j]);
+        }
+        for (int i = 0; i < t; i++) {
+            F acc = hzh::f_mul(tab.M[(size_t)i * t], st[0]);
+            for (int j = 1; j < t; j++) acc = hzh::f_add(acc, hzh::f_mul(tab.M[(size_t)i * t + j], st[j]));
+            nx[i] = acc;
+        }
+        for (int i = 0; i < t; i++) st[i] = nx[i];
+    }
+    return st[0];
+}
+extern "C" int hzb_poseidon(int n_in, const uint8_t* in, uint8_t* out) {
+    if (n_in < 1 || n_in > 6) return 1;
+    F x[6];
+    for (int i = 0; i < n_in; i++) x[i] = hzh::f_from_canon(in + 32 * i);
+    hzh::f_to_canon(host_poseidon(x, n_in), out);
+    return 0;
+}
+// `count` independent hashes of n_in inputs each: in = [count][n_in] elements, out = [count] digests
+extern "C" int hzb_poseidon_many(int n_in, uint64_t count, const uint8_t* in, uint8_t* out) {
+    if (n_in < 1 || n_in > 6) return 1;
+    for (uint64_t k = 0; k < count; k++) {
+        F x[6];
+        for (int i = 0; i < n_in; i++) x[i] = hzh::f_from_canon(in + 32 * (k * n_in + i));
+        hzh::f_to_canon(host_poseidon(x, n_in), out + 32 * k);
+    }
+    return 0;
+}
+
+// ---- BabyJubjub (twisted Edwards a = 168700, d = 168696), extended coordinates, on the host field -------------------------------
+struct HPt { F X, Y, Z, T; };
+static HPt hpt_from_affine(const F& x, const F& y) { return HPt{x, y, hzh::f_one(), hzh::f_mul(x, y)}; }
+static HPt hpt_add(const HPt& p, const HPt& q, const F& a, const F& d) {   // add-2008-hwcd, unified
+    using namespace hzh;
+    const F A = f_mul(p.X, q.X), B = f_mul(p.Y, q.Y), C = f_mul(f_mul(p.T, q.T), d), D = f_mul(p.Z, q.Z);
+    const F E = f_sub(f_sub(f_mul(f_add(p.X, p.Y), f_add(q.X, q.Y)), A), B);
+    const F Fv = f_sub(D, C), G = f_add(D, C), H = f_sub(B, f_mul(a, A));
+    return HPt{f_mul(E, Fv), f_mul(G, H), f_mul(Fv, G), f_mul(E, H)};
+}
+static void hpt_to_affine(const HPt& p, uint8_t* ox, uint8_t* oy) {
+    const F zi = hzh::f_inv(p.Z);
+    hzh::f_to_canon(hzh::f_mul(p.X, zi), ox);
+    hzh::f_to_canon(hzh::f_mul(p.Y, zi), oy);
+}
+// (ox,oy) = k * (px,py), affine Edwards coordinates, k a 256-bit LE integer
+extern "C" int hzb_bjj_mul(const uint8_t* px, const uint8_t* py, const uint8_t* k, uint8_t* ox, uint8_t* oy) {
+    const F a = hzh::f_from_u64(168700), d = hzh::f_from_u64(168696);
+    const HPt p = hpt_from_affine(hzh::f_from_canon(px), hzh::f_from_canon(py));
+    HPt acc{hzh::f_zero(), hzh::f_one(), hzh::f_one(), hzh::f_zero()};
+    for (int i = 255; i >= 0; i--) {
+        acc = hpt_add(acc, acc, a, d);
+        if ((k[i >> 3] >> (i & 7)) & 1) acc = hpt_add(acc, p, a, d);
+    }
+    hpt_to_affine(acc, ox, oy);
+    return 0;
+}
+extern "C" int hzb_bjj_add(const uint8_t* px, const uint8_t* py, const uint8_t* qx, const uint8_t* qy, uint8_t* ox, uint8_t* oy) {
+    const F a = hzh::f_from_u64(168700), d = hzh::f_from_u64(168696);
+    hpt_to_affine(hpt_add(hpt_from_affine(hzh::f_from_canon(px), hzh::f_from_canon(py)), hpt_from_affine(hzh::f_from_canon(qx), hzh::f_from_canon(qy)), a, d), ox, oy);
+    return 0;
+}
+
+// ---- self test hooks: the device-form (9 x 29-bit) routines compiled for the host ----------------------------------------------
 static Fr load(const uint8_t* b) {
     Fc c;
     memcpy(c.v, b, 32);
@@ -24,14 +126,13 @@ static void store(uint8_t* b, const Fr& m) {
     const Fc c = fr_to_canon(m);
     memcpy(b, c.v, 32);
 }
-
 template <int T>
 static Fr hash_t(const Fr* in, const uint32_t (*K)[9]) {
     NoSink s;
     return poseidon_hash<T>(in, reinterpret_cast<const Fr*>(K), s);
 }
-
-extern "C" int hzb_poseidon(int n_in, const uint8_t* in, uint8_t* out) {
+// the digest through the device's sparse-form permutation (poseidon.h): must equal hzb_poseidon
+extern "C" int hzb_poseidon_dev9(int n_in, const uint8_t* in, uint8_t* out) {
     Fr x[6];
     if (n_in < 1 || n_in > 6) return 1;
     for (int i = 0; i < n_in; i++) x[i] = load(in + 32 * i);
@@ -47,30 +148,10 @@ extern "C" int hzb_poseidon(int n_in, const uint8_t* in, uint8_t* out) {
     store(out, h);
     return 0;
 }
-
-// (ox,oy) = k * (px,py) on BabyJubjub, affine Edwards coordinates, k a 256-bit LE integer
-extern "C" int hzb_bjj_mul(const uint8_t* px, const uint8_t* py, const uint8_t* k, uint8_t* ox, uint8_t* oy) {
-    uint32_t kk[8];
-    memcpy(kk, k, 32);
-    const PtE r = pte_mul(pte_from_affine(load(px), load(py)), kk);
-    Fr x, y;
-    pte_to_affine(r, x, y);
-    store(ox, x);
-    store(oy, y);
-    return 0;
-}
-// self test hooks: both inverses of a canonical element (Montgomery domain inside)
+// both inverses of a canonical element (Montgomery domain inside)
 extern "C" int hzb_fr_inv(const uint8_t* x, uint8_t* safegcd_out, uint8_t* fermat_out) {
     const Fr a = load(x);
     store(safegcd_out, fr_inv(a));
     store(fermat_out, fr_inv_fermat(a));
-    return 0;
-}
-extern "C" int hzb_bjj_add(const uint8_t* px, const uint8_t* py, const uint8_t* qx, const uint8_t* qy, uint8_t* ox, uint8_t* oy) {
-    const PtE r = pte_add(pte_from_affine(load(px), load(py)), pte_from_affine(load(qx), load(qy)), bj_a(), bj_d());
-    Fr x, y;
-    pte_to_affine(r, x, y);
-    store(ox, x);
-    store(oy, y);
     return 0;
 }
