@@ -436,6 +436,7 @@ def main():
     ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon-BN254/sec secondary metric")
     ap.add_argument("--no-withdraw", action="store_true", help="skip the config-5 (withdraw) secondary line")
     ap.add_argument("--no-e2e", action="store_true", help="skip the upload-inclusive run (value_e2e)")
+    ap.add_argument("--python-builder", action="store_true", help="build the synthetic batches with the Python builder in a process pool (host hashing) instead of the native builder + hz_poseidon_dag")
     ap.add_argument("--no-node", action="store_true", help="skip value_node (the same loop driven from Node.js through the N-API addon)")
     ap.add_argument("--keep-packed", default="", help="leave the packed batches and their expected outputs at PATH.packed / PATH.json (the Node host line reads them)")
     ap.add_argument("--gpu-worker", action="store_true", help=argparse.SUPPRESS)   # internal: the process that touches the GPU (see main)
@@ -501,9 +502,23 @@ def main():
     n_build = len(seeds) + (1 if want_shard else 0)
     build_workers = args.build_workers or max(1, min(n_build, 64, ((os.cpu_count() or 2) - 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))),
                                                    int(host_limits()[1] // 4 // (3 << 30)) or 1))
-    batches = build_packed_batches(seeds + ([SEED] if want_shard else []), nTx, lv, m1, F, n_acc, layout, build_workers)
+    pbytes = layout[0]
+    all_seeds = seeds + ([SEED] if want_shard else [])
+    native = not args.python_builder and n_acc >= 16 and n_acc & (n_acc - 1) == 0
+    builder_stats = None
+    if native:
+        # the native batch builder (libhz_host.so): walk + signing in C++, each batch's hashes as one DAG on this rank's GPU, the packed
+        # inputs written straight into the pinned buffer the uploads read
+        from circuits_amd.batchgen import build_packed_batches_native
+        pin_all = L.host_alloc(pbytes * len(all_seeds))
+        batches, builder_stats = build_packed_batches_native(all_seeds, nTx, lv, m1, F, n_acc, layout, L, local, pin_all)
+        batches = [(pin_all + i * pbytes, b[1], b[2]) for i, b in enumerate(batches)]
+    else:
+        batches = build_packed_batches(all_seeds, nTx, lv, m1, F, n_acc, layout, build_workers)
     t_build = time.time() - t_build
     shared = batches.pop() if want_shard else None
+    if shared is not None and native:
+        shared = (ctypes.string_at(shared[0], pbytes), shared[1], shared[2])
     n_l2 = (batches[0] if batches else shared)[2]
     if args.shard_tx:
         res = bench_sharded(args, L, D, shared[0], shared[1])
@@ -517,10 +532,12 @@ def main():
                                            "unit": "GB/s", "frac": round(res["whole_pass_GBs"] / (HBM_PEAK_GBS * world), 5), "traffic": None}}))
         return D.close()
     # pinned host copies of the packed inputs: the source of every upload
-    pbytes = layout[0]
-    pin = L.host_alloc(pbytes * n_distinct)
-    for i, (pk, _, _) in enumerate(batches):
-        ctypes.memmove(pin + i * pbytes, pk, pbytes)
+    if native:
+        pin = pin_all
+    else:
+        pin = L.host_alloc(pbytes * n_distinct)
+        for i, (pk, _, _) in enumerate(batches):
+            ctypes.memmove(pin + i * pbytes, pk, pbytes)
     expected = [b[1] for b in batches]
     del batches
     packed_file = None
@@ -647,20 +664,24 @@ def main():
         t_deep = time.time()
         kk = args.deep_accounts_log2
         base = B.DenseState.build(kk, seed=SEED ^ 0xD33F, hash_rows=lambda t, n, data: L.poseidon_batch_bytes(t, n, data, device=local))
-        fd, base_path = tempfile.mkstemp(suffix=".npz", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-        os.close(fd)
-        base.save(base_path)
         t_base = time.time() - t_deep
         n_deep = min(8, n_res)
-        try:
-            dbatches = build_packed_batches([SEED + 77000 + i for i in range(n_deep)], nTx, lv, m1, F, 0, layout, min(n_deep, build_workers), base_path=base_path)
-        finally:
-            os.unlink(base_path)
+        dseeds = [SEED + 77000 + i for i in range(n_deep)]
+        dpin = L.host_alloc(pbytes * n_deep)
+        if native:
+            dbatches, _ = build_packed_batches_native(dseeds, nTx, lv, m1, F, 0, layout, L, local, dpin, base=base)
+        else:
+            fd, base_path = tempfile.mkstemp(suffix=".npz", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            os.close(fd)
+            base.save(base_path)
+            try:
+                dbatches = build_packed_batches(dseeds, nTx, lv, m1, F, 0, layout, min(n_deep, build_workers), base_path=base_path)
+            finally:
+                os.unlink(base_path)
+            for i, (pk, _, _) in enumerate(dbatches):
+                ctypes.memmove(dpin + i * pbytes, pk, pbytes)
         del base
         t_deep = time.time() - t_deep
-        dpin = L.host_alloc(pbytes * n_deep)
-        for i, (pk, _, _) in enumerate(dbatches):
-            ctypes.memmove(dpin + i * pbytes, pk, pbytes)
         dexp = [b[1] for b in dbatches]
         del dbatches
         for k in range(inflight):
@@ -722,7 +743,11 @@ def main():
             "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "batches_per_launch": Bp, "contexts_in_flight": inflight,
                        "distinct_batches": n_distinct, "state_accounts": n_acc, "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
                        "world_size": world, "backend": D.backend if world > 1 else None,
-                       "witness_bytes_per_batch": witness_bytes, "step_latency_ms": round(single_ms, 3), "batch_build_s": round(t_build, 1)},
+                       "witness_bytes_per_batch": witness_bytes, "step_latency_ms": round(single_ms, 3), "batch_build_s": round(t_build, 1),
+                       "batch_builder": ({"kind": "native (libhz_host.so hzb_batch_build) + hz_poseidon_dag", "batches": len(all_seeds),
+                                          "hashes": builder_stats["jobs"], "dag_segments": builder_stats["segments"], "device_ms": round(builder_stats["device_ms"], 1),
+                                          "walk_and_sign_s": round(builder_stats["walk_s"], 2), "evaluator_s": round(builder_stats["eval_s"], 2)}
+                                         if builder_stats else {"kind": "python (circuits_amd/builder.py), host hashing, process pool", "batches": len(all_seeds)})},
             "roofline": {"bound": "hbm", "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dk, Bp),
                          "launches_per_step": dlaunches, "launch_ms": round(dms / dlaunches, 3),

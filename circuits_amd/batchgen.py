@@ -4,7 +4,11 @@ The batch builder (circuits_amd/builder.py, the counterpart of @hermeznetwork/co
 tools/generate-input.js:61-109) is caller-side work: a rollup coordinator produces the circuit inputs, the witness generator
 consumes them. bench.py needs many DIFFERENT batches resident at once (64 at the default shape), so a process pool builds them
 -- one seeded batch per task, host hashing, no GPU in the workers -- and returns each one already in the packed bulk-upload
-format of hz_inputs_upload together with the public hash the builder expects."""
+format of hz_inputs_upload together with the public hash the builder expects.
+
+build_packed_batches_native is the same job on the NATIVE builder (circuits_amd/native_builder.py over libhz_host.so): the walk and
+the signing in C++, the hashing of each batch as one DAG on the GPU (hz_poseidon_dag), the packed buffer written straight into the
+caller's pinned memory -- in the calling process, one batch after another (a fifth of a second each at the headline shape)."""
 import os
 import sys
 
@@ -40,3 +44,22 @@ def build_packed_batches(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, lay
         return [_one(t) for t in tasks]
     with mp.get_context("spawn").Pool(workers) as pool:   # spawn: the parent holds a HIP context
         return pool.map(_one, tasks, chunksize=1)
+
+
+def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, lib, device, out_addr, base=None):
+    """one batch per seed, written to out_addr + i * layout[0] (pinned host memory): [(None, expected hashGlobalInputs, signed L2
+    transactions)] plus the builder's counters. n_accounts must be a power of two >= 16 unless a shared `base` (DenseState) is given."""
+    from circuits_amd import builder as B
+    from circuits_amd import native_builder as NB
+    tables = NB.layout_tables(layout)
+    hash_rows = lambda t, n, data: lib.poseidon_batch_bytes(t, n, data, device=device)   # noqa: E731
+    res, stats = [], {"jobs": 0, "segments": 0, "device_ms": 0.0, "walk_s": 0.0, "eval_s": 0.0}
+    for i, seed in enumerate(seeds):
+        b = base if base is not None else B.DenseState.build(n_accounts.bit_length() - 1, seed=seed, hash_rows=hash_rows)
+        bb, _, hgi = NB.synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, tables, seed=seed, device=device, base=b, out=out_addr + i * layout[0])
+        for k, v in bb.stats().items():
+            stats[k] += v
+        res.append((None, hgi, n_tx - min(max_l1, n_tx)))
+        bb.close()
+        bb._db_keep.close()
+    return res, stats

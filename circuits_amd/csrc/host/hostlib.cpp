@@ -13,6 +13,7 @@
 #include "../babyjub.h"
 #include "../poseidon.h"
 #include "hostfield.h"
+#include "../../../include/hz_host.h"
 
 namespace hz {
 #define HZ_CONST_ARR static const
@@ -113,6 +114,30 @@ extern "C" int hzb_bjj_mul(const uint8_t* px, const uint8_t* py, const uint8_t* 
 extern "C" int hzb_bjj_add(const uint8_t* px, const uint8_t* py, const uint8_t* qx, const uint8_t* qy, uint8_t* ox, uint8_t* oy) {
     const F a = hzh::f_from_u64(168700), d = hzh::f_from_u64(168696);
     hpt_to_affine(hpt_add(hpt_from_affine(hzh::f_from_canon(px), hzh::f_from_canon(py)), hpt_from_affine(hzh::f_from_canon(qx), hzh::f_from_canon(qy)), a, d), ox, oy);
+    return 0;
+}
+
+// k * Base8 (circomlib babyjub.js Base8 = 8 * Generator): 64 windows of 4 bits, table of j * 16^w * Base8 built at first use
+extern "C" int hzb_bjj_mul_base8(const uint8_t* k, uint8_t* ox, uint8_t* oy) {
+    static const uint64_t BX[4] = {0x2893f3f6bb957051ull, 0x2ab8d8010534e0b6ull, 0x4eacb2e09d6277c1ull, 0x0bb77a6ad63e739bull};
+    static const uint64_t BY[4] = {0x4b3c257a872d7d8bull, 0xfce0051fb9e13377ull, 0x25572e1cd16bf9edull, 0x25797203f7a0b249ull};
+    static const F a = hzh::f_from_u64(168700), d = hzh::f_from_u64(168696);
+    static const std::vector<HPt> table = [] {
+        std::vector<HPt> t(64 * 16);
+        HPt base = hpt_from_affine(hzh::f_from_words(BX), hzh::f_from_words(BY));
+        for (int w = 0; w < 64; w++) {
+            t[(size_t)w * 16] = HPt{hzh::f_zero(), hzh::f_one(), hzh::f_one(), hzh::f_zero()};
+            for (int j = 1; j < 16; j++) t[(size_t)w * 16 + j] = hpt_add(t[(size_t)w * 16 + j - 1], base, a, d);
+            base = hpt_add(t[(size_t)w * 16 + 15], base, a, d);
+        }
+        return t;
+    }();
+    HPt acc{hzh::f_zero(), hzh::f_one(), hzh::f_one(), hzh::f_zero()};
+    for (int w = 0; w < 64; w++) {
+        const int nib = (k[w >> 1] >> (4 * (w & 1))) & 15;
+        if (nib) acc = hpt_add(acc, table[(size_t)w * 16 + nib], a, d);
+    }
+    hpt_to_affine(acc, ox, oy);
     return 0;
 }
 

@@ -1,0 +1,287 @@
+"""The native batch builder (circuits_amd/libhz_host.so hzb_db_* / hzb_batch_*, include/hz_host.h) against the Python builder it
+replaces on the hot side of the coordinator: every batch the suites build -- the scenario batches of tests/scenarios.py, all recorded
+scripts of the reference's test/rollup-tx.test.js and test/rollup-main.test.js (tests/golden/reference_scripts.json), synthetic
+batches with and without a pre-populated DenseState -- is built by BOTH from the same transaction objects, and the packed input
+buffers, hashGlobalInputs, roots, nullifier flags, exit proofs and rejections must be identical. Role in the reference:
+@hermeznetwork/commonjs BatchBuilder (test/helpers/helpers.js:46,148, tools/generate-input.js:70-107)."""
+import copy
+import ctypes
+import json
+import os
+
+import pytest
+
+from circuits_amd import builder as B
+from circuits_amd import native_builder as NB
+from circuits_amd.capi import pack_inputs, _flatten
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def make_layout(nTx, L, F):
+    """a packed layout over EVERY signal the Python builder emits (the real circuit's list is a subset; offsets are arbitrary for the builder)"""
+    per_tx = ("txCompressedData amountF txCompressedDataV2 fromIdx auxFromIdx toIdx auxToIdx toBjjAy toEthAddr maxNumBatch onChain newAccount rqOffset "
+              "rqTxCompressedDataV2 rqToEthAddr rqToBjjAy s r8x r8y loadAmountF fromEthAddr tokenID1 nonce1 sign1 balance1 ay1 ethAddr1 isOld0_1 oldKey1 "
+              "oldValue1 tokenID2 nonce2 sign2 balance2 ay2 ethAddr2 newExit isOld0_2 oldKey2 oldValue2").split()
+    sizes = {n: nTx for n in per_tx}
+    sizes.update({"fromBjjCompressed": nTx * 256, "siblings1": nTx * (L + 1), "siblings2": nTx * (L + 1), "imOnChain": nTx - 1, "imOutIdx": nTx - 1,
+                  "imStateRoot": nTx - 1, "imExitRoot": nTx - 1, "imAccFeeOut": (nTx - 1) * F, "oldLastIdx": 1, "oldStateRoot": 1, "globalChainID": 1,
+                  "currentNumBatch": 1, "feePlanTokens": F, "imInitStateRootFee": 1, "imFinalAccFee": F, "feeIdxs": F, "siblings3": F * (L + 1),
+                  "imStateRootFee": F - 1})
+    for n in ("tokenID3", "nonce3", "sign3", "balance3", "ay3", "ethAddr3"):
+        sizes[n] = F
+    sigs, off = [], 0
+    for name in sorted(sizes):
+        w = 1 if name == "fromBjjCompressed" else 32
+        sigs.append((name, off, w, sizes[name]))
+        off += w * sizes[name] + 7   # odd gaps: offsets are the layout's business
+    return off, sigs
+
+
+class ShadowBatch(B.BatchBuilder):
+    """builds the batch twice -- Python and native -- and compares everything the two expose"""
+    checked = 0
+
+    def build(self):
+        db = self.db
+        db.sync_native()
+        txs = [dict(t) for t in self.txs]
+        nb = db.native.build_batch(self.nTx, self.L, self.maxL1, self.F)
+        py_err = nat_err = None
+        try:
+            super().build()
+        except (ValueError, KeyError) as e:
+            py_err = e
+        layout = make_layout(self.nTx, self.L, self.F)
+        packed = hgi = None
+        try:
+            for t in txs:
+                nb.add_tx(t)
+            for t in self.fee_tokens:
+                nb.add_token(t)
+            for i in self.fee_idxs:
+                nb.add_fee_idx(i)
+            packed, hgi = nb.build(layout)
+        except NB.BuilderError as e:
+            nat_err = e
+        assert (py_err is None) == (nat_err is None), (py_err, nat_err)
+        if py_err is not None:
+            ShadowBatch.checked += 1
+            raise py_err
+        inp = self.get_input()
+        assert set(inp) == {s[0] for s in layout[1]}
+        want = pack_inputs(layout, inp)
+        if packed != want:
+            for name, off, w, n in layout[1]:
+                a, b = packed[off:off + w * n], want[off:off + w * n]
+                if a != b:
+                    k = next(i for i in range(n) if a[w * i:w * i + w] != b[w * i:w * i + w])
+                    raise AssertionError("native builder: %s[%d] = %s, Python builder: %s" % (
+                        name, k, int.from_bytes(a[w * k:w * k + w], "little"), int.from_bytes(b[w * k:w * k + w], "little")))
+            raise AssertionError("native builder wrote outside the layout's signals")
+        assert hgi == self.get_hash_inputs()
+        assert nb.roots() == (self.new_state_root, self.new_exit_root, self.new_last_idx)
+        assert [nb.is_amount_nullified(i) for i in range(self.nTx)] == [m["isAmountNullified"] for m in self.tx_meta]
+        for idx in self.exit_leaves:
+            w_in, _ = B.withdraw_input(self, idx, self.L)
+            lf, sib = nb.exit_proof(idx)
+            assert lf == self.exit_leaves[idx] and sib == w_in["siblingsState"]
+        for idx, st in db.leaves.items():
+            assert db.native.account(idx) == st
+        assert db.native.last_idx == db.last_idx and db.native.num_batch == db.num_batch
+        ShadowBatch.checked += 1
+        return self
+
+
+class ShadowDB(B.RollupDB):
+    def __init__(self, chain_id=1, device=None, dag_evaluator=None, first_idx=256, base=None):
+        super().__init__(chain_id=chain_id, device=device, dag_evaluator=dag_evaluator, first_idx=first_idx, base=base)
+        self.native = NB.NativeRollupDB(chain_id=chain_id, first_idx=first_idx, base=base, dag_fn=getattr(ShadowDB, "dag_fn", None))
+
+    def __copy__(self):
+        c = object.__new__(type(self))
+        c.__dict__.update(self.__dict__)
+        c.native = self.native.clone()
+        return c
+
+    def sync_native(self):
+        """accounts the suite put into the state directly (pre-population) reach the native database the same way"""
+        for idx in range(self.native.last_idx + 1, self.last_idx + 1):
+            assert self.native.add_account(self.leaves[idx]) == idx
+
+    def build_batch(self, n_tx, n_levels, max_l1, max_fee):
+        return ShadowBatch(self, n_tx, n_levels, max_l1, max_fee)
+
+
+@pytest.fixture
+def shadow(monkeypatch):
+    monkeypatch.setattr(B, "RollupDB", ShadowDB)
+    ShadowBatch.checked = 0
+    ShadowDB.dag_fn = None
+    yield ShadowBatch
+    ShadowDB.dag_fn = None
+
+
+def test_native_builder_on_the_scenario_batches(shadow):
+    import scenarios as S
+    S.all_tx_types()
+    S.atomic_pair()
+    S.eddsa_kat_rollup_tx()
+    S.config2_batch()
+    S.reference_rollup_main_scripts()
+    S.reference_l1_edge_scripts()
+    assert shadow.checked >= 7
+
+
+def test_native_builder_replays_every_recorded_reference_script(shadow):
+    import test_reference_scripts as R
+    n = 0
+    for case in R.SCRIPTS:
+        ops = [op for op in case["ops"] if op["op"] in ("newState", "buildBatch", "addTx", "addToken", "addFeeIdx", "build", "consolidate", "assertBalances")]
+        rp = R.Replay(None, None)
+        try:
+            rp.play({"case": case["case"], "ops": ops})
+        except (ValueError, KeyError):
+            pass   # a script that ends in a rejected build: both builders rejected it (ShadowBatch.build compared them)
+        n += 1
+    assert n == len(R.SCRIPTS) and shadow.checked >= n
+
+
+def test_native_builder_on_synthetic_batches(shadow):
+    # direct state construction (add_account), exits, several batches on one database
+    for seed, shape, kw in ((7, (16, 16, 4, 2), {"n_accounts": 40}), (8, (24, 10, 8, 3), {"n_accounts": 64, "exits": 5}), (9, (8, 8, 3, 2), {"n_accounts": 20, "first_idx": 2})):
+        bb = B.synthetic_batch(*shape, seed=seed, **kw)
+        assert bb.built
+    assert shadow.checked == 3
+
+
+def test_native_builder_on_a_dense_state(shadow):
+    base = B.DenseState.build(6, seed=11, first_idx=256)
+    bb = B.synthetic_batch(20, 16, 6, 2, seed=12, base=base, exits=3)
+    assert bb.built
+    # the recipe of the native module itself gives the same bytes as the Python builder's batch
+    layout = make_layout(20, 16, 2)
+    nb, packed, hgi = NB.synthetic_batch_native(20, 16, 6, 2, layout, seed=12, base=base, exits=3)
+    assert packed == pack_inputs(layout, bb.get_input()) and hgi == bb.get_hash_inputs()
+    st = nb.stats()
+    assert st["jobs"] > 200 and st["segments"] >= 8
+    # new accounts beyond the dense range share residues with base leaves: the tree pushes base leaves down
+    base = B.DenseState.build(4, seed=13, first_idx=256)
+    bb = B.synthetic_batch(40, 12, 30, 2, seed=14, base=base)
+    assert bb.built and shadow.checked == 2
+
+
+def test_native_builder_through_a_dag_evaluator(shadow):
+    """the DAG interface itself (what hz_poseidon_dag receives on the GPU): segments in dependency order, one width per segment, no job
+    reading a value a later segment produces -- evaluated here by the host library"""
+    import numpy as np
+    h = B.host()
+    seen = {"calls": 0, "segments": 0}
+
+    def evaluator(device, vals, n_vals, job_in, job_out, n_jobs, seg_t, seg_first, seg_count, n_seg, device_ms):
+        v = (ctypes.c_uint8 * (32 * n_vals)).from_address(vals)
+        ji = np.frombuffer((ctypes.c_uint32 * (6 * n_jobs)).from_address(job_in), dtype=np.uint32).reshape(n_jobs, 6)
+        jo = np.frombuffer((ctypes.c_uint32 * n_jobs).from_address(job_out), dtype=np.uint32)
+        st = np.frombuffer((ctypes.c_uint32 * n_seg).from_address(seg_t), dtype=np.uint32)
+        sf = np.frombuffer((ctypes.c_uint64 * n_seg).from_address(seg_first), dtype=np.uint64)
+        sc = np.frombuffer((ctypes.c_uint64 * n_seg).from_address(seg_count), dtype=np.uint64)
+        done = np.zeros(n_vals, dtype=bool)
+        done[n_jobs:] = True   # constants
+        assert int(sc.sum()) == n_jobs
+        for t, first, count in zip(st.tolist(), sf.tolist(), sc.tolist()):
+            assert 2 <= t <= 7
+            rows = ji[first:first + count, :t - 1]
+            assert done[rows].all(), "a job reads a value that a later segment produces"
+            raw = bytes(v)
+            data = b"".join(raw[32 * int(i):32 * int(i) + 32] for i in rows.reshape(-1))
+            out = h.poseidon_many(t, count, data)
+            for k, o in enumerate(jo[first:first + count].tolist()):
+                v[32 * o:32 * o + 32] = list(out[32 * k:32 * k + 32])
+            done[jo[first:first + count]] = True
+        assert done.all()
+        seen["calls"] += 1
+        seen["segments"] += n_seg
+        return 0
+
+    ShadowDB.dag_fn = NB.DAG_FN(evaluator)
+    import scenarios as S
+    S.all_tx_types()
+    S.config2_batch()
+    assert seen["calls"] >= 4 and shadow.checked >= 4
+
+
+def test_native_signing_matches_the_python_signer():
+    c = NB.host_lib()
+    for seed in (1, 2, 77):
+        a = B.Account(seed)
+        ax, ay = (ctypes.c_uint8 * 32)(), (ctypes.c_uint8 * 32)()
+        c.hzb_eddsa_pubkey(NB._b32(a.k), ax, ay)
+        assert (NB._int(ax), NB._int(ay)) == (a.ax, a.ay)
+        for msg in (0, 1, B.P - 1, 0x1234567890ABCDEF << 100):
+            want = a.sign_msg(msg)
+            r8x, r8y, s = (ctypes.c_uint8 * 32)(), (ctypes.c_uint8 * 32)(), (ctypes.c_uint8 * 32)()
+            c.hzb_eddsa_sign(NB._b32(a.k), NB._b32(msg), r8x, r8y, s)
+            assert {"r8x": NB._int(r8x), "r8y": NB._int(r8y), "s": NB._int(s)} == want
+
+
+def test_native_builder_reports_what_the_circuit_would_reject():
+    db = NB.NativeRollupDB()
+    a = B.Account(1)
+    bb = db.build_batch(4, 8, 2, 2)
+    bb.add_tx({"onChain": 1, "fromIdx": 0, "toIdx": 0, "tokenID": 1, "loadAmountF": B.fix2float(100), "fromBjjCompressed": a.bjj_compressed, "fromEthAddr": a.eth_addr})
+    bb.add_tx({"fromIdx": 256, "toIdx": 300, "amount": 10, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": a})
+    with pytest.raises(NB.BuilderError, match="receiver account 300 does not exist") as e:
+        bb.build(make_layout(4, 8, 2))
+    assert e.value.status == 2
+    bb = NB.NativeRollupDB().build_batch(2, 8, 1, 1)
+    for _ in range(2):
+        bb.add_tx({"onChain": 0})
+    with pytest.raises(NB.BuilderError, match="batch full"):
+        bb.add_tx({"onChain": 0})
+    with pytest.raises(NB.BuilderError, match="does not produce the input signal"):
+        NB.NativeRollupDB().build_batch(2, 8, 1, 1).build((64, [("notASignal", 0, 32, 1)]))
+    with pytest.raises(NB.BuilderError, match="packed buffer too small"):
+        NB.NativeRollupDB().build_batch(2, 8, 1, 1).build((16, [("oldLastIdx", 0, 32, 1)]))
+
+
+@pytest.mark.gpu
+def test_hip_native_builder_with_the_device_evaluator(hz):
+    """BASELINE config 3 shape on the real input layout: the native builder hashing through hz_poseidon_dag writes, into pinned memory,
+    the bytes the Python builder (host hashing) packs; the witness generator accepts them with the expected public hash; an exit of
+    that batch withdraws."""
+    from circuits_amd.batchgen import build_packed_batches_native
+    shape = dict(nTx=256, nLevels=16, maxL1Tx=128, maxFeeTx=64)
+    c = hz.ctx("rollup-main", n_instances=2, **shape)
+    layout = c.packed_layout()
+    total = layout[0]
+    seeds = [0x51, 0x52]
+    pin = hz.host_alloc(total * 2)
+    res, stats = build_packed_batches_native(seeds, 256, 16, 128, 64, 1024, layout, hz, 0, pin)
+    assert stats["jobs"] > 2 * 256 * 10 and stats["device_ms"] > 0 and stats["segments"] >= 2 * 12
+    for i, seed in enumerate(seeds):
+        bb = B.synthetic_batch(256, 16, 128, 64, seed=seed, n_accounts=1024, dense=True)
+        assert ctypes.string_at(pin + i * total, total) == pack_inputs(layout, bb.get_input())
+        assert res[i][1] == bb.get_hash_inputs() and res[i][2] == 128
+        c.upload(i, pin + i * total, total)
+    c.run()
+    for i in range(2):
+        assert c.get("main.hashGlobalInputs", i) == res[i][1]
+    # exits + a withdrawal proof from the native batch
+    base = B.DenseState.build(8, seed=0x61, hash_rows=lambda t, n, data: hz.poseidon_batch_bytes(t, n, data, device=0))
+    nb, packed, hgi = NB.synthetic_batch_native(256, 16, 128, 64, layout, seed=0x62, device=0, base=base, exits=4)
+    c.upload(0, packed)
+    c.run()
+    assert c.get("main.hashGlobalInputs", 0) == hgi
+    _, exit_root, _ = nb.roots()
+    w = hz.ctx("withdraw", nLevels=16)
+    done = 0
+    for idx in range(256, 256 + 256):
+        try:
+            lf, sib = nb.exit_proof(idx)
+        except NB.BuilderError:
+            continue
+        w.set_inputs({"rootExit": exit_root, "ethAddr": lf["ethAddr"], "tokenID": lf["tokenID"], "balance": lf["balance"], "idx": idx, "sign": lf["sign"],
+                      "ay": lf["ay"], "siblingsState": sib})
+        w.run()
+        done += 1
+    assert 1 <= done <= 4

@@ -28,6 +28,15 @@ def test_library_exports_every_declared_symbol():
     assert "gfx950" in L.version()
 
 
+def test_host_library_exports_every_declared_symbol():
+    import ctypes
+    hdr = open(os.path.join(ROOT, "include", "hz_host.h")).read()
+    declared = set(re.findall(r"\b(hzb_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    c = ctypes.CDLL(os.path.join(ROOT, "circuits_amd", "libhz_host.so"))
+    assert [s for s in sorted(declared) if not hasattr(c, s)] == []
+
+
 def test_no_cpu_fallback_without_device():
     from circuits_amd import HzError, lib
     L = lib()
