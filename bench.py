@@ -138,7 +138,7 @@ def measured_traffic(kernel, bpl):
     (profiles/r03_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
     this configuration."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_counters.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_counters.json")))
         if bpl is not None and d.get("batches_per_launch") != bpl:
             return None
         k = d["kernels"][kernel]
