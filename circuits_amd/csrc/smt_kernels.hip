@@ -145,9 +145,15 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
         if (o.fnc != ~0u) { io.put_m(o.fnc, fnc0); io.put_m(o.fnc + 1, fnc1); }
         io.put_m(o.enabled, enabled);
         num2bits_strict_dev(io, o.n2bOld, oldKey_c, P.cid_alias_old);
-        // isZero[i]: batched inverses, 8 at a time
+        // isZero[i]: batched inverses, 8 at a time. A group whose siblings are zero on every lane of the wavefront (the levels above
+        // the leaf: 20 of 33 in a tree of 2^13 accounts) needs no inversion: IsZero(0) = (inv 0, out 1).
         for (int base = 0; base < n; base += 8) {
             const int cnt = (n - base) < 8 ? (n - base) : 8;
+            const uint64_t grp = ((1ull << cnt) - 1ull) << base;
+            if (__all((zmask & grp) == grp)) {
+                for (int k = 0; k < cnt; k++) { io.put_c(o.isz + 2 * (base + k), fc_zero()); io.put_bit(o.isz + 2 * (base + k) + 1, 1u); }
+                continue;
+            }
             Fr z[8], zi[8];
             for (int k = 0; k < cnt; k++) { z[k] = io.in_m(P.siblings + base + k); zi[k] = z[k]; }
             batch_inv<8>(zi, cnt);
@@ -177,6 +183,23 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
     const Fr O = fr_mul(A2, isOld0);
     const Fr U = fr_sub(enabled, A2);
     const Fr m = fr_sub(A2, O);
+    // Levels that are empty for STRUCTURAL reasons (child and sibling are zero whatever the hashes are): from the level thr_lane on.
+    // Old side: the child of level k is root(k+1) = h1old * s_a(k+1), zero from k = kx on (k = kl on when m = 0: update / nop / insert
+    // into an empty slot); new side: both switcher inputs vanish above kx (from kl on when m = 0). The siblings above the highest
+    // non-zero one are zero by inspection. thr_wave = the first level that is empty for every lane of the wavefront.
+    // ABOVE thr_wave (k > thr_wave) every per-level signal of every lane is zero as well -- the state-machine states (k > kl, and
+    // k > kx or m = 0), the switcher auxiliaries and the roots (root(k) = h1 * s(k) with s(k) = 0): they are stored as zeros without
+    // the products and conversions (`dead`, wave-uniform; 19 of 33 levels in a tree of 2^13 accounts).
+    uint32_t thr_wave = (uint32_t)n;
+    {
+        const bool m_zero = fr_is_zero(m);
+        const uint64_t nz = ~zmask & ((n < 64 ? (1ull << n) : 0ull) - 1ull);
+        const int hi_nz = nz ? 63 - __builtin_clzll(nz) : -1;
+        int thr_lane = m_zero ? kl : (new_side ? kx + 1 : kx);
+        if (thr_lane < hi_nz + 1) thr_lane = hi_nz + 1;
+        if (thr_lane > n) thr_lane = n;
+        thr_wave = wave_max_u6((uint32_t)thr_lane);
+    }
     if (new_side) {
         Fr p_na = fr_sub(one, enabled), p_new1 = zero, p_old0 = zero, p_upd = zero;
         Fr last_sum = zero;
@@ -189,34 +212,36 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
             const Fr t_bot = (k >= kl && k < kx) ? m : zero;
             const Fr t_na = fr_add(fr_add(fr_add(p_new1, p_old0), p_na), p_upd);
             const uint32_t b = o.sm + SM_N * k;
-            io.put_m(b + SM_AUX1, aux1); io.put_m(b + SM_AUX2, aux2); io.put_m(b + SM_OLD0, t_old0); io.put_m(b + SM_NEW1, t_new1);
-            io.put_m(b + SM_BOT, t_bot);
+            if (thr_wave > 0 && (uint32_t)k > thr_wave) {
+                const Fc z0 = fc_zero();
+                io.put_c(b + SM_AUX1, z0); io.put_c(b + SM_AUX2, z0); io.put_c(b + SM_OLD0, z0); io.put_c(b + SM_NEW1, z0); io.put_c(b + SM_BOT, z0);
+            } else {
+                io.put_m(b + SM_AUX1, aux1); io.put_m(b + SM_AUX2, aux2); io.put_m(b + SM_OLD0, t_old0); io.put_m(b + SM_NEW1, t_new1);
+                io.put_m(b + SM_BOT, t_bot);
+            }
             if (k == n - 1) last_sum = fr_add(fr_add(fr_add(t_na, t_new1), t_old0), t_upd);
             p_old0 = t_old0; p_new1 = t_new1; p_na = t_na; p_upd = t_upd;
         }
         io.chk(P.cid_sm_final, last_sum, one);
     }
     const Fr mU = fr_add(m, U), OU = fr_add(O, U);
-    // Levels that are empty for STRUCTURAL reasons (child and sibling are zero whatever the hashes are): from the level thr_lane on.
-    // Old side: the child of level k is root(k+1) = h1old * s_a(k+1), zero from k = kx on (k = kl on when m = 0: update / nop / insert
-    // into an empty slot); new side: both switcher inputs vanish above kx (from kl on when m = 0). The siblings above the highest
-    // non-zero one are zero by inspection. thr_wave = the first level that is empty for every lane of the wavefront.
-    uint32_t thr_wave = (uint32_t)n;
-    {
-        const bool m_zero = fr_is_zero(m);
-        const uint64_t nz = ~zmask & ((n < 64 ? (1ull << n) : 0ull) - 1ull);
-        const int hi_nz = nz ? 63 - __builtin_clzll(nz) : -1;
-        int thr_lane = m_zero ? kl : (new_side ? kx + 1 : kx);
-        if (thr_lane < hi_nz + 1) thr_lane = hi_nz + 1;
-        if (thr_lane > n) thr_lane = n;
-        thr_wave = wave_max_u6((uint32_t)thr_lane);
-    }
     // level chain, bottom-up. Both sides run the level hash through ONE inlined copy of the permutation (the kernel's
     // hot code): wavefronts of the old and the new side that share a CU then share its instruction-cache lines.
     const int root_slot = new_side ? P.sc_root_new : P.sc_root_old;
     Fr child = zero;
     for (int k = n - 1; k >= 0; k--) {
         const uint32_t lv = o.levels + LV_SIZE * k;
+        if (thr_wave > 0 && (uint32_t)k > thr_wave) {
+            // dead level: nothing but zeros beside its (constant) hash block, which a hashing level stores
+            const Fc z0 = fc_zero();
+            if (!new_side) {
+                io.put_c(lv + LV_OLDSW_AUX, z0); io.put_c(lv + LV_AUX0, z0); io.put_c(lv + LV_OLDROOT, z0);
+            } else {
+                io.put_c(lv + LV_NEWSW_AUX, z0); io.put_c(lv + LV_AUX1, z0); io.put_c(lv + LV_AUX2, z0);
+                io.put_c(lv + LV_NEWSW_L, z0); io.put_c(lv + LV_NEWSW_R, z0); io.put_c(lv + LV_AUX3, z0); io.put_c(lv + LV_NEWROOT, z0);
+            }
+            continue;   // child stays zero
+        }
         const uint32_t sel = c_bit(newKey_c, k);
         const Fr sib = io.in_m(P.siblings + k);
         Fr hin[2];

@@ -40,11 +40,26 @@ struct DecResult {
     Fr fromIdx, toIdx, toBjjSign, amount, tokenID, nonce, userFee, sigL2Hash, outIdx, v2;
 };
 
+// L1TxFullData[160 + 255 - i] = fromBjjCompressed[i] * onChain (src/decode-tx.circom:300-303). The bit is an input signal (checked
+// boolean by RollupMain phase A): for 0 and 1 the product is 0 or onChain itself -- a copy, whatever onChain is; anything else takes
+// the field product.
+__device__ __forceinline__ void l1full_bjj_bit_dev(const UnitIO& io, uint32_t l1full, int i, const Fc& b, const Fr& onChain, const Fc& on_c) {
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++) hi |= b.v[k];
+    const uint32_t sig = l1full + (160 + 256 - 1 - i);
+    if (hi == 0 && b.v[0] <= 1u) io.put_c(sig, b.v[0] ? on_c : fc_zero());
+    else io.put_m(sig, fr_mul(fr_from_canon(b), onChain));
+}
+
 // DecodeTx. `IN` provides the signal offsets of the inputs inside the lane's section (MainTxInOff
 // or DecInOff share the member names used here). K7 = Poseidon t=7 constant block.
+// `with_bjj` = false: the 256 fromBjjCompressed rows of L1TxFullData are somebody else's (k_main_front: the RollupTx-front lane reads
+// those bits anyway -- l1full_bjj_bit_dev -- so that 8 KB of input per transaction are read once instead of three times).
 template <class IN>
 __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOff& o, const IN& in, int L, const Fr& previousOnChain,
-                                                   const Fr& inIdx, const Fr& globalChainID, const Fr& currentNumBatch, const Fr* K7) {
+                                                   const Fr& inIdx, const Fr& globalChainID, const Fr& currentNumBatch, const Fr* K7,
+                                                   bool with_bjj = true) {
     DecResult r;
     const Fr one = fr_one();
     const Fr onChain = io.in_m(in.onChain), newAccount = io.in_m(in.newAccount);
@@ -129,10 +144,8 @@ __device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOf
     {
         auto put = [&](int pos, uint32_t bit) { io.put_c(o.l1full + pos, bit ? on_c : fc_zero()); };
         for (int i = 0; i < 160; i++) put(160 - 1 - i, c_bit(fe, i));
-        for (int i = 0; i < 256; i++) {
-            // fromBjjCompressed[i] is an input signal (checked boolean by RollupMain phase A)
-            const Fr b = io.in_m(in.fromBjjCompressed + i);
-            io.put_m(o.l1full + (160 + 256 - 1 - i), fr_mul(b, onChain));
+        if (with_bjj) {
+            for (int i = 0; i < 256; i++) l1full_bjj_bit_dev(io, o.l1full, i, io.in_c(in.fromBjjCompressed + i), onChain, on_c);
         }
         for (int i = 0; i < 48; i++) put(160 + 256 + 48 - 1 - i, c_bit(d, 48 + i));
         for (int i = 0; i < 40; i++) put(160 + 256 + 48 + 40 - 1 - i, c_bit(la, i));
@@ -367,9 +380,11 @@ struct FrontOut {
 // RollupTx phases A, B, C, E, G, H and the preparation of D/I (hash-state inputs), J (keys, fnc)
 // and F (signature inputs). `IN` gives the offsets of the per-unit inputs (MainTxInOff / RtxInOff).
 // accFeeIn / feePlanTokens are read through the pointers (Montgomery conversion on load).
+// `l1full` != ~0u (k_main_front): this lane also stores DecodeTx's L1TxFullData rows of the fromBjjCompressed bits (signal offset of
+// L1TxFullData in the section) and makes RollupMain's boolean check of them (`bjj_bool_cid`), from the one read of those inputs.
 template <class IN, class FEE>
 __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const Scratch& sc, const RtxOff& o, const IN& in, const RtxExt& x,
-                                                       int Fn, const FEE& feeSrc, bool own_sig = true) {
+                                                       int Fn, const FEE& feeSrc, bool own_sig = true, uint32_t l1full = ~0u, int bjj_bool_cid = -1) {
     const Fr one = fr_one(), zero = fr_zero();
     const Fr onChain = io.in_m(in.onChain), newAccount = io.in_m(in.newAccount);
     const Fr notOn = fr_sub(one, onChain);
@@ -510,10 +525,19 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
         // fromBjjCompressed are boolean inputs (RollupMain phase A); pack bits 0..253 into an integer
         Fr acc = fr_zero();
         bool all_bool = true;
-        for (int i = 0; i < 254; i++) {
+        const Fc on_c = l1full != ~0u ? fr_to_canon(onChain) : fc_zero();
+        for (int i = 0; i < (l1full != ~0u ? 256 : 254); i++) {
             const Fc b = io.in_c(in.fromBjjCompressed + i);
             bool is1 = b.v[0] == 1u, is0 = b.v[0] == 0u;
             for (int k = 1; k < 8; k++) { is1 = is1 && b.v[k] == 0u; is0 = is0 && b.v[k] == 0u; }
+            if (l1full != ~0u) {
+                l1full_bjj_bit_dev(io, l1full, i, b, onChain, on_c);
+                if (!(is0 || is1) && bjj_bool_cid >= 0) {
+                    const Fr v = fr_from_canon(b);
+                    io.chk_zero(bjj_bool_cid, fr_mul(v, fr_sub(v, one)));
+                }
+            }
+            if (i >= 254) continue;
             if (!(is0 || is1)) all_bool = false;
             if (is1) bjjAy_c.v[i >> 5] |= 1u << (i & 31);
         }

@@ -48,6 +48,9 @@ struct FeeSrcRtx {
 // Two lanes per transaction (blockIdx.y): 0 = RollupMain's boolean checks, DecodeTx and the im* checks on its outputs; 1 = the
 // RollupTx front logic, which takes the few DecodeTx outputs it consumes straight from the input bits (decode_fields_dev). The halves
 // share no signal; a single batch has 32 wavefronts per half and the kernel is the head of both of its critical paths.
+// The 256 fromBjjCompressed input rows (8 KB per transaction) are read by lane 1 only: it packs them into the key (its own job),
+// checks them boolean (RollupMain phase A) and stores DecodeTx's L1TxFullData rows bit * onChain as copies -- round 2 read them three
+// times and paid three field conversions per bit (1.1 GB of the kernel's 4.6 GB of reads, a quarter of lane 0's instructions).
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_main_front(const MainFrontArgs a) {
     const Fr* K7 = poseidon_consts_w<7>();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,18 +69,13 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
         if (i + 1 < a.nTx) bool_chk(C_MAIN_IMONCHAIN_BOOL, io.in_m(m.imOnChain));
         bool_chk(C_MAIN_ONCHAIN_BOOL, io.in_m(m.onChain));
         bool_chk(C_MAIN_NEWACCOUNT_BOOL, io.in_m(m.newAccount));
-        for (int j = 0; j < 256; j++) {
-            const Fc b = io.in_c(m.fromBjjCompressed + j);
-            uint32_t hi = 0;
-            for (int k = 1; k < 8; k++) hi |= b.v[k];
-            if (hi || b.v[0] > 1u) bool_chk(C_MAIN_BJJ_BOOL, fr_from_canon(b));
-        }
+        // (the boolean check of the 256 fromBjjCompressed bits and their L1TxFullData rows: the other lane, which reads them anyway)
         bool_chk(C_MAIN_ISOLD0_1_BOOL, io.in_m(m.isOld0_1));
         bool_chk(C_MAIN_ISOLD0_2_BOOL, io.in_m(m.isOld0_2));
         // B
         const Fr previousOnChain = i == 0 ? one : io.in_m_u(m.imOnChain, u - 1);
         const Fr inIdx = i == 0 ? glob(a.g.oldLastIdx) : io.in_m_u(m.imOutIdx, u - 1);
-        const DecResult d = decode_tx_dev(io, a.dec, m, (int)a.L, previousOnChain, inIdx, glob(a.g.globalChainID), glob(a.g.currentNumBatch), K7);
+        const DecResult d = decode_tx_dev(io, a.dec, m, (int)a.L, previousOnChain, inIdx, glob(a.g.globalChainID), glob(a.g.currentNumBatch), K7, false);
         // C (:258-265)
         io.chk(C_MAIN_IM_V2, d.v2, io.in_m(m.txCompressedDataV2));
         if (i + 1 < a.nTx) {
@@ -106,7 +104,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
         x.pastAy[j] = ok ? io.in_m_u(m.toBjjAy, u - j - 1) : fr_zero();
     }
     const FeeSrcMain fs{&io, a.fee_base, a.B * a.F, b * a.F, a.fi.feePlanTokens, a.fi.imFinalAccFee, m.imAccFeeOut, a.nTx, i};
-    rollup_tx_front_dev(io, sc, a.rtx, m, x, (int)a.F, fs, false);
+    rollup_tx_front_dev(io, sc, a.rtx, m, x, (int)a.F, fs, false, a.dec.l1full, C_MAIN_BJJ_BOOL);
 }
 
 
