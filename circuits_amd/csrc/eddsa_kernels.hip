@@ -72,7 +72,7 @@ __device__ Fr fr_sqrt_circom_dev(const Fr& n) {
 }
 
 #ifndef HZ_ED_G
-#define HZ_ED_G 2   // signatures per lane (launches above 8192 signatures)
+#define HZ_ED_G 4   // signatures per segment lane (launches above HZ_ED_SPLIT_MAX signatures: k_eddsa_seg)
 #endif
 #ifndef HZ_ED_SPLIT_MAX
 #define HZ_ED_SPLIT_MAX 8192   // launches up to this many signatures: segments as lanes, no inversion per step (seg_any_proj)
@@ -266,7 +266,7 @@ __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// The same ladder with the per-signature state parked in LDS between a signature's turns (throughput launches, k_eddsa_chain<G>).
+// The same ladder with the per-signature state parked in LDS between a signature's turns (throughput launches, k_eddsa_seg<G>).
 // seg_any_lock keeps its state in arrays indexed by g: with G = 2 the compiler puts them in scratch memory, and every turn of a
 // signature loads and stores its nine field elements through the vector-memory path -- round 2's counters: 23 GB of traffic for
 // 9.4 GB of signals, and a full memory latency in front of every turn of a kernel that is one long dependent chain on 512
@@ -287,10 +287,10 @@ struct LaneLds {
     }
 };
 // Slots: six per signature (the doubling chain's point in scales 0 / 1, the accumulator, the next doubler's numerator), the 2 G - 1
-// prefix products of the step's shared inversion, and the ladder bits of the G signatures (8 words each): 17 slots = 38 KB at G = 2,
-// i.e. four such wavefronts per CU -- the ladders of BOTH contexts in flight are resident at once (at 24 slots / 54 KB only two per
-// CU fit, the second context's ladder queued behind the first one's and the step got 5 % longer although the kernel alone was
-// 12 % shorter).
+// prefix products of the step's shared inversion, and the ladder bits of the G signatures (8 words each): 17 slots = 38 KB at G = 2
+// (four such wavefronts per CU), 31 slots = 70 KB at G = 4 (two per CU: see k_eddsa_seg for what that means for two contexts in
+// flight). With whole signatures as lanes (the 254-step chain of round 3) a footprint above a quarter of a CU made the step longer;
+// with the segments as lanes the chain is short enough for the contexts' ladders to alternate.
 enum { LS_DX1 = 0, LS_DY0, LS_AX, LS_AY, LS_DNUM, LS_DX0, LS_PER_G_MAX };
 // G <= 3 parks the doubling chain's x in both scales; G = 4 recomputes the scale-0 twin (one reduction, three times a step) to
 // stay within two wavefronts per CU (31 slots = 70 KB)
@@ -874,76 +874,71 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     }
 }
 
-// The whole signature as ONE chain per lane (both segments back to back, no k_eddsa_pre): 8 % fewer instructions than the split form
-// (no projective doubling chain) and half the wavefronts. Throughput-sized launches use it -- the device is full anyway, and the split
-// form measured 50.3 ms per step against 46.0 -- the split form is for launches the device does not fill (a single batch: latency).
-// The G signatures of a lane take turns; whatever a signature carries from one turn to the next lives in LDS (LaneLds above), what
-// it carries from one segment to the next in the inter-kernel scratch (its start points, its segment outputs).
+// The throughput form (launches above HZ_ED_SPLIT_MAX signatures): after k_eddsa_pre, lane = (segment, G signatures in lockstep). The
+// G signatures of a lane take turns; whatever a signature carries from one turn to the next lives in LDS (LaneLds above), its start
+// points and segment outputs in the inter-kernel scratch. 148 / 106 dependent steps instead of 254, so FOUR signatures can share an
+// inversion (a quarter of one per ladder step and signature) and the chain is still shorter than one lane walking both segments of
+// two signatures (round 3's k_eddsa_chain<2>: 4.03 G wave-instructions and 21.1 ms alone per 65 536 signatures; this form 2.59 G +
+// 0.89 G for k_eddsa_pre -- whose prologue the chain contained -- and 17.3 ms; step 38.0 -> 36.6-37.1 ms on one box,
+// profiles/r03_eddsa_seg_ab.txt). G = 4 needs 31 LDS slots = 70 KB per wavefront: two wavefronts per CU, i.e. ONE context's 512
+// ladder wavefronts are resident at a time and the other context's follow -- which is how two contexts in flight alternate anyway.
+// G = 3 (26 slots) and G = 2 (17) measured: 36.9-37.4 / 37.4-37.8 ms.
 template <int G>
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_chain(const EddsaArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t st[];   // ls_slots<G>() * 9 * 64 words (launch_eddsa_g)
-    static_assert(HZ_BLOCK == 64, "LaneLds: one wavefront per workgroup");
-    const Fr* K6 = poseidon_consts_w<6>();
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_seg(const EddsaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t st[];   // ls_slots<G>() * 9 * 64 words
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t nl = (n + G - 1) / G;
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= nl) return;
+    const uint32_t seg = blockIdx.y;
     const LaneLds L{(lds_u32*)(st + threadIdx.x)};
     EdK K;
     K.one = fr_one();
     K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
     const EddsaOff& o = a.ed;
-    // (the base pointer goes through an explicit global-address-space cast: captured in the lambda it would otherwise be a generic
-    // pointer, and flat_store counts against lgkmcnt -- the counter the LDS reads of the ladder wait on)
     typedef __attribute__((address_space(1))) uint8_t gl_u8;
     uint8_t* const wbase = (uint8_t*)(gl_u8*)a.base;
     const uint32_t n_units = a.n_units, upi = a.upi, u0 = a.u0;
     ErrBuf* const errp = a.err;
     auto mk_io = [=](int g) {
         uint32_t ui = li + (uint32_t)g * nl;
-        if (ui >= n) ui = li;   // a slot past the end repeats the lane's first unit (same values to the same addresses)
+        if (ui >= n) ui = li;
         const uint32_t i = u0 + ui;
         return UnitIO{wbase, n_units, i, i / upi, i % upi, errp};
     };
+    const SegAnyOff& so = o.seg[seg];
+    const int e0 = seg ? 148 : 0, nb = seg ? 106 : 148;
+    const int sx = seg ? SC_ED_S1X : SC_ED_S0X, sy = seg ? SC_ED_S1Y : SC_ED_S0Y;
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const UnitIO io = mk_io(g);
         const Scratch sc{a.scratch, a.n_units, io.unit};
-        EdSig sg;
-        bool on_curve;
-        ed_prologue(K, io, sc, o, K6, sg, &on_curve);
-        sc.set(SC_ED_ZP, sg.zp);
-        sc.set(SC_ED_P0X, sg.p0.x); sc.set(SC_ED_P0Y, sg.p0.y);
-        ls_hput(L, ls_h0<G>(), g, sg.h_c);   // the 254 ladder bits as plain 32-bit words
-        seg_lds_init<G>(K, io, o.seg[0], sg.p0, L, g);
+        ls_hput(L, ls_h0<G>(), g, fr_to_canon(sc.get(SC_ED_H)));
+        PtA p;
+        if (seg == 0) {
+            p.x = sc.get(SC_ED_P0X); p.y = sc.get(SC_ED_P0Y);
+        } else {
+            // the doubling between the segments and the second segment's base point (escalarmulany.circom: doublers / m2e)
+            const EdCtx c = K.with(io);
+            PtA d147;
+            d147.x = sc.get(SC_ED_DBLX); d147.y = sc.get(SC_ED_DBLY);
+            const MDbl dd = mont_dbl_dev(c, d147);
+            c.io.put_m(o.dblr, dd.x1_2); c.io.put_m(o.dblr + 1, dd.lamda); c.io.put_m(o.dblr + 2, dd.out.x); c.io.put_m(o.dblr + 3, dd.out.y);
+            p = m2e_dev(c, dd.out);
+            c.io.put_m(o.m2e0, p.x); c.io.put_m(o.m2e0 + 1, p.y);
+            sc.set(SC_ED_Q1X, p.x); sc.set(SC_ED_Q1Y, p.y);   // kept for the end of the segment
+        }
+        seg_lds_init<G>(K, io, so, p, L, g);
     }
-    seg_lds_steps<G>(K, mk_io, o.seg[0], 0, 148, L);
+    seg_lds_steps<G>(K, mk_io, so, e0, nb, L);
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const UnitIO io = mk_io(g);
         const Scratch sc{a.scratch, a.n_units, io.unit};
-        PtA p0, dbl;
-        p0.x = sc.get(SC_ED_P0X); p0.y = sc.get(SC_ED_P0Y);
-        const PtA r = seg_lds_fin<G>(K, io, o.seg[0], ls_hbit(L, ls_h0<G>(), g, 0), p0, L, g, &dbl);
-        sc.set(SC_ED_S0X, r.x); sc.set(SC_ED_S0Y, r.y);
-        // the doubling between the segments and the second segment's base point (escalarmulany.circom: doublers / m2e)
-        const EdCtx c = K.with(io);
-        const MDbl dd = mont_dbl_dev(c, dbl);
-        c.io.put_m(o.dblr, dd.x1_2); c.io.put_m(o.dblr + 1, dd.lamda); c.io.put_m(o.dblr + 2, dd.out.x); c.io.put_m(o.dblr + 3, dd.out.y);
-        const PtA q = m2e_dev(c, dd.out);
-        c.io.put_m(o.m2e0, q.x); c.io.put_m(o.m2e0 + 1, q.y);
-        sc.set(SC_ED_DBLX, q.x); sc.set(SC_ED_DBLY, q.y);   // (the split form keeps 2^147 * 8A here; this form the second start point)
-        seg_lds_init<G>(K, io, o.seg[1], q, L, g);
-    }
-    seg_lds_steps<G>(K, mk_io, o.seg[1], 148, 106, L);
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {   // the sum, the zero-point substitution and R8 + h*8A belong to k_eddsa_final
-        const UnitIO io = mk_io(g);
-        const Scratch sc{a.scratch, a.n_units, io.unit};
-        PtA q, dbl;
-        q.x = sc.get(SC_ED_DBLX); q.y = sc.get(SC_ED_DBLY);
-        const PtA r = seg_lds_fin<G>(K, io, o.seg[1], ls_hbit(L, ls_h0<G>(), g, 148), q, L, g, &dbl);
-        sc.set(SC_ED_S1X, r.x); sc.set(SC_ED_S1Y, r.y);
+        PtA p, dbl;
+        p.x = sc.get(seg ? SC_ED_Q1X : SC_ED_P0X); p.y = sc.get(seg ? SC_ED_Q1Y : SC_ED_P0Y);
+        const PtA r = seg_lds_fin<G>(K, io, so, ls_hbit(L, ls_h0<G>(), g, e0), p, L, g, &dbl);
+        sc.set(sx, r.x); sc.set(sy, r.y);
     }
 }
 
@@ -1034,14 +1029,15 @@ static hipError_t launch_eddsa_split(const EddsaArgs& a, uint32_t n, hipStream_t
     return hipGetLastError();
 }
 template <int G>
-static hipError_t launch_eddsa_g(const EddsaArgs& a, uint32_t n, hipStream_t s) {
+static hipError_t launch_eddsa_seg(const EddsaArgs& a, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_eddsa_pre, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
     const uint32_t nl = (n + G - 1) / G;
     constexpr size_t lds = (size_t)ls_slots<G>() * 9 * HZ_BLOCK * sizeof(uint32_t);
-    if (lds > 64 * 1024) {   // beyond the default limit of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eddsa_chain<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) {
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eddsa_seg<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (once != hipSuccess) return once;
     }
-    hipLaunchKernelGGL(k_eddsa_chain<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), lds, s, a);
+    hipLaunchKernelGGL(k_eddsa_seg<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK, 2), dim3(HZ_BLOCK), lds, s, a);
     return hipGetLastError();
 }
 template <int G>
@@ -1058,11 +1054,7 @@ hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
     // a launch the device does not fill is latency bound: the two segments of every signature as independent lanes (148 / 106
     // dependent steps instead of 254), one signature per lane
     if (n <= HZ_ED_SPLIT_MAX) return launch_eddsa_split<1>(a, n, s);
-    // Two signatures per lane. Four (one inversion shared by four ladder steps) issue fewer instructions but take 42.6 ms against
-    // 28.5 ms per 65 536 signatures: since the SMT chain stores its empty-subtree levels from a table (25 ms per step instead of 42)
-    // the ladder is the longest chain of a step, and its length, not its instruction count, sets the step: 1.27 vs 1.19 M tx/s
-    // (one per lane: 20.8 ms, 1.23 M tx/s).
-    return launch_eddsa_g<HZ_ED_G>(a, n, s);
+    return launch_eddsa_seg<HZ_ED_G>(a, n, s);
 }
 hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;

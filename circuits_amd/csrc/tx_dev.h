@@ -25,6 +25,7 @@ enum ScratchField {
     // k_eddsa_pre -> the two segment lanes of k_eddsa_ladder -> k_eddsa_final: message hash, zero-point flag, 8A (or Base8), 2^147 * 8A
     // (Montgomery form), the two segment outputs
     SC_ED_H, SC_ED_ZP, SC_ED_P0X, SC_ED_P0Y, SC_ED_DBLX, SC_ED_DBLY, SC_ED_S0X, SC_ED_S0Y, SC_ED_S1X, SC_ED_S1Y,
+    SC_ED_Q1X, SC_ED_Q1Y,   // k_eddsa_seg: the second segment's start point (DBL* keeps 2^147 * 8A: a lane's padding slot repeats a unit)
     SC_ISAMTNULL,
     // written by the hash step
     SC_LEAF_P1OLD, SC_LEAF_P1NEW, SC_LEAF_P2OLD, SC_LEAF_P2NEW,

@@ -87,6 +87,84 @@ def test_rollup_tx_config2_bit_exact(hz, batch):
         assert g.read(g.lookup("main.accFeeOut[0]"), 4, i) == exp["accFeeOut"]
 
 
+
+def _compare_replicated(g, o, n_gpu, n_dist, which, rows_per_chunk=256):
+    """Instanced template (one section, physical layout [signal][instance]): instance k of the GPU context holds the inputs of the
+    oracle's instance which[k]; whole physical buffers, a few hundred signal rows at a time."""
+    import numpy as np
+    wl = g.witness_len()
+    assert wl == o.witness_len() and g.total() == wl * n_gpu and o.total() == wl * n_dist
+    idx = np.asarray(which)
+    for r0 in range(0, wl, rows_per_chunk):
+        rows = min(rows_per_chunk, wl - r0)
+        a = np.frombuffer(g.read_raw_bytes(r0 * n_gpu, rows * n_gpu), dtype=np.uint8).reshape(rows, n_gpu, 32)
+        b = np.frombuffer(o.read_raw_bytes(r0 * n_dist, rows * n_dist), dtype=np.uint8).reshape(rows, n_dist, 32)[:, idx, :]
+        if not np.array_equal(a, b):
+            r, k = np.argwhere((a != b).any(axis=2))[0]
+            raise AssertionError("witness differs at signal row %d, instance %d (oracle instance %d): gpu=%d oracle=%d" % (
+                r0 + r, k, which[k], int.from_bytes(a[r, k].tobytes(), "little"), int.from_bytes(b[r, k].tobytes(), "little")))
+
+
+def test_throughput_signature_kernels_bit_exact(hz):
+    """Launches of more than 8 192 transactions take the THROUGHPUT form of the signature check -- k_eddsa_pre + k_eddsa_seg<4> (lane =
+    segment x four signatures in lockstep, their state parked in LDS between turns, one shared inversion per ladder step) and
+    k_eddsa_fix<4> -- which is what bench.py measures; every other GPU test stays below that size and runs the split form. 8 259
+    RollupTx(16, 4) instances (not a multiple of four: one lane carries a padding slot that repeats its first unit), drawn from 40
+    different transactions (L1 creates, signed L2 transfers, exits) that the oracle evaluates once each; the whole physical buffer
+    (7.9 GB) is compared. reference src/rollup-tx.circom:445-482, circomlib eddsaposeidon.circom."""
+    from circuits_amd import builder as B
+    bb = B.synthetic_batch(40, 16, 6, 4, n_accounts=12, exits=3, seed=4242)
+    D, N = bb.nTx, 8192 + 67
+    o = OracleCtx("rollup-tx", nLevels=16, maxFeeTx=4, n_instances=D)
+    g = hz.ctx("rollup-tx", nLevels=16, maxFeeTx=4, n_instances=N)
+    which = [(7 * k + 3) % D if k >= D else k for k in range(N)]
+    for i in range(D):
+        inp = bb.get_single_tx_input(i)[0]
+        o.set_inputs(inp, instance=i)
+        g.set_inputs(inp, instance=i)
+    for k in range(D, N):
+        g.copy_instance_inputs(which[k], k)
+    g.run()
+    assert o.run() is None
+    _compare_replicated(g, o, N, D, which)
+    # a bad signature in the ragged last wavefront is reported for exactly that instance, by the verifier's own constraint
+    from circuits_amd import ConstraintError
+    i_l2 = next(i for i in range(D) if not bb.get_single_tx_input(i)[0]["onChain"] and bb.get_single_tx_input(i)[0]["fromIdx"])
+    bad = dict(bb.get_single_tx_input(i_l2)[0])
+    bad["s"] = (bad["s"] + 1) % P
+    g.set_inputs(bad, instance=N - 2)
+    with pytest.raises(ConstraintError) as e:
+        g.run()
+    assert e.value.instance == N - 2 and "sigVerifier" in e.value.name
+
+
+def test_throughput_rollup_main_many_batches(hz):
+    """The benchmark's own schedule at a size where the throughput kernels run: RollupMain(8, 16, 3, 4) x 1 030 batches in ONE set of
+    launches (8 240 transactions: the signature chain pairs transactions of DIFFERENT batches), five different batches replicated on
+    the device. Every batch's hashGlobalInputs against the builder's, no constraint failure, and the complete logical witness of
+    the first, a middle and the last instance against the oracle's."""
+    from circuits_amd import builder as B
+    shape, D, N = (8, 16, 3, 4), 5, 1030
+    bbs = [B.synthetic_batch(*shape, n_accounts=6 + b, exits=b % 3, seed=900 + b) for b in range(D)]
+    o = OracleCtx("rollup-main", *shape, n_instances=D)
+    g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3], n_instances=N)
+    for b in range(D):
+        o.set_inputs(bbs[b].get_input(), instance=b)
+        g.set_inputs(bbs[b].get_input(), instance=b)
+    which = [(3 * k + 1) % D if k >= D else k for k in range(N)]
+    for k in range(D, N):
+        g.copy_instance_inputs(which[k], k)
+    g.run()
+    assert o.run() is None
+    sig = g.lookup("main.hashGlobalInputs")
+    for k in range(N):
+        assert g.read(sig, 1, k)[0] == bbs[which[k]].get_hash_inputs()
+    wl = g.witness_len()
+    for k in (0, N // 2 + 1, N - 1):
+        for first in range(0, wl, 1 << 17):
+            cnt = min(1 << 17, wl - first)
+            assert g.read(first, cnt, k) == o.read(first, cnt, which[k]), "instance %d, elements from %d" % (k, first)
+
 def test_rollup_tx_config2_literal_shape_bit_exact(hz):
     """BASELINE config 2 as written: RollupTx(nLevels = 8, maxFeeTx = 16), account indices below 256 (tests/scenarios.py
     config2_batch): L1 createAccountDeposit / deposit, signed L2 transfer, exit (insert and update of the exit leaf), NOP --
