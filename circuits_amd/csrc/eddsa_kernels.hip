@@ -1033,9 +1033,15 @@ static hipError_t launch_eddsa_seg(const EddsaArgs& a, uint32_t n, hipStream_t s
     hipLaunchKernelGGL(k_eddsa_pre, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
     const uint32_t nl = (n + G - 1) / G;
     constexpr size_t lds = (size_t)ls_slots<G>() * 9 * HZ_BLOCK * sizeof(uint32_t);
-    if (lds > 64 * 1024) {
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eddsa_seg<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (once != hipSuccess) return once;
+    if (lds > 64 * 1024) {   // beyond the default limit of dynamic LDS per workgroup (gfx950 has 160 KB per CU); the attribute is per device
+        static bool done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!done[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eddsa_seg<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            done[dev] = true;
+        }
     }
     hipLaunchKernelGGL(k_eddsa_seg<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK, 2), dim3(HZ_BLOCK), lds, s, a);
     return hipGetLastError();
@@ -1059,7 +1065,10 @@ hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
 hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     if (n <= 8192) return launch_eddsa_fix_g<1>(a, n, s);
-    return launch_eddsa_fix_g<4>(a, n, s);   // 9.2 ms per 65 536 signatures (eight per lane: 14.1 ms, same step time)
+    // Eight signatures per lane: 85 windows x (8 turns + one shared inversion) is still a shorter chain than the variable-base ladder
+    // beside it (11.0 ms alone against 17.4), and an eighth of an inversion per window instead of a quarter is 0.2 G fewer
+    // wave-instructions per 65 536 signatures (four per lane: 7.5 ms alone, step +0.3..0.6 ms; profiles/r03_eddsa_seg_ab.txt).
+    return launch_eddsa_fix_g<8>(a, n, s);
 }
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;

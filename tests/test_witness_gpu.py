@@ -108,7 +108,7 @@ def _compare_replicated(g, o, n_gpu, n_dist, which, rows_per_chunk=256):
 def test_throughput_signature_kernels_bit_exact(hz):
     """Launches of more than 8 192 transactions take the THROUGHPUT form of the signature check -- k_eddsa_pre + k_eddsa_seg<4> (lane =
     segment x four signatures in lockstep, their state parked in LDS between turns, one shared inversion per ladder step) and
-    k_eddsa_fix<4> -- which is what bench.py measures; every other GPU test stays below that size and runs the split form. 8 259
+    k_eddsa_fix<8> -- which is what bench.py measures; every other GPU test stays below that size and runs the split form. 8 259
     RollupTx(16, 4) instances (not a multiple of four: one lane carries a padding slot that repeats its first unit), drawn from 40
     different transactions (L1 creates, signed L2 transfers, exits) that the oracle evaluates once each; the whole physical buffer
     (7.9 GB) is compared. reference src/rollup-tx.circom:445-482, circomlib eddsaposeidon.circom."""

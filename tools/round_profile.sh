@@ -26,6 +26,7 @@ sys.stdout.flush()
 subprocess.run([sys.executable, "tools/gantt.py", sys.argv[1], str(lo), str(lo + 230), "2"])
 PY
 fi
+if [ -z "$SKIP_MICRO" ]; then   # SKIP_MICRO=1: only what depends on the library (bench line, kernel stats, counters, Gantt)
 tools/microbench/instbench > $OUT/instbench.txt 2>&1
 tools/microbench/mulbench > $OUT/mulbench.txt 2>&1
 tools/microbench/invbench > $OUT/invbench.txt 2>&1
@@ -39,5 +40,6 @@ for l in sys.stdin:
     m=re.search(r'sclk clock speed:.*\|\s*card0,\((\d+)Mhz\),\d+,\((\d+)Mhz\),\d+,\((\d+)Mhz\),\d+,\((\d+)Mhz\),S,([0-9.]+)', l)
     print('    fclk %s mclk %s sclk %s MHz, package power %s W' % (m.group(1), m.group(2), m.group(3), m.group(5)) if m else l)
 " > $OUT/power_probe.txt
+fi
 rm -rf gpurun_out/round_tl gpurun_out/prof/trace gpurun_out/prof/pmc_fetch gpurun_out/prof/pmc_write gpurun_out/pmc/valu
 tail -c 600 $OUT/bench_line.json; echo; ls -la $OUT
