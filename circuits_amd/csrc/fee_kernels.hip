@@ -360,7 +360,16 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_sha_expand(const HashInputsArgs a)
 }
 
 // ---- Withdraw: lane = instance -----------------------------------------------------------------------
-__global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
+// Two wavefronts per workgroup for the Poseidon-bound half (like k_smt, smt_kernels.hip): beside the store-bound k_withdraw_sha a
+// launch of 2^16 witnesses takes 24.2-24.6 ms instead of 26.2-27.1 (2.67-2.71 M witnesses/s against 2.42-2.50 M on one box; 256:
+// 26.0-26.7 ms; the SHA half at 128: 24.8-25.6 ms; profiles/r03_workgroup_ab.txt).
+#ifndef HZ_WD_BLOCK
+#define HZ_WD_BLOCK 128
+#endif
+#ifndef HZ_WDSHA_BLOCK
+#define HZ_WDSHA_BLOCK HZ_BLOCK
+#endif
+__global__ __launch_bounds__(HZ_WD_BLOCK) void k_withdraw(const WithdrawArgs a) {
     const Fr* K5 = poseidon_consts_w<5>();
     const Fr* K4 = poseidon_consts_w<4>();
     const Fr* K3 = poseidon_consts_w<3>();
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_withdraw(const WithdrawArgs a) {
 // Lane granularity measured on 2^16 instances per launch: one lane per instance (both blocks) 1.915 M witnesses/s, per block 1.910 M,
 // two / four lanes per block (unstored rounds recomputed) 1.76-1.83 M: more concurrent store streams are slower, the ~4.5 TB/s
 // are the store rate of this access pattern (hipMemset of the same buffer: 6.0 TB/s).
-__global__ __launch_bounds__(HZ_BLOCK) void k_withdraw_sha(const WithdrawArgs a) {
+__global__ __launch_bounds__(HZ_WDSHA_BLOCK) void k_withdraw_sha(const WithdrawArgs a) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     if (gt >= 2 * a.N) return;
     const uint32_t i = gt % a.N, blk = gt / a.N;   // consecutive lanes = consecutive instances: coalesced stores
@@ -649,12 +658,11 @@ hipError_t launch_da_import(const DaArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_withdraw(const WithdrawArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_withdraw, grid1(a.N), dim3(HZ_BLOCK),
-                       0, s, a);
+    hipLaunchKernelGGL(k_withdraw, dim3((a.N + HZ_WD_BLOCK - 1) / HZ_WD_BLOCK), dim3(HZ_WD_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_withdraw_sha(const WithdrawArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_withdraw_sha, grid1(2 * a.N), dim3(HZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_withdraw_sha, dim3((2 * a.N + HZ_WDSHA_BLOCK - 1) / HZ_WDSHA_BLOCK), dim3(HZ_WDSHA_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

@@ -15,7 +15,10 @@ namespace hz {
 // HashState x4 + SMTHash1 x4 (reference src/rollup-tx.circom:297-312,517-532 and the hash1Old /
 // hash1New components of circomlib's SMTProcessor). blockIdx.y = j.
 
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_hash4(const Hash4Args a) {
+#ifndef HZ_HASH4_BLOCK
+#define HZ_HASH4_BLOCK HZ_BLOCK
+#endif
+__global__ __launch_bounds__(HZ_HASH4_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_hash4(const Hash4Args a) {
     const Fr* K5 = poseidon_consts_w<5>();
     const Fr* K4 = poseidon_consts_w<4>();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,7 +102,14 @@ __device__ __forceinline__ uint32_t wave_max_u6(uint32_t v) {
     return r;
 }
 // Two wavefronts of this kernel per SIMD saturate the integer pipe (three, with the register budget that implies: no faster).
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_smt(const SmtArgs a) {
+// Two wavefronts per workgroup: the kernel alone does not care (20.7 ms either way), the STEP does -- with the signature ladders, the
+// fee chain and the SHA-256 tail of two contexts beside it, pairs of k_smt wavefronts placed together measured 35.7-35.9 ms per step
+// against 36.7-36.9 for single-wavefront workgroups and 38.7 for four per workgroup on one box (profiles/r03_workgroup_ab.txt); 128
+// for k_hash4 / k_main_front as well: within noise.
+#ifndef HZ_SMT_BLOCK
+#define HZ_SMT_BLOCK 128
+#endif
+__global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_smt(const SmtArgs a) {
     const Fr* K3 = poseidon_consts_w<3>();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
@@ -305,18 +315,20 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
 // ---------------------------------------------------------------------------------------------------
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
-    dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
+    const uint32_t nl = a.ucnt ? a.ucnt : a.n_units;
+    dim3 g((nl + HZ_HASH4_BLOCK - 1) / HZ_HASH4_BLOCK);
     g.y = a.n_jobs;
-    hipLaunchKernelGGL(k_hash4, g, dim3(HZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_hash4, g, dim3(HZ_HASH4_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 // One launch for the whole chain (round 1 launched it in chunks of 11 levels so that workgroup slots turned over during its store
 // phase; with the empty-level blocks stored in the shadow of the hashing levels one launch is as good for the step and better for
 // the kernel itself: no per-chunk prologue, no tail of a chunk waiting for its slowest wavefront).
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s) {
-    dim3 g = grid1(a.ucnt ? a.ucnt : a.n_units);
+    const uint32_t nl = a.ucnt ? a.ucnt : a.n_units;
+    dim3 g((nl + HZ_SMT_BLOCK - 1) / HZ_SMT_BLOCK);
     g.y = 2 * a.n_proc;
-    hipLaunchKernelGGL(k_smt, g, dim3(HZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_smt, g, dim3(HZ_SMT_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

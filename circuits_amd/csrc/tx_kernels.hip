@@ -51,7 +51,10 @@ struct FeeSrcRtx {
 // The 256 fromBjjCompressed input rows (8 KB per transaction) are read by lane 1 only: it packs them into the key (its own job),
 // checks them boolean (RollupMain phase A) and stores DecodeTx's L1TxFullData rows bit * onChain as copies -- round 2 read them three
 // times and paid three field conversions per bit (1.1 GB of the kernel's 4.6 GB of reads, a quarter of lane 0's instructions).
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_main_front(const MainFrontArgs a) {
+#ifndef HZ_FRONT_BLOCK
+#define HZ_FRONT_BLOCK HZ_BLOCK
+#endif
+__global__ __launch_bounds__(HZ_FRONT_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_main_front(const MainFrontArgs a) {
     const Fr* K7 = poseidon_consts_w<7>();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_units = a.B * a.nTx;
@@ -192,9 +195,10 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_da_mask(const RtxBackArgs a) {
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
-    dim3 g = grid1(a.ucnt ? a.ucnt : a.B * a.nTx);
+    const uint32_t nl = a.ucnt ? a.ucnt : a.B * a.nTx;
+    dim3 g((nl + HZ_FRONT_BLOCK - 1) / HZ_FRONT_BLOCK);
     g.y = 2;   // DecodeTx lane, RollupTx-front lane
-    hipLaunchKernelGGL(k_main_front, g, dim3(HZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_main_front, g, dim3(HZ_FRONT_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
