@@ -286,7 +286,11 @@ def test_constraint_failures_match_oracle(hz, batch):
     cases.append(bad)
     bad = dict(inp); bad["onChain"] = list(inp["onChain"]); bad["onChain"][0] = 2
     cases.append(bad)
-    for bad in cases:
+    # a key bit that is not a bit (RollupMain phase A, src/rollup-main.circom:214-216): the lane that packs the key reports it, and the
+    # L1TxFullData row of that bit takes the general product instead of the copy
+    bad = dict(inp); bad["fromBjjCompressed"] = [list(x) for x in inp["fromBjjCompressed"]]; bad["fromBjjCompressed"][1][5] = 2
+    cases.append(bad)
+    for n_case, bad in enumerate(cases):
         g = hz.ctx("rollup-main", nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4)
         o = OracleCtx("rollup-main", 8, 16, 3, 4)
         g.set_inputs(bad)
@@ -297,6 +301,10 @@ def test_constraint_failures_match_oracle(hz, batch):
             g.run()
         assert "Constraint doesn't match" in str(e.value)
         assert (e.value.instance, e.value.unit, e.value.constraint_id, e.value.lhs, e.value.rhs) == (r[0], r[1], r[2], r[4], r[5])
+        if n_case == len(cases) - 1:
+            # the row of the offending bit: 2 * onChain, as the oracle has it
+            sig = g.lookup("main.decodeTx[1].L1TxFullData[%d]" % (160 + 256 - 1 - 5))
+            assert g.read(sig, 1) == o.read(sig, 1)
 
 
 def test_failure_in_the_last_transaction_of_a_batch(hz):
