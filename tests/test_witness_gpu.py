@@ -105,18 +105,21 @@ def _compare_replicated(g, o, n_gpu, n_dist, which, rows_per_chunk=256):
                 r0 + r, k, which[k], int.from_bytes(a[r, k].tobytes(), "little"), int.from_bytes(b[r, k].tobytes(), "little")))
 
 
-def test_throughput_signature_kernels_bit_exact(hz):
+@pytest.mark.parametrize("L,F", [(16, 4), (32, 64)])
+def test_throughput_signature_kernels_bit_exact(hz, L, F):
     """Launches of more than 8 192 transactions take the THROUGHPUT form of the signature check -- k_eddsa_pre + k_eddsa_seg<4> (lane =
     segment x four signatures in lockstep, their state parked in LDS between turns, one shared inversion per ladder step) and
     k_eddsa_fix<8> -- which is what bench.py measures; every other GPU test stays below that size and runs the split form. 8 259
-    RollupTx(16, 4) instances (not a multiple of four: one lane carries a padding slot that repeats its first unit), drawn from 40
+    RollupTx instances (not a multiple of four: one lane carries a padding slot that repeats its first unit), drawn from 40
     different transactions (L1 creates, signed L2 transfers, exits) that the oracle evaluates once each; the whole physical buffer
-    (7.9 GB) is compared. reference src/rollup-tx.circom:445-482, circomlib eddsaposeidon.circom."""
+    is compared: 7.4 GB at (16, 4), and 11.8 GB at the benchmark's own (nLevels, maxFeeTx) = (32, 64), where k_smt's 33-level chains
+    and their empty-level blocks run at this unit count too. reference src/rollup-tx.circom:445-482,537-570, circomlib
+    eddsaposeidon.circom."""
     from circuits_amd import builder as B
-    bb = B.synthetic_batch(40, 16, 6, 4, n_accounts=12, exits=3, seed=4242)
+    bb = B.synthetic_batch(40, L, 6, F, n_accounts=12, exits=3, seed=4242)
     D, N = bb.nTx, 8192 + 67
-    o = OracleCtx("rollup-tx", nLevels=16, maxFeeTx=4, n_instances=D)
-    g = hz.ctx("rollup-tx", nLevels=16, maxFeeTx=4, n_instances=N)
+    o = OracleCtx("rollup-tx", nLevels=L, maxFeeTx=F, n_instances=D)
+    g = hz.ctx("rollup-tx", nLevels=L, maxFeeTx=F, n_instances=N)
     which = [(7 * k + 3) % D if k >= D else k for k in range(N)]
     for i in range(D):
         inp = bb.get_single_tx_input(i)[0]
