@@ -355,8 +355,9 @@ __device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, c
                 const UnitIO w = mk_io(g);
                 const Fr nx1_2 = fr_mul(dx0, L.get(s0 + LS_DX1));
                 (void)ed_put0(w, b + BIT_N + BIT_DBL_X1_2, nx1_2);     // doubler_{i+1}.x1_2
-                L.put(s0 + LS_DNUM, fr_add(fr_add(fr_add(fr_dbl(nx1_2), nx1_2), fr_mul(A2, dx0)), one0));
-                const Fr dd = fr_dbl(L.get(s0 + LS_DY0));
+                // 3 x1_2 + 2A x + 1 below 4.2 p, not reduced: it only feeds the product with the inverse (fr.h "lazily reduced sums")
+                L.put(s0 + LS_DNUM, fr_3a_b_c_lazy(nx1_2, fr_mul(A2, dx0), one0));
+                const Fr dd = fr_dbl_lazy(L.get(s0 + LS_DY0));   // y is stored canonical: 2y < 2p as it is
                 if (!fr_is_zero(dd)) acc = fr_mul(acc, dd);
             }
         }
@@ -372,7 +373,7 @@ __device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, c
             Fr inv_dd = fr_zero();
             bool dd_zero = true;
             if (more) {
-                const Fr dd = fr_dbl(dy0);
+                const Fr dd = fr_dbl_lazy(dy0);
                 dd_zero = fr_is_zero(dd);
                 if (!dd_zero) {
                     inv_dd = fr_mul(inv, L.get(ls_pre0<G>() + 2 * g));
@@ -386,15 +387,15 @@ __device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, c
                 inv_a = g > 0 ? fr_mul(inv, L.get(ls_pre0<G>() + 2 * g - 1)) : inv;
                 if (g > 0) inv = fr_mul(inv, a_den);
             }
-            const Fr a_num = fr_sub(addIn.y, dy0);
+            const Fr a_num = fr_sub_lazy(addIn.y, dy0);   // in (p, 3p): a multiplicand only
             const Fr a_l1 = fr_mul(a_num, inv_a);
             const Fr a_l0 = fr_canon_limbs(a_l1);
             if (a_zero) w.chk(C_RTX_SIG_EC, fr_zero(), fr_scale_up(a_num));
             PtA ao;
-            ao.x = fr_sub(fr_sub(fr_sub(fr_mul(a_l0, a_l1), A0), dx0), addIn.x);
-            ao.y = fr_sub(fr_mul(a_l1, fr_sub(dx0, ao.x)), dy0);
+            ao.x = ed_put0(w, b + BIT_ADD_OUT0, fr_sub3(fr_mul(a_l0, a_l1), A0, dx0, addIn.x));   // one reduction for the three differences
+            ao.y = fr_sub(fr_mul(a_l1, fr_sub_lazy(dx0, ao.x)), dy0);
             w.put_c(b + BIT_ADD_LAMDA, fr_pack_canon(a_l0));
-            ao.x = ed_put0(w, b + BIT_ADD_OUT0, ao.x); ao.y = ed_put0(w, b + BIT_ADD_OUT1, ao.y);
+            ao.y = ed_put0(w, b + BIT_ADD_OUT1, ao.y);
             const uint32_t sel = ls_hbit(L, ls_h0<G>(), g, e0 + i + 1);
             const PtA so = sel ? ao : addIn;
             w.put_c(b + BIT_SEL_OUT0, fr_pack_canon(so.x)); w.put_c(b + BIT_SEL_OUT1, fr_pack_canon(so.y));
@@ -404,9 +405,9 @@ __device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, c
                 const Fr l1 = fr_mul(d_num, inv_dd);
                 const Fr l0 = fr_canon_limbs(l1);
                 if (dd_zero) w.chk(C_RTX_SIG_EC, fr_zero(), fr_scale_up(d_num));
-                const Fr nx1 = fr_sub(fr_sub(fr_sqr(l1), K.A), fr_dbl(L.get(s0 + LS_DX1)));
+                const Fr nx1 = fr_sub_a_2x(fr_sqr(l1), K.A, L.get(s0 + LS_DX1));   // l^2 - A - 2x in [0, 2p), one reduction
                 const Fr nx0 = fr_canon_limbs(nx1);
-                const Fr ny0 = fr_sub(fr_mul(l1, fr_sub(dx0, nx0)), dy0);
+                const Fr ny0 = fr_sub(fr_mul(l1, fr_sub_lazy(dx0, nx0)), dy0);
                 const uint32_t bn = b + BIT_N;
                 w.put_c(bn + BIT_DBL_LAMDA, fr_pack_canon(l0)); w.put_c(bn + BIT_DBL_OUT0, fr_pack_canon(nx0));
                 L.put(s0 + LS_DY0, ed_put0(w, bn + BIT_DBL_OUT1, ny0));

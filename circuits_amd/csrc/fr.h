@@ -189,6 +189,65 @@ HZ_HD Fr fr_sub(const Fr& a, const Fr& b) {
     fr_cond_sub_2p(r.v);
     return r;
 }
+// ---- lazily reduced sums (the signature ladder, eddsa_kernels.hip). A product accepts operands below 2^257 (> 10 p), so a difference
+// that only feeds products needs no conditional subtraction, and a chain of differences that is stored needs one reduction, not
+// one per link. Every routine states the range of its operands and of its result; limbs stay normalised.
+// a - b + 2p in (0, A + 2p) for a in [0, A), b in [0, 2p): not reduced
+HZ_HD Fr fr_sub_lazy(const Fr& a, const Fr& b) {
+    Fr r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t x = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)fr_2p29(i) + c;
+        r.v[i] = (i < 8) ? (uint32_t)(x & (int32_t)HZ_M29) : (uint32_t)x;
+        c = x >> 29;
+    }
+    return r;
+}
+// 2a in [0, 2A) for a in [0, A): not reduced (for a below p this IS fr_dbl(a))
+HZ_HD Fr fr_dbl_lazy(const Fr& a) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] << 1;
+    fr_norm(r.v);
+    return r;
+}
+// m - a - b - c reduced to [0, 2p); m in [0, 2p), a, b, c in [0, 2p) with a + b + c < 4p
+HZ_HD Fr fr_sub3(const Fr& m, const Fr& a, const Fr& b, const Fr& c3) {
+    Fr t;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {   // m - a - b - c + 4p in (0, 6p): per limb within [-3 * 2^29, 2 * 2^29]
+        const int32_t x = (int32_t)m.v[i] - (int32_t)a.v[i] - (int32_t)b.v[i] - (int32_t)c3.v[i] + (int32_t)fr_4p29(i) + c;
+        t.v[i] = (i < 8) ? (uint32_t)(x & (int32_t)HZ_M29) : (uint32_t)x;
+        c = x >> 29;
+    }
+    Fr r = fr_cond_sub_4p(t);   // [0, 4p)
+    fr_cond_sub_2p(r.v);
+    return r;
+}
+// s - a - 2x reduced to [0, 2p); s, a, x in [0, 2p)
+HZ_HD Fr fr_sub_a_2x(const Fr& s, const Fr& a, const Fr& x2) {
+    Fr t;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {   // s - a - 2x + 6p in (0, 8p): per limb within [-3 * 2^29, 3 * 2^29]
+        const int32_t x = (int32_t)s.v[i] - (int32_t)a.v[i] - 2 * (int32_t)x2.v[i] + (int32_t)fr_2p29(i) + (int32_t)fr_4p29(i) + c;
+        t.v[i] = (i < 8) ? (uint32_t)(x & (int32_t)HZ_M29) : (uint32_t)x;
+        c = x >> 29;
+    }
+    Fr r = fr_cond_sub_4p(t);   // t < 8p -> [0, 4p)
+    fr_cond_sub_2p(r.v);
+    return r;
+}
+// 3a + b + c, not reduced: below 3A + B + C for a in [0, A), b in [0, B), c in [0, C) (limbs: 3 * 2^29 + 2^29 + 2^29 fit 32 bits)
+HZ_HD Fr fr_3a_b_c_lazy(const Fr& a, const Fr& b, const Fr& c) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = 3u * a.v[i] + b.v[i] + c.v[i];
+    fr_norm(r.v);
+    return r;
+}
 HZ_HD Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
 HZ_HD Fr fr_dbl(const Fr& a) { return fr_add(a, a); }
 // value in {0, p} (both represent zero; limbs are normalised, so each integer has one encoding)

@@ -134,3 +134,15 @@ def test_inversion_on_the_host(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", src, "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "mismatches=0" in r.stdout, r.stdout + r.stderr
+
+
+def test_lazily_reduced_sums_on_the_host(tmp_path):
+    """fr.h's lazily reduced sums (the signature ladder: differences that only feed products skip the conditional subtraction, chains
+    of differences that are stored take one reduction) against the plain routines over the product header on the host: same field
+    elements, results normalised and below 2p, on the edges of the operand ranges and on random operands."""
+    import subprocess
+    src = os.path.join(os.path.dirname(__file__), "native", "lazy_sums_check.cpp")
+    exe = str(tmp_path / "lazy_sums_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "mismatches=0" in r.stdout, r.stdout + r.stderr
