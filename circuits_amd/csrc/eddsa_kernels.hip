@@ -610,15 +610,15 @@ __device__ __noinline__ void seg_fix_lock(const EdK& K, const UnitIO* io, const 
             mo.y = ld_const(HZ_BJJ_FIX_WIN0[((win0 + i) * 8 + k) * 2 + 1]);
             w.put_bit(wb + WIN_S10, (k & 1) & ((k >> 1) & 1));
             w.put_c(wb + WIN_MUX0, fr_pack_canon(mo.x)); w.put_c(wb + WIN_MUX1, fr_pack_canon(mo.y));
-            const Fr num = fr_sub(mo.y, acc[g].y);
+            const Fr num = fr_sub_lazy(mo.y, acc[g].y);   // a multiplicand only (fr.h "lazily reduced sums")
             const Fr l1 = fr_mul(num, inv[g]);
             const Fr l0 = fr_canon_limbs(l1);
             if ((zmask >> g) & 1) w.chk(C_RTX_SIG_EC, fr_zero(), fr_scale_up(num));
             PtA ao;
-            ao.x = fr_sub(fr_sub(fr_sub(fr_mul(l0, l1), A0), acc[g].x), mo.x);
-            ao.y = fr_sub(fr_mul(l1, fr_sub(acc[g].x, ao.x)), acc[g].y);
+            ao.x = ed_put0(w, wb + WIN_ADD_OUT0, fr_sub3(fr_mul(l0, l1), A0, acc[g].x, mo.x));
+            ao.y = fr_sub(fr_mul(l1, fr_sub_lazy(acc[g].x, ao.x)), acc[g].y);
             w.put_c(wb + WIN_ADD_LAMDA, fr_pack_canon(l0));
-            acc[g].x = ed_put0(w, wb + WIN_ADD_OUT0, ao.x); acc[g].y = ed_put0(w, wb + WIN_ADD_OUT1, ao.y);
+            acc[g].x = ao.x; acc[g].y = ed_put0(w, wb + WIN_ADD_OUT1, ao.y);
         }
     }
 #pragma unroll 1
