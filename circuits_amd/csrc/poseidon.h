@@ -164,8 +164,11 @@ HZ_HD Fr poseidon_hash(const Fr* in, const Fr* K, Sink& sink) {
     // Partial rounds, sparse form: lane 0 <- row . (y, lanes) + next constant ; lane i <- lane i + col[i] * y. Two rounds
     // per iteration so that lanes 1.. are reduced once per pair: round b's row is applied to the lanes as they were before
     // round a (its constants absorb colA through beta * yA), then lane i <- lane i + colA[i]*yA + colB[i]*yB in one
-    // reduction. Lanes 1.. grow by at most ~1.02 p per pair and are brought back below 4p after every pair.
+    // reduction. Lanes 1.. grow by at most ~1.02 p per pair (two products of values below p, the reduction's multiple of p) and are
+    // brought back below 4p after every THIRD pair: fr_muladd2 takes an addend below 8p, and 4p + 3 x 1.02 p stays under it (the
+    // conditional subtraction is 45 instructions per lane: after every pair it was 2 % of a permutation).
     const Fr* S = K + poseidon_k_part<T>();
+    int lazy = 0;
 #pragma unroll 1
     for (int r = 0; r + 1 < RP; r += 2) {
         Fr v[T + 1];
@@ -179,8 +182,11 @@ HZ_HD Fr poseidon_hash(const Fr* in, const Fr* K, Sink& sink) {
         st[0] = poseidon_row<T + 1>(S + T + 1, v, S + 2 * T + 2);
         const Fr* CA = S + 2 * T + 3;
 #pragma unroll
-        for (int j = 1; j < T; j++) {
-            st[j] = fr_cond_sub_4p(fr_muladd2(CA[j - 1], v[T], CA[T - 1 + j - 1], v[0], st[j]));
+        for (int j = 1; j < T; j++) st[j] = fr_muladd2(CA[j - 1], v[T], CA[T - 1 + j - 1], v[0], st[j]);
+        if (++lazy == 3) {   // (a branch around the subtraction only: two copies of the products cost the batch kernel twice its registers)
+            lazy = 0;
+#pragma unroll
+            for (int j = 1; j < T; j++) st[j] = fr_cond_sub_4p(st[j]);
         }
         S += 4 * T + 1;
     }
