@@ -709,9 +709,14 @@ __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const S
 // itself). Off-curve keys (a witness that fails BabyCheck anyway) take the circuit's own affine doubling chain instead (ed_dbl_chain_affine).
 struct PtP { Fr X, Y, Z; };
 // dbl-2008-hwcd for a*x^2 + y^2 = 1 + d*x^2*y^2 without the T coordinate (doubling only): 3M + 4S + 1 small-constant product
+// Every sum here only feeds products (operands below 2^257 > 10 p): none is reduced (fr.h "lazily reduced sums"). With the
+// coordinates below 2p: A, B, D and the squares are below 1.1 p; E = (X + Y)^2 - A - B + 4p < 5.2 p, G = D + B < 2.2 p,
+// F = G - 2 Z^2 + 4p < 6.2 p, H = D - B + 2p < 3.1 p; the three products come out below 1.2 p again.
 __device__ __forceinline__ PtP ed_dbl_proj(const EdK& K, const PtP& p) {
-    const Fr A = fr_sqr(p.X), B = fr_sqr(p.Y), C = fr_dbl(fr_sqr(p.Z)), D = fr_mul(K.a, A);
-    const Fr E = fr_sub(fr_sub(fr_sqr(fr_add(p.X, p.Y)), A), B), G = fr_add(D, B), F = fr_sub(G, C), H = fr_sub(D, B);
+    const Fr A = fr_sqr(p.X), B = fr_sqr(p.Y), C = fr_dbl_lazy(fr_sqr(p.Z)), D = fr_mul(K.a, A);
+    const Fr E = fr_sub2_lazy(fr_sqr(fr_add_lazy(p.X, p.Y)), A, B), G = fr_add_lazy(D, B);
+    const Fr zero = fr_zero();
+    const Fr F = fr_sub2_lazy(G, C, zero), H = fr_sub_lazy(D, B);
     PtP r;
     r.X = fr_mul(E, F); r.Y = fr_mul(G, H); r.Z = fr_mul(F, G);
     return r;

@@ -212,6 +212,26 @@ HZ_HD Fr fr_dbl_lazy(const Fr& a) {
     fr_norm(r.v);
     return r;
 }
+// a + b, not reduced: below A + B
+HZ_HD Fr fr_add_lazy(const Fr& a, const Fr& b) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    fr_norm(r.v);
+    return r;
+}
+// a - b - c + 4p in (0, A + 4p) for a in [0, A), b + c < 4p: not reduced
+HZ_HD Fr fr_sub2_lazy(const Fr& a, const Fr& b, const Fr& c2) {
+    Fr r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t x = (int32_t)a.v[i] - (int32_t)b.v[i] - (int32_t)c2.v[i] + (int32_t)fr_4p29(i) + c;
+        r.v[i] = (i < 8) ? (uint32_t)(x & (int32_t)HZ_M29) : (uint32_t)x;
+        c = x >> 29;
+    }
+    return r;
+}
 // m - a - b - c reduced to [0, 2p); m in [0, 2p), a, b, c in [0, 2p) with a + b + c < 4p
 HZ_HD Fr fr_sub3(const Fr& m, const Fr& a, const Fr& b, const Fr& c3) {
     Fr t;

@@ -48,6 +48,8 @@ int main() {
                 if (!same(fr_mul(fr_sub_lazy(a, b), mul_by), fr_mul(fr_sub(a, b), mul_by))) bad++;
                 if (!same(fr_mul(fr_sub_lazy(m, pool[(n * 3) % pool.size()]), mul_by), fr_mul(fr_sub(m, pool[(n * 3) % pool.size()]), mul_by))) bad++;
                 if (!same(fr_dbl_lazy(a), fr_dbl(a)) || !below_2p_normalised(fr_dbl_lazy(a))) bad++;
+                if (!same(fr_mul(fr_add_lazy(m, a), mul_by), fr_mul(fr_add(m, a), mul_by))) bad++;
+                if (!same(fr_mul(fr_sub2_lazy(m, a, b), mul_by), fr_mul(fr_sub(fr_sub(m, a), b), mul_by))) bad++;
                 const Fr q = fr_3a_b_c_lazy(m, b, small);
                 if (!same(fr_mul(q, mul_by), fr_mul(fr_add(fr_add(fr_add(fr_dbl(m), m), b), small), mul_by))) bad++;
             }
