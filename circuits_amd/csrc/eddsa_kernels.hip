@@ -75,7 +75,10 @@ __device__ Fr fr_sqrt_circom_dev(const Fr& n) {
 #define HZ_ED_G 4   // signatures per segment lane (launches above HZ_ED_SPLIT_MAX signatures: k_eddsa_seg)
 #endif
 #ifndef HZ_ED_SPLIT_MAX
-#define HZ_ED_SPLIT_MAX 8192   // launches up to this many signatures: segments as lanes, no inversion per step (seg_any_proj)
+// launches up to this many signatures: one segment of one signature per lane, no inversion per step (seg_any_proj). Measured with
+// k_eddsa_seg<4> as the alternative (two contexts in flight): 8 192 signatures 10.2 vs 12.7 ms per step, 16 384: 13.3-13.5 vs 14.6,
+// 32 768: 21.4 vs 20.7 -- the crossover lies between 8 and 16 batches of 2048 (profiles/r03_eddsa_seg_ab.txt)
+#define HZ_ED_SPLIT_MAX 16384
 #endif
 
 struct EdCtx {

@@ -105,19 +105,19 @@ def _compare_replicated(g, o, n_gpu, n_dist, which, rows_per_chunk=256):
                 r0 + r, k, which[k], int.from_bytes(a[r, k].tobytes(), "little"), int.from_bytes(b[r, k].tobytes(), "little")))
 
 
-@pytest.mark.parametrize("L,F", [(16, 4), (32, 64)])
-def test_throughput_signature_kernels_bit_exact(hz, L, F):
-    """Launches of more than 8 192 transactions take the THROUGHPUT form of the signature check -- k_eddsa_pre + k_eddsa_seg<4> (lane =
+@pytest.mark.parametrize("L,F,N", [(16, 4, 8192 + 67), (16, 4, 16384 + 67), (32, 64, 16384 + 67)])
+def test_throughput_signature_kernels_bit_exact(hz, L, F, N):
+    """Launches of more than 16 384 transactions take the THROUGHPUT form of the signature check -- k_eddsa_pre + k_eddsa_seg<4> (lane =
     segment x four signatures in lockstep, their state parked in LDS between turns, one shared inversion per ladder step) and
-    k_eddsa_fix<8> -- which is what bench.py measures; every other GPU test stays below that size and runs the split form. 8 259
-    RollupTx instances (not a multiple of four: one lane carries a padding slot that repeats its first unit), drawn from 40
-    different transactions (L1 creates, signed L2 transfers, exits) that the oracle evaluates once each; the whole physical buffer
-    is compared: 7.4 GB at (16, 4), and 11.8 GB at the benchmark's own (nLevels, maxFeeTx) = (32, 64), where k_smt's 33-level chains
-    and their empty-level blocks run at this unit count too. reference src/rollup-tx.circom:445-482,537-570, circomlib
-    eddsaposeidon.circom."""
+    k_eddsa_fix<8> -- which is what bench.py measures; between 8 192 and 16 384 the ladder keeps the split form (one segment of one
+    signature per lane) beside k_eddsa_fix<8>; every other GPU test stays below both sizes. 8 259 and 16 451 RollupTx instances (not
+    multiples of four or eight: lanes with a padding slot that repeats their first unit), drawn from 40 different transactions (L1
+    creates, signed L2 transfers, exits) that the oracle evaluates once each; the whole physical buffer is compared: up to 23.6 GB
+    at the benchmark's own (nLevels, maxFeeTx) = (32, 64), where k_smt's 33-level chains and their empty-level blocks run at this unit
+    count too. reference src/rollup-tx.circom:445-482,537-570, circomlib eddsaposeidon.circom."""
     from circuits_amd import builder as B
     bb = B.synthetic_batch(40, L, 6, F, n_accounts=12, exits=3, seed=4242)
-    D, N = bb.nTx, 8192 + 67
+    D = bb.nTx
     o = OracleCtx("rollup-tx", nLevels=L, maxFeeTx=F, n_instances=D)
     g = hz.ctx("rollup-tx", nLevels=L, maxFeeTx=F, n_instances=N)
     which = [(7 * k + 3) % D if k >= D else k for k in range(N)]
@@ -142,12 +142,12 @@ def test_throughput_signature_kernels_bit_exact(hz, L, F):
 
 
 def test_throughput_rollup_main_many_batches(hz):
-    """The benchmark's own schedule at a size where the throughput kernels run: RollupMain(8, 16, 3, 4) x 1 030 batches in ONE set of
-    launches (8 240 transactions: the signature chain pairs transactions of DIFFERENT batches), five different batches replicated on
+    """The benchmark's own schedule at a size where the throughput kernels run: RollupMain(8, 16, 3, 4) x 2 060 batches in ONE set of
+    launches (16 480 transactions: the ladder lanes hold transactions of DIFFERENT batches), five different batches replicated on
     the device. Every batch's hashGlobalInputs against the builder's, no constraint failure, and the complete logical witness of
     the first, a middle and the last instance against the oracle's."""
     from circuits_amd import builder as B
-    shape, D, N = (8, 16, 3, 4), 5, 1030
+    shape, D, N = (8, 16, 3, 4), 5, 2060
     bbs = [B.synthetic_batch(*shape, n_accounts=6 + b, exits=b % 3, seed=900 + b) for b in range(D)]
     o = OracleCtx("rollup-main", *shape, n_instances=D)
     g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3], n_instances=N)
