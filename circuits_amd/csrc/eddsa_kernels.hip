@@ -1073,7 +1073,7 @@ hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
 }
 hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
-    if (n <= 8192) return launch_eddsa_fix_g<1>(a, n, s);
+    if (n <= HZ_ED_SPLIT_MAX) return launch_eddsa_fix_g<1>(a, n, s);   // the same switch as the ladder (16 384 signatures: 12.9 ms per step against 13.3 with eight per lane)
     // Eight signatures per lane: 85 windows x (8 turns + one shared inversion) is still a shorter chain than the variable-base ladder
     // beside it (11.0 ms alone against 17.4), and an eighth of an inversion per window instead of a quarter is 0.2 G fewer
     // wave-instructions per 65 536 signatures (four per lane: 7.5 ms alone, step +0.3..0.6 ms; profiles/r03_eddsa_seg_ab.txt).

@@ -105,13 +105,13 @@ def _compare_replicated(g, o, n_gpu, n_dist, which, rows_per_chunk=256):
                 r0 + r, k, which[k], int.from_bytes(a[r, k].tobytes(), "little"), int.from_bytes(b[r, k].tobytes(), "little")))
 
 
-@pytest.mark.parametrize("L,F,N", [(16, 4, 8192 + 67), (16, 4, 16384 + 67), (32, 64, 16384 + 67)])
+@pytest.mark.parametrize("L,F,N", [(16, 4, 16384 + 67), (32, 64, 16384 + 67)])
 def test_throughput_signature_kernels_bit_exact(hz, L, F, N):
     """Launches of more than 16 384 transactions take the THROUGHPUT form of the signature check -- k_eddsa_pre + k_eddsa_seg<4> (lane =
     segment x four signatures in lockstep, their state parked in LDS between turns, one shared inversion per ladder step) and
-    k_eddsa_fix<8> -- which is what bench.py measures; between 8 192 and 16 384 the ladder keeps the split form (one segment of one
-    signature per lane) beside k_eddsa_fix<8>; every other GPU test stays below both sizes. 8 259 and 16 451 RollupTx instances (not
-    multiples of four or eight: lanes with a padding slot that repeats their first unit), drawn from 40 different transactions (L1
+    k_eddsa_fix<8> -- which is what bench.py measures; every other GPU test stays below that size and runs the split form. 16 451
+    RollupTx instances (not a multiple of four or eight: lanes with a padding slot that repeats their first unit), drawn from 40
+    different transactions (L1
     creates, signed L2 transfers, exits) that the oracle evaluates once each; the whole physical buffer is compared: up to 23.6 GB
     at the benchmark's own (nLevels, maxFeeTx) = (32, 64), where k_smt's 33-level chains and their empty-level blocks run at this unit
     count too. reference src/rollup-tx.circom:445-482,537-570, circomlib eddsaposeidon.circom."""
