@@ -58,7 +58,7 @@ EXPORTS = [
     "hz_version", "hz_last_error", "hz_device_count", "hz_ctx_create", "hz_ctx_destroy", "hz_witness_len",
     "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_copy_instance_inputs", "hz_inputs_packed_bytes", "hz_input_packed_width",
     "hz_input_packed_offset", "hz_host_alloc", "hz_host_free", "hz_inputs_upload", "hz_inputs_stage", "hz_inputs_stage_range", "hz_clear_inputs", "hz_input_count", "hz_input_name",
-    "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_read", "hz_witness_dev_ptr",
+    "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_failures", "hz_witness_read", "hz_witness_dev_ptr",
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_witness_enqueue_tail_chain", "hz_sha_blocks", "hz_sha_state_bytes", "hz_sha_export", "hz_sha_expand",
@@ -117,6 +117,7 @@ class Lib:
         c.hz_witness_enqueue.argtypes = [vp, vp]
         c.hz_witness_check.argtypes = [vp, ctypes.POINTER(hz_error)]
         c.hz_witness_run.argtypes = [vp, ctypes.POINTER(hz_error)]
+        c.hz_witness_failures.argtypes = [vp, ctypes.POINTER(hz_error), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         c.hz_witness_read.argtypes = [vp, ctypes.c_int32, u64, u64, vp]
         c.hz_witness_read_raw.argtypes = [vp, u64, u64, vp]
         c.hz_witness_dev_ptr.argtypes = [vp]
@@ -343,6 +344,18 @@ class Ctx:
         err = hz_error()
         self._raise(self.L.c.hz_witness_check(self.h, ctypes.byref(err)), err)
 
+    def failures(self):
+        """After run() / check(): the first violated constraint of every failing instance, ordered by instance, as
+        (instance, unit, constraint_id, name, lhs, rhs) tuples (hz_witness_failures)."""
+        n = ctypes.c_size_t(0)
+        self.L._check(self.L.c.hz_witness_failures(self.h, None, 0, ctypes.byref(n)))
+        if n.value == 0:
+            return []
+        arr = (hz_error * n.value)()
+        self.L._check(self.L.c.hz_witness_failures(self.h, arr, n.value, ctypes.byref(n)))
+        return [(e.instance, e.unit, e.constraint_id, self.L.c.hz_constraint_name(e.constraint_id).decode(),
+                 int.from_bytes(bytes(e.lhs), "little"), int.from_bytes(bytes(e.rhs), "little")) for e in arr]
+
     def set_inputs_json(self, text, instance=0):
         b = text.encode() if isinstance(text, str) else text
         self.L._check(self.L.c.hz_set_inputs_json(self.h, instance, b, len(b)))
@@ -360,6 +373,12 @@ class Ctx:
         buf = ctypes.create_string_buffer(32 * max(count, 1))
         self.L._check(self.L.c.hz_witness_read(self.h, instance, first, count, buf))
         return fr_from_bytes(buf.raw[:32 * count])
+
+    def read_bytes(self, first, count, instance=0):
+        """the same elements as read(), as 32-byte little-endian records (no Python integers: GB-sized compares)"""
+        buf = ctypes.create_string_buffer(32 * max(count, 1))
+        self.L._check(self.L.c.hz_witness_read(self.h, instance, first, count, buf))
+        return buf.raw[:32 * count]
 
     def read_raw_bytes(self, first=0, count=None):
         count = self.total() - first if count is None else count

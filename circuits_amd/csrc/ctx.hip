@@ -24,7 +24,13 @@ struct hz_ctx {
     Layout lo;
     int device = 0;
     DevBuf wit, sc_tx, sc_fee, err, msg, chain, stage;
-    DevBuf ed_side;   // the small-launch signature ladder's parked numerators (eddsa_side_bytes)
+    DevBuf ed_side;   // the small-launch signature ladder's parked numerators (eddsa_side_bytes), allocated by the first launch that needs it
+    // per-instance failure report (hz_witness_failures): every instance's lowest failing key, kept by report_fail beside the
+    // launch-wide minimum, and -- allocated by the first call that finds failures -- the operands of each
+    DevBuf inst_min, inst_rec;
+    bool inst_min_dirty = false;          // a failure was seen (or no check told otherwise) since inst_min was last reset
+    unsigned long long last_minkey = ~0ull;
+    bool checked = false;                 // hz_witness_check has completed for the last enqueue
     std::vector<uint8_t> input_set;
     std::vector<uint8_t> host_stage;
     hipStream_t last_stream = nullptr;
@@ -177,8 +183,11 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     if (e == hipSuccess) e = c->wit.alloc(lo.total * 32);
     if (e == hipSuccess) e = hipMemset(c->wit.p, 0, lo.total * 32);
     if (e == hipSuccess) e = c->err.alloc(sizeof(ErrBuf));
+    if (e == hipSuccess) e = c->inst_min.alloc((size_t)lo.n_inst * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->inst_min.p, 0xFF, c->inst_min.bytes);
+    if (e == hipSuccess) e = hipMemset(c->err.p, 0, offsetof(ErrBuf, rec));
+    if (e == hipSuccess) e = hipMemcpy((uint8_t*)c->err.p + offsetof(ErrBuf, inst_min), &c->inst_min.p, sizeof(void*), hipMemcpyHostToDevice);
     if (e == hipSuccess && lo.sec_tx >= 0) e = c->sc_tx.alloc((size_t)SC_COUNT * lo.sections[lo.sec_tx].n_units * sizeof(Fr));
-    if (e == hipSuccess && (lo.p.tmpl == T_ROLLUP_MAIN || lo.p.tmpl == T_ROLLUP_TX)) e = c->ed_side.alloc(eddsa_side_bytes(lo.sections[lo.sec_tx].n_units));
     if (e == hipSuccess && lo.sec_fee >= 0) e = c->sc_fee.alloc((size_t)SC_COUNT * lo.sections[lo.sec_fee].n_units * sizeof(Fr));
     if (e == hipSuccess && lo.sec_hi >= 0) {
         e = c->msg.alloc((size_t)lo.hi.sha.nblocks * 64 * lo.n_inst);
@@ -609,7 +618,16 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.upi = lo.sections[lo.sec_tx].upi; ea.ed = lo.rtx.ed;
     const uint32_t u0 = is_main ? c->sh_first : 0, ucnt = is_main ? c->sh_count : 0;
     ea.u0 = u0; ea.ucnt = ucnt;
-    ea.side = (uint32_t*)c->ed_side.p;   // sized for the whole section; a shard uses a prefix
+    {
+        // the split form (launches of <= HZ_ED_SPLIT_MAX signatures) parks its numerators in a side buffer: 84.7 KB per signature,
+        // allocated by the first launch that takes that form and sized for it (a shard: its own range, not the section)
+        const size_t need = eddsa_side_bytes(ucnt ? ucnt : n_units);
+        if (need > c->ed_side.bytes || (need && !c->ed_side.p)) {
+            HZ_HIP(hipStreamSynchronize(c->s_ed));
+            HZ_HIP(c->ed_side.alloc(need));
+        }
+    }
+    ea.side = (uint32_t*)c->ed_side.p;
     {
         // the signature ladders only need the front step: run them beside the hash/SMT chain
         // the two halves of the check (S*B8 and R8 + h*8A) are independent: two kernels on two streams, then the equality
@@ -746,7 +764,26 @@ static HashInputsArgs make_hi(hz_ctx* c, bool is_main) {
     return a;
 }
 
+// error buffer header: minkey = ~0, filter (= ~0 unless this is a second pass), count = 0
+static hz_status reset_err(hz_ctx* c, hipStream_t s, unsigned long long filter) {
+    HZ_HIP(hipMemsetAsync(c->err.p, 0xFF, 16, s));
+    HZ_HIP(hipMemsetAsync((uint8_t*)c->err.p + 16, 0, 8, s));
+    if (filter != ~0ull) {
+        c->filter_stage = filter;
+        HZ_HIP(hipMemcpyAsync((uint8_t*)c->err.p + 8, &c->filter_stage, 8, hipMemcpyHostToDevice, s));
+    } else {
+        // the per-instance minima are reset only when the last pass lowered one (or nobody checked): a clean serving loop pays nothing
+        if (c->inst_min_dirty || !c->checked) HZ_HIP(hipMemsetAsync(c->inst_min.p, 0xFF, c->inst_min.bytes, s));
+        c->inst_min_dirty = false;
+        c->checked = false;
+    }
+    return HZ_OK;
+}
+
+// filter != ~0: a second pass over the SAME inputs for the operands of failures the first pass found (hz_witness_check after an
+// overflow of the record list; hz_witness_failures): inputs staged for the next step stay staged, the per-instance minima stay.
 static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter) {
+    const bool rerun = filter != ~0ull;
     if (!c) return set_err(HZ_ERR_ARG, "hz_witness_enqueue: null context");
     const Layout& lo = c->lo;
     for (size_t i = 0; i < c->input_set.size(); i++)
@@ -755,7 +792,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
     // the legacy default stream has implicit-synchronisation semantics that do not mix with the
     // context's non-blocking side streams: a NULL stream means "the context's own stream"
     hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
-    if (c->any_staged) {   // scatter the staged inputs (hz_inputs_stage) into the witness layout
+    if (c->any_staged && !rerun) {   // scatter the staged inputs (hz_inputs_stage) into the witness layout
         HZ_HIP(hipStreamWaitEvent(s, c->ev_staged, 0));
         for (uint32_t b = 0; b < lo.n_inst;) {   // one launch per run of consecutive staged instances (usually: all of them)
             if (!c->staged[b]) { b++; continue; }
@@ -785,13 +822,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
         StreamAlias(hz_ctx* c_, hipStream_t s_) : c(c_), ed(c_->s_ed), fee(c_->s_fee) { if (c->exclusive) c->s_ed = c->s_fee = s_; }
         ~StreamAlias() { c->s_ed = ed; c->s_fee = fee; }
     } alias(c, s);
-    // error buffer header: minkey = ~0, filter (= ~0 unless hz_witness_check re-runs after an overflow), count = 0
-    HZ_HIP(hipMemsetAsync(c->err.p, 0xFF, 16, s));
-    HZ_HIP(hipMemsetAsync((uint8_t*)c->err.p + 16, 0, 8, s));
-    if (filter != ~0ull) {
-        c->filter_stage = filter;
-        HZ_HIP(hipMemcpyAsync((uint8_t*)c->err.p + 8, &c->filter_stage, 8, hipMemcpyHostToDevice, s));
-    }
+    { const hz_status st = reset_err(c, s, filter); if (st != HZ_OK) return st; }
     HZ_HIP(hipEventRecord(c->ev_reset, s));
     ErrBuf* err = (ErrBuf*)c->err.p;
     c->prof_used = 0;
@@ -943,6 +974,9 @@ extern "C" hz_status hz_witness_check(hz_ctx* c, hz_error* out) {
             return set_err(HZ_ERR_INPUT, "input %s[%llu] is not a canonical field element (>= r)", idx < c->lo.inputs.size() ? c->lo.inputs[idx].name.c_str() : "?",
                            (unsigned long long)(bad & ((1ull << 40) - 1)));
         }
+        c->checked = true;
+        c->last_minkey = hd.minkey;
+        c->inst_min_dirty = hd.minkey != ~0ull;
         if (hd.minkey == ~0ull) return HZ_OK;
         const unsigned int n = std::min<unsigned int>(hd.count, HZ_ERR_CAP);
         std::vector<ErrRec> recs(n);
@@ -964,6 +998,46 @@ extern "C" hz_status hz_witness_check(hz_ctx* c, hz_error* out) {
     fill_error(out, hd.minkey, nullptr);
     return set_err(HZ_ERR_CONSTRAINT, "Constraint doesn't match (%s, instance %d unit %d; operands not captured)", constraint_name((int)(hd.minkey & 0xFFFF)),
                    (int)(hd.minkey >> 40), (int)((hd.minkey >> 16) & 0xFFFFFF));
+}
+
+// The first violated constraint of EVERY instance of the last launch (a step evaluates 32 batches at once: the caller wants to know
+// which of them to reject, not only the first). The first pass already left each instance's lowest key in inst_min; the operands
+// come from one more pass over the same inputs in which the lane that owns an instance's lowest key writes them to the instance's slot.
+extern "C" hz_status hz_witness_failures(hz_ctx* c, hz_error* out, size_t cap, size_t* n_failed) {
+    if (!c || !n_failed || (cap && !out)) return set_err(HZ_ERR_ARG, "hz_witness_failures: null argument");
+    if (!c->checked) return set_err(HZ_ERR_ARG, "hz_witness_failures: call hz_witness_check / hz_witness_run first");
+    if (c->sharded) return set_err(HZ_ERR_ARG, "hz_witness_failures: not for tx-sharded contexts (one batch: hz_witness_check reports it)");
+    *n_failed = 0;
+    if (c->last_minkey == ~0ull) return HZ_OK;
+    HZ_HIP(hipSetDevice(c->device));
+    const uint32_t B = c->lo.n_inst;
+    hipStream_t s = c->last_stream ? c->last_stream : c->s_main;
+    std::vector<unsigned long long> mins(B);
+    HZ_HIP(hipMemcpyAsync(mins.data(), c->inst_min.p, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+    HZ_HIP(hipStreamSynchronize(s));
+    if (cap == 0) {   // count only: the first pass knows it
+        for (uint32_t b = 0; b < B; b++) *n_failed += mins[b] != ~0ull;
+        return HZ_OK;
+    }
+    if (!c->inst_rec.p) {
+        HZ_HIP(c->inst_rec.alloc((size_t)B * sizeof(ErrRec)));
+        HZ_HIP(hipMemcpyAsync((uint8_t*)c->err.p + offsetof(ErrBuf, inst_rec), &c->inst_rec.p, sizeof(void*), hipMemcpyHostToDevice, s));
+    }
+    HZ_HIP(hipMemsetAsync(c->inst_rec.p, 0xFF, c->inst_rec.bytes, s));
+    hz_status st = enqueue_impl(c, s, HZ_FILTER_PER_INST);
+    if (st != HZ_OK) return st;
+    std::vector<ErrRec> recs(B);
+    HZ_HIP(hipMemcpyAsync(recs.data(), c->inst_rec.p, (size_t)B * sizeof(ErrRec), hipMemcpyDeviceToHost, c->last_stream));
+    HZ_HIP(hipStreamSynchronize(c->last_stream));
+    c->enqueued = false;
+    size_t k = 0;
+    for (uint32_t b = 0; b < B; b++) {
+        if (mins[b] == ~0ull) continue;
+        if (k < cap) fill_error(&out[k], mins[b], recs[b].key == mins[b] ? &recs[b] : nullptr);
+        k++;
+    }
+    *n_failed = k;
+    return HZ_OK;
 }
 
 // ---- multi-GPU intra-batch sharding ------------------------------------------------------------------
@@ -1059,8 +1133,8 @@ extern "C" hz_status hz_sha_expand(hz_ctx* c, int32_t first, int32_t count, cons
         HZ_HIP(hipMemcpyAsync(c->chain.p, (const uint8_t*)d_buf + mb, cb, hipMemcpyDeviceToDevice, s));
     }
     if (!c->enqueued) {   // a rank with an empty transaction shard has not reset its failure record this step
-        HZ_HIP(hipMemsetAsync(c->err.p, 0xFF, 16, s));
-        HZ_HIP(hipMemsetAsync((uint8_t*)c->err.p + 16, 0, 8, s));
+        const hz_status st = reset_err(c, s, ~0ull);
+        if (st != HZ_OK) return st;
     }
     HZ_HIP(launch_sha_expand_range(make_hi(c, true), (uint32_t)first, (uint32_t)count, s));
     c->last_stream = s;

@@ -102,6 +102,9 @@ struct WitSboxSink {
 // evaluation order -- and (2) appends its operands to a bounded list. If the list overflowed and
 // lost the minimum, the host re-enqueues with `filter` = minkey so only that lane appends.
 #define HZ_ERR_CAP 1024
+// `filter` value of the second pass of hz_witness_failures: every instance's first failure, found by the first pass
+// (inst_min), gets its operands written to inst_rec[instance]; nothing else is recorded.
+#define HZ_FILTER_PER_INST (~1ull)
 struct ErrRec {
     unsigned long long key;
     uint32_t lhs[8];
@@ -112,6 +115,8 @@ struct ErrBuf {
     unsigned long long filter;  // ~0ull = record everything
     unsigned int count;
     unsigned int pad;
+    unsigned long long* inst_min;  // [n_instances] lowest failing key of each instance (~0ull: none); every pass lowers it
+    ErrRec* inst_rec;              // [n_instances] operands of those failures, written by the HZ_FILTER_PER_INST pass
     ErrRec rec[HZ_ERR_CAP];
 };
 
@@ -122,14 +127,25 @@ __device__ __forceinline__ unsigned long long err_key(uint32_t inst, uint32_t un
 __device__ __noinline__ void report_fail(ErrBuf* e, uint32_t inst, uint32_t unit, uint32_t cid, const Fr& lhs_m, const Fr& rhs_m) {
     const unsigned long long key = err_key(inst, unit, cid);
     atomicMin(&e->minkey, key);
-    if (e->filter != ~0ull && e->filter != key) return;
-    const unsigned int slot = atomicAdd(&e->count, 1u);
-    if (slot >= HZ_ERR_CAP) return;
+    const unsigned long long filter = e->filter;
+    ErrRec* dst;
+    if (filter == HZ_FILTER_PER_INST) {
+        // the lane that reports an instance's lowest key takes that instance's slot; a lane that reports the same key several
+        // times (a loop over the elements of one `===` array) keeps the first, as the shared list does
+        if (e->inst_min[inst] != key || atomicCAS(&e->inst_rec[inst].key, ~0ull, key) != ~0ull) return;
+        dst = &e->inst_rec[inst];
+    } else {
+        atomicMin(&e->inst_min[inst], key);
+        if (filter != ~0ull && filter != key) return;
+        const unsigned int slot = atomicAdd(&e->count, 1u);
+        if (slot >= HZ_ERR_CAP) return;
+        dst = &e->rec[slot];
+        dst->key = key;
+    }
     const Fc l = fr_to_canon(lhs_m), r = fr_to_canon(rhs_m);
-    e->rec[slot].key = key;
     for (int i = 0; i < 8; i++) {
-        e->rec[slot].lhs[i] = l.v[i];
-        e->rec[slot].rhs[i] = r.v[i];
+        dst->lhs[i] = l.v[i];
+        dst->rhs[i] = r.v[i];
     }
 }
 

@@ -1085,6 +1085,20 @@ hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// the field self test's square root (hz_fr_ops, HZ_FR_SQRT): circomlib pointbits.circom sqrt() -- the root <= (r-1)/2, 0 for a
+// non-residue -- one operand per lane, canonical in and out
+__global__ __launch_bounds__(256) void k_fr_sqrt(const uint8_t* __restrict__ a, uint8_t* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        store_fr(out + i * 32, fr_to_canon(fr_sqrt_circom_dev(fr_from_canon(load_fr(a + i * 32)))));
+}
+hipError_t launch_fr_sqrt(const void* d_a, void* d_out, size_t n, hipStream_t s) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fr_sqrt, dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)d_a, (uint8_t*)d_out, n);
+    return hipGetLastError();
+}
+
 // `component main = AySign2Ax()` (test/lib/utils-bjj.test.js:104-150): one lane per instance
 __global__ __launch_bounds__(HZ_BLOCK) void k_ay_sign_2_ax_main(const GadgetArgs a, const EddsaOff o) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

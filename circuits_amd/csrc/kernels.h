@@ -199,6 +199,7 @@ hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s);
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s);
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s);
 hipError_t launch_gadget(int tmpl, const GadgetArgs& a, hipStream_t s);
+hipError_t launch_fr_sqrt(const void* d_a, void* d_out, size_t n, hipStream_t s);   // eddsa_kernels.hip (hz_fr_ops HZ_FR_SQRT)
 hipError_t launch_ay_sign_2_ax_main(const GadgetArgs& a, const EddsaOff& o, hipStream_t s);   // eddsa_kernels.hip (shares the curve code)
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s);

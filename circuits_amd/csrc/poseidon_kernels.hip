@@ -12,6 +12,7 @@
 #include "hostutil.h"
 
 namespace hz {
+hipError_t launch_fr_sqrt(const void* d_a, void* d_out, size_t n, hipStream_t s);   // eddsa_kernels.hip (beside the curve code that uses it)
 
 template <int T, bool WIT>
 __global__ __launch_bounds__(256) void poseidon_batch_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
@@ -119,7 +120,7 @@ extern "C" hz_status hz_poseidon_batch_dev(int32_t t, size_t n, const void* d_in
 }
 
 extern "C" hz_status hz_fr_ops(int32_t device, int32_t op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
-    if (op < 0 || op > HZ_FR_MIX || (n && (!a || !out))) return set_err(HZ_ERR_ARG, "hz_fr_ops: bad argument");
+    if (op < 0 || op > HZ_FR_SQRT || (n && (!a || !out))) return set_err(HZ_ERR_ARG, "hz_fr_ops: bad argument");
     if (hz_device_count() <= 0) return set_err(HZ_ERR_NODEVICE, "no usable gfx950 device");
     if (n == 0) return HZ_OK;
     HZ_HIP(hipSetDevice(device));
@@ -135,7 +136,8 @@ extern "C" hz_status hz_fr_ops(int32_t device, int32_t op, size_t n, const uint8
     }
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(fr_ops_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, op, (const uint8_t*)d_a.p, (const uint8_t*)d_b.p, (uint8_t*)d_o.p, n);
+    if (op == HZ_FR_SQRT) HZ_HIP(launch_fr_sqrt(d_a.p, d_o.p, n, 0));
+    else hipLaunchKernelGGL(fr_ops_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, op, (const uint8_t*)d_a.p, (const uint8_t*)d_b.p, (uint8_t*)d_o.p, n);
     HZ_HIP(hipGetLastError());
     HZ_HIP(hipDeviceSynchronize());
     HZ_HIP(hipMemcpy(out, d_o.p, n * 32, hipMemcpyDeviceToHost));

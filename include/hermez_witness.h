@@ -170,6 +170,13 @@ const char* hz_input_name(const hz_ctx* ctx, int32_t i, uint64_t* flat_len);
 hz_status hz_witness_enqueue(hz_ctx* ctx, void* stream);
 hz_status hz_witness_check(hz_ctx* ctx, hz_error* err);
 hz_status hz_witness_run(hz_ctx* ctx, hz_error* err);
+/* After hz_witness_check / hz_witness_run: the first violated constraint of EVERY instance of that launch, ordered by instance
+ * (out[0] is what hz_witness_check reported). The reference evaluates one circuit per calculateWitness call and throws at its first
+ * failing `===` (test/rollup-main.test.js:868-877, test/rollup-tx.test.js:911-918); a launch here evaluates n_instances of them, and
+ * a serving loop has to know every batch to reject, not only the first. *n_failed = number of failing instances (0 when the launch
+ * was clean), of which min(cap, *n_failed) are written. cap = 0 only counts; otherwise the operands cost one more pass over the
+ * kernels when there are failures. */
+hz_status hz_witness_failures(hz_ctx* ctx, hz_error* out, size_t cap, size_t* n_failed);
 
 /* Per-kernel timing of the last enqueue, measured with HIP events on the launch stream.
  * `algorithmic_bytes` = 32 B x (witness signals the kernel is responsible for) x units.
@@ -242,7 +249,8 @@ hz_status hz_poseidon_batch_dev(int32_t t, size_t n, const void* d_in, void* d_o
 
 /* Field self test (SURVEY 8a' K0): out[i] = a[i] (op) b[i] over BN254 Fr, one operation per lane, canonical operands and results.
  * No reference counterpart (the reference's field is ffiasm's Fr, tools/helpers/actions.js:207-215); used by tests/ only. */
-enum { HZ_FR_ADD = 0, HZ_FR_SUB = 1, HZ_FR_MUL = 2, HZ_FR_SQR = 3, HZ_FR_INV = 4 /* inverse(0) = 0 */, HZ_FR_MULADD = 5 /* a*b + a + b */, HZ_FR_MIX = 6 /* 2a * (-b) */ };
+enum { HZ_FR_ADD = 0, HZ_FR_SUB = 1, HZ_FR_MUL = 2, HZ_FR_SQR = 3, HZ_FR_INV = 4 /* inverse(0) = 0 */, HZ_FR_MULADD = 5 /* a*b + a + b */, HZ_FR_MIX = 6 /* 2a * (-b) */,
+       HZ_FR_SQRT = 7 /* circomlib pointbits.circom sqrt(): the root <= (r-1)/2 of a, 0 when a is a non-residue (AySign2Ax, src/lib/utils-bjj.circom:37-58) */ };
 hz_status hz_fr_ops(int32_t device, int32_t op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 
 /* multi-GPU, one process per GPU (reference src/rollup-main.circom:93-99: every DecodeTx / RollupTx is

@@ -18,11 +18,19 @@
 namespace orc {
 
 // ---- witness writer + first-failure record ---------------------------------------------------
-struct Fail {
+struct FailRec {
     bool failed = false;
     uint64_t key = ~0ull;
     int inst = 0, unit = 0, cid = 0;
     F lhs, rhs;
+    void take(uint64_t k, int i, int u, int c, const F& l, const F& r) {
+        if (k >= key) return;   // lowest key; among equal keys the first evaluated
+        failed = true; key = k; inst = i; unit = u; cid = c; lhs = l; rhs = r;
+    }
+};
+// the first failure of the whole run and of every instance (orc_failure_of: what the product's hz_witness_failures reports)
+struct Fail : FailRec {
+    std::vector<FailRec> per_inst;
 };
 
 struct W {
@@ -45,15 +53,8 @@ struct W {
     void chk(int cid, const F& lhs, const F& rhs) const {
         if (lhs == rhs) return;
         const uint64_t key = ((uint64_t)inst << 40) | ((uint64_t)(uint32_t)err_unit << 16) | (uint32_t)cid;
-        if (key < fail->key) {
-            fail->failed = true;
-            fail->key = key;
-            fail->inst = (int)inst;
-            fail->unit = err_unit;
-            fail->cid = cid;
-            fail->lhs = lhs;
-            fail->rhs = rhs;
-        }
+        fail->take(key, (int)inst, err_unit, cid, lhs, rhs);
+        if (inst < fail->per_inst.size()) fail->per_inst[inst].take(key, (int)inst, err_unit, cid, lhs, rhs);
     }
 };
 

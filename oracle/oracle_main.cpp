@@ -297,6 +297,7 @@ extern "C" int orc_run(void* h, int32_t* err_inst, int32_t* err_unit, int32_t* e
     for (size_t i = 0; i < c->input_set.size(); i++)
         if (!c->input_set[i]) return 4;
     c->fail = Fail();
+    c->fail.per_inst.assign(c->lo.n_inst, FailRec());
     if (c->lo.p.tmpl == T_ROLLUP_MAIN) {
         for (uint32_t b = 0; b < c->lo.n_inst; b++) run_rollup_main(c, b);
     }
@@ -325,6 +326,18 @@ extern "C" int orc_run(void* h, int32_t* err_inst, int32_t* err_unit, int32_t* e
     return 0;
 }
 
+// the first failure of one instance in the last run: 0 = none, 3 = filled (the per-instance twin of orc_run's report)
+extern "C" int orc_failure_of(void* h, int instance, int32_t* err_unit, int32_t* err_cid, uint8_t* lhs, uint8_t* rhs) {
+    OrcCtx* c = (OrcCtx*)h;
+    if (instance < 0 || (size_t)instance >= c->fail.per_inst.size()) return 1;
+    const FailRec& f = c->fail.per_inst[instance];
+    if (!f.failed) return 0;
+    if (err_unit) *err_unit = f.unit;
+    if (err_cid) *err_cid = f.cid;
+    if (lhs) f.lhs.to_bytes(lhs);
+    if (rhs) f.rhs.to_bytes(rhs);
+    return 3;
+}
 extern "C" int orc_read(void* h, int instance, uint64_t first, uint64_t count, uint8_t* out) {
     OrcCtx* c = (OrcCtx*)h;
     if (first + count > c->lo.per_instance) return 1;

@@ -5,7 +5,7 @@ Sources of each fixture:
   poseidon_kat.json  -- (a) known answers published in the test suites of the upstream packages that
       hold the algorithm (circomlib / its Go twin go-iden3-crypto; the reference pins circomlib
       0.5.2, package-lock.json:861-862, which is not on disk), quoted from memory and then REPRODUCED
-      by the independently re-derived Grain-LFSR parameters of oracle/pyref/poseidon_params.py;
+      by the independently re-derived Grain-LFSR parameters of tools/poseidon_params.py;
       (b) seeded random vectors evaluated by that Python big-int implementation.
 The reference's own tests hold no literal Poseidon output: Poseidon parity is pinned
 on (a), not on the reference repository.
@@ -17,7 +17,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, os.path.join(ROOT, "oracle", "pyref"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from poseidon_params import P, poseidon, generate  # noqa: E402
 
 UPSTREAM_KAT = [

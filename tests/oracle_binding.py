@@ -106,10 +106,27 @@ class OracleCtx:
             return (a.value, b.value, cc.value, self.o.c.orc_constraint_name(cc.value).decode(), int.from_bytes(l.raw, "little"), int.from_bytes(r.raw, "little"))
         raise RuntimeError("oracle run rc=%d (missing input?)" % rc)
 
+    def failure_of(self, instance):
+        """first failure of one instance in the last run: None or (unit, constraint id, lhs, rhs)"""
+        u, cc = ctypes.c_int32(), ctypes.c_int32()
+        l, r = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        f = self.o.c.orc_failure_of
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, ctypes.c_void_p]
+        rc = f(self.h, instance, ctypes.byref(u), ctypes.byref(cc), l, r)
+        if rc == 0:
+            return None
+        assert rc == 3
+        return (u.value, cc.value, int.from_bytes(l.raw, "little"), int.from_bytes(r.raw, "little"))
+
     def read(self, first, count, instance=0):
         buf = ctypes.create_string_buffer(32 * count)
         assert self.o.c.orc_read(self.h, instance, first, count, buf) == 0
         return fr_from_bytes(buf.raw)
+
+    def read_bytes(self, first, count, instance=0):
+        buf = ctypes.create_string_buffer(32 * count)
+        assert self.o.c.orc_read(self.h, instance, first, count, buf) == 0
+        return buf.raw
 
     def read_raw_bytes(self, first=0, count=None):
         count = self.total() - first if count is None else count

@@ -71,13 +71,29 @@ def test_hip_poseidon_golden(hz):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("t", [3, 4, 5, 7])
+@pytest.mark.parametrize("t", [2, 3, 4, 5, 6, 7])
 def test_hip_poseidon_sbox_witness_bit_exact(hz, oracle, t):
     rows = _cases(t, 130, 31 * t)
     got, gw = hz.poseidon_batch(t, rows, witness=True)
     exp, ew = oracle.poseidon_batch(t, rows, witness=True)
     assert got == exp
     assert gw == ew
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [2, 3, 4, 5, 6, 7])
+def test_hip_poseidon_at_the_top_of_the_lazy_ranges(hz, oracle, t):
+    """tools/range_check.py proves the bounds of the lazily reduced lanes (they peak at 7.03 p against the 8 p the product takes);
+    this feeds the batch kernel the inputs that sit highest in those ranges -- every input p - 1, p - 2, (p - 1) / 2 +- 1, 2^253 and
+    friends, on whole wavefronts so that the wave-uniform rare-subtraction branch (fr_cond_sub_p_rare) is taken and skipped -- with
+    and without the S-box witness, all widths, against the oracle's dense evaluation."""
+    tops = [P - 1, P - 2, P - 3, (P - 1) // 2, (P + 1) // 2, (1 << 253) - 1, 1 << 253, (1 << 253) + 1, P - (1 << 29), P - (1 << 232), (1 << 232) - 1, 1, 0]
+    rows = [[v] * (t - 1) for v in tops for _ in range(64)]                      # whole wavefronts of one extreme value
+    rows += [[tops[(i + j) % len(tops)] for j in range(t - 1)] for i in range(128)]   # mixed lanes
+    got, gw = hz.poseidon_batch(t, rows, witness=True)
+    exp, ew = oracle.poseidon_batch(t, rows, witness=True)
+    assert got == exp and gw == ew
+    assert hz.poseidon_batch(t, rows)[0] == exp
 
 
 @pytest.mark.gpu
@@ -111,6 +127,15 @@ def test_hip_field_ops_against_python_bigints(hz):
         m = n if op != 4 else 4096
         got = hz.fr_ops(op, a[:m], b[:m])
         assert got == [f(x, y) for x, y in zip(a[:m], b[:m])], "field op %d" % op
+    # op 7, the square root of circomlib's pointbits.circom (AySign2Ax): the root <= (r-1)/2, 0 for a non-residue
+    m = 2048
+    sq = [x * x % Pm for x in a[:m // 2]] + a[m // 2:m]
+    got = hz.fr_ops(7, sq, None)
+    for x, r in zip(sq, got):
+        if pow(x, (Pm - 1) // 2, Pm) in (0, 1):
+            assert r * r % Pm == x and r <= (Pm - 1) // 2, x
+        else:
+            assert r == 0, x
 
 
 def test_canonical_sbox_form_matches_the_montgomery_form(tmp_path):

@@ -557,6 +557,49 @@ def test_config4_rollup_main_2048_32_full_size_bit_exact(hz):
     _compare_chunked(g, o)
 
 
+def test_headline_launch_whole_buffer(hz):
+    """The launch bench.py times, compared whole: RollupMain(2048, 32, 256, 64) x 9 batches in ONE set of launches -- 18 432 transactions,
+    above the size switch of the signature check (k_eddsa_pre + k_eddsa_seg<4> + k_eddsa_fix<8>, lanes holding signatures of different
+    batches), the early HashInputs tail over 766 blocks x 9 with its half-wavefront bit stores, k_smt's empty-level blocks at this
+    unit count. Two different batches replicated on the device; the complete 3.86 GB witness of the first, the middle and the last
+    instance against the oracle's (reference src/rollup-main.circom:201-475)."""
+    import threading
+    from circuits_amd import builder as B
+    shape, N = (2048, 32, 256, 64), 9
+    bbs = [B.synthetic_batch(*shape, n_accounts=2048, exits=32, seed=0x48455A31),
+           B.synthetic_batch(*shape, n_accounts=4096, exits=7, seed=0x48455A32)]
+    which = [0, 1, 1, 0, 1, 0, 0, 1, 1]
+    g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3], n_instances=N)
+    for b in (0, 1):
+        g.set_inputs(bbs[b].get_input(), instance=b)
+    for k in range(2, N):
+        g.copy_instance_inputs(which[k], k)
+    g.enqueue()
+    oc = [OracleCtx("rollup-main", *shape) for _ in bbs]
+    res = [None, None]
+
+    def work(b):
+        oc[b].set_inputs(bbs[b].get_input())
+        res[b] = oc[b].run()
+    ths = [threading.Thread(target=work, args=(b,)) for b in (0, 1)]   # ctypes releases the GIL: the two batches side by side
+    for t in ths:
+        t.start()
+    g.check()
+    for t in ths:
+        t.join()
+    assert res == [None, None]
+    sig = g.lookup("main.hashGlobalInputs")
+    for k in range(N):
+        assert g.read(sig, 1, k)[0] == bbs[which[k]].get_hash_inputs()
+    wl = g.witness_len()
+    assert wl == 120493511
+    for k in (0, N // 2, N - 1):
+        o = oc[which[k]]
+        for first in range(0, wl, 1 << 21):
+            cnt = min(1 << 21, wl - first)
+            assert g.read_bytes(first, cnt, k) == o.read_bytes(first, cnt, 0), "instance %d, elements from %d" % (k, first)
+
+
 def test_command_line_input_then_witness(hz, tmp_path):
     """`python -m circuits_amd input` then `witness` (the reference's `node build-circuit.js input|witness` pair): the .wtns holds
     the public hash the builder predicted."""

@@ -187,6 +187,94 @@ __device__ __forceinline__ F29 mul_v6(const F29& a, const F29& b) {
     return r;
 }
 
+
+// V8: 5 x 52-bit limbs held as doubles (R = 2^260); every limb product by the two-FMA split in round-toward-zero (Emmart, Zheng,
+// Weems, ARITH 2018): hi = fma_rz(a, b, 2^104) = 2^104 + floor(ab / 2^52) 2^52, lo = fma_rz(a, b, (2^104 + 2^52) - hi) = 2^52 + ab mod 2^52;
+// the mantissa fields of hi / lo ARE the two 52-bit halves, so the column sums are integer additions of the bit patterns (the exponent
+// fields, a known count per column, are subtracted up front). Per limb product: 2 v_fma_f64 + 1 v_add_f64 + 2 v_lshl_add_u64 = 5
+// instructions for 52 x 52 bit-products; v_mad_u64_u32 does 29 x 29 in ONE. N products share one reduction (the fr_dot form).
+struct F52 { double v[5]; };
+#define V8_C1 0x1p104
+#define V8_C2 (0x1p104 + 0x1p52)
+#define V8_LOB 0x4330000000000000ull   // bit pattern of 2^52
+#define V8_HIB 0x4670000000000000ull   // bit pattern of 2^104
+#define V8_M52 0xfffffffffffffull
+__device__ __forceinline__ constexpr double p52(int i) {
+    constexpr double k[5] = {(double)0x1f593f0000001ull, (double)0x4879b9709143eull, (double)0x181585d2833e8ull, (double)0xa029b85045b68ull, (double)0x30644e72e131ull};
+    return k[i];
+}
+#define V8_PINV ((double)0x1f593efffffffull)   // -p^-1 mod 2^52
+__device__ __forceinline__ void v8_mac(uint64_t* col, int k, double a, double b) {
+    const double hi = __builtin_fma(a, b, V8_C1);          // MODE.fp_round (f64) = toward zero, set once by the kernel
+    const double lo = __builtin_fma(a, b, V8_C2 - hi);
+    col[k] += (uint64_t)__double_as_longlong(lo);
+    col[k + 1] += (uint64_t)__double_as_longlong(hi);
+}
+__device__ __forceinline__ constexpr int v8_pairs(int k) { return (k < 0 || k > 8) ? 0 : (k < 5 ? k + 1 : 9 - k); }
+template <int N>
+__device__ __forceinline__ F52 mul_v8(const F52* a, const F52* b) {
+    uint64_t col[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++)   // exponent fields of every lo / hi this column will receive: N products + one reduction
+        col[k] = 0ull - (uint64_t)(N + 1) * ((uint64_t)v8_pairs(k) * V8_LOB + (uint64_t)v8_pairs(k - 1) * V8_HIB);
+#pragma unroll
+    for (int n = 0; n < N; n++)
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 5; j++) v8_mac(col, i + j, a[n].v[i], b[n].v[j]);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint64_t tl = col[i] & V8_M52;
+        const double td = __longlong_as_double((long long)(tl | V8_LOB)) - 0x1p52;
+        const double qh = __builtin_fma(td, V8_PINV, V8_C1);
+        const double ql = __builtin_fma(td, V8_PINV, V8_C2 - qh);   // 2^52 + (t * pinv mod 2^52)
+        const double q = ql - 0x1p52;
+#pragma unroll
+        for (int j = 0; j < 5; j++) v8_mac(col, i + j, q, p52(j));
+        col[i + 1] += col[i] >> 52;   // col[i] is a multiple of 2^52 now
+    }
+    F52 r;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        r.v[k] = __longlong_as_double((long long)((col[5 + k] & V8_M52) | V8_LOB)) - 0x1p52;
+        if (k < 4) col[6 + k] += col[5 + k] >> 52;
+    }
+    return r;
+}
+template <int N>
+__global__ __launch_bounds__(64) void kbench8(uint32_t* x, int n, uint64_t* dbg) {
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");   // f64 rounding: toward zero
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    F52 a[N], b[N];
+    for (int i = 0; i < 5; i++) {
+        const uint64_t la = ((uint64_t)x[tid * 18 + 2 * i] | ((uint64_t)x[tid * 18 + 2 * i + 1] << 32)) & (i == 4 ? 0x1fffffffffffull : V8_M52);
+        const uint64_t lb = ((uint64_t)x[tid * 18 + 8 + 2 * i] | ((uint64_t)x[tid * 18 + 9 + 2 * i] << 32)) & (i == 4 ? 0x1fffffffffffull : V8_M52);
+        for (int q = 0; q < N; q++) { a[q].v[i] = (double)(la ^ (uint64_t)q); b[q].v[i] = (double)(lb ^ (uint64_t)(3 * q)); }
+    }
+    if (tid == 777 && dbg) for (int i = 0; i < 5; i++) { dbg[i] = (uint64_t)a[0].v[i]; dbg[5 + i] = (uint64_t)b[0].v[i]; }
+    for (int i = 0; i < n; i++) {
+        a[0] = mul_v8<N>(a, b);
+        for (int q = 1; q < N; q++) a[q].v[0] = a[0].v[1];   // the other products follow the chain
+    }
+    if (tid == 777 && dbg) for (int i = 0; i < 5; i++) dbg[10 + i] = (uint64_t)a[0].v[i];
+    for (int i = 0; i < 5; i++) { x[tid * 18 + 2 * i] = (uint32_t)(uint64_t)a[0].v[i]; }
+}
+// the adopted 9 x 29-bit form with N products per reduction (fr.h fr_dot<N>), same dependent chain
+template <int N>
+__global__ __launch_bounds__(64) void kbench_dot(uint32_t* x, int n) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr a[N], b[N];
+    for (int q = 0; q < N; q++)
+        for (int i = 0; i < 9; i++) { a[q].v[i] = (x[tid * 18 + i] ^ q) & HZ_M29; b[q].v[i] = (x[tid * 18 + 9 + i] ^ (3 * q)) & HZ_M29; }
+    for (int q = 0; q < N; q++) { a[q].v[8] &= 0xffff; b[q].v[8] &= 0xffff; }
+    for (int i = 0; i < n; i++) {
+        a[0] = fr_dot<N>(a, b);
+        for (int q = 1; q < N; q++) a[q].v[0] = a[0].v[1];
+    }
+    for (int i = 0; i < 9; i++) x[tid * 18 + i] = a[0].v[i];
+}
+
 template <int V>
 __global__ __launch_bounds__(64) void kbench(uint32_t* x, int n) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -219,7 +307,9 @@ int main() {
         for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t)(i * 2654435761u + 12345);
         uint32_t* d;
         hipMalloc(&d, h.size() * 4);
-        for (int v : {3, 4, 5, 7}) {
+        uint64_t* dbg;
+        hipMalloc(&dbg, 15 * 8);
+        for (int v : {4, 7, 8, 10, 9}) {
             hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
@@ -231,9 +321,20 @@ int main() {
                 if (v == 5) hipLaunchKernelGGL(kbench<5>, dim3(waves), dim3(64), 0, 0, d, n);
                 if (v == 6) hipLaunchKernelGGL(kbench<6>, dim3(waves), dim3(64), 0, 0, d, n);
                 if (v == 7) hipLaunchKernelGGL(kbench<7>, dim3(waves), dim3(64), 0, 0, d, n);
+                if (v == 8) hipLaunchKernelGGL(kbench8<1>, dim3(waves), dim3(64), 0, 0, d, n, dbg);       // double-FMA limbs, one product
+                if (v == 9) hipLaunchKernelGGL(kbench8<3>, dim3(waves), dim3(64), 0, 0, d, n, (uint64_t*)nullptr);   // three products, one reduction
+                if (v == 10) hipLaunchKernelGGL(kbench_dot<3>, dim3(waves), dim3(64), 0, 0, d, n);          // fr_dot<3>, 9 x 29
             };
             launch();
             hipDeviceSynchronize();
+            if (v == 8 && waves == 256 * 4) {   // operands and result of one lane, for tools/microbench/check_v8.py (a0 * b^n / R^n mod p, R = 2^260)
+                uint64_t h8[15];
+                hipMemcpy(h8, dbg, sizeof h8, hipMemcpyDeviceToHost);
+                printf("V8CHECK n=%d", n);
+                for (int i = 0; i < 15; i++) printf(" %llx", (unsigned long long)h8[i]);
+                printf("\n");
+                hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+            }
             hipEventRecord(e0);
             launch();
             hipEventRecord(e1);
@@ -243,7 +344,9 @@ int main() {
             uint32_t chk[9];
             hipMemcpy(chk, d + 18 * 777, sizeof chk, hipMemcpyDeviceToHost);
             printf("[%08x %08x] ", chk[0], chk[8]);
-            printf("waves/SIMD=%d variant=%d: %.2f ms  %.1f ns per dependent mul per wave  %.2f Gmul/s\n", waves / 1024, v, ms, ms * 1e6 / n, (double)threads * n / ms / 1e6);
+            const int prods = (v == 9 || v == 10) ? 3 : 1;
+            printf("waves/SIMD=%d variant=%d: %.2f ms  %.1f ns per dependent step per wave  %.2f Gmul/s (%d product%s per reduction)\n", waves / 1024, v, ms, ms * 1e6 / n,
+                   (double)threads * n * prods / ms / 1e6, prods, prods > 1 ? "s" : "");
         }
         hipFree(d);
     }

@@ -17,14 +17,14 @@ implementations) bring a partial round down to 2t - 1 constant products:
    lane 0). After the last partial round the pending N_RP is applied once (dense, (t-1)^2 products).
 
 state[0] is never transformed, so the S-box inputs and outputs are bit-identical to the naive
-evaluation; `check()` verifies this against oracle/pyref for random inputs.
+evaluation; `check()` verifies this against tools/poseidon_params.py (the textbook permutation) for random inputs.
 """
 import os
 import random
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle", "pyref"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from poseidon_params import P, N_ROUNDS_P, generate  # noqa: E402
 
 
