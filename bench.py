@@ -135,10 +135,10 @@ def poseidon_rates(L, torch):
 
 def measured_traffic(kernel, bpl):
     """HBM bytes of one launch of `kernel` (mean over its launches of the transaction grid) from the committed rocprofv3 PMC passes
-    (profiles/r03_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
+    (profiles/r04_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
     this configuration."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_counters.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_hbm_counters.json")))
         if bpl is not None and d.get("batches_per_launch") != bpl:
             return None
         k = d["kernels"][kernel]
@@ -147,6 +147,25 @@ def measured_traffic(kernel, bpl):
         return int(k["fetch_bytes"] + k["write_bytes"])
     except (OSError, KeyError, ValueError):
         return None
+
+
+def measured_valu(kernel=None):
+    """VALU wave-instructions from the committed rocprofv3 SQ_INSTS_VALU pass of this command line (profiles/r04_valu_counters.json,
+    tools/gpu_pmc.sh): per step over every kernel, or per launch of `kernel`'s transaction grid. None when the file is missing."""
+    for name in ("r04_valu_counters.json",):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if kernel is None:
+                return d["insts_valu_per_step"], d
+            return d["kernels"][kernel]["insts_valu_largest_grid_mean"], d
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+# cycles one SIMD spends on one wave-instruction of this instruction mix when nothing stalls: 61 % v_mad_u64_u32 at 4.6-4.9, the 64-bit
+# shifts / adds and v_mul_lo_u32 at 4.1-4.3, a few 32-bit VOP2 at 2.1 (tools/microbench/instbench.hip -> profiles/r03_instbench.txt)
+VALU_CYCLES_PER_INST = 4.3
 
 
 def host_limits():
@@ -229,8 +248,10 @@ def with_node_host(args):
     the same loop at 1.14 M tx/s instead of 1.61 M (the device's hardware queue slots are oversubscribed and time-sliced). So the
     benchmark proper runs in a worker process (this file again, --gpu-worker), which leaves the packed batches behind; when it has
     exited the Node host replays the upload-inclusive loop on them, and this process prints the one merged line."""
+    import shutil
     import tempfile
-    keep = tempfile.mktemp(prefix="hz_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    keep_dir = tempfile.mkdtemp(prefix="hz_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)   # a directory of our own: no predictable path
+    keep = os.path.join(keep_dir, "batches")
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--gpu-worker", "--keep-packed", keep]
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
@@ -249,9 +270,7 @@ def with_node_host(args):
             out["node_host"] = node_line
         print(json.dumps(out))
     finally:
-        for ext in (".packed", ".json"):
-            if os.path.exists(keep + ext):
-                os.unlink(keep + ext)
+        shutil.rmtree(keep_dir, ignore_errors=True)
 
 
 def bench_sharded(args, L, D, packed, expected):
@@ -417,6 +436,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="contexts in flight (each with its own witness buffers and streams): the fee/SHA tail of one step overlaps the next step's kernels")
     ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = every CPU this process may use -- cgroup quota, affinity -- as far as a third of its memory allows: a RollupMain(2048, 32, ..) oracle holds a 3.9 GB witness)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="nTx of the CPU-baseline sample (0 = skip; default: the headline shape, one batch per process)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip single_batch_latency_ms and batches_sweep (the occupancy points of SURVEY 8d)")
     ap.add_argument("--no-deep-state", action="store_true", help="skip the deep_state line (the same step on a state of 2^20 accounts)")
     ap.add_argument("--deep-accounts-log2", type=int, default=20)
     ap.add_argument("--batches-per-launch", type=int, default=32,
@@ -478,8 +498,13 @@ def main():
     # every batch keeps its whole witness resident (3.86 GB at the default shape): fit batches x contexts into free HBM
     probe = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=1)
     layout = probe.packed_layout()
-    per_batch = probe.witness_len() * 32 * 1.04 + (64 << 20) + layout[0]
     del probe
+    # what one resident batch costs: the library's own count for a context of Bp instances (witness, scratch, upload staging, and up to
+    # 16 384 transactions per launch the signature ladder's side buffer -- 84.7 KB per transaction) plus allocator slack
+
+    def per_batch_bytes(b):
+        return L.template_device_bytes("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, n_instances=b) / b * 1.02 + (64 << 20)
+    per_batch = per_batch_bytes(Bp)
     free_b, _total_b = torch.cuda.mem_get_info()
     if "HZ_BENCH_DEVICE" in os.environ:
         free_b //= world   # test hook: the ranks share one device
@@ -713,6 +738,57 @@ def main():
                 "note": "same step, same shape; the pre-populated state (builder.DenseState, hashed on the device) is shared by the batches, "
                         "each of which has its own L1 keys, transactions and signatures"}
     del ctxs, c
+    torch.cuda.empty_cache()
+    # SURVEY 8(d) "occupancy caveat": a single 2048-transaction batch is 32 wavefronts per per-transaction kernel on a 1024-SIMD device.
+    # (i) the latency of ONE batch alone, with and without HZ_FLAG_LATENCY (CU-masked chains); (ii) throughput against batches per launch,
+    # two contexts in flight, up to the headline's own point; (iii) what binds at each point.
+    sweep, single = None, None
+    if world == 1 and not args.no_sweep:
+        def small(bp, nctx, flags, steps):
+            cs = [L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=bp, flags=flags) for _ in range(nctx)]
+            for k, cc in enumerate(cs):
+                for b in range(bp):
+                    cc.upload(b, pin + ((k * bp + b) % n_distinct) * pbytes, pbytes, streams[k % len(streams)].cuda_stream)
+            for k, cc in enumerate(cs):
+                cc.enqueue(streams[k % len(streams)].cuda_stream)
+                cc.check()
+                if not args.no_verify:
+                    assert cc.get("main.hashGlobalInputs", bp - 1) == expected[(k * bp + bp - 1) % n_distinct], "hashGlobalInputs mismatch (sweep, %d x %d)" % (bp, nctx)
+
+            def go(n):
+                pend = [False] * nctx
+                for i in range(n):
+                    k = i % nctx
+                    if pend[k]:
+                        cs[k].check()
+                    cs[k].enqueue(streams[k % len(streams)].cuda_stream)
+                    pend[k] = True
+                for k in range(nctx):
+                    if pend[k]:
+                        cs[k].check()
+            go(nctx)
+            t = D.timed(lambda: go(steps))
+            del cs
+            return t / steps
+        single = {}
+        for key, flags in (("default", 0), ("latency_flag", 2)):
+            single[key] = round(small(1, 1, flags, 6) * 1e3, 3)
+        sweep = []
+        for bp in (1, 2, 4, 8, 16):
+            if bp >= Bp or 2 * per_batch_bytes(bp) * bp > free_b - (6 << 30):
+                continue
+            ms = small(bp, 2, 0, 8) * 1e3
+            sweep.append({"batches_per_launch": bp, "contexts": 2, "ms_per_step": round(ms, 3), "tx_per_s": round(nTx * bp / ms * 1e3, 1)})
+        sweep.append({"batches_per_launch": Bp, "contexts": inflight, "ms_per_step": round(dt / args.steps * 1e3, 3), "tx_per_s": round(nTx * Bp * args.steps / dt, 1)})
+        for i, pt in enumerate(sweep):
+            # doubling the batches of a launch: a step that barely gets longer is waiting on dependent chains (latency); one that
+            # doubles is out of issue slots (the integer pipe: see roofline_valu) -- HBM never binds this pass (whole_pass.frac)
+            if i + 1 < len(sweep) and sweep[i + 1]["batches_per_launch"] == 2 * pt["batches_per_launch"]:
+                g = sweep[i + 1]["ms_per_step"] / pt["ms_per_step"]
+                pt["step_growth_when_doubled"] = round(g, 3)
+                pt["binds"] = "latency" if g < 1.35 else ("latency -> valu" if g < 1.75 else "valu")
+            else:
+                pt["binds"] = "valu"
     L.host_free(pin)
     torch.cuda.empty_cache()
 
@@ -735,6 +811,25 @@ def main():
         dms, dbytes, dunits, dlaunches = acc[dname]
         dlaunches = max(1, int(round(dlaunches)))
         achieved = dbytes / (dms * 1e-3) / 1e9
+        # which roofline binds, from measured fractions: the HBM side is this run's bytes / time; the integer side prices the VALU
+        # wave-instructions the committed SQ_INSTS_VALU pass counted for this command line at the issue cost of the instruction mix
+        props = torch.cuda.get_device_properties(local)
+        n_simd = props.multi_processor_count * 4
+        clock_hz = float(getattr(props, "clock_rate", 0) or 2400000) * 1e3
+        frac_hbm = achieved / HBM_PEAK_GBS
+        k_insts, vmeta = measured_valu(dk)
+        frac_valu = k_insts * VALU_CYCLES_PER_INST / (n_simd * clock_hz * (dms / dlaunches) * 1e-3) if k_insts else None
+        step_insts, _ = measured_valu(None)
+        roofline_valu = None
+        if step_insts:
+            step_s = dt / args.steps
+            roofline_valu = {"insts_per_step": int(step_insts), "cycles_per_inst": VALU_CYCLES_PER_INST, "simds": n_simd, "clock_GHz": round(clock_hz / 1e9, 3),
+                             "frac": round(step_insts * VALU_CYCLES_PER_INST / (n_simd * clock_hz * step_s), 5),
+                             "measured_cycles_per_inst": round(n_simd * clock_hz * step_s / step_insts, 3),
+                             "kernel": dk, "kernel_insts_per_launch": int(k_insts) if k_insts else None, "kernel_frac": round(frac_valu, 5) if frac_valu else None,
+                             "source": "SQ_INSTS_VALU of profiles/r04_valu_counters.json (%s), x %.1f cycles per wave-instruction of this mix (profiles/r03_instbench.txt), "
+                                       "/ (SIMDs x clock x the step time of THIS run)" % (vmeta.get("command", "?") if vmeta else "?", VALU_CYCLES_PER_INST)}
+        bound = "valu" if (frac_valu or 0) > frac_hbm else "hbm"
         out = {
             "metric": "rollup-main tx-witnesses/sec (nTx=%d, nLevels=%d)" % (nTx, lv),
             "value": round(value, 1), "unit": "tx-witnesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -748,11 +843,14 @@ def main():
                                           "hashes": builder_stats["jobs"], "dag_segments": builder_stats["segments"], "device_ms": round(builder_stats["device_ms"], 1),
                                           "walk_and_sign_s": round(builder_stats["walk_s"], 2), "evaluator_s": round(builder_stats["eval_s"], 2)}
                                          if builder_stats else {"kind": "python (circuits_amd/builder.py), host hashing, process pool", "batches": len(all_seeds)})},
-            "roofline": {"bound": "hbm", "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dk, Bp),
+            "roofline": {"bound": bound, "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_hbm": round(frac_hbm, 5), "frac_valu": round(frac_valu, 5) if frac_valu else None,
+                         "traffic": measured_traffic(dk, Bp),
                          "launches_per_step": dlaunches, "launch_ms": round(dms / dlaunches, 3),
                          "algorithmic_bytes_per_launch": int(dbytes // dlaunches), "gpu_ms_per_step_all_launches": round(tot[dk], 3),
-                         "note": "algorithmic bytes = 32 B x the witness signals this launch is responsible for; duration = HIP events on its stream with the "
+                         "note": "achieved / peak / frac price the kernel against the HBM roofline (the contract's figure); `bound` names the roofline with "
+                                 "the larger measured fraction: frac_valu = its VALU wave-instructions x issue cycles / (SIMDs x clock x its duration). "
+                                 "algorithmic bytes = 32 B x the witness signals this launch is responsible for; duration = HIP events on its stream with the "
                                  "kernel alone on the device; traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes. "
                                  "Levels of an SMT proof below the leaf (the hash of an empty subtree) are stored from a constant block and are "
                                  "HBM-store bound; the levels that hash data are integer-VALU issue bound (DESIGN.md 4)"},
@@ -762,8 +860,15 @@ def main():
             "kernels_ms": {k: round(v[0], 3) for k, v in acc.items()},
             "kernels_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in acc.items() if v[0] > 0},
         }
+        if roofline_valu is not None:
+            out["roofline_valu"] = roofline_valu
+        if single is not None:
+            out["single_batch_latency_ms"] = dict(single, note="one 2048-transaction batch alone on the device, enqueue + check, mean of 6; latency_flag = HZ_FLAG_LATENCY "
+                                                              "(the context's concurrent chains on disjoint compute units)")
+            out["batches_sweep"] = sweep
         if deep is not None:
             deep["ratio_to_value"] = round(deep["value"] / value, 4)
+            out["value_deep_state"] = deep["value"]
             out["deep_state"] = deep
         if dt_e2e is not None:
             out["value_e2e"] = round(total_tx / dt_e2e, 1)

@@ -55,7 +55,7 @@ TEMPLATES = {"rollup-main": 0, "rollup-tx": 1, "decode-tx": 2, "fee-tx": 3, "has
 
 # every symbol include/hermez_witness.h declares; tests check the .so exports all of them
 EXPORTS = [
-    "hz_version", "hz_last_error", "hz_device_count", "hz_ctx_create", "hz_ctx_destroy", "hz_witness_len",
+    "hz_version", "hz_last_error", "hz_device_count", "hz_ctx_create", "hz_ctx_destroy", "hz_witness_len", "hz_ctx_device_bytes", "hz_template_device_bytes",
     "hz_constraint_estimate", "hz_set_input", "hz_set_input_dev", "hz_copy_instance_inputs", "hz_inputs_packed_bytes", "hz_input_packed_width",
     "hz_input_packed_offset", "hz_host_alloc", "hz_host_free", "hz_inputs_upload", "hz_inputs_stage", "hz_inputs_stage_range", "hz_clear_inputs", "hz_input_count", "hz_input_name",
     "hz_witness_enqueue", "hz_witness_check", "hz_witness_run", "hz_witness_failures", "hz_witness_read", "hz_witness_dev_ptr",
@@ -91,7 +91,7 @@ class Lib:
         c.hz_ctx_create.argtypes = [ctypes.POINTER(hz_params), ctypes.POINTER(vp)]
         c.hz_ctx_destroy.argtypes = [vp]
         c.hz_ctx_destroy.restype = None
-        for f in ("hz_witness_len", "hz_constraint_estimate", "hz_witness_total", "hz_symbol_count"):
+        for f in ("hz_witness_len", "hz_ctx_device_bytes", "hz_template_device_bytes", "hz_constraint_estimate", "hz_witness_total", "hz_symbol_count"):
             getattr(c, f).argtypes = [vp]
             getattr(c, f).restype = u64
         c.hz_set_input.argtypes = [vp, ctypes.c_int32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
@@ -185,6 +185,13 @@ class Lib:
     def poseidon_batch_dev(self, t, n, d_in, d_out, d_wit=None, stream=None):
         self._check(self.c.hz_poseidon_batch_dev(t, n, d_in, d_out, d_wit, stream))
 
+    def template_device_bytes(self, template, nTx=0, nLevels=0, maxL1Tx=0, maxFeeTx=0, n_instances=1):
+        """device memory a context of this shape will hold (hz_template_device_bytes): no device needed"""
+        p = hz_params(TEMPLATES[template], nTx, nLevels, maxL1Tx, maxFeeTx, 0, n_instances, 0)
+        self.c.hz_template_device_bytes.restype = ctypes.c_uint64
+        self.c.hz_template_device_bytes.argtypes = [ctypes.POINTER(hz_params)]
+        return self.c.hz_template_device_bytes(ctypes.byref(p))
+
     def fr_ops(self, op, a, b=None, device=0):
         """out[i] = a[i] (op) b[i]; op: 0 add, 1 sub, 2 mul, 3 sqr, 4 inv, 5 a*b+a+b, 6 2a*(-b)."""
         n = len(a)
@@ -275,6 +282,10 @@ class Ctx:
 
     def total(self):
         return self.L.c.hz_witness_total(self.h)
+
+    def device_bytes(self):
+        """device memory of this context, buffers allocated on first use included (hz_ctx_device_bytes)"""
+        return self.L.c.hz_ctx_device_bytes(self.h)
 
     def constraint_estimate(self):
         return self.L.c.hz_constraint_estimate(self.h)

@@ -257,6 +257,28 @@ extern "C" void hz_ctx_destroy(hz_ctx* c) {
     delete c;
 }
 extern "C" uint64_t hz_witness_len(const hz_ctx* c) { return c ? c->lo.per_instance : 0; }
+// Device memory a context of this layout holds once every buffer that is allocated on first use exists (capacity planning: how many
+// batches fit the 288 GB of a device). The same arithmetic as hz_ctx_create and the lazy allocations below.
+static uint64_t layout_device_bytes(const Layout& lo) {
+    uint64_t n = lo.total * 32 + sizeof(ErrBuf) + (uint64_t)lo.n_inst * (sizeof(unsigned long long) + sizeof(ErrRec));
+    if (lo.sec_tx >= 0) n += (uint64_t)SC_COUNT * lo.sections[lo.sec_tx].n_units * sizeof(Fr);
+    if (lo.p.tmpl == T_ROLLUP_MAIN || lo.p.tmpl == T_ROLLUP_TX) n += eddsa_side_bytes(lo.sections[lo.sec_tx].n_units);
+    if (lo.sec_fee >= 0) n += (uint64_t)SC_COUNT * lo.sections[lo.sec_fee].n_units * sizeof(Fr);
+    if (lo.sec_hi >= 0) n += ((uint64_t)lo.hi.sha.nblocks * 64 + ((uint64_t)lo.hi.sha.nblocks + 1) * 32) * lo.n_inst;
+    uint64_t packed = 0;   // the staging slots of the bulk-upload path (hz_inputs_upload / hz_inputs_stage), one per instance
+    for (const InputDesc& d : lo.inputs) packed = ((packed + 31) & ~31ull) + (uint64_t)d.inner * d.outer * d.ebytes;
+    return n + ((packed + 31) & ~31ull) * lo.n_inst;
+}
+extern "C" uint64_t hz_ctx_device_bytes(const hz_ctx* c) { return c ? layout_device_bytes(c->lo) : 0; }
+extern "C" uint64_t hz_template_device_bytes(const hz_params* p) {
+    if (!p || p->template_id < 0 || p->template_id >= T_COUNT) return 0;
+    Params lp;
+    lp.tmpl = p->template_id; lp.nTx = p->nTx; lp.L = p->nLevels; lp.maxL1 = p->maxL1Tx; lp.F = p->maxFeeTx;
+    lp.n_inst = p->n_instances > 0 ? p->n_instances : 1;
+    Layout lo;
+    build_layout(lp, lo);
+    return layout_device_bytes(lo);
+}
 extern "C" uint64_t hz_constraint_estimate(const hz_ctx* c) { return c ? constraint_estimate(c->lo.p) : 0; }
 extern "C" const void* hz_witness_dev_ptr(const hz_ctx* c) { return c ? c->wit.p : nullptr; }
 extern "C" int32_t hz_input_count(const hz_ctx* c) { return c ? (int32_t)c->lo.inputs.size() : 0; }

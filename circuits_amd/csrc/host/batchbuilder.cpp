@@ -392,6 +392,10 @@ struct hzb_db {
     uint32_t chain_id = 1;
     uint64_t last_idx = 255;
     uint32_t num_batch = 0;
+    // A batch walks and updates this state in place (tree versions, leaves, last_idx, pending hash jobs). When the walk stops half way --
+    // a transaction the circuit would reject, memory -- what is left is neither the old state nor the new one: the database refuses
+    // further work instead of building on it (callers that may meet rejections build on hzb_db_clone copies, as the reference's suites do).
+    bool poisoned = false;
     Dag dag;
     Base base;
     Tree* state = nullptr;
@@ -948,8 +952,10 @@ extern "C" {
 const char* hzb_last_error(void) { return g_err.c_str(); }
 
 // the working copy the reference's suites build a batch on before they consolidate it (rollupDb.buildBatch on a copy of the state)
+static const char* const POISONED = "the database was left half-updated by a batch that failed to build: discard it (build on hzb_db_clone copies)";
 hzb_db* hzb_db_clone(const hzb_db* src) {
     if (!src) { fail(HZB_ERR_ARG, "hzb_db_clone: null database"); return nullptr; }
+    if (src->poisoned) { fail(HZB_ERR_REJECTED, POISONED); return nullptr; }
     hzb_db* db = new hzb_db();
     db->chain_id = src->chain_id; db->last_idx = src->last_idx; db->num_batch = src->num_batch;
     db->dag = src->dag;
@@ -995,14 +1001,20 @@ int hzb_db_set_base(hzb_db* db, int32_t k, uint64_t first_idx, const uint8_t* co
 }
 int hzb_db_add_account(hzb_db* db, const hzb_leaf* leaf, uint64_t* idx) {
     if (!db || !leaf) return fail(HZB_ERR_ARG, "hzb_db_add_account: null argument");
+    if (db->poisoned) return fail(HZB_ERR_REJECTED, POISONED);
     try {
-        const Leaf l = leaf_from_c(*leaf);
-        db->last_idx += 1;
-        db->state->insert(db->last_idx, hash_state(db->dag, l));
-        db->leaves[db->last_idx] = l;
-        if (idx) *idx = db->last_idx;
+        const Leaf l = leaf_from_c(*leaf);   // rejects before anything is touched
+        const uint64_t at = db->last_idx + 1;
+        db->leaves[at] = l;
+        db->state->insert(at, hash_state(db->dag, l));
+        db->last_idx = at;                   // only once the tree holds the leaf
+        if (idx) *idx = at;
     } catch (const Reject& r) {
+        db->leaves.erase(db->last_idx + 1);
         return fail(HZB_ERR_REJECTED, r.msg);
+    } catch (const std::bad_alloc&) {
+        db->poisoned = true;                 // the tree may hold half a path
+        return fail(HZB_ERR_ARG, "hzb_db_add_account: out of memory");
     }
     return HZB_OK;
 }
@@ -1014,6 +1026,7 @@ int hzb_db_get_account(hzb_db* db, uint64_t idx, hzb_leaf* out) {
 }
 int hzb_db_state_root(hzb_db* db, uint8_t* out) {
     if (!db || !out) return fail(HZB_ERR_ARG, "hzb_db_state_root: null argument");
+    if (db->poisoned) return fail(HZB_ERR_REJECTED, POISONED);
     const int st = db->flush(nullptr, nullptr);
     if (st) return st;
     u_to_bytes(db->state->root_hash().v, out);
@@ -1024,6 +1037,7 @@ uint32_t hzb_db_num_batch(const hzb_db* db) { return db ? db->num_batch : 0; }
 
 hzb_batch* hzb_batch_create(hzb_db* db, int32_t n_tx, int32_t n_levels, int32_t max_l1, int32_t max_fee) {
     if (!db || n_tx < 1 || n_levels < 1 || n_levels > 48 || max_l1 < 0 || max_fee < 1) { fail(HZB_ERR_ARG, "hzb_batch_create: bad parameters"); return nullptr; }
+    if (db->poisoned) { fail(HZB_ERR_REJECTED, POISONED); return nullptr; }
     hzb_batch* b = new hzb_batch();
     b->db = db; b->nTx = n_tx; b->L = n_levels; b->maxL1 = max_l1; b->F = max_fee;
     b->current_num_batch = db->num_batch + 1;
@@ -1055,6 +1069,7 @@ int hzb_batch_build(hzb_batch* b, int32_t n_signals, const char* const* names, c
                     uint8_t* hash_global_inputs) {
     if (!b || !names || !offsets || !widths || !packed || n_signals < 0) return fail(HZB_ERR_ARG, "hzb_batch_build: null argument");
     if (b->built) return fail(HZB_ERR_ARG, "hzb_batch_build: the batch has been built");
+    if (b->db->poisoned) return fail(HZB_ERR_REJECTED, POISONED);
     Out o;
     o.packed = packed;
     o.packed_bytes = packed_bytes;
@@ -1068,10 +1083,14 @@ int hzb_batch_build(hzb_batch* b, int32_t n_signals, const char* const* names, c
         o.width[s] = widths[i];
     }
     try {
-        return build(b, o, hash_global_inputs);
+        const int st = build(b, o, hash_global_inputs);
+        if (st != HZB_OK) b->db->poisoned = true;   // the evaluator failed after the walk had updated the state
+        return st;
     } catch (const Reject& r) {
+        b->db->poisoned = true;
         return fail(HZB_ERR_REJECTED, r.msg);
     } catch (const std::bad_alloc&) {
+        b->db->poisoned = true;
         return fail(HZB_ERR_ARG, "hzb_batch_build: out of memory");
     }
 }

@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <utility>
+#include <vector>
 #include "../../include/hermez_witness.h"
 
 #define NAPI_OK(call)                                             \
@@ -49,6 +51,7 @@ struct Api {
     decltype(&hz_inputs_stage_range) inputs_stage_range;
     decltype(&hz_witness_enqueue) witness_enqueue;
     decltype(&hz_witness_check) witness_check;
+    decltype(&hz_witness_failures) witness_failures;
     decltype(&hz_witness_total) witness_total;
     decltype(&hz_witness_read_raw) witness_read_raw;
     decltype(&hz_witness_dev_ptr) witness_dev_ptr;
@@ -80,7 +83,7 @@ static bool load_api(std::string& err) {
     SYM(clear_inputs) SYM(input_count) SYM(input_name) SYM(witness_run) SYM(witness_read) SYM(symbol_count) SYM(symbol_get) SYM(symbol_lookup)
     SYM(constraint_name)
     SYM(inputs_packed_bytes) SYM(input_packed_width) SYM(input_packed_offset) SYM(host_alloc) SYM(host_free) SYM(inputs_upload) SYM(inputs_stage)
-    SYM(inputs_stage_range) SYM(witness_enqueue) SYM(witness_check) SYM(witness_total) SYM(witness_read_raw) SYM(witness_dev_ptr)
+    SYM(inputs_stage_range) SYM(witness_enqueue) SYM(witness_check) SYM(witness_failures) SYM(witness_total) SYM(witness_read_raw) SYM(witness_dev_ptr)
     SYM(set_inputs_json) SYM(witness_write_json) SYM(witness_write_wtns) SYM(symbols_write_sym) SYM(symmap_create) SYM(symmap_destroy)
     SYM(symmap_nvars) SYM(symmap_unresolved) SYM(witness_write_wtns_sym) SYM(poseidon_batch)
 #undef SYM
@@ -92,12 +95,44 @@ static napi_value throw_hz(napi_env env, const char* what) {
     napi_throw_error(env, nullptr, m.c_str());
     return nullptr;
 }
-static hz_ctx* get_ctx(napi_env env, napi_value v) {
+// What a circuit handle points to: the context, and the host buffers whose asynchronous upload may still be in flight. A staged copy
+// (stageRange / step / upload) is issued on a stream and consumed by the NEXT enqueue; its source ArrayBuffer must outlive the DMA,
+// whatever the JS side does with it. Enqueues are numbered; a buffer staged after enqueue e is referenced until the check of
+// enqueue e + 1 has completed (that enqueue waited for the copy on the device).
+struct NodeCtx {
+    hz_ctx* c = nullptr;
+    uint64_t enq = 0;                                    // enqueues issued so far
+    std::vector<std::pair<napi_ref, uint64_t>> held;     // (reference, enqueue count when it was staged); JS thread only
+};
+static NodeCtx* get_node(napi_env env, napi_value v) {
     void* p = nullptr;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_error(env, nullptr, "bad circuit handle"); return nullptr; }
-    return (hz_ctx*)p;
+    return (NodeCtx*)p;
 }
-static void finalize_ctx(napi_env, void* data, void*) { if (data && api.ctx_destroy) api.ctx_destroy((hz_ctx*)data); }
+static hz_ctx* get_ctx(napi_env env, napi_value v) {
+    NodeCtx* n = get_node(env, v);
+    return n ? n->c : nullptr;
+}
+// JS thread: drop the references of every copy that an enqueue numbered <= `checked` has consumed
+static void release_held(napi_env env, NodeCtx* n, uint64_t checked) {
+    size_t k = 0;
+    for (size_t i = 0; i < n->held.size(); i++) {
+        if (n->held[i].second < checked) napi_delete_reference(env, n->held[i].first);
+        else n->held[k++] = n->held[i];
+    }
+    n->held.resize(k);
+}
+static void hold(napi_env env, NodeCtx* n, napi_value buf) {
+    napi_ref r = nullptr;
+    if (napi_create_reference(env, buf, 1, &r) == napi_ok && r) n->held.push_back({r, n->enq});
+}
+static void finalize_ctx(napi_env env, void* data, void*) {
+    NodeCtx* n = (NodeCtx*)data;
+    if (!n) return;
+    if (n->c && api.ctx_destroy) api.ctx_destroy(n->c);   // synchronises the device: nothing reads the held buffers after this
+    for (auto& h : n->held) napi_delete_reference(env, h.first);
+    delete n;
+}
 
 // create(templateId, nTx, nLevels, maxL1Tx, maxFeeTx, nInstances = 1, flags = 0, device = 0) -> handle
 static napi_value Create(napi_env env, napi_callback_info info) {
@@ -113,8 +148,10 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     p.template_id = a[0]; p.nTx = a[1]; p.nLevels = a[2]; p.maxL1Tx = a[3]; p.maxFeeTx = a[4]; p.n_instances = a[5]; p.flags = a[6]; p.device = a[7];
     hz_ctx* c = nullptr;
     if (api.ctx_create(&p, &c) != HZ_OK) return throw_hz(env, "hz_ctx_create");
+    NodeCtx* n = new NodeCtx();
+    n->c = c;
     napi_value ext;
-    NAPI_OK(napi_create_external(env, c, finalize_ctx, nullptr, &ext));
+    if (napi_create_external(env, n, finalize_ctx, nullptr, &ext) != napi_ok) { api.ctx_destroy(c); delete n; napi_throw_error(env, nullptr, "napi_create_external"); return nullptr; }
     return ext;
 }
 
@@ -150,10 +187,24 @@ struct RunWork {
     napi_async_work work;
     napi_deferred deferred;
     hz_ctx* ctx;
+    NodeCtx* node = nullptr;      // check(): whose staged buffers the completed step releases
+    uint64_t checked = 0;
     hz_status st;
     hz_error err;
     std::string msg;
 };
+static napi_value failure_record(napi_env env, const hz_error& err) {
+    napi_value result, v;
+    napi_create_object(env, &result);
+    napi_create_int32(env, err.instance, &v); napi_set_named_property(env, result, "instance", v);
+    napi_create_int32(env, err.unit, &v); napi_set_named_property(env, result, "unit", v);
+    napi_create_int32(env, err.constraint_id, &v); napi_set_named_property(env, result, "constraintId", v);
+    napi_create_string_utf8(env, api.constraint_name(err.constraint_id), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, result, "constraintName", v);
+    void* p;
+    napi_create_buffer_copy(env, 32, err.lhs, &p, &v); napi_set_named_property(env, result, "lhs", v);
+    napi_create_buffer_copy(env, 32, err.rhs, &p, &v); napi_set_named_property(env, result, "rhs", v);
+    return result;
+}
 static void run_execute(napi_env, void* data) {
     RunWork* w = (RunWork*)data;
     memset(&w->err, 0, sizeof w->err);
@@ -163,20 +214,12 @@ static void run_execute(napi_env, void* data) {
 static void run_complete(napi_env env, napi_status, void* data) {
     RunWork* w = (RunWork*)data;
     napi_value result;
+    if (w->node && (w->st == HZ_OK || w->st == HZ_ERR_CONSTRAINT)) release_held(env, w->node, w->checked);
     if (w->st == HZ_OK) {
         napi_get_null(env, &result);
         napi_resolve_deferred(env, w->deferred, result);
     } else if (w->st == HZ_ERR_CONSTRAINT) {
-        napi_create_object(env, &result);
-        napi_value v;
-        napi_create_int32(env, w->err.instance, &v); napi_set_named_property(env, result, "instance", v);
-        napi_create_int32(env, w->err.unit, &v); napi_set_named_property(env, result, "unit", v);
-        napi_create_int32(env, w->err.constraint_id, &v); napi_set_named_property(env, result, "constraintId", v);
-        napi_create_string_utf8(env, api.constraint_name(w->err.constraint_id), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, result, "constraintName", v);
-        void* p;
-        napi_create_buffer_copy(env, 32, w->err.lhs, &p, &v); napi_set_named_property(env, result, "lhs", v);
-        napi_create_buffer_copy(env, 32, w->err.rhs, &p, &v); napi_set_named_property(env, result, "rhs", v);
-        napi_resolve_deferred(env, w->deferred, result);
+        napi_resolve_deferred(env, w->deferred, failure_record(env, w->err));
     } else {
         napi_value msg, e;
         napi_create_string_utf8(env, w->msg.c_str(), NAPI_AUTO_LENGTH, &msg);
@@ -335,6 +378,27 @@ static double num(napi_env env, napi_value v, double dflt = 0) {
     if (napi_typeof(env, v, &t) == napi_ok && t == napi_number) napi_get_value_double(env, v, &d);
     return d;
 }
+// a byte offset / stride / count from JavaScript: a finite, non-negative integer (a cast of NaN or of a negative double is undefined)
+static bool get_size(napi_env env, napi_value v, const char* what, size_t* out, bool has_default = false, size_t dflt = 0) {
+    napi_valuetype t = napi_undefined;
+    napi_typeof(env, v, &t);
+    if (t == napi_undefined && has_default) { *out = dflt; return true; }
+    double d = 0;
+    if (t != napi_number || napi_get_value_double(env, v, &d) != napi_ok || !(d >= 0) || d > 9007199254740992.0 || d != (double)(uint64_t)d) {
+        std::string m = std::string(what) + ": expected a non-negative integer";
+        napi_throw_range_error(env, nullptr, m.c_str());
+        return false;
+    }
+    *out = (size_t)d;
+    return true;
+}
+// off + (count - 1) * stride + each <= len, without wrapping
+static bool range_fits(size_t off, size_t count, size_t stride, size_t each, size_t len) {
+    if (count == 0) return off <= len;
+    size_t span = 0, end = 0;
+    if (__builtin_mul_overflow(count - 1, stride, &span) || __builtin_add_overflow(span, each, &span) || __builtin_add_overflow(off, span, &end)) return false;
+    return end <= len;
+}
 // bytes of an ArrayBuffer / Buffer / TypedArray argument
 static bool get_bytes(napi_env env, napi_value v, uint8_t** data, size_t* len) {
     bool is = false;
@@ -394,34 +458,38 @@ static napi_value HostAlloc(napi_env env, napi_callback_info info) {
 static napi_value Upload(napi_env env, napi_callback_info info) {
     napi_value argv[4];
     if (!get_args(env, info, 4, argv)) return nullptr;
-    hz_ctx* c = get_ctx(env, argv[0]);
-    uint8_t* data; size_t len;
-    if (!c || !get_bytes(env, argv[2], &data, &len)) return nullptr;
-    const size_t off = (size_t)num(env, argv[3]), each = (size_t)api.inputs_packed_bytes(c);
-    if (off + each > len) { napi_throw_error(env, nullptr, "upload: buffer too small"); return nullptr; }
-    if (api.inputs_upload(c, (int32_t)num(env, argv[1]), data + off, each, nullptr) != HZ_OK) return throw_hz(env, "hz_inputs_upload");
+    NodeCtx* n = get_node(env, argv[0]);
+    uint8_t* data; size_t len, off, inst;
+    if (!n || !get_bytes(env, argv[2], &data, &len) || !get_size(env, argv[1], "upload: instance", &inst) || !get_size(env, argv[3], "upload: byteOffset", &off, true, 0)) return nullptr;
+    const size_t each = (size_t)api.inputs_packed_bytes(n->c);
+    if (inst > 0x7fffffff || !range_fits(off, 1, each, each, len)) { napi_throw_range_error(env, nullptr, "upload: buffer too small"); return nullptr; }
+    if (api.inputs_upload(n->c, (int32_t)inst, data + off, each, nullptr) != HZ_OK) return throw_hz(env, "hz_inputs_upload");
+    hold(env, n, argv[2]);
     return nullptr;
 }
 // stageRange(handle, first, count, bytes, byteOffset = 0, stride = packed bytes): the next step's inputs, asynchronous H2D
 static napi_value StageRange(napi_env env, napi_callback_info info) {
     napi_value argv[6];
     if (!get_args(env, info, 6, argv)) return nullptr;
-    hz_ctx* c = get_ctx(env, argv[0]);
-    uint8_t* data; size_t len;
-    if (!c || !get_bytes(env, argv[3], &data, &len)) return nullptr;
-    const int32_t first = (int32_t)num(env, argv[1]), count = (int32_t)num(env, argv[2]);
-    const size_t each = (size_t)api.inputs_packed_bytes(c), off = (size_t)num(env, argv[4]), stride = (size_t)num(env, argv[5], (double)each);
-    if (count < 0 || off + (count ? (size_t)(count - 1) * stride + each : 0) > len) { napi_throw_error(env, nullptr, "stageRange: buffer too small"); return nullptr; }
-    if (api.inputs_stage_range(c, first, count, data + off, each, stride, nullptr) != HZ_OK) return throw_hz(env, "hz_inputs_stage_range");
+    NodeCtx* n = get_node(env, argv[0]);
+    uint8_t* data; size_t len, first, count, off, stride;
+    if (!n || !get_bytes(env, argv[3], &data, &len)) return nullptr;
+    const size_t each = (size_t)api.inputs_packed_bytes(n->c);
+    if (!get_size(env, argv[1], "stageRange: first", &first) || !get_size(env, argv[2], "stageRange: count", &count) ||
+        !get_size(env, argv[4], "stageRange: byteOffset", &off, true, 0) || !get_size(env, argv[5], "stageRange: stride", &stride, true, each)) return nullptr;
+    if (first > 0x7fffffff || count > 0x7fffffff || !range_fits(off, count, stride, each, len)) { napi_throw_range_error(env, nullptr, "stageRange: buffer too small"); return nullptr; }
+    if (api.inputs_stage_range(n->c, (int32_t)first, (int32_t)count, data + off, each, stride, nullptr) != HZ_OK) return throw_hz(env, "hz_inputs_stage_range");
+    if (count) hold(env, n, argv[3]);
     return nullptr;
 }
 // enqueue(handle): the kernels of one step on the context's stream; returns at once
 static napi_value Enqueue(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return nullptr;
-    hz_ctx* c = get_ctx(env, argv[0]);
-    if (!c) return nullptr;
-    if (api.witness_enqueue(c, nullptr) != HZ_OK) return throw_hz(env, "hz_witness_enqueue");
+    NodeCtx* n = get_node(env, argv[0]);
+    if (!n) return nullptr;
+    if (api.witness_enqueue(n->c, nullptr) != HZ_OK) return throw_hz(env, "hz_witness_enqueue");
+    n->enq++;
     return nullptr;
 }
 // check(handle) -> Promise<null | failure record> (same shape as run): waits for the step on the libuv pool
@@ -434,10 +502,10 @@ static void check_execute(napi_env, void* data) {
 static napi_value Check(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return nullptr;
-    hz_ctx* c = get_ctx(env, argv[0]);
-    if (!c) return nullptr;
+    NodeCtx* n = get_node(env, argv[0]);
+    if (!n) return nullptr;
     RunWork* w = new RunWork();
-    w->ctx = c;
+    w->ctx = n->c; w->node = n; w->checked = n->enq;
     napi_value promise, name;
     NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
     NAPI_OK(napi_create_string_utf8(env, "hz_witness_check", NAPI_AUTO_LENGTH, &name));
@@ -450,24 +518,67 @@ static napi_value Check(napi_env env, napi_callback_info info) {
 static napi_value CheckSync(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return nullptr;
-    hz_ctx* c = get_ctx(env, argv[0]);
-    if (!c) return nullptr;
+    NodeCtx* n = get_node(env, argv[0]);
+    if (!n) return nullptr;
     hz_error err;
     memset(&err, 0, sizeof err);
-    const hz_status st = api.witness_check(c, &err);
+    const hz_status st = api.witness_check(n->c, &err);
     napi_value result;
+    if (st == HZ_OK || st == HZ_ERR_CONSTRAINT) release_held(env, n, n->enq);
     if (st == HZ_OK) { napi_get_null(env, &result); return result; }
     if (st != HZ_ERR_CONSTRAINT) return throw_hz(env, "hz_witness_check");
-    napi_create_object(env, &result);
-    napi_value v;
-    napi_create_int32(env, err.instance, &v); napi_set_named_property(env, result, "instance", v);
-    napi_create_int32(env, err.unit, &v); napi_set_named_property(env, result, "unit", v);
-    napi_create_int32(env, err.constraint_id, &v); napi_set_named_property(env, result, "constraintId", v);
-    napi_create_string_utf8(env, api.constraint_name(err.constraint_id), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, result, "constraintName", v);
-    void* p;
-    napi_create_buffer_copy(env, 32, err.lhs, &p, &v); napi_set_named_property(env, result, "lhs", v);
-    napi_create_buffer_copy(env, 32, err.rhs, &p, &v); napi_set_named_property(env, result, "rhs", v);
-    return result;
+    return failure_record(env, err);
+}
+// failures(handle) -> Promise<[failure record]>: the first violated constraint of EVERY instance of the step that check() reported
+// on (hz_witness_failures: a launch evaluates nInstances circuits, the reference one per call), ordered by instance
+struct FailWork {
+    napi_async_work work;
+    napi_deferred deferred;
+    hz_ctx* ctx;
+    hz_status st;
+    std::vector<hz_error> recs;
+    std::string msg;
+};
+static void fail_execute(napi_env, void* data) {
+    FailWork* w = (FailWork*)data;
+    size_t n = 0;
+    w->st = api.witness_failures(w->ctx, nullptr, 0, &n);
+    if (w->st == HZ_OK && n) {
+        w->recs.resize(n);
+        w->st = api.witness_failures(w->ctx, w->recs.data(), n, &n);
+        if (w->st == HZ_OK) w->recs.resize(n);
+    }
+    if (w->st != HZ_OK) w->msg = api.last_error();
+}
+static void fail_complete(napi_env env, napi_status, void* data) {
+    FailWork* w = (FailWork*)data;
+    if (w->st == HZ_OK) {
+        napi_value arr;
+        napi_create_array_with_length(env, w->recs.size(), &arr);
+        for (size_t i = 0; i < w->recs.size(); i++) napi_set_element(env, arr, (uint32_t)i, failure_record(env, w->recs[i]));
+        napi_resolve_deferred(env, w->deferred, arr);
+    } else {
+        napi_value msg, e;
+        napi_create_string_utf8(env, w->msg.c_str(), NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &e);
+        napi_reject_deferred(env, w->deferred, e);
+    }
+    napi_delete_async_work(env, w->work);
+    delete w;
+}
+static napi_value Failures(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    FailWork* w = new FailWork();
+    w->ctx = c;
+    napi_value promise, name;
+    NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
+    NAPI_OK(napi_create_string_utf8(env, "hz_witness_failures", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(napi_create_async_work(env, nullptr, name, fail_execute, fail_complete, w, &w->work));
+    NAPI_OK(napi_queue_async_work(env, w->work));
+    return promise;
 }
 // devPtr(handle) -> BigInt device address of the physical witness buffer (for a prover in the same process); witnessTotal -> elements
 static napi_value DevPtr(napi_env env, napi_callback_info info) {
@@ -601,8 +712,10 @@ static napi_value PoseidonBatch(napi_env env, napi_callback_info info) {
 struct StepWork {
     napi_async_work work;
     napi_deferred deferred;
-    napi_ref keep;          // the staged ArrayBuffer stays alive until the copy has been issued
+    napi_ref keep;          // the staged ArrayBuffer: handed to the context's list when the work item completes
     hz_ctx* ctx;
+    NodeCtx* node;
+    uint64_t checked, staged_at;
     uint8_t* data;
     size_t each, stride;
     int32_t first, count;
@@ -615,60 +728,56 @@ static void step_execute(napi_env, void* data) {
     StepWork* w = (StepWork*)data;
     memset(&w->err, 0, sizeof w->err);
     w->st = HZ_OK;
+    w->checked = 0;
     if (w->had_prev) {
         w->st = api.witness_check(w->ctx, &w->err);
         if (w->st != HZ_OK && w->st != HZ_ERR_CONSTRAINT) { w->msg = api.last_error(); return; }
+        w->checked = w->node->enq;   // one work item per circuit at a time (index.js): nobody else moves the counter
     }
     hz_status e = api.witness_enqueue(w->ctx, nullptr);
+    if (e == HZ_OK) w->node->enq++;
+    w->staged_at = w->node->enq;
     if (e == HZ_OK && w->data && w->count > 0) e = api.inputs_stage_range(w->ctx, w->first, w->count, w->data, w->each, w->stride, nullptr);
     if (e != HZ_OK) { w->st = e; w->msg = api.last_error(); }
 }
 static void step_complete(napi_env env, napi_status, void* data) {
     StepWork* w = (StepWork*)data;
     napi_value result;
+    release_held(env, w->node, w->checked);
+    if (w->keep) w->node->held.push_back({w->keep, w->staged_at});   // released when the step that consumes the copy has been checked
     if (w->st == HZ_OK) {
         napi_get_null(env, &result);
         napi_resolve_deferred(env, w->deferred, result);
     } else if (w->st == HZ_ERR_CONSTRAINT) {
-        napi_create_object(env, &result);
-        napi_value v;
-        napi_create_int32(env, w->err.instance, &v); napi_set_named_property(env, result, "instance", v);
-        napi_create_int32(env, w->err.unit, &v); napi_set_named_property(env, result, "unit", v);
-        napi_create_int32(env, w->err.constraint_id, &v); napi_set_named_property(env, result, "constraintId", v);
-        napi_create_string_utf8(env, api.constraint_name(w->err.constraint_id), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, result, "constraintName", v);
-        void* p;
-        napi_create_buffer_copy(env, 32, w->err.lhs, &p, &v); napi_set_named_property(env, result, "lhs", v);
-        napi_create_buffer_copy(env, 32, w->err.rhs, &p, &v); napi_set_named_property(env, result, "rhs", v);
-        napi_resolve_deferred(env, w->deferred, result);
+        napi_resolve_deferred(env, w->deferred, failure_record(env, w->err));
     } else {
         napi_value msg, e;
         napi_create_string_utf8(env, w->msg.c_str(), NAPI_AUTO_LENGTH, &msg);
         napi_create_error(env, nullptr, msg, &e);
         napi_reject_deferred(env, w->deferred, e);
     }
-    if (w->keep) napi_delete_reference(env, w->keep);
     napi_delete_async_work(env, w->work);
     delete w;
 }
 static napi_value Step(napi_env env, napi_callback_info info) {
     napi_value argv[7];
     if (!get_args(env, info, 7, argv)) return nullptr;
-    hz_ctx* c = get_ctx(env, argv[0]);
-    if (!c) return nullptr;
+    NodeCtx* n = get_node(env, argv[0]);
+    if (!n) return nullptr;
     StepWork* w = new StepWork();
-    w->ctx = c; w->keep = nullptr; w->data = nullptr; w->count = 0; w->first = 0;
-    w->each = (size_t)api.inputs_packed_bytes(c);
+    w->ctx = n->c; w->node = n; w->keep = nullptr; w->data = nullptr; w->count = 0; w->first = 0; w->checked = 0; w->staged_at = 0;
+    w->each = (size_t)api.inputs_packed_bytes(n->c);
+    w->stride = w->each;
     napi_valuetype t = napi_undefined;
     napi_typeof(env, argv[1], &t);
     if (t == napi_object) {
-        uint8_t* data; size_t len;
-        if (!get_bytes(env, argv[1], &data, &len)) { delete w; return nullptr; }
-        const size_t off = (size_t)num(env, argv[2]);
-        w->first = (int32_t)num(env, argv[3]); w->count = (int32_t)num(env, argv[4]);
-        w->stride = (size_t)num(env, argv[5], (double)w->each);
-        if (w->count < 0 || off + (w->count ? (size_t)(w->count - 1) * w->stride + w->each : 0) > len) { delete w; napi_throw_error(env, nullptr, "step: buffer too small"); return nullptr; }
+        uint8_t* data; size_t len, off, first, count;
+        if (!get_bytes(env, argv[1], &data, &len) || !get_size(env, argv[2], "step: byteOffset", &off, true, 0) || !get_size(env, argv[3], "step: first", &first, true, 0) ||
+            !get_size(env, argv[4], "step: count", &count, true, 0) || !get_size(env, argv[5], "step: stride", &w->stride, true, w->each)) { delete w; return nullptr; }
+        if (first > 0x7fffffff || count > 0x7fffffff || !range_fits(off, count, w->stride, w->each, len)) { delete w; napi_throw_range_error(env, nullptr, "step: buffer too small"); return nullptr; }
+        w->first = (int32_t)first; w->count = (int32_t)count;
         w->data = data + off;
-        napi_create_reference(env, argv[1], 1, &w->keep);
+        if (count) napi_create_reference(env, argv[1], 1, &w->keep);
     }
     bool prev = false;
     napi_get_value_bool(env, argv[6], &prev);
@@ -688,7 +797,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"symbolCount", SymbolCount}, {"symbolGet", SymbolGet}, {"deviceCount", DeviceCount}, {"version", Version},
         {"packedLayout", PackedLayout}, {"hostAlloc", HostAlloc}, {"upload", Upload}, {"stageRange", StageRange}, {"enqueue", Enqueue},
         {"check", Check}, {"devPtr", DevPtr}, {"witnessTotal", WitnessTotal}, {"readRaw", ReadRaw}, {"setInputsJson", SetInputsJson},
-        {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}, {"step", Step}, {"checkSync", CheckSync}};
+        {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}, {"step", Step}, {"checkSync", CheckSync}, {"failures", Failures}};
     for (const auto& f : fns) {
         napi_value fn;
         napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn);

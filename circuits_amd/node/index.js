@@ -191,15 +191,25 @@ class Circuit {
             const flat = flatten(input[d.name], []);
             if (flat.length !== d.length) throw new Error(`Signal ${d.name}: expected ${d.length} values, got ${flat.length}`);
             if (d.width === 1) {
-                for (let i = 0; i < flat.length; i++) u8[base + d.offset + i] = Number(toFr(flat[i]) & 1n);
+                // bit-valued signals travel as one byte each. A value that is not a bit must reach the device as it is -- the circuit's
+                // own boolean constraint rejects it there (src/rollup-main.circom:214-216), exactly as the reference calculator would --
+                // so nothing is masked; what a byte cannot carry is refused here instead of being coerced into a passing witness.
+                for (let i = 0; i < flat.length; i++) {
+                    const v = toFr(flat[i]);
+                    if (v > 255n) throw new RangeError(`Signal ${d.name}[${i}] = ${v}: the packed form carries 0..255 per element; use calculateWitness() for this input`);
+                    u8[base + d.offset + i] = Number(v);
+                }
             } else {
                 const b = packFr(flat);
                 u8.set(b, base + d.offset);
             }
         }
     }
-    upload(instance, buf, byteOffset) { addon.upload(this.handle, instance, buf, byteOffset || 0); }
-    stageRange(first, count, buf, byteOffset, stride) { addon.stageRange(this.handle, first, count, buf, byteOffset || 0, stride || this.packedLayout().bytes); }
+    // offsets / strides are validated by the addon (finite non-negative integers): `undefined` takes the default, nothing else is coerced
+    upload(instance, buf, byteOffset) { addon.upload(this.handle, instance, buf, byteOffset === undefined ? 0 : byteOffset); }
+    stageRange(first, count, buf, byteOffset, stride) {
+        addon.stageRange(this.handle, first, count, buf, byteOffset === undefined ? 0 : byteOffset, stride === undefined || stride === 0 ? this.packedLayout().bytes : stride);
+    }
     /** the kernels of one step, asynchronous; check() resolves when they are done and rejects on the first violated constraint */
     enqueue() { this._inFlight = true; addon.enqueue(this.handle); }
     async check(sanityCheck) {
@@ -212,8 +222,10 @@ class Circuit {
      *  been issued; rejects if the PREVIOUS step violated a constraint. Finish a loop with check(). */
     async step(buf, byteOffset, first, count, stride, sanityCheck) {
         const hadPrev = !!this._inFlight;
+        const work = addon.step(this.handle, buf || null, byteOffset === undefined ? 0 : byteOffset, first === undefined ? 0 : first, buf ? (count === undefined ? 0 : count) : 0,
+                                stride === undefined || stride === 0 ? this.packedLayout().bytes : stride, hadPrev);   // bad arguments throw here: nothing enqueued
         this._inFlight = true;
-        const fail = await addon.step(this.handle, buf || null, byteOffset || 0, first | 0, buf ? count | 0 : 0, stride || this.packedLayout().bytes, hadPrev);
+        const fail = await work;
         if (fail && wantsSanityCheck(sanityCheck)) throw constraintError(fail);
     }
     /** check() on the calling thread: blocks the event loop until the step is done (command-line tools, measurements) */
@@ -221,6 +233,12 @@ class Circuit {
         this._inFlight = false;
         const fail = addon.checkSync(this.handle);
         if (fail && wantsSanityCheck(sanityCheck)) throw constraintError(fail);
+    }
+    /** After a check() / step() that reported a violated constraint: the first violated constraint of EVERY instance of that launch
+     *  (the reference evaluates one circuit per calculateWitness call; a launch here evaluates nInstances), ordered by instance,
+     *  each as the `constraint` record of the error check() throws. Empty when the launch was clean. */
+    async failures() {
+        return (await addon.failures(this.handle)).map((f) => Object.assign({ message: constraintError(f).message }, f));
     }
     devPtr() { return addon.devPtr(this.handle); }
     witnessTotal() { return addon.witnessTotal(this.handle); }

@@ -124,6 +124,11 @@ hz_status hz_ctx_create(const hz_params* params, hz_ctx** out);
 void hz_ctx_destroy(hz_ctx* ctx);
 /* number of field elements in the witness of ONE instance (w[0] == 1 included) */
 uint64_t hz_witness_len(const hz_ctx* ctx);
+/* bytes of device memory the context holds, counting the buffers that are only allocated on first use (upload staging, the
+ * signature ladder's side buffer of small launches): what n_instances of this template cost of a device's 288 GB */
+uint64_t hz_ctx_device_bytes(const hz_ctx* ctx);
+/* the same figure for a context that does not exist yet (no device needed): hz_template_device_bytes(&params) */
+uint64_t hz_template_device_bytes(const hz_params* params);
 /* closed-form constraint count of the template (reference tools/circuit-constraints.js:31-75) */
 uint64_t hz_constraint_estimate(const hz_ctx* ctx);
 

@@ -56,7 +56,10 @@ typedef struct hzb_tx {   /* the fields of the reference's tx objects (test/roll
 } hzb_tx;
 
 hzb_db* hzb_db_create(uint32_t chain_id, uint64_t first_idx);
-/* a working copy (the reference's suites build a batch on a copy of the state and consolidate it afterwards) */
+/* a working copy (the reference's suites build a batch on a copy of the state and consolidate it afterwards). hzb_batch_build updates
+ * its database in place while it walks the batch: when it fails (HZB_ERR_REJECTED: a transaction the circuit would reject; HZB_ERR_EVAL;
+ * memory) the database is left half-updated and every later call on it returns HZB_ERR_REJECTED -- build on a clone when a batch may
+ * be rejected, and keep the original. */
 hzb_db* hzb_db_clone(const hzb_db* db);
 void hzb_db_destroy(hzb_db* db);
 /* fn = hz_poseidon_dag (or NULL: host hashing) */

@@ -32,3 +32,18 @@ def hz():
     if L.device_count() <= 0:
         pytest.fail("libhermez_witness.so loaded but no gfx950 device is usable")
     return L
+
+
+@pytest.fixture(scope="session")
+def config4():
+    """BASELINE config 4's batch -- RollupMain(2048, 32, 256, 64), the benchmark's own synthetic recipe -- with the oracle's complete
+    witness, computed once for the GPU tests that compare against it (33 s of one core, 3.9 GB)."""
+    from circuits_amd import builder as B
+    from oracle_binding import OracleCtx
+    shape = (2048, 32, 256, 64)
+    bb = B.synthetic_batch(*shape, n_accounts=2048, exits=32, seed=0x48455A31)
+    inp = bb.get_input()
+    o = OracleCtx("rollup-main", *shape)
+    o.set_inputs(inp)
+    assert o.run() is None
+    return {"shape": shape, "batch": bb, "input": inp, "oracle": o}

@@ -130,6 +130,36 @@ async function main() {
         circuit.enqueue();
         await assert.rejects(circuit.check(true), (e) => /Constraint doesn't match/.test(e.message) && e.constraint.instance === 2);
         await assert.rejects(async () => circuit.packInput(Object.assign({ nope: 1 }, many[0].input), pin, 0), /Signal not found/);
+        // failures(): the first violated constraint of EVERY instance of the launch, not only the first one (hz_witness_failures)
+        const bad0 = JSON.parse(JSON.stringify(many[0].input));
+        bad0.imExitRoot[1] = (BigInt(bad0.imExitRoot[1]) + 1n).toString();
+        circuit.packInput(bad0, pin, 0);
+        circuit.stageRange(0, 1, pin, 0, lay.bytes);
+        circuit.enqueue();
+        await assert.rejects(circuit.check(true), (e) => e.constraint.instance === 0);
+        const all = await circuit.failures();
+        assert.deepStrictEqual(all.map((f) => f.instance), [0, 2]);
+        assert.ok(/imExitRoot/.test(all[0].constraintName) && /imStateRoot/.test(all[1].constraintName) && /Constraint doesn't match/.test(all[1].message));
+        // a key bit that is not a bit reaches the device as it is and fails the circuit's own boolean constraint (it used to be masked to
+        // a bit, so that an input the reference rejects came back as an accepted witness); what a byte cannot carry is refused
+        const nb = JSON.parse(JSON.stringify(many[0].input));
+        nb.fromBjjCompressed[1][5] = 2;
+        circuit.packInput(nb, pin, 0);
+        circuit.packInput(many[2].input, pin, 2 * lay.bytes);
+        await circuit.step(pin, 0, 0, many.length, lay.bytes, false);    // (the step in flight failed: not asserted here) stage instance 0 with the bad bit
+        await circuit.step(null, 0, 0, 0, 0, false);
+        await assert.rejects(circuit.check(true), (e) => /fromBjjCompressed boolean/.test(e.message) && e.constraint.instance === 0 && e.constraint.unit === 1 && /2 != 0/.test(e.message));
+        nb.fromBjjCompressed[1][5] = 256;
+        assert.throws(() => circuit.packInput(nb, pin, 0), RangeError);
+        // offsets, strides and counts from JavaScript are validated, not cast
+        assert.throws(() => circuit.stageRange(0, 1, pin, -32, lay.bytes), RangeError);
+        assert.throws(() => circuit.stageRange(0, 2, pin, 0, Number.MAX_SAFE_INTEGER), RangeError);
+        assert.throws(() => circuit.stageRange(0, 1, pin, NaN, lay.bytes), RangeError);
+        await assert.rejects(circuit.step(pin, 0, 0, many.length + 1, lay.bytes, false), RangeError);
+        circuit.packInput(many[0].input, pin, 0);
+        circuit.stageRange(0, 1, pin, 0, lay.bytes);
+        circuit.enqueue();
+        await circuit.check(true);
     }
     console.log(`node facade: ok (${nCases} cases over ${fx.mains.length} mains + batched path)`);
 }

@@ -268,6 +268,116 @@ def test_sharded_batch_split_sha_tail_matches_oracle(hz):
 
 
 @pytest.mark.gpu
+def test_config4_eight_shards_on_one_gpu_match_oracle(hz, config4):
+    """BASELINE config 4 at its literal shape, partitioned as the north star says -- RollupMain(2048, 32, 256, 64), 8 ranks x 256
+    transactions, the 766 SHA-256 blocks split 8 ways (reference src/rollup-main.circom:93-99,433-474) -- with eight contexts standing
+    in for the eight ranks on one device (no 8-GPU node is available to the builds; the exchange buffers are the real hz_da_export /
+    hz_sha_export records). The UNION of the shards is the oracle's witness: every transaction's signals on the rank that owns it,
+    every SHA-256 block written by exactly its owner, the fee transactions and the public output on rank 0."""
+    import numpy as np
+    import torch
+    from circuits_amd.multigpu import ShardedBatch
+    shape, bb, inp, o = config4["shape"], config4["batch"], config4["input"], config4["oracle"]
+    n_tx, world = shape[0], 8
+    ctxs = [hz.ctx("rollup-main", nTx=n_tx, nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3]) for _ in range(world)]
+    for name in inp:   # one host pass per signal, then device-to-device onto the other "ranks"
+        ctxs[0].set_input(name, inp[name])
+    lay = ctxs[0].packed_layout()
+    from circuits_amd.capi import pack_inputs
+    packed = pack_inputs(lay, inp)
+    for c in ctxs[1:]:
+        c.upload(0, packed)
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    mailbox, shabox = {}, {}
+
+    def alloc(n):
+        return torch.zeros(n, dtype=torch.uint8, device="cuda")
+    sbs = []
+    for r in range(world):
+        def all_gather(recv, send, r=r):
+            with torch.cuda.stream(streams[r]):
+                mailbox[r] = send.clone()
+                if r == 0:   # rank 0 runs after the others' first halves in this single-process stand-in
+                    for k in range(1, world):
+                        streams[0].wait_stream(streams[k])
+                    recv.copy_(torch.cat([mailbox[k] for k in range(world)]))
+
+        def broadcast(buf, r=r):
+            with torch.cuda.stream(streams[r]):
+                if r == 0:
+                    shabox[0] = buf.clone()
+                else:
+                    streams[r].wait_stream(streams[0])
+                    buf.copy_(shabox[0])
+        sbs.append(ShardedBatch(ctxs[r], hz, n_tx, r, world, alloc, all_gather, broadcast))
+    assert [sb.count for sb in sbs] == [256] * 8 and sbs[0].rec * 2048 == sbs[0].slot * world
+    for r in range(1, world):   # the other ranks' first halves: their transactions, their export
+        c, s = ctxs[r], streams[r].cuda_stream
+        c.enqueue(s)
+        c.da_export(sbs[r].send.data_ptr(), s)
+        sbs[r].all_gather(sbs[r].recv, sbs[r].send)
+    sbs[0].step(streams[0].cuda_stream)
+    for r in range(1, world):   # their second halves: the broadcast, their share of the blocks
+        sbs[r].broadcast(sbs[r].sha)
+        ctxs[r].sha_expand(sbs[r].blocks[0], sbs[r].blocks[1], sbs[r].sha.data_ptr(), streams[r].cuda_stream)
+        ctxs[r].check()
+    assert ctxs[0].get("main.hashGlobalInputs") == bb.get_hash_inputs()
+    nb = ctxs[0].sha_blocks()
+    assert nb == 766 and sum(sb.blocks[1] for sb in sbs) == nb and all(sbs[r].blocks[0] == sum(sb.blocks[1] for sb in sbs[:r]) for r in range(world))
+    # transactions: the computed signals of the tx section (signal-major: element = first + sig * nTx + unit), unit u on the rank that owns u
+    idx0 = ctxs[0].lookup("main.decodeTx[0].n2bData.out[0]")
+    idx_end = ctxs[0].lookup("main.rollupTx[0].s5.out") + n_tx
+    rows = (idx_end - idx0) // n_tx
+    assert (idx_end - idx0) % n_tx == 0 and rows > 40000
+    for r0 in range(0, rows, 2048):
+        nr = min(2048, rows - r0)
+        ref = np.frombuffer(o.read_raw_bytes(idx0 + r0 * n_tx, nr * n_tx), dtype=np.uint8).reshape(nr, n_tx, 32)
+        for r in range(world):
+            f, n = sbs[r].first, sbs[r].count
+            got = np.frombuffer(ctxs[r].read_raw_bytes(idx0 + r0 * n_tx, nr * n_tx), dtype=np.uint8).reshape(nr, n_tx, 32)
+            assert np.array_equal(got[:, f:f + n, :], ref[:, f:f + n, :]), "rank %d, signal rows from %d" % (r, r0)
+    # SHA-256 blocks: exactly the owner holds a block's witness
+    first = o.lookup("main.hasherInputs.inputsHasher.sha256compression[0]")
+    names = [n for n in o.symbol_names() if ".inputsHasher.sha256compression[" in n]
+    per_block = len(names) // nb
+    assert len(names) % nb == 0
+    for r in range(world):
+        b0, bn = sbs[r].blocks
+        for owner_side in (True, False):
+            if owner_side:
+                lo_i, cnt = first + b0 * per_block, bn * per_block
+                assert ctxs[r].read_raw_bytes(lo_i, cnt) == o.read_raw_bytes(lo_i, cnt), "rank %d: its own blocks" % r
+            else:
+                for blk in ((b0 + bn) % nb, (b0 - 1) % nb):   # a neighbour's block on either side: not written here
+                    lo_i = first + blk * per_block
+                    assert ctxs[r].read_raw_bytes(lo_i, per_block) != o.read_raw_bytes(lo_i, per_block), "block %d also written by rank %d" % (blk, r)
+    # fee transactions and the rest of HashInputs (bit packing, the digest) on rank 0
+    fee0 = ctxs[0].lookup("main.feeTx[0].feeIdxIsZero.inv")
+    assert ctxs[0].read_raw_bytes(fee0, first - fee0) == o.read_raw_bytes(fee0, first - fee0)
+    tail0 = first + nb * per_block
+    assert ctxs[0].read_raw_bytes(tail0) == o.read_raw_bytes(tail0)
+
+
+@pytest.mark.gpu
+def test_bench_gpus8_eight_ranks_on_one_gpu(hz):
+    """`python bench.py --gpus 8` as the driver launches it on an 8-GPU node, here with the one-GPU hook (all eight ranks on device 0,
+    gloo collectives): eight real processes, real hz_da_export records through the all_gather and the SHA-256 state through the
+    broadcast, n_gpus = 8 in the line and the tx-sharded secondary line at 5 transactions per rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, HZ_BENCH_DEVICE="0", HZ_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--nTx", "40", "--nLevels", "16", "--maxL1Tx", "8", "--maxFeeTx", "4",
+           "--batches-per-launch", "2", "--inflight", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--build-workers", "1", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["world_size"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    sh = line["shard_tx"]
+    assert sh["scaling"] == "strong" and sh["transactions_per_rank"] == 5 and "all_gather" in sh["collective"] and "broadcast" in sh["collective"]
+
+
+@pytest.mark.gpu
 def test_bench_sharded_pass_through_rccl_on_one_gpu(hz):
     """the RCCL calls of the sharded pass -- all_gather_into_tensor and broadcast enqueued on the pass's own
     stream between the export / import / expansion kernels -- executed for real: a process group of backend nccl with world size 1

@@ -230,9 +230,20 @@ def test_native_builder_reports_what_the_circuit_would_reject():
     bb = db.build_batch(4, 8, 2, 2)
     bb.add_tx({"onChain": 1, "fromIdx": 0, "toIdx": 0, "tokenID": 1, "loadAmountF": B.fix2float(100), "fromBjjCompressed": a.bjj_compressed, "fromEthAddr": a.eth_addr})
     bb.add_tx({"fromIdx": 256, "toIdx": 300, "amount": 10, "tokenID": 1, "userFee": 0, "onChain": 0, "signer": a})
+    keep = db.clone()
     with pytest.raises(NB.BuilderError, match="receiver account 300 does not exist") as e:
         bb.build(make_layout(4, 8, 2))
     assert e.value.status == 2
+    # the walk had created account 256 before it met the bad transfer: the database is neither the old state nor the new one and
+    # refuses further work; the copy taken before the batch is intact
+    with pytest.raises(NB.BuilderError, match="half-updated"):
+        db.build_batch(4, 8, 2, 2)
+    with pytest.raises(NB.BuilderError, match="half-updated"):
+        db.clone()
+    ok = keep.build_batch(4, 8, 2, 2)
+    ok.add_tx({"onChain": 1, "fromIdx": 0, "toIdx": 0, "tokenID": 1, "loadAmountF": B.fix2float(100), "fromBjjCompressed": a.bjj_compressed, "fromEthAddr": a.eth_addr})
+    ok.build(make_layout(4, 8, 2))
+    assert keep.last_idx == 256
     bb = NB.NativeRollupDB().build_batch(2, 8, 1, 1)
     for _ in range(2):
         bb.add_tx({"onChain": 0})

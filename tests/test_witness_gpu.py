@@ -536,14 +536,11 @@ def test_config3_rollup_main_256_16_bit_exact(hz):
     _compare_chunked(g, o)
 
 
-def test_config4_rollup_main_2048_32_full_size_bit_exact(hz):
+def test_config4_rollup_main_2048_32_full_size_bit_exact(hz, config4):
     """BASELINE config 4 shape on one GPU: RollupMain(2048, 32, 256, 64), the benchmark's own synthetic batch. The full 3.86 GB
     witness is compared with the oracle's, plus the size-independent properties: no constraint fails, the public hash equals the
     builder's independent SHA-256 over the data-availability bits, and the last intermediate roots chain to the new state."""
-    from circuits_amd import builder as B
-    shape = (2048, 32, 256, 64)
-    bb = B.synthetic_batch(*shape, n_accounts=2048, exits=32, seed=0x48455A31)
-    inp = bb.get_input()
+    shape, bb, inp, o = config4["shape"], config4["batch"], config4["input"], config4["oracle"]
     g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3])
     g.set_inputs(inp)
     g.run()
@@ -551,23 +548,18 @@ def test_config4_rollup_main_2048_32_full_size_bit_exact(hz):
     assert g.get("main.hashGlobalInputs") == bb.get_hash_inputs()
     assert g.get("main.rollupTx[2047].s4.out") == inp["imInitStateRootFee"]
     assert g.get("main.rollupTx[2046].s4.out") == inp["imStateRoot"][2046]
-    o = OracleCtx("rollup-main", *shape)
-    o.set_inputs(inp)
-    assert o.run() is None
     _compare_chunked(g, o)
 
 
-def test_headline_launch_whole_buffer(hz):
+def test_headline_launch_whole_buffer(hz, config4):
     """The launch bench.py times, compared whole: RollupMain(2048, 32, 256, 64) x 9 batches in ONE set of launches -- 18 432 transactions,
     above the size switch of the signature check (k_eddsa_pre + k_eddsa_seg<4> + k_eddsa_fix<8>, lanes holding signatures of different
     batches), the early HashInputs tail over 766 blocks x 9 with its half-wavefront bit stores, k_smt's empty-level blocks at this
     unit count. Two different batches replicated on the device; the complete 3.86 GB witness of the first, the middle and the last
     instance against the oracle's (reference src/rollup-main.circom:201-475)."""
-    import threading
     from circuits_amd import builder as B
-    shape, N = (2048, 32, 256, 64), 9
-    bbs = [B.synthetic_batch(*shape, n_accounts=2048, exits=32, seed=0x48455A31),
-           B.synthetic_batch(*shape, n_accounts=4096, exits=7, seed=0x48455A32)]
+    shape, N = config4["shape"], 9
+    bbs = [config4["batch"], B.synthetic_batch(*shape, n_accounts=4096, exits=7, seed=0x48455A32)]
     which = [0, 1, 1, 0, 1, 0, 0, 1, 1]
     g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3], n_instances=N)
     for b in (0, 1):
@@ -575,19 +567,11 @@ def test_headline_launch_whole_buffer(hz):
     for k in range(2, N):
         g.copy_instance_inputs(which[k], k)
     g.enqueue()
-    oc = [OracleCtx("rollup-main", *shape) for _ in bbs]
-    res = [None, None]
-
-    def work(b):
-        oc[b].set_inputs(bbs[b].get_input())
-        res[b] = oc[b].run()
-    ths = [threading.Thread(target=work, args=(b,)) for b in (0, 1)]   # ctypes releases the GIL: the two batches side by side
-    for t in ths:
-        t.start()
+    o1 = OracleCtx("rollup-main", *shape)   # the second batch's oracle runs while the device works
+    o1.set_inputs(bbs[1].get_input())
+    assert o1.run() is None
+    oc = [config4["oracle"], o1]
     g.check()
-    for t in ths:
-        t.join()
-    assert res == [None, None]
     sig = g.lookup("main.hashGlobalInputs")
     for k in range(N):
         assert g.read(sig, 1, k)[0] == bbs[which[k]].get_hash_inputs()

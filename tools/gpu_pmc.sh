@@ -4,10 +4,10 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc; rm -rf $OUT; mkdir -p $OUT
 cd $R
-timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/valu -o run --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 "$@" > $OUT/bench_valu.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/valu -o run --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-sweep "$@" > $OUT/bench_valu.log 2>&1
 tail -2 $OUT/bench_valu.log | cut -c1-300
 find $OUT -name "*.csv" | head
-python - <<'PY'
+python - "$@" <<'PY'
 import csv, glob, collections, os
 out = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/pmc"
 for f in glob.glob(out + "/valu/**/*counter_collection.csv", recursive=True):
@@ -25,5 +25,32 @@ for f in glob.glob(out + "/valu/**/*counter_collection.csv", recursive=True):
         for k in sorted(acc, key=lambda k: -acc[k].get("SQ_INSTS_VALU", 0)):
             o.write(k + "," + str(n[k]) + "," + ",".join("%.4g" % (acc[k][c] / n[k]) for c in names) + "\n")
     print(open(out + "/valu_summary.csv").read())
+    # per step / per transaction-grid launch, for bench.py's roofline_valu: a step = one k_main_front dispatch; the transaction launch of
+    # a kernel = its dispatches with the most waves
+    import json
+    per = collections.defaultdict(list)   # kernel -> [(SQ_WAVES, SQ_INSTS_VALU)] per dispatch
+    cur = {}
+    for r in csv.DictReader(open(f)):
+        k, d = r["Kernel_Name"].split("(")[0], r["Dispatch_Id"]
+        e = cur.setdefault(d, {"k": k, "w": 0.0, "v": 0.0})
+        if r["Counter_Name"] == "SQ_WAVES": e["w"] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_INSTS_VALU": e["v"] += float(r["Counter_Value"])
+    for e in cur.values():
+        per[e["k"]].append((e["w"], e["v"]))
+    steps = max(1, len(per.get("hz::k_main_front", [])))
+    kernels = {}
+    for k, v in per.items():
+        wmax = max(x[0] for x in v)
+        big = [x[1] for x in v if x[0] >= 0.9 * wmax]
+        key = "k_" + k.replace("void ", "").replace("hz::", "").split("<")[0].replace("k_", "")
+        e = kernels.setdefault(key, {"insts_valu_per_step": 0.0, "insts_valu_largest_grid_mean": 0.0, "dispatches": 0})
+        e["insts_valu_per_step"] += sum(x[1] for x in v) / steps
+        e["insts_valu_largest_grid_mean"] = max(e["insts_valu_largest_grid_mean"], sum(big) / len(big))
+        e["dispatches"] += len(v)
+    json.dump({"command": "python bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-sweep " + " ".join(__import__("sys").argv[1:]), "steps_enqueued": steps,
+               "insts_valu_per_step": sum(e["insts_valu_per_step"] for e in kernels.values()),
+               "note": "SQ_INSTS_VALU (wave-instructions), rocprofv3 --pmc pass of its own; per step = all dispatches / k_main_front dispatches; largest_grid_mean = mean over the dispatches with the most waves (the transaction launch)",
+               "kernels": kernels}, open(out + "/valu_counters.json", "w"), indent=1)
+    print("insts_valu_per_step %.4g" % sum(e["insts_valu_per_step"] for e in kernels.values()))
 PY
 find $OUT -name "*.csv" -size +4M -delete

@@ -21,7 +21,7 @@ f = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
     with open(out + "/kernel_stats.csv", "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats -- %s   (round 3, MI355X)\n" % cmd)
+        o.write("# rocprofv3 --kernel-trace --stats -- %s   (round %s, MI355X)\n" % (cmd, os.environ.get("HZ_ROUND", "4")))
         o.write("name,calls,total_duration_us,average_us,percentage\n")
         for r in rows:
             o.write("%s,%s,%.0f,%.1f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
