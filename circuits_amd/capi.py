@@ -62,7 +62,7 @@ EXPORTS = [
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_witness_enqueue_tail_chain", "hz_sha_blocks", "hz_sha_state_bytes", "hz_sha_export", "hz_sha_expand",
-    "hz_symmap_create", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
+    "hz_symmap_create", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_symmap_derived", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
     "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym", "hz_fr_ops", "hz_poseidon_dag",
 ]
@@ -490,6 +490,12 @@ class SymMap:
             self.ctx.L.c.hz_symmap_unresolved(self.h, i, ctypes.byref(v), ctypes.byref(nm))
             out.append((v.value, nm.value.decode()))
         return out
+
+    def derived(self):
+        """variables evaluated from stored signals by a rule (linear signals an unreduced compile keeps)"""
+        f = self.ctx.L.c.hz_symmap_derived
+        f.restype, f.argtypes = ctypes.c_uint64, [ctypes.c_void_p]
+        return f(self.h)
 
     def read(self, first=0, count=None, instance=0):
         count = self.nvars() - first if count is None else count

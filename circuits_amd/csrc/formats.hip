@@ -12,10 +12,12 @@
 // `./circuit input.json witness.json` (circuits_amd/csrc/cli/hz_witness.cpp).
 #include <stdio.h>
 #include <string.h>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
 #include "hostutil.h"
+#include "derived.h"
 
 namespace hz {
 
@@ -273,11 +275,374 @@ extern "C" hz_status hz_symbols_write_sym(const hz_ctx* ctx, const char* path) {
 // as is. The import joins the two by NAME: variable v is resolved when ANY label of v is a stored signal. Variables none of
 // whose labels is stored are reported (hz_symmap_unresolved): such a circuit build keeps signals this layout drops, and its
 // witness cannot be produced from this one.
+// Derived signals. This layout stores what a constraint-reducing compile keeps; the reference's suites compile with
+// reduceConstraints:false (reference test/rollup-main.test.js:52), which keeps every LINEAR signal as a variable of its own. Those are
+// functions of stored signals and are evaluated when the witness is read in the compiler's order:
+//   * every signal inside circomlib's Poseidon(n) -- ark[i].in/out[j], mix[i].in/out[j], sigmaF[k][j].in, sigmaP[k].in, inputs[j], out
+//     (poseidon.circom of circomlib 0.5.2) -- from the component's stored S-box signals alone: the inputs of round 0's S-boxes are
+//     out / in4 (x^5 / x^4), every later state follows forward from the stored S-box outputs through Ark and Mix;
+//   * the linear intermediates and linearly fed component inputs of the reference's own templates (a rule table transcribed from
+//     src/*.circom: e0, loadAmount, isAmount, underflowOk, p_fnc1, nonceChecker.enabled, newSt1Hash.nonce, Bits2Num outputs ...),
+//     as linear forms over stored signals or other derived ones.
+// A variable whose labels match neither a stored signal nor a rule stays unresolved and is reported as before.
+enum { DV_POSEIDON = 1, DV_LINEAR = 2 };
+using hzderived::PW_ARK_IN; using hzderived::PW_ARK_OUT; using hzderived::PW_MIX_IN; using hzderived::PW_MIX_OUT;
+struct DerivedVar {
+    uint8_t kind = 0, t = 0, what = 0;
+    uint16_t round = 0, lane = 0;
+    uint32_t lin = 0;                 // DV_LINEAR: index into hz_symmap::lins
+    uint64_t first = 0, stride = 0;   // DV_POSEIDON: this library's index of sigmaF[0][0].in2 and the distance between consecutive stored signals
+};
+static const uint64_t DERIVED_FLAG = 1ull << 63;
+struct LinForm {
+    hzh::F c0;
+    std::vector<std::pair<hzh::F, uint64_t>> terms;   // coefficient (Montgomery form), stored index or DERIVED_FLAG | derived index
+};
 struct hz_symmap {
-    std::vector<uint64_t> index;          // per variable: index in this library's per-instance witness, ~0 = unresolved
+    std::vector<uint64_t> index;          // per variable: index in this library's per-instance witness, DERIVED_FLAG | k, or ~0 = unresolved
     std::vector<std::string> first_label; // per unresolved variable (in variable order): one of its names
     std::vector<uint64_t> unresolved;     // variable numbers
+    std::vector<DerivedVar> derived;
+    std::vector<LinForm> lins;
+    std::map<std::string, uint64_t> memo; // name -> resolved index (rules refer to each other)
+    struct PosBlk { int t; uint64_t first, stride; };
+    std::map<std::string, PosBlk> pos_memo;   // component prefix -> its Poseidon block (t = 0: not one)
+    uint64_t n_derived = 0;
 };
+
+namespace {
+using hzh::F;
+using namespace hzderived;
+// ---- name -> stored signal or rule ---------------------------------------------------------------------------------------------------
+bool parse_index(const std::string& s, size_t& p, int& v) {   // "[123]" at p
+    if (p >= s.size() || s[p] != '[') return false;
+    size_t q = p + 1;
+    long long x = 0;
+    int nd = 0;
+    while (q < s.size() && s[q] >= '0' && s[q] <= '9' && nd < 9) { x = x * 10 + (s[q] - '0'); q++; nd++; }
+    if (!nd || q >= s.size() || s[q] != ']') return false;
+    v = (int)x; p = q + 1;
+    return true;
+}
+// is `prefix` a Poseidon component of this layout? -> width, index of its first stored signal, distance between its stored signals
+bool pos_block(const hz_ctx* ctx, const std::string& prefix, int& t, uint64_t& first, uint64_t& stride) {
+    uint64_t a = 0, b = 0;
+    if (!hz_symbol_lookup(ctx, (prefix + ".sigmaF[0][0].in2").c_str(), &a) || !hz_symbol_lookup(ctx, (prefix + ".sigmaF[0][0].in4").c_str(), &b) || b <= a) return false;
+    t = 0;
+    for (int k = 7; k >= 2; k--) {
+        uint64_t x;
+        if (hz_symbol_lookup(ctx, (prefix + ".sigmaF[0][" + std::to_string(k - 1) + "].in2").c_str(), &x)) { t = k; break; }
+    }
+    first = a; stride = b - a;
+    return t >= 2;
+}
+bool resolve_poseidon(const hz_ctx* ctx, hz_symmap* m, const std::string& name, DerivedVar& d) {
+    static const char* marks[] = {".ark[", ".mix[", ".sigmaF[", ".sigmaP[", ".inputs["};
+    size_t pos = std::string::npos;
+    int which = -1;
+    for (int m = 0; m < 5; m++) {
+        const size_t p = name.rfind(marks[m]);
+        if (p != std::string::npos && (pos == std::string::npos || p > pos)) { pos = p; which = m; }
+    }
+    std::string prefix;
+    int what = -1, round = 0, lane = 0;
+    if (which < 0) {
+        if (name.size() < 5 || name.compare(name.size() - 4, 4, ".out") != 0) return false;
+        prefix = name.substr(0, name.size() - 4);
+    } else {
+        prefix = name.substr(0, pos);
+        size_t p = pos + strlen(marks[which]) - 1;   // at '['
+        int i = 0, j = 0;
+        if (!parse_index(name, p, i)) return false;
+        const std::string rest = name.substr(p);
+        if (which <= 1) {   // ark[i].in[j] / ark[i].out[j] / mix[i]...
+            size_t q = 0;
+            bool out;
+            if (rest.compare(0, 4, ".in[") == 0) { out = false; q = 3; }
+            else if (rest.compare(0, 5, ".out[") == 0) { out = true; q = 4; }
+            else return false;
+            if (!parse_index(rest, q, j) || q != rest.size()) return false;
+            what = which == 0 ? (out ? PW_ARK_OUT : PW_ARK_IN) : (out ? PW_MIX_OUT : PW_MIX_IN);
+            round = i; lane = j;
+        } else if (which == 2) {   // sigmaF[k][j].in = ark[round(k)].out[j]
+            size_t q = 0;
+            if (!parse_index(rest, q, j) || rest.substr(q) != ".in") return false;
+            what = PW_ARK_OUT; round = i; lane = j;   // the round is fixed below (needs the width)
+            which = 20;
+        } else if (which == 3) {   // sigmaP[k].in = ark[4 + k].out[0]
+            if (rest != ".in") return false;
+            what = PW_ARK_OUT; round = 4 + i; lane = 0;
+        } else {                   // inputs[j] = ark[0].in[j + 1]
+            if (!rest.empty()) return false;
+            what = PW_ARK_IN; round = 0; lane = i + 1;
+        }
+    }
+    int t = 0;
+    uint64_t first = 0, stride = 0;
+    auto pm = m->pos_memo.find(prefix);
+    if (pm == m->pos_memo.end()) {   // a component has hundreds of such names: look its block up once
+        if (!pos_block(ctx, prefix, t, first, stride)) t = 0;
+        pm = m->pos_memo.emplace(prefix, hz_symmap::PosBlk{t, first, stride}).first;
+    }
+    if (pm->second.t == 0) return false;
+    t = pm->second.t; first = pm->second.first; stride = pm->second.stride;
+    if (which == 20 && round >= 4) round += POS_RP[t - 2];
+    if (what < 0) { what = PW_MIX_OUT; round = pos_rounds(t) - 1; lane = 0; }   // <component>.out
+    if (round < 0 || round >= pos_rounds(t) || lane < 0 || lane >= t) return false;
+    if (which == 3 && round >= 4 + POS_RP[t - 2]) return false;
+    d = DerivedVar();
+    d.kind = DV_POSEIDON; d.t = (uint8_t)t; d.what = (uint8_t)what; d.round = (uint16_t)round; d.lane = (uint16_t)lane; d.first = first; d.stride = stride;
+    return true;
+}
+
+// Linear intermediates and linearly fed component inputs of the reference's templates. `suffix`: the end of the signal's name, from a
+// component boundary; `expr`: its value over names relative to what precedes the suffix -- terms joined by " + " / " - ", each an
+// integer, 2^k, a name, `c*name`, `2^k*name`, bits(name,first,count) = sum of 2^i * name[first + i], or sumto(name,K) / sumbelow(name,K) =
+// the sum of `name` with its % replaced by 0..K / 0..K-1. A # in the suffix matches one array index, and stands for it in the expr. One line per `<==` of
+// src/*.circom whose right-hand side is linear (file:line in the comment); a term that resolves to neither a stored nor a derived
+// signal makes the rule not apply.
+struct LinRule { const char* suffix; const char* expr; };
+const LinRule LIN_RULES[] = {
+    {"e0", "hash.inputs[0]"},                                                     // lib/hash-state.circom:30,34 (tokenID + nonce 2^32 + sign 2^72)
+    {"loadAmount", "dfLoadAmount.out"},                                           // rollup-tx.circom:181-192
+    {"dfLoadAmount.scale10", "dfLoadAmount.pe[4]"},                               // lib/decode-float.circom:34
+    {"decoder.scale10", "decoder.pe[4]"},                                         // the DecodeFloat main
+    {"states.finalFromIdx", "states.selectFromIdx.out"},                          // rollup-tx-states.circom (selectFromIdx.out ==> finalFromIdx)
+    {"states.finalToIdx", "states.selectToIdx.out"},
+    {"states.isFinalFromIdx", "1 - states.finalFromIdxIsZero.out"},               // rollup-tx-states.circom:155
+    {"states.isLoadAmount", "1 - states.loadAmountIsZero.out"},                   // :162
+    {"states.isAmount", "1 - states.amountIsZero.out"},                           // :169
+    {"states.shouldCheckTokenID1", "states.onChainNotCreateAccount"},             // :279
+    {"balanceUpdater.underflowOk", "balanceUpdater.n2bSender.out[192]"},          // balance-updater.circom:80
+    {"nonceChecker.enabled", "1 - onChain"},                                      // rollup-tx.circom
+    {"checkTokenID1.enabled", "1 - onChain"},
+    {"newSt1Hash.nonce", "s1Nonce.out + 1 - onChain"},                            // rollup-tx.circom:519
+    {"p_fnc0", "0"},                                                              // fee-tx.circom:72
+    {"p_fnc1", "1 - feeIdxIsZero.out"},                                           // :73
+    {"tokenIDChecker.enabled", "1 - feeIdxIsZero.out"},
+    {"newStFeePck.balance", "accFee + balance"},
+    {"constSig", "bits(n2bData.out,0,32)"},                                       // decode-tx.circom:95-101 (b2nConstSig.out ==> constSig)
+    {"b2nConstSig.out", "bits(n2bData.out,0,32)"},
+    {"chainID", "bits(n2bData.out,32,16)"},                                       // :103-108
+    {"b2nChainID.out", "bits(n2bData.out,32,16)"},
+    {"chainIDChecker.enabled", "1 - onChain"},
+    {"constSigChecker.enabled", "1 - onChain"},
+    // circomlib smt/smtprocessorsm.circom: st_top <== prev_top - aux1; st_upd <== aux1 - aux2; st_na <== prev_new1 + prev_old0 + prev_na + prev_upd,
+    // chained from (prev_top, prev_na) = (enabled, 1 - enabled) in smtprocessor.circom -- closed forms over the stored products
+    {"sm[#].st_upd", "sm[#].aux1 - sm[#].aux2"},
+    {"sm[#].st_top", "enabled - sumto(sm[%].aux1,#)"},
+    {"sm[#].st_na", "1 - enabled + sumbelow(sm[%].st_new1,#) + sumbelow(sm[%].st_old0,#) + sumbelow(sm[%].aux1,#) - sumbelow(sm[%].aux2,#)"},
+    // circomlib switcher.circom on the processor's top: outL <== aux + L; outR <== -aux + R with (L, R) = levels[0].(oldRoot, newRoot)
+    {"topSwitcher.outL", "topSwitcher.aux + levels[0].oldRoot"},
+    {"topSwitcher.outR", "levels[0].newRoot - topSwitcher.aux"},
+};
+}  // namespace
+
+namespace {
+F f_small(uint64_t x) { return hzh::f_from_u64(x); }
+F f_pow2(int k) {
+    F r = hzh::f_one();
+    for (int i = 0; i < k; i++) r = hzh::f_add(r, r);
+    return r;
+}
+F f_neg(const F& a) { return hzh::f_sub(hzh::f_zero(), a); }
+bool parse_coef(const std::string& tok, F& c) {   // "123" or "2^k"
+    if (tok.empty()) return false;
+    if (tok.compare(0, 2, "2^") == 0) {
+        const int k = atoi(tok.c_str() + 2);
+        if (k < 0 || k > 253) return false;
+        c = f_pow2(k);
+        return true;
+    }
+    uint64_t v = 0;
+    for (char ch : tok) {
+        if (ch < '0' || ch > '9' || v > (1ull << 60)) return false;
+        v = v * 10 + (uint64_t)(ch - '0');
+    }
+    c = f_small(v);
+    return true;
+}
+uint64_t resolve_name(const hz_ctx* ctx, hz_symmap* m, const std::string& name, int depth);
+// expr over names relative to `prefix` -> linear form; false when a term does not resolve
+bool parse_linear(const hz_ctx* ctx, hz_symmap* m, const std::string& prefix, const char* expr, LinForm& lf, int depth) {
+    lf.c0 = hzh::f_zero();
+    lf.terms.clear();
+    bool neg = false;
+    const char* p = expr;
+    while (*p) {
+        while (*p == ' ') p++;
+        const char* q = p;
+        int par = 0;
+        while (*q && (*q != ' ' || par)) { par += *q == '(' ? 1 : (*q == ')' ? -1 : 0); q++; }
+        const std::string tok(p, q);
+        p = q;
+        if (tok.empty()) break;
+        if (tok == "+") { neg = false; continue; }
+        if (tok == "-") { neg = true; continue; }
+        auto add_term = [&](F coef, const std::string& rel) -> bool {
+            const uint64_t idx = resolve_name(ctx, m, prefix.empty() ? rel : prefix + "." + rel, depth + 1);
+            if (idx == ~0ull) return false;
+            lf.terms.push_back({neg ? f_neg(coef) : coef, idx});
+            return true;
+        };
+        F c;
+        if (tok.compare(0, 5, "bits(") == 0 && tok.back() == ')') {   // bits(name,first,count)
+            const std::string in = tok.substr(5, tok.size() - 6);
+            const size_t c1 = in.find(','), c2 = in.find(',', c1 == std::string::npos ? 0 : c1 + 1);
+            if (c1 == std::string::npos || c2 == std::string::npos) return false;
+            const int first = atoi(in.c_str() + c1 + 1), count = atoi(in.c_str() + c2 + 1);
+            if (first < 0 || count < 1 || count > 254) return false;
+            F w = hzh::f_one();
+            for (int i = 0; i < count; i++) {
+                if (!add_term(w, in.substr(0, c1) + "[" + std::to_string(first + i) + "]")) return false;
+                w = hzh::f_add(w, w);
+            }
+        } else if ((tok.compare(0, 6, "sumto(") == 0 || tok.compare(0, 9, "sumbelow(") == 0) && tok.back() == ')') {
+            const bool incl = tok[3] == 't';
+            const std::string in = tok.substr(incl ? 6 : 9, tok.size() - (incl ? 7 : 10));
+            const size_t c1 = in.rfind(',');
+            const size_t pc = in.find('%');
+            if (c1 == std::string::npos || pc == std::string::npos || pc > c1) return false;
+            const int K = atoi(in.c_str() + c1 + 1);
+            if (K < 0 || K > 64) return false;
+            for (int i = 0; i < K + (incl ? 1 : 0); i++)
+                if (!add_term(hzh::f_one(), in.substr(0, pc) + std::to_string(i) + in.substr(pc + 1, c1 - pc - 1))) return false;
+        } else if (parse_coef(tok, c)) {
+            lf.c0 = neg ? hzh::f_sub(lf.c0, c) : hzh::f_add(lf.c0, c);
+        } else {
+            const size_t star = tok.find('*');
+            if (star != std::string::npos) {
+                if (!parse_coef(tok.substr(0, star), c) || !add_term(c, tok.substr(star + 1))) return false;
+            } else if (!add_term(hzh::f_one(), tok)) return false;
+        }
+        neg = false;
+    }
+    return true;
+}
+// this library's index of a signal name: a stored signal, DERIVED_FLAG | k for one a rule evaluates, ~0 when neither
+uint64_t resolve_name(const hz_ctx* ctx, hz_symmap* m, const std::string& name_in, int depth) {
+    const std::string name = name_in.compare(0, 5, "main.") == 0 ? name_in : "main." + name_in;
+    auto it = m->memo.find(name);
+    if (it != m->memo.end()) return it->second;
+    uint64_t idx = 0;
+    if (hz_symbol_lookup(ctx, name.c_str(), &idx)) return m->memo[name] = idx;
+    if (depth > 4) return ~0ull;
+    DerivedVar d;
+    if (resolve_poseidon(ctx, m, name, d)) {
+        m->derived.push_back(d);
+        return m->memo[name] = DERIVED_FLAG | (m->derived.size() - 1);
+    }
+    for (const LinRule& r : LIN_RULES) {
+        // match the suffix from the end of the name; a # stands for one array index
+        long long cap = -1;
+        size_t ni = name.size();
+        bool ok = true;
+        for (size_t ri = strlen(r.suffix); ri > 0 && ok; ri--) {
+            const char ch = r.suffix[ri - 1];
+            if (ch == '#') {
+                size_t e = ni;
+                while (ni > 0 && name[ni - 1] >= '0' && name[ni - 1] <= '9') ni--;
+                ok = ni < e && e - ni < 9;
+                if (ok) cap = atoll(name.substr(ni, e - ni).c_str());
+            } else ok = ni > 0 && name[--ni] == ch;
+        }
+        if (!ok || ni < 2 || name[ni - 1] != '.') continue;
+        std::string expr = r.expr;
+        if (cap >= 0)
+            for (size_t q; (q = expr.find('#')) != std::string::npos;) expr.replace(q, 1, std::to_string(cap));
+        LinForm lf;
+        if (!parse_linear(ctx, m, name.substr(0, ni - 1), expr.c_str(), lf, depth)) continue;
+        if (lf.terms.size() == 1 && hzh::f_is_zero(lf.c0) && hzh::f_eq(lf.terms[0].first, hzh::f_one())) return m->memo[name] = lf.terms[0].second;   // a wire-through
+        d = DerivedVar();
+        d.kind = DV_LINEAR; d.lin = (uint32_t)m->lins.size();
+        m->lins.push_back(std::move(lf));
+        m->derived.push_back(d);
+        return m->memo[name] = DERIVED_FLAG | (m->derived.size() - 1);
+    }
+    return ~0ull;
+}
+
+// `count` variables of the map from `first` on, stored ones gathered from the device, derived ones evaluated on the host
+hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const uint64_t* index, uint64_t count, uint8_t* out) {
+    // what has to come from the device: the stored variables themselves, the stored terms of the linear forms (through other
+    // derived variables), the S-box signals of every Poseidon component one of the variables lies in
+    std::vector<uint64_t> need;
+    std::map<uint64_t, size_t> slot;   // stored index -> position in `need`
+    auto want = [&](uint64_t idx) { if (slot.emplace(idx, need.size()).second) need.push_back(idx); };
+    std::vector<uint8_t> seen(m->derived.size(), 0);
+    std::vector<uint64_t> stack;
+    bool any_derived = false;
+    for (uint64_t i = 0; i < count; i++) {
+        if (index[i] == ~0ull) return set_err(HZ_ERR_INPUT, "variable %llu of the .sym is not resolved", (unsigned long long)i);
+        if (!(index[i] & DERIVED_FLAG)) continue;
+        any_derived = true;
+        stack.push_back(index[i] & ~DERIVED_FLAG);
+    }
+    if (!any_derived) return hz_witness_gather(ctx, instance, index, count, out);
+    std::map<uint64_t, int> blocks;    // Poseidon component (index of its first stored signal) -> width
+    while (!stack.empty()) {
+        const uint64_t k = stack.back();
+        stack.pop_back();
+        if (seen[k]) continue;
+        seen[k] = 1;
+        const DerivedVar& d = m->derived[k];
+        if (d.kind == DV_POSEIDON) {
+            if (blocks.emplace(d.first, d.t).second)
+                for (int j = 0; j < 3 * pos_nsbox(d.t); j++) want(d.first + (uint64_t)j * d.stride);
+        } else {
+            for (const auto& tm : m->lins[d.lin].terms) {
+                if (tm.second & DERIVED_FLAG) stack.push_back(tm.second & ~DERIVED_FLAG);
+                else want(tm.second);
+            }
+        }
+    }
+    for (uint64_t i = 0; i < count; i++)
+        if (!(index[i] & DERIVED_FLAG)) want(index[i]);
+    std::vector<uint8_t> vals(need.size() * 32);
+    if (!need.empty()) {
+        const hz_status st = hz_witness_gather(ctx, instance, need.data(), need.size(), vals.data());
+        if (st != HZ_OK) return st;
+    }
+    std::map<uint64_t, std::vector<F>> traces;
+    std::vector<uint8_t> sbox;
+    for (const auto& b : blocks) {
+        const int n = 3 * pos_nsbox(b.second);
+        sbox.resize((size_t)n * 32);
+        const uint64_t stride = [&] { for (const DerivedVar& d : m->derived) if (d.kind == DV_POSEIDON && d.first == b.first) return d.stride; return (uint64_t)1; }();
+        for (int j = 0; j < n; j++) memcpy(sbox.data() + 32 * (size_t)j, vals.data() + 32 * slot[b.first + (uint64_t)j * stride], 32);
+        pos_trace(b.second, sbox.data(), traces[b.first]);
+    }
+    std::vector<F> dval(m->derived.size());
+    std::vector<uint8_t> done(m->derived.size(), 0);
+    // linear forms over other derived variables: evaluate in dependency order (depth is bounded by the resolver)
+    struct Eval {
+        const hz_symmap* m; std::vector<F>& dval; std::vector<uint8_t>& done; std::map<uint64_t, std::vector<F>>& traces; std::vector<uint8_t>& vals; std::map<uint64_t, size_t>& slot;
+        F get(uint64_t k) {
+            if (done[k]) return dval[k];
+            const DerivedVar& d = m->derived[k];
+            F v;
+            if (d.kind == DV_POSEIDON) {
+                const int R = pos_rounds(d.t);
+                v = traces[d.first][((size_t)d.what * R + d.round) * d.t + d.lane];
+            } else {
+                const LinForm& lf = m->lins[d.lin];
+                v = lf.c0;
+                for (const auto& tm : lf.terms) {
+                    const F x = (tm.second & DERIVED_FLAG) ? get(tm.second & ~DERIVED_FLAG) : hzh::f_from_canon(vals.data() + 32 * slot[tm.second]);
+                    v = hzh::f_add(v, hzh::f_mul(tm.first, x));
+                }
+            }
+            done[k] = 1;
+            return dval[k] = v;
+        }
+    } ev{m, dval, done, traces, vals, slot};
+    for (uint64_t i = 0; i < count; i++) {
+        if (index[i] & DERIVED_FLAG) hzh::f_to_canon(ev.get(index[i] & ~DERIVED_FLAG), out + 32 * i);
+        else memcpy(out + 32 * i, vals.data() + 32 * slot[index[i]], 32);
+    }
+    return HZ_OK;
+}
+}  // namespace
 
 extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_t len, hz_symmap** out) {
     if (!ctx || !text || !out) return set_err(HZ_ERR_ARG, "hz_symmap_create: null argument");
@@ -324,7 +689,7 @@ extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_
                     const std::string name(q, (size_t)(ne - q));
                     uint64_t idx = 0;
                     if (var == 0 && (name == "one" || name == "main.one")) idx = 0, m->index[0] = 0;
-                    else if (hz_symbol_lookup(ctx, name.c_str(), &idx)) m->index[(size_t)var] = idx;
+                    else if ((idx = resolve_name(ctx, m, name, 0)) != ~0ull) m->index[(size_t)var] = idx;   // stored, or evaluated by a rule
                     else if (label[(size_t)var].empty()) label[(size_t)var] = name;
                 }
             }
@@ -332,11 +697,14 @@ extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_
         p = nl ? nl + 1 : e;
     }
     if (!m->index.empty() && m->index[0] == ~0ull) m->index[0] = 0;   // variable 0 is the constant 1 whether or not the file names it
-    for (size_t v = 0; v < m->index.size(); v++)
+    for (size_t v = 0; v < m->index.size(); v++) {
         if (m->index[v] == ~0ull) {
             m->unresolved.push_back(v);
             m->first_label.push_back(label[v].empty() ? std::string("(no label in the file)") : label[v]);
-        }
+        } else if (m->index[v] & DERIVED_FLAG) m->n_derived++;
+    }
+    m->memo.clear();
+    m->pos_memo.clear();
     *out = m;
     return HZ_OK;
     } catch (const std::bad_alloc&) {   // nothing may unwind through the C ABI
@@ -364,8 +732,9 @@ extern "C" hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* m, int32_
     const hz_status st = symmap_usable(m, "hz_witness_read_sym");
     if (st != HZ_OK) return st;
     if (first > m->index.size() || count > m->index.size() - first) return set_err(HZ_ERR_ARG, "hz_witness_read_sym: range beyond the %zu variables", m->index.size());
-    return hz_witness_gather(ctx, instance, m->index.data() + first, count, out);
+    return symmap_values(ctx, m, instance, m->index.data() + first, count, out);
 }
+extern "C" uint64_t hz_symmap_derived(const hz_symmap* m) { return m ? m->n_derived : 0; }
 extern "C" hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const char* path) {
     if (!ctx || !path) return set_err(HZ_ERR_ARG, "hz_witness_write_wtns_sym: null argument");
     hz_status st = symmap_usable(m, "hz_witness_write_wtns_sym");
@@ -386,7 +755,7 @@ extern "C" hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* m, 
     std::vector<uint8_t> buf(CHUNK * 32);
     for (uint64_t i = 0; i < n; i += CHUNK) {
         const uint64_t c = n - i < CHUNK ? n - i : CHUNK;
-        st = hz_witness_gather(ctx, instance, m->index.data() + i, c, buf.data());
+        st = symmap_values(ctx, m, instance, m->index.data() + i, c, buf.data());
         if (st != HZ_OK) { fclose(f); return st; }
         if (fwrite(buf.data(), 32, c, f) != c) { fclose(f); return set_err(HZ_ERR_ARG, "short write to %s", path); }
     }

@@ -222,6 +222,11 @@ hz_status hz_symmap_create(const hz_ctx* ctx, const char* sym_text, size_t len, 
 void hz_symmap_destroy(hz_symmap* map);
 uint64_t hz_symmap_nvars(const hz_symmap* map);
 uint64_t hz_symmap_unresolved(const hz_symmap* map, uint64_t i, uint64_t* var, const char** name);
+/* how many variables of the map are DERIVED: linear signals this layout does not store and a compile without constraint reduction
+ * keeps (reference test/rollup-main.test.js:52, reduceConstraints:false) -- every signal inside a Poseidon component (ark / mix /
+ * S-box inputs, from the stored S-box products), and the linear intermediates / linearly fed component inputs of the reference's own
+ * templates (rule table in csrc/formats.hip) -- evaluated from stored signals when the witness is read in the compiler's order */
+uint64_t hz_symmap_derived(const hz_symmap* map);
 hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instance, uint64_t first_var, uint64_t count, uint8_t* out);
 hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instance, const char* path);
 hz_status hz_witness_gather(hz_ctx* ctx, int32_t instance, const uint64_t* index, uint64_t count, uint8_t* out);

@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE -- CPU oracle (see gadgets_ref.h).
 #include "gadgets_ref.h"
+#include <map>
 
 namespace orc {
 
@@ -85,9 +86,12 @@ F fr_sqrt_circom(const F& n) {
     return gt ? -r : r;
 }
 
+// test aid (orc_poseidon_inputs): the inputs every Poseidon component was evaluated on, by the physical index of its first stored signal
+thread_local std::map<uint64_t, std::vector<F>>* g_poseidon_log = nullptr;
 F poseidon_w(const W& w, hzl::PoseidonOff off, const F* in, int n_in) {
     std::vector<F> sb;
     F h = poseidon(in, n_in, &sb);
+    if (g_poseidon_log) (*g_poseidon_log)[w.lo->phys(w.sec, off, w.unit)] = std::vector<F>(in, in + n_in);
     for (size_t k = 0; k < sb.size(); k++) w.set(off + (uint32_t)k, sb[k]);
     return h;
 }

@@ -13,6 +13,7 @@
 #include <vector>
 #include "../include/hz_layout.h"
 #include "fr64.h"
+#include <map>
 #include "poseidon_ref.h"
 
 namespace orc {
@@ -220,6 +221,7 @@ void smt_verifier(const W& w, const hzl::SmtVerOff& o, int n, const F& enabled, 
                   const F& oldValue, const F& isOld0, const F& key, const F& value, const F& fnc, const SmtVerCids& c);
 
 // writes the S-box signals of a Poseidon and returns the digest
+extern thread_local std::map<uint64_t, std::vector<F>>* g_poseidon_log;
 F poseidon_w(const W& w, hzl::PoseidonOff off, const F* in, int n_in);
 
 }  // namespace orc

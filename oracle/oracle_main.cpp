@@ -18,6 +18,8 @@ struct OrcCtx {
     std::vector<uint8_t> written;
     std::vector<uint8_t> input_set;
     Fail fail;
+    bool log_poseidon = false;                          // orc_log_poseidon: keep every Poseidon component's inputs of the next runs
+    std::map<uint64_t, std::vector<F>> poseidon_in;     // physical index of the component's first stored signal -> its inputs
 };
 
 static bool lt_p(const uint8_t* b) {
@@ -298,6 +300,8 @@ extern "C" int orc_run(void* h, int32_t* err_inst, int32_t* err_unit, int32_t* e
         if (!c->input_set[i]) return 4;
     c->fail = Fail();
     c->fail.per_inst.assign(c->lo.n_inst, FailRec());
+    c->poseidon_in.clear();
+    struct LogScope { LogScope(OrcCtx* c) { g_poseidon_log = c->log_poseidon ? &c->poseidon_in : nullptr; } ~LogScope() { g_poseidon_log = nullptr; } } log_scope(c);
     if (c->lo.p.tmpl == T_ROLLUP_MAIN) {
         for (uint32_t b = 0; b < c->lo.n_inst; b++) run_rollup_main(c, b);
     }
@@ -337,6 +341,17 @@ extern "C" int orc_failure_of(void* h, int instance, int32_t* err_unit, int32_t*
     if (lhs) f.lhs.to_bytes(lhs);
     if (rhs) f.rhs.to_bytes(rhs);
     return 3;
+}
+// test aid for the derived (linear) signals: what each Poseidon component was evaluated on. orc_log_poseidon(h, 1) before orc_run;
+// orc_poseidon_inputs(h, instance, virtual index of the component's first stored signal, out, cap) -> number of inputs (0: none there)
+extern "C" void orc_log_poseidon(void* h, int on) { ((OrcCtx*)h)->log_poseidon = on != 0; }
+extern "C" int orc_poseidon_inputs(void* h, int instance, uint64_t virt_first, uint8_t* out, int cap) {
+    OrcCtx* c = (OrcCtx*)h;
+    auto it = c->poseidon_in.find(c->lo.virt_to_phys(virt_first, (uint32_t)instance));
+    if (it == c->poseidon_in.end()) return 0;
+    const int n = (int)it->second.size();
+    for (int i = 0; i < n && i < cap; i++) it->second[i].to_bytes(out + 32 * i);
+    return n;
 }
 extern "C" int orc_read(void* h, int instance, uint64_t first, uint64_t count, uint8_t* out) {
     OrcCtx* c = (OrcCtx*)h;

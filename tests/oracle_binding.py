@@ -123,6 +123,19 @@ class OracleCtx:
         assert self.o.c.orc_read(self.h, instance, first, count, buf) == 0
         return fr_from_bytes(buf.raw)
 
+    def log_poseidon(self, on=True):
+        """keep the inputs of every Poseidon component of the next runs (poseidon_inputs)"""
+        self.o.c.orc_log_poseidon.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.o.c.orc_log_poseidon(self.h, 1 if on else 0)
+
+    def poseidon_inputs(self, virt_first, instance=0):
+        """inputs the Poseidon component whose first stored signal has per-instance index `virt_first` was evaluated on, or None"""
+        f = self.o.c.orc_poseidon_inputs
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]
+        buf = ctypes.create_string_buffer(32 * 8)
+        n = f(self.h, instance, virt_first, buf, 8)
+        return fr_from_bytes(buf.raw[:32 * n]) if n else None
+
     def read_bytes(self, first, count, instance=0):
         buf = ctypes.create_string_buffer(32 * count)
         assert self.o.c.orc_read(self.h, instance, first, count, buf) == 0
