@@ -646,7 +646,7 @@ class BatchBuilder:
             if not nop:
                 # ---- sender leaf as processor 1 sees it
                 if new_account:
-                    ay = bjj & ((1 << 254) - 1)
+                    ay = (bjj & ((1 << 254) - 1)) % P   # a field element in the circuit (Bits2Num of 254 bits): an invalid key may exceed r
                     sg = (bjj >> 255) & 1
                     # coordinator-chosen leaf data for an INSERT: the circuit takes every field from the tx
                     old1 = {"tokenID": token, "nonce": 0, "sign": sg, "balance": 0, "ay": ay, "ethAddr": from_eth}

@@ -717,7 +717,11 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
             Leaf old1;
             if (new_account) {
                 old1.token = token; old1.nonce = 0; old1.sign = u_bit(bjj, 255); old1.balance = u_zero();
-                old1.ay = u_low_bits(bjj, 254); old1.eth = from_eth;
+                // the circuit reads the key as a FIELD element: Bits2Num over the low 254 bits (src/lib/utils-bjj.circom:22-27), i.e. mod r --
+                // an invalid key such as 2^256 - 1 (reference test/rollup-main-L1.test.js:113-119) has 2^254 - 1 > r there
+                old1.ay = u_low_bits(bjj, 254);
+                while (u_cmp(old1.ay, u_p()) >= 0) old1.ay = u_sub(old1.ay, u_p());
+                old1.eth = from_eth;
             } else {
                 if (!db->has_leaf(from_idx)) throw Reject{"sender account " + std::to_string(from_idx) + " does not exist"};
                 old1 = db->leaf(from_idx);

@@ -6,8 +6,7 @@
 // Nothing is computed: the reference's JS packages are not on disk, so expected roots and hashes cannot be recorded; the
 // scripts are replayed in Python on this repository's batch builder, oracle and HIP path (tests/test_reference_scripts.py).
 // Run in the build container only:   node tests/golden/extract_reference_scripts.js > tests/golden/reference_scripts.json
-// Suites: test/rollup-tx.test.js:56-919, test/rollup-main.test.js:65-900 (withdraw / fee-tx / hash-inputs scripts are short and
-//         transcribed by hand in tests/test_reference_scripts.py).
+// Suites: test/rollup-tx.test.js:56-919, test/rollup-main.test.js:65-900 (the other eleven suites: extract_reference_suites.js).
 const Module = require("module");
 const path = require("path");
 const REF = "/root/reference/test";

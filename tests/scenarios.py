@@ -217,59 +217,6 @@ def reference_rollup_main_scripts():
     return (3, 16, 2, 2), idx, S
 
 
-def reference_l1_edge_scripts():
-    """The L1 edge cases of reference test/rollup-main-L1.test.js:88-519 (RollupMain(3, 16, 2, 2)): each entry is
-    (name, setup batches, [(tx, expected isAmountNullified, expected sender-balance delta or None)]); every edge transaction goes in a
-    batch of its own, the circuit must accept all of them (invalid L1 transactions are nullified, never rejected)."""
-    acc = [B.Account(i + 1) for i in range(3)]
-    rnd_eth = 0xD8Af0C5c6dEE7dCe32E59577675C026e1aDe4De5
-
-    def dep(a, token, amount):
-        return {"fromIdx": 0, "loadAmountF": B.fix2float(amount), "tokenID": token, "fromBjjCompressed": acc[a].bjj_compressed,
-                "fromEthAddr": acc[a].eth_addr, "toIdx": 0, "onChain": 1}
-
-    def tx(**kw):
-        d = {"fromIdx": 0, "loadAmountF": 0, "tokenID": 1, "amountF": 0, "fromBjjCompressed": 0, "fromEthAddr": acc[0].eth_addr, "toIdx": 0, "onChain": 1}
-        d.update(kw)
-        return d
-    S = []
-    ca = dict(fromBjjCompressed=acc[0].bjj_compressed)
-    S.append(("createAccount (:88)", [], [
-        (tx(**ca), 0, None), (tx(fromBjjCompressed=0x12345), 0, None), (tx(fromBjjCompressed=(1 << 256) - 1), 0, None)]))
-    S.append(("createAccountDeposit (:125)", [], [
-        (tx(loadAmountF=0, **ca), 0, None), (tx(loadAmountF=0xFFFF, **ca), 0, None)]))
-    base = dict(loadAmountF=500, fromBjjCompressed=acc[2].bjj_compressed, fromEthAddr=acc[2].eth_addr, toIdx=256, amountF=100)
-    S.append(("createAccountDepositTransfer (:158)", [[dep(0, 1, 1000), dep(1, 2, 1000)]], [
-        (tx(**dict(base, amountF=0)), 0, None),
-        (tx(**dict(base, amountF=0xFFFF)), 1, None),                          # not enough funds: amount nullified
-        (tx(**dict(base, loadAmountF=0xFFFF, amountF=0xFFFF)), 0, None),      # transfers all it loaded
-        (tx(**dict(base, toIdx=257)), 1, None)]))                              # receiver of another token: amount nullified
-    d = dict(fromIdx=256, loadAmountF=500)
-    S.append(("deposit (:219)", [[dep(0, 1, 1000), dep(1, 2, 1000)]], [
-        (tx(**dict(d, tokenID=2)), 0, 0),                                      # wrong token: loadAmount nullified, balance unchanged
-        (tx(**dict(d, fromEthAddr=rnd_eth)), 0, 500),                          # anybody may deposit
-        (tx(**dict(d, loadAmountF=0)), 0, 0)]))
-    dt = dict(fromIdx=256, loadAmountF=200, toIdx=258, amountF=100, userFee=184)
-    S.append(("depositTransfer (:273)", [[dep(0, 1, 1000), dep(1, 2, 1000)], [dep(2, 1, 1000)]], [
-        (tx(**dict(dt, tokenID=2)), 1, 0),                                     # load and amount nullified
-        (tx(**dict(dt, toIdx=257)), 1, 200),                                   # amount nullified, deposit kept
-        (tx(**dict(dt, fromEthAddr=acc[2].eth_addr)), 1, 200)]))
-    ft = dict(fromIdx=256, toIdx=258, amountF=B.fix2float(500))
-    S.append(("forceTransfer (:338)", [[dep(0, 1, 1000), dep(1, 2, 1000)], [dep(2, 1, 1000)]], [
-        (tx(**dict(ft, toIdx=257)), 1, 0),
-        (tx(**dict(ft, toIdx=257, tokenID=2)), 1, 0),
-        (tx(**dict(ft, fromEthAddr=acc[2].eth_addr)), 1, 0),
-        (tx(**dict(ft, amountF=0)), 0, 0),
-        (tx(**ft), 0, -500)]))
-    fe = dict(fromIdx=256, toIdx=1, amountF=B.fix2float(100))
-    S.append(("forceExit (:419)", [[dep(0, 1, 1000), dep(1, 2, 1000)]], [
-        (tx(**dict(fe, tokenID=2)), 1, 0),                                     # creates an exit leaf with balance 0
-        (tx(**dict(fe, fromEthAddr=acc[1].eth_addr)), 1, 0),
-        (tx(**dict(fe, amountF=0)), 0, 0),                                     # no exit leaf
-        (tx(**fe), 0, -100)]))
-    return (3, 16, 2, 2), S
-
-
 def config2_batch():
     """BASELINE config 2 at its literal shape: RollupTx(nLevels=8, maxFeeTx=16) -- the parameters of reference
     test/rollup-tx.test.js:20-23 are (16, 16); BASELINE.json asks for nLevels = 8, whose tree only has room for indices below

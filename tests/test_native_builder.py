@@ -129,8 +129,21 @@ def test_native_builder_on_the_scenario_batches(shadow):
     S.eddsa_kat_rollup_tx()
     S.config2_batch()
     S.reference_rollup_main_scripts()
-    S.reference_l1_edge_scripts()
     assert shadow.checked >= 7
+
+
+def test_native_builder_replays_the_recorded_l1_edge_suite(shadow):
+    """reference test/rollup-main-L1.test.js (seven scripts of L1 edge cases: invalid keys, float40 0xFFFF, nullified loads and amounts,
+    exits of balance 0) as recorded by tests/golden/extract_reference_suites.js: both builders, byte-identical inputs"""
+    import test_reference_suites as RS
+    n = 0
+    for case in RS.CASES:
+        if case["suite"] != "rollup-main-L1.test.js":
+            continue
+        ops = [op for op in case["ops"] if op["op"] in ("newState", "buildBatch", "addTx", "addToken", "addFeeIdx", "build", "consolidate")]
+        RS.SuiteReplay(None, None).play({"case": case["case"], "ops": ops})
+        n += 1
+    assert n == 7 and shadow.checked >= 20
 
 
 def test_native_builder_replays_every_recorded_reference_script(shadow):

@@ -333,8 +333,10 @@ def test_hip_verifies_upstream_eddsa_kat_and_rejects_tampering(hz):
 
 
 # ---- DecodeTx scenario scripts of the reference suite (test/decode-tx.test.js:151-269,451-494), literal replay ----------
-def _decode_tx_scenarios(make_ctx, fails):
-    """`make_ctx()` gives a DecodeTx(nLevels) context with run()/get(); `fails(ctx)` is True when run() reports a violated constraint."""
+def _decode_tx_signature_constant_and_chain_id(make_ctx, fails):
+    """(The scenario scripts of reference test/decode-tx.test.js are replayed from the machine recording: tests/test_reference_suites.py.)
+    What the suite does not exercise: the signature constant and the chain id are enforced on L2 transactions only
+    (reference src/decode-tx.circom:341-357)."""
     from circuits_amd import builder as B
     zero = {k: 0 for k in ("previousOnChain txCompressedData maxNumBatch amountF toEthAddr toBjjAy rqTxCompressedDataV2 rqToEthAddr rqToBjjAy "
                            "fromEthAddr loadAmountF globalChainID currentNumBatch onChain newAccount auxFromIdx auxToIdx inIdx").split()}
@@ -344,28 +346,6 @@ def _decode_tx_scenarios(make_ctx, fails):
         c = make_ctx()
         c.set_inputs(inp)
         return c, fails(c)
-
-    # L2 / L1 ordering (:151-206): only "previous L2, current L1" is rejected
-    base = dict(zero, txCompressedData=B.build_tx_compressed_data({"fromIdx": 1}, 0), maxNumBatch=3, currentNumBatch=3)
-    for prev, on, bad in ((0, 0, False), (0, 1, True), (1, 0, False), (1, 1, False)):
-        # an L1 tx with fromIdx != 0 must not set newAccount; fromIdx = 1 here so newAccount stays 0
-        _, f = run(dict(base, previousOnChain=prev, onChain=on))
-        assert f == bad, ("ordering", prev, on)
-    # incremental idx and newAccount (:208-268)
-    base = dict(zero, previousOnChain=1, txCompressedData=B.build_tx_compressed_data({}, 0), onChain=1, newAccount=1, auxFromIdx=3, inIdx=2, currentNumBatch=6)
-    c, f = run(base)
-    assert not f and c.get("main.outIdx") == 3
-    assert run(dict(base, inIdx=5))[1]
-    assert run(dict(base, inIdx=5, newAccount=0))[1]
-    c, f = run(dict(base, inIdx=5, onChain=0, newAccount=0))
-    assert not f and c.get("main.outIdx") == 5
-    # maxNumBatch vs currentNumBatch (:451-493)
-    base = dict(zero, txCompressedData=B.build_tx_compressed_data({"fromIdx": 1}, 0), maxNumBatch=42, currentNumBatch=30)
-    assert not run(base)[1]
-    assert not run(dict(base, currentNumBatch=42))[1]
-    assert run(dict(base, currentNumBatch=43))[1]
-    assert not run(dict(base, currentNumBatch=43, maxNumBatch=0))[1]
-    # signature constant and chain id are enforced on L2 only (src/decode-tx.circom:341-357)
     good = B.build_tx_compressed_data({"fromIdx": 1}, 5)
     assert not run(dict(zero, txCompressedData=good, globalChainID=5))[1]
     assert run(dict(zero, txCompressedData=good, globalChainID=6))[1]
@@ -373,15 +353,15 @@ def _decode_tx_scenarios(make_ctx, fails):
     assert not run(dict(zero, txCompressedData=good ^ 1, globalChainID=6, onChain=1, previousOnChain=1))[1]
 
 
-def test_oracle_decode_tx_reference_scenarios():
+def test_oracle_decode_tx_signature_constant_and_chain_id():
     class Ctx(_O):
         def run(self):
             self.failed = self.o.run() is not None
-    _decode_tx_scenarios(lambda: Ctx("decode-tx", nLevels=L), lambda c: (c.run(), c.failed)[1])
+    _decode_tx_signature_constant_and_chain_id(lambda: Ctx("decode-tx", nLevels=L), lambda c: (c.run(), c.failed)[1])
 
 
 @pytest.mark.gpu
-def test_hip_decode_tx_reference_scenarios(hz):
+def test_hip_decode_tx_signature_constant_and_chain_id(hz):
     from circuits_amd import ConstraintError
 
     def fails(c):
@@ -391,119 +371,7 @@ def test_hip_decode_tx_reference_scenarios(hz):
         except ConstraintError as e:
             assert "Constraint doesn't match" in str(e)
             return True
-    _decode_tx_scenarios(lambda: hz.ctx("decode-tx", nLevels=L), fails)
-
-
-# ---- RqTxVerifier scenario script of the reference suite (test/rq-tx-verifier.test.js:43-94), through a NOP RollupTx -------
-def _rq_scenarios(make_ctx, run):
-    """run(ctx) -> None or the failure text."""
-    def go(inp):
-        c = make_ctx()
-        c.set_inputs(inp)
-        return run(c)
-    assert go(_rtx_zero_input()) is None                      # empty rqTxData
-    bad = _rtx_zero_input()
-    bad["futureTxCompressedDataV2"] = [1, 0, 0]
-    bad["rqOffset"] = 1
-    msg = go(bad)
-    assert msg is not None and "1 != 0" in msg                # requested tx 1 does not match
-    inp = _rtx_zero_input()
-    for i in range(1, 8):                                      # every offset selects its slot (cumulative, as in the suite)
-        if i < 4:
-            for k in ("futureTxCompressedDataV2", "futureToEthAddr", "futureToBjjAy"):
-                inp[k] = list(inp[k]); inp[k][i - 1] = i
-        else:
-            pos = 3 - (i - 4)
-            for k in ("pastTxCompressedDataV2", "pastToEthAddr", "pastToBjjAy"):
-                inp[k] = list(inp[k]); inp[k][pos] = i
-        inp.update({"rqTxCompressedDataV2": i, "rqToEthAddr": i, "rqToBjjAy": i, "rqOffset": i})
-        assert go(inp) is None, i
-
-
-def test_oracle_rq_tx_verifier_reference_scenarios():
-    def run(c):
-        r = c.o.run()
-        return None if r is None else "Constraint doesn't match %d != %d (%s)" % (r[4], r[5], r[3])
-    _rq_scenarios(lambda: _O("rollup-tx", nLevels=L, maxFeeTx=F), run)
-
-
-@pytest.mark.gpu
-def test_hip_rq_tx_verifier_reference_scenarios(hz):
-    from circuits_amd import ConstraintError
-
-    def run(c):
-        try:
-            c.run()
-            return None
-        except ConstraintError as e:
-            return str(e)
-    _rq_scenarios(lambda: hz.ctx("rollup-tx", nLevels=L, maxFeeTx=F), run)
-
-
-# ---- BalanceUpdater vectors of the reference suite (test/balance-updater.test.js:31-190) through RollupTx ----------------
-# Reachable through RollupTxStates: standard L2, standard L1, nullified amount (L1, foreign ethAddr), L1 underflow, L2 underflow
-# error. (The suite's "nullifyLoadAmount = 1, nullifyAmount = 0, amount != 0" input cannot be produced by RollupTxStates:
-# a token mismatch nullifies the amount as well, src/rollup-tx-states.circom:307-313.)
-def _bu_input(old_sender, old_receiver, amount, load, fee_sel, on, eth_mismatch=False):
-    from circuits_amd import builder as B
-    inp = _rtx_zero_input()
-    inp.update({"fromIdx": 300, "toIdx": 301 if amount else 0, "amount": amount, "loadAmountF": B.fix2float(load), "userFee": fee_sel, "onChain": on,
-                "tokenID": 1, "tokenID1": 1, "tokenID2": 1, "balance1": old_sender, "balance2": old_receiver,
-                "fromEthAddr": 7, "ethAddr1": 8 if eth_mismatch else 7})
-    return inp
-
-
-def _bu_scenarios(make_ctx, failure_of):
-    from circuits_amd import builder as B
-    pre = "main.balanceUpdater."
-
-    def go(inp):
-        c = make_ctx()
-        c.set_inputs(inp)
-        msg = failure_of(c)
-        return c, msg
-    fee = B.compute_fee(50, 126)
-    c, _ = go(_bu_input(100, 200, 50, 0, 126, 0))                       # standard L2: sender 100 - 50 - fee, receiver 250
-    assert (c.get(pre + "effectiveAmount3"), c.get(pre + "effectiveLoadAmount2"), c.get(pre + "isAmountNullified")) == (50, 0, 0)
-    assert c.get(pre + "computeFee.feeOut") == fee if _has(c, pre + "computeFee.feeOut") else True
-    c, _ = go(_bu_input(100, 200, 0, 50, 200, 1))                       # standard L1 deposit: sender 150, no fee
-    assert (c.get(pre + "effectiveAmount3"), c.get(pre + "effectiveLoadAmount2"), c.get(pre + "isAmountNullified")) == (0, 50, 0)
-    assert c.get(pre + "effectiveAmountIsZero.out") == 1               # isP2Nop = 0
-    c, _ = go(_bu_input(100, 200, 500, 50, 200, 1, eth_mismatch=True))  # nullified amount: sender 150, receiver 200
-    assert (c.get(pre + "effectiveAmount3"), c.get(pre + "effectiveLoadAmount2"), c.get(pre + "isAmountNullified")) == (0, 50, 1)
-    assert c.get(pre + "effectiveAmountIsZero.out") == 0               # isP2Nop = 1: the receiver leaf is still processed
-    c, _ = go(_bu_input(100, 200, 110, 0, 200, 1))                      # L1 underflow: balances unchanged, amount nullified
-    assert (c.get(pre + "effectiveAmount2"), c.get(pre + "effectiveAmount3"), c.get(pre + "isAmountNullified")) == (110, 0, 1)
-    _, msg = go(_bu_input(100, 200, 98, 0, 200, 0))                     # L2 underflow (98 + fee > 100): rejected
-    assert msg is not None and "1 != 0" in msg and "balanceUpdater" in msg
-
-
-def _has(c, name):
-    try:
-        c.get(name)
-        return True
-    except KeyError:
-        return False
-
-
-def test_oracle_balance_updater_reference_vectors():
-    def failure_of(c):
-        r = c.o.run()
-        return None if r is None else "Constraint doesn't match %d != %d (%s)" % (r[4], r[5], r[3])
-    _bu_scenarios(lambda: _O("rollup-tx", nLevels=L, maxFeeTx=F), failure_of)
-
-
-@pytest.mark.gpu
-def test_hip_balance_updater_reference_vectors(hz):
-    from circuits_amd import ConstraintError
-
-    def failure_of(c):
-        try:
-            c.run()
-            return None
-        except ConstraintError as e:
-            return str(e)
-    _bu_scenarios(lambda: hz.ctx("rollup-tx", nLevels=L, maxFeeTx=F), failure_of)
+    _decode_tx_signature_constant_and_chain_id(lambda: hz.ctx("decode-tx", nLevels=L), fails)
 
 
 # ---- the scenario scripts of the reference's rollup-main suite, with the balances it asserts -------------------------------
@@ -545,49 +413,6 @@ def test_hip_replays_reference_rollup_main_scripts(hz):
         except ConstraintError as e:
             return str(e)
     _replay_rollup_main_scripts(lambda s: hz.ctx("rollup-main", nTx=s[0], nLevels=s[1], maxL1Tx=s[2], maxFeeTx=s[3]), run)
-
-
-def _replay_l1_edge_scripts(make_ctx, run):
-    from circuits_amd import builder as B
-    from scenarios import reference_l1_edge_scripts
-    shape, scripts = reference_l1_edge_scripts()
-    for name, setup, cases in scripts:
-        db = B.RollupDB(chain_id=1)
-        for txs in setup:
-            bb = db.build_batch(*shape)
-            for t in txs:
-                bb.add_tx(t)
-            bb.build()
-        for k, (t, nullified, delta) in enumerate(cases):
-            before = db.leaves[t["fromIdx"]]["balance"] if t["fromIdx"] else None
-            bb = db.build_batch(*shape)
-            bb.add_tx(dict(t))
-            bb.build()
-            c = make_ctx(shape)
-            c.set_inputs(bb.get_input())
-            assert run(c) is None, (name, k)
-            assert c.get("main.hashGlobalInputs") == bb.get_hash_inputs(), (name, k)
-            assert bb.tx_meta[0]["isAmountNullified"] == nullified, (name, k)
-            assert c.get("main.rollupTx[0].balanceUpdater.isAmountNullified") == nullified, (name, k)
-            if delta is not None:
-                assert db.leaves[t["fromIdx"]]["balance"] - before == delta, (name, k)
-
-
-def test_oracle_replays_reference_l1_edge_cases():
-    _replay_l1_edge_scripts(lambda s: _O("rollup-main", *s), lambda c: c.o.run())
-
-
-@pytest.mark.gpu
-def test_hip_replays_reference_l1_edge_cases(hz):
-    from circuits_amd import ConstraintError
-
-    def run(c):
-        try:
-            c.run()
-            return None
-        except ConstraintError as e:
-            return str(e)
-    _replay_l1_edge_scripts(lambda s: hz.ctx("rollup-main", nTx=s[0], nLevels=s[1], maxL1Tx=s[2], maxFeeTx=s[3]), run)
 
 
 # ---- reference test/rollup-tx.test.js pattern (`assertTxs`, test/helpers/helpers.js:139-145): every transaction of a built batch,

@@ -199,134 +199,4 @@ def test_hip_replays_reference_script(hz, case):
     Replay(lambda t, **kw: hz.ctx(t, **kw), _hip_run).play(case)
 
 
-# ---- test/withdraw.test.js:39-171 -----------------------------------------------------------------------------------------------
-def _withdraw_script():
-    """four deposits (token 0: 1000..4000), four L2 exits (100..400) in the next batch, one Withdraw per exit leaf; then the first
-    input again with balance = 2 (must fail in the SMT verifier with "1 != 0")"""
-    from circuits_amd import builder as B
-    NTX, NLEVELS = 5, 16   # the suite's own constants (test/withdraw.test.js:21-22)
-    db = B.RollupDB(chain_id=1)
-    acc = [B.Account(i + 1) for i in range(4)]
-    bb = db.build_batch(NTX, NLEVELS, NTX, 1)
-    for a, amount in zip(acc, (1000, 2000, 3000, 4000)):
-        bb.add_tx({"fromIdx": 0, "loadAmountF": B.fix2float(amount), "tokenID": 0, "fromBjjCompressed": a.bjj_compressed, "fromEthAddr": a.eth_addr, "toIdx": 0, "onChain": 1})
-    bb.build()
-    bb2 = db.build_batch(NTX, NLEVELS, NTX, 1)
-    for k, (a, amount) in enumerate(zip(acc, (100, 200, 300, 400))):
-        bb2.add_tx({"fromIdx": 256 + k, "toIdx": 1, "tokenID": 0, "amount": amount, "nonce": 0, "userFee": 0, "signer": a})
-    bb2.build()
-    ins = [B.withdraw_input(bb2, 256 + k, NLEVELS) for k in range(4)]
-    for k, (inp, _) in enumerate(ins):
-        assert inp["balance"] == (100, 200, 300, 400)[k] and inp["tokenID"] == 0 and inp["rootExit"] == bb2.new_exit_root
-    return NLEVELS, ins
-
-
-def _check_withdraw_script(make_ctx, run):
-    L, ins = _withdraw_script()
-    c = make_ctx("withdraw", nLevels=L, n_instances=4)
-    for k, (inp, _) in enumerate(ins):
-        c.set_inputs(inp, instance=k)
-    assert run(c) is None
-    for k, (_, exp) in enumerate(ins):
-        assert c.get("main.hashGlobalInputs", k) == exp
-    bad = dict(ins[0][0], balance=2)
-    c = make_ctx("withdraw", nLevels=L)
-    c.set_inputs(bad)
-    f = run(c)
-    assert f is not None and "Constraint doesn't match 1 != 0" in f
-
-
-def test_oracle_withdraw_script():
-    _check_withdraw_script(_oracle_ctx, _oracle_run)
-
-
-@pytest.mark.gpu
-def test_hip_withdraw_script(hz):
-    _check_withdraw_script(lambda t, **kw: hz.ctx(t, **kw), _hip_run)
-
-
-# ---- test/fee-tx.test.js:82-201 -------------------------------------------------------------------------------------------------
-def _fee_tx_script():
-    """six deposits (two users x tokens 1, 2; two fee accounts), two L2 transfers with fees 173 / 126 on 50, fee plan
-    [(1, 260), (2, 261)]: FeeTx on each fee slot, expected root = the next intermediate fee root / the batch's new state root"""
-    from circuits_amd import builder as B
-    L, maxTx, maxL1 = 16, 8, 6
-    db = B.RollupDB(chain_id=1)
-    a1, a2, f1, f2 = (B.Account(i + 1) for i in range(4))
-    bb = db.build_batch(maxTx, L, maxL1, 2)
-    for a, tok, amt in ((a1, 1, 1000), (a2, 1, 1000), (a1, 2, 1000), (a2, 2, 1000), (f1, 1, 0), (f2, 2, 0)):
-        bb.add_tx({"fromIdx": 0, "loadAmountF": B.fix2float(amt), "tokenID": tok, "fromBjjCompressed": a.bjj_compressed, "fromEthAddr": a.eth_addr, "toIdx": 0, "onChain": 1})
-    bb.build()
-    bb2 = db.build_batch(maxTx, L, maxL1, 2)
-    bb2.add_tx({"fromIdx": 256, "toIdx": 257, "tokenID": 1, "amount": 50, "nonce": 0, "userFee": 173, "signer": a1})
-    bb2.add_tx({"fromIdx": 258, "toIdx": 259, "tokenID": 2, "amount": 50, "nonce": 0, "userFee": 126, "signer": a1})
-    bb2.add_token(1); bb2.add_fee_idx(260)
-    bb2.add_token(2); bb2.add_fee_idx(261)
-    bb2.build()
-    g = bb2.get_input()
-    roots = [g["imInitStateRootFee"]] + list(g["imStateRootFee"]) + [bb2.new_state_root]
-    cases = []
-    for j in range(2):
-        cases.append(({"oldStateRoot": roots[j], "feePlanToken": g["feePlanTokens"][j], "feeIdx": g["feeIdxs"][j], "accFee": g["imFinalAccFee"][j],
-                       "tokenID": g["tokenID3"][j], "nonce": g["nonce3"][j], "sign": g["sign3"][j], "balance": g["balance3"][j], "ay": g["ay3"][j],
-                       "ethAddr": g["ethAddr3"][j], "siblings": g["siblings3"][j]}, roots[j + 1]))
-    assert [c[0]["accFee"] for c in cases] == [B.compute_fee(50, 173), B.compute_fee(50, 126)] and cases[0][0]["feeIdx"] == 260
-    # :181-201 a fee slot whose leaf holds another token
-    bad = {"oldStateRoot": 12345678901234567890, "feePlanToken": 1, "feeIdx": 257, "accFee": 99, "tokenID": 2, "nonce": 7, "sign": 0, "balance": 1000, "ay": 1234567,
-           "ethAddr": 7654321, "siblings": [0] * (L + 1)}
-    return L, cases, bad
-
-
-def _check_fee_tx_script(make_ctx, run):
-    L, cases, bad = _fee_tx_script()
-    c = make_ctx("fee-tx", nLevels=L, n_instances=len(cases))
-    for k, (inp, _) in enumerate(cases):
-        c.set_inputs(inp, instance=k)
-    assert run(c) is None
-    for k, (_, exp) in enumerate(cases):
-        assert c.get("main.newStateRoot", k) == exp
-    c = make_ctx("fee-tx", nLevels=L)
-    c.set_inputs(bad)
-    f = run(c)
-    assert f is not None and "Constraint doesn't match 1 != 0" in f
-
-
-def test_oracle_fee_tx_script():
-    _check_fee_tx_script(_oracle_ctx, _oracle_run)
-
-
-@pytest.mark.gpu
-def test_hip_fee_tx_script(hz):
-    _check_fee_tx_script(lambda t, **kw: hz.ctx(t, **kw), _hip_run)
-
-
-# ---- test/hash-inputs.test.js:42-149 ---------------------------------------------------------------------------------------------
-def _check_hash_inputs_scripts(make_ctx, run):
-    """:42-82 an empty batch (all inputs zero but the sizes), :84-149 a batch with L1 and L2 transactions and a fee slot: HashInputs as
-    main on the values RollupMain wires into it (src/rollup-main.circom:433-470), output = SHA-256 of the builder's own bit string"""
-    import hashlib
-    from scenarios import hash_inputs_case
-    from circuits_amd import builder as B
-    P = B.P
-    shape = (6, 16, 3, 2)
-    nTx, L, m1, F = shape
-    zero = {"oldLastIdx": 0, "newLastIdx": 0, "oldStateRoot": 0, "newStateRoot": 0, "newExitRoot": 0, "L1TxsFullData": [0] * (m1 * 624),
-            "L1L2TxsData": [0] * (nTx * (2 * L + 48)), "feeTxsData": [0] * F, "globalChainID": 0, "currentNumBatch": 0}
-    nbits = 2 * 48 + 3 * 256 + m1 * 624 + nTx * (2 * L + 48) + F * L + 16 + 32
-    assert nbits % 8 == 0
-    exp0 = int.from_bytes(hashlib.sha256(bytes(nbits // 8)).digest(), "big") % P
-    _, hin, exp1 = hash_inputs_case(shape)
-    for inp, exp in ((zero, exp0), (hin, exp1)):
-        c = make_ctx("hash-inputs", nTx=nTx, nLevels=L, maxL1Tx=m1, maxFeeTx=F)
-        c.set_inputs(inp)
-        assert run(c) is None
-        assert c.get("main.hashInputsOut") == exp
-
-
-def test_oracle_hash_inputs_scripts():
-    _check_hash_inputs_scripts(_oracle_ctx, _oracle_run)
-
-
-@pytest.mark.gpu
-def test_hip_hash_inputs_scripts(hz):
-    _check_hash_inputs_scripts(lambda t, **kw: hz.ctx(t, **kw), _hip_run)
+# (test/withdraw.test.js, test/fee-tx.test.js, test/hash-inputs.test.js and the other unit suites: recorded by machine as well, tests/test_reference_suites.py)
