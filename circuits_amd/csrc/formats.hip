@@ -284,8 +284,11 @@ extern "C" hz_status hz_symbols_write_sym(const hz_ctx* ctx, const char* path) {
 //   * the linear intermediates and linearly fed component inputs of the reference's own templates (a rule table transcribed from
 //     src/*.circom: e0, loadAmount, isAmount, underflowOk, p_fnc1, nonceChecker.enabled, newSt1Hash.nonce, Bits2Num outputs ...),
 //     as linear forms over stored signals or other derived ones.
+//   * the input of every circomlib IsZero (`<c>.in` beside stored `<c>.inv`, `<c>.out`; IsEqual and ForceEqualIfEnabled reach it as
+//     `<c>.isz.in`): inv <-- in != 0 ? 1/in : 0 determines it, in = inv == 0 ? 0 : 1/inv; and the input of every Num2Bits whose bits are
+//     stored as `<c>.out[k]`: the template's own constraint, in = sum of 2^k out[k].
 // A variable whose labels match neither a stored signal nor a rule stays unresolved and is reported as before.
-enum { DV_POSEIDON = 1, DV_LINEAR = 2 };
+enum { DV_POSEIDON = 1, DV_LINEAR = 2, DV_ISZERO_IN = 3 };
 using hzderived::PW_ARK_IN; using hzderived::PW_ARK_OUT; using hzderived::PW_MIX_IN; using hzderived::PW_MIX_OUT;
 struct DerivedVar {
     uint8_t kind = 0, t = 0, what = 0;
@@ -532,6 +535,32 @@ uint64_t resolve_name(const hz_ctx* ctx, hz_symmap* m, const std::string& name_i
         m->derived.push_back(d);
         return m->memo[name] = DERIVED_FLAG | (m->derived.size() - 1);
     }
+    if (name.size() > 3 && name.compare(name.size() - 3, 3, ".in") == 0) {
+        const std::string comp = name.substr(0, name.size() - 3);
+        uint64_t inv = 0, out = 0;
+        if (hz_symbol_lookup(ctx, (comp + ".inv").c_str(), &inv) && hz_symbol_lookup(ctx, (comp + ".out").c_str(), &out)) {   // IsZero
+            d = DerivedVar();
+            d.kind = DV_ISZERO_IN; d.first = inv;
+            m->derived.push_back(d);
+            return m->memo[name] = DERIVED_FLAG | (m->derived.size() - 1);
+        }
+        if (hz_symbol_lookup(ctx, (comp + ".out[0]").c_str(), &out)) {   // Num2Bits: in = sum 2^k out[k] over the stored bits
+            LinForm lf;
+            lf.c0 = hzh::f_zero();
+            F w = hzh::f_one();
+            for (int k = 0; k < 256; k++) {
+                uint64_t b;
+                if (!hz_symbol_lookup(ctx, (comp + ".out[" + std::to_string(k) + "]").c_str(), &b)) break;
+                lf.terms.push_back({w, b});
+                w = hzh::f_add(w, w);
+            }
+            d = DerivedVar();
+            d.kind = DV_LINEAR; d.lin = (uint32_t)m->lins.size();
+            m->lins.push_back(std::move(lf));
+            m->derived.push_back(d);
+            return m->memo[name] = DERIVED_FLAG | (m->derived.size() - 1);
+        }
+    }
     for (const LinRule& r : LIN_RULES) {
         // match the suffix from the end of the name; a # stands for one array index
         long long cap = -1;
@@ -589,6 +618,8 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
         if (d.kind == DV_POSEIDON) {
             if (blocks.emplace(d.first, d.t).second)
                 for (int j = 0; j < 3 * pos_nsbox(d.t); j++) want(d.first + (uint64_t)j * d.stride);
+        } else if (d.kind == DV_ISZERO_IN) {
+            want(d.first);
         } else {
             for (const auto& tm : m->lins[d.lin].terms) {
                 if (tm.second & DERIVED_FLAG) stack.push_back(tm.second & ~DERIVED_FLAG);
@@ -624,6 +655,8 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
             if (d.kind == DV_POSEIDON) {
                 const int R = pos_rounds(d.t);
                 v = traces[d.first][((size_t)d.what * R + d.round) * d.t + d.lane];
+            } else if (d.kind == DV_ISZERO_IN) {
+                v = hzh::f_inv(hzh::f_from_canon(vals.data() + 32 * slot[d.first]));   // inverse(0) = 0
             } else {
                 const LinForm& lf = m->lins[d.lin];
                 v = lf.c0;

@@ -178,6 +178,24 @@ def _declared_linear_names(o, stored):
     return names
 
 
+def _constraint_checked_names(stored):
+    """linear signals whose literal value needs the component's wiring, but which the TEMPLATE's own constraints pin: the input of
+    every circomlib IsZero (out <== -in*inv + 1 ; in*out === 0) and of every Num2Bits (sum of 2^k out[k] === in). -> {name: check(value, get)}"""
+    index = {nm: i for nm, i in stored}
+    checks = {}
+    for nm in index:
+        if nm.endswith(".inv") and nm[:-4] + ".out" in index and nm[:-4] + ".in" not in index:
+            c = nm[:-4]
+            checks[c + ".in"] = lambda v, get, c=c: get(c + ".out") == (1 - v * get(c + ".inv")) % P and v * get(c + ".out") % P == 0
+        if nm.endswith(".out[0]") and nm[:-7] + ".in" not in index and not nm[:-7].endswith(".isz"):
+            c = nm[:-7]
+            n = 0
+            while "%s.out[%d]" % (c, n) in index:
+                n += 1
+            checks[c + ".in"] = lambda v, get, c=c, n=n: v == sum(get("%s.out[%d]" % (c, k)) << k for k in range(n)) % P
+    return checks
+
+
 CASES = [("hash-state", {}, None), ("rollup-tx", dict(nLevels=8, maxFeeTx=16), "rtx"), ("rollup-main", dict(nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4), "main"),
          ("fee-tx", dict(nLevels=16), "fee"), ("decode-tx", dict(nLevels=16), "dec")]
 
@@ -224,7 +242,11 @@ def test_unreduced_sym_resolves_and_serves_the_linear_signals(hz, template, shap
     linear = _declared_linear_names(o, stored)
     assert len(linear) > (300 if template == "hash-state" else 1000)
     rng = random.Random(77)
-    entries = [(nm, own[idx]) for nm, idx in stored if nm != "main.one"] + sorted(linear.items())
+    checks = {nm: f for nm, f in _constraint_checked_names(stored).items() if nm not in linear}
+    assert len(checks) >= (0 if template == "hash-state" else 3)
+    n_lin = len(linear)
+    linear.update({nm: None for nm in checks})
+    entries = [(nm, own[idx]) for nm, idx in stored if nm != "main.one"] + sorted(linear.items(), key=lambda kv: kv[0])
     var_of = list(range(1, len(entries) + 1))
     rng.shuffle(var_of)
     lines = ["0,0,0,one"]
@@ -233,11 +255,15 @@ def test_unreduced_sym_resolves_and_serves_the_linear_signals(hz, template, shap
     rng.shuffle(lines)
     m = g.import_sym("\n".join(lines) + "\n")
     assert m.unresolved() == [], m.unresolved()[:5]
-    assert m.nvars() == len(entries) + 1 and 0 <= len(linear) - m.derived() <= 64   # (a few rules are wire-throughs onto a stored signal)
+    assert m.nvars() == len(entries) + 1 and 0 <= len(linear) - m.derived() <= 64 and n_lin > 0   # (a few rules are wire-throughs onto a stored signal)
     got = m.read()
     assert got[0] == 1
-    bad = [(nm, got[v], val) for (nm, val), v in zip(entries, var_of) if got[v] != val]
+    bad = [(nm, got[v], val) for (nm, val), v in zip(entries, var_of) if val is not None and got[v] != val]
     assert not bad, bad[:5]
+    own_of = dict(stored)
+    for (nm, val), v in zip(entries, var_of):   # pinned by the template's own constraints rather than by a literal value
+        if val is None:
+            assert checks[nm](got[v], lambda name: own[own_of[name]]), nm
     # a name no rule knows is still reported, by variable and label
     mb = g.import_sym("\n".join(lines) + "\n%d,%d,9,main.someComponent.notASignal\n" % (len(entries) + 1, len(entries) + 1))
     assert mb.unresolved() == [(len(entries) + 1, "main.someComponent.notASignal")]
