@@ -841,7 +841,9 @@ def main():
                        "witness_bytes_per_batch": witness_bytes, "step_latency_ms": round(single_ms, 3), "batch_build_s": round(t_build, 1),
                        "batch_builder": ({"kind": "native (libhz_host.so hzb_batch_build) + hz_poseidon_dag", "batches": len(all_seeds),
                                           "hashes": builder_stats["jobs"], "dag_segments": builder_stats["segments"], "device_ms": round(builder_stats["device_ms"], 1),
-                                          "walk_and_sign_s": round(builder_stats["walk_s"], 2), "evaluator_s": round(builder_stats["eval_s"], 2)}
+                                          "walk_and_sign_s": round(builder_stats["walk_s"], 2), "evaluator_s": round(builder_stats["eval_s"], 2),
+                                          "state_s": round(builder_stats["state_s"], 2), "batch_s": round(builder_stats["batch_s"], 2),
+                                          "ms_per_batch": round(1e3 * builder_stats["batch_s"] / max(1, len(all_seeds)), 1)}
                                          if builder_stats else {"kind": "python (circuits_amd/builder.py), host hashing, process pool", "batches": len(all_seeds)})},
             "roofline": {"bound": bound, "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_hbm": round(frac_hbm, 5), "frac_valu": round(frac_valu, 5) if frac_valu else None,

@@ -53,10 +53,17 @@ def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accoun
     from circuits_amd import native_builder as NB
     tables = NB.layout_tables(layout)
     hash_rows = lambda t, n, data: lib.poseidon_batch_bytes(t, n, data, device=device)   # noqa: E731
-    res, stats = [], {"jobs": 0, "segments": 0, "device_ms": 0.0, "walk_s": 0.0, "eval_s": 0.0}
+    import time
+    # state_s: the pre-populated state of each seed (DenseState, not part of building a batch); batch_s: everything from the first
+    # add_tx to the packed inputs (Python transaction recipe + hzb_batch_build: walk, signing, hashing, packing)
+    res, stats = [], {"jobs": 0, "segments": 0, "device_ms": 0.0, "walk_s": 0.0, "eval_s": 0.0, "state_s": 0.0, "batch_s": 0.0}
     for i, seed in enumerate(seeds):
+        t0 = time.perf_counter()
         b = base if base is not None else B.DenseState.build(n_accounts.bit_length() - 1, seed=seed, hash_rows=hash_rows)
+        t1 = time.perf_counter()
         bb, _, hgi = NB.synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, tables, seed=seed, device=device, base=b, out=out_addr + i * layout[0])
+        stats["state_s"] += t1 - t0
+        stats["batch_s"] += time.perf_counter() - t1
         for k, v in bb.stats().items():
             stats[k] += v
         res.append((None, hgi, n_tx - min(max_l1, n_tx)))

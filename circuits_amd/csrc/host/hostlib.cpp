@@ -9,6 +9,9 @@
 // device-form routines stay reachable for the self tests (hzb_fr_inv, hzb_poseidon_dev9: same digests).
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <thread>
 #include <vector>
 #include "../babyjub.h"
 #include "../poseidon.h"
@@ -117,27 +120,99 @@ extern "C" int hzb_bjj_add(const uint8_t* px, const uint8_t* py, const uint8_t* 
     return 0;
 }
 
-// k * Base8 (circomlib babyjub.js Base8 = 8 * Generator): 64 windows of 4 bits, table of j * 16^w * Base8 built at first use
-extern "C" int hzb_bjj_mul_base8(const uint8_t* k, uint8_t* ox, uint8_t* oy) {
-    static const uint64_t BX[4] = {0x2893f3f6bb957051ull, 0x2ab8d8010534e0b6ull, 0x4eacb2e09d6277c1ull, 0x0bb77a6ad63e739bull};
-    static const uint64_t BY[4] = {0x4b3c257a872d7d8bull, 0xfce0051fb9e13377ull, 0x25572e1cd16bf9edull, 0x25797203f7a0b249ull};
-    static const F a = hzh::f_from_u64(168700), d = hzh::f_from_u64(168696);
-    static const std::vector<HPt> table = [] {
-        std::vector<HPt> t(64 * 16);
-        HPt base = hpt_from_affine(hzh::f_from_words(BX), hzh::f_from_words(BY));
-        for (int w = 0; w < 64; w++) {
-            t[(size_t)w * 16] = HPt{hzh::f_zero(), hzh::f_one(), hzh::f_one(), hzh::f_zero()};
-            for (int j = 1; j < 16; j++) t[(size_t)w * 16 + j] = hpt_add(t[(size_t)w * 16 + j - 1], base, a, d);
-            base = hpt_add(t[(size_t)w * 16 + 15], base, a, d);
-        }
-        return t;
-    }();
-    HPt acc{hzh::f_zero(), hzh::f_one(), hzh::f_one(), hzh::f_zero()};
-    for (int w = 0; w < 64; w++) {
-        const int nib = (k[w >> 1] >> (4 * (w & 1))) & 15;
-        if (nib) acc = hpt_add(acc, table[(size_t)w * 16 + nib], a, d);
+// k * Base8 (circomlib babyjub.js Base8 = 8 * Generator): 32 windows of 8 bits over a table of AFFINE points j * 256^w * Base8
+// (X, Y, T = XY; Z = 1 saves a product per addition), built at first use and normalised with one inversion; the result stays
+// projective so that callers with many scalars pay one inversion for all of them (hzb_bjj_mul_base8_many)
+struct APt { F X, Y, T; };
+static HPt hpt_add_affine(const HPt& p, const APt& q, const F& a, const F& d) {   // madd-2008-hwcd
+    using namespace hzh;
+    const F A = f_mul(p.X, q.X), B = f_mul(p.Y, q.Y), C = f_mul(f_mul(p.T, q.T), d), D = p.Z;
+    const F E = f_sub(f_sub(f_mul(f_add(p.X, p.Y), f_add(q.X, q.Y)), A), B);
+    const F Fv = f_sub(D, C), G = f_add(D, C), H = f_sub(B, f_mul(a, A));
+    return HPt{f_mul(E, Fv), f_mul(G, H), f_mul(Fv, G), f_mul(E, H)};
+}
+// out[i] = 1 / in[i] for every i with one inversion (Montgomery's trick); zeros stay zero
+static void batch_inverse(const F* in, F* out, size_t n) {
+    using namespace hzh;
+    std::vector<F> pre(n);
+    F acc = f_one();
+    for (size_t i = 0; i < n; i++) {
+        pre[i] = acc;
+        if (!f_is_zero(in[i])) acc = f_mul(acc, in[i]);
     }
-    hpt_to_affine(acc, ox, oy);
+    F inv = f_inv(acc);
+    for (size_t i = n; i-- > 0;) {
+        if (f_is_zero(in[i])) { out[i] = f_zero(); continue; }
+        out[i] = f_mul(inv, pre[i]);
+        inv = f_mul(inv, in[i]);
+    }
+}
+static const F& bjj_a() { static const F v = hzh::f_from_u64(168700); return v; }
+static const F& bjj_d() { static const F v = hzh::f_from_u64(168696); return v; }
+static const std::vector<APt>& base8_table() {
+    static const std::vector<APt> table = [] {
+        static const uint64_t BX[4] = {0x2893f3f6bb957051ull, 0x2ab8d8010534e0b6ull, 0x4eacb2e09d6277c1ull, 0x0bb77a6ad63e739bull};
+        static const uint64_t BY[4] = {0x4b3c257a872d7d8bull, 0xfce0051fb9e13377ull, 0x25572e1cd16bf9edull, 0x25797203f7a0b249ull};
+        const F &a = bjj_a(), &d = bjj_d();
+        std::vector<HPt> t(32 * 256);
+        HPt base = hpt_from_affine(hzh::f_from_words(BX), hzh::f_from_words(BY));
+        for (int w = 0; w < 32; w++) {
+            t[(size_t)w * 256] = HPt{hzh::f_zero(), hzh::f_one(), hzh::f_one(), hzh::f_zero()};
+            for (int j = 1; j < 256; j++) t[(size_t)w * 256 + j] = hpt_add(t[(size_t)w * 256 + j - 1], base, a, d);
+            base = hpt_add(t[(size_t)w * 256 + 255], base, a, d);
+        }
+        std::vector<F> z(t.size()), zi(t.size());
+        for (size_t i = 0; i < t.size(); i++) z[i] = t[i].Z;
+        batch_inverse(z.data(), zi.data(), z.size());
+        std::vector<APt> out(t.size());
+        for (size_t i = 0; i < t.size(); i++) {
+            out[i].X = hzh::f_mul(t[i].X, zi[i]);
+            out[i].Y = hzh::f_mul(t[i].Y, zi[i]);
+            out[i].T = hzh::f_mul(out[i].X, out[i].Y);
+        }
+        return out;
+    }();
+    return table;
+}
+static HPt base8_mul_proj(const uint8_t* k) {
+    const std::vector<APt>& table = base8_table();
+    const F &a = bjj_a(), &d = bjj_d();
+    HPt acc{hzh::f_zero(), hzh::f_one(), hzh::f_one(), hzh::f_zero()};
+    for (int w = 0; w < 32; w++)
+        if (k[w]) acc = hpt_add_affine(acc, table[(size_t)w * 256 + k[w]], a, d);
+    return acc;
+}
+extern "C" int hzb_bjj_mul_base8(const uint8_t* k, uint8_t* ox, uint8_t* oy) {
+    hpt_to_affine(base8_mul_proj(k), ox, oy);
+    return 0;
+}
+// count scalars (32 bytes each, little endian) -> count affine points: the additions spread over `threads` host threads (0: as many
+// as the host offers, at most 8; a signature batch is a few thousand independent scalars), ONE inversion for all of them
+extern "C" int hzb_bjj_mul_base8_many(uint64_t count, const uint8_t* k, uint8_t* ox, uint8_t* oy, int32_t threads) {
+    if (!count) return 0;
+    base8_table();
+    std::vector<HPt> pts((size_t)count);
+    unsigned nt = threads > 0 ? (unsigned)threads : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("HZB_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    nt = (unsigned)std::min<uint64_t>(nt, (count + 63) / 64);
+    auto work = [&](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) pts[(size_t)i] = base8_mul_proj(k + 32 * i); };
+    if (nt <= 1) work(0, count);
+    else {
+        std::vector<std::thread> th;
+        const uint64_t per = (count + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; t++) {
+            const uint64_t lo = std::min<uint64_t>(count, per * t), hi = std::min<uint64_t>(count, lo + per);
+            if (lo < hi) th.emplace_back(work, lo, hi);
+        }
+        for (auto& x : th) x.join();
+    }
+    std::vector<F> z((size_t)count), zi((size_t)count);
+    for (size_t i = 0; i < (size_t)count; i++) z[i] = pts[i].Z;
+    batch_inverse(z.data(), zi.data(), (size_t)count);
+    for (size_t i = 0; i < (size_t)count; i++) {
+        hzh::f_to_canon(hzh::f_mul(pts[i].X, zi[i]), ox + 32 * i);
+        hzh::f_to_canon(hzh::f_mul(pts[i].Y, zi[i]), oy + 32 * i);
+    }
     return 0;
 }
 

@@ -30,6 +30,23 @@ class hzb_tx(ctypes.Structure):
                     "r8x", "r8y", "s", "signer_key")]
 
 
+_tx_dtype = None
+
+
+def tx_dtype():
+    """hzb_tx as a numpy record type (same field names, offsets and size): synthetic batches fill it by columns"""
+    global _tx_dtype
+    if _tx_dtype is None:
+        import numpy as np
+        fields = []
+        for name, ct in hzb_tx._fields_:
+            fields.append((name, "V32") if ctypes.sizeof(ct) == 32 else (name, {8: "<u8", 4: "<u4", 1: "u1"}[ctypes.sizeof(ct)]))
+        dt = np.dtype(fields, align=True)
+        assert dt.itemsize == ctypes.sizeof(hzb_tx) and all(dt.fields[n][1] == getattr(hzb_tx, n).offset for n, _ in hzb_tx._fields_)
+        _tx_dtype = dt
+    return _tx_dtype
+
+
 DAG_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p)
 
@@ -62,6 +79,7 @@ def host_lib():
         c.hzb_batch_create.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4
         c.hzb_batch_destroy.argtypes = [ctypes.c_void_p]
         c.hzb_batch_add_tx.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        c.hzb_batch_add_txs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         c.hzb_batch_add_token.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         c.hzb_batch_add_fee_idx.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         c.hzb_batch_build.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
@@ -84,6 +102,9 @@ class BuilderError(ValueError):
 def _check(st):
     if st:
         raise BuilderError(st, host_lib().hzb_last_error().decode())
+
+
+_ZERO32 = bytes(32)
 
 
 def _b32(v):
@@ -254,6 +275,11 @@ class NativeBatchBuilder:
         t = tx if isinstance(tx, hzb_tx) else tx_struct(tx)
         _check(self.c.hzb_batch_add_tx(self.h, ctypes.byref(t)))
 
+    def add_txs(self, arr):
+        """hzb_batch_add_txs: a numpy array of TX_DTYPE records (the hzb_tx layout), all in one call"""
+        assert arr.dtype == tx_dtype() and arr.flags.c_contiguous
+        _check(self.c.hzb_batch_add_txs(self.h, arr.ctypes.data, len(arr)))
+
     def add_token(self, token_id):
         _check(self.c.hzb_batch_add_token(self.h, token_id))
 
@@ -314,28 +340,38 @@ def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455
         if not (n_accounts >= 16 and n_accounts & (n_accounts - 1) == 0):
             raise ValueError("synthetic_batch_native: n_accounts must be a power of two >= 16 (DenseState)")
         base = B.DenseState.build(n_accounts.bit_length() - 1, seed=seed, first_idx=first_idx, n_keys=n_keys)
+    import numpy as np
     db = NativeRollupDB(chain_id=1, device=device, base=base)
     keys = [B.Account(seed * 1000 + i) for i in range(n_keys)]
     bkeys = base.keys()
     bb = db.build_batch(n_tx, n_levels, max_l1, max_fee)
     n_l1 = min(max_l1, n_tx)
-    for _ in range(n_l1):
-        a = keys[rng.randrange(n_keys)]
-        bb.add_tx({"fromIdx": 0, "loadAmountF": B.floor_fix2float(rng.randrange(1 << 96)), "tokenID": 1, "fromBjjCompressed": a.bjj_compressed,
-                   "fromEthAddr": a.eth_addr, "toIdx": 0, "onChain": 1})
+    # the transactions as columns of one hzb_tx array (one hzb_batch_add_txs call); 32-byte fields as rows of bytes
+    col = {k: [0] * n_tx for k in ("from_idx", "to_idx", "amount_f", "load_amount_f", "nonce", "user_fee", "on_chain", "flags")}
+    wide = {k: [_ZERO32] * n_tx for k in ("from_eth_addr", "from_bjj_compressed", "signer_key")}
+    l1_fields = [(a.bjj_compressed.to_bytes(32, "little"), a.eth_addr.to_bytes(32, "little")) for a in keys]
+    for i in range(n_l1):
+        q = rng.randrange(n_keys)
+        col["load_amount_f"][i] = B.floor_fix2float(rng.randrange(1 << 96))
+        col["on_chain"][i] = 1
+        wide["from_bjj_compressed"][i], wide["from_eth_addr"][i] = l1_fields[q]
     tmp = {}
     pick = lambda: base.first_idx + rng.randrange(base.N)   # noqa: E731
+    signer_bytes = [a.k.to_bytes(32, "little") for a in bkeys]
     for t in range(n_tx - n_l1):
+        i = n_l1 + t
         frm, to = pick(), pick()
         if frm in tmp:
             bal, nonce = tmp[frm]
         else:
             st = base.state(frm)
             bal, nonce = st["balance"], st["nonce"]
-        amount = B.float2fix(B.floor_fix2float(bal * 20 // 100))
+        amount_f = B.floor_fix2float(bal * 20 // 100)
+        amount = B.float2fix(amount_f)
         is_exit = t < exits
-        bb.add_tx({"fromIdx": frm, "toIdx": B.EXIT_IDX if is_exit else to, "amount": amount, "tokenID": 1, "userFee": 176, "nonce": nonce, "onChain": 0,
-                   "signer": bkeys[int(base.key_idx[frm - base.first_idx])]})
+        col["from_idx"][i], col["to_idx"][i], col["amount_f"][i], col["nonce"][i] = frm, (B.EXIT_IDX if is_exit else to), amount_f, nonce
+        col["user_fee"][i], col["flags"][i] = 176, HAS_NONCE | HAS_SIGNER
+        wide["signer_key"][i] = signer_bytes[int(base.key_idx[frm - base.first_idx])]
         nb = bal - amount - B.compute_fee(amount, 176)
         tmp[frm] = (nb, nonce + 1)
         if not is_exit and to != frm:
@@ -347,6 +383,13 @@ def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455
             tmp[to] = (tb + amount, tn)
         elif not is_exit and to == frm:
             tmp[frm] = (nb + amount, nonce + 1)
+    arr = np.zeros(n_tx, dtype=tx_dtype())
+    for k, v in col.items():
+        arr[k] = v
+    arr["token_id"] = 1
+    for k, v in wide.items():
+        arr[k] = np.frombuffer(b"".join(v), dtype="V32")
+    bb.add_txs(arr)
     bb.add_token(1)
     bb.add_fee_idx(pick())
     packed, hgi = bb.build(layout, out)

@@ -18,7 +18,9 @@ int hzb_poseidon(int n_in, const uint8_t* in, uint8_t* out);                    
 int hzb_poseidon_many(int n_in, uint64_t count, const uint8_t* in, uint8_t* out);        /* count independent hashes */
 int hzb_bjj_mul(const uint8_t* px, const uint8_t* py, const uint8_t* k, uint8_t* ox, uint8_t* oy);   /* BabyJubjub k * P, affine */
 int hzb_bjj_add(const uint8_t* px, const uint8_t* py, const uint8_t* qx, const uint8_t* qy, uint8_t* ox, uint8_t* oy);
-int hzb_bjj_mul_base8(const uint8_t* k, uint8_t* ox, uint8_t* oy);                         /* k * Base8: 4-bit fixed-base windows */
+int hzb_bjj_mul_base8(const uint8_t* k, uint8_t* ox, uint8_t* oy);                         /* k * Base8: 8-bit fixed-base windows */
+/* count scalars -> count affine points; threads = 0: up to 8 host threads (HZB_THREADS overrides), one inversion for all */
+int hzb_bjj_mul_base8_many(uint64_t count, const uint8_t* k, uint8_t* ox, uint8_t* oy, int32_t threads);
 int hzb_poseidon_dev9(int n_in, const uint8_t* in, uint8_t* out);                        /* self test: the device-form permutation on the host */
 int hzb_fr_inv(const uint8_t* x, uint8_t* safegcd_out, uint8_t* fermat_out);             /* self test */
 /* EdDSA-Poseidon signature of `msg` under the private scalar `key` (deterministic nonce: SHA-512(key || msg) mod l, as
@@ -79,6 +81,7 @@ uint32_t hzb_db_num_batch(const hzb_db* db);
 hzb_batch* hzb_batch_create(hzb_db* db, int32_t n_tx, int32_t n_levels, int32_t max_l1, int32_t max_fee);
 void hzb_batch_destroy(hzb_batch* b);
 int hzb_batch_add_tx(hzb_batch* b, const hzb_tx* tx);
+int hzb_batch_add_txs(hzb_batch* b, const hzb_tx* txs, uint64_t n);   /* n calls of hzb_batch_add_tx; stops at the first refusal */
 int hzb_batch_add_token(hzb_batch* b, uint32_t token_id);
 int hzb_batch_add_fee_idx(hzb_batch* b, uint64_t idx);
 /* Walks the batch, hashes it, and writes the circuit inputs in the packed bulk-upload format of hz_inputs_upload: signal i of the

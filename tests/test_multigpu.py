@@ -374,6 +374,7 @@ def test_bench_gpus8_eight_ranks_on_one_gpu(hz):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 8 and line["config"]["world_size"] == 8 and line["scaling"] == "weak" and line["value"] > 0
     sh = line["shard_tx"]
+    assert "error" not in sh, "%s\n%s" % (sh, r.stderr[-3000:])
     assert sh["scaling"] == "strong" and sh["transactions_per_rank"] == 5 and "all_gather" in sh["collective"] and "broadcast" in sh["collective"]
 
 

@@ -237,6 +237,69 @@ def test_native_signing_matches_the_python_signer():
             assert {"r8x": NB._int(r8x), "r8y": NB._int(r8y), "s": NB._int(s)} == want
 
 
+def test_batched_fixed_base_multiplication_matches_the_python_curve():
+    """hzb_bjj_mul_base8_many (8-bit windows over an affine table, host threads, one inversion for all the points) against
+    a plain affine double-and-add in Python integers -- the R8 of every signature of a batch goes through it; edge scalars: 0 (the identity, Z inverse of 1),
+    1, single-window values, all windows 255, and every thread count"""
+    import random
+    c = NB.host_lib()
+    c.hzb_bjj_mul_base8_many.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32]
+    rng = random.Random(0xB8)
+    ks = [0, 1, 255, 256, 255 << 248, (1 << 256) - 1, B.SUBORDER - 1, B.SUBORDER] + [rng.getrandbits(251) for _ in range(56)]
+    P, A, D = B.P, 168700, 168696
+
+    def add(p, q):   # twisted Edwards addition, affine (circomlib babyjub.js addPoint)
+        (x1, y1), (x2, y2) = p, q
+        m = D * x1 * x2 * y1 * y2 % P
+        return (x1 * y2 + y1 * x2) * pow(1 + m, P - 2, P) % P, (y1 * y2 - A * x1 * x2) * pow(1 - m, P - 2, P) % P
+
+    def mul(p, k):
+        acc = (0, 1)
+        while k:
+            if k & 1:
+                acc = add(acc, p)
+            p, k = add(p, p), k >> 1
+        return acc
+    want = [mul(tuple(B.BASE8), k) for k in ks]
+    kb = b"".join(k.to_bytes(32, "little") for k in ks)
+    for threads in (1, 3, 8, 0):
+        ox, oy = ctypes.create_string_buffer(32 * len(ks)), ctypes.create_string_buffer(32 * len(ks))
+        assert c.hzb_bjj_mul_base8_many(len(ks), kb, ox, oy, threads) == 0
+        got = [(int.from_bytes(ox.raw[32 * i:32 * i + 32], "little"), int.from_bytes(oy.raw[32 * i:32 * i + 32], "little")) for i in range(len(ks))]
+        assert got == [tuple(w) for w in want], threads
+    assert c.hzb_bjj_mul_base8_many(0, None, None, None, 0) == 0
+
+
+def test_add_txs_takes_the_records_a_loop_of_add_tx_would():
+    """hzb_batch_add_txs on a numpy array of tx_dtype() records == the same transactions through tx_struct / hzb_batch_add_tx, and
+    tx_dtype() has hzb_tx's field offsets (asserted when it is built)"""
+    import numpy as np
+    layout = make_layout(6, 8, 2)
+    a, b = B.Account(1), B.Account(2)
+    txs = [{"fromIdx": 0, "loadAmountF": 500, "tokenID": 1, "fromBjjCompressed": a.bjj_compressed, "fromEthAddr": a.eth_addr, "toIdx": 0, "onChain": 1},
+           {"fromIdx": 0, "loadAmountF": 300, "tokenID": 1, "fromBjjCompressed": b.bjj_compressed, "fromEthAddr": b.eth_addr, "toIdx": 0, "onChain": 1},
+           {"fromIdx": 256, "toIdx": 257, "amount": 20, "tokenID": 1, "userFee": 126, "nonce": 0, "onChain": 0, "signer": a}]
+    out = []
+    for bulk in (False, True):
+        db = NB.NativeRollupDB(chain_id=1)
+        bb = db.build_batch(6, 8, 3, 2)
+        if bulk:
+            arr = np.zeros(len(txs), dtype=NB.tx_dtype())
+            for i, t in enumerate(txs):
+                arr[i] = np.frombuffer(bytes(NB.tx_struct(t)), dtype=NB.tx_dtype())[0]
+            bb.add_txs(arr)
+        else:
+            for t in txs:
+                bb.add_tx(t)
+        bb.add_token(1)
+        out.append(bb.build(layout))
+    assert out[0] == out[1]
+    full = NB.NativeRollupDB(chain_id=1).build_batch(2, 8, 2, 2)
+    arr = np.zeros(3, dtype=NB.tx_dtype())
+    with pytest.raises(NB.BuilderError):
+        full.add_txs(arr)   # the third does not fit: refused like the third add_tx
+
+
 def test_native_builder_reports_what_the_circuit_would_reject():
     db = NB.NativeRollupDB()
     a = B.Account(1)

@@ -12,13 +12,13 @@ def sample(stop, out):
         time.sleep(0.25)
 def idle_power():
     out, stop = [], [False]
-    th = threading.Thread(target=sample, args=(stop, out)); th.start(); time.sleep(2.0); stop[0] = True; th.join()
+    th = threading.Thread(target=sample, args=(stop, out), daemon=True); th.start(); time.sleep(2.0); stop[0] = True; th.join()
     return sum(p for _, p in out) / max(1, len(out))
 idle = idle_power()
 print("idle package power %.0f W" % idle)
 for unit in ("valu", "mfma32", "mfma16"):
     out, stop = [], [False]
-    th = threading.Thread(target=sample, args=(stop, out)); th.start()
+    th = threading.Thread(target=sample, args=(stop, out), daemon=True); th.start()   # daemon: a failure below must not leave the sampler running
     t0 = time.time()
     r = subprocess.run([os.path.join(HERE, "mfmabench"), unit, "4"], stdout=subprocess.PIPE, text=True).stdout.strip()
     t1 = time.time(); stop[0] = True; th.join()

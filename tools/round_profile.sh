@@ -27,12 +27,14 @@ subprocess.run([sys.executable, "tools/gantt.py", sys.argv[1], str(lo), str(lo +
 PY
 fi
 if [ -z "$SKIP_MICRO" ]; then   # SKIP_MICRO=1: only what depends on the library (bench line, kernel stats, counters, Gantt)
-tools/microbench/instbench > $OUT/instbench.txt 2>&1
-tools/microbench/mulbench > $OUT/mulbench.txt 2>&1
-tools/microbench/invbench > $OUT/invbench.txt 2>&1
-python tools/microbench/run_mfmabench.py > $OUT/mfmabench.txt 2>&1
-( tools/microbench/storebench 1048576 256 5; tools/microbench/storebench 65536 2048 5 ) > $OUT/storebench.txt 2>&1
-( python tools/experiments/overlap_probe.py 3; python tools/experiments/overlap_probe.py 5 ) > $OUT/overlap_probe.txt 2>/dev/null
+# every probe under its own timeout: a missing binary or a stuck sampler must not eat the call (round 4 lost 50 GPU-minutes to one)
+for b in instbench mulbench invbench mfmabench storebench; do [ -x tools/microbench/$b ] || echo "tools/microbench/$b not built (tools/microbench/build.sh)"; done
+timeout 120 tools/microbench/instbench > $OUT/instbench.txt 2>&1
+timeout 300 tools/microbench/mulbench > $OUT/mulbench.txt 2>&1
+timeout 120 tools/microbench/invbench > $OUT/invbench.txt 2>&1
+timeout 180 python tools/microbench/run_mfmabench.py > $OUT/mfmabench.txt 2>&1
+( timeout 120 tools/microbench/storebench 1048576 256 5; timeout 120 tools/microbench/storebench 65536 2048 5 ) > $OUT/storebench.txt 2>&1
+( timeout 300 python tools/experiments/overlap_probe.py 3; timeout 300 python tools/experiments/overlap_probe.py 5 ) > $OUT/overlap_probe.txt 2>/dev/null
 timeout 120 python tools/experiments/power_probe.py 2>/dev/null | python -c "
 import sys,re
 for l in sys.stdin:
