@@ -284,7 +284,9 @@ def bench_sharded(args, L, D, packed, expected):
     stream = torch.cuda.Stream(device=D.local)
 
     def alloc(n):
-        return torch.zeros(n, dtype=torch.uint8, device="cuda")
+        t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()   # the fill runs on torch's current stream, the pass on its own non-blocking one: without this the zeros may land on top of the first export
+        return t
 
     def all_gather(recv, send):
         if D.world == 1 and not D.force:

@@ -24,7 +24,8 @@ def max_shard(ranges):
 class ShardedBatch:
     """Drives one sharded witness pass. `ctx` is a RollupMain Ctx (or any object with the same
     set_shard/enqueue/da_export/da_import/enqueue_tail[_chain]/sha_*/check methods); `alloc(nbytes)` returns a
-    device byte buffer object with .data_ptr(); `all_gather(out_list_buf, in_buf)` gathers equal
+    device byte buffer object with .data_ptr(), COMPLETE when it returns (a fill still queued on another stream would land on top of
+    the first export: the pass runs on the caller's stream only); `all_gather(out_list_buf, in_buf)` gathers equal
     sized buffers from all ranks into rank order; `broadcast(buf)` (optional) sends rank 0's buffer to
     every rank -- with it the SHA-256 block witness is split over the ranks, without it rank 0 writes all of it."""
 

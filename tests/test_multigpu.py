@@ -161,7 +161,9 @@ def test_sharded_batch_on_one_gpu_matches_oracle(hz):
     mailbox = {}
 
     def alloc(n):
-        return torch.zeros(n, dtype=torch.uint8, device="cuda")
+        t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()   # filled before any other stream touches it
+        return t
 
     sbs = []
     streams = [torch.cuda.Stream() for _ in range(world)]
@@ -219,7 +221,9 @@ def test_sharded_batch_split_sha_tail_matches_oracle(hz):
     mailbox, shabox = {}, {}
 
     def alloc(n):
-        return torch.zeros(n, dtype=torch.uint8, device="cuda")
+        t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()   # filled before any other stream touches it
+        return t
 
     sbs = []
     for r in range(world):
@@ -291,7 +295,9 @@ def test_config4_eight_shards_on_one_gpu_match_oracle(hz, config4):
     mailbox, shabox = {}, {}
 
     def alloc(n):
-        return torch.zeros(n, dtype=torch.uint8, device="cuda")
+        t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()   # filled before any other stream touches it
+        return t
     sbs = []
     for r in range(world):
         def all_gather(recv, send, r=r):
