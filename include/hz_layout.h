@@ -832,11 +832,12 @@ inline void lay_states(Section& s, const std::string& pre, StatesOff& o) {
     o.isP1Insert = s.add(pre + "isP1Insert");
     o.P1_fnc0 = s.add(pre + "P1_fnc0");
     o.P1_fnc1 = s.add(pre + "P1_fnc1");
-    o.mux1 = s.add(pre + "mux1.s10"); s.add(pre + "mux1.a10[0]"); s.add(pre + "mux1.a1[0]"); s.add(pre + "mux1.a0[0]");
+    // Mux2 wraps `component mux = MultiMux2(1)` (circomlib mux2.circom): the products are signals of that inner component
+    o.mux1 = s.add(pre + "mux1.mux.s10"); s.add(pre + "mux1.mux.a10[0]"); s.add(pre + "mux1.mux.a1[0]"); s.add(pre + "mux1.mux.a0[0]");
     o.isP2Insert = s.add(pre + "isP2Insert");
     o.P2_fnc0 = s.add(pre + "P2_fnc0");
     o.P2_fnc1 = s.add(pre + "P2_fnc1");
-    o.mux2 = s.add(pre + "mux2.s10"); s.add(pre + "mux2.a10[0]"); s.add(pre + "mux2.a1[0]"); s.add(pre + "mux2.a0[0]");
+    o.mux2 = s.add(pre + "mux2.mux.s10"); s.add(pre + "mux2.mux.a10[0]"); s.add(pre + "mux2.mux.a1[0]"); s.add(pre + "mux2.mux.a0[0]");
     o.verifySignEnabled = s.add(pre + "verifySignEnabled");
     o.tmpCheckToEthAddr = s.add(pre + "tmpCheckToEthAddr");
     o.tmpCheckToBjj = s.add(pre + "tmpCheckToBjj");
@@ -860,9 +861,11 @@ inline void lay_states(Section& s, const std::string& pre, StatesOff& o) {
 
 // circomlib mux4.circom MultiMux4(1) whose inputs are signals: every product term is a variable (MX4V_* order)
 inline uint32_t lay_mux4v(Section& s, const std::string& q) {
-    const uint32_t base = s.add(q + "s10"); s.add(q + "s20"); s.add(q + "s21"); s.add(q + "s210");
+    // Mux4 wraps `component mux = MultiMux4(1)` (circomlib mux4.circom): its products are `<q>mux.s10` ... `<q>mux.a0[0]`; the output
+    // keeps the outer label (`mux.out[0] ==> out`: one variable in a reducing compile, an alias otherwise -- formats.hip)
+    const uint32_t base = s.add(q + "mux.s10"); s.add(q + "mux.s20"); s.add(q + "mux.s21"); s.add(q + "mux.s210");
     static const char* an[14] = {"a3210", "a321", "a320", "a310", "a32", "a31", "a30", "a210", "a21", "a20", "a10", "a2", "a1", "a0"};
-    for (int i = 0; i < 14; i++) s.add(q + an[i] + "[0]");
+    for (int i = 0; i < 14; i++) s.add(q + "mux." + an[i] + "[0]");
     s.add(q + "out");
     return base;
 }
@@ -874,7 +877,7 @@ inline void lay_computefee(Section& s, const std::string& pre, ComputeFeeOff& o)
     o.mux1 = s.n_sigs;
     for (int i = 0; i < 16; i++) {
         const std::string q = pre + "mux256.mux[" + istr(i) + "].";
-        s.add(q + "s10"); s.add(q + "s20"); s.add(q + "s21"); s.add(q + "s210"); s.add(q + "out");
+        s.add(q + "mux.s10"); s.add(q + "mux.s20"); s.add(q + "mux.s21"); s.add(q + "mux.s210"); s.add(q + "out");
     }
     o.mux2 = lay_mux4v(s, pre + "mux256.mux[16].");
     o.feeOutNotShifted = s.add(pre + "feeOutNotShifted");

@@ -29,20 +29,23 @@ def templates(src):
 
 
 def declared(body):
-    signals, components = {}, {}
+    """signals {name: kind}, components {name: template}, and how many array dimensions each name was declared with"""
+    signals, components, sdims, cdims = {}, {}, {}, {}
     for m in re.finditer(r"\bsignal\s+(private\s+input|input|output)?\s*([^;]+);", body):
         kind = (m.group(1) or "intermediate").replace("private input", "input").strip()
         for part in m.group(2).split(","):
-            nm = re.match(r"\s*(\w+)", part)
+            nm = re.match(r"\s*(\w+)\s*((?:\[[^\]]*\]\s*)*)", part)
             if nm:
                 signals[nm.group(1)] = kind
+                sdims[nm.group(1)] = nm.group(2).count("[")
     for m in re.finditer(r"\bcomponent\s+(\w+)\s*((?:\[[^\]]*\]\s*)*)(?:=\s*(\w+)\s*\()?", body):
         name, tmpl = m.group(1), m.group(3)
         if tmpl is None:   # `component x[n];` assigned later: x[i] = Template(...)
             a = re.search(r"\b%s\s*(?:\[[^\]]*\]\s*)+=\s*(\w+)\s*\(" % re.escape(name), body)
             tmpl = a.group(1) if a else None
         components[name] = tmpl
-    return signals, components
+        cdims[name] = m.group(2).count("[")
+    return signals, components, sdims, cdims
 
 
 def classify(body, name):
@@ -75,8 +78,8 @@ def main():
             rel = os.path.relpath(os.path.join(root, f), ref)
             src = strip_comments(open(os.path.join(root, f)).read())
             for name, body in templates(src):
-                sig, comp = declared(body)
-                out[name] = {"file": rel, "signals": sig, "components": comp,
+                sig, comp, sdims, cdims = declared(body)
+                out[name] = {"file": rel, "signals": sig, "components": comp, "signal_dims": sdims, "component_dims": cdims,
                              "intermediates": {n: classify(body, n) for n, k in sig.items() if k == "intermediate"}}
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "circom_names.json")
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)

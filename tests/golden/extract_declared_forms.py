@@ -1,0 +1,705 @@
+#!/usr/bin/env python3
+"""Records, from the reference's own circuit sources, HOW every signal that is not a product or a hint is wired: a symbolic run of
+the templates under /root/reference/src (a small interpreter for the circom subset they use: templates, functions, var, for, if,
+signal / component arrays, <== ==> <-- --> ===) in which every signal is its own symbol, as in an unreduced compile. Output:
+tests/golden/declared_forms.json.gz -- per main template and shape
+
+    forms   {signal name: [constant, [[coefficient, signal name], ...]]}   every `x <== linear expression` of the sources, one level at a
+            time (the right-hand names are signals again: of the same template, inputs of a sub-component, outputs of one)
+    quads   [[A, B, C], ...]   every other constraint of the sources as A * B = C with A, B, C linear forms as above: the `x <== a * b + c`
+            lines and the `===` lines (A = B = 0 for a linear `===`)
+    bases   [signal name, ...]   signals defined by a product of signals or a `<--` hint, inputs of the main component, outputs of
+            circomlib components: values a witness has to hold (or, for a few circomlib outputs, derive: see MODELS)
+    declared [signal name, ...]  every signal the reference's templates declare below this main, all indices
+
+-- data, no source text. The sources of circomlib 0.5.2 are not in the reference repository; its templates are black boxes here:
+their inputs receive forms from the reference's wiring, their outputs are symbols. The few whose outputs are LINEAR in their inputs
+or wrap another component (Bits2Num, LessThan and its family, IsEqual, ForceEqualIfEnabled, NOT, Switcher, Mux1..Mux4) are stated in
+MODELS from circomlib's published sources.
+
+tests/test_declared_signals.py imports these names as a .sym, asks the library for every value and compares it with the form
+evaluated on the oracle's witness.
+
+    python tests/golden/extract_declared_forms.py [/root/reference]        (run in the build container; the reference does not travel)
+"""
+import gzip
+import json
+import os
+import re
+import sys
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+TOKEN = re.compile(r"\s*(?:(0x[0-9a-fA-F]+|\d+)|([A-Za-z_$][\w$]*)|(<==|==>|<--|-->|===|\*\*|<<|>>|<=|>=|==|!=|&&|\|\||\+\+|--|\+=|-=|\*=|/=|[-+*/\\%<>=!&|^~?:;,.(){}\[\]]))")
+
+
+def tokenize(src):
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r'include\s+"[^"]*"\s*;?', " ", src)
+    out, i = [], 0
+    while i < len(src):
+        m = TOKEN.match(src, i)
+        if not m:
+            if src[i:].strip() == "":
+                break
+            raise SyntaxError("cannot tokenize at %r" % src[i:i + 40])
+        i = m.end()
+        if m.group(1) is not None:
+            out.append(("num", int(m.group(1), 0)))
+        elif m.group(2) is not None:
+            out.append(("id", m.group(2)))
+        else:
+            out.append(("op", m.group(3)))
+    return out
+
+
+# ---- parser: statements and expressions as nested tuples -------------------------------------------------------------------------
+class Parser:
+    def __init__(self, toks):
+        self.t, self.i = toks, 0
+
+    def peek(self, k=0):
+        return self.t[self.i + k] if self.i + k < len(self.t) else ("eof", None)
+
+    def next(self):
+        tok = self.peek()
+        self.i += 1
+        return tok
+
+    def accept(self, kind, val=None):
+        tok = self.peek()
+        if tok[0] == kind and (val is None or tok[1] == val):
+            self.i += 1
+            return tok
+        return None
+
+    def expect(self, kind, val=None):
+        tok = self.accept(kind, val)
+        if tok is None:
+            raise SyntaxError("expected %s %r, found %r (token %d)" % (kind, val, self.peek(), self.i))
+        return tok
+
+    def program(self):
+        defs = {}
+        while self.peek()[0] != "eof":
+            kw = self.expect("id")[1]
+            if kw in ("template", "function"):
+                name = self.expect("id")[1]
+                self.expect("op", "(")
+                params = []
+                while not self.accept("op", ")"):
+                    params.append(self.expect("id")[1])
+                    self.accept("op", ",")
+                defs[name] = (kw, params, self.block())
+            elif kw == "component":   # component main = ...;
+                while not self.accept("op", ";"):
+                    self.next()
+            else:
+                raise SyntaxError("top level: %r" % kw)
+        return defs
+
+    def block(self):
+        self.expect("op", "{")
+        out = []
+        while not self.accept("op", "}"):
+            out.append(self.statement())
+        return ("block", out)
+
+    def body(self):
+        return self.block() if self.peek() == ("op", "{") else self.statement()
+
+    def dims(self):
+        d = []
+        while self.accept("op", "["):
+            d.append(self.expr())
+            self.expect("op", "]")
+        return d
+
+    def statement(self):
+        tok = self.peek()
+        if tok == ("op", "{"):
+            return self.block()
+        if tok[0] == "id" and tok[1] == "signal":
+            self.next()
+            kind = "intermediate"
+            if self.accept("id", "private"):
+                pass
+            if self.accept("id", "input"):
+                kind = "input"
+            elif self.accept("id", "output"):
+                kind = "output"
+            decls = []
+            while True:
+                decls.append((self.expect("id")[1], self.dims()))
+                if not self.accept("op", ","):
+                    break
+            self.expect("op", ";")
+            return ("signal", kind, decls)
+        if tok[0] == "id" and tok[1] == "component":
+            self.next()
+            name = self.expect("id")[1]
+            d = self.dims()
+            init = None
+            if self.accept("op", "="):
+                init = self.expr()
+            self.expect("op", ";")
+            return ("component", name, d, init)
+        if tok[0] == "id" and tok[1] == "var":
+            self.next()
+            decls = []
+            while True:
+                name = self.expect("id")[1]
+                d = self.dims()
+                init = self.expr() if self.accept("op", "=") else None
+                decls.append((name, d, init))
+                if not self.accept("op", ","):
+                    break
+            self.expect("op", ";")
+            return ("var", decls)
+        if tok[0] == "id" and tok[1] == "for":
+            self.next()
+            self.expect("op", "(")
+            init = self.statement()          # consumes its ';'
+            cond = self.expr()
+            self.expect("op", ";")
+            step = self.simple()
+            self.expect("op", ")")
+            return ("for", init, cond, step, self.body())
+        if tok[0] == "id" and tok[1] == "while":
+            self.next()
+            self.expect("op", "(")
+            cond = self.expr()
+            self.expect("op", ")")
+            return ("for", ("block", []), cond, ("block", []), self.body())
+        if tok[0] == "id" and tok[1] == "if":
+            self.next()
+            self.expect("op", "(")
+            cond = self.expr()
+            self.expect("op", ")")
+            then = self.body()
+            other = self.body() if self.accept("id", "else") else None
+            return ("if", cond, then, other)
+        if tok[0] == "id" and tok[1] == "return":
+            self.next()
+            e = self.expr()
+            self.expect("op", ";")
+            return ("return", e)
+        s = self.simple()
+        if self.peek() != ("op", "}"):   # (one statement of the sources ends its block without a semicolon)
+            self.expect("op", ";")
+        return s
+
+    def simple(self):
+        """assignment-like statement without its ';'"""
+        lhs = self.expr()
+        tok = self.peek()
+        if tok[0] == "op" and tok[1] in ("=", "+=", "-=", "*=", "/=", "<==", "<--", "==>", "-->", "==="):
+            self.next()
+            rhs = self.expr()
+            return ("assign", tok[1], lhs, rhs)
+        if tok[0] == "op" and tok[1] in ("++", "--"):
+            self.next()
+            return ("assign", "+=" if tok[1] == "++" else "-=", lhs, ("num", 1))
+        return ("expr", lhs)
+
+    LEVELS = [["||"], ["&&"], ["|"], ["^"], ["&"], ["==", "!="], ["<", ">", "<=", ">="], ["<<", ">>"], ["+", "-"], ["*", "/", "\\", "%"]]
+
+    def expr(self):
+        c = self.binary(0)
+        if self.accept("op", "?"):
+            a = self.expr()
+            self.expect("op", ":")
+            b = self.expr()
+            return ("cond", c, a, b)
+        return c
+
+    def binary(self, lv):
+        if lv == len(self.LEVELS):
+            return self.power()
+        left = self.binary(lv + 1)
+        while self.peek()[0] == "op" and self.peek()[1] in self.LEVELS[lv]:
+            op = self.next()[1]
+            left = ("bin", op, left, self.binary(lv + 1))
+        return left
+
+    def power(self):
+        base = self.unary()
+        if self.accept("op", "**"):
+            return ("bin", "**", base, self.power())
+        return base
+
+    def unary(self):
+        if self.accept("op", "-"):
+            return ("neg", self.unary())
+        if self.accept("op", "!"):
+            return ("not", self.unary())
+        if self.accept("op", "~"):
+            return ("inv", self.unary())
+        return self.postfix()
+
+    def postfix(self):
+        tok = self.next()
+        if tok[0] == "num":
+            node = ("num", tok[1])
+        elif tok == ("op", "("):
+            node = self.expr()
+            self.expect("op", ")")
+        elif tok == ("op", "["):
+            items = []
+            while not self.accept("op", "]"):
+                items.append(self.expr())
+                self.accept("op", ",")
+            node = ("list", items)
+        elif tok[0] == "id":
+            node = ("name", tok[1])
+            if self.accept("op", "("):
+                args = []
+                while not self.accept("op", ")"):
+                    args.append(self.expr())
+                    self.accept("op", ",")
+                node = ("call", tok[1], args)
+        else:
+            raise SyntaxError("unexpected %r" % (tok,))
+        while True:
+            if self.accept("op", "["):
+                node = ("index", node, self.expr())
+                self.expect("op", "]")
+            elif self.accept("op", "."):
+                node = ("member", node, self.expect("id")[1])
+            else:
+                return node
+
+
+# ---- symbolic values -----------------------------------------------------------------------------------------------------------------
+class Lin:
+    """constant + sum of coefficient * signal name, over the field"""
+    __slots__ = ("c", "t")
+
+    def __init__(self, c=0, t=None):
+        self.c, self.t = c % P, t or {}
+
+    @staticmethod
+    def of(v):
+        return v if isinstance(v, Lin) else Lin(int(v))
+
+    def is_const(self):
+        return not self.t
+
+    def add(self, o, sign=1):
+        t = dict(self.t)
+        for k, v in o.t.items():
+            nv = (t.get(k, 0) + sign * v) % P
+            if nv:
+                t[k] = nv
+            else:
+                t.pop(k, None)
+        return Lin(self.c + sign * o.c, t)
+
+    def scale(self, k):
+        k %= P
+        return Lin(self.c * k, {n: v * k % P for n, v in self.t.items() if v * k % P})
+
+
+class Quad:
+    """A*B + C with A, B, C linear: what one R1CS constraint can hold. a is None for anything else non-linear (shifts, masks and
+    comparisons of signals: they only occur on the right of `<--`)."""
+    __slots__ = ("a", "b", "c")
+
+    def __init__(self, a=None, b=None, c=None):
+        self.a, self.b, self.c = a, b, c or Lin()
+
+
+QUAD = Quad()
+
+
+class Comp:   # a component instance
+    def __init__(self, tmpl, path, args, known):
+        self.tmpl, self.path, self.args, self.known = tmpl, path, args, known
+        self.signals = {}   # reference templates: name -> dims (list of ints)
+
+
+class Return(Exception):
+    def __init__(self, v):
+        self.v = v
+
+
+def arr(dims, fill):
+    return fill() if not dims else [arr(dims[1:], fill) for _ in range(dims[0])]
+
+
+class Run:
+    def __init__(self, defs):
+        self.defs = defs
+        self.forms, self.bases, self.declared, self.quads = {}, set(), [], []
+
+    # -- black boxes: circomlib templates whose outputs are linear in their inputs or that wrap another component ----------------
+    def model(self, tmpl, path, args):
+        f = self.forms
+        one = lambda n: Lin(0, {n: 1})   # noqa: E731
+        if tmpl == "Bits2Num":
+            acc = Lin()
+            for i in range(args[0]):
+                acc = acc.add(one("%s.in[%d]" % (path, i)).scale(1 << i))
+            f[path + ".out"] = acc
+        elif tmpl == "LessThan":
+            n = args[0]
+            f[path + ".n2b.in"] = one(path + ".in[0]").add(Lin(1 << n)).add(one(path + ".in[1]"), -1)
+            f[path + ".out"] = Lin(1).add(one("%s.n2b.out[%d]" % (path, n)), -1)
+        elif tmpl in ("GreaterThan", "LessEqThan", "GreaterEqThan"):
+            a, b = (1, 0) if tmpl != "LessEqThan" else (0, 1)
+            f[path + ".lt.in[0]"] = one("%s.in[%d]" % (path, a))
+            f[path + ".lt.in[1]"] = one("%s.in[%d]" % (path, b)).add(Lin(0 if tmpl == "GreaterThan" else 1))
+            f[path + ".out"] = one(path + ".lt.out")
+            self.model("LessThan", path + ".lt", args)
+        elif tmpl in ("IsEqual", "ForceEqualIfEnabled"):
+            f[path + ".isz.in"] = one(path + ".in[1]").add(one(path + ".in[0]"), -1)
+            if tmpl == "IsEqual":
+                f[path + ".out"] = one(path + ".isz.out")
+        elif tmpl == "NOT":
+            f[path + ".out"] = Lin(1).add(one(path + ".in"), -1)
+        elif tmpl == "Switcher":
+            f[path + ".outL"] = one(path + ".aux").add(one(path + ".L"))
+            f[path + ".outR"] = one(path + ".R").add(one(path + ".aux"), -1)
+        elif tmpl in ("Mux1", "Mux2", "Mux3", "Mux4"):
+            k = int(tmpl[3])
+            for i in range(1 << k):
+                f["%s.mux.c[0][%d]" % (path, i)] = one("%s.c[%d]" % (path, i))
+            if k == 1:
+                f[path + ".mux.s"] = one(path + ".s")
+            else:
+                for i in range(k):
+                    f["%s.mux.s[%d]" % (path, i)] = one("%s.s[%d]" % (path, i))
+            f[path + ".out"] = one(path + ".mux.out[0]")
+            # MultiMux<k>(1): the term without a selector is a signal of its own, so is the difference that only the top selector
+            # multiplies; MultiMux2's output is the plain sum of its terms (mux2.circom / mux3.circom / mux4.circom)
+            m = path + ".mux."
+            f[m + "a[0]"] = one(m + "c[0][0]")
+            if k == 2:
+                f[m + "out[0]"] = one(m + "a10[0]").add(one(m + "a1[0]")).add(one(m + "a0[0]")).add(one(m + "a[0]"))
+            elif k >= 3:
+                top = 1 << (k - 1)
+                f["%sa%d[0]" % (m, k - 1)] = one("%sc[0][%d]" % (m, top)).add(one(m + "c[0][0]"), -1)
+
+    # -- templates ---------------------------------------------------------------------------------------------------------------------
+    def instantiate(self, tmpl, args, path):
+        if tmpl not in self.defs or self.defs[tmpl][0] != "template":
+            self.model(tmpl, path, args)
+            return Comp(tmpl, path, args, False)
+        _, params, body = self.defs[tmpl]
+        c = Comp(tmpl, path, args, True)
+        env = {"vars": dict(zip(params, args)), "comp": c, "components": {}, "is_main": path == "main"}
+        self.exec(body, env)
+        return c
+
+    def sig_names(self, base, dims):
+        if not dims:
+            return [base]
+        return [n for i in range(dims[0]) for n in self.sig_names("%s[%d]" % (base, i), dims[1:])]
+
+    def exec(self, node, env):
+        k = node[0]
+        if k == "block":
+            for s in node[1]:
+                self.exec(s, env)
+        elif k == "signal":
+            c = env["comp"]
+            for name, dims in node[2]:
+                d = [self.const(self.eval(x, env)) for x in dims]
+                c.signals[name] = d
+                names = self.sig_names("%s.%s" % (c.path, name), d)
+                self.declared += names
+                if node[1] == "input" and env["is_main"]:
+                    self.bases.update(names)
+        elif k == "component":
+            _, name, dims, init = node
+            d = [self.const(self.eval(x, env)) for x in dims]
+            env["components"][name] = arr(d, lambda: None) if d else None
+            if init is not None:
+                env["components"][name] = self.make(init, env, "%s.%s" % (env["comp"].path, name))
+        elif k == "var":
+            for name, dims, init in node[1]:
+                d = [self.const(self.eval(x, env)) for x in dims]
+                v = self.eval(init, env) if init is not None else (arr(d, lambda: 0) if d else 0)
+                env["vars"][name] = v
+        elif k == "for":
+            _, init, cond, step, body = node
+            self.exec(init, env)
+            while self.const(self.eval(cond, env)):
+                self.exec(body, env)
+                self.exec(step, env)
+        elif k == "if":
+            if self.const(self.eval(node[1], env)):
+                self.exec(node[2], env)
+            elif node[3] is not None:
+                self.exec(node[3], env)
+        elif k == "return":
+            raise Return(self.eval(node[1], env))
+        elif k == "expr":
+            self.eval(node[1], env)
+        elif k == "assign":
+            self.assign(node, env)
+        else:
+            raise NotImplementedError(k)
+
+    def make(self, init, env, path):
+        assert init[0] == "call", init
+        return self.instantiate(init[1], [self.const(self.eval(a, env)) for a in init[2]], path)
+
+    def const(self, v):
+        if isinstance(v, Lin):
+            assert v.is_const(), "a compile-time value depends on a signal"
+            v = v.c
+        return int(v)
+
+    # lvalues: ("var", name, idx) | ("sig", full name) | ("comp", name, idx)
+    def lvalue(self, node, env):
+        idx = []
+        while node[0] == "index":
+            idx.insert(0, self.const(self.eval(node[2], env)))
+            node = node[1]
+        if node[0] == "name":
+            nm = node[1]
+            if nm in env["comp"].signals:
+                return ("sig", "%s.%s%s" % (env["comp"].path, nm, "".join("[%d]" % i for i in idx)))
+            if nm in env["components"]:
+                return ("comp", nm, idx)
+            return ("var", nm, idx)
+        if node[0] == "member":
+            comp = self.eval_comp(node[1], env)
+            return ("sig", "%s.%s%s" % (comp.path, node[2], "".join("[%d]" % i for i in idx)))
+        raise NotImplementedError(node)
+
+    def eval_comp(self, node, env):
+        idx = []
+        while node[0] == "index":
+            idx.insert(0, self.const(self.eval(node[2], env)))
+            node = node[1]
+        assert node[0] == "name" and node[1] in env["components"], node
+        c = env["components"][node[1]]
+        for i in idx:
+            c = c[i]
+        assert isinstance(c, Comp), "component %s%s used before it is assigned" % (node[1], idx)
+        return c
+
+    def assign(self, node, env):
+        _, op, lhs, rhs = node
+        if op in ("==>", "-->"):
+            lhs, rhs, op = rhs, lhs, {"==>": "<==", "-->": "<--"}[op]
+        if op == "===":
+            d = self.binop("-", self.eval(lhs, env), self.eval(rhs, env))
+            self.constrain(d, "=== in %s" % env["comp"].path)
+            return
+        lv = self.lvalue(lhs, env)
+        if lv[0] == "comp":
+            _, name, idx = lv
+            path = "%s.%s%s" % (env["comp"].path, name, "".join("[%d]" % i for i in idx))
+            c = self.make(rhs, env, path)
+            if idx:
+                a = env["components"][name]
+                for i in idx[:-1]:
+                    a = a[i]
+                a[idx[-1]] = c
+            else:
+                env["components"][name] = c
+            return
+        if lv[0] == "sig":
+            name = lv[1]
+            if op == "<--":
+                self.bases.add(name)
+                return
+            assert op == "<==", (op, name)
+            v = self.eval(rhs, env)
+            if isinstance(v, Quad):
+                self.bases.add(name)
+                self.constrain(self.binop("-", v, Lin(0, {name: 1})), name)
+            else:
+                assert name not in self.forms, "%s assigned twice" % name
+                self.forms[name] = Lin.of(v)
+            return
+        _, name, idx = lv
+        v = self.eval(rhs, env)
+        if op != "=":
+            cur = env["vars"][name]
+            for i in idx:
+                cur = cur[i]
+            v = self.binop(op[0], cur, v)
+        if idx:
+            a = env["vars"][name]
+            for i in idx[:-1]:
+                a = a[i]
+            a[idx[-1]] = v
+        else:
+            env["vars"][name] = v
+
+    def constrain(self, d, where):
+        """d == 0: A*B + C = 0 is stored as A*B = -C"""
+        if isinstance(d, Quad):
+            assert d.a is not None, "a constraint that is not quadratic: %s" % where
+            self.quads.append((d.a, d.b, d.c.scale(-1)))
+        else:
+            d = Lin.of(d)
+            assert not d.is_const() or d.c == 0, "a constant constraint that does not hold: %s" % where
+            if not d.is_const():
+                self.quads.append((Lin(), Lin(), d))
+
+    def binop(self, op, a, b):
+        if isinstance(a, Quad) or isinstance(b, Quad):
+            qa, qb = isinstance(a, Quad), isinstance(b, Quad)
+            if (qa and a.a is None) or (qb and b.a is None) or (qa and qb):
+                return QUAD
+            q, o, left = (a, b, True) if qa else (b, a, False)
+            o = Lin.of(o)
+            if op == "+":
+                return Quad(q.a, q.b, q.c.add(o))
+            if op == "-":
+                return Quad(q.a, q.b, q.c.add(o, -1)) if left else Quad(q.a.scale(-1), q.b, o.add(q.c, -1))
+            if op == "*" and o.is_const():
+                return Quad(q.a.scale(o.c), q.b, q.c.scale(o.c))
+            return QUAD
+        if isinstance(a, Lin) or isinstance(b, Lin):
+            a, b = Lin.of(a), Lin.of(b)
+            if op == "+":
+                return a.add(b)
+            if op == "-":
+                return a.add(b, -1)
+            if op == "*":
+                if a.is_const():
+                    return b.scale(a.c)
+                if b.is_const():
+                    return a.scale(b.c)
+                return Quad(a, b, Lin())
+            if a.is_const() and b.is_const():
+                return self.binop(op, a.c, b.c)
+            return QUAD   # shifts / masks / comparisons of signals: only inside <-- hints
+        if op == "+":
+            return a + b
+        if op == "-":
+            return a - b
+        if op == "*":
+            return a * b
+        if op == "**":
+            return a ** b
+        if op == "/":
+            return a * pow(b, P - 2, P) % P
+        if op == "\\":
+            return a // b
+        if op == "%":
+            return a % b
+        if op == "<<":
+            return a << b
+        if op == ">>":
+            return a >> b
+        if op == "&":
+            return a & b
+        if op == "|":
+            return a | b
+        if op == "^":
+            return a ^ b
+        if op == "&&":
+            return int(bool(a) and bool(b))
+        if op == "||":
+            return int(bool(a) or bool(b))
+        return int({"==": a == b, "!=": a != b, "<": a < b, ">": a > b, "<=": a <= b, ">=": a >= b}[op])
+
+    def eval(self, node, env):
+        k = node[0]
+        if k == "num":
+            return node[1]
+        if k == "name":
+            nm = node[1]
+            if nm in env["vars"]:
+                return env["vars"][nm]
+            if nm in env["comp"].signals:
+                assert not env["comp"].signals[nm], "array signal %s used whole" % nm
+                return Lin(0, {"%s.%s" % (env["comp"].path, nm): 1})
+            raise NameError(nm)
+        if k == "index" or k == "member":
+            idx, base = [], node
+            while base[0] == "index":
+                idx.insert(0, self.const(self.eval(base[2], env)))
+                base = base[1]
+            if base[0] == "name" and base[1] in env["vars"]:
+                v = env["vars"][base[1]]
+                for i in idx:
+                    v = v[i]
+                return v
+            if base[0] == "call":
+                v = self.eval(base, env)
+                for i in idx:
+                    v = v[i]
+                return v
+            lv = self.lvalue(node, env)
+            assert lv[0] == "sig", lv
+            return Lin(0, {lv[1]: 1})
+        if k == "bin":
+            return self.binop(node[1], self.eval(node[2], env), self.eval(node[3], env))
+        if k == "neg":
+            v = self.eval(node[1], env)
+            if isinstance(v, Quad):
+                return QUAD if v.a is None else Quad(v.a.scale(-1), v.b, v.c.scale(-1))
+            return Lin.of(v).scale(-1) if isinstance(v, Lin) else -v
+        if k == "not":
+            return int(not self.const(self.eval(node[1], env)))
+        if k == "cond":
+            return self.eval(node[2] if self.const(self.eval(node[1], env)) else node[3], env)
+        if k == "list":
+            return [self.eval(x, env) for x in node[1]]
+        if k == "call":
+            kind, params, body = self.defs[node[1]]
+            assert kind == "function", node[1]
+            fenv = {"vars": dict(zip(params, [self.eval(a, env) for a in node[2]])), "comp": Comp("", "", [], True), "components": {}, "is_main": False}
+            try:
+                self.exec(body, fenv)
+            except Return as r:
+                return r.v
+            return 0
+        raise NotImplementedError(k)
+
+
+MAINS = [
+    ("rollup-main", "RollupMain", [6, 16, 3, 2]),
+    ("rollup-tx", "RollupTx", [16, 2]),
+    ("decode-tx", "DecodeTx", [16]),
+    ("fee-tx", "FeeTx", [16]),
+    ("hash-inputs", "HashInputs", [16, 6, 3, 2]),
+    ("withdraw", "Withdraw", [16]),
+    ("hash-state", "HashState", []),
+    ("decode-float", "DecodeFloat", []),
+    ("compute-fee", "ComputeFee", []),
+    ("fee-accumulator", "FeeAccumulator", [16]),
+    ("balance-updater", "BalanceUpdater", []),
+    ("rollup-tx-states", "RollupTxStates", []),
+    ("rq-tx-verifier", "RqTxVerifier", []),
+    ("mux256", "Mux256", []),
+    ("bits-compressed-2-ay-sign", "BitsCompressed2AySign", []),
+    ("ay-sign-2-ax", "AySign2Ax", []),
+]
+
+
+def main():
+    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    defs = {}
+    for root, _, files in os.walk(os.path.join(ref, "src")):
+        for f in sorted(files):
+            if f.endswith(".circom"):
+                defs.update(Parser(tokenize(open(os.path.join(root, f)).read())).program())
+    out = {}
+    for key, tmpl, args in MAINS:
+        r = Run(defs)
+        r.instantiate(tmpl, args, "main")
+        # outputs of black boxes and everything else a form refers to without defining it
+        used = {n for f in r.forms.values() for n in f.t} | {n for q in r.quads for f in q for n in f.t}
+        bases = sorted((r.bases | used) - set(r.forms))
+        lin = lambda f: [str(f.c), [[str(c), m] for m, c in sorted(f.t.items())]]   # noqa: E731
+        out[key] = {"template": tmpl, "args": args, "forms": {n: lin(f) for n, f in sorted(r.forms.items())},
+                    "quads": [[lin(a), lin(b), lin(c)] for a, b, c in r.quads], "bases": bases, "declared": r.declared}
+        print("%-28s %6d forms, %6d product / === constraints, %6d bases, %6d declared" % ("%s(%s)" % (tmpl, ",".join(map(str, args))), len(r.forms), len(r.quads), len(bases), len(r.declared)))
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "declared_forms.json.gz")
+    with gzip.GzipFile(dst, "wb", mtime=0) as g:
+        g.write(json.dumps(out, sort_keys=True, separators=(",", ":")).encode())
+    print("-> %s (%d bytes)" % (dst, os.path.getsize(dst)))
+
+
+if __name__ == "__main__":
+    main()

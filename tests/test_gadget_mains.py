@@ -201,7 +201,7 @@ def test_oracle_gadget_symbols_follow_the_reference_names():
     for n in ("main.oldStBalanceSender", "main.newStBalanceReceiver", "main.computeFee.feeOut", "main.n2bSender.out[192]", "main.effectiveAmountIsZero.out"):
         o.lookup(n)
     o = OracleCtx("rollup-tx-states")
-    for n in ("main.isP1Insert", "main.key2", "main.mux2.s10", "main.checkTokenID2.isz.inv", "main.nullifyAmount"):
+    for n in ("main.isP1Insert", "main.key2", "main.mux2.mux.s10", "main.checkTokenID2.isz.inv", "main.nullifyAmount"):
         o.lookup(n)
     o = OracleCtx("compute-fee")
     for n in ("main.feeSel", "main.applyFee", "main.mux256.mux[16].out", "main.bitsFeeOut[252]", "main.feeOut"):
@@ -213,7 +213,7 @@ def test_oracle_gadget_symbols_follow_the_reference_names():
     for n in ("main.futureToBjjAy[2]", "main.n2b.out[2]", "main.muxToEthAddr.mux.out[0]"):
         o.lookup(n)
     o = OracleCtx("mux256")
-    for n in ("main.s[7]", "main.in[255]", "main.mux[0].a3210[0]", "main.mux[16].out", "main.out"):
+    for n in ("main.s[7]", "main.in[255]", "main.mux[0].mux.a3210[0]", "main.mux[16].out", "main.out"):
         o.lookup(n)
     o = OracleCtx("ay-sign-2-ax")
     for n in ("main.ay", "main.ax", "main.n2bAy.out[253]", "main.b2Point.out[0]", "main.b2Point.babyCheck.x2", "main.b2Point.n2bX.out[0]"):

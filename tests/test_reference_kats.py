@@ -50,8 +50,8 @@ def _states_input(v):
 def _states_outputs(get):
     g = lambda n: get("main.states." + n)  # noqa: E731
     return {
-        "key1": (g("mux1.a10[0]") + g("mux1.a1[0]") + g("mux1.a0[0]")) % P,
-        "key2": (g("mux2.a10[0]") + g("mux2.a1[0]") + g("mux2.a0[0]")) % P,
+        "key1": (g("mux1.mux.a10[0]") + g("mux1.mux.a1[0]") + g("mux1.mux.a0[0]")) % P,
+        "key2": (g("mux2.mux.a10[0]") + g("mux2.mux.a1[0]") + g("mux2.mux.a0[0]")) % P,
         "P1_fnc0": g("P1_fnc0"), "P1_fnc1": g("P1_fnc1"), "P2_fnc0": g("P2_fnc0"), "P2_fnc1": g("P2_fnc1"),
         "isExit": g("checkIsExit.isz.out"), "verifySignEnabled": g("verifySignEnabled"), "nop": g("finalFromIdxIsZero.out"),
         "checkToEthAddr": g("checkToEthAddr"), "checkToBjj": g("checkToBjj"), "nullifyLoadAmount": g("nullifyLoadAmount"),

@@ -147,7 +147,7 @@ def test_oracle_missing_and_misshaped_inputs(small_batch):
 def test_symbol_names_follow_circom_convention():
     o = OracleCtx("rollup-main", 8, 16, 3, 4)
     for name in ("main.hashGlobalInputs", "hashGlobalInputs", "main.siblings1[3][5]", "main.decodeTx[0].n2bData.out[224]",
-                 "main.rollupTx[7].processor1.levels[16].oldProofHash.h.sigmaP[56].in4", "main.rollupTx[2].states.mux2.a10[0]",
+                 "main.rollupTx[7].processor1.levels[16].oldProofHash.h.sigmaP[56].in4", "main.rollupTx[2].states.mux2.mux.a10[0]",
                  "main.rollupTx[1].feeAccumulator.chain[3].mux.out", "main.feeTx[3].processor.newRoot", "main.imStateRootFee[2]",
                  "main.rollupTx[0].sigVerifier.mulAny.segments[1].bits[104].adder.lamda",
                  "main.hasherInputs.n2bFeeTxsData[3].out[47]"):
