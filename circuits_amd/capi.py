@@ -62,7 +62,7 @@ EXPORTS = [
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_witness_enqueue_tail_chain", "hz_sha_blocks", "hz_sha_state_bytes", "hz_sha_export", "hz_sha_expand",
-    "hz_symmap_create", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_symmap_derived", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
+    "hz_symmap_create", "hz_symmap_create_r1cs", "hz_symmap_solved", "hz_symmap_check_r1cs", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_symmap_derived", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
     "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym", "hz_fr_ops", "hz_poseidon_dag",
 ]
@@ -128,6 +128,10 @@ class Lib:
         c.hz_symbols_write_sym.argtypes = [vp, ctypes.c_char_p]
         c.hz_symbol_get.argtypes = [vp, u64, ctypes.POINTER(hz_symbol)]
         c.hz_symmap_create.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(vp)]
+        c.hz_symmap_create_r1cs.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(vp)]
+        c.hz_symmap_solved.argtypes = [vp]
+        c.hz_symmap_solved.restype = u64
+        c.hz_symmap_check_r1cs.argtypes = [vp, vp, ctypes.c_int32, ctypes.POINTER(u64), ctypes.POINTER(u64), u64]
         c.hz_symmap_destroy.argtypes = [vp]
         c.hz_symmap_destroy.restype = None
         c.hz_symmap_nvars.argtypes = [vp]
@@ -452,11 +456,15 @@ class Ctx:
     def get(self, name, instance=0):
         return self.read(self.lookup(name), 1, instance)[0]
 
-    def import_sym(self, text):
-        """circom .sym text -> SymMap (the witness in the compiler's variable order)"""
+    def import_sym(self, text, r1cs=None):
+        """circom .sym text (and, optionally, the .r1cs bytes of the same compile: hz_symmap_create_r1cs) -> SymMap (the witness in the
+        compiler's variable order)"""
         b = text.encode() if isinstance(text, str) else text
         h = ctypes.c_void_p()
-        self.L._check(self.L.c.hz_symmap_create(self.h, b, len(b), ctypes.byref(h)))
+        if r1cs is None:
+            self.L._check(self.L.c.hz_symmap_create(self.h, b, len(b), ctypes.byref(h)))
+        else:
+            self.L._check(self.L.c.hz_symmap_create_r1cs(self.h, b, len(b), bytes(r1cs), len(r1cs), ctypes.byref(h)))
         return SymMap(self, h)
 
     def symbol_count(self):
@@ -490,6 +498,16 @@ class SymMap:
             self.ctx.L.c.hz_symmap_unresolved(self.h, i, ctypes.byref(v), ctypes.byref(nm))
             out.append((v.value, nm.value.decode()))
         return out
+
+    def solved(self):
+        """variables defined by the linear constraints of the .r1cs (hz_symmap_create_r1cs)"""
+        return self.ctx.L.c.hz_symmap_solved(self.h)
+
+    def check_r1cs(self, instance=0, cap=16):
+        """(number of violated constraints, indices of the first `cap`) of the map's .r1cs on the witness it serves"""
+        n, first = ctypes.c_uint64(), (ctypes.c_uint64 * cap)()
+        self.ctx.L._check(self.ctx.L.c.hz_symmap_check_r1cs(self.ctx.h, self.h, instance, ctypes.byref(n), first, cap))
+        return n.value, list(first[:min(cap, n.value)])
 
     def derived(self):
         """variables evaluated from stored signals by a rule (linear signals an unreduced compile keeps)"""

@@ -1304,6 +1304,7 @@ extern "C" hz_status hz_symbol_get(const hz_ctx* cc, uint64_t i, hz_symbol* out)
     const uint32_t u = (uint32_t)(rel / b.count), k = (uint32_t)(rel % b.count);
     std::string nm = ssub(b.name, "{u}", istr(u));
     if (b.kind == BK_POSEIDON) nm += poseidon_signame(b.t, (int)k);
+    else if (b.kind == BK_SHA) nm += "[" + istr(k / SHA_BLOCK_SIGS) + "]" + sha_signame(k % SHA_BLOCK_SIGS);
     else if (b.count > 1 || b.scalar_array) nm += "[" + istr(b.idx0 + u * b.ustride + k) + "]";   // slices keep circom's index (Block::idx0)
     c->sym_name = nm;
     out->name = c->sym_name.c_str();

@@ -12,6 +12,7 @@
 // `./circuit input.json witness.json` (circuits_amd/csrc/cli/hz_witness.cpp).
 #include <stdio.h>
 #include <string.h>
+#include <array>
 #include <map>
 #include <new>
 #include <string>
@@ -310,7 +311,15 @@ struct hz_symmap {
     std::map<std::string, uint64_t> memo; // name -> resolved index (rules refer to each other)
     struct PosBlk { int t; uint64_t first, stride; };
     std::map<std::string, PosBlk> pos_memo;   // component prefix -> its Poseidon block (t = 0: not one)
-    uint64_t n_derived = 0;
+    uint64_t n_derived = 0, n_solved = 0;
+    // the constraint system of the same compile (hz_symmap_create_r1cs): linear combination q of constraint c, q = 0..2 for A, B, C,
+    // holds the terms [off[3c + q], off[3c + q + 1]) of (wire, index into the coefficient pool)
+    struct R1cs {
+        uint64_t n_wires = 0, n_cons = 0;
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> wire, coef;
+        std::vector<hzh::F> pool;
+    } r1cs;
 };
 
 namespace {
@@ -561,6 +570,20 @@ uint64_t resolve_name(const hz_ctx* ctx, hz_symmap* m, const std::string& name_i
             return m->memo[name] = DERIVED_FLAG | (m->derived.size() - 1);
         }
     }
+    if (name.back() == ']') {   // Sha256(n).out[k]: bit 31 - k % 32 of the last block's closing sum k / 32 (circomlib sha256.circom, sha256compression.circom)
+        const size_t lb = name.rfind('[');
+        if (lb > 4 && name.compare(lb - 4, 4, ".out") == 0) {
+            const std::string comp = name.substr(0, lb - 4) + ".sha256compression[";
+            const long long k = atoll(name.c_str() + lb + 1);
+            uint64_t x = 0;
+            if (k >= 0 && k < 256 && hz_symbol_lookup(ctx, (comp + "0].fsum[0].out[0]").c_str(), &x)) {
+                int last = 0;
+                while (hz_symbol_lookup(ctx, (comp + std::to_string(last + 1) + "].fsum[0].out[0]").c_str(), &x)) last++;
+                if (hz_symbol_lookup(ctx, (comp + std::to_string(last) + "].fsum[" + std::to_string(k / 32) + "].out[" + std::to_string(31 - k % 32) + "]").c_str(), &x))
+                    return m->memo[name] = x;
+            }
+        }
+    }
     for (const LinRule& r : LIN_RULES) {
         // match the suffix from the end of the name; a # stands for one array index
         long long cap = -1;
@@ -643,42 +666,199 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
         for (int j = 0; j < n; j++) memcpy(sbox.data() + 32 * (size_t)j, vals.data() + 32 * slot[b.first + (uint64_t)j * stride], 32);
         pos_trace(b.second, sbox.data(), traces[b.first]);
     }
+    // a derived variable only refers to derived variables created before it (a rule resolves its terms first, a solved variable is
+    // defined over known ones): ascending order evaluates every dependency first -- no recursion, chains may be long
     std::vector<F> dval(m->derived.size());
-    std::vector<uint8_t> done(m->derived.size(), 0);
-    // linear forms over other derived variables: evaluate in dependency order (depth is bounded by the resolver)
-    struct Eval {
-        const hz_symmap* m; std::vector<F>& dval; std::vector<uint8_t>& done; std::map<uint64_t, std::vector<F>>& traces; std::vector<uint8_t>& vals; std::map<uint64_t, size_t>& slot;
-        F get(uint64_t k) {
-            if (done[k]) return dval[k];
-            const DerivedVar& d = m->derived[k];
-            F v;
-            if (d.kind == DV_POSEIDON) {
-                const int R = pos_rounds(d.t);
-                v = traces[d.first][((size_t)d.what * R + d.round) * d.t + d.lane];
-            } else if (d.kind == DV_ISZERO_IN) {
-                v = hzh::f_inv(hzh::f_from_canon(vals.data() + 32 * slot[d.first]));   // inverse(0) = 0
-            } else {
-                const LinForm& lf = m->lins[d.lin];
-                v = lf.c0;
-                for (const auto& tm : lf.terms) {
-                    const F x = (tm.second & DERIVED_FLAG) ? get(tm.second & ~DERIVED_FLAG) : hzh::f_from_canon(vals.data() + 32 * slot[tm.second]);
-                    v = hzh::f_add(v, hzh::f_mul(tm.first, x));
-                }
+    for (size_t k = 0; k < m->derived.size(); k++) {
+        if (!seen[k]) continue;
+        const DerivedVar& d = m->derived[k];
+        F v;
+        if (d.kind == DV_POSEIDON) {
+            const int R = pos_rounds(d.t);
+            v = traces[d.first][((size_t)d.what * R + d.round) * d.t + d.lane];
+        } else if (d.kind == DV_ISZERO_IN) {
+            v = hzh::f_inv(hzh::f_from_canon(vals.data() + 32 * slot[d.first]));   // inverse(0) = 0
+        } else {
+            const LinForm& lf = m->lins[d.lin];
+            v = lf.c0;
+            for (const auto& tm : lf.terms) {
+                const F x = (tm.second & DERIVED_FLAG) ? dval[tm.second & ~DERIVED_FLAG] : hzh::f_from_canon(vals.data() + 32 * slot[tm.second]);
+                v = hzh::f_add(v, hzh::f_mul(tm.first, x));
             }
-            done[k] = 1;
-            return dval[k] = v;
         }
-    } ev{m, dval, done, traces, vals, slot};
+        dval[k] = v;
+    }
     for (uint64_t i = 0; i < count; i++) {
-        if (index[i] & DERIVED_FLAG) hzh::f_to_canon(ev.get(index[i] & ~DERIVED_FLAG), out + 32 * i);
+        if (index[i] & DERIVED_FLAG) hzh::f_to_canon(dval[index[i] & ~DERIVED_FLAG], out + 32 * i);
         else memcpy(out + 32 * i, vals.data() + 32 * slot[index[i]], 32);
     }
     return HZ_OK;
 }
 }  // namespace
 
+namespace {
+// ---- .r1cs (iden3 binary format, version 1) ----------------------------------------------------------------------------------------------
+// "r1cs", version, number of sections; per section: type u32, size u64. Type 1 = header (field size, prime, nWires, nPubOut, nPubIn,
+// nPrvIn, nLabels u64, nConstraints), type 2 = constraints (per constraint three linear combinations A, B, C: count, then count x
+// (wire u32, coefficient field-size bytes little endian)), type 3 = wire -> label map (not needed: circom's wire w IS variable w of
+// the .sym). All little endian.
+struct Rd {
+    const uint8_t* p; const uint8_t* e;
+    bool u32(uint32_t& v) { if (e - p < 4) return false; memcpy(&v, p, 4); p += 4; return true; }
+    bool u64(uint64_t& v) { if (e - p < 8) return false; memcpy(&v, p, 8); p += 8; return true; }
+};
+hz_status parse_r1cs(const uint8_t* data, size_t len, hz_symmap::R1cs& r) {
+    static const uint8_t PRIME[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
+                                      0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+    Rd rd{data, data + len};
+    uint32_t ver = 0, nsec = 0;
+    if (len < 12 || memcmp(data, "r1cs", 4) != 0) return set_err(HZ_ERR_INPUT, ".r1cs: not an r1cs file (magic)");
+    rd.p += 4;
+    if (!rd.u32(ver) || !rd.u32(nsec) || ver != 1) return set_err(HZ_ERR_INPUT, ".r1cs: version %u is not supported (1 is)", ver);
+    const uint8_t* hdr = nullptr; const uint8_t* cons = nullptr;
+    uint64_t hdr_len = 0, cons_len = 0;
+    for (uint32_t i = 0; i < nsec; i++) {
+        uint32_t type = 0; uint64_t size = 0;
+        if (!rd.u32(type) || !rd.u64(size) || size > (uint64_t)(rd.e - rd.p)) return set_err(HZ_ERR_INPUT, ".r1cs: section %u runs past the end of the file", i);
+        if (type == 1) { hdr = rd.p; hdr_len = size; }
+        if (type == 2) { cons = rd.p; cons_len = size; }
+        rd.p += size;
+    }
+    if (!hdr || !cons) return set_err(HZ_ERR_INPUT, ".r1cs: header or constraint section missing");
+    Rd h{hdr, hdr + hdr_len};
+    uint32_t fs = 0, nw = 0, x = 0, nc = 0; uint64_t nl = 0;
+    if (!h.u32(fs) || fs != 32 || h.e - h.p < 32 || memcmp(h.p, PRIME, 32) != 0) return set_err(HZ_ERR_INPUT, ".r1cs: the field is not BN254's scalar field");
+    h.p += 32;
+    if (!h.u32(nw) || !h.u32(x) || !h.u32(x) || !h.u32(x) || !h.u64(nl) || !h.u32(nc)) return set_err(HZ_ERR_INPUT, ".r1cs: short header");
+    // every term takes 36 bytes and every combination 4: the section's size bounds what may be allocated
+    if ((uint64_t)nc * 12 > cons_len) return set_err(HZ_ERR_INPUT, ".r1cs: %u constraints do not fit a section of %llu bytes", nc, (unsigned long long)cons_len);
+    r.n_wires = nw; r.n_cons = nc;
+    r.off.assign(1, 0);
+    r.off.reserve((size_t)nc * 3 + 1);
+    r.wire.reserve((size_t)(cons_len / 36)); r.coef.reserve((size_t)(cons_len / 36));
+    std::map<std::array<uint64_t, 4>, uint32_t> ids;
+    Rd c{cons, cons + cons_len};
+    for (uint64_t k = 0; k < (uint64_t)nc * 3; k++) {
+        uint32_t n = 0;
+        if (!c.u32(n) || (uint64_t)n * 36 > (uint64_t)(c.e - c.p)) return set_err(HZ_ERR_INPUT, ".r1cs: constraint %llu runs past its section", (unsigned long long)(k / 3));
+        for (uint32_t t = 0; t < n; t++) {
+            uint32_t w = 0;
+            c.u32(w);
+            if (w >= nw) return set_err(HZ_ERR_INPUT, ".r1cs: constraint %llu names wire %u of %u", (unsigned long long)(k / 3), w, nw);
+            std::array<uint64_t, 4> key;
+            memcpy(key.data(), c.p, 32);
+            auto it = ids.find(key);
+            if (it == ids.end()) {
+                if (key[3] >= 0x30644e72e131a029ull + 1) return set_err(HZ_ERR_INPUT, ".r1cs: constraint %llu has a coefficient that is not reduced", (unsigned long long)(k / 3));
+                it = ids.emplace(key, (uint32_t)r.pool.size()).first;
+                r.pool.push_back(hzh::f_from_canon(c.p));
+            }
+            c.p += 32;
+            r.wire.push_back(w); r.coef.push_back(it->second);
+        }
+        r.off.push_back(r.wire.size());
+    }
+    return HZ_OK;
+}
+// Variables no name resolved, solved from the circuit's own LINEAR constraints: (A.w)(B.w) = C.w is linear when A or B holds nothing
+// but the constant wire (circom writes `x <== linear` as 0 * 0 = linear - x). A linear constraint with exactly ONE unknown variable
+// defines it over known ones; every variable so defined may complete another constraint. This is how an unreduced compile's
+// wire-through signals -- component inputs, aliases of outputs, Bits2Num sums, comparators' differences, whatever the circuit and
+// the library version declare -- get their values without a rule that knows their names.
+void solve_linear(hz_symmap* m) {
+    const hz_symmap::R1cs& r = m->r1cs;
+    if (m->index.size() < r.n_wires) m->index.resize((size_t)r.n_wires, ~0ull);
+    const size_t nv = m->index.size();
+    size_t n_unknown = 0;
+    for (size_t v = 0; v < nv; v++) n_unknown += m->index[v] == ~0ull;
+    if (!n_unknown) return;
+    auto only_one = [&](uint64_t c, int q, F& k0) {   // combination q of constraint c holds the constant wire alone (or nothing)
+        k0 = hzh::f_zero();
+        for (uint64_t t = r.off[3 * c + q]; t < r.off[3 * c + q + 1]; t++) {
+            if (r.wire[t] != 0) return false;
+            k0 = hzh::f_add(k0, r.pool[r.coef[t]]);
+        }
+        return true;
+    };
+    // the linear constraints that mention an unknown variable, as merged term lists  sum k_i w_i = 0
+    struct LinCon { std::vector<std::pair<uint32_t, F>> t; uint32_t unknown = 0; };
+    std::vector<LinCon> lc;
+    std::vector<std::vector<uint32_t>> uses(nv);   // unknown variable -> constraints of `lc`
+    for (uint64_t c = 0; c < r.n_cons; c++) {
+        F ka, kb;
+        const bool la = only_one(c, 0, ka), lb = only_one(c, 1, kb);
+        if (!la && !lb) continue;
+        bool any = false;
+        for (int q = 0; q < 3 && !any; q++)
+            for (uint64_t t = r.off[3 * c + q]; t < r.off[3 * c + q + 1] && !any; t++) any = m->index[r.wire[t]] == ~0ull && r.wire[t] != 0;
+        if (!any) continue;
+        std::map<uint32_t, F> acc;
+        auto add = [&](int q, const F& scale) {
+            for (uint64_t t = r.off[3 * c + q]; t < r.off[3 * c + q + 1]; t++) {
+                F& a = acc.emplace(r.wire[t], hzh::f_zero()).first->second;
+                a = hzh::f_add(a, hzh::f_mul(scale, r.pool[r.coef[t]]));
+            }
+        };
+        if (la) add(1, ka); else add(0, kb);     // ka * B  (or kb * A) ...
+        if (la && lb) { /* a constant times a constant */ acc.clear(); F& a = acc.emplace(0u, hzh::f_zero()).first->second; a = hzh::f_mul(ka, kb); }
+        add(2, f_neg(hzh::f_one()));             // ... - C
+        LinCon con;
+        for (const auto& kv : acc)
+            if (!hzh::f_is_zero(kv.second)) {
+                con.t.push_back(kv);
+                if (kv.first != 0 && m->index[kv.first] == ~0ull) con.unknown++;
+            }
+        if (!con.unknown) continue;
+        for (const auto& kv : con.t)
+            if (kv.first != 0 && m->index[kv.first] == ~0ull) uses[kv.first].push_back((uint32_t)lc.size());
+        lc.push_back(std::move(con));
+    }
+    std::vector<uint32_t> work;
+    for (uint32_t i = 0; i < lc.size(); i++)
+        if (lc[i].unknown == 1) work.push_back(i);
+    while (!work.empty()) {
+        const uint32_t i = work.back();
+        work.pop_back();
+        LinCon& con = lc[i];
+        if (con.unknown != 1) continue;
+        uint32_t u = 0; F ku = hzh::f_zero();
+        for (const auto& kv : con.t)
+            if (kv.first != 0 && m->index[kv.first] == ~0ull) { u = kv.first; ku = kv.second; }
+        const F s = f_neg(hzh::f_inv(ku));       // w_u = -(1 / k_u) * (the rest)
+        LinForm lf;
+        lf.c0 = hzh::f_zero();
+        for (const auto& kv : con.t) {
+            if (kv.first == u) continue;
+            if (kv.first == 0) lf.c0 = hzh::f_add(lf.c0, hzh::f_mul(s, kv.second));
+            else lf.terms.push_back({hzh::f_mul(s, kv.second), m->index[kv.first]});
+        }
+        if (lf.terms.size() == 1 && hzh::f_is_zero(lf.c0) && hzh::f_eq(lf.terms[0].first, hzh::f_one())) {
+            m->index[u] = lf.terms[0].second;    // a plain wire: the same signal under another variable
+        } else {
+            DerivedVar d;
+            d.kind = DV_LINEAR; d.lin = (uint32_t)m->lins.size();
+            m->lins.push_back(std::move(lf));
+            m->derived.push_back(d);
+            m->index[u] = DERIVED_FLAG | (m->derived.size() - 1);
+        }
+        m->n_solved++;
+        for (uint32_t j : uses[u])
+            if (lc[j].unknown && --lc[j].unknown == 1) work.push_back(j);
+    }
+}
+hz_status symmap_build(const hz_ctx* ctx, const char* text, size_t len, const uint8_t* r1cs, size_t r1cs_len, hz_symmap** out);
+}  // namespace
+
 extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_t len, hz_symmap** out) {
     if (!ctx || !text || !out) return set_err(HZ_ERR_ARG, "hz_symmap_create: null argument");
+    return symmap_build(ctx, text, len, nullptr, 0, out);
+}
+extern "C" hz_status hz_symmap_create_r1cs(const hz_ctx* ctx, const char* text, size_t len, const uint8_t* r1cs, size_t r1cs_len, hz_symmap** out) {
+    if (!ctx || !text || !r1cs || !out) return set_err(HZ_ERR_ARG, "hz_symmap_create_r1cs: null argument");
+    return symmap_build(ctx, text, len, r1cs, r1cs_len, out);
+}
+namespace {
+hz_status symmap_build(const hz_ctx* ctx, const char* text, size_t len, const uint8_t* r1cs, size_t r1cs_len, hz_symmap** out) {
     try {
     hz_symmap* m = new hz_symmap();
     std::vector<std::string> label;   // one label per variable, kept until the variable resolves
@@ -730,6 +910,13 @@ extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_
         p = nl ? nl + 1 : e;
     }
     if (!m->index.empty() && m->index[0] == ~0ull) m->index[0] = 0;   // variable 0 is the constant 1 whether or not the file names it
+    if (r1cs) {
+        const hz_status st = parse_r1cs(r1cs, r1cs_len, m->r1cs);
+        if (st != HZ_OK) { delete m; return st; }
+        if (m->r1cs.n_wires > var_cap) { delete m; return set_err(HZ_ERR_INPUT, ".r1cs: %llu wires for a .sym of %llu lines", (unsigned long long)m->r1cs.n_wires, (unsigned long long)n_lines); }
+        solve_linear(m);
+        label.resize(m->index.size());
+    }
     for (size_t v = 0; v < m->index.size(); v++) {
         if (m->index[v] == ~0ull) {
             m->unresolved.push_back(v);
@@ -744,6 +931,8 @@ extern "C" hz_status hz_symmap_create(const hz_ctx* ctx, const char* text, size_
         return set_err(HZ_ERR_INPUT, "hz_symmap_create: out of memory while reading the .sym");
     }
 }
+}  // namespace
+extern "C" uint64_t hz_symmap_solved(const hz_symmap* m) { return m ? m->n_solved : 0; }
 extern "C" void hz_symmap_destroy(hz_symmap* m) { delete m; }
 extern "C" uint64_t hz_symmap_nvars(const hz_symmap* m) { return m ? m->index.size() : 0; }
 extern "C" uint64_t hz_symmap_unresolved(const hz_symmap* m, uint64_t i, uint64_t* var, const char** name) {
@@ -768,6 +957,38 @@ extern "C" hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* m, int32_
     return symmap_values(ctx, m, instance, m->index.data() + first, count, out);
 }
 extern "C" uint64_t hz_symmap_derived(const hz_symmap* m) { return m ? m->n_derived : 0; }
+// every constraint of the map's .r1cs on the witness as the map serves it (what `snarkjs wtns check` does with the files this library
+// writes): the number of violated constraints and the indices of the first `cap` of them
+extern "C" hz_status hz_symmap_check_r1cs(hz_ctx* ctx, const hz_symmap* m, int32_t instance, uint64_t* n_bad, uint64_t* first_bad, uint64_t cap) {
+    const hz_status st0 = symmap_usable(m, "hz_symmap_check_r1cs");
+    if (st0 != HZ_OK) return st0;
+    if (!n_bad || !m->r1cs.n_cons) return set_err(HZ_ERR_ARG, "hz_symmap_check_r1cs: %s", n_bad ? "the map was made without an .r1cs (hz_symmap_create_r1cs)" : "null argument");
+    try {
+    const hz_symmap::R1cs& r = m->r1cs;
+    std::vector<uint8_t> raw(m->index.size() * 32);
+    const hz_status st = symmap_values(ctx, m, instance, m->index.data(), m->index.size(), raw.data());
+    if (st != HZ_OK) return st;
+    std::vector<hzh::F> w(m->index.size());
+    for (size_t v = 0; v < w.size(); v++) w[v] = hzh::f_from_canon(raw.data() + 32 * v);
+    if (!hzh::f_eq(w[0], hzh::f_one())) return set_err(HZ_ERR_INPUT, "hz_symmap_check_r1cs: variable 0 is not 1");
+    std::vector<uint8_t>().swap(raw);
+    *n_bad = 0;
+    for (uint64_t c = 0; c < r.n_cons; c++) {
+        hzh::F v[3];
+        for (int q = 0; q < 3; q++) {
+            v[q] = hzh::f_zero();
+            for (uint64_t t = r.off[3 * c + q]; t < r.off[3 * c + q + 1]; t++) v[q] = hzh::f_add(v[q], hzh::f_mul(r.pool[r.coef[t]], w[r.wire[t]]));
+        }
+        if (!hzh::f_eq(hzh::f_mul(v[0], v[1]), v[2])) {
+            if (first_bad && *n_bad < cap) first_bad[*n_bad] = c;
+            ++*n_bad;
+        }
+    }
+    return HZ_OK;
+    } catch (const std::bad_alloc&) {
+        return set_err(HZ_ERR_INPUT, "hz_symmap_check_r1cs: out of memory");
+    }
+}
 extern "C" hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const char* path) {
     if (!ctx || !path) return set_err(HZ_ERR_ARG, "hz_witness_write_wtns_sym: null argument");
     hz_status st = symmap_usable(m, "hz_witness_write_wtns_sym");

@@ -227,6 +227,16 @@ uint64_t hz_symmap_unresolved(const hz_symmap* map, uint64_t i, uint64_t* var, c
  * S-box inputs, from the stored S-box products), and the linear intermediates / linearly fed component inputs of the reference's own
  * templates (rule table in csrc/formats.hip) -- evaluated from stored signals when the witness is read in the compiler's order */
 uint64_t hz_symmap_derived(const hz_symmap* map);
+/* .sym AND .r1cs of the same compile (tools/helpers/actions.js:30-68 writes both). Variables that no label resolves -- the
+ * wire-through signals an unreduced compile keeps: inputs of sub-components, aliases of their outputs, Bits2Num sums, comparator
+ * differences, for ANY circuit and circomlib version -- are solved from the circuit's own LINEAR constraints: one with exactly one
+ * unknown variable defines it over known ones, and so on until nothing changes (hz_symmap_solved = how many). The r1cs stays with
+ * the map: hz_symmap_check_r1cs evaluates every constraint (A.w)(B.w) = C.w on the witness as the map serves it -- what
+ * `snarkjs wtns check` would do with the .wtns this library writes -- and returns the number of violated constraints and the
+ * indices of the first `cap` of them. r1cs: iden3 binary format version 1, field BN254 Fr; circom's wire w is variable w. */
+hz_status hz_symmap_create_r1cs(const hz_ctx* ctx, const char* sym_text, size_t sym_len, const uint8_t* r1cs, size_t r1cs_len, hz_symmap** out);
+uint64_t hz_symmap_solved(const hz_symmap* map);
+hz_status hz_symmap_check_r1cs(hz_ctx* ctx, const hz_symmap* map, int32_t instance, uint64_t* n_bad, uint64_t* first_bad, uint64_t cap);
 hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instance, uint64_t first_var, uint64_t count, uint8_t* out);
 hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instance, const char* path);
 hz_status hz_witness_gather(hz_ctx* ctx, int32_t instance, const uint64_t* index, uint64_t count, uint8_t* out);

@@ -442,7 +442,7 @@ struct WithdrawOff {
 // ------------------------------------------------------------------------------------------------
 // blocks, sections, symbols
 
-enum BlockKind : uint8_t { BK_PLAIN = 0, BK_POSEIDON = 1 };
+enum BlockKind : uint8_t { BK_PLAIN = 0, BK_POSEIDON = 1, BK_SHA = 2 };
 
 struct Block {
     std::string name;   // may contain "{u}" (unit index); "[k]" is appended when count > 1
@@ -505,6 +505,12 @@ struct Section {
         n_sigs += b.count;
         return b.off;
     }
+    // `nblocks` SHA-256 compression blocks: name = "<...>.sha256compression", symbols name[b] + sha_signame(j)
+    uint32_t add_sha(const std::string& name, uint32_t nblocks, uint32_t block_sigs) {
+        const uint32_t off = add(name, nblocks * block_sigs);
+        blocks.back().kind = BK_SHA;
+        return off;
+    }
     IsZOff add_isz(const std::string& name) {
         uint32_t o = add(name + ".inv");
         add(name + ".out");
@@ -552,6 +558,69 @@ inline std::string poseidon_signame(int t, int j) {
     else if (k < 4 * t + rp) snprintf(b, sizeof b, ".sigmaP[%d].%s", k - 4 * t, sn[s]);
     else snprintf(b, sizeof b, ".sigmaF[%d][%d].%s", 4 + (k - 4 * t - rp) / t, (k - 4 * t - rp) % t, sn[s]);
     return b;
+}
+
+// Names of the stored signals of one SHA-256 block, relative to `sha256compression[b]` (circomlib 0.5.2 sha256/sha256compression.circom
+// and the templates it instantiates: SigmaPlus = {sigma0, sigma1: SmallSigma -> xor3: Xor3(32) with mid / out, sum: BinSum(32, 4)},
+// T1 = {bigsigma1: BigSigma -> xor3, ch: Ch_t(32), sum: BinSum(32, 5)}, T2 = {bigsigma0: BigSigma -> xor3, maj: Maj_t(32) with mid / out,
+// sum: BinSum(32, 2)}, suma / sume / fsum: BinSum(32, 2)). The products and the sums' hinted bits are what a block stores (in the order
+// of SHA_SCHED_W / SHA_ROUND_W below); everything else inside the component is a wire of one of them.
+struct ShaPart { const char* name; int width; };
+inline const ShaPart* sha_sched_parts() {
+    static const ShaPart p[] = {{"sigma0.xor3.mid", 32}, {"sigma0.xor3.out", 32}, {"sigma1.xor3.mid", 32}, {"sigma1.xor3.out", 32}, {"sum.out", 34}, {nullptr, 0}};
+    return p;
+}
+struct ShaRoundPart { const char* comp; const char* name; int width; };
+inline const ShaRoundPart* sha_round_parts() {
+    static const ShaRoundPart p[] = {{"t1", "bigsigma1.xor3.mid", 32}, {"t1", "bigsigma1.xor3.out", 32}, {"t1", "ch.out", 32}, {"t1", "sum.out", 35},
+                                     {"t2", "bigsigma0.xor3.mid", 32}, {"t2", "bigsigma0.xor3.out", 32}, {"t2", "maj.mid", 32}, {"t2", "maj.out", 32}, {"t2", "sum.out", 33},
+                                     {"sume", "out", 33}, {"suma", "out", 33}, {nullptr, nullptr, 0}};
+    return p;
+}
+inline std::string sha_signame(uint32_t j) {
+    char b[96];
+    if (j < 48u * 162u) {
+        uint32_t t = j / 162u, r = j % 162u;
+        for (const ShaPart* p = sha_sched_parts(); p->name; p++) {
+            if (r < (uint32_t)p->width) { snprintf(b, sizeof b, ".sigmaPlus[%u].%s[%u]", t, p->name, r); return b; }
+            r -= (uint32_t)p->width;
+        }
+    }
+    j -= 48u * 162u;
+    if (j < 64u * 358u) {
+        uint32_t t = j / 358u, r = j % 358u;
+        for (const ShaRoundPart* p = sha_round_parts(); p->name; p++) {
+            if (r < (uint32_t)p->width) { snprintf(b, sizeof b, ".%s[%u].%s[%u]", p->comp, t, p->name, r); return b; }
+            r -= (uint32_t)p->width;
+        }
+    }
+    j -= 64u * 358u;
+    snprintf(b, sizeof b, ".fsum[%u].out[%u]", j / 33u, j % 33u);
+    return b;
+}
+// the inverse: ".sigmaPlus[3].sigma1.xor3.out[7]" -> index inside the block, or -1
+inline long sha_sigindex(const std::string& rest) {
+    unsigned t = 0, k = 0;
+    char comp[16], name[40];
+    int used = 0;
+    if (sscanf(rest.c_str(), ".%15[a-zA-Z0-9][%u].%39[a-zA-Z0-9.][%u]%n", comp, &t, name, &k, &used) != 4 || (size_t)used != rest.size()) return -1;
+    const std::string c = comp, n = name;
+    if (c == "sigmaPlus" && t < 48) {
+        uint32_t r = 0;
+        for (const ShaPart* p = sha_sched_parts(); p->name; p++) {
+            if (n == p->name) return k < (unsigned)p->width ? (long)(t * 162u + r + k) : -1;
+            r += (uint32_t)p->width;
+        }
+        return -1;
+    }
+    if (c == "fsum" && t < 8 && n == "out") return k < 33 ? (long)(48u * 162u + 64u * 358u + t * 33u + k) : -1;
+    if (t >= 64) return -1;
+    uint32_t r = 0;
+    for (const ShaRoundPart* p = sha_round_parts(); p->name; p++) {
+        if (c == p->comp && n == p->name) return k < (unsigned)p->width ? (long)(48u * 162u + t * 358u + r + k) : -1;
+        r += (uint32_t)p->width;
+    }
+    return -1;
 }
 
 struct Layout;
@@ -609,6 +678,9 @@ struct Layout {
                     if (b.kind == BK_POSEIDON) {
                         if (!expand_poseidon) { f(base + ".sigma*", (int)si, b.off, u); continue; }
                         for (uint32_t j = 0; j < b.count; j++) f(base + poseidon_signame(b.t, (int)j), (int)si, b.off + j, u);
+                    } else if (b.kind == BK_SHA) {
+                        const uint32_t per = 48u * 162u + 64u * 358u + 8u * 33u;
+                        for (uint32_t k = 0; k < b.count; k++) f(base + "[" + istr(k / per) + "]" + sha_signame(k % per), (int)si, b.off + k, u);
                     } else if (b.count == 1 && !b.scalar_array) {
                         f(base, (int)si, b.off, u);
                     } else {
@@ -637,6 +709,22 @@ struct Layout {
         std::string name = name_in;
         if (name.compare(0, 5, "main.") != 0) name = "main." + name;
         if (index_.empty()) const_cast<Layout*>(this)->build_index();
+        {   // a signal inside a SHA-256 block: <component>.sha256compression[b].<rest>
+            static const char mark[] = ".sha256compression[";
+            const size_t sp = name.find(mark);
+            if (sp != std::string::npos) {
+                auto it = index_.find(name.substr(0, sp + sizeof mark - 2));
+                const size_t rb = name.find(']', sp);
+                if (it == index_.end() || rb == std::string::npos) return false;
+                const Block& b = sections[it->second.first].blocks[it->second.second];
+                const uint32_t per = 48u * 162u + 64u * 358u + 8u * 33u;
+                const long long blk = atoll(name.c_str() + sp + sizeof mark - 1);
+                const long j = sha_sigindex(name.substr(rb + 1));
+                if (b.kind != BK_SHA || j < 0 || blk < 0 || (uint64_t)blk * per + (uint64_t)j >= b.count) return false;
+                *out = virt(it->second.first, b.off + (uint32_t)blk * per + (uint32_t)j, 0);
+                return true;
+            }
+        }
         // split trailing Poseidon suffix
         std::string key = name;
         long long unit = 0, k = 0;
@@ -1069,7 +1157,7 @@ inline void lay_hashinputs(Section& s, const std::string& pre, int L, int nTx, i
     o.n2bCurrentNumBatch = s.add(pre + "n2bCurrentNumBatch.out", 32);
     o.sha.nblocks = (int)((o.totalBits + 64) / 512 + 1);
     o.sha.block_size = SHA_BLOCK_SIGS;
-    o.sha.blocks = s.add(pre + "inputsHasher.sha256compression", (uint32_t)((uint64_t)o.sha.nblocks * SHA_BLOCK_SIGS));
+    o.sha.blocks = s.add_sha(pre + "inputsHasher.sha256compression", (uint32_t)o.sha.nblocks, SHA_BLOCK_SIGS);
 }
 
 inline void add_input(Layout& lo, const std::string& name, int sec, uint32_t off, uint32_t inner, uint32_t outer, bool /*unused*/) {
@@ -1304,7 +1392,7 @@ inline void build_layout(const Params& p, Layout& lo) {
             w.n2bTokenID = T.add(h + "n2bTokenID.out", 32); w.n2bBalance = T.add(h + "n2bBalance.out", 192);
             w.n2bIdx = T.add(h + "n2bIdx.out", 48);
             w.sha.nblocks = 2; w.sha.block_size = SHA_BLOCK_SIGS;
-            w.sha.blocks = T.add(h + "inputsHasher.sha256compression", 2 * SHA_BLOCK_SIGS);
+            w.sha.blocks = T.add_sha(h + "inputsHasher.sha256compression", 2, SHA_BLOCK_SIGS);
             lo.outputs = {{"hashGlobalInputs", w.hashGlobalInputs}};
             break;
         }

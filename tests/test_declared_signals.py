@@ -126,3 +126,62 @@ def test_synthetic_r1cs_has_the_documented_shape():
     nw, _, _, _, nl, nc = struct.unpack_from("<IIIIQI", r1cs, 60)
     assert nw == len(names) + 1 == nl and nc == len(m["forms"]) + len(m["quads"])
     assert len(sym.splitlines()) == len(names)
+
+
+# ---- GPU: the same system as a compiler's files ------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", TEMPLATES)
+def test_hip_serves_every_declared_signal_through_sym_and_r1cs(hz, key):
+    """.sym + .r1cs of an unreduced compile (every signal of the recorded system a variable of its own, in a seeded random order):
+    nothing unresolved, every value the one that follows from the ORACLE's stored signals, no violated constraint; a constraint the
+    witness does not satisfy is found by its index."""
+    import copy
+    import random
+    m = DF.load(key)
+    kw = dict(zip(KEYS.get(key, ()), m["args"]))
+    inp = inputs_of(key)[-1]
+    g = hz.ctx(key, **kw)
+    g.set_inputs(inp)
+    g.run()
+    _, known = oracle_known(key, m, inp)
+    val, unknown = DF.solve_with_hashes(m, known, lambda xs: B.host().poseidon(xs))
+    assert not unknown
+    order = DF.all_names(m)
+    random.Random(0xD5).shuffle(order)
+    sym, r1cs, names = DF.sym_and_r1cs(m, order)
+    mp = g.import_sym(sym, r1cs)
+    assert mp.unresolved() == [], (len(mp.unresolved()), mp.unresolved()[:8])
+    assert mp.nvars() == len(names) + 1
+    got = mp.read()
+    assert got[0] == 1
+    bad = [(n, got[v + 1], val[n]) for v, n in enumerate(names) if got[v + 1] != val[n]]
+    assert not bad, (len(bad), bad[:4])
+    assert mp.check_r1cs() == (0, [])
+    # names alone (no .r1cs) leave the wire-through signals open unless a rule knows them: the propagation is what closes the set
+    alone = g.import_sym(sym)
+    assert len(alone.unresolved()) <= mp.solved()
+    # a system the witness does NOT satisfy: the constant of one product constraint changed
+    m2 = copy.deepcopy(m)
+    products = [i for i, (a, b, _) in enumerate(m2["quads"]) if a[1] and b[1]]   # (a linear === line may DEFINE a variable instead)
+    if not products:
+        return
+    q = products[len(products) // 2]
+    m2["quads"][q][2][0] = str((int(m2["quads"][q][2][0]) + 1) % DF.P)
+    _, r1cs2, _ = DF.sym_and_r1cs(m2, order)
+    mp2 = g.import_sym(sym, r1cs2)
+    assert mp2.unresolved() == []
+    assert mp2.check_r1cs() == (1, [len(m["forms"]) + q])
+
+
+@pytest.mark.gpu
+def test_hip_r1cs_import_rejects_malformed_files(hz):
+    from circuits_amd import HzError
+    m = DF.load("hash-state")
+    sym, r1cs, _ = DF.sym_and_r1cs(m)
+    g = hz.ctx("hash-state")
+    for blob in (b"", b"r1cz" + r1cs[4:], r1cs[:40], r1cs[:-7], r1cs[:28] + bytes(32) + r1cs[60:]):
+        with pytest.raises(HzError):
+            g.import_sym(sym, blob)
+    mp = g.import_sym(sym)   # made without an .r1cs: nothing to check against
+    with pytest.raises(HzError):
+        mp.check_r1cs()

@@ -259,9 +259,9 @@ def test_sharded_batch_split_sha_tail_matches_oracle(hz):
     gb = [c.read_raw_bytes() for c in ctxs]
     nb = ctxs[0].sha_blocks()
     assert sbs[0].blocks[1] + sbs[1].blocks[1] == nb and sbs[1].blocks[0] == sbs[0].blocks[1] and nb >= 8
-    # block b's witness = sha256compression[b * per_block .. (b + 1) * per_block) (one flat array in the symbol table)
+    # block b's witness = the per_block signals named sha256compression[b].* (contiguous in the symbol table, block after block)
     names = [n for n in o.symbol_names() if ".inputsHasher.sha256compression[" in n]
-    first = o.lookup("main.hasherInputs.inputsHasher.sha256compression[0]")
+    first = o.lookup("main.hasherInputs.inputsHasher.sha256compression[0].sigmaPlus[0].sigma0.xor3.mid[0]")
     assert len(names) % nb == 0
     per_block = len(names) // nb
     for blk in range(nb):
@@ -343,7 +343,7 @@ def test_config4_eight_shards_on_one_gpu_match_oracle(hz, config4):
             got = np.frombuffer(ctxs[r].read_raw_bytes(idx0 + r0 * n_tx, nr * n_tx), dtype=np.uint8).reshape(nr, n_tx, 32)
             assert np.array_equal(got[:, f:f + n, :], ref[:, f:f + n, :]), "rank %d, signal rows from %d" % (r, r0)
     # SHA-256 blocks: exactly the owner holds a block's witness
-    first = o.lookup("main.hasherInputs.inputsHasher.sha256compression[0]")
+    first = o.lookup("main.hasherInputs.inputsHasher.sha256compression[0].sigmaPlus[0].sigma0.xor3.mid[0]")
     names = [n for n in o.symbol_names() if ".inputsHasher.sha256compression[" in n]
     per_block = len(names) // nb
     assert len(names) % nb == 0
