@@ -2,7 +2,7 @@
 // `./circuit input.json witness.json` the reference runs at tools/helpers/actions.js:132-146 (and of
 // `snarkjs wtns calculate` for the .wtns output). Plain C++ over the C ABI of include/hermez_witness.h.
 //
-//   hz_witness "RollupMain(2048,32,256,64)" input.json witness.wtns [--sym out.sym] [--circom-sym circuit.sym] [--device 0]
+//   hz_witness "RollupMain(2048,32,256,64)" input.json witness.wtns [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--check]]] [--device 0]
 //   hz_witness path/to/main.circom input.json witness.json
 //
 // The first argument is `Template(params)` or a .circom file whose `component main = Template(params);` line is
@@ -12,6 +12,9 @@
 // Without --circom-sym the witness is in this library's own signal numbering (--sym writes the matching symbol file): good for
 // name-based checks, NOT for the reference's prover. With --circom-sym <the .sym of the circom compile> the .wtns is written
 // in the compiler's variable order (name join, hz_symmap_create); it fails listing the variables this layout does not store.
+// With --circom-r1cs <the .r1cs of the same compile> the variables no name resolves -- the wire-through signals of a compile without
+// constraint reduction -- are solved from the circuit's linear constraints (hz_symmap_create_r1cs), and --check evaluates every
+// constraint of the .r1cs on the witness before it is written (what `snarkjs wtns check` does; exit status 1 when one fails).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -106,18 +109,23 @@ static hz_status set_json_unsupported() {
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s \"Template(params)\"|main.circom input.json witness.{wtns,json} [--sym out.sym] [--circom-sym circuit.sym] [--device N]\n", argv[0]);
+        fprintf(stderr, "usage: %s \"Template(params)\"|main.circom input.json witness.{wtns,json} [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--check]]] [--device N]\n", argv[0]);
         return 2;
     }
     const char* sym = nullptr;
     const char* circom_sym = nullptr;
+    const char* circom_r1cs = nullptr;
+    bool check = false;
     int device = 0;
     for (int i = 4; i < argc; i++) {
         if (!strcmp(argv[i], "--sym") && i + 1 < argc) sym = argv[++i];
         else if (!strcmp(argv[i], "--circom-sym") && i + 1 < argc) circom_sym = argv[++i];
+        else if (!strcmp(argv[i], "--circom-r1cs") && i + 1 < argc) circom_r1cs = argv[++i];
+        else if (!strcmp(argv[i], "--check")) check = true;
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
+    if ((circom_r1cs && !circom_sym) || (check && !circom_r1cs)) { fprintf(stderr, "--circom-r1cs goes with --circom-sym, --check with --circom-r1cs\n"); return 2; }
     std::string spec = argv[1];
     bool ok;
     if (spec.find('(') == std::string::npos) {
@@ -150,7 +158,24 @@ int main(int argc, char** argv) {
             const std::string st_text = slurp(circom_sym, &ok);
             hz_symmap* m = nullptr;
             if (!ok) { fprintf(stderr, "cannot read %s\n", circom_sym); hz_ctx_destroy(c); return 2; }
+            if (circom_r1cs) {
+                const std::string r1 = slurp(circom_r1cs, &ok);
+                if (!ok) { fprintf(stderr, "cannot read %s\n", circom_r1cs); hz_ctx_destroy(c); return 2; }
+                st = hz_symmap_create_r1cs(c, st_text.data(), st_text.size(), (const uint8_t*)r1.data(), r1.size(), &m);
+            } else
             st = hz_symmap_create(c, st_text.data(), st_text.size(), &m);
+            if (st == HZ_OK && check && hz_symmap_unresolved(m, 0, nullptr, nullptr) == 0) {
+                uint64_t n_bad = 0, first[8];
+                st = hz_symmap_check_r1cs(c, m, 0, &n_bad, first, 8);
+                if (st == HZ_OK && n_bad) {
+                    for (uint64_t i = 0; i < n_bad && i < 8; i++) fprintf(stderr, "constraint %llu of the .r1cs does not hold\n", (unsigned long long)first[i]);
+                    fprintf(stderr, "Error: %llu constraints of %s do not hold on this witness\n", (unsigned long long)n_bad, circom_r1cs);
+                    hz_symmap_destroy(m);
+                    hz_ctx_destroy(c);
+                    return 1;
+                }
+                if (st == HZ_OK) fprintf(stderr, "%s: every constraint holds (%llu variables solved from linear constraints)\n", circom_r1cs, (unsigned long long)hz_symmap_solved(m));
+            }
             if (st == HZ_OK) {
                 const char* nm = nullptr;
                 uint64_t var = 0;

@@ -185,3 +185,38 @@ def test_hip_r1cs_import_rejects_malformed_files(hz):
     mp = g.import_sym(sym)   # made without an .r1cs: nothing to check against
     with pytest.raises(HzError):
         mp.check_r1cs()
+
+
+@pytest.mark.gpu
+def test_hip_native_binary_with_the_compilers_sym_and_r1cs(hz, tmp_path):
+    """`hz_witness RollupTx(16,2) input.json out.wtns --circom-sym c.sym --circom-r1cs c.r1cs --check` (the place of the reference's
+    generated `./circuit input.json witness.wtns`, tools/helpers/actions.js:132-146): the .wtns holds every variable of the compile in
+    its order; --check refuses a witness that does not satisfy the .r1cs."""
+    import copy
+    import json
+    import subprocess
+    from test_witness_gpu import _parse_wtns
+    m = DF.load("rollup-tx")
+    inp = inputs_of("rollup-tx")[1]
+    _, known = oracle_known("rollup-tx", m, inp)
+    val, _ = DF.solve_with_hashes(m, known, lambda xs: B.host().poseidon(xs))
+    sym, r1cs, names = DF.sym_and_r1cs(m)
+    spath, rpath, ipath, wpath = (str(tmp_path / n) for n in ("c.sym", "c.r1cs", "input.json", "out.wtns"))
+    open(spath, "w").write(sym)
+    open(rpath, "wb").write(r1cs)
+    json.dump({k: ([str(x) for x in v] if isinstance(v, list) else str(v)) for k, v in inp.items()}, open(ipath, "w"))
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "circuits_amd", "bin", "hz_witness")
+    r = subprocess.run([cli, "RollupTx(16,2)", ipath, wpath, "--circom-sym", spath, "--circom-r1cs", rpath, "--check"], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "every constraint holds" in r.stderr, r.stderr
+    got = _parse_wtns(wpath)
+    assert got[0] == 1 and got[1:] == [val[n] for n in names]
+    # without the .r1cs the same .sym cannot be served: the wire-through variables are listed
+    r = subprocess.run([cli, "RollupTx(16,2)", ipath, str(tmp_path / "no.wtns"), "--circom-sym", spath], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "not stored by this layout" in r.stderr and not os.path.exists(str(tmp_path / "no.wtns"))
+    # an .r1cs this witness does not satisfy
+    m2 = copy.deepcopy(m)
+    q = [i for i, (a, b, _) in enumerate(m2["quads"]) if a[1] and b[1]][3]
+    m2["quads"][q][2][0] = str((int(m2["quads"][q][2][0]) + 5) % DF.P)
+    open(rpath, "wb").write(DF.sym_and_r1cs(m2)[1])
+    r = subprocess.run([cli, "RollupTx(16,2)", ipath, str(tmp_path / "bad.wtns"), "--circom-sym", spath, "--circom-r1cs", rpath, "--check"], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "constraint %d of the .r1cs does not hold" % (len(m["forms"]) + q) in r.stderr and not os.path.exists(str(tmp_path / "bad.wtns"))
