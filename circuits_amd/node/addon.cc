@@ -60,6 +60,8 @@ struct Api {
     decltype(&hz_witness_write_wtns) witness_write_wtns;
     decltype(&hz_symbols_write_sym) symbols_write_sym;
     decltype(&hz_symmap_create) symmap_create;
+    decltype(&hz_symmap_create_r1cs) symmap_create_r1cs;
+    decltype(&hz_symmap_check_r1cs) symmap_check_r1cs;
     decltype(&hz_symmap_destroy) symmap_destroy;
     decltype(&hz_symmap_nvars) symmap_nvars;
     decltype(&hz_symmap_unresolved) symmap_unresolved;
@@ -84,7 +86,7 @@ static bool load_api(std::string& err) {
     SYM(constraint_name)
     SYM(inputs_packed_bytes) SYM(input_packed_width) SYM(input_packed_offset) SYM(host_alloc) SYM(host_free) SYM(inputs_upload) SYM(inputs_stage)
     SYM(inputs_stage_range) SYM(witness_enqueue) SYM(witness_check) SYM(witness_failures) SYM(witness_total) SYM(witness_read_raw) SYM(witness_dev_ptr)
-    SYM(set_inputs_json) SYM(witness_write_json) SYM(witness_write_wtns) SYM(symbols_write_sym) SYM(symmap_create) SYM(symmap_destroy)
+    SYM(set_inputs_json) SYM(witness_write_json) SYM(witness_write_wtns) SYM(symbols_write_sym) SYM(symmap_create) SYM(symmap_create_r1cs) SYM(symmap_check_r1cs) SYM(symmap_destroy)
     SYM(symmap_nvars) SYM(symmap_unresolved) SYM(witness_write_wtns_sym) SYM(poseidon_batch)
 #undef SYM
     return true;
@@ -628,21 +630,30 @@ static napi_value SetInputsJson(napi_env env, napi_callback_info info) {
     if (api.set_inputs_json(c, (int32_t)num(env, argv[1]), text.c_str(), text.size()) != HZ_OK) return throw_hz(env, "hz_set_inputs_json");
     return nullptr;
 }
-// writeWtns(handle, instance, path[, symText]) / writeJson(handle, instance, path) / writeSym(handle, path)
+// writeWtns(handle, instance, path[, symText[, r1cs Buffer[, check]]]) / writeJson(handle, instance, path) / writeSym(handle, path)
+// symText: the .sym of the circom compile -> the compiler's variable order; r1cs: the .r1cs of the same compile -> the variables no
+// label resolves are solved from its linear constraints (hz_symmap_create_r1cs); check: every constraint is evaluated first and a
+// witness that violates one is not written (hz_symmap_check_r1cs)
 static napi_value WriteWtns(napi_env env, napi_callback_info info) {
-    napi_value argv[4];
+    napi_value argv[6];
     size_t got = 0;
-    if (!get_args(env, info, 4, argv, &got)) return nullptr;
+    if (!get_args(env, info, 6, argv, &got)) return nullptr;
     hz_ctx* c = get_ctx(env, argv[0]);
     std::string path, sym;
     if (!c || !get_str(env, argv[2], path)) return nullptr;
     const int32_t inst = (int32_t)num(env, argv[1]);
     napi_valuetype t = napi_undefined;
-    napi_typeof(env, argv[3], &t);
+    if (got >= 4) napi_typeof(env, argv[3], &t);
     if (got >= 4 && t == napi_string) {
         if (!get_str(env, argv[3], sym)) return nullptr;
         hz_symmap* m = nullptr;
-        if (api.symmap_create(c, sym.c_str(), sym.size(), &m) != HZ_OK) return throw_hz(env, "hz_symmap_create");
+        bool is_buf = false, check = false;
+        void* rdata = nullptr; size_t rlen = 0;
+        if (got >= 5 && napi_is_buffer(env, argv[4], &is_buf) == napi_ok && is_buf) napi_get_buffer_info(env, argv[4], &rdata, &rlen);
+        if (got >= 6) napi_get_value_bool(env, argv[5], &check);
+        if (is_buf) {
+            if (api.symmap_create_r1cs(c, sym.c_str(), sym.size(), (const uint8_t*)rdata, rlen, &m) != HZ_OK) return throw_hz(env, "hz_symmap_create_r1cs");
+        } else if (api.symmap_create(c, sym.c_str(), sym.size(), &m) != HZ_OK) return throw_hz(env, "hz_symmap_create");
         uint64_t var = 0; const char* nm = nullptr;
         const uint64_t miss = api.symmap_unresolved(m, 0, &var, &nm);
         if (miss) {
@@ -650,6 +661,17 @@ static napi_value WriteWtns(napi_env env, napi_callback_info info) {
             api.symmap_destroy(m);
             napi_throw_error(env, nullptr, e.c_str());
             return nullptr;
+        }
+        if (check && is_buf) {
+            uint64_t n_bad = 0, first = 0;
+            const hz_status cs = api.symmap_check_r1cs(c, m, inst, &n_bad, &first, 1);
+            if (cs != HZ_OK) { api.symmap_destroy(m); return throw_hz(env, "hz_symmap_check_r1cs"); }
+            if (n_bad) {
+                std::string e = std::to_string(n_bad) + " constraints of the .r1cs do not hold on this witness (first: constraint " + std::to_string(first) + ")";
+                api.symmap_destroy(m);
+                napi_throw_error(env, nullptr, e.c_str());
+                return nullptr;
+            }
         }
         const hz_status st = api.witness_write_wtns_sym(c, m, inst, path.c_str());
         api.symmap_destroy(m);

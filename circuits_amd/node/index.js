@@ -244,8 +244,14 @@ class Circuit {
     witnessTotal() { return addon.witnessTotal(this.handle); }
     readRaw(first, count) { return addon.readRaw(this.handle, first, count); }
     setInputsJson(text, instance) { addon.setInputsJson(this.handle, instance | 0, text); }
-    /** snarkjs .wtns of one instance; with `symText` (a circom .sym) in the compiler's variable order */
-    writeWtns(file, instance, symText) { if (symText) addon.writeWtns(this.handle, instance | 0, file, symText); else addon.writeWtns(this.handle, instance | 0, file); }
+    /** snarkjs .wtns of one instance; with `symText` (a circom .sym) in the compiler's variable order; with `r1cs` (a Buffer: the .r1cs
+     *  of the same compile) the wire-through variables of an unreduced compile are solved from its linear constraints, and with
+     *  `check` every constraint is evaluated first (an Error instead of a file when one does not hold) */
+    writeWtns(file, instance, symText, r1cs, check) {
+        if (symText && r1cs) addon.writeWtns(this.handle, instance | 0, file, symText, r1cs, !!check);
+        else if (symText) addon.writeWtns(this.handle, instance | 0, file, symText);
+        else addon.writeWtns(this.handle, instance | 0, file);
+    }
     writeJson(file, instance) { addon.writeJson(this.handle, instance | 0, file); }
     writeSym(file) { addon.writeSym(this.handle, file); }
 
