@@ -12,6 +12,7 @@
 // `./circuit input.json witness.json` (circuits_amd/csrc/cli/hz_witness.cpp).
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <array>
 #include <map>
 #include <new>
@@ -618,9 +619,10 @@ uint64_t resolve_name(const hz_ctx* ctx, hz_symmap* m, const std::string& name_i
 hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const uint64_t* index, uint64_t count, uint8_t* out) {
     // what has to come from the device: the stored variables themselves, the stored terms of the linear forms (through other
     // derived variables), the S-box signals of every Poseidon component one of the variables lies in
+    // (collected with repeats, then sorted and made unique: a full-size RollupMain has 1.2 * 10^8 variables, a tree map per index
+    // would take minutes; the position of an index is found by binary search)
     std::vector<uint64_t> need;
-    std::map<uint64_t, size_t> slot;   // stored index -> position in `need`
-    auto want = [&](uint64_t idx) { if (slot.emplace(idx, need.size()).second) need.push_back(idx); };
+    auto want = [&](uint64_t idx) { need.push_back(idx); };
     std::vector<uint8_t> seen(m->derived.size(), 0);
     std::vector<uint64_t> stack;
     bool any_derived = false;
@@ -652,6 +654,12 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
     }
     for (uint64_t i = 0; i < count; i++)
         if (!(index[i] & DERIVED_FLAG)) want(index[i]);
+    std::sort(need.begin(), need.end());
+    need.erase(std::unique(need.begin(), need.end()), need.end());
+    struct Slot {
+        const std::vector<uint64_t>& need;
+        size_t operator[](uint64_t idx) const { return (size_t)(std::lower_bound(need.begin(), need.end(), idx) - need.begin()); }
+    } slot{need};
     std::vector<uint8_t> vals(need.size() * 32);
     if (!need.empty()) {
         const hz_status st = hz_witness_gather(ctx, instance, need.data(), need.size(), vals.data());
