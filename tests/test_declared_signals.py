@@ -113,6 +113,44 @@ def test_a_wrong_witness_value_breaks_a_recorded_constraint():
         assert DF.violated(m, val), name
 
 
+@pytest.mark.parametrize("key,shape,gen", [
+    ("rollup-tx", (0, 16, 0, 2), lambda FZ: FZ.rollup_tx_cases(160, 16, 2, 77)),
+    ("withdraw", (0, 16, 0, 0), lambda FZ: FZ.withdraw_cases(120, 16, 78)),
+])
+def test_oracle_rejects_whatever_violates_a_recorded_constraint(key, shape, gen):
+    """garbage inputs (tests/fuzz_common.py): the oracle still writes a complete witness; whenever that witness violates a constraint
+    the reference's sources state, the oracle must have reported a failure (its checks are the restatement of those lines; the other
+    direction does not hold: most garbage is rejected inside circomlib's templates, whose constraints are not recorded)."""
+    import collections
+    import fuzz_common as FZ
+    m = DF.load(key)
+    kw = dict(zip(KEYS.get(key, ()), m["args"]))
+    probe = OracleCtx(key, **kw)
+    idx = {}
+    for n in DF.all_names(m):
+        try:
+            idx[n] = probe.lookup(n)
+        except KeyError:
+            pass
+    stat = collections.Counter()
+    for inp in gen(FZ):
+        o = OracleCtx(key, **kw)
+        o.set_inputs(inp)
+        failed = o.run() is not None
+        vals = o.read(0, o.witness_len())
+        try:
+            val, unknown = DF.solve_with_hashes(m, {n: vals[i] for n, i in idx.items()}, lambda xs: B.host().poseidon([x % DF.P for x in xs]))
+        except AssertionError:   # SHA-256 input bits that are not bits: the oracle must have refused them
+            assert failed
+            stat["not bits"] += 1
+            continue
+        assert not unknown
+        bad = DF.violated(m, val)
+        assert failed or not bad, (inp, bad[:3])
+        stat[(failed, bool(bad))] += 1
+    assert stat[(False, False)] > 5 and stat[(True, True)] + stat["not bits"] > 5, stat   # both kinds occur
+
+
 def test_synthetic_r1cs_has_the_documented_shape():
     """the .r1cs bytes the GPU test hands to the library: header fields and one constraint per form / product line"""
     import struct
