@@ -290,7 +290,7 @@ extern "C" hz_status hz_symbols_write_sym(const hz_ctx* ctx, const char* path) {
 //     `<c>.isz.in`): inv <-- in != 0 ? 1/in : 0 determines it, in = inv == 0 ? 0 : 1/inv; and the input of every Num2Bits whose bits are
 //     stored as `<c>.out[k]`: the template's own constraint, in = sum of 2^k out[k].
 // A variable whose labels match neither a stored signal nor a rule stays unresolved and is reported as before.
-enum { DV_POSEIDON = 1, DV_LINEAR = 2, DV_ISZERO_IN = 3 };
+enum { DV_POSEIDON = 1, DV_LINEAR = 2, DV_ISZERO_IN = 3, DV_PRODUCT = 4 };   // DV_PRODUCT: lins[lin] * lins[lin + 1] + lins[lin + 2]
 using hzderived::PW_ARK_IN; using hzderived::PW_ARK_OUT; using hzderived::PW_MIX_IN; using hzderived::PW_MIX_OUT;
 struct DerivedVar {
     uint8_t kind = 0, t = 0, what = 0;
@@ -646,10 +646,11 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
         } else if (d.kind == DV_ISZERO_IN) {
             want(d.first);
         } else {
-            for (const auto& tm : m->lins[d.lin].terms) {
-                if (tm.second & DERIVED_FLAG) stack.push_back(tm.second & ~DERIVED_FLAG);
-                else want(tm.second);
-            }
+            for (uint32_t f = d.lin; f < d.lin + (d.kind == DV_PRODUCT ? 3u : 1u); f++)
+                for (const auto& tm : m->lins[f].terms) {
+                    if (tm.second & DERIVED_FLAG) stack.push_back(tm.second & ~DERIVED_FLAG);
+                    else want(tm.second);
+                }
         }
     }
     for (uint64_t i = 0; i < count; i++)
@@ -687,12 +688,15 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
         } else if (d.kind == DV_ISZERO_IN) {
             v = hzh::f_inv(hzh::f_from_canon(vals.data() + 32 * slot[d.first]));   // inverse(0) = 0
         } else {
-            const LinForm& lf = m->lins[d.lin];
-            v = lf.c0;
-            for (const auto& tm : lf.terms) {
-                const F x = (tm.second & DERIVED_FLAG) ? dval[tm.second & ~DERIVED_FLAG] : hzh::f_from_canon(vals.data() + 32 * slot[tm.second]);
-                v = hzh::f_add(v, hzh::f_mul(tm.first, x));
-            }
+            auto eval = [&](const LinForm& lf) {
+                F r = lf.c0;
+                for (const auto& tm : lf.terms) {
+                    const F x = (tm.second & DERIVED_FLAG) ? dval[tm.second & ~DERIVED_FLAG] : hzh::f_from_canon(vals.data() + 32 * slot[tm.second]);
+                    r = hzh::f_add(r, hzh::f_mul(tm.first, x));
+                }
+                return r;
+            };
+            v = d.kind == DV_PRODUCT ? hzh::f_add(hzh::f_mul(eval(m->lins[d.lin]), eval(m->lins[d.lin + 1])), eval(m->lins[d.lin + 2])) : eval(m->lins[d.lin]);
         }
         dval[k] = v;
     }
@@ -821,12 +825,85 @@ void solve_linear(hz_symmap* m) {
             if (kv.first != 0 && m->index[kv.first] == ~0ull) uses[kv.first].push_back((uint32_t)lc.size());
         lc.push_back(std::move(con));
     }
+    // Product constraints A * B = C with an unknown variable: once A and B hold none, a single unknown of C is DEFINED by them -- a
+    // product signal the layout does not store under that name (circomlib's MultiMux4 terms over constant inputs: constants times a
+    // selector product, signals of their own in an unreduced compile). qc[i]: constraint, unknowns in A or B, unknowns in C only.
+    struct QuadCon { uint64_t c; uint32_t in_ab = 0, in_c = 0; };
+    std::vector<QuadCon> qc;
+    const uint32_t QFLAG = 1u << 31;
+    for (uint64_t c = 0; c < r.n_cons; c++) {
+        F k0;
+        if (only_one(c, 0, k0) || only_one(c, 1, k0)) continue;
+        QuadCon q; q.c = c;
+        std::vector<uint32_t> ab, cc;
+        for (int part = 0; part < 3; part++)
+            for (uint64_t t = r.off[3 * c + part]; t < r.off[3 * c + part + 1]; t++) {
+                const uint32_t w = r.wire[t];
+                if (w == 0 || m->index[w] != ~0ull) continue;
+                std::vector<uint32_t>& dst = part < 2 ? ab : cc;
+                if (std::find(dst.begin(), dst.end(), w) == dst.end()) dst.push_back(w);
+            }
+        for (uint32_t w : ab) cc.erase(std::remove(cc.begin(), cc.end(), w), cc.end());   // in A or B: counted there
+        if (ab.empty() && cc.empty()) continue;
+        if (qc.size() >= QFLAG) break;
+        q.in_ab = (uint32_t)ab.size(); q.in_c = (uint32_t)cc.size();
+        for (uint32_t w : ab) uses[w].push_back(QFLAG | (uint32_t)qc.size());
+        for (uint32_t w : cc) uses[w].push_back(QFLAG | (uint32_t)qc.size());
+        qc.push_back(q);
+    }
+    auto index_form = [&](uint64_t c, int part, const F& scale, uint32_t skip, LinForm& lf) {   // scale * (combination `part` without `skip`)
+        lf.c0 = hzh::f_zero();
+        lf.terms.clear();
+        for (uint64_t t = r.off[3 * c + part]; t < r.off[3 * c + part + 1]; t++) {
+            const uint32_t w = r.wire[t];
+            if (w == skip && skip != 0) continue;
+            const F k = hzh::f_mul(scale, r.pool[r.coef[t]]);
+            if (w == 0) lf.c0 = hzh::f_add(lf.c0, k);
+            else lf.terms.push_back({k, m->index[w]});
+        }
+    };
     std::vector<uint32_t> work;
     for (uint32_t i = 0; i < lc.size(); i++)
         if (lc[i].unknown == 1) work.push_back(i);
+    for (uint32_t i = 0; i < qc.size(); i++)
+        if (qc[i].in_ab == 0 && qc[i].in_c == 1) work.push_back(QFLAG | i);
+    auto solved = [&](uint32_t u) {
+        m->n_solved++;
+        for (uint32_t j : uses[u]) {
+            if (j & QFLAG) {
+                QuadCon& q = qc[j & ~QFLAG];
+                // which count the variable was in: A / B terms are looked at first
+                bool in_ab = false;
+                for (int part = 0; part < 2 && !in_ab; part++)
+                    for (uint64_t t = r.off[3 * q.c + part]; t < r.off[3 * q.c + part + 1] && !in_ab; t++) in_ab = r.wire[t] == u;
+                if (in_ab) q.in_ab--; else q.in_c--;
+                if (q.in_ab == 0 && q.in_c == 1) work.push_back(j);
+            } else if (lc[j].unknown && --lc[j].unknown == 1) work.push_back(j);
+        }
+    };
     while (!work.empty()) {
         const uint32_t i = work.back();
         work.pop_back();
+        if (i & QFLAG) {
+            const QuadCon& q = qc[i & ~QFLAG];
+            if (q.in_ab != 0 || q.in_c != 1) continue;
+            uint32_t u = 0; F ku = hzh::f_zero();
+            for (uint64_t t = r.off[3 * q.c + 2]; t < r.off[3 * q.c + 3]; t++)
+                if (r.wire[t] != 0 && m->index[r.wire[t]] == ~0ull) { u = r.wire[t]; ku = hzh::f_add(ku, r.pool[r.coef[t]]); }
+            if (!u || hzh::f_is_zero(ku)) continue;
+            const F s = hzh::f_inv(ku);          // w_u = (1 / k_u) * (A * B - the rest of C)
+            LinForm fa, fb, fr;
+            index_form(q.c, 0, s, 0, fa);
+            index_form(q.c, 1, hzh::f_one(), 0, fb);
+            index_form(q.c, 2, f_neg(s), u, fr);
+            DerivedVar d;
+            d.kind = DV_PRODUCT; d.lin = (uint32_t)m->lins.size();
+            m->lins.push_back(std::move(fa)); m->lins.push_back(std::move(fb)); m->lins.push_back(std::move(fr));
+            m->derived.push_back(d);
+            m->index[u] = DERIVED_FLAG | (m->derived.size() - 1);
+            solved(u);
+            continue;
+        }
         LinCon& con = lc[i];
         if (con.unknown != 1) continue;
         uint32_t u = 0; F ku = hzh::f_zero();
@@ -849,9 +926,7 @@ void solve_linear(hz_symmap* m) {
             m->derived.push_back(d);
             m->index[u] = DERIVED_FLAG | (m->derived.size() - 1);
         }
-        m->n_solved++;
-        for (uint32_t j : uses[u])
-            if (lc[j].unknown && --lc[j].unknown == 1) work.push_back(j);
+        solved(u);
     }
 }
 hz_status symmap_build(const hz_ctx* ctx, const char* text, size_t len, const uint8_t* r1cs, size_t r1cs_len, hz_symmap** out);

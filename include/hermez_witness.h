@@ -230,7 +230,9 @@ uint64_t hz_symmap_derived(const hz_symmap* map);
 /* .sym AND .r1cs of the same compile (tools/helpers/actions.js:30-68 writes both). Variables that no label resolves -- the
  * wire-through signals an unreduced compile keeps: inputs of sub-components, aliases of their outputs, Bits2Num sums, comparator
  * differences, for ANY circuit and circomlib version -- are solved from the circuit's own LINEAR constraints: one with exactly one
- * unknown variable defines it over known ones, and so on until nothing changes (hz_symmap_solved = how many). The r1cs stays with
+ * unknown variable defines it over known ones, and so on until nothing changes (hz_symmap_solved = how many); a product constraint
+ * A * B = C whose A and B are known and whose C holds one unknown variable defines that one too (a product signal the layout does
+ * not store under that name, e.g. MultiMux4's terms over constant inputs). The r1cs stays with
  * the map: hz_symmap_check_r1cs evaluates every constraint (A.w)(B.w) = C.w on the witness as the map serves it -- what
  * `snarkjs wtns check` would do with the .wtns this library writes -- and returns the number of violated constraints and the
  * indices of the first `cap` of them. r1cs: iden3 binary format version 1, field BN254 Fr; circom's wire w is variable w. */

@@ -59,33 +59,51 @@ def linear_constraints(m):
 
 
 def solve(m, known):
-    """values for every name from `known` {name: value} by propagation through the linear constraints (one with exactly one unknown
-    name defines it). Returns (values, names that stayed unknown)."""
+    """values for every name from `known` {name: value} by propagation: a linear constraint with exactly one unknown name defines
+    it; so does a product constraint A * B = C whose A and B are known and whose C holds exactly one unknown name (a product
+    signal the witness does not store under that name). Returns (values, names that stayed unknown)."""
     val = dict(known)
-    cons = linear_constraints(m)
+    lin = linear_constraints(m)
+    n_lin = len(lin)
+    # constraint i < n_lin: linear (constant, terms) == 0; otherwise the product line quads[i - n_lin]
+    quads = [(_lin(a), _lin(b), _lin(c)) for a, b, c in m["quads"] if a[1] and b[1]]
+    names_of = [[n for _, n in t] for _, t in lin] + [[n for f in q for _, n in f[1]] for q in quads]
     where = {}
-    for i, (_, t) in enumerate(cons):
-        for _, n in t:
+    for i, ns in enumerate(names_of):
+        for n in ns:
             where.setdefault(n, []).append(i)
-    unknown = [sum(1 for _, n in t if n not in val) for _, t in cons]
-    work = [i for i, u in enumerate(unknown) if u == 1]
+
+    def ready(i):
+        """the single unknown name constraint i can define, or None"""
+        unk = {n for n in names_of[i] if n not in val}
+        if len(unk) != 1:
+            return None
+        u = next(iter(unk))
+        if i >= n_lin:
+            a, b, _ = quads[i - n_lin]
+            if any(n == u for _, n in a[1]) or any(n == u for _, n in b[1]):
+                return None
+        return u
+    work = [i for i in range(len(names_of)) if ready(i) is not None]
+    ev = lambda f: (f[0] + sum(k * val[n] for k, n in f[1])) % P   # noqa: E731
     while work:
         i = work.pop()
-        if unknown[i] != 1:
+        u = ready(i)
+        if u is None:
             continue
-        c, t = cons[i]
-        acc, coef, name = c, 0, None
-        for k, n in t:
-            if n in val:
-                acc += k * val[n]
-            else:
-                coef, name = (coef + k) % P, n
+        if i < n_lin:
+            c, t = lin[i]
+            rest = (c + sum(k * val[n] for k, n in t if n != u)) % P
+            coef = sum(k for k, n in t if n == u) % P
+        else:
+            a, b, c = quads[i - n_lin]
+            rest = (c[0] + sum(k * val[n] for k, n in c[1] if n != u) - ev(a) * ev(b)) % P
+            coef = sum(k for k, n in c[1] if n == u) % P
         if coef == 0:
             continue
-        val[name] = (-acc) * pow(coef, P - 2, P) % P
-        for j in where[name]:
-            unknown[j] = sum(1 for _, n in cons[j][1] if n not in val)
-            if unknown[j] == 1:
+        val[u] = (-rest) * pow(coef, P - 2, P) % P
+        for j in where[u]:
+            if ready(j) is not None:
                 work.append(j)
     return val, [n for n in all_names(m) if n not in val]
 

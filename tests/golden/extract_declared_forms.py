@@ -15,7 +15,9 @@ tests/golden/declared_forms.json.gz -- per main template and shape
 -- data, no source text. The sources of circomlib 0.5.2 are not in the reference repository; its templates are black boxes here:
 their inputs receive forms from the reference's wiring, their outputs are symbols. The few whose outputs are LINEAR in their inputs
 or wrap another component (Bits2Num, LessThan and its family, IsEqual, ForceEqualIfEnabled, NOT, Switcher, Mux1..Mux4) are stated in
-MODELS from circomlib's published sources.
+`Run.model` from circomlib's published sources, and so are the constraints of its small gadgets the reference's logic is made of:
+Num2Bits (bits are bits, their sum is the input), IsZero, ForceEqualIfEnabled, MultiMux1..4 (every product term). Poseidon, SHA-256,
+the sparse Merkle tree and the EdDSA verifier stay opaque (they are pinned by upstream known answers).
 
 tests/test_declared_signals.py imports these names as a .sym, asks the library for every value and compares it with the form
 evaluated on the oracle's witness.
@@ -331,12 +333,24 @@ def arr(dims, fill):
 class Run:
     def __init__(self, defs):
         self.defs = defs
-        self.forms, self.bases, self.declared, self.quads = {}, set(), [], []
+        self.forms, self.bases, self.declared, self.quads, self.models_used = {}, set(), [], [], set()
 
     # -- black boxes: circomlib templates whose outputs are linear in their inputs or that wrap another component ----------------
     def model(self, tmpl, path, args):
         f = self.forms
         one = lambda n: Lin(0, {n: 1})   # noqa: E731
+        q = lambda a, b, c: self.quads.append((Lin.of(a), Lin.of(b), Lin.of(c)))   # noqa: E731   a * b = c
+        self.models_used.add(tmpl)
+        if tmpl == "Num2Bits":           # bitify.circom: out[i] * (out[i] - 1) === 0; sum of 2^i out[i] === in
+            acc = Lin()
+            for i in range(args[0]):
+                b = one("%s.out[%d]" % (path, i))
+                q(b, b.add(Lin(1), -1), Lin())
+                acc = acc.add(b.scale(1 << i))
+            q(Lin(), Lin(), acc.add(one(path + ".in"), -1))
+        elif tmpl == "IsZero":           # comparators.circom: out <== -in * inv + 1; in * out === 0
+            q(one(path + ".in").scale(-1), one(path + ".inv"), one(path + ".out").add(Lin(1), -1))
+            q(one(path + ".in"), one(path + ".out"), Lin())
         if tmpl == "Bits2Num":
             acc = Lin()
             for i in range(args[0]):
@@ -346,6 +360,7 @@ class Run:
             n = args[0]
             f[path + ".n2b.in"] = one(path + ".in[0]").add(Lin(1 << n)).add(one(path + ".in[1]"), -1)
             f[path + ".out"] = Lin(1).add(one("%s.n2b.out[%d]" % (path, n)), -1)
+            self.model("Num2Bits", path + ".n2b", [n + 1])
         elif tmpl in ("GreaterThan", "LessEqThan", "GreaterEqThan"):
             a, b = (1, 0) if tmpl != "LessEqThan" else (0, 1)
             f[path + ".lt.in[0]"] = one("%s.in[%d]" % (path, a))
@@ -354,8 +369,11 @@ class Run:
             self.model("LessThan", path + ".lt", args)
         elif tmpl in ("IsEqual", "ForceEqualIfEnabled"):
             f[path + ".isz.in"] = one(path + ".in[1]").add(one(path + ".in[0]"), -1)
+            self.model("IsZero", path + ".isz", [])
             if tmpl == "IsEqual":
                 f[path + ".out"] = one(path + ".isz.out")
+            else:                        # (1 - isz.out) * enabled === 0
+                q(Lin(1).add(one(path + ".isz.out"), -1), one(path + ".enabled"), Lin())
         elif tmpl == "NOT":
             f[path + ".out"] = Lin(1).add(one(path + ".in"), -1)
         elif tmpl == "Switcher":
@@ -374,12 +392,47 @@ class Run:
             # MultiMux<k>(1): the term without a selector is a signal of its own, so is the difference that only the top selector
             # multiplies; MultiMux2's output is the plain sum of its terms (mux2.circom / mux3.circom / mux4.circom)
             m = path + ".mux."
-            f[m + "a[0]"] = one(m + "c[0][0]")
-            if k == 2:
-                f[m + "out[0]"] = one(m + "a10[0]").add(one(m + "a1[0]")).add(one(m + "a0[0]")).add(one(m + "a[0]"))
-            elif k >= 3:
-                top = 1 << (k - 1)
-                f["%sa%d[0]" % (m, k - 1)] = one("%sc[0][%d]" % (m, top)).add(one(m + "c[0][0]"), -1)
+            c = lambda i: one("%sc[0][%d]" % (m, i))   # noqa: E731
+            sel = lambda i: one(m + "s") if k == 1 else one("%ss[%d]" % (m, i))   # noqa: E731
+            if k == 1:                   # mux1.circom: out[i] <== (c[i][1] - c[i][0]) * s + c[i][0]
+                q(c(1).add(c(0), -1), sel(0), one(m + "out[0]").add(c(0), -1))
+                return
+            # MultiMux2 / 3 / 4 (n = 1): the multilinear expansion over the LOW selector bits, one signal per term -- a<bits>[0] =
+            # (alternating sum of the inputs below that bit set) * (product of those selector bits); the products of two and three
+            # selector bits are signals themselves (s10, s20, s21, s210 <== s21 * s[0]); Mux3 / Mux4 keep the top bit apart:
+            # out <== (sum of the terms with the top bit) * s[top] + (sum of the terms without)
+            low = 2 if k <= 3 else 3
+            top = low if k >= 3 else None
+            digits = lambda T: "".join(str(b) for b in sorted(T, reverse=True))   # noqa: E731
+            subsets = [[b for b in range(low) if (x >> b) & 1] for x in range(1 << low)]
+            for T in subsets:
+                if len(T) == 2:
+                    q(sel(T[1]), sel(T[0]), one("%ss%s" % (m, digits(T))))
+                elif len(T) == 3:
+                    q(one(m + "s21"), sel(0), one(m + "s210"))
+
+            def prod_of(T):
+                return None if not T else sel(T[0]) if len(T) == 1 else one("%ss%s" % (m, digits(T)))
+            sums = {False: Lin(), True: Lin()}
+            for with_top in ([False, True] if top is not None else [False]):
+                for T in subsets:
+                    alt = Lin()
+                    for x in range(1 << len(T)):
+                        U = [T[j] for j in range(len(T)) if (x >> j) & 1]
+                        idx = sum(1 << b for b in U)
+                        sign = -1 if (len(T) - len(U)) % 2 else 1
+                        term = c(idx + (1 << top)).add(c(idx), -1) if with_top else c(idx)
+                        alt = alt.add(term, sign)
+                    name = "%sa%s%s[0]" % (m, str(top) if with_top else "", digits(T))
+                    if T:
+                        q(alt, prod_of(T), one(name))
+                    else:
+                        f[name] = alt
+                    sums[with_top] = sums[with_top].add(one(name))
+            if top is None:
+                f[m + "out[0]"] = sums[False]
+            else:
+                q(sums[True], sel(top), one(m + "out[0]").add(sums[False], -1))
 
     # -- templates ---------------------------------------------------------------------------------------------------------------------
     def instantiate(self, tmpl, args, path):

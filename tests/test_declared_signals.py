@@ -200,7 +200,8 @@ def test_hip_serves_every_declared_signal_through_sym_and_r1cs(hz, key):
     assert len(alone.unresolved()) <= mp.solved()
     # a system the witness does NOT satisfy: the constant of one product constraint changed
     m2 = copy.deepcopy(m)
-    products = [i for i, (a, b, _) in enumerate(m2["quads"]) if a[1] and b[1]]   # (a linear === line may DEFINE a variable instead)
+    # a product line all of whose signals the witness STORES (any other may define a variable instead of constraining one)
+    products = [i for i, (a, b, c) in enumerate(m2["quads"]) if a[1] and b[1] and all(n in known for f in (a, b, c) for _, n in f[1])]
     if not products:
         return
     q = products[len(products) // 2]
@@ -253,7 +254,7 @@ def test_hip_native_binary_with_the_compilers_sym_and_r1cs(hz, tmp_path):
     assert r.returncode == 1 and "not stored by this layout" in r.stderr and not os.path.exists(str(tmp_path / "no.wtns"))
     # an .r1cs this witness does not satisfy
     m2 = copy.deepcopy(m)
-    q = [i for i, (a, b, _) in enumerate(m2["quads"]) if a[1] and b[1]][3]
+    q = [i for i, (a, b, c) in enumerate(m2["quads"]) if a[1] and b[1] and all(n in known for f in (a, b, c) for _, n in f[1])][3]
     m2["quads"][q][2][0] = str((int(m2["quads"][q][2][0]) + 5) % DF.P)
     open(rpath, "wb").write(DF.sym_and_r1cs(m2)[1])
     r = subprocess.run([cli, "RollupTx(16,2)", ipath, str(tmp_path / "bad.wtns"), "--circom-sym", spath, "--circom-r1cs", rpath, "--check"], stderr=subprocess.PIPE, text=True)
