@@ -17,6 +17,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "hostutil.h"
 #include "derived.h"
@@ -309,7 +310,7 @@ struct hz_symmap {
     std::vector<uint64_t> unresolved;     // variable numbers
     std::vector<DerivedVar> derived;
     std::vector<LinForm> lins;
-    std::map<std::string, uint64_t> memo; // name -> resolved index (rules refer to each other)
+    std::unordered_map<std::string, uint64_t> memo; // name -> resolved index of a DERIVED signal (rules refer to each other); stored names are looked up each time
     struct PosBlk { int t; uint64_t first, stride; };
     std::map<std::string, PosBlk> pos_memo;   // component prefix -> its Poseidon block (t = 0: not one)
     uint64_t n_derived = 0, n_solved = 0;
@@ -535,10 +536,10 @@ bool parse_linear(const hz_ctx* ctx, hz_symmap* m, const std::string& prefix, co
 // this library's index of a signal name: a stored signal, DERIVED_FLAG | k for one a rule evaluates, ~0 when neither
 uint64_t resolve_name(const hz_ctx* ctx, hz_symmap* m, const std::string& name_in, int depth) {
     const std::string name = name_in.compare(0, 5, "main.") == 0 ? name_in : "main." + name_in;
+    uint64_t idx = 0;
+    if (hz_symbol_lookup(ctx, name.c_str(), &idx)) return idx;   // (not memoised: a .sym of 10^8 stored names would build a table of them)
     auto it = m->memo.find(name);
     if (it != m->memo.end()) return it->second;
-    uint64_t idx = 0;
-    if (hz_symbol_lookup(ctx, name.c_str(), &idx)) return m->memo[name] = idx;
     if (depth > 4) return ~0ull;
     DerivedVar d;
     if (resolve_poseidon(ctx, m, name, d)) {
@@ -950,7 +951,8 @@ hz_status symmap_build(const hz_ctx* ctx, const char* text, size_t len, const ui
     uint64_t line_no = 0;
     uint64_t n_lines = 1;
     for (const char* c = text; c < e; c++) n_lines += *c == '\n';
-    const uint64_t var_cap = std::min<uint64_t>(n_lines, 8 * hz_witness_len(ctx) + 1024);
+    // (this library's own .sym numbers by witness position and leaves positions without a name: as many variables as the witness is long)
+    const uint64_t var_cap = std::min<uint64_t>(std::max<uint64_t>(n_lines, hz_witness_len(ctx)) + 1024, 8 * hz_witness_len(ctx) + 1024);
     while (p < e) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
         const char* le = nl ? nl : e;

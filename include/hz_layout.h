@@ -623,6 +623,32 @@ inline long sha_sigindex(const std::string& rest) {
     return -1;
 }
 
+// the inverse of poseidon_signame: ".sigmaF[r][j].in2" / ".sigmaP[k].out" -> index of the signal inside the component, or -1
+inline int poseidon_sigindex(int t, const std::string& suffix) {
+    const int rp = poseidon_rp(t);
+    const char* p = suffix.c_str();
+    const bool full = suffix.compare(0, 8, ".sigmaF[") == 0;
+    if (!full && suffix.compare(0, 8, ".sigmaP[") != 0) return -1;
+    p += 8;
+    char* e = nullptr;
+    const long a = strtol(p, &e, 10);
+    if (e == p || *e != ']' || a < 0) return -1;
+    p = e + 1;
+    long k;
+    if (full) {
+        if (*p != '[') return -1;
+        const long j = strtol(p + 1, &e, 10);
+        if (e == p + 1 || *e != ']' || j < 0 || j >= t || a >= 8) return -1;
+        p = e + 1;
+        k = a < 4 ? a * t + j : 4 * t + rp + (a - 4) * t + j;
+    } else {
+        if (a >= rp) return -1;
+        k = 4 * t + a;
+    }
+    const int sidx = !strcmp(p, ".in2") ? 0 : !strcmp(p, ".in4") ? 1 : !strcmp(p, ".out") ? 2 : -1;
+    return sidx < 0 ? -1 : (int)(3 * k + sidx);
+}
+
 struct Layout;
 inline void build_layout(const Params& p, Layout& out);  // defined below
 
@@ -762,10 +788,8 @@ struct Layout {
             if (unit < 0 || (uint64_t)unit >= units) return false;
             if (b.kind == BK_POSEIDON) {
                 if (suffix.empty() || has_k) return false;
-                pj = -1;
-                for (uint32_t j = 0; j < b.count; j++)
-                    if (poseidon_signame(b.t, (int)j) == suffix) { pj = (int)j; break; }
-                if (pj < 0) return false;
+                pj = poseidon_sigindex(b.t, suffix);
+                if (pj < 0 || (uint32_t)pj >= b.count) return false;
                 *out = virt(it->second.first, b.off + (uint32_t)pj, (uint32_t)unit);
                 return true;
             }

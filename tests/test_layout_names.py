@@ -131,3 +131,26 @@ def test_intermediate_signals_of_reference_templates_are_stored_or_linear():
     assert not missing, missing
     # and the layout stores no reference intermediate that the source defines as linear, except as noted: none
     assert sum(1 for v in kinds.values() if v == "linear") == 16 and sum(1 for v in kinds.values() if v != "linear") == 21
+
+
+def test_poseidon_signal_names_and_lookup_are_inverse():
+    """every stored signal of a Poseidon component by its circom name (sigmaF[r][j] / sigmaP[k] . in2 / in4 / out) resolves to its
+    position, in order; names outside the component's ranges do not resolve (the lookup computes the index from the name)"""
+    o = OracleCtx("hash-state")
+    t, rp = 5, 60
+    names = []
+    for k in range(8 * t + rp):
+        for s in ("in2", "in4", "out"):
+            if k < 4 * t:
+                nm = ".sigmaF[%d][%d].%s" % (k // t, k % t, s)
+            elif k < 4 * t + rp:
+                nm = ".sigmaP[%d].%s" % (k - 4 * t, s)
+            else:
+                nm = ".sigmaF[%d][%d].%s" % (4 + (k - 4 * t - rp) // t, (k - 4 * t - rp) % t, s)
+            names.append("main.hash" + nm)
+    idx = [o.lookup(n) for n in names]
+    assert idx == list(range(idx[0], idx[0] + len(names)))
+    for bad in ("main.hash.sigmaF[8][0].in2", "main.hash.sigmaF[0][5].in2", "main.hash.sigmaP[60].out", "main.hash.sigmaP[1].in3", "main.hash.sigmaF[0][0].in2x",
+                "main.hash.sigmaF[-1][0].in2", "main.hash.sigmaF[0].in2"):
+        with pytest.raises(KeyError):
+            o.lookup(bad)
