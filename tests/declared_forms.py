@@ -24,6 +24,8 @@ def _lin(f):
 
 def all_names(m):
     """every signal name of the system, in a fixed order"""
+    if "_names" in m:
+        return list(m["_names"])   # (a copy: callers shuffle it)
     names, seen = [], set()
 
     def add(n):
@@ -42,7 +44,8 @@ def all_names(m):
                 add(t)
     for n in m["bases"]:
         add(n)
-    return names
+    m["_names"] = names
+    return list(names)
 
 
 def linear_constraints(m):
@@ -58,54 +61,65 @@ def linear_constraints(m):
     return out
 
 
+def _system(m):
+    """the constraints in the solver's form, cached on the fixture object: (linear [(constant, [(coefficient, name)])],
+    products [(A, B, C)], names of each, for products the names of A and B)"""
+    if "_sys" not in m:
+        lin = linear_constraints(m)
+        quads = [(_lin(a), _lin(b), _lin(c)) for a, b, c in m["quads"] if a[1] and b[1]]
+        names_of = [sorted({n for _, n in t}) for _, t in lin] + [sorted({n for f in q for _, n in f[1]}) for q in quads]
+        ab_of = [frozenset(n for f in q[:2] for _, n in f[1]) for q in quads]
+        where = {}
+        for i, ns in enumerate(names_of):
+            for n in ns:
+                where.setdefault(n, []).append(i)
+        m["_sys"] = (lin, quads, names_of, ab_of, where)
+    return m["_sys"]
+
+
 def solve(m, known):
     """values for every name from `known` {name: value} by propagation: a linear constraint with exactly one unknown name defines
     it; so does a product constraint A * B = C whose A and B are known and whose C holds exactly one unknown name (a product
     signal the witness does not store under that name). Returns (values, names that stayed unknown)."""
     val = dict(known)
-    lin = linear_constraints(m)
+    lin, quads, names_of, ab_of, where = _system(m)
     n_lin = len(lin)
-    # constraint i < n_lin: linear (constant, terms) == 0; otherwise the product line quads[i - n_lin]
-    quads = [(_lin(a), _lin(b), _lin(c)) for a, b, c in m["quads"] if a[1] and b[1]]
-    names_of = [[n for _, n in t] for _, t in lin] + [[n for f in q for _, n in f[1]] for q in quads]
-    where = {}
-    for i, ns in enumerate(names_of):
-        for n in ns:
-            where.setdefault(n, []).append(i)
-
-    def ready(i):
-        """the single unknown name constraint i can define, or None"""
-        unk = {n for n in names_of[i] if n not in val}
-        if len(unk) != 1:
-            return None
-        u = next(iter(unk))
-        if i >= n_lin:
-            a, b, _ = quads[i - n_lin]
-            if any(n == u for _, n in a[1]) or any(n == u for _, n in b[1]):
-                return None
-        return u
-    work = [i for i in range(len(names_of)) if ready(i) is not None]
-    ev = lambda f: (f[0] + sum(k * val[n] for k, n in f[1])) % P   # noqa: E731
+    unknown = [sum(1 for n in ns if n not in val) for ns in names_of]
+    work = [i for i, u in enumerate(unknown) if u == 1]
     while work:
         i = work.pop()
-        u = ready(i)
-        if u is None:
+        if unknown[i] != 1:
             continue
+        u = next(n for n in names_of[i] if n not in val)
         if i < n_lin:
             c, t = lin[i]
-            rest = (c + sum(k * val[n] for k, n in t if n != u)) % P
-            coef = sum(k for k, n in t if n == u) % P
+            rest, coef = c, 0
+            for k, n in t:
+                if n == u:
+                    coef += k
+                else:
+                    rest += k * val[n]
         else:
+            if u in ab_of[i - n_lin]:
+                continue   # unknown inside a factor: this line cannot define it
             a, b, c = quads[i - n_lin]
-            rest = (c[0] + sum(k * val[n] for k, n in c[1] if n != u) - ev(a) * ev(b)) % P
-            coef = sum(k for k, n in c[1] if n == u) % P
+            ea = a[0] + sum(k * val[n] for k, n in a[1])
+            eb = b[0] + sum(k * val[n] for k, n in b[1])
+            rest, coef = c[0] - ea * eb, 0
+            for k, n in c[1]:
+                if n == u:
+                    coef += k
+                else:
+                    rest += k * val[n]
+        coef %= P
         if coef == 0:
             continue
         val[u] = (-rest) * pow(coef, P - 2, P) % P
         for j in where[u]:
-            if ready(j) is not None:
+            unknown[j] -= 1
+            if unknown[j] == 1:
                 work.append(j)
-    return val, [n for n in all_names(m) if n not in val]
+    return val, [n for n in m.get("_names") or all_names(m) if n not in val]
 
 
 def solve_with_hashes(m, known, poseidon):

@@ -331,8 +331,9 @@ def arr(dims, fill):
 
 
 class Run:
-    def __init__(self, defs):
+    def __init__(self, defs, sha_model=False):
         self.defs = defs
+        self.sha_model = sha_model   # Sha256 with every wire and constraint (one main only: 40 k signals per block), else a black box
         self.forms, self.bases, self.declared, self.quads, self.models_used = {}, set(), [], [], set()
 
     # -- black boxes: circomlib templates whose outputs are linear in their inputs or that wrap another component ----------------
@@ -341,6 +342,9 @@ class Run:
         one = lambda n: Lin(0, {n: 1})   # noqa: E731
         q = lambda a, b, c: self.quads.append((Lin.of(a), Lin.of(b), Lin.of(c)))   # noqa: E731   a * b = c
         self.models_used.add(tmpl)
+        if tmpl == "Sha256" and self.sha_model:
+            self.sha256(path, args[0])
+            return
         if tmpl == "Num2Bits":           # bitify.circom: out[i] * (out[i] - 1) === 0; sum of 2^i out[i] === in
             acc = Lin()
             for i in range(args[0]):
@@ -433,6 +437,154 @@ class Run:
                 f[m + "out[0]"] = sums[False]
             else:
                 q(sums[True], sel(top), one(m + "out[0]").add(sums[False], -1))
+
+    # -- circomlib 0.5.2 sha256/*.circom as published: every wire and every constraint of Sha256(nBits) -----------------------------------
+    def sha256(self, P, n_bits):
+        f = self.forms
+        one = lambda n: Lin(0, {n: 1})   # noqa: E731
+        q = lambda a, b, c: self.quads.append((Lin.of(a), Lin.of(b), Lin.of(c)))   # noqa: E731
+        H0 = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+        K = [0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+             0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+             0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+             0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+             0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+             0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+        nb = (n_bits + 64) // 512 + 1
+
+        def wire(dst, src):
+            f[dst] = src if isinstance(src, Lin) else one(src)
+
+        def binsum(B, ops):            # binsum.circom: out bits are bits; sum of 2^k in[j][k] === sum of 2^k out[k]
+            nout = ((2 ** 32 - 1) * ops).bit_length()
+            lin, lout = Lin(), Lin()
+            for k in range(32):
+                for j in range(ops):
+                    lin = lin.add(one("%s.in[%d][%d]" % (B, j, k)).scale(1 << k))
+            for k in range(nout):
+                b = one("%s.out[%d]" % (B, k))
+                q(b, b.add(Lin(1), -1), Lin())
+                lout = lout.add(b.scale(1 << k))
+            q(Lin(), Lin(), lin.add(lout, -1))
+
+        def xor3(X):                   # xor3.circom: mid = b * c; out = a * (1 - 2b - 2c + 4 mid) + b + c - 2 mid
+            for k in range(32):
+                a, b, c, mid = (one("%s.%s[%d]" % (X, n, k)) for n in ("a", "b", "c", "mid"))
+                q(b, c, mid)
+                q(a, Lin(1).add(b.scale(2), -1).add(c.scale(2), -1).add(mid.scale(4)), one("%s.out[%d]" % (X, k)).add(b, -1).add(c, -1).add(mid.scale(2)))
+
+        def sigma(G, ra, rb, rc, big):  # sigma.circom: SmallSigma = RotR, RotR, ShR; BigSigma = three RotR; then Xor3
+            for nm, r, shift in (("rota", ra, False), ("rotb", rb, False), ("rotc" if big else "shrc", rc, not big)):
+                for k in range(32):
+                    wire("%s.%s.in[%d]" % (G, nm, k), "%s.in[%d]" % (G, k))
+                    if shift:
+                        wire("%s.%s.out[%d]" % (G, nm, k), Lin() if k + r >= 32 else one("%s.%s.in[%d]" % (G, nm, k + r)))
+                    else:
+                        wire("%s.%s.out[%d]" % (G, nm, k), "%s.%s.in[%d]" % (G, nm, (k + r) % 32))
+            for k in range(32):
+                wire("%s.xor3.a[%d]" % (G, k), "%s.rota.out[%d]" % (G, k))
+                wire("%s.xor3.b[%d]" % (G, k), "%s.rotb.out[%d]" % (G, k))
+                wire("%s.xor3.c[%d]" % (G, k), "%s.%s.out[%d]" % (G, "rotc" if big else "shrc", k))
+                wire("%s.out[%d]" % (G, k), "%s.xor3.out[%d]" % (G, k))
+            xor3(G + ".xor3")
+
+        for k in range(nb * 512):
+            if k < n_bits:
+                src = one("%s.in[%d]" % (P, k))
+            elif k == n_bits:
+                src = Lin(1)
+            elif k < nb * 512 - 64:
+                src = Lin()
+            else:
+                src = Lin((n_bits >> (nb * 512 - 1 - k)) & 1)
+            wire("%s.paddedIn[%d]" % (P, k), src)
+        for j in range(8):
+            for k in range(32):
+                wire("%s.ha%d.out[%d]" % (P, j, k), Lin((H0[j] >> k) & 1))
+        regs = "abcdefgh"
+        for i in range(nb):
+            C = "%s.sha256compression[%d]" % (P, i)
+            for j in range(8):
+                for k in range(32):
+                    wire("%s.hin[%d]" % (C, 32 * j + k), "%s.ha%d.out[%d]" % (P, j, k) if i == 0 else "%s.sha256compression[%d].out[%d]" % (P, i - 1, 32 * j + 31 - k))
+            for k in range(512):
+                wire("%s.inp[%d]" % (C, k), "%s.paddedIn[%d]" % (P, i * 512 + k))
+            for t in range(64):
+                for k in range(32):
+                    wire("%s.ct_k[%d].out[%d]" % (C, t, k), Lin((K[t] >> k) & 1))
+                if t >= 16:
+                    S = "%s.sigmaPlus[%d]" % (C, t - 16)
+                    for k in range(32):
+                        wire("%s.in2[%d]" % (S, k), "%s.w[%d][%d]" % (C, t - 2, k))
+                        wire("%s.in7[%d]" % (S, k), "%s.w[%d][%d]" % (C, t - 7, k))
+                        wire("%s.in15[%d]" % (S, k), "%s.w[%d][%d]" % (C, t - 15, k))
+                        wire("%s.in16[%d]" % (S, k), "%s.w[%d][%d]" % (C, t - 16, k))
+                        wire("%s.sigma1.in[%d]" % (S, k), "%s.in2[%d]" % (S, k))
+                        wire("%s.sigma0.in[%d]" % (S, k), "%s.in15[%d]" % (S, k))
+                        wire("%s.sum.in[0][%d]" % (S, k), "%s.sigma1.out[%d]" % (S, k))
+                        wire("%s.sum.in[1][%d]" % (S, k), "%s.in7[%d]" % (S, k))
+                        wire("%s.sum.in[2][%d]" % (S, k), "%s.sigma0.out[%d]" % (S, k))
+                        wire("%s.sum.in[3][%d]" % (S, k), "%s.in16[%d]" % (S, k))
+                        wire("%s.out[%d]" % (S, k), "%s.sum.out[%d]" % (S, k))
+                    sigma(S + ".sigma1", 17, 19, 10, False)
+                    sigma(S + ".sigma0", 7, 18, 3, False)
+                    binsum(S + ".sum", 4)
+                for k in range(32):
+                    wire("%s.w[%d][%d]" % (C, t, k), "%s.inp[%d]" % (C, t * 32 + 31 - k) if t < 16 else "%s.sigmaPlus[%d].out[%d]" % (C, t - 16, k))
+            for j, rname in enumerate(regs):
+                for k in range(32):
+                    wire("%s.%s[0][%d]" % (C, rname, k), "%s.hin[%d]" % (C, 32 * j + k))
+            for t in range(64):
+                T1, T2 = "%s.t1[%d]" % (C, t), "%s.t2[%d]" % (C, t)
+                for k in range(32):
+                    for nm in "hefg":
+                        wire("%s.%s[%d]" % (T1, nm, k), "%s.%s[%d][%d]" % (C, nm, t, k))
+                    wire("%s.k[%d]" % (T1, k), "%s.ct_k[%d].out[%d]" % (C, t, k))
+                    wire("%s.w[%d]" % (T1, k), "%s.w[%d][%d]" % (C, t, k))
+                    for nm in "abc":
+                        wire("%s.%s[%d]" % (T2, nm, k), "%s.%s[%d][%d]" % (C, nm, t, k))
+                    # T1: ch = Ch_t(32) on (e, f, g), bigsigma1 = BigSigma(6, 11, 25) on e, sum = BinSum(32, 5) of h, bigsigma1, ch, k, w
+                    wire("%s.bigsigma1.in[%d]" % (T1, k), "%s.e[%d]" % (T1, k))
+                    wire("%s.ch.a[%d]" % (T1, k), "%s.e[%d]" % (T1, k))
+                    wire("%s.ch.b[%d]" % (T1, k), "%s.f[%d]" % (T1, k))
+                    wire("%s.ch.c[%d]" % (T1, k), "%s.g[%d]" % (T1, k))
+                    a, b, c = (one("%s.ch.%s[%d]" % (T1, n, k)) for n in "abc")
+                    q(a, b.add(c, -1), one("%s.ch.out[%d]" % (T1, k)).add(c, -1))          # ch.circom: out = a * (b - c) + c
+                    for j, src in enumerate(("h[%d]" % k, "bigsigma1.out[%d]" % k, "ch.out[%d]" % k, "k[%d]" % k, "w[%d]" % k)):
+                        wire("%s.sum.in[%d][%d]" % (T1, j, k), "%s.%s" % (T1, src))
+                    wire("%s.out[%d]" % (T1, k), "%s.sum.out[%d]" % (T1, k))
+                    # T2: bigsigma0 = BigSigma(2, 13, 22) on a, maj = Maj_t(32) on (a, b, c), sum = BinSum(32, 2)
+                    wire("%s.bigsigma0.in[%d]" % (T2, k), "%s.a[%d]" % (T2, k))
+                    for nm in "abc":
+                        wire("%s.maj.%s[%d]" % (T2, nm, k), "%s.%s[%d]" % (T2, nm, k))
+                    a, b, c, mid = (one("%s.maj.%s[%d]" % (T2, n, k)) for n in ("a", "b", "c", "mid"))
+                    q(b, c, mid)                                                              # maj.circom: mid = b * c; out = a * (b + c - 2 mid) + mid
+                    q(a, b.add(c).add(mid.scale(2), -1), one("%s.maj.out[%d]" % (T2, k)).add(mid, -1))
+                    wire("%s.sum.in[0][%d]" % (T2, k), "%s.bigsigma0.out[%d]" % (T2, k))
+                    wire("%s.sum.in[1][%d]" % (T2, k), "%s.maj.out[%d]" % (T2, k))
+                    wire("%s.out[%d]" % (T2, k), "%s.sum.out[%d]" % (T2, k))
+                    wire("%s.sume[%d].in[0][%d]" % (C, t, k), "%s.d[%d][%d]" % (C, t, k))
+                    wire("%s.sume[%d].in[1][%d]" % (C, t, k), "%s.out[%d]" % (T1, k))
+                    wire("%s.suma[%d].in[0][%d]" % (C, t, k), "%s.out[%d]" % (T1, k))
+                    wire("%s.suma[%d].in[1][%d]" % (C, t, k), "%s.out[%d]" % (T2, k))
+                    for dst, src in (("h", "g"), ("g", "f"), ("f", "e"), ("d", "c"), ("c", "b"), ("b", "a")):
+                        wire("%s.%s[%d][%d]" % (C, dst, t + 1, k), "%s.%s[%d][%d]" % (C, src, t, k))
+                    wire("%s.e[%d][%d]" % (C, t + 1, k), "%s.sume[%d].out[%d]" % (C, t, k))
+                    wire("%s.a[%d][%d]" % (C, t + 1, k), "%s.suma[%d].out[%d]" % (C, t, k))
+                sigma(T1 + ".bigsigma1", 6, 11, 25, True)
+                sigma(T2 + ".bigsigma0", 2, 13, 22, True)
+                binsum(T1 + ".sum", 5)
+                binsum(T2 + ".sum", 2)
+                binsum("%s.sume[%d]" % (C, t), 2)
+                binsum("%s.suma[%d]" % (C, t), 2)
+            for j, rname in enumerate(regs):
+                for k in range(32):
+                    wire("%s.fsum[%d].in[0][%d]" % (C, j, k), "%s.hin[%d]" % (C, 32 * j + k))
+                    wire("%s.fsum[%d].in[1][%d]" % (C, j, k), "%s.%s[64][%d]" % (C, rname, k))
+                    wire("%s.out[%d]" % (C, 32 * j + 31 - k), "%s.fsum[%d].out[%d]" % (C, j, k))
+                binsum("%s.fsum[%d]" % (C, j), 2)
+        for k in range(256):
+            wire("%s.out[%d]" % (P, k), "%s.sha256compression[%d].out[%d]" % (P, nb - 1, k))
 
     # -- templates ---------------------------------------------------------------------------------------------------------------------
     def instantiate(self, tmpl, args, path):
@@ -739,7 +891,7 @@ def main():
                 defs.update(Parser(tokenize(open(os.path.join(root, f)).read())).program())
     out = {}
     for key, tmpl, args in MAINS:
-        r = Run(defs)
+        r = Run(defs, sha_model=key == "withdraw")
         r.instantiate(tmpl, args, "main")
         # outputs of black boxes and everything else a form refers to without defining it
         used = {n for f in r.forms.values() for n in f.t} | {n for q in r.quads for f in q for n in f.t}

@@ -53,7 +53,7 @@ def test_node_facade_writes_the_wtns_of_an_unreduced_compile(tmp_path):
     _, known = T.oracle_known("rollup-tx", m, inp)
     val, _ = DF.solve_with_hashes(m, known, lambda xs: B.host().poseidon(xs))
     sym, r1cs, names = DF.sym_and_r1cs(m)
-    m2 = copy.deepcopy(m)
+    m2 = {k: copy.deepcopy(v) for k, v in m.items() if not k.startswith("_")}   # (without the solver's caches)
     q = [i for i, (a, b, c) in enumerate(m2["quads"]) if a[1] and b[1] and all(n in known for f in (a, b, c) for _, n in f[1])][3]
     m2["quads"][q][2][0] = str((int(m2["quads"][q][2][0]) + 1) % DF.P)
     files = {n: str(tmp_path / n) for n in ("input.json", "c.sym", "c.r1cs", "out.wtns", "bad.r1cs")}

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-( time timeout 1500 python -m pytest tests/test_declared_signals.py tests/test_node.py tests/test_derived_signals.py -m gpu -x -q --durations=5 ) 2>&1 | tail -60
+( time timeout 1500 python -m pytest tests/test_declared_signals.py -m gpu -x -q --durations=5 ) 2>&1 | tail -60
