@@ -331,8 +331,10 @@ def arr(dims, fill):
 
 
 class Run:
-    def __init__(self, defs, sha_model=False):
+    def __init__(self, defs, sha_model=False, pos_model=False, smt_model=False):
         self.defs = defs
+        self.smt_model = smt_model
+        self.pos_model, self._pos = pos_model, {}   # Poseidon with every round signal (a few mains only: ~1 500 entries per component)
         self.sha_model = sha_model   # Sha256 with every wire and constraint (one main only: 40 k signals per block), else a black box
         self.forms, self.bases, self.declared, self.quads, self.models_used = {}, set(), [], [], set()
 
@@ -344,6 +346,12 @@ class Run:
         self.models_used.add(tmpl)
         if tmpl == "Sha256" and self.sha_model:
             self.sha256(path, args[0])
+            return
+        if tmpl == "Poseidon" and self.pos_model:
+            self.poseidon(path, args[0])
+            return
+        if tmpl == "SMTProcessor" and self.smt_model:
+            self.smt_processor(path, args[0])
             return
         if tmpl == "Num2Bits":           # bitify.circom: out[i] * (out[i] - 1) === 0; sum of 2^i out[i] === in
             acc = Lin()
@@ -437,6 +445,212 @@ class Run:
                 f[m + "out[0]"] = sums[False]
             else:
                 q(sums[True], sel(top), one(m + "out[0]").add(sums[False], -1))
+
+    # -- circomlib 0.5.2 poseidon.circom as published: Ark (constants), Sigma (in2 = in * in, in4 = in2 * in2, out = in4 * in), Mix (the MDS
+    # matrix), 4 full rounds, R_P partial rounds on lane 0, 4 full rounds; state[0] = 0, out = mix[last].out[0] --------------------------
+    def poseidon(self, P_, n_in):
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools"))
+        from poseidon_params import N_ROUNDS_P, generate
+        f = self.forms
+        one = lambda n: Lin(0, {n: 1})   # noqa: E731
+        t = n_in + 1
+        if t not in self._pos:
+            self._pos[t] = generate(t)
+        C, M = self._pos[t]
+        rp = N_ROUNDS_P[t - 2]
+
+        def sigma(S):
+            x, x2, x4 = one(S + ".in"), one(S + ".in2"), one(S + ".in4")
+            self.quads.append((x, x, x2))
+            self.quads.append((x2, x2, x4))
+            self.quads.append((x4, x, one(S + ".out")))
+        for i in range(8 + rp):
+            A, X = "%s.ark[%d]" % (P_, i), "%s.mix[%d]" % (P_, i)
+            for j in range(t):
+                if i == 0:
+                    f["%s.in[%d]" % (A, j)] = one("%s.inputs[%d]" % (P_, j - 1)) if j else Lin()
+                else:
+                    f["%s.in[%d]" % (A, j)] = one("%s.mix[%d].out[%d]" % (P_, i - 1, j))
+                f["%s.out[%d]" % (A, j)] = one("%s.in[%d]" % (A, j)).add(Lin(C[t * i + j]))
+            if i < 4 or i >= 4 + rp:
+                k = i if i < 4 else i - rp
+                for j in range(t):
+                    S = "%s.sigmaF[%d][%d]" % (P_, k, j)
+                    f[S + ".in"] = one("%s.out[%d]" % (A, j))
+                    sigma(S)
+                    f["%s.in[%d]" % (X, j)] = one(S + ".out")
+            else:
+                S = "%s.sigmaP[%d]" % (P_, i - 4)
+                f[S + ".in"] = one(A + ".out[0]")
+                sigma(S)
+                f[X + ".in[0]"] = one(S + ".out")
+                for j in range(1, t):
+                    f["%s.in[%d]" % (X, j)] = one("%s.out[%d]" % (A, j))
+            for r in range(t):
+                acc = Lin()
+                for j in range(t):
+                    acc = acc.add(one("%s.in[%d]" % (X, j)).scale(M[r][j]))
+                f["%s.out[%d]" % (X, r)] = acc
+        f[P_ + ".out"] = one("%s.mix[%d].out[0]" % (P_, 8 + rp - 1))
+
+    # -- circomlib 0.5.2 smt/smtprocessor.circom as published, with smtlevins, smtprocessorsm, smtprocessorlevel, smthash_poseidon, switcher,
+    # gates (XOR, AND, MultiAND), bitify (Num2Bits_strict), aliascheck, compconstant ----------------------------------------------------
+    def smt_processor(self, S, n):
+        f = self.forms
+        one = lambda x: Lin(0, {x: 1})   # noqa: E731
+        q = lambda a, b, c: self.quads.append((Lin.of(a), Lin.of(b), Lin.of(c)))   # noqa: E731
+        K1 = Lin(1)
+
+        def wire(dst, src):
+            f[dst] = src if isinstance(src, Lin) else one(src)
+
+        def num2bits_strict(N):
+            wire(N + ".n2b.in", N + ".in")
+            self.model("Num2Bits", N + ".n2b", [254])
+            for i in range(254):
+                wire("%s.out[%d]" % (N, i), "%s.n2b.out[%d]" % (N, i))
+                wire("%s.aliasCheck.in[%d]" % (N, i), "%s.n2b.out[%d]" % (N, i))
+                wire("%s.aliasCheck.compConstant.in[%d]" % (N, i), "%s.aliasCheck.in[%d]" % (N, i))
+            # compconstant.circom against ct = -1 = r - 1: parts of two bits each, their sum through Num2Bits(135), out = bit 127
+            CC = N + ".aliasCheck.compConstant"
+            ct = P - 1
+            b, a, e = (1 << 128) - 1, 1, 1
+            total = Lin()
+            for i in range(127):
+                clsb, cmsb = (ct >> (2 * i)) & 1, (ct >> (2 * i + 1)) & 1
+                slsb, smsb, part = one("%s.in[%d]" % (CC, 2 * i)), one("%s.in[%d]" % (CC, 2 * i + 1)), one("%s.parts[%d]" % (CC, i))
+                if not cmsb and not clsb:      # parts = -b smsb slsb + b smsb + b slsb
+                    q(smsb.scale(-b), slsb, part.add(smsb.scale(b), -1).add(slsb.scale(b), -1))
+                elif not cmsb and clsb:        # a smsb slsb - a slsb + b smsb - a smsb + a
+                    q(smsb.scale(a), slsb, part.add(slsb.scale(a)).add(smsb.scale(b), -1).add(smsb.scale(a)).add(Lin(a), -1))
+                elif cmsb and not clsb:        # b smsb slsb - a smsb + a
+                    q(smsb.scale(b), slsb, part.add(smsb.scale(a)).add(Lin(a), -1))
+                else:                          # -a smsb slsb + a
+                    q(smsb.scale(-a), slsb, part.add(Lin(a), -1))
+                total = total.add(part)
+                b, a, e = b - e, a + e, e * 2
+            wire(CC + ".sout", total)
+            wire(CC + ".num2bits.in", CC + ".sout")
+            self.model("Num2Bits", CC + ".num2bits", [135])
+            wire(CC + ".out", CC + ".num2bits.out[127]")
+            q(Lin(), Lin(), one(CC + ".out"))                                   # aliascheck.circom: compConstant.out === 0
+
+        def switcher(W):               # switcher.circom
+            q(one(W + ".R").add(one(W + ".L"), -1), one(W + ".sel"), one(W + ".aux"))
+            wire(W + ".outL", one(W + ".aux").add(one(W + ".L")))
+            wire(W + ".outR", one(W + ".R").add(one(W + ".aux"), -1))
+
+        def hash_(Hc, ins):            # smthash_poseidon.circom: SMTHash1 = Poseidon(3) of (key, value, 1), SMTHash2 = Poseidon(2) of (L, R)
+            for j, src in enumerate(ins):
+                wire("%s.h.inputs[%d]" % (Hc, j), src)
+            if self.pos_model:
+                self.poseidon(Hc + ".h", len(ins))
+            wire(Hc + ".out", Hc + ".h.out")
+
+        fnc0, fnc1 = one(S + ".fnc[0]"), one(S + ".fnc[1]")
+        q(fnc0, fnc1, fnc0.add(fnc1).add(one(S + ".enabled"), -1))             # enabled <== fnc[0] + fnc[1] - fnc[0]*fnc[1]
+        for nm, key, value in (("hash1Old", "oldKey", "oldValue"), ("hash1New", "newKey", "newValue")):
+            wire("%s.%s.key" % (S, nm), "%s.%s" % (S, key))
+            wire("%s.%s.value" % (S, nm), "%s.%s" % (S, value))
+            hash_("%s.%s" % (S, nm), ["%s.%s.key" % (S, nm), "%s.%s.value" % (S, nm), K1])
+        wire(S + ".n2bOld.in", S + ".oldKey")
+        wire(S + ".n2bNew.in", S + ".newKey")
+        num2bits_strict(S + ".n2bOld")
+        num2bits_strict(S + ".n2bNew")
+        # smtlevins.circom
+        LI = S + ".smtLevIns"
+        wire(LI + ".enabled", S + ".enabled")
+        for i in range(n):
+            wire("%s.siblings[%d]" % (LI, i), "%s.siblings[%d]" % (S, i))
+            wire("%s.isZero[%d].in" % (LI, i), "%s.siblings[%d]" % (LI, i))
+            self.model("IsZero", "%s.isZero[%d]" % (LI, i), [])
+        q(one("%s.isZero[%d].out" % (LI, n - 1)).add(K1, -1), one(LI + ".enabled"), Lin())
+        wire("%s.levIns[%d]" % (LI, n - 1), K1.add(one("%s.isZero[%d].out" % (LI, n - 2)), -1))
+        wire("%s.done[%d]" % (LI, n - 2), "%s.levIns[%d]" % (LI, n - 1))
+        for i in range(n - 2, 0, -1):
+            q(K1.add(one("%s.done[%d]" % (LI, i)), -1), K1.add(one("%s.isZero[%d].out" % (LI, i - 1)), -1), one("%s.levIns[%d]" % (LI, i)))
+            wire("%s.done[%d]" % (LI, i - 1), one("%s.levIns[%d]" % (LI, i)).add(one("%s.done[%d]" % (LI, i))))
+        wire(LI + ".levIns[0]", K1.add(one(LI + ".done[0]"), -1))
+        for i in range(n):             # gates.circom XOR: out <== a + b - 2*a*b
+            X = "%s.xors[%d]" % (S, i)
+            wire(X + ".a", "%s.n2bOld.out[%d]" % (S, i))
+            wire(X + ".b", "%s.n2bNew.out[%d]" % (S, i))
+            q(one(X + ".a").scale(2), one(X + ".b"), one(X + ".a").add(one(X + ".b")).add(one(X + ".out"), -1))
+        st = ("top", "old0", "bot", "new1", "na", "upd")
+        for i in range(n):             # smtprocessorsm.circom
+            M = "%s.sm[%d]" % (S, i)
+            for nm in st:
+                if i == 0:
+                    wire("%s.prev_%s" % (M, nm), one(S + ".enabled") if nm == "top" else K1.add(one(S + ".enabled"), -1) if nm == "na" else Lin())
+                else:
+                    wire("%s.prev_%s" % (M, nm), "%s.sm[%d].st_%s" % (S, i - 1, nm))
+            wire(M + ".is0", S + ".isOld0")
+            wire(M + ".xor", "%s.xors[%d].out" % (S, i))
+            wire(M + ".fnc[0]", S + ".fnc[0]")
+            wire(M + ".fnc[1]", S + ".fnc[1]")
+            wire(M + ".levIns", "%s.levIns[%d]" % (LI, i))
+            g = lambda x, M=M: one("%s.%s" % (M, x))   # noqa: E731
+            q(g("prev_top"), g("levIns"), g("aux1"))
+            q(g("aux1"), g("fnc[0]"), g("aux2"))
+            wire(M + ".st_top", g("prev_top").add(g("aux1"), -1))
+            q(g("aux2"), g("is0"), g("st_old0"))
+            mid = g("aux2").add(g("st_old0"), -1).add(g("prev_bot"))
+            q(mid, g("xor"), g("st_new1"))
+            q(K1.add(g("xor"), -1), mid, g("st_bot"))
+            wire(M + ".st_upd", g("aux1").add(g("aux2"), -1))
+            wire(M + ".st_na", g("prev_new1").add(g("prev_old0")).add(g("prev_na")).add(g("prev_upd")))
+        last = "%s.sm[%d]" % (S, n - 1)
+        q(Lin(), Lin(), one(last + ".st_na").add(one(last + ".st_new1")).add(one(last + ".st_old0")).add(one(last + ".st_upd")).add(K1, -1))
+        for i in range(n - 1, -1, -1):  # smtprocessorlevel.circom
+            Lv = "%s.levels[%d]" % (S, i)
+            for nm in st:
+                wire("%s.st_%s" % (Lv, nm), "%s.sm[%d].st_%s" % (S, i, nm))
+            wire(Lv + ".sibling", "%s.siblings[%d]" % (S, i))
+            wire(Lv + ".old1leaf", S + ".hash1Old.out")
+            wire(Lv + ".new1leaf", S + ".hash1New.out")
+            wire(Lv + ".newlrbit", "%s.n2bNew.out[%d]" % (S, i))
+            wire(Lv + ".oldChild", Lin() if i == n - 1 else one("%s.levels[%d].oldRoot" % (S, i + 1)))
+            wire(Lv + ".newChild", Lin() if i == n - 1 else one("%s.levels[%d].newRoot" % (S, i + 1)))
+            g = lambda x, Lv=Lv: one("%s.%s" % (Lv, x))   # noqa: E731
+            wire(Lv + ".oldSwitcher.L", g("oldChild")); wire(Lv + ".oldSwitcher.R", g("sibling")); wire(Lv + ".oldSwitcher.sel", g("newlrbit"))
+            switcher(Lv + ".oldSwitcher")
+            hash_(Lv + ".oldProofHash", [Lv + ".oldProofHash.L", Lv + ".oldProofHash.R"])
+            wire(Lv + ".oldProofHash.L", Lv + ".oldSwitcher.outL"); wire(Lv + ".oldProofHash.R", Lv + ".oldSwitcher.outR")
+            q(g("old1leaf"), g("st_bot").add(g("st_new1")).add(g("st_upd")), g("aux[0]"))
+            q(g("oldProofHash.out"), g("st_top"), g("oldRoot").add(g("aux[0]"), -1))
+            q(g("newChild"), g("st_top").add(g("st_bot")), g("aux[1]"))
+            q(g("new1leaf"), g("st_new1"), g("newSwitcher.L").add(g("aux[1]"), -1))
+            q(g("sibling"), g("st_top"), g("aux[2]"))
+            q(g("old1leaf"), g("st_new1"), g("newSwitcher.R").add(g("aux[2]"), -1))
+            wire(Lv + ".newSwitcher.sel", g("newlrbit"))
+            switcher(Lv + ".newSwitcher")
+            hash_(Lv + ".newProofHash", [Lv + ".newProofHash.L", Lv + ".newProofHash.R"])
+            wire(Lv + ".newProofHash.L", Lv + ".newSwitcher.outL"); wire(Lv + ".newProofHash.R", Lv + ".newSwitcher.outR")
+            q(g("newProofHash.out"), g("st_top").add(g("st_bot")).add(g("st_new1")), g("aux[3]"))
+            q(g("new1leaf"), g("st_old0").add(g("st_upd")), g("newRoot").add(g("aux[3]"), -1))
+        T = S + ".topSwitcher"
+        q(fnc0, fnc1, one(T + ".sel"))
+        wire(T + ".L", S + ".levels[0].oldRoot")
+        wire(T + ".R", S + ".levels[0].newRoot")
+        switcher(T)
+        Ck = S + ".checkOldInput"
+        wire(Ck + ".enabled", S + ".enabled"); wire(Ck + ".in[0]", S + ".oldRoot"); wire(Ck + ".in[1]", T + ".outL")
+        self.model("ForceEqualIfEnabled", Ck, [])
+        q(one(S + ".enabled"), one(T + ".outR").add(one(S + ".oldRoot"), -1), one(S + ".newRoot").add(one(S + ".oldRoot"), -1))
+        E = S + ".areKeyEquals"
+        wire(E + ".in[0]", S + ".oldKey"); wire(E + ".in[1]", S + ".newKey")
+        self.model("IsEqual", E, [])
+        Kk = S + ".keysOk"             # gates.circom MultiAND(3) = AND(MultiAND(1), MultiAND(2))
+        wire(Kk + ".in[0]", K1.add(fnc0, -1)); wire(Kk + ".in[1]", fnc1); wire(Kk + ".in[2]", K1.add(one(E + ".out"), -1))
+        wire(Kk + ".ands[0].in[0]", Kk + ".in[0]"); wire(Kk + ".ands[0].out", Kk + ".ands[0].in[0]")
+        wire(Kk + ".ands[1].in[0]", Kk + ".in[1]"); wire(Kk + ".ands[1].in[1]", Kk + ".in[2]")
+        wire(Kk + ".ands[1].and1.a", Kk + ".ands[1].in[0]"); wire(Kk + ".ands[1].and1.b", Kk + ".ands[1].in[1]")
+        q(one(Kk + ".ands[1].and1.a"), one(Kk + ".ands[1].and1.b"), one(Kk + ".ands[1].and1.out"))
+        wire(Kk + ".ands[1].out", Kk + ".ands[1].and1.out")
+        wire(Kk + ".and2.a", Kk + ".ands[0].out"); wire(Kk + ".and2.b", Kk + ".ands[1].out")
+        q(one(Kk + ".and2.a"), one(Kk + ".and2.b"), one(Kk + ".and2.out"))
+        wire(Kk + ".out", Kk + ".and2.out")
+        q(Lin(), Lin(), one(Kk + ".out"))                                       # keysOk.out === 0
 
     # -- circomlib 0.5.2 sha256/*.circom as published: every wire and every constraint of Sha256(nBits) -----------------------------------
     def sha256(self, P, n_bits):
@@ -891,7 +1105,8 @@ def main():
                 defs.update(Parser(tokenize(open(os.path.join(root, f)).read())).program())
     out = {}
     for key, tmpl, args in MAINS:
-        r = Run(defs, sha_model=key == "withdraw")
+        r = Run(defs, sha_model=key == "withdraw", pos_model=key in ("hash-state", "decode-tx", "fee-tx", "rollup-tx"),
+                smt_model=key in ("fee-tx", "rollup-tx"))
         r.instantiate(tmpl, args, "main")
         # outputs of black boxes and everything else a form refers to without defining it
         used = {n for f in r.forms.values() for n in f.t} | {n for q in r.quads for f in q for n in f.t}
