@@ -291,7 +291,7 @@ extern "C" hz_status hz_symbols_write_sym(const hz_ctx* ctx, const char* path) {
 //     `<c>.isz.in`): inv <-- in != 0 ? 1/in : 0 determines it, in = inv == 0 ? 0 : 1/inv; and the input of every Num2Bits whose bits are
 //     stored as `<c>.out[k]`: the template's own constraint, in = sum of 2^k out[k].
 // A variable whose labels match neither a stored signal nor a rule stays unresolved and is reported as before.
-enum { DV_POSEIDON = 1, DV_LINEAR = 2, DV_ISZERO_IN = 3, DV_PRODUCT = 4 };   // DV_PRODUCT: lins[lin] * lins[lin + 1] + lins[lin + 2]
+enum { DV_POSEIDON = 1, DV_LINEAR = 2, DV_ISZERO_IN = 3, DV_PRODUCT = 4, DV_QUOTIENT = 5 };   // DV_PRODUCT: lins[lin] * lins[lin + 1] + lins[lin + 2]; DV_QUOTIENT: lins[lin] / lins[lin + 1] + lins[lin + 2] (0 / 0 = 0)
 using hzderived::PW_ARK_IN; using hzderived::PW_ARK_OUT; using hzderived::PW_MIX_IN; using hzderived::PW_MIX_OUT;
 struct DerivedVar {
     uint8_t kind = 0, t = 0, what = 0;
@@ -647,7 +647,7 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
         } else if (d.kind == DV_ISZERO_IN) {
             want(d.first);
         } else {
-            for (uint32_t f = d.lin; f < d.lin + (d.kind == DV_PRODUCT ? 3u : 1u); f++)
+            for (uint32_t f = d.lin; f < d.lin + (d.kind == DV_LINEAR ? 1u : 3u); f++)
                 for (const auto& tm : m->lins[f].terms) {
                     if (tm.second & DERIVED_FLAG) stack.push_back(tm.second & ~DERIVED_FLAG);
                     else want(tm.second);
@@ -697,7 +697,9 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
                 }
                 return r;
             };
-            v = d.kind == DV_PRODUCT ? hzh::f_add(hzh::f_mul(eval(m->lins[d.lin]), eval(m->lins[d.lin + 1])), eval(m->lins[d.lin + 2])) : eval(m->lins[d.lin]);
+            if (d.kind == DV_PRODUCT) v = hzh::f_add(hzh::f_mul(eval(m->lins[d.lin]), eval(m->lins[d.lin + 1])), eval(m->lins[d.lin + 2]));
+            else if (d.kind == DV_QUOTIENT) v = hzh::f_add(hzh::f_mul(eval(m->lins[d.lin]), hzh::f_inv(eval(m->lins[d.lin + 1]))), eval(m->lins[d.lin + 2]));
+            else v = eval(m->lins[d.lin]);
         }
         dval[k] = v;
     }
@@ -866,8 +868,26 @@ void solve_linear(hz_symmap* m) {
     std::vector<uint32_t> work;
     for (uint32_t i = 0; i < lc.size(); i++)
         if (lc[i].unknown == 1) work.push_back(i);
-    for (uint32_t i = 0; i < qc.size(); i++)
+    // A quotient: the single unknown of the constraint sits in ONE factor, the other factor and C hold none -- the `x <-- a / b;
+    // x * b === a` hints of signals whose values are constants of the circuit (EscalarMulFix's window tables: lamda, Edwards <->
+    // Montgomery conversions). Tried only when nothing else is left: the same variable often has a plain definition that is not ready
+    // yet, and a quotient by a factor that is 0 for this witness defines nothing (it reads as 0).
+    std::vector<uint32_t> later;
+    auto quotient_side = [&](const QuadCon& q) -> int {   // 0 / 1: the factor that holds the single unknown; -1: not this shape
+        if (q.in_ab != 1 || q.in_c != 0) return -1;
+        int side = -1;
+        for (int part = 0; part < 2; part++)
+            for (uint64_t t = r.off[3 * q.c + part]; t < r.off[3 * q.c + part + 1]; t++)
+                if (r.wire[t] != 0 && m->index[r.wire[t]] == ~0ull) { if (side >= 0 && side != part) return -1; side = part; }
+        if (side < 0) return -1;
+        for (uint64_t t = r.off[3 * q.c + 2]; t < r.off[3 * q.c + 3]; t++)
+            if (r.wire[t] != 0 && m->index[r.wire[t]] == ~0ull) return -1;   // (the same unknown again, in C)
+        return side;
+    };
+    for (uint32_t i = 0; i < qc.size(); i++) {
         if (qc[i].in_ab == 0 && qc[i].in_c == 1) work.push_back(QFLAG | i);
+        else if (qc[i].in_ab == 1 && qc[i].in_c == 0) later.push_back(i);
+    }
     auto solved = [&](uint32_t u) {
         m->n_solved++;
         for (uint32_t j : uses[u]) {
@@ -879,10 +899,33 @@ void solve_linear(hz_symmap* m) {
                     for (uint64_t t = r.off[3 * q.c + part]; t < r.off[3 * q.c + part + 1] && !in_ab; t++) in_ab = r.wire[t] == u;
                 if (in_ab) q.in_ab--; else q.in_c--;
                 if (q.in_ab == 0 && q.in_c == 1) work.push_back(j);
+                else if (q.in_ab == 1 && q.in_c == 0) later.push_back(j & ~QFLAG);
             } else if (lc[j].unknown && --lc[j].unknown == 1) work.push_back(j);
         }
     };
-    while (!work.empty()) {
+    while (!work.empty() || !later.empty()) {
+        if (work.empty()) {
+            const QuadCon& q = qc[later.back()];
+            later.pop_back();
+            const int side = quotient_side(q);
+            if (side < 0) continue;
+            uint32_t u = 0; F ku = hzh::f_zero();
+            for (uint64_t t = r.off[3 * q.c + side]; t < r.off[3 * q.c + side + 1]; t++)
+                if (r.wire[t] != 0 && m->index[r.wire[t]] == ~0ull) { u = r.wire[t]; ku = hzh::f_add(ku, r.pool[r.coef[t]]); }
+            if (!u || hzh::f_is_zero(ku)) continue;
+            const F s = hzh::f_inv(ku);          // (k_u w_u + rest) * other = C  ->  w_u = (1 / k_u) * C / other - (1 / k_u) * rest
+            LinForm fc, fo, fr;
+            index_form(q.c, 2, s, 0, fc);
+            index_form(q.c, 1 - side, hzh::f_one(), 0, fo);
+            index_form(q.c, side, f_neg(s), u, fr);
+            DerivedVar d;
+            d.kind = DV_QUOTIENT; d.lin = (uint32_t)m->lins.size();
+            m->lins.push_back(std::move(fc)); m->lins.push_back(std::move(fo)); m->lins.push_back(std::move(fr));
+            m->derived.push_back(d);
+            m->index[u] = DERIVED_FLAG | (m->derived.size() - 1);
+            solved(u);
+            continue;
+        }
         const uint32_t i = work.back();
         work.pop_back();
         if (i & QFLAG) {

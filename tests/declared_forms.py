@@ -80,14 +80,21 @@ def _system(m):
 def solve(m, known):
     """values for every name from `known` {name: value} by propagation: a linear constraint with exactly one unknown name defines
     it; so does a product constraint A * B = C whose A and B are known and whose C holds exactly one unknown name (a product
-    signal the witness does not store under that name). Returns (values, names that stayed unknown)."""
+    signal the witness does not store under that name), and one whose single unknown sits in one factor while the other factor and C are
+    known (a quotient: the `x <-- a / b; x * b === a` hints of values that are constants of the circuit). Returns (values, names that
+    stayed unknown)."""
     val = dict(known)
     lin, quads, names_of, ab_of, where = _system(m)
     n_lin = len(lin)
     unknown = [sum(1 for n in ns if n not in val) for ns in names_of]
     work = [i for i, u in enumerate(unknown) if u == 1]
-    while work:
-        i = work.pop()
+    later = []   # lines that could define their unknown only as a quotient: tried when nothing else is left (the same signal often has a
+    #              plain definition that just is not ready yet, and a quotient by a factor that happens to be 0 defines nothing)
+    while work or later:
+        if work:
+            i, quotient_ok = work.pop(), False
+        else:
+            i, quotient_ok = later.pop(), True
         if unknown[i] != 1:
             continue
         u = next(n for n in names_of[i] if n not in val)
@@ -100,17 +107,31 @@ def solve(m, known):
                 else:
                     rest += k * val[n]
         else:
-            if u in ab_of[i - n_lin]:
-                continue   # unknown inside a factor: this line cannot define it
             a, b, c = quads[i - n_lin]
-            ea = a[0] + sum(k * val[n] for k, n in a[1])
-            eb = b[0] + sum(k * val[n] for k, n in b[1])
-            rest, coef = c[0] - ea * eb, 0
-            for k, n in c[1]:
-                if n == u:
-                    coef += k
-                else:
-                    rest += k * val[n]
+            in_a, in_b, in_c = (any(n == u for _, n in f[1]) for f in (a, b, c))
+            if in_a + in_b + in_c != 1 and not (in_c and not in_a and not in_b):
+                continue   # the unknown in more than one of A, B, C: this line cannot define it
+            if in_c:
+                ea = a[0] + sum(k * val[n] for k, n in a[1])
+                eb = b[0] + sum(k * val[n] for k, n in b[1])
+                rest, coef = c[0] - ea * eb, 0
+                for k, n in c[1]:
+                    if n == u:
+                        coef += k
+                    else:
+                        rest += k * val[n]
+            else:
+                # a quotient: (k u + rest) * other = C with `other` and C known -- the `x <-- a / b; x * b === a` hints
+                if not quotient_ok:
+                    later.append(i)
+                    continue
+                mine, other = (a, b) if in_a else (b, a)
+                eo = (other[0] + sum(k * val[n] for k, n in other[1])) % P
+                if eo == 0:
+                    continue   # 0 * u = C says nothing about u
+                ec = (c[0] + sum(k * val[n] for k, n in c[1])) % P
+                rest, coef = (mine[0] + sum(k * val[n] for k, n in mine[1] if n != u)), sum(k for k, n in mine[1] if n == u)
+                rest -= ec * pow(eo, P - 2, P)
         coef %= P
         if coef == 0:
             continue

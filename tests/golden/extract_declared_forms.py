@@ -331,8 +331,9 @@ def arr(dims, fill):
 
 
 class Run:
-    def __init__(self, defs, sha_model=False, pos_model=False, smt_model=False):
+    def __init__(self, defs, sha_model=False, pos_model=False, smt_model=False, eddsa_model=False):
         self.defs = defs
+        self.eddsa_model = eddsa_model
         self.smt_model = smt_model
         self.pos_model, self._pos = pos_model, {}   # Poseidon with every round signal (a few mains only: ~1 500 entries per component)
         self.sha_model = sha_model   # Sha256 with every wire and constraint (one main only: 40 k signals per block), else a black box
@@ -352,6 +353,9 @@ class Run:
             return
         if tmpl == "SMTProcessor" and self.smt_model:
             self.smt_processor(path, args[0])
+            return
+        if tmpl == "EdDSAPoseidonVerifier" and self.eddsa_model:
+            self.eddsa(path)
             return
         if tmpl == "Num2Bits":           # bitify.circom: out[i] * (out[i] - 1) === 0; sum of 2^i out[i] === in
             acc = Lin()
@@ -651,6 +655,289 @@ class Run:
         q(one(Kk + ".and2.a"), one(Kk + ".and2.b"), one(Kk + ".and2.out"))
         wire(Kk + ".out", Kk + ".and2.out")
         q(Lin(), Lin(), one(Kk + ".out"))                                       # keysOk.out === 0
+
+    # -- circomlib 0.5.2 eddsaposeidon.circom as published, with babyjub (BabyAdd, BabyDbl), montgomery (Edwards2Montgomery,
+    # Montgomery2Edwards, MontgomeryAdd, MontgomeryDouble), escalarmulany (Multiplexor2, BitElementMulAny, SegmentMulAny, EscalarMulAny),
+    # escalarmulfix (WindowMulFix, SegmentMulFix, EscalarMulFix over BASE8), compconstant, bitify -------------------------------------------
+    def eddsa(self, V):
+        f = self.forms
+        one = lambda x: Lin(0, {x: 1})   # noqa: E731
+        q = lambda a, b, c: self.quads.append((Lin.of(a), Lin.of(b), Lin.of(c)))   # noqa: E731
+        K1 = Lin(1)
+        a_, d_ = 168700, 168696
+        A_, B_ = 168698, 1                                   # (2 (a + d)) / (a - d), 4 / (a - d)
+        BASE8 = (5299619240641551281634865583518297030282874472190772894086521144482721001553, 16950150798460657717958625567821834550301663161624707787222815936182638968203)
+
+        def wire(dst, src):
+            f[dst] = src if isinstance(src, Lin) else one(src)
+
+        def pair(dst, src):                                  # dst[0], dst[1] <== src[0], src[1]
+            for k in range(2):
+                wire("%s[%d]" % (dst, k), "%s[%d]" % (src, k))
+
+        def baby_add(C):
+            x1, y1, x2, y2 = (one("%s.%s" % (C, n)) for n in ("x1", "y1", "x2", "y2"))
+            beta, gamma, delta, tau = (one("%s.%s" % (C, n)) for n in ("beta", "gamma", "delta", "tau"))
+            q(x1, y2, beta); q(y1, x2, gamma)
+            q(x1.scale(-a_).add(y1), x2.add(y2), delta)
+            q(beta, gamma, tau)
+            q(K1.add(tau.scale(d_)), one(C + ".xout"), beta.add(gamma))
+            q(K1.add(tau.scale(d_), -1), one(C + ".yout"), delta.add(beta.scale(a_)).add(gamma, -1))
+
+        def baby_dbl(D):
+            for k, n in (("x1", "x"), ("y1", "y"), ("x2", "x"), ("y2", "y")):
+                wire("%s.adder.%s" % (D, k), "%s.%s" % (D, n))
+            baby_add(D + ".adder")
+            wire(D + ".xout", D + ".adder.xout"); wire(D + ".yout", D + ".adder.yout")
+
+        def e2m(E):                                          # out[0] * (1 - in[1]) === 1 + in[1]; out[1] * in[0] === out[0]
+            i0, i1, o0, o1 = one(E + ".in[0]"), one(E + ".in[1]"), one(E + ".out[0]"), one(E + ".out[1]")
+            q(o0, K1.add(i1, -1), K1.add(i1)); q(o1, i0, o0)
+
+        def m2e(E):                                          # out[0] * in[1] === in[0]; out[1] * (in[0] + 1) === in[0] - 1
+            i0, i1, o0, o1 = one(E + ".in[0]"), one(E + ".in[1]"), one(E + ".out[0]"), one(E + ".out[1]")
+            q(o0, i1, i0); q(o1, i0.add(K1), i0.add(K1, -1))
+
+        def mont_add(M):
+            a0, a1, b0, b1 = (one("%s.%s" % (M, n)) for n in ("in1[0]", "in1[1]", "in2[0]", "in2[1]"))
+            lam, o0, o1 = one(M + ".lamda"), one(M + ".out[0]"), one(M + ".out[1]")
+            q(lam, b0.add(a0, -1), b1.add(a1, -1))
+            q(lam.scale(B_), lam, o0.add(Lin(A_)).add(a0).add(b0))          # out[0] <== B lamda^2 - A - in1[0] - in2[0]
+            q(lam, a0.add(o0, -1), o1.add(a1))                                # out[1] <== lamda (in1[0] - out[0]) - in1[1]
+
+        def mont_dbl(M):
+            i0, i1, lam, x2, o0, o1 = (one("%s.%s" % (M, n)) for n in ("in[0]", "in[1]", "lamda", "x1_2", "out[0]", "out[1]"))
+            q(i0, i0, x2)
+            q(lam, i1.scale(2 * B_), x2.scale(3).add(i0.scale(2 * A_)).add(K1))
+            q(lam.scale(B_), lam, o0.add(Lin(A_)).add(i0.scale(2)))
+            q(lam, i0.add(o0, -1), o1.add(i1))
+
+        def mux2(X):                                         # escalarmulany.circom Multiplexor2
+            for k in range(2):
+                lo, hi = one("%s.in[0][%d]" % (X, k)), one("%s.in[1][%d]" % (X, k))
+                q(hi.add(lo, -1), one(X + ".sel"), one("%s.out[%d]" % (X, k)).add(lo, -1))
+
+        def segment_any(G, n):
+            pair(G + ".e2m.in", G + ".p")
+            e2m(G + ".e2m")
+            for i in range(n - 1):
+                Bt = "%s.bits[%d]" % (G, i)
+                if i == 0:
+                    pair(Bt + ".dblIn", G + ".e2m.out"); pair(Bt + ".addIn", G + ".e2m.out")
+                else:
+                    pair(Bt + ".dblIn", "%s.bits[%d].dblOut" % (G, i - 1)); pair(Bt + ".addIn", "%s.bits[%d].addOut" % (G, i - 1))
+                wire(Bt + ".sel", "%s.e[%d]" % (G, i + 1))
+                wire(Bt + ".selector.sel", Bt + ".sel")
+                pair(Bt + ".doubler.in", Bt + ".dblIn")
+                pair(Bt + ".adder.in1", Bt + ".doubler.out"); pair(Bt + ".adder.in2", Bt + ".addIn")
+                pair(Bt + ".selector.in[0]", Bt + ".addIn"); pair(Bt + ".selector.in[1]", Bt + ".adder.out")
+                pair(Bt + ".dblOut", Bt + ".doubler.out"); pair(Bt + ".addOut", Bt + ".selector.out")
+                mont_dbl(Bt + ".doubler"); mont_add(Bt + ".adder"); mux2(Bt + ".selector")
+            pair(G + ".dbl", "%s.bits[%d].dblOut" % (G, n - 2))
+            pair(G + ".m2e.in", "%s.bits[%d].addOut" % (G, n - 2))
+            m2e(G + ".m2e")
+            wire(G + ".eadder.x1", G + ".m2e.out[0]"); wire(G + ".eadder.y1", G + ".m2e.out[1]")
+            wire(G + ".eadder.x2", one(G + ".p[0]").scale(-1)); wire(G + ".eadder.y2", G + ".p[1]")
+            baby_add(G + ".eadder")
+            wire(G + ".lastSel.sel", G + ".e[0]")
+            wire(G + ".lastSel.in[0][0]", G + ".eadder.xout"); wire(G + ".lastSel.in[0][1]", G + ".eadder.yout")
+            pair(G + ".lastSel.in[1]", G + ".m2e.out")
+            mux2(G + ".lastSel")
+            pair(G + ".out", G + ".lastSel.out")
+
+        def escalar_any(Mx, n):
+            nseg_all = (n - 1) // 148 + 1
+            nlast = n - (nseg_all - 1) * 148
+            wire(Mx + ".zeropoint.in", Mx + ".p[0]")
+            self.model("IsZero", Mx + ".zeropoint", [])
+            zp = one(Mx + ".zeropoint.out")
+            for s_ in range(nseg_all):
+                nseg = 148 if s_ < nseg_all - 1 else nlast
+                G = "%s.segments[%d]" % (Mx, s_)
+                for i in range(nseg):
+                    wire("%s.e[%d]" % (G, i), "%s.e[%d]" % (Mx, s_ * 148 + i))
+                if s_ == 0:
+                    for k in range(2):                       # the G8 point instead of a zero input point
+                        p = one("%s.p[%d]" % (Mx, k))
+                        q(Lin(BASE8[k]).add(p, -1), zp, one("%s.p[%d]" % (G, k)).add(p, -1))
+                else:
+                    D, E, Ad = "%s.doublers[%d]" % (Mx, s_ - 1), "%s.m2e[%d]" % (Mx, s_ - 1), "%s.adders[%d]" % (Mx, s_ - 1)
+                    pair(D + ".in", "%s.segments[%d].dbl" % (Mx, s_ - 1))
+                    mont_dbl(D)
+                    pair(E + ".in", D + ".out")
+                    m2e(E)
+                    pair(G + ".p", E + ".out")
+                    if s_ == 1:
+                        wire(Ad + ".x1", "%s.segments[0].out[0]" % Mx); wire(Ad + ".y1", "%s.segments[0].out[1]" % Mx)
+                    else:
+                        wire(Ad + ".x1", "%s.adders[%d].xout" % (Mx, s_ - 2)); wire(Ad + ".y1", "%s.adders[%d].yout" % (Mx, s_ - 2))
+                    wire(Ad + ".x2", G + ".out[0]"); wire(Ad + ".y2", G + ".out[1]")
+                    baby_add(Ad)
+                segment_any(G, nseg)
+            fx, fy = ("%s.segments[0].out[0]" % Mx, "%s.segments[0].out[1]" % Mx) if nseg_all == 1 else ("%s.adders[%d].xout" % (Mx, nseg_all - 2), "%s.adders[%d].yout" % (Mx, nseg_all - 2))
+            q(one(fx), K1.add(zp, -1), one(Mx + ".out[0]"))
+            q(K1.add(one(fy), -1), zp, one(Mx + ".out[1]").add(one(fy), -1))
+
+        def window_fix(W):
+            for j in range(3):
+                wire("%s.mux.s[%d]" % (W, j), "%s.in[%d]" % (W, j))
+            pair(W + ".dbl2.in", W + ".base")
+            mont_dbl(W + ".dbl2")
+            prev = W + ".dbl2.out"
+            for k in range(3, 9):
+                Ad = "%s.adr%d" % (W, k)
+                pair(Ad + ".in1", W + ".base"); pair(Ad + ".in2", prev)
+                mont_add(Ad)
+                prev = Ad + ".out"
+            srcs = [W + ".base", W + ".dbl2.out"] + ["%s.adr%d.out" % (W, k) for k in range(3, 9)]
+            for j, src in enumerate(srcs):
+                for k in range(2):
+                    wire("%s.mux.c[%d][%d]" % (W, k, j), "%s[%d]" % (src, k))
+            pair(W + ".out8", W + ".adr8.out")
+            pair(W + ".out", W + ".mux.out")
+            # MultiMux3(2): s10 <== s[1] * s[0]; a210 / a21 / a20 / a10 / a1 / a0 products, a2 and a linear; out = (..) * s[2] + (..)
+            m = W + ".mux."
+            sel = lambda i: one("%ss[%d]" % (m, i))   # noqa: E731
+            q(sel(1), sel(0), one(m + "s10"))
+            for k in range(2):
+                c = lambda i, k=k: one("%sc[%d][%d]" % (m, k, i))   # noqa: E731
+                nm = lambda t, k=k: one("%s%s[%d]" % (m, t, k))   # noqa: E731
+                q(c(7).add(c(6), -1).add(c(5), -1).add(c(4)).add(c(3), -1).add(c(2)).add(c(1)).add(c(0), -1), one(m + "s10"), nm("a210"))
+                q(c(6).add(c(4), -1).add(c(2), -1).add(c(0)), sel(1), nm("a21"))
+                q(c(5).add(c(4), -1).add(c(1), -1).add(c(0)), sel(0), nm("a20"))
+                wire("%sa2[%d]" % (m, k), c(4).add(c(0), -1))
+                q(c(3).add(c(2), -1).add(c(1), -1).add(c(0)), one(m + "s10"), nm("a10"))
+                q(c(2).add(c(0), -1), sel(1), nm("a1"))
+                q(c(1).add(c(0), -1), sel(0), nm("a0"))
+                wire("%sa[%d]" % (m, k), c(0))
+                q(nm("a210").add(nm("a21")).add(nm("a20")).add(nm("a2")), sel(2), nm("out").add(nm("a10"), -1).add(nm("a1"), -1).add(nm("a0"), -1).add(nm("a"), -1))
+
+        def segment_fix(G, nw):
+            pair(G + ".e2m.in", G + ".base")
+            e2m(G + ".e2m")
+            for i in range(nw):
+                W, Cd = "%s.windows[%d]" % (G, i), "%s.cadders[%d]" % (G, i)
+                if i == 0:
+                    pair(W + ".base", G + ".e2m.out"); pair(Cd + ".in1", G + ".e2m.out")
+                else:
+                    pair(W + ".base", "%s.windows[%d].out8" % (G, i - 1)); pair(Cd + ".in1", "%s.cadders[%d].out" % (G, i - 1))
+                for j in range(3):
+                    wire("%s.in[%d]" % (W, j), "%s.e[%d]" % (G, 3 * i + j))
+                if i < nw - 1:
+                    pair(Cd + ".in2", W + ".out8")
+                else:
+                    pair(G + ".dblLast.in", W + ".out8")
+                    mont_dbl(G + ".dblLast")
+                    pair(Cd + ".in2", G + ".dblLast.out")
+                window_fix(W)
+                mont_add(Cd)
+            for i in range(nw):
+                Ad = "%s.adders[%d]" % (G, i)
+                pair(Ad + ".in1", G + ".dblLast.out" if i == 0 else "%s.adders[%d].out" % (G, i - 1))
+                pair(Ad + ".in2", "%s.windows[%d].out" % (G, i))
+                mont_add(Ad)
+            pair(G + ".m2e.in", "%s.adders[%d].out" % (G, nw - 1)); m2e(G + ".m2e")
+            pair(G + ".cm2e.in", "%s.cadders[%d].out" % (G, nw - 1)); m2e(G + ".cm2e")
+            wire(G + ".cAdd.x1", G + ".m2e.out[0]"); wire(G + ".cAdd.y1", G + ".m2e.out[1]")
+            wire(G + ".cAdd.x2", one(G + ".cm2e.out[0]").scale(-1)); wire(G + ".cAdd.y2", G + ".cm2e.out[1]")
+            baby_add(G + ".cAdd")
+            wire(G + ".out[0]", G + ".cAdd.xout"); wire(G + ".out[1]", G + ".cAdd.yout")
+            pair(G + ".dbl", "%s.windows[%d].out8" % (G, nw - 1))
+
+        def escalar_fix(Mx, n):
+            nseg_all = (n - 1) // 246 + 1                # 246 bits = 82 windows of three per segment
+            nlast = n - (nseg_all - 1) * 246
+            for s_ in range(nseg_all):
+                nseg = 246 if s_ < nseg_all - 1 else nlast
+                nw = (nseg - 1) // 3 + 1
+                G = "%s.segments[%d]" % (Mx, s_)
+                for i in range(nw * 3):
+                    wire("%s.e[%d]" % (G, i), one("%s.e[%d]" % (Mx, s_ * 246 + i)) if i < nseg else Lin())
+                if s_ == 0:
+                    wire(G + ".base[0]", Lin(BASE8[0])); wire(G + ".base[1]", Lin(BASE8[1]))
+                else:
+                    E, Ad = "%s.m2e[%d]" % (Mx, s_ - 1), "%s.adders[%d]" % (Mx, s_ - 1)
+                    pair(E + ".in", "%s.segments[%d].dbl" % (Mx, s_ - 1))
+                    m2e(E)
+                    pair(G + ".base", E + ".out")
+                    if s_ == 1:
+                        wire(Ad + ".x1", "%s.segments[0].out[0]" % Mx); wire(Ad + ".y1", "%s.segments[0].out[1]" % Mx)
+                    else:
+                        wire(Ad + ".x1", "%s.adders[%d].xout" % (Mx, s_ - 2)); wire(Ad + ".y1", "%s.adders[%d].yout" % (Mx, s_ - 2))
+                    wire(Ad + ".x2", G + ".out[0]"); wire(Ad + ".y2", G + ".out[1]")
+                    baby_add(Ad)
+                segment_fix(G, nw)
+            if nseg_all == 1:
+                pair(Mx + ".out", Mx + ".segments[0].out")
+            else:
+                wire(Mx + ".out[0]", "%s.adders[%d].xout" % (Mx, nseg_all - 2)); wire(Mx + ".out[1]", "%s.adders[%d].yout" % (Mx, nseg_all - 2))
+
+        def comp_constant(CC, ct):     # compconstant.circom
+            b, a, e = (1 << 128) - 1, 1, 1
+            total = Lin()
+            for i in range(127):
+                clsb, cmsb = (ct >> (2 * i)) & 1, (ct >> (2 * i + 1)) & 1
+                slsb, smsb, part = one("%s.in[%d]" % (CC, 2 * i)), one("%s.in[%d]" % (CC, 2 * i + 1)), one("%s.parts[%d]" % (CC, i))
+                if not cmsb and not clsb:
+                    q(smsb.scale(-b), slsb, part.add(smsb.scale(b), -1).add(slsb.scale(b), -1))
+                elif not cmsb and clsb:
+                    q(smsb.scale(a), slsb, part.add(slsb.scale(a)).add(smsb.scale(b), -1).add(smsb.scale(a)).add(Lin(a), -1))
+                elif cmsb and not clsb:
+                    q(smsb.scale(b), slsb, part.add(smsb.scale(a)).add(Lin(a), -1))
+                else:
+                    q(smsb.scale(-a), slsb, part.add(Lin(a), -1))
+                total = total.add(part)
+                b, a, e = b - e, a + e, e * 2
+            wire(CC + ".sout", total)
+            wire(CC + ".num2bits.in", CC + ".sout")
+            self.model("Num2Bits", CC + ".num2bits", [135])
+            wire(CC + ".out", CC + ".num2bits.out[127]")
+
+        en = one(V + ".enabled")
+        wire(V + ".snum2bits.in", V + ".S")
+        self.model("Num2Bits", V + ".snum2bits", [253])
+        for i in range(253):
+            wire("%s.compConstant.in[%d]" % (V, i), "%s.snum2bits.out[%d]" % (V, i))
+        wire(V + ".compConstant.in[253]", Lin())
+        comp_constant(V + ".compConstant", 2736030358979909402780800718157159386076813972158567259200215660948447373040)
+        q(one(V + ".compConstant.out"), en, Lin())
+        for j, nm in enumerate(("R8x", "R8y", "Ax", "Ay", "M")):
+            wire("%s.hash.inputs[%d]" % (V, j), "%s.%s" % (V, nm))
+        if self.pos_model:
+            self.poseidon(V + ".hash", 5)
+        # Num2Bits_strict on the hash
+        H = V + ".h2bits"
+        wire(H + ".in", V + ".hash.out")
+        wire(H + ".n2b.in", H + ".in")
+        self.model("Num2Bits", H + ".n2b", [254])
+        for i in range(254):
+            wire("%s.out[%d]" % (H, i), "%s.n2b.out[%d]" % (H, i))
+            wire("%s.aliasCheck.in[%d]" % (H, i), "%s.n2b.out[%d]" % (H, i))
+            wire("%s.aliasCheck.compConstant.in[%d]" % (H, i), "%s.aliasCheck.in[%d]" % (H, i))
+        comp_constant(H + ".aliasCheck.compConstant", P - 1)
+        q(Lin(), Lin(), one(H + ".aliasCheck.compConstant.out"))
+        wire(V + ".dbl1.x", V + ".Ax"); wire(V + ".dbl1.y", V + ".Ay")
+        wire(V + ".dbl2.x", V + ".dbl1.xout"); wire(V + ".dbl2.y", V + ".dbl1.yout")
+        wire(V + ".dbl3.x", V + ".dbl2.xout"); wire(V + ".dbl3.y", V + ".dbl2.yout")
+        for nm in ("dbl1", "dbl2", "dbl3"):
+            baby_dbl("%s.%s" % (V, nm))
+        wire(V + ".isZero.in", V + ".dbl3.x")
+        self.model("IsZero", V + ".isZero", [])
+        q(one(V + ".isZero.out"), en, Lin())
+        for i in range(254):
+            wire("%s.mulAny.e[%d]" % (V, i), "%s.out[%d]" % (H, i))
+        wire(V + ".mulAny.p[0]", V + ".dbl3.xout"); wire(V + ".mulAny.p[1]", V + ".dbl3.yout")
+        escalar_any(V + ".mulAny", 254)
+        wire(V + ".addRight.x1", V + ".R8x"); wire(V + ".addRight.y1", V + ".R8y")
+        wire(V + ".addRight.x2", V + ".mulAny.out[0]"); wire(V + ".addRight.y2", V + ".mulAny.out[1]")
+        baby_add(V + ".addRight")
+        for i in range(253):
+            wire("%s.mulFix.e[%d]" % (V, i), "%s.snum2bits.out[%d]" % (V, i))
+        escalar_fix(V + ".mulFix", 253)
+        for nm, a0, a1 in (("eqCheckX", "mulFix.out[0]", "addRight.xout"), ("eqCheckY", "mulFix.out[1]", "addRight.yout")):
+            Cq = "%s.%s" % (V, nm)
+            wire(Cq + ".enabled", V + ".enabled"); wire(Cq + ".in[0]", "%s.%s" % (V, a0)); wire(Cq + ".in[1]", "%s.%s" % (V, a1))
+            self.model("ForceEqualIfEnabled", Cq, [])
 
     # -- circomlib 0.5.2 sha256/*.circom as published: every wire and every constraint of Sha256(nBits) -----------------------------------
     def sha256(self, P, n_bits):
@@ -1106,7 +1393,7 @@ def main():
     out = {}
     for key, tmpl, args in MAINS:
         r = Run(defs, sha_model=key == "withdraw", pos_model=key in ("hash-state", "decode-tx", "fee-tx", "rollup-tx"),
-                smt_model=key in ("fee-tx", "rollup-tx"))
+                smt_model=key in ("fee-tx", "rollup-tx"), eddsa_model=key == "rollup-tx")
         r.instantiate(tmpl, args, "main")
         # outputs of black boxes and everything else a form refers to without defining it
         used = {n for f in r.forms.values() for n in f.t} | {n for q in r.quads for f in q for n in f.t}
