@@ -888,8 +888,36 @@ void solve_linear(hz_symmap* m) {
         if (qc[i].in_ab == 0 && qc[i].in_c == 1) work.push_back(QFLAG | i);
         else if (qc[i].in_ab == 1 && qc[i].in_c == 0) later.push_back(i);
     }
+    // Constant folding: a solved variable all of whose terms are constants (the window tables of EscalarMulFix: a chain of quotients and
+    // products over BASE8 -- 3 k variables per transaction, each a field inversion if it were evaluated per read) is evaluated HERE, once,
+    // and becomes a linear form without terms.
+    std::vector<uint8_t> is_const;
+    std::vector<F> const_val;
+    auto fold = [&]() {
+        const size_t k = m->derived.size() - 1;
+        is_const.resize(k + 1, 0); const_val.resize(k + 1);
+        DerivedVar& d = m->derived[k];
+        const uint32_t nf = d.kind == DV_LINEAR ? 1u : 3u;
+        F v[3];
+        for (uint32_t f = 0; f < nf; f++) {
+            const LinForm& lf = m->lins[d.lin + f];
+            v[f] = lf.c0;
+            for (const auto& tm : lf.terms) {
+                const uint64_t j = tm.second & ~DERIVED_FLAG;
+                if (!(tm.second & DERIVED_FLAG) || j >= is_const.size() || !is_const[j]) return;
+                v[f] = hzh::f_add(v[f], hzh::f_mul(tm.first, const_val[j]));
+            }
+        }
+        const F val = d.kind == DV_LINEAR ? v[0] : d.kind == DV_PRODUCT ? hzh::f_add(hzh::f_mul(v[0], v[1]), v[2]) : hzh::f_add(hzh::f_mul(v[0], hzh::f_inv(v[1])), v[2]);
+        m->lins.resize(d.lin + 1);
+        m->lins[d.lin].c0 = val;
+        m->lins[d.lin].terms.clear();
+        d.kind = DV_LINEAR;
+        is_const[k] = 1; const_val[k] = val;
+    };
     auto solved = [&](uint32_t u) {
         m->n_solved++;
+        if ((m->index[u] & DERIVED_FLAG) && (m->index[u] & ~DERIVED_FLAG) == m->derived.size() - 1) fold();
         for (uint32_t j : uses[u]) {
             if (j & QFLAG) {
                 QuadCon& q = qc[j & ~QFLAG];
