@@ -354,6 +354,12 @@ class Run:
         if tmpl == "SMTProcessor" and self.smt_model:
             self.smt_processor(path, args[0])
             return
+        if tmpl == "Bits2Point_Strict" and self.eddsa_model:
+            self.bits2point_strict(path)
+            return
+        if tmpl == "SMTVerifier" and self.smt_model:
+            self.smt_verifier(path, args[0])
+            return
         if tmpl == "EdDSAPoseidonVerifier" and self.eddsa_model:
             self.eddsa(path)
             return
@@ -499,7 +505,62 @@ class Run:
 
     # -- circomlib 0.5.2 smt/smtprocessor.circom as published, with smtlevins, smtprocessorsm, smtprocessorlevel, smthash_poseidon, switcher,
     # gates (XOR, AND, MultiAND), bitify (Num2Bits_strict), aliascheck, compconstant ----------------------------------------------------
-    def smt_processor(self, S, n):
+    # -- circomlib 0.5.2 pointbits.circom Bits2Point_Strict as published (AliasCheck, Bits2Num, BabyCheck, Num2Bits, CompConstant) -----------
+    def bits2point_strict(self, B):
+        f = self.forms
+        one = lambda x: Lin(0, {x: 1})   # noqa: E731
+        q = lambda a, b, c: self.quads.append((Lin.of(a), Lin.of(b), Lin.of(c)))   # noqa: E731
+
+        def comp_constant(CC, ct):
+            b, a, e = (1 << 128) - 1, 1, 1
+            total = Lin()
+            for i in range(127):
+                clsb, cmsb = (ct >> (2 * i)) & 1, (ct >> (2 * i + 1)) & 1
+                slsb, smsb, part = one("%s.in[%d]" % (CC, 2 * i)), one("%s.in[%d]" % (CC, 2 * i + 1)), one("%s.parts[%d]" % (CC, i))
+                if not cmsb and not clsb:
+                    q(smsb.scale(-b), slsb, part.add(smsb.scale(b), -1).add(slsb.scale(b), -1))
+                elif not cmsb and clsb:
+                    q(smsb.scale(a), slsb, part.add(slsb.scale(a)).add(smsb.scale(b), -1).add(smsb.scale(a)).add(Lin(a), -1))
+                elif cmsb and not clsb:
+                    q(smsb.scale(b), slsb, part.add(smsb.scale(a)).add(Lin(a), -1))
+                else:
+                    q(smsb.scale(-a), slsb, part.add(Lin(a), -1))
+                total = total.add(part)
+                b, a, e = b - e, a + e, e * 2
+            f[CC + ".sout"] = total
+            f[CC + ".num2bits.in"] = one(CC + ".sout")
+            self.model("Num2Bits", CC + ".num2bits", [135])
+            f[CC + ".out"] = one(CC + ".num2bits.out[127]")
+        acc = Lin()
+        for i in range(254):
+            f["%s.aliasCheckY.in[%d]" % (B, i)] = one("%s.in[%d]" % (B, i))
+            f["%s.aliasCheckY.compConstant.in[%d]" % (B, i)] = one("%s.aliasCheckY.in[%d]" % (B, i))
+            f["%s.b2nY.in[%d]" % (B, i)] = one("%s.in[%d]" % (B, i))
+            acc = acc.add(one("%s.b2nY.in[%d]" % (B, i)).scale(1 << i))
+        comp_constant(B + ".aliasCheckY.compConstant", P - 1)
+        q(Lin(), Lin(), one(B + ".aliasCheckY.compConstant.out"))
+        q(Lin(), Lin(), one(B + ".in[254]"))                                  # in[254] === 0
+        f[B + ".b2nY.out"] = acc
+        f[B + ".out[1]"] = one(B + ".b2nY.out")
+        self.bases.add(B + ".out[0]")                                        # out[0] <-- the square root with the sign of in[255]
+        f[B + ".babyCheck.x"] = one(B + ".out[0]")
+        f[B + ".babyCheck.y"] = one(B + ".out[1]")
+        x, y, x2, y2 = (one("%s.babyCheck.%s" % (B, n)) for n in ("x", "y", "x2", "y2"))
+        q(x, x, x2); q(y, y, y2)
+        q(x2.scale(168696), y2, x2.scale(168700).add(y2).add(Lin(1), -1))    # a x2 + y2 === 1 + d x2 y2
+        f[B + ".n2bX.in"] = one(B + ".out[0]")
+        self.model("Num2Bits", B + ".n2bX", [254])
+        for i in range(254):
+            f["%s.aliasCheckX.in[%d]" % (B, i)] = one("%s.n2bX.out[%d]" % (B, i))
+            f["%s.aliasCheckX.compConstant.in[%d]" % (B, i)] = one("%s.aliasCheckX.in[%d]" % (B, i))
+            f["%s.signCalc.in[%d]" % (B, i)] = one("%s.n2bX.out[%d]" % (B, i))
+        comp_constant(B + ".aliasCheckX.compConstant", P - 1)
+        q(Lin(), Lin(), one(B + ".aliasCheckX.compConstant.out"))
+        comp_constant(B + ".signCalc", 10944121435919637611123202872628637544274182200208017171849102093287904247808)
+        q(Lin(), Lin(), one(B + ".signCalc.out").add(one(B + ".in[255]"), -1))
+
+    def smt_parts(self):
+        """the pieces SMTProcessor and SMTVerifier share: wire, Num2Bits_strict, Switcher, SMTHash1 / 2, SMTLevIns, MultiAND"""
         f = self.forms
         one = lambda x: Lin(0, {x: 1})   # noqa: E731
         q = lambda a, b, c: self.quads.append((Lin.of(a), Lin.of(b), Lin.of(c)))   # noqa: E731
@@ -551,6 +612,99 @@ class Run:
                 self.poseidon(Hc + ".h", len(ins))
             wire(Hc + ".out", Hc + ".h.out")
 
+
+        def levins(S, n):              # smtlevins.circom
+            LI = S + ".smtLevIns"
+            wire(LI + ".enabled", S + ".enabled")
+            for i in range(n):
+                wire("%s.siblings[%d]" % (LI, i), "%s.siblings[%d]" % (S, i))
+                wire("%s.isZero[%d].in" % (LI, i), "%s.siblings[%d]" % (LI, i))
+                self.model("IsZero", "%s.isZero[%d]" % (LI, i), [])
+            q(one("%s.isZero[%d].out" % (LI, n - 1)).add(K1, -1), one(LI + ".enabled"), Lin())
+            wire("%s.levIns[%d]" % (LI, n - 1), K1.add(one("%s.isZero[%d].out" % (LI, n - 2)), -1))
+            wire("%s.done[%d]" % (LI, n - 2), "%s.levIns[%d]" % (LI, n - 1))
+            for i in range(n - 2, 0, -1):
+                q(K1.add(one("%s.done[%d]" % (LI, i)), -1), K1.add(one("%s.isZero[%d].out" % (LI, i - 1)), -1), one("%s.levIns[%d]" % (LI, i)))
+                wire("%s.done[%d]" % (LI, i - 1), one("%s.levIns[%d]" % (LI, i)).add(one("%s.done[%d]" % (LI, i))))
+            wire(LI + ".levIns[0]", K1.add(one(LI + ".done[0]"), -1))
+
+        def multi_and(Kk, n):          # gates.circom: MultiAND(1) = wire, MultiAND(2) = AND, else AND(MultiAND(n \ 2), MultiAND(n - n \ 2))
+            if n == 1:
+                wire(Kk + ".out", Kk + ".in[0]")
+            elif n == 2:
+                wire(Kk + ".and1.a", Kk + ".in[0]"); wire(Kk + ".and1.b", Kk + ".in[1]")
+                q(one(Kk + ".and1.a"), one(Kk + ".and1.b"), one(Kk + ".and1.out"))
+                wire(Kk + ".out", Kk + ".and1.out")
+            else:
+                n1 = n // 2
+                for i in range(n1):
+                    wire("%s.ands[0].in[%d]" % (Kk, i), "%s.in[%d]" % (Kk, i))
+                for i in range(n - n1):
+                    wire("%s.ands[1].in[%d]" % (Kk, i), "%s.in[%d]" % (Kk, n1 + i))
+                multi_and(Kk + ".ands[0]", n1); multi_and(Kk + ".ands[1]", n - n1)
+                wire(Kk + ".and2.a", Kk + ".ands[0].out"); wire(Kk + ".and2.b", Kk + ".ands[1].out")
+                q(one(Kk + ".and2.a"), one(Kk + ".and2.b"), one(Kk + ".and2.out"))
+                wire(Kk + ".out", Kk + ".and2.out")
+        return f, one, q, K1, wire, num2bits_strict, switcher, hash_, levins, multi_and
+
+    # -- circomlib 0.5.2 smt/smtverifier.circom as published, with smtverifiersm, smtverifierlevel ------------------------------------------
+    def smt_verifier(self, S, n):
+        f, one, q, K1, wire, num2bits_strict, switcher, hash_, levins, multi_and = self.smt_parts()
+        for nm, key, value in (("hash1Old", "oldKey", "oldValue"), ("hash1New", "key", "value")):
+            wire("%s.%s.key" % (S, nm), "%s.%s" % (S, key))
+            wire("%s.%s.value" % (S, nm), "%s.%s" % (S, value))
+            hash_("%s.%s" % (S, nm), ["%s.%s.key" % (S, nm), "%s.%s.value" % (S, nm), K1])
+        wire(S + ".n2bOld.in", S + ".oldKey"); wire(S + ".n2bNew.in", S + ".key")
+        num2bits_strict(S + ".n2bOld"); num2bits_strict(S + ".n2bNew")
+        levins(S, n)
+        st = ("top", "i0", "iold", "inew", "na")
+        for i in range(n):
+            M = "%s.sm[%d]" % (S, i)
+            for nm in st:
+                if i == 0:
+                    wire("%s.prev_%s" % (M, nm), one(S + ".enabled") if nm == "top" else K1.add(one(S + ".enabled"), -1) if nm == "na" else Lin())
+                else:
+                    wire("%s.prev_%s" % (M, nm), "%s.sm[%d].st_%s" % (S, i - 1, nm))
+            wire(M + ".is0", S + ".isOld0"); wire(M + ".fnc", S + ".fnc"); wire(M + ".levIns", "%s.smtLevIns.levIns[%d]" % (S, i))
+            g = lambda x, M=M: one("%s.%s" % (M, x))   # noqa: E731
+            q(g("prev_top"), g("levIns"), g("prev_top_lev_ins"))
+            q(g("prev_top_lev_ins"), g("fnc"), g("prev_top_lev_ins_fnc"))
+            wire(M + ".st_top", g("prev_top").add(g("prev_top_lev_ins"), -1))
+            wire(M + ".st_inew", g("prev_top_lev_ins").add(g("prev_top_lev_ins_fnc"), -1))
+            q(g("prev_top_lev_ins_fnc"), K1.add(g("is0"), -1), g("st_iold"))
+            q(g("prev_top_lev_ins"), g("is0"), g("st_i0"))
+            wire(M + ".st_na", g("prev_na").add(g("prev_inew")).add(g("prev_iold")).add(g("prev_i0")))
+        last = "%s.sm[%d]" % (S, n - 1)
+        q(Lin(), Lin(), one(last + ".st_na").add(one(last + ".st_iold")).add(one(last + ".st_inew")).add(one(last + ".st_i0")).add(K1, -1))
+        for i in range(n - 1, -1, -1):
+            Lv = "%s.levels[%d]" % (S, i)
+            for nm in st:
+                wire("%s.st_%s" % (Lv, nm), "%s.sm[%d].st_%s" % (S, i, nm))
+            wire(Lv + ".sibling", "%s.siblings[%d]" % (S, i))
+            wire(Lv + ".old1leaf", S + ".hash1Old.out"); wire(Lv + ".new1leaf", S + ".hash1New.out")
+            wire(Lv + ".lrbit", "%s.n2bNew.out[%d]" % (S, i))
+            wire(Lv + ".child", Lin() if i == n - 1 else one("%s.levels[%d].root" % (S, i + 1)))
+            g = lambda x, Lv=Lv: one("%s.%s" % (Lv, x))   # noqa: E731
+            wire(Lv + ".switcher.L", g("child")); wire(Lv + ".switcher.R", g("sibling")); wire(Lv + ".switcher.sel", g("lrbit"))
+            switcher(Lv + ".switcher")
+            hash_(Lv + ".proofHash", [Lv + ".proofHash.L", Lv + ".proofHash.R"])
+            wire(Lv + ".proofHash.L", Lv + ".switcher.outL"); wire(Lv + ".proofHash.R", Lv + ".switcher.outR")
+            q(g("proofHash.out"), g("st_top"), g("aux[0]"))
+            q(g("old1leaf"), g("st_iold"), g("aux[1]"))
+            q(g("new1leaf"), g("st_inew"), g("root").add(g("aux[0]"), -1).add(g("aux[1]"), -1))
+        E = S + ".areKeyEquals"
+        wire(E + ".in[0]", S + ".oldKey"); wire(E + ".in[1]", S + ".key")
+        self.model("IsEqual", E, [])
+        Kk = S + ".keysOk"
+        wire(Kk + ".in[0]", S + ".fnc"); wire(Kk + ".in[1]", K1.add(one(S + ".isOld0"), -1)); wire(Kk + ".in[2]", E + ".out"); wire(Kk + ".in[3]", S + ".enabled")
+        multi_and(Kk, 4)
+        q(Lin(), Lin(), one(Kk + ".out"))
+        Ck = S + ".checkRoot"
+        wire(Ck + ".enabled", S + ".enabled"); wire(Ck + ".in[0]", S + ".levels[0].root"); wire(Ck + ".in[1]", S + ".root")
+        self.model("ForceEqualIfEnabled", Ck, [])
+
+    def smt_processor(self, S, n):
+        f, one, q, K1, wire, num2bits_strict, switcher, hash_, levins, multi_and = self.smt_parts()
         fnc0, fnc1 = one(S + ".fnc[0]"), one(S + ".fnc[1]")
         q(fnc0, fnc1, fnc0.add(fnc1).add(one(S + ".enabled"), -1))             # enabled <== fnc[0] + fnc[1] - fnc[0]*fnc[1]
         for nm, key, value in (("hash1Old", "oldKey", "oldValue"), ("hash1New", "newKey", "newValue")):
@@ -561,20 +715,8 @@ class Run:
         wire(S + ".n2bNew.in", S + ".newKey")
         num2bits_strict(S + ".n2bOld")
         num2bits_strict(S + ".n2bNew")
-        # smtlevins.circom
+        levins(S, n)
         LI = S + ".smtLevIns"
-        wire(LI + ".enabled", S + ".enabled")
-        for i in range(n):
-            wire("%s.siblings[%d]" % (LI, i), "%s.siblings[%d]" % (S, i))
-            wire("%s.isZero[%d].in" % (LI, i), "%s.siblings[%d]" % (LI, i))
-            self.model("IsZero", "%s.isZero[%d]" % (LI, i), [])
-        q(one("%s.isZero[%d].out" % (LI, n - 1)).add(K1, -1), one(LI + ".enabled"), Lin())
-        wire("%s.levIns[%d]" % (LI, n - 1), K1.add(one("%s.isZero[%d].out" % (LI, n - 2)), -1))
-        wire("%s.done[%d]" % (LI, n - 2), "%s.levIns[%d]" % (LI, n - 1))
-        for i in range(n - 2, 0, -1):
-            q(K1.add(one("%s.done[%d]" % (LI, i)), -1), K1.add(one("%s.isZero[%d].out" % (LI, i - 1)), -1), one("%s.levIns[%d]" % (LI, i)))
-            wire("%s.done[%d]" % (LI, i - 1), one("%s.levIns[%d]" % (LI, i)).add(one("%s.done[%d]" % (LI, i))))
-        wire(LI + ".levIns[0]", K1.add(one(LI + ".done[0]"), -1))
         for i in range(n):             # gates.circom XOR: out <== a + b - 2*a*b
             X = "%s.xors[%d]" % (S, i)
             wire(X + ".a", "%s.n2bOld.out[%d]" % (S, i))
@@ -1392,8 +1534,8 @@ def main():
                 defs.update(Parser(tokenize(open(os.path.join(root, f)).read())).program())
     out = {}
     for key, tmpl, args in MAINS:
-        r = Run(defs, sha_model=key == "withdraw", pos_model=key in ("hash-state", "decode-tx", "fee-tx", "rollup-tx"),
-                smt_model=key in ("fee-tx", "rollup-tx"), eddsa_model=key == "rollup-tx")
+        r = Run(defs, sha_model=key == "withdraw", pos_model=key in ("hash-state", "decode-tx", "fee-tx", "rollup-tx", "withdraw"),
+                smt_model=key in ("fee-tx", "rollup-tx", "withdraw"), eddsa_model=key in ("rollup-tx", "ay-sign-2-ax"))
         r.instantiate(tmpl, args, "main")
         # outputs of black boxes and everything else a form refers to without defining it
         used = {n for f in r.forms.values() for n in f.t} | {n for q in r.quads for f in q for n in f.t}
