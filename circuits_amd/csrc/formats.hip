@@ -751,7 +751,8 @@ hz_status parse_r1cs(const uint8_t* data, size_t len, hz_symmap::R1cs& r) {
     r.off.assign(1, 0);
     r.off.reserve((size_t)nc * 3 + 1);
     r.wire.reserve((size_t)(cons_len / 36)); r.coef.reserve((size_t)(cons_len / 36));
-    std::map<std::array<uint64_t, 4>, uint32_t> ids;
+    struct KeyHash { size_t operator()(const std::array<uint64_t, 4>& k) const { return (size_t)(k[0] * 0x9E3779B97F4A7C15ull ^ k[1] ^ (k[2] << 1) ^ (k[3] * 31)); } };
+    std::unordered_map<std::array<uint64_t, 4>, uint32_t, KeyHash> ids;
     Rd c{cons, cons + cons_len};
     for (uint64_t k = 0; k < (uint64_t)nc * 3; k++) {
         uint32_t n = 0;
@@ -807,22 +808,24 @@ void solve_linear(hz_symmap* m) {
         for (int q = 0; q < 3 && !any; q++)
             for (uint64_t t = r.off[3 * c + q]; t < r.off[3 * c + q + 1] && !any; t++) any = m->index[r.wire[t]] == ~0ull && r.wire[t] != 0;
         if (!any) continue;
-        std::map<uint32_t, F> acc;
+        std::vector<std::pair<uint32_t, F>> acc;   // terms with repeats, merged after a sort (a tree map per constraint was the cost of the import)
         auto add = [&](int q, const F& scale) {
-            for (uint64_t t = r.off[3 * c + q]; t < r.off[3 * c + q + 1]; t++) {
-                F& a = acc.emplace(r.wire[t], hzh::f_zero()).first->second;
-                a = hzh::f_add(a, hzh::f_mul(scale, r.pool[r.coef[t]]));
-            }
+            for (uint64_t t = r.off[3 * c + q]; t < r.off[3 * c + q + 1]; t++) acc.push_back({r.wire[t], hzh::f_mul(scale, r.pool[r.coef[t]])});
         };
         if (la) add(1, ka); else add(0, kb);     // ka * B  (or kb * A) ...
-        if (la && lb) { /* a constant times a constant */ acc.clear(); F& a = acc.emplace(0u, hzh::f_zero()).first->second; a = hzh::f_mul(ka, kb); }
         add(2, f_neg(hzh::f_one()));             // ... - C
+        std::sort(acc.begin(), acc.end(), [](const std::pair<uint32_t, F>& x, const std::pair<uint32_t, F>& y) { return x.first < y.first; });
         LinCon con;
-        for (const auto& kv : acc)
-            if (!hzh::f_is_zero(kv.second)) {
-                con.t.push_back(kv);
-                if (kv.first != 0 && m->index[kv.first] == ~0ull) con.unknown++;
+        for (size_t i = 0; i < acc.size();) {
+            F sum = acc[i].second;
+            size_t j = i + 1;
+            for (; j < acc.size() && acc[j].first == acc[i].first; j++) sum = hzh::f_add(sum, acc[j].second);
+            if (!hzh::f_is_zero(sum)) {
+                con.t.push_back({acc[i].first, sum});
+                if (acc[i].first != 0 && m->index[acc[i].first] == ~0ull) con.unknown++;
             }
+            i = j;
+        }
         if (!con.unknown) continue;
         for (const auto& kv : con.t)
             if (kv.first != 0 && m->index[kv.first] == ~0ull) uses[kv.first].push_back((uint32_t)lc.size());
@@ -1072,6 +1075,7 @@ hz_status symmap_build(const hz_ctx* ctx, const char* text, size_t len, const ui
         if (m->r1cs.n_wires > var_cap) { delete m; return set_err(HZ_ERR_INPUT, ".r1cs: %llu wires for a .sym of %llu lines", (unsigned long long)m->r1cs.n_wires, (unsigned long long)n_lines); }
         solve_linear(m);
         label.resize(m->index.size());
+
     }
     for (size_t v = 0; v < m->index.size(); v++) {
         if (m->index[v] == ~0ull) {
