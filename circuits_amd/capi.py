@@ -62,7 +62,7 @@ EXPORTS = [
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_witness_enqueue_tail_chain", "hz_sha_blocks", "hz_sha_state_bytes", "hz_sha_export", "hz_sha_expand",
-    "hz_symmap_create", "hz_symmap_create_r1cs", "hz_symmap_solved", "hz_symmap_check_r1cs", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_symmap_derived", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
+    "hz_symmap_create", "hz_symmap_create_r1cs", "hz_symmap_solved", "hz_symmap_check_r1cs", "hz_symmap_save", "hz_symmap_load", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_symmap_derived", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
     "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym", "hz_fr_ops", "hz_poseidon_dag",
 ]
@@ -132,6 +132,8 @@ class Lib:
         c.hz_symmap_solved.argtypes = [vp]
         c.hz_symmap_solved.restype = u64
         c.hz_symmap_check_r1cs.argtypes = [vp, vp, ctypes.c_int32, ctypes.POINTER(u64), ctypes.POINTER(u64), u64]
+        c.hz_symmap_save.argtypes = [vp, vp, ctypes.c_char_p]
+        c.hz_symmap_load.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp)]
         c.hz_symmap_destroy.argtypes = [vp]
         c.hz_symmap_destroy.restype = None
         c.hz_symmap_nvars.argtypes = [vp]
@@ -467,6 +469,12 @@ class Ctx:
             self.L._check(self.L.c.hz_symmap_create_r1cs(self.h, b, len(b), bytes(r1cs), len(r1cs), ctypes.byref(h)))
         return SymMap(self, h)
 
+    def load_symmap(self, path):
+        """hz_symmap_load: a map written by SymMap.save for this template and shape"""
+        h = ctypes.c_void_p()
+        self.L._check(self.L.c.hz_symmap_load(self.h, path.encode(), ctypes.byref(h)))
+        return SymMap(self, h)
+
     def symbol_count(self):
         return self.L.c.hz_symbol_count(self.h)
 
@@ -498,6 +506,9 @@ class SymMap:
             self.ctx.L.c.hz_symmap_unresolved(self.h, i, ctypes.byref(v), ctypes.byref(nm))
             out.append((v.value, nm.value.decode()))
         return out
+
+    def save(self, path):
+        self.ctx.L._check(self.ctx.L.c.hz_symmap_save(self.ctx.h, self.h, path.encode()))
 
     def solved(self):
         """variables defined by the linear constraints of the .r1cs (hz_symmap_create_r1cs)"""

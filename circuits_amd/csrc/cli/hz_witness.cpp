@@ -2,7 +2,7 @@
 // `./circuit input.json witness.json` the reference runs at tools/helpers/actions.js:132-146 (and of
 // `snarkjs wtns calculate` for the .wtns output). Plain C++ over the C ABI of include/hermez_witness.h.
 //
-//   hz_witness "RollupMain(2048,32,256,64)" input.json witness.wtns [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--check]]] [--device 0]
+//   hz_witness "RollupMain(2048,32,256,64)" input.json witness.wtns [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--check]]] [--map circuit.hzmap] [--device 0]
 //   hz_witness path/to/main.circom input.json witness.json
 //
 // The first argument is `Template(params)` or a .circom file whose `component main = Template(params);` line is
@@ -15,6 +15,8 @@
 // With --circom-r1cs <the .r1cs of the same compile> the variables no name resolves -- the wire-through signals of a compile without
 // constraint reduction -- are solved from the circuit's linear constraints (hz_symmap_create_r1cs), and --check evaluates every
 // constraint of the .r1cs on the witness before it is written (what `snarkjs wtns check` does; exit status 1 when one fails).
+// --map <file>: the resolved map is kept there -- read when the file exists (the .sym / .r1cs are then not needed), written after an
+// import otherwise: the import of a full-size circuit takes minutes, the map loads in seconds.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -109,12 +111,13 @@ static hz_status set_json_unsupported() {
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s \"Template(params)\"|main.circom input.json witness.{wtns,json} [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--check]]] [--device N]\n", argv[0]);
+        fprintf(stderr, "usage: %s \"Template(params)\"|main.circom input.json witness.{wtns,json} [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--check]]] [--map circuit.hzmap] [--device N]\n", argv[0]);
         return 2;
     }
     const char* sym = nullptr;
     const char* circom_sym = nullptr;
     const char* circom_r1cs = nullptr;
+    const char* map_path = nullptr;
     bool check = false;
     int device = 0;
     for (int i = 4; i < argc; i++) {
@@ -122,6 +125,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--circom-sym") && i + 1 < argc) circom_sym = argv[++i];
         else if (!strcmp(argv[i], "--circom-r1cs") && i + 1 < argc) circom_r1cs = argv[++i];
         else if (!strcmp(argv[i], "--check")) check = true;
+        else if (!strcmp(argv[i], "--map") && i + 1 < argc) map_path = argv[++i];
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -154,7 +158,16 @@ int main(int argc, char** argv) {
     } else {
         const size_t n = strlen(argv[3]);
         const bool wtns = n > 5 && !strcmp(argv[3] + n - 5, ".wtns");
-        if (circom_sym) {
+        FILE* have_map = map_path ? fopen(map_path, "rb") : nullptr;
+        if (have_map) {
+            fclose(have_map);
+            hz_symmap* m = nullptr;
+            st = hz_symmap_load(c, map_path, &m);
+            if (st == HZ_OK) {
+                st = wtns ? hz_witness_write_wtns_sym(c, m, 0, argv[3]) : set_json_unsupported();
+                hz_symmap_destroy(m);
+            }
+        } else if (circom_sym) {
             const std::string st_text = slurp(circom_sym, &ok);
             hz_symmap* m = nullptr;
             if (!ok) { fprintf(stderr, "cannot read %s\n", circom_sym); hz_ctx_destroy(c); return 2; }
@@ -185,6 +198,7 @@ int main(int argc, char** argv) {
                     fprintf(stderr, "not stored by this layout: variable %llu (%s)\n", (unsigned long long)var, nm);
                 }
                 st = wtns ? hz_witness_write_wtns_sym(c, m, 0, argv[3]) : set_json_unsupported();
+                if (st == HZ_OK && map_path) st = hz_symmap_save(c, m, map_path);
                 hz_symmap_destroy(m);
             }
         } else

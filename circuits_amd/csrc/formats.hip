@@ -1094,6 +1094,102 @@ hz_status symmap_build(const hz_ctx* ctx, const char* text, size_t len, const ui
 }  // namespace
 extern "C" uint64_t hz_symmap_solved(const hz_symmap* m) { return m ? m->n_solved : 0; }
 extern "C" void hz_symmap_destroy(hz_symmap* m) { delete m; }
+static hz_status symmap_usable(const hz_symmap* m, const char* who);
+// A resolved map on disk: importing the .sym / .r1cs of a full-size circuit takes minutes (10^8 names, as many constraints), the map
+// itself is a few arrays. "hzsm", version, the layout's witness length and symbol count (a map belongs to one template and shape),
+// then index / derived / linear forms. The constraint system is not kept: a loaded map serves the witness, hz_symmap_check_r1cs wants
+// the one made from the files.
+namespace {
+struct MapHdr { char magic[4]; uint32_t version; uint64_t witness_len, symbols, n_index, n_derived, n_lins, n_terms, n_solved, n_derived_vars; };
+}
+extern "C" hz_status hz_symmap_save(const hz_ctx* ctx, const hz_symmap* m, const char* path) {
+    const hz_status st0 = symmap_usable(m, "hz_symmap_save");
+    if (st0 != HZ_OK) return st0;
+    if (!ctx || !path) return set_err(HZ_ERR_ARG, "hz_symmap_save: null argument");
+    FILE* f = fopen(path, "wb");
+    if (!f) return set_err(HZ_ERR_INPUT, "hz_symmap_save: cannot write %s", path);
+    uint64_t n_terms = 0;
+    for (const LinForm& lf : m->lins) n_terms += lf.terms.size();
+    MapHdr h{{'h', 'z', 's', 'm'}, 1, hz_witness_len(ctx), hz_symbol_count(ctx), m->index.size(), m->derived.size(), m->lins.size(), n_terms, m->n_solved, m->n_derived};
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+    ok = ok && (m->index.empty() || fwrite(m->index.data(), 8, m->index.size(), f) == m->index.size());
+    for (const DerivedVar& d : m->derived) {
+        const uint64_t rec[4] = {(uint64_t)d.kind | ((uint64_t)d.t << 8) | ((uint64_t)d.what << 16) | ((uint64_t)d.round << 24) | ((uint64_t)d.lane << 40), d.lin, d.first, d.stride};
+        ok = ok && fwrite(rec, 8, 4, f) == 4;
+    }
+    for (const LinForm& lf : m->lins) {
+        const uint64_t n = lf.terms.size();
+        ok = ok && fwrite(&n, 8, 1, f) == 1 && fwrite(lf.c0.v, 8, 4, f) == 4;
+        for (const auto& tm : lf.terms) ok = ok && fwrite(tm.first.v, 8, 4, f) == 4 && fwrite(&tm.second, 8, 1, f) == 1;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? HZ_OK : set_err(HZ_ERR_INPUT, "hz_symmap_save: short write to %s", path);
+}
+extern "C" hz_status hz_symmap_load(const hz_ctx* ctx, const char* path, hz_symmap** out) {
+    if (!ctx || !path || !out) return set_err(HZ_ERR_ARG, "hz_symmap_load: null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return set_err(HZ_ERR_INPUT, "hz_symmap_load: cannot read %s", path);
+    hz_symmap* m = nullptr;
+    try {
+        MapHdr h;
+        bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "hzsm", 4) && h.version == 1;
+        if (ok && (h.witness_len != hz_witness_len(ctx) || h.symbols != hz_symbol_count(ctx))) {
+            fclose(f);
+            return set_err(HZ_ERR_INPUT, "hz_symmap_load: %s was made for another template or shape (witness length %llu, this context %llu)", path,
+                           (unsigned long long)h.witness_len, (unsigned long long)hz_witness_len(ctx));
+        }
+        // every count is bounded by the file's own size before anything is allocated
+        fseek(f, 0, SEEK_END);
+        const uint64_t size = (uint64_t)ftell(f);
+        fseek(f, (long)sizeof h, SEEK_SET);
+        ok = ok && h.n_index <= size / 8 && h.n_derived <= size / 32 && h.n_lins <= size / 40 && h.n_terms <= size / 40 && h.n_index <= 8 * h.witness_len + 2048;
+        if (ok) {
+            m = new hz_symmap();
+            m->index.resize((size_t)h.n_index);
+            ok = m->index.empty() || fread(m->index.data(), 8, m->index.size(), f) == m->index.size();
+            m->derived.resize((size_t)h.n_derived);
+            for (DerivedVar& d : m->derived) {
+                uint64_t rec[4];
+                ok = ok && fread(rec, 8, 4, f) == 4;
+                d.kind = (uint8_t)rec[0]; d.t = (uint8_t)(rec[0] >> 8); d.what = (uint8_t)(rec[0] >> 16); d.round = (uint16_t)(rec[0] >> 24); d.lane = (uint16_t)(rec[0] >> 40);
+                d.lin = (uint32_t)rec[1]; d.first = rec[2]; d.stride = rec[3];
+                ok = ok && d.kind >= DV_POSEIDON && d.kind <= DV_QUOTIENT && (d.kind == DV_POSEIDON || d.kind == DV_ISZERO_IN || (uint64_t)d.lin + (d.kind == DV_LINEAR ? 1 : 3) <= h.n_lins);
+                ok = ok && (d.kind != DV_POSEIDON || (d.t >= 2 && d.t <= 7 && d.first + 3ull * pos_nsbox(d.t) * d.stride <= h.witness_len)) && (d.kind != DV_ISZERO_IN || d.first < h.witness_len);
+            }
+            m->lins.resize((size_t)h.n_lins);
+            uint64_t left = h.n_terms;
+            for (size_t k = 0; k < m->lins.size() && ok; k++) {
+                LinForm& lf = m->lins[k];
+                uint64_t n = 0;
+                ok = fread(&n, 8, 1, f) == 1 && fread(lf.c0.v, 8, 4, f) == 4 && n <= left;
+                if (!ok) break;
+                left -= n;
+                lf.terms.resize((size_t)n);
+                for (auto& tm : lf.terms) {
+                    ok = ok && fread(tm.first.v, 8, 4, f) == 4 && fread(&tm.second, 8, 1, f) == 1;
+                    // a term names a stored signal, or a derived variable made BEFORE the one this form belongs to (evaluation order)
+                    ok = ok && ((tm.second & DERIVED_FLAG) ? (tm.second & ~DERIVED_FLAG) < h.n_derived : tm.second < h.witness_len);
+                }
+            }
+            for (size_t k = 0; k < m->derived.size() && ok; k++) {   // forward references would read an unevaluated value
+                const DerivedVar& d = m->derived[k];
+                if (d.kind == DV_POSEIDON || d.kind == DV_ISZERO_IN) continue;
+                for (uint32_t q = d.lin; q < d.lin + (d.kind == DV_LINEAR ? 1u : 3u); q++)
+                    for (const auto& tm : m->lins[q].terms) ok = ok && (!(tm.second & DERIVED_FLAG) || (tm.second & ~DERIVED_FLAG) < k);
+            }
+            for (uint64_t v : m->index) ok = ok && ((v & DERIVED_FLAG) ? (v & ~DERIVED_FLAG) < h.n_derived : v < h.witness_len);
+            m->n_solved = h.n_solved; m->n_derived = h.n_derived_vars;
+        }
+        fclose(f);
+        if (!ok) { delete m; return set_err(HZ_ERR_INPUT, "hz_symmap_load: %s is not a symbol map of this library (or is damaged)", path); }
+        *out = m;
+        return HZ_OK;
+    } catch (const std::bad_alloc&) {
+        fclose(f);
+        delete m;
+        return set_err(HZ_ERR_INPUT, "hz_symmap_load: out of memory");
+    }
+}
 extern "C" uint64_t hz_symmap_nvars(const hz_symmap* m) { return m ? m->index.size() : 0; }
 extern "C" uint64_t hz_symmap_unresolved(const hz_symmap* m, uint64_t i, uint64_t* var, const char** name) {
     if (!m) return 0;

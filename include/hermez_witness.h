@@ -239,6 +239,10 @@ uint64_t hz_symmap_derived(const hz_symmap* map);
 hz_status hz_symmap_create_r1cs(const hz_ctx* ctx, const char* sym_text, size_t sym_len, const uint8_t* r1cs, size_t r1cs_len, hz_symmap** out);
 uint64_t hz_symmap_solved(const hz_symmap* map);
 hz_status hz_symmap_check_r1cs(hz_ctx* ctx, const hz_symmap* map, int32_t instance, uint64_t* n_bad, uint64_t* first_bad, uint64_t cap);
+/* A resolved map on disk: importing the files of a full-size circuit takes minutes, the map is a few arrays. A map belongs to one
+ * template and shape (checked on load); the constraint system is not kept (hz_symmap_check_r1cs needs a map made from the files). */
+hz_status hz_symmap_save(const hz_ctx* ctx, const hz_symmap* map, const char* path);
+hz_status hz_symmap_load(const hz_ctx* ctx, const char* path, hz_symmap** out);
 hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instance, uint64_t first_var, uint64_t count, uint8_t* out);
 hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instance, const char* path);
 hz_status hz_witness_gather(hz_ctx* ctx, int32_t instance, const uint64_t* index, uint64_t count, uint8_t* out);

@@ -249,6 +249,24 @@ def test_hip_native_binary_with_the_compilers_sym_and_r1cs(hz, tmp_path):
     assert r.returncode == 0 and "every constraint holds" in r.stderr, r.stderr
     got = _parse_wtns(wpath)
     assert got[0] == 1 and got[1:] == [val[n] for n in names]
+    # the resolved map kept on disk (--map): written by an import, then enough on its own -- the same file without .sym / .r1cs
+    mpath, w2, w3 = str(tmp_path / "c.hzmap"), str(tmp_path / "out2.wtns"), str(tmp_path / "out3.wtns")
+    subprocess.run([cli, "RollupTx(16,2)", ipath, w2, "--circom-sym", spath, "--circom-r1cs", rpath, "--map", mpath], check=True)
+    assert os.path.getsize(mpath) > 0 and open(w2, "rb").read() == open(wpath, "rb").read()
+    subprocess.run([cli, "RollupTx(16,2)", ipath, w3, "--map", mpath], check=True)
+    assert open(w3, "rb").read() == open(wpath, "rb").read()
+    r = subprocess.run([cli, "RollupTx(16,4)", ipath, str(tmp_path / "no2.wtns"), "--map", mpath], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and not os.path.exists(str(tmp_path / "no2.wtns"))   # a map of another shape (or inputs that do not fit it)
+    blob = bytearray(open(mpath, "rb").read())
+    for cut in (10, len(blob) // 2, len(blob) - 9):
+        open(mpath + ".cut", "wb").write(blob[:cut])
+        r = subprocess.run([cli, "RollupTx(16,2)", ipath, str(tmp_path / "no3.wtns"), "--map", mpath + ".cut"], stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 1 and "hz_symmap_load" in r.stderr
+    blob[len(blob) // 3] ^= 0x80   # an index or a count out of range must be refused, never followed
+    blob[-5] ^= 0x80
+    open(mpath + ".bad", "wb").write(blob)
+    r = subprocess.run([cli, "RollupTx(16,2)", ipath, str(tmp_path / "no4.wtns"), "--map", mpath + ".bad"], stderr=subprocess.PIPE, text=True)
+    assert r.returncode in (0, 1) and (r.returncode == 0 or "hz_symmap_load" in r.stderr or "Error" in r.stderr)
     # without the .r1cs the same .sym cannot be served: the wire-through variables are listed
     r = subprocess.run([cli, "RollupTx(16,2)", ipath, str(tmp_path / "no.wtns"), "--circom-sym", spath], stderr=subprocess.PIPE, text=True)
     assert r.returncode == 1 and "not stored by this layout" in r.stderr and not os.path.exists(str(tmp_path / "no.wtns"))
