@@ -1525,25 +1525,36 @@ MAINS = [
 ]
 
 
-def main():
-    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+def load_defs(ref):
     defs = {}
     for root, _, files in os.walk(os.path.join(ref, "src")):
         for f in sorted(files):
             if f.endswith(".circom"):
                 defs.update(Parser(tokenize(open(os.path.join(root, f)).read())).program())
+    return defs
+
+
+def build(defs, tmpl, args, **models):
+    """the recorded system of `tmpl(args)` as `component main` (the object stored per main in declared_forms.json.gz)"""
+    r = Run(defs, **models)
+    r.instantiate(tmpl, args, "main")
+    # outputs of black boxes and everything else a form refers to without defining it
+    used = {n for f in r.forms.values() for n in f.t} | {n for q in r.quads for f in q for n in f.t}
+    bases = sorted((r.bases | used) - set(r.forms))
+    lin = lambda f: [str(f.c), [[str(c), m] for m, c in sorted(f.t.items())]]   # noqa: E731
+    return {"template": tmpl, "args": args, "forms": {n: lin(f) for n, f in sorted(r.forms.items())},
+            "quads": [[lin(a), lin(b), lin(c)] for a, b, c in r.quads], "bases": bases, "declared": r.declared}
+
+
+def main():
+    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    defs = load_defs(ref)
     out = {}
     for key, tmpl, args in MAINS:
-        r = Run(defs, sha_model=key == "withdraw", pos_model=key in ("hash-state", "decode-tx", "fee-tx", "rollup-tx", "withdraw"),
-                smt_model=key in ("fee-tx", "rollup-tx", "withdraw"), eddsa_model=key in ("rollup-tx", "ay-sign-2-ax"))
-        r.instantiate(tmpl, args, "main")
-        # outputs of black boxes and everything else a form refers to without defining it
-        used = {n for f in r.forms.values() for n in f.t} | {n for q in r.quads for f in q for n in f.t}
-        bases = sorted((r.bases | used) - set(r.forms))
-        lin = lambda f: [str(f.c), [[str(c), m] for m, c in sorted(f.t.items())]]   # noqa: E731
-        out[key] = {"template": tmpl, "args": args, "forms": {n: lin(f) for n, f in sorted(r.forms.items())},
-                    "quads": [[lin(a), lin(b), lin(c)] for a, b, c in r.quads], "bases": bases, "declared": r.declared}
-        print("%-28s %6d forms, %6d product / === constraints, %6d bases, %6d declared" % ("%s(%s)" % (tmpl, ",".join(map(str, args))), len(r.forms), len(r.quads), len(bases), len(r.declared)))
+        out[key] = m = build(defs, tmpl, args, sha_model=key == "withdraw", pos_model=key in ("hash-state", "decode-tx", "fee-tx", "rollup-tx", "withdraw"),
+                             smt_model=key in ("fee-tx", "rollup-tx", "withdraw"), eddsa_model=key in ("rollup-tx", "ay-sign-2-ax"))
+        print("%-28s %6d forms, %6d product / === constraints, %6d bases, %6d declared" % ("%s(%s)" % (tmpl, ",".join(map(str, args))), len(m["forms"]), len(m["quads"]),
+                                                                                             len(m["bases"]), len(m["declared"])))
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "declared_forms.json.gz")
     with gzip.GzipFile(dst, "wb", mtime=0) as g:
         g.write(json.dumps(out, sort_keys=True, separators=(",", ":")).encode())

@@ -151,6 +151,40 @@ def test_oracle_rejects_whatever_violates_a_recorded_constraint(key, shape, gen)
     assert stat[(False, False)] >= 1 and stat[(True, True)] + stat["not bits"] >= 1, stat   # both kinds occur
 
 
+def test_complete_rollup_main_when_the_reference_is_at_hand():
+    """RollupMain with EVERY circomlib model on (Poseidon, SMTProcessor, EdDSAPoseidonVerifier, Bits2Point_Strict; Sha256 -- a million
+    signals -- only on request) is too large to commit as a fixture; where the reference's sources are present (the build
+    container) the system is recorded on the spot: the main-level wiring together with every component, 4 x 10^5 constraints, all
+    satisfied by the oracle's witness of a synthetic batch."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src")):
+        pytest.skip("the reference's sources are not here")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("extract_declared_forms", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "extract_declared_forms.py"))
+    X = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(X)
+    shape = (3, 16, 2, 1)   # (the bit string SHA-256 hashes must be whole bytes for hashlib: (2 nTx + maxFeeTx) * nLevels a multiple of 8)
+    # HZ_FULL_SYSTEM=1 turns the Sha256 model on as well (nothing opaque at all: 1.4 x 10^6 signals, 90 s; it passes -- the Withdraw
+    # fixture holds the same Sha256 model in every run)
+    m = X.build(X.load_defs(ref), "RollupMain", list(shape), pos_model=True, smt_model=True, eddsa_model=True, sha_model=os.environ.get("HZ_FULL_SYSTEM") == "1")
+    assert len(m["quads"]) > 100000 and len(m["forms"]) > 300000
+    bb = B.synthetic_batch(*shape, n_accounts=5, exits=1, seed=3)
+    o = OracleCtx("rollup-main", *shape)
+    o.set_inputs(bb.get_input())
+    assert o.run() is None
+    vals = o.read(0, o.witness_len())
+    known = {}
+    for n in DF.all_names(m):
+        try:
+            known[n] = vals[o.lookup(n)]
+        except KeyError:
+            pass
+    val, unknown = DF.solve_with_hashes(m, known, lambda xs: B.host().poseidon(xs))
+    assert not unknown, (len(unknown), unknown[:6])
+    assert DF.violated(m, val) == []
+    assert all(val[n] == v for n, v in known.items())
+
+
 def test_synthetic_r1cs_has_the_documented_shape():
     """the .r1cs bytes the GPU test hands to the library: header fields and one constraint per form / product line"""
     import struct
