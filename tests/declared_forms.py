@@ -18,6 +18,11 @@ def load(key):
     return _DATA[key]
 
 
+def load_file(path):
+    """one main's system from a file of its own (tests/_generated/, written by __graft_entry__.build() where the reference is present)"""
+    return json.loads(gzip.open(path).read())
+
+
 def _lin(f):
     return int(f[0]), [(int(c), n) for c, n in f[1]]
 

@@ -311,3 +311,44 @@ def test_hip_native_binary_with_the_compilers_sym_and_r1cs(hz, tmp_path):
     open(rpath, "wb").write(DF.sym_and_r1cs(m2)[1])
     r = subprocess.run([cli, "RollupTx(16,2)", ipath, str(tmp_path / "bad.wtns"), "--circom-sym", spath, "--circom-r1cs", rpath, "--check"], stderr=subprocess.PIPE, text=True)
     assert r.returncode == 1 and "constraint %d of the .r1cs does not hold" % (len(m["forms"]) + q) in r.stderr and not os.path.exists(str(tmp_path / "bad.wtns"))
+
+
+@pytest.mark.gpu
+def test_hip_complete_rollup_main(hz):
+    """The COMPLETE RollupMain(3,16,2,1) -- main-level wiring, three DecodeTx + RollupTx, FeeTx, HashInputs, every circomlib template
+    below them but Sha256's inside, 4 x 10^5 constraints; recorded by __graft_entry__.build() in the build container, shipped with the
+    built libraries -- through .sym + .r1cs on the HIP path: nothing unresolved, every variable as it follows from the ORACLE's
+    witness, no violated constraint."""
+    import random
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_generated", "rollup_main_3_16_2_1.json.gz")
+    if not os.path.exists(path):
+        pytest.skip("tests/_generated/ was not built (the reference's sources were not present at build time)")
+    m = DF.load_file(path)
+    shape = tuple(m["args"])
+    bb = B.synthetic_batch(*shape, n_accounts=5, exits=1, seed=3)
+    inp = bb.get_input()
+    g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3])
+    g.set_inputs(inp)
+    g.run()
+    o = OracleCtx("rollup-main", *shape)
+    o.set_inputs(inp)
+    assert o.run() is None
+    vals = o.read(0, o.witness_len())
+    known = {}
+    for n in DF.all_names(m):
+        try:
+            known[n] = vals[o.lookup(n)]
+        except KeyError:
+            pass
+    val, unknown = DF.solve_with_hashes(m, known, lambda xs: B.host().poseidon(xs))
+    assert not unknown
+    order = DF.all_names(m)
+    random.Random(0xC0).shuffle(order)
+    sym, r1cs, names = DF.sym_and_r1cs(m, order)
+    mp = g.import_sym(sym, r1cs)
+    assert mp.unresolved() == [], (len(mp.unresolved()), mp.unresolved()[:6])
+    got = mp.read()
+    bad = [(n, got[v + 1], val[n]) for v, n in enumerate(names) if got[v + 1] != val[n]]
+    assert not bad, (len(bad), bad[:4])
+    assert mp.check_r1cs() == (0, [])
+    assert len(m["quads"]) > 100000 and mp.nvars() > 400000
