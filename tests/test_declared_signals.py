@@ -114,8 +114,8 @@ def test_a_wrong_witness_value_breaks_a_recorded_constraint():
 
 
 @pytest.mark.parametrize("key,shape,gen", [
-    ("rollup-tx", (0, 16, 0, 2), lambda FZ: FZ.rollup_tx_cases(24, 16, 2, 77)),
-    ("withdraw", (0, 16, 0, 0), lambda FZ: FZ.withdraw_cases(6, 16, 78)),
+    ("rollup-tx", (0, 16, 0, 2), lambda FZ: FZ.rollup_tx_cases(10, 16, 2, 77)),
+    ("withdraw", (0, 16, 0, 0), lambda FZ: FZ.withdraw_cases(3, 16, 78)),
 ])
 def test_oracle_rejects_whatever_violates_a_recorded_constraint(key, shape, gen):
     """garbage inputs (tests/fuzz_common.py): the oracle still writes a complete witness; whenever that witness violates a constraint
