@@ -158,7 +158,7 @@ int main(int argc, char** argv) {
     } else {
         const size_t n = strlen(argv[3]);
         const bool wtns = n > 5 && !strcmp(argv[3] + n - 5, ".wtns");
-        FILE* have_map = map_path ? fopen(map_path, "rb") : nullptr;
+        FILE* have_map = (map_path && !check) ? fopen(map_path, "rb") : nullptr;   // (--check needs the constraints: a full import)
         if (have_map) {
             fclose(have_map);
             hz_symmap* m = nullptr;
