@@ -352,3 +352,20 @@ def test_hip_complete_rollup_main(hz):
     assert not bad, (len(bad), bad[:4])
     assert mp.check_r1cs() == (0, [])
     assert len(m["quads"]) > 100000 and mp.nvars() > 400000
+    # The verdicts agree on garbage: the kernels' constraint checks are a restatement of the circuit's `===` lines, the .r1cs IS the
+    # circuit -- a batch the kernels reject violates a constraint of it, a batch they accept violates none. (Sha256's inside is the
+    # one thing not in this system; its only way to fail -- input bits that are not bits -- is caught by the Num2Bits before it.)
+    import fuzz_common as FZ
+    from circuits_amd import ConstraintError
+    stat = {True: 0, False: 0}
+    for case in FZ.rollup_main_cases(160, shape, 4242):
+        g.set_inputs(case)
+        try:
+            g.run()
+            rejected = False
+        except ConstraintError:
+            rejected = True
+        n_bad, first = mp.check_r1cs(cap=4)
+        assert rejected == (n_bad > 0), (rejected, n_bad, first)
+        stat[rejected] += 1
+    assert stat[True] >= 40 and stat[False] >= 10, stat
