@@ -369,3 +369,32 @@ def test_hip_complete_rollup_main(hz):
         assert rejected == (n_bad > 0), (rejected, n_bad, first)
         stat[rejected] += 1
     assert stat[True] >= 40 and stat[False] >= 10, stat
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key,n,gen", [
+    ("rollup-tx", 300, lambda FZ, n: FZ.rollup_tx_cases(n, 16, 2, 91)),
+    ("withdraw", 200, lambda FZ, n: FZ.withdraw_cases(n, 16, 92)),
+])
+def test_hip_verdict_equals_the_complete_system(hz, key, n, gen):
+    """RollupTx(16,2) and Withdraw(16) are recorded COMPLETE (every template of the reference and of circomlib as published): on garbage
+    inputs the kernels reject an instance exactly when the served witness violates a constraint of that system."""
+    import fuzz_common as FZ
+    from circuits_amd import ConstraintError
+    m = DF.load(key)
+    g = hz.ctx(key, **dict(zip(KEYS[key], m["args"])))
+    sym, r1cs, _ = DF.sym_and_r1cs(m)
+    mp = g.import_sym(sym, r1cs)
+    assert mp.unresolved() == []
+    stat = {True: 0, False: 0}
+    for case in gen(FZ, n):
+        g.set_inputs(case)
+        try:
+            g.run()
+            rejected = False
+        except ConstraintError:
+            rejected = True
+        n_bad, first = mp.check_r1cs(cap=4)
+        assert rejected == (n_bad > 0), (key, rejected, n_bad, first)
+        stat[rejected] += 1
+    assert stat[True] >= n // 4 and stat[False] >= n // 20, stat
