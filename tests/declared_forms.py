@@ -24,7 +24,7 @@ def load_file(path):
 
 
 def _lin(f):
-    return int(f[0]), [(int(c), n) for c, n in f[1]]
+    return int(f[0]) % P, [(int(c) % P, n) for c, n in f[1]]
 
 
 def all_names(m):

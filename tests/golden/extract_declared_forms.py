@@ -4,8 +4,8 @@ the templates under /root/reference/src (a small interpreter for the circom subs
 signal / component arrays, <== ==> <-- --> ===) in which every signal is its own symbol, as in an unreduced compile. Output:
 tests/golden/declared_forms.json.gz -- per main template and shape
 
-    forms   {signal name: [constant, [[coefficient, signal name], ...]]}   every `x <== linear expression` of the sources, one level at a
-            time (the right-hand names are signals again: of the same template, inputs of a sub-component, outputs of one)
+    forms   {signal name: [constant, [[coefficient, signal name], ...]]}   (field elements as decimal strings, those above r / 2 as negative
+            numbers) every `x <== linear expression` of the sources, one level at a time (the right-hand names are signals again: of the same template, inputs of a sub-component, outputs of one)
     quads   [[A, B, C], ...]   every other constraint of the sources as A * B = C with A, B, C linear forms as above: the `x <== a * b + c`
             lines and the `===` lines (A = B = 0 for a linear `===`)
     bases   [signal name, ...]   signals defined by a product of signals or a `<--` hint, inputs of the main component, outputs of
@@ -1541,7 +1541,8 @@ def build(defs, tmpl, args, **models):
     # outputs of black boxes and everything else a form refers to without defining it
     used = {n for f in r.forms.values() for n in f.t} | {n for q in r.quads for f in q for n in f.t}
     bases = sorted((r.bases | used) - set(r.forms))
-    lin = lambda f: [str(f.c), [[str(c), m] for m, c in sorted(f.t.items())]]   # noqa: E731
+    sgn = lambda c: str(c if c <= P // 2 else c - P)   # noqa: E731   (-1 instead of 77 digits: a third of the file)
+    lin = lambda f: [sgn(f.c), [[sgn(c), m] for m, c in sorted(f.t.items())]]   # noqa: E731
     return {"template": tmpl, "args": args, "forms": {n: lin(f) for n, f in sorted(r.forms.items())},
             "quads": [[lin(a), lin(b), lin(c)] for a, b, c in r.quads], "bases": bases, "declared": r.declared}
 
