@@ -398,3 +398,28 @@ def test_hip_verdict_equals_the_complete_system(hz, key, n, gen):
         assert rejected == (n_bad > 0), (key, rejected, n_bad, first)
         stat[rejected] += 1
     assert stat[True] >= n // 4 and stat[False] >= n // 20, stat
+
+
+@pytest.mark.gpu
+def test_hip_verdict_per_instance_of_one_launch(hz):
+    """the same on a launch of many instances: hz_witness_failures names the rejected instances, hz_symmap_check_r1cs(instance) finds
+    a violated constraint in exactly those (the map reads instance k's witness: stored signals and everything solved from them)"""
+    import fuzz_common as FZ
+    from circuits_amd import ConstraintError
+    m = DF.load("rollup-tx")
+    n = 48
+    g = hz.ctx("rollup-tx", n_instances=n, **dict(zip(KEYS["rollup-tx"], m["args"])))
+    sym, r1cs, _ = DF.sym_and_r1cs(m)
+    mp = g.import_sym(sym, r1cs)
+    cases = FZ.rollup_tx_cases(n, 16, 2, 93)
+    for k, case in enumerate(cases):
+        g.set_inputs(case, instance=k)
+    try:
+        g.run()
+    except ConstraintError:
+        pass
+    rejected = {f[0] for f in g.failures()}
+    assert 5 < len(rejected) < n - 2
+    for k in range(n):
+        n_bad, _ = mp.check_r1cs(instance=k, cap=1)
+        assert (n_bad > 0) == (k in rejected), (k, n_bad)
