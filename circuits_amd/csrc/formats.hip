@@ -827,6 +827,7 @@ void solve_linear(hz_symmap* m) {
             i = j;
         }
         if (!con.unknown) continue;
+        if (lc.size() >= (1u << 31) - 1) break;   // (indices of `lc` share a word with the flag of the product constraints below)
         for (const auto& kv : con.t)
             if (kv.first != 0 && m->index[kv.first] == ~0ull) uses[kv.first].push_back((uint32_t)lc.size());
         lc.push_back(std::move(con));
