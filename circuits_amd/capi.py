@@ -63,6 +63,7 @@ EXPORTS = [
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_witness_enqueue_tail_chain", "hz_sha_blocks", "hz_sha_state_bytes", "hz_sha_export", "hz_sha_expand",
     "hz_symmap_create", "hz_symmap_create_r1cs", "hz_symmap_solved", "hz_symmap_check_r1cs", "hz_symmap_save", "hz_symmap_load", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_symmap_derived", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
+    "hz_symmap_from_index", "hz_component_major_index", "hz_symmap_upload", "hz_witness_export_dev", "hz_witness_export_range_dev", "hz_witness_export_host", "hz_symmap_dev_index", "hz_witness_derive_dev",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
     "hz_poseidon_batch_dev", "hz_shard_range", "hz_set_inputs_json", "hz_witness_write_json", "hz_witness_write_wtns", "hz_symbols_write_sym", "hz_fr_ops", "hz_poseidon_dag",
 ]
@@ -143,6 +144,15 @@ class Lib:
         c.hz_witness_read_sym.argtypes = [vp, vp, ctypes.c_int32, u64, u64, vp]
         c.hz_witness_write_wtns_sym.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_char_p]
         c.hz_witness_gather.argtypes = [vp, ctypes.c_int32, vp, u64, vp]
+        c.hz_symmap_upload.argtypes = [vp, vp, ctypes.POINTER(u64)]
+        c.hz_symmap_from_index.argtypes = [vp, vp, u64, ctypes.POINTER(vp)]
+        c.hz_component_major_index.argtypes = [vp, vp, u64]
+        c.hz_component_major_index.restype = u64
+        c.hz_witness_export_dev.argtypes = [vp, vp, ctypes.c_int32, vp, vp]
+        c.hz_witness_export_range_dev.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
+        c.hz_witness_export_host.argtypes = [vp, vp, ctypes.c_int32, u64, u64, vp]
+        c.hz_symmap_dev_index.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u64)]
+        c.hz_witness_derive_dev.argtypes = [vp, vp, ctypes.c_int32, ctypes.POINTER(vp), vp]
         c.hz_symbol_lookup.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(u64)]
         c.hz_constraint_name.restype = ctypes.c_char_p
         c.hz_ctx_set_shard.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
@@ -469,6 +479,22 @@ class Ctx:
             self.L._check(self.L.c.hz_symmap_create_r1cs(self.h, b, len(b), bytes(r1cs), len(r1cs), ctypes.byref(h)))
         return SymMap(self, h)
 
+    def symmap_from_index(self, index):
+        """hz_symmap_from_index: `index` a numpy uint64 array, variable v = stored signal index[v] (index[0] == 0)"""
+        import numpy as np
+        a = np.ascontiguousarray(index, dtype=np.uint64)
+        h = ctypes.c_void_p()
+        self.L._check(self.L.c.hz_symmap_from_index(self.h, a.ctypes.data, a.size, ctypes.byref(h)))
+        return SymMap(self, h)
+
+    def component_major_index(self):
+        """hz_component_major_index -> numpy uint64 array"""
+        import numpy as np
+        n = self.L.c.hz_component_major_index(self.h, None, 0)
+        a = np.empty(n, dtype=np.uint64)
+        self.L.c.hz_component_major_index(self.h, a.ctypes.data, n)
+        return a
+
     def load_symmap(self, path):
         """hz_symmap_load: a map written by SymMap.save for this template and shape"""
         h = ctypes.c_void_p()
@@ -534,6 +560,45 @@ class SymMap:
 
     def write_wtns(self, path, instance=0):
         self.ctx.L._check(self.ctx.L.c.hz_witness_write_wtns_sym(self.ctx.h, self.h, instance, path.encode()))
+
+    def read_small(self, first, count, instance=0):
+        """hz_witness_read_sym in pieces small enough to stay on its host evaluator (the independent route the device export is
+        compared with in tests)"""
+        out = []
+        for f in range(first, first + count, 4096):
+            out += self.read(f, min(4096, first + count - f), instance)
+        return out
+
+    def upload(self):
+        """hz_symmap_upload: the map's device tables for this context; returns their size in bytes"""
+        n = ctypes.c_uint64()
+        self.ctx.L._check(self.ctx.L.c.hz_symmap_upload(self.ctx.h, self.h, ctypes.byref(n)))
+        return n.value
+
+    def export_dev(self, d_out, instance=0, stream=None):
+        """hz_witness_export_dev: the witness of `instance` (-1: every instance) in this map's variable order into device memory"""
+        self.ctx.L._check(self.ctx.L.c.hz_witness_export_dev(self.ctx.h, self.h, instance, d_out, stream))
+
+    def export_host(self, instance=0, first=0, count=None, out=None):
+        """hz_witness_export_host -> bytes (or into the caller's buffer address `out`)"""
+        count = self.nvars() - first if count is None else count
+        if out is not None:
+            self.ctx.L._check(self.ctx.L.c.hz_witness_export_host(self.ctx.h, self.h, instance, first, count, out))
+            return None
+        buf = ctypes.create_string_buffer(32 * max(count, 1))
+        self.ctx.L._check(self.ctx.L.c.hz_witness_export_host(self.ctx.h, self.h, instance, first, count, buf))
+        return buf.raw[:32 * count]
+
+    def dev_index(self):
+        """hz_symmap_dev_index -> (device pointer to u64 phys0[nvars], device pointer to u32 inst_stride[nvars], derived slots)"""
+        a, b, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        self.ctx.L._check(self.ctx.L.c.hz_symmap_dev_index(self.ctx.h, self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
+        return a.value, b.value, n.value
+
+    def derive_dev(self, instance=0, stream=None):
+        p = ctypes.c_void_p()
+        self.ctx.L._check(self.ctx.L.c.hz_witness_derive_dev(self.ctx.h, self.h, instance, ctypes.byref(p), stream))
+        return p.value
 
 
 _lib = None

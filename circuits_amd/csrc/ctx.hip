@@ -11,6 +11,7 @@
 #include "hostutil.h"
 #include "kernels.h"
 #include "tx_dev.h"
+#include "ctx_internal.h"
 
 using namespace hz;
 using namespace hzl;
@@ -1190,8 +1191,15 @@ extern "C" hz_status hz_witness_run(hz_ctx* c, hz_error* err) {
     return hz_witness_check(c, err);
 }
 
+void hz::ctx_geometry(const hz_ctx* c, CtxGeom& g) {
+    const Layout& lo = c->lo;
+    g.nsec = (uint32_t)std::min<size_t>(lo.sections.size(), 4);
+    for (uint32_t i = 0; i < g.nsec; i++) g.sec[i] = SecMap{lo.sections[i].vbase, lo.sections[i].base, lo.sections[i].upi, lo.sections[i].n_units};
+    g.n_inst = lo.n_inst; g.per_instance = lo.per_instance; g.total = lo.total;
+    g.device = c->device; g.s_main = c->s_main; g.wit = c->wit.p;
+}
+
 // gather `count` elements of the per-instance (virtual) witness of instance `inst` into a dense buffer
-struct SecMap { uint64_t vbase, base; uint32_t upi, n_units; };
 struct GatherArgs { const uint4* wit; uint4* out; uint64_t first, count; uint32_t inst, nsec; SecMap sec[4]; };
 __global__ void k_gather_virtual(const GatherArgs a) {
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.count; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -1272,6 +1280,27 @@ extern "C" hz_status hz_witness_gather(hz_ctx* c, int32_t instance, const uint64
         HZ_HIP(hipStreamSynchronize(c->s_main));
     }
     return HZ_OK;
+}
+
+// This library's stored signals in COMPONENT-MAJOR order, as index[] for hz_symmap_from_index: the constant, then section by section
+// every unit's signals together (transaction 0's signals, transaction 1's, ...) -- the shape of a constraint-reducing circom
+// compile's numbering (a component's signals are consecutive variables), without the compiler. Returns the number of entries
+// (= hz_witness_len); writes min(cap, that) of them.
+extern "C" uint64_t hz_component_major_index(const hz_ctx* c, uint64_t* index, uint64_t cap) {
+    if (!c) return 0;
+    const Layout& lo = c->lo;
+    uint64_t n = 0;
+    auto put = [&](uint64_t v) { if (index && n < cap) index[n] = v; n++; };
+    for (size_t si = 0; si < lo.sections.size(); si++) {
+        const Section& s = lo.sections[si];
+        for (uint32_t u = 0; u < s.upi; u++)
+            for (uint32_t sig = 0; sig < s.n_sigs; sig++) {
+                const uint64_t v = lo.virt((int)si, sig, u);
+                if (v == 0 && n != 0) continue;   // (the constant is variable 0 wherever the layout keeps it)
+                put(v);
+            }
+    }
+    return n;
 }
 
 // raw physical view (signal-major), for bulk consumers and tests

@@ -21,6 +21,7 @@
 #include <vector>
 #include "hostutil.h"
 #include "derived.h"
+#include "symmap.h"
 
 namespace hz {
 
@@ -198,6 +199,8 @@ extern "C" hz_status hz_set_inputs_json(hz_ctx* ctx, int32_t instance, const cha
 }
 
 static const size_t CHUNK = 1 << 16;   // elements per device read
+static const uint64_t SMALL_READ = 4096;   // hz_witness_read_sym: up to here the host evaluates derived variables, beyond it the device pass does
+namespace hz { hz_status export_to_file(hz_ctx* ctx, const hz_symmap* m, int32_t instance, FILE* f, const char* path); }
 
 extern "C" hz_status hz_witness_write_wtns(hz_ctx* ctx, int32_t instance, const char* path) {
     if (!ctx || !path) return set_err(HZ_ERR_ARG, "hz_witness_write_wtns: null argument");
@@ -291,39 +294,6 @@ extern "C" hz_status hz_symbols_write_sym(const hz_ctx* ctx, const char* path) {
 //     `<c>.isz.in`): inv <-- in != 0 ? 1/in : 0 determines it, in = inv == 0 ? 0 : 1/inv; and the input of every Num2Bits whose bits are
 //     stored as `<c>.out[k]`: the template's own constraint, in = sum of 2^k out[k].
 // A variable whose labels match neither a stored signal nor a rule stays unresolved and is reported as before.
-enum { DV_POSEIDON = 1, DV_LINEAR = 2, DV_ISZERO_IN = 3, DV_PRODUCT = 4, DV_QUOTIENT = 5 };   // DV_PRODUCT: lins[lin] * lins[lin + 1] + lins[lin + 2]; DV_QUOTIENT: lins[lin] / lins[lin + 1] + lins[lin + 2] (0 / 0 = 0)
-using hzderived::PW_ARK_IN; using hzderived::PW_ARK_OUT; using hzderived::PW_MIX_IN; using hzderived::PW_MIX_OUT;
-struct DerivedVar {
-    uint8_t kind = 0, t = 0, what = 0;
-    uint16_t round = 0, lane = 0;
-    uint32_t lin = 0;                 // DV_LINEAR: index into hz_symmap::lins
-    uint64_t first = 0, stride = 0;   // DV_POSEIDON: this library's index of sigmaF[0][0].in2 and the distance between consecutive stored signals
-};
-static const uint64_t DERIVED_FLAG = 1ull << 63;
-struct LinForm {
-    hzh::F c0;
-    std::vector<std::pair<hzh::F, uint64_t>> terms;   // coefficient (Montgomery form), stored index or DERIVED_FLAG | derived index
-};
-struct hz_symmap {
-    std::vector<uint64_t> index;          // per variable: index in this library's per-instance witness, DERIVED_FLAG | k, or ~0 = unresolved
-    std::vector<std::string> first_label; // per unresolved variable (in variable order): one of its names
-    std::vector<uint64_t> unresolved;     // variable numbers
-    std::vector<DerivedVar> derived;
-    std::vector<LinForm> lins;
-    std::unordered_map<std::string, uint64_t> memo; // name -> resolved index of a DERIVED signal (rules refer to each other); stored names are looked up each time
-    struct PosBlk { int t; uint64_t first, stride; };
-    std::map<std::string, PosBlk> pos_memo;   // component prefix -> its Poseidon block (t = 0: not one)
-    uint64_t n_derived = 0, n_solved = 0;
-    // the constraint system of the same compile (hz_symmap_create_r1cs): linear combination q of constraint c, q = 0..2 for A, B, C,
-    // holds the terms [off[3c + q], off[3c + q + 1]) of (wire, index into the coefficient pool)
-    struct R1cs {
-        uint64_t n_wires = 0, n_cons = 0;
-        std::vector<uint64_t> off;
-        std::vector<uint32_t> wire, coef;
-        std::vector<hzh::F> pool;
-    } r1cs;
-};
-
 namespace {
 using hzh::F;
 using namespace hzderived;
@@ -616,52 +586,49 @@ uint64_t resolve_name(const hz_ctx* ctx, hz_symmap* m, const std::string& name_i
     return ~0ull;
 }
 
-// `count` variables of the map from `first` on, stored ones gathered from the device, derived ones evaluated on the host
+// `count` variables of the map, stored ones gathered from the device, derived ones evaluated on the host: the route of SMALL reads
+// (assertOut-sized; hz_witness_read_sym below sends anything larger through the device pass of export.hip). The work is proportional
+// to what the requested variables reach, not to the map: the reached derived variables are kept in a sorted list, their values in a
+// compact vector beside it.
 hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const uint64_t* index, uint64_t count, uint8_t* out) {
-    // what has to come from the device: the stored variables themselves, the stored terms of the linear forms (through other
-    // derived variables), the S-box signals of every Poseidon component one of the variables lies in
-    // (collected with repeats, then sorted and made unique: a full-size RollupMain has 1.2 * 10^8 variables, a tree map per index
-    // would take minutes; the position of an index is found by binary search)
-    std::vector<uint64_t> need;
-    auto want = [&](uint64_t idx) { need.push_back(idx); };
-    std::vector<uint8_t> seen(m->derived.size(), 0);
+    std::vector<uint64_t> need;       // stored signals to fetch (with repeats, made unique below)
+    std::vector<uint64_t> reach;      // derived variables the request depends on
     std::vector<uint64_t> stack;
-    bool any_derived = false;
     for (uint64_t i = 0; i < count; i++) {
         if (index[i] == ~0ull) return set_err(HZ_ERR_INPUT, "variable %llu of the .sym is not resolved", (unsigned long long)i);
-        if (!(index[i] & DERIVED_FLAG)) continue;
-        any_derived = true;
-        stack.push_back(index[i] & ~DERIVED_FLAG);
+        if (index[i] & DERIVED_FLAG) stack.push_back(index[i] & ~DERIVED_FLAG);
+        else need.push_back(index[i]);
     }
-    if (!any_derived) return hz_witness_gather(ctx, instance, index, count, out);
-    std::map<uint64_t, int> blocks;    // Poseidon component (index of its first stored signal) -> width
+    if (stack.empty()) return hz_witness_gather(ctx, instance, index, count, out);
+    std::unordered_map<uint64_t, uint32_t> seen;   // derived variable -> visited
+    struct Blk { int t; uint64_t stride; };
+    std::map<uint64_t, Blk> blocks;    // Poseidon component (index of its first stored signal) -> width, distance between its stored signals
     while (!stack.empty()) {
         const uint64_t k = stack.back();
         stack.pop_back();
-        if (seen[k]) continue;
-        seen[k] = 1;
+        if (!seen.emplace(k, 0u).second) continue;
+        reach.push_back(k);
         const DerivedVar& d = m->derived[k];
         if (d.kind == DV_POSEIDON) {
-            if (blocks.emplace(d.first, d.t).second)
-                for (int j = 0; j < 3 * pos_nsbox(d.t); j++) want(d.first + (uint64_t)j * d.stride);
+            if (blocks.emplace(d.first, Blk{d.t, d.stride}).second)
+                for (int j = 0; j < 3 * pos_nsbox(d.t); j++) need.push_back(d.first + (uint64_t)j * d.stride);
         } else if (d.kind == DV_ISZERO_IN) {
-            want(d.first);
+            need.push_back(d.first);
         } else {
             for (uint32_t f = d.lin; f < d.lin + (d.kind == DV_LINEAR ? 1u : 3u); f++)
                 for (const auto& tm : m->lins[f].terms) {
                     if (tm.second & DERIVED_FLAG) stack.push_back(tm.second & ~DERIVED_FLAG);
-                    else want(tm.second);
+                    else need.push_back(tm.second);
                 }
         }
     }
-    for (uint64_t i = 0; i < count; i++)
-        if (!(index[i] & DERIVED_FLAG)) want(index[i]);
     std::sort(need.begin(), need.end());
     need.erase(std::unique(need.begin(), need.end()), need.end());
+    std::sort(reach.begin(), reach.end());
     struct Slot {
         const std::vector<uint64_t>& need;
         size_t operator[](uint64_t idx) const { return (size_t)(std::lower_bound(need.begin(), need.end(), idx) - need.begin()); }
-    } slot{need};
+    } slot{need}, dslot{reach};
     std::vector<uint8_t> vals(need.size() * 32);
     if (!need.empty()) {
         const hz_status st = hz_witness_gather(ctx, instance, need.data(), need.size(), vals.data());
@@ -670,18 +637,16 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
     std::map<uint64_t, std::vector<F>> traces;
     std::vector<uint8_t> sbox;
     for (const auto& b : blocks) {
-        const int n = 3 * pos_nsbox(b.second);
+        const int n = 3 * pos_nsbox(b.second.t);
         sbox.resize((size_t)n * 32);
-        const uint64_t stride = [&] { for (const DerivedVar& d : m->derived) if (d.kind == DV_POSEIDON && d.first == b.first) return d.stride; return (uint64_t)1; }();
-        for (int j = 0; j < n; j++) memcpy(sbox.data() + 32 * (size_t)j, vals.data() + 32 * slot[b.first + (uint64_t)j * stride], 32);
-        pos_trace(b.second, sbox.data(), traces[b.first]);
+        for (int j = 0; j < n; j++) memcpy(sbox.data() + 32 * (size_t)j, vals.data() + 32 * slot[b.first + (uint64_t)j * b.second.stride], 32);
+        pos_trace(b.second.t, sbox.data(), traces[b.first]);
     }
     // a derived variable only refers to derived variables created before it (a rule resolves its terms first, a solved variable is
     // defined over known ones): ascending order evaluates every dependency first -- no recursion, chains may be long
-    std::vector<F> dval(m->derived.size());
-    for (size_t k = 0; k < m->derived.size(); k++) {
-        if (!seen[k]) continue;
-        const DerivedVar& d = m->derived[k];
+    std::vector<F> dval(reach.size());
+    for (size_t r = 0; r < reach.size(); r++) {
+        const DerivedVar& d = m->derived[reach[r]];
         F v;
         if (d.kind == DV_POSEIDON) {
             const int R = pos_rounds(d.t);
@@ -690,21 +655,21 @@ hz_status symmap_values(hz_ctx* ctx, const hz_symmap* m, int32_t instance, const
             v = hzh::f_inv(hzh::f_from_canon(vals.data() + 32 * slot[d.first]));   // inverse(0) = 0
         } else {
             auto eval = [&](const LinForm& lf) {
-                F r = lf.c0;
+                F acc = lf.c0;
                 for (const auto& tm : lf.terms) {
-                    const F x = (tm.second & DERIVED_FLAG) ? dval[tm.second & ~DERIVED_FLAG] : hzh::f_from_canon(vals.data() + 32 * slot[tm.second]);
-                    r = hzh::f_add(r, hzh::f_mul(tm.first, x));
+                    const F x = (tm.second & DERIVED_FLAG) ? dval[dslot[tm.second & ~DERIVED_FLAG]] : hzh::f_from_canon(vals.data() + 32 * slot[tm.second]);
+                    acc = hzh::f_add(acc, hzh::f_mul(tm.first, x));
                 }
-                return r;
+                return acc;
             };
             if (d.kind == DV_PRODUCT) v = hzh::f_add(hzh::f_mul(eval(m->lins[d.lin]), eval(m->lins[d.lin + 1])), eval(m->lins[d.lin + 2]));
             else if (d.kind == DV_QUOTIENT) v = hzh::f_add(hzh::f_mul(eval(m->lins[d.lin]), hzh::f_inv(eval(m->lins[d.lin + 1]))), eval(m->lins[d.lin + 2]));
             else v = eval(m->lins[d.lin]);
         }
-        dval[k] = v;
+        dval[r] = v;
     }
     for (uint64_t i = 0; i < count; i++) {
-        if (index[i] & DERIVED_FLAG) hzh::f_to_canon(dval[index[i] & ~DERIVED_FLAG], out + 32 * i);
+        if (index[i] & DERIVED_FLAG) hzh::f_to_canon(dval[dslot[index[i] & ~DERIVED_FLAG]], out + 32 * i);
         else memcpy(out + 32 * i, vals.data() + 32 * slot[index[i]], 32);
     }
     return HZ_OK;
@@ -1093,6 +1058,23 @@ hz_status symmap_build(const hz_ctx* ctx, const char* text, size_t len, const ui
     }
 }
 }  // namespace
+// A map given explicitly: variable v is stored signal index[v] of this library's per-instance numbering (a consumer whose tooling
+// already knows where the compiler put every signal; the tests' permuted orders). Variable 0 must be the constant 1 (index 0).
+extern "C" hz_status hz_symmap_from_index(const hz_ctx* ctx, const uint64_t* index, uint64_t n, hz_symmap** out) {
+    if (!ctx || !index || !out || n == 0) return set_err(HZ_ERR_ARG, "hz_symmap_from_index: null argument");
+    const uint64_t wl = hz_witness_len(ctx);
+    if (index[0] != 0) return set_err(HZ_ERR_INPUT, "hz_symmap_from_index: variable 0 must be the constant 1 (index 0)");
+    for (uint64_t v = 0; v < n; v++)
+        if (index[v] >= wl) return set_err(HZ_ERR_INPUT, "hz_symmap_from_index: variable %llu names signal %llu of %llu", (unsigned long long)v, (unsigned long long)index[v], (unsigned long long)wl);
+    try {
+        hz_symmap* m = new hz_symmap();
+        m->index.assign(index, index + n);
+        *out = m;
+        return HZ_OK;
+    } catch (const std::bad_alloc&) {
+        return set_err(HZ_ERR_INPUT, "hz_symmap_from_index: out of memory");
+    }
+}
 extern "C" uint64_t hz_symmap_solved(const hz_symmap* m) { return m ? m->n_solved : 0; }
 extern "C" void hz_symmap_destroy(hz_symmap* m) { delete m; }
 static hz_status symmap_usable(const hz_symmap* m, const char* who);
@@ -1149,13 +1131,24 @@ extern "C" hz_status hz_symmap_load(const hz_ctx* ctx, const char* path, hz_symm
             m->index.resize((size_t)h.n_index);
             ok = m->index.empty() || fread(m->index.data(), 8, m->index.size(), f) == m->index.size();
             m->derived.resize((size_t)h.n_derived);
+            std::unordered_map<uint64_t, std::pair<int, uint64_t>> pos_seen;
             for (DerivedVar& d : m->derived) {
                 uint64_t rec[4];
                 ok = ok && fread(rec, 8, 4, f) == 4;
                 d.kind = (uint8_t)rec[0]; d.t = (uint8_t)(rec[0] >> 8); d.what = (uint8_t)(rec[0] >> 16); d.round = (uint16_t)(rec[0] >> 24); d.lane = (uint16_t)(rec[0] >> 40);
                 d.lin = (uint32_t)rec[1]; d.first = rec[2]; d.stride = rec[3];
                 ok = ok && d.kind >= DV_POSEIDON && d.kind <= DV_QUOTIENT && (d.kind == DV_POSEIDON || d.kind == DV_ISZERO_IN || (uint64_t)d.lin + (d.kind == DV_LINEAR ? 1 : 3) <= h.n_lins);
-                ok = ok && (d.kind != DV_POSEIDON || (d.t >= 2 && d.t <= 7 && d.first + 3ull * pos_nsbox(d.t) * d.stride <= h.witness_len)) && (d.kind != DV_ISZERO_IN || d.first < h.witness_len);
+                if (d.kind == DV_POSEIDON) {
+                    // what / round / lane index the component's trace (4 x rounds x t entries); first + 3 nsbox stride must stay inside the
+                    // witness without wrapping; every record of one component must agree on its width and stride
+                    ok = ok && d.t >= 2 && d.t <= 7 && d.what <= PW_MIX_OUT && d.round < pos_rounds(d.t) && d.lane < d.t && d.stride >= 1 && d.first < h.witness_len &&
+                         d.stride <= (h.witness_len - d.first) / (3ull * (uint64_t)pos_nsbox(d.t));
+                    if (ok) {
+                        auto it = pos_seen.emplace(d.first, std::make_pair((int)d.t, d.stride)).first;
+                        ok = it->second.first == (int)d.t && it->second.second == d.stride;
+                    }
+                }
+                ok = ok && (d.kind != DV_ISZERO_IN || d.first < h.witness_len);
             }
             m->lins.resize((size_t)h.n_lins);
             uint64_t left = h.n_terms;
@@ -1211,6 +1204,7 @@ extern "C" hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* m, int32_
     const hz_status st = symmap_usable(m, "hz_witness_read_sym");
     if (st != HZ_OK) return st;
     if (first > m->index.size() || count > m->index.size() - first) return set_err(HZ_ERR_ARG, "hz_witness_read_sym: range beyond the %zu variables", m->index.size());
+    if (count > SMALL_READ) return hz_witness_export_host(ctx, m, instance, first, count, out);   // the device pass (export.hip)
     return symmap_values(ctx, m, instance, m->index.data() + first, count, out);
 }
 extern "C" uint64_t hz_symmap_derived(const hz_symmap* m) { return m ? m->n_derived : 0; }
@@ -1222,8 +1216,9 @@ extern "C" hz_status hz_symmap_check_r1cs(hz_ctx* ctx, const hz_symmap* m, int32
     if (!n_bad || !m->r1cs.n_cons) return set_err(HZ_ERR_ARG, "hz_symmap_check_r1cs: %s", n_bad ? "the map was made without an .r1cs (hz_symmap_create_r1cs)" : "null argument");
     try {
     const hz_symmap::R1cs& r = m->r1cs;
+    // the witness as the device pass exports it -- the buffer a prover would be handed
     std::vector<uint8_t> raw(m->index.size() * 32);
-    const hz_status st = symmap_values(ctx, m, instance, m->index.data(), m->index.size(), raw.data());
+    const hz_status st = hz_witness_export_host(ctx, m, instance, 0, m->index.size(), raw.data());
     if (st != HZ_OK) return st;
     std::vector<hzh::F> w(m->index.size());
     for (size_t v = 0; v < w.size(); v++) w[v] = hzh::f_from_canon(raw.data() + 32 * v);
@@ -1263,13 +1258,8 @@ extern "C" hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* m, 
     fwrite(R_LIMBS, 8, 4, f);
     u32((uint32_t)n);
     u32(2); u64(n * 32);
-    std::vector<uint8_t> buf(CHUNK * 32);
-    for (uint64_t i = 0; i < n; i += CHUNK) {
-        const uint64_t c = n - i < CHUNK ? n - i : CHUNK;
-        st = symmap_values(ctx, m, instance, m->index.data() + i, c, buf.data());
-        if (st != HZ_OK) { fclose(f); return st; }
-        if (fwrite(buf.data(), 32, c, f) != c) { fclose(f); return set_err(HZ_ERR_ARG, "short write to %s", path); }
-    }
+    st = hz::export_to_file(ctx, m, instance, f, path);   // one device pass, then pinned double-buffered copies feeding fwrite
+    if (st != HZ_OK) { fclose(f); return st; }
     if (ferror(f)) { fclose(f); return set_err(HZ_ERR_ARG, "write to %s failed", path); }
     if (fclose(f) != 0) return set_err(HZ_ERR_ARG, "close of %s failed", path);
     return HZ_OK;

@@ -247,6 +247,37 @@ hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instanc
 hz_status hz_witness_write_wtns_sym(hz_ctx* ctx, const hz_symmap* map, int32_t instance, const char* path);
 hz_status hz_witness_gather(hz_ctx* ctx, int32_t instance, const uint64_t* index, uint64_t count, uint8_t* out);
 
+/* The witness in the compiler's order ON THE DEVICE (SURVEY 8a' K8): what a prover on the same GPU consumes. The reference hands
+ * w[] over in circom's numbering (test/helpers/helpers.js:142,149) and its prove step reads that vector beside the .r1cs / zkey
+ * (tools/helpers/actions.js:132-170); the kernels of a step write a signal-major layout of their own (include/hz_layout.h).
+ *   hz_symmap_upload            takes the map to the context's device once (the first export does it implicitly): per 128-byte line of
+ *                               the physical buffer -- four consecutive units of one signal -- the four variables it feeds, ordered
+ *                               so that consecutive lanes write consecutive variables; CSR tables of the derived variables.
+ *                               device_bytes (optional) = size of those tables.
+ *   hz_witness_export_dev       ONE pass: variable v of instance `instance` -> d_out[v] (hz_symmap_nvars x 32 bytes, canonical LE),
+ *                               stored variables gathered, derived ones (an unreduced compile's linear signals) evaluated on the
+ *                               device. instance = -1: every instance, d_out[instance][v]. Asynchronous on `stream` (NULL = the
+ *                               context's stream), ordered after a hz_witness_enqueue on the same stream.
+ *   hz_witness_export_range_dev the same for instances [first, first + count)
+ *   hz_witness_export_host      the same pass, then asynchronous copies through a ring of two pinned buffers into `out`
+ *                               (count x 32 bytes from variable first_var on); PCIe bound: 3.86 GB per headline batch at <= 63 GB/s.
+ *                               hz_witness_write_wtns_sym and hz_symmap_check_r1cs run on exactly this buffer.
+ *   hz_symmap_dev_index         for a consumer that prefers indirection over a copy: phys0[v] = element of hz_witness_dev_ptr() that
+ *                               holds variable v of instance 0, inst_stride[v] = elements to add per instance; a derived variable
+ *                               has phys0[v] = 2^63 | k, its value is element (instance slot) * n_derived_slots + k of the buffer
+ *                               hz_witness_derive_dev fills (instance = -1: slot = instance; otherwise slot 0). */
+/* A map given explicitly -- variable v is signal index[v] of this library's per-instance numbering, variable 0 the constant --
+ * and the stored signals in component-major order (every unit's signals together: the shape of a reducing compile's numbering)
+ * as such an index: hz_component_major_index returns the number of entries and writes min(cap, that). */
+hz_status hz_symmap_from_index(const hz_ctx* ctx, const uint64_t* index, uint64_t n, hz_symmap** out);
+uint64_t hz_component_major_index(const hz_ctx* ctx, uint64_t* index, uint64_t cap);
+hz_status hz_symmap_upload(hz_ctx* ctx, const hz_symmap* map, uint64_t* device_bytes);
+hz_status hz_witness_export_dev(hz_ctx* ctx, const hz_symmap* map, int32_t instance, void* d_out, void* stream);
+hz_status hz_witness_export_range_dev(hz_ctx* ctx, const hz_symmap* map, int32_t first_instance, int32_t count, void* d_out, void* stream);
+hz_status hz_witness_export_host(hz_ctx* ctx, const hz_symmap* map, int32_t instance, uint64_t first_var, uint64_t count, uint8_t* out);
+hz_status hz_symmap_dev_index(hz_ctx* ctx, const hz_symmap* map, const uint64_t** d_phys0, const uint32_t** d_inst_stride, uint64_t* n_derived_slots);
+hz_status hz_witness_derive_dev(hz_ctx* ctx, const hz_symmap* map, int32_t instance, const void** d_derived, void* stream);
+
 /* symbols ------------------------------------------------------------------------------------ */
 uint64_t hz_symbol_count(const hz_ctx* ctx);
 hz_status hz_symbol_get(const hz_ctx* ctx, uint64_t i, hz_symbol* out);
