@@ -431,6 +431,97 @@ def bench_withdraw(args, L, D, launches=None, steps=None):
     return res
 
 
+def bench_export(args, L, D, ctxs, streams, run_enqueue, nTx, Bp):
+    """The witness in a prover's order (SURVEY 8a' K8, 8d "D2H excluded / included reported separately"): hz_witness_export_dev turns
+    one instance of the signal-major buffer into w[var] on the device. The map is this layout's stored signals in COMPONENT-MAJOR order
+    (hz_component_major_index: every transaction's signals together, the shape of a constraint-reducing circom compile's numbering; the
+    compiler itself cannot run here). Returns the `export` object of the line."""
+    import tempfile
+    torch = D.torch
+    c0 = ctxs[0]
+    wl = c0.witness_len()
+    t0 = time.time()
+    index = c0.component_major_index()
+    maps = [c.symmap_from_index(index) for c in ctxs]
+    tables = [m.upload() for m in maps]
+    t_plan = time.time() - t0
+    nbuf = 2
+    outs = [torch.empty(wl * 32, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+    torch.cuda.synchronize()
+    s0 = streams[0]
+    # (1) one batch, the device otherwise idle: HIP events on the export's stream
+    times = []
+    for r in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s0)
+        maps[0].export_dev(outs[0].data_ptr(), r % Bp, stream=s0.cuda_stream)
+        e1.record(s0)
+        torch.cuda.synchronize()
+        if r:
+            times.append(e0.elapsed_time(e1))
+    exp_ms = sorted(times)[len(times) // 2]
+    # the exported vector holds the public output where the map says (parity of the whole vector: tests/test_export_dev.py)
+    pos = int((index == c0.lookup("main.hashGlobalInputs")).nonzero()[0][0])
+    got = int.from_bytes(bytes(outs[0][32 * pos:32 * pos + 32].cpu().numpy()), "little")
+    assert got == c0.get("main.hashGlobalInputs", 5 % Bp), "exported hashGlobalInputs mismatch"
+    # (2) the step WITH the export of every batch it produced (each context's exports follow its kernels on its stream)
+    inflight = len(ctxs)
+
+    def run(n):
+        pend = [False] * inflight
+        for i in range(n):
+            k = i % inflight
+            if pend[k]:
+                ctxs[k].check()
+            run_enqueue(k)
+            for b in range(Bp):
+                maps[k].export_dev(outs[(k + b) % nbuf].data_ptr(), b, stream=streams[k].cuda_stream)
+            pend[k] = True
+        for k in range(inflight):
+            if pend[k]:
+                ctxs[k].check()
+    esteps = max(inflight, min(args.steps, 4))
+    run(inflight)
+    dt = D.timed(lambda: run(esteps))
+    # (3) delivered to the host: export + device-to-host copy into pinned memory, a few batches (PCIe bound)
+    nh = 3
+    pin = L.host_alloc(wl * 32)
+    maps[0].export_host(instance=0, out=pin)
+    t1 = time.perf_counter()
+    for b in range(nh):
+        maps[0].export_host(instance=(b + 1) % Bp, out=pin)
+    dt_host = (time.perf_counter() - t1) / nh
+    L.host_free(pin)
+    # (4) one batch as a snarkjs .wtns in that order (the ring of two pinned buffers feeding fwrite), to a memory-backed file
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    fd, path = tempfile.mkstemp(suffix=".wtns", dir=d)
+    os.close(fd)
+    try:
+        t2 = time.perf_counter()
+        maps[0].write_wtns(path, instance=0)
+        wtns_s = time.perf_counter() - t2
+        wtns_bytes = os.path.getsize(path)
+    finally:
+        os.unlink(path)
+    del outs
+    res = {"order": "component-major (hz_component_major_index): the stored signals, every transaction's together -- the shape of a reducing compile's numbering",
+           "variables_per_batch": int(wl), "bytes_per_batch": int(wl * 32),
+           "export_ms_per_batch": round(exp_ms, 3), "export_GBs_read_plus_write": round(2 * wl * 32 / exp_ms / 1e6, 1),
+           "frac_of_hbm_peak": round(2 * wl * 32 / exp_ms / 1e6 / HBM_PEAK_GBS, 4),
+           "value_export": round(nTx * Bp * esteps * D.world / dt, 1), "value_export_ms_per_step": round(dt / esteps * 1e3, 3), "value_export_steps": esteps,
+           "delivered_host_ms_per_batch": round(dt_host * 1e3, 2), "delivered_host_GBs": round(wl * 32 / dt_host / 1e9, 2),
+           "value_delivered_host": round(nTx / dt_host, 1), "pcie_ceiling_tx_per_s": round(nTx / (wl * 32 / 63e9), 1),
+           "wtns_write_s": round(wtns_s, 2), "wtns_bytes": int(wtns_bytes), "wtns_GBs": round(wtns_bytes / wtns_s / 1e9, 2),
+           "plan_build_s": round(t_plan / len(ctxs), 2), "plan_device_bytes": int(tables[0]),
+           "note": "export_ms_per_batch: hz_witness_export_dev of ONE batch on the otherwise idle device, HIP events on its stream (target of the round-4 review: <= 2.5 ms). "
+                   "value_export: the timed step plus the export of every batch it produced into a ring of device buffers -- a full copy of 3.86 GB per batch costs more "
+                   "than computing it (the step writes each byte once, the export reads and writes it again); a consumer on the same GPU can take the map's "
+                   "indirection instead (hz_symmap_dev_index). value_delivered_host: export + one device-to-host copy into pinned memory, PCIe Gen5 x16 <= 63 GB/s: "
+                   "the ceiling is pcie_ceiling_tx_per_s. wtns_write_s: one batch as .wtns through the pinned ring into a memory-backed file"}
+    del maps
+    return res
+
+
 def respawn(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks (one process per GPU) and hand over."""
     s = socket.socket()
@@ -458,6 +549,7 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline processes (0 = every CPU this process may use -- cgroup quota, affinity -- as far as a third of its memory allows: a RollupMain(2048, 32, ..) oracle holds a 3.9 GB witness)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="nTx of the CPU-baseline sample (0 = skip; default: the headline shape, one batch per process)")
     ap.add_argument("--no-sweep", action="store_true", help="skip single_batch_latency_ms and batches_sweep (the occupancy points of SURVEY 8d)")
+    ap.add_argument("--no-export", action="store_true", help="skip the export figures (the witness in variable order on the device / delivered to the host / as .wtns)")
     ap.add_argument("--no-deep-state", action="store_true", help="skip the deep_state line (the same step on a state of 2^20 accounts)")
     ap.add_argument("--deep-accounts-log2", type=int, default=20)
     ap.add_argument("--batches-per-launch", type=int, default=32,
@@ -529,7 +621,7 @@ def main():
     free_b, _total_b = torch.cuda.mem_get_info()
     if "HZ_BENCH_DEVICE" in os.environ:
         free_b //= world   # test hook: the ranks share one device
-    fit = int((free_b - (6 << 30)) // (per_batch * inflight))
+    fit = int((free_b - (16 << 30)) // (per_batch * inflight))   # (the export figures take two vectors of one batch and the maps' tables)
     if fit < Bp:
         print("bench: %d batches x %d contexts do not fit %.0f GB of free HBM, using %d batches per launch" % (Bp, inflight, free_b / 1e9, max(1, fit)), file=sys.stderr)
         Bp = max(1, fit)
@@ -698,6 +790,13 @@ def main():
         torch.cuda.synchronize()
         upload_ms = e0.elapsed_time(e1) / Bp
     witness_bytes = ctxs[0].witness_len() * 32
+    export = None
+    if world == 1 and not args.no_export:
+        try:
+            export = bench_export(args, L, D, ctxs, streams, lambda k: ctxs[k].enqueue(streams[k].cuda_stream), nTx, Bp)
+        except Exception as e:   # noqa: BLE001 -- a secondary figure must never cost the main line
+            export = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
     deep = None
     if world == 1 and not args.no_deep_state and n_acc < (1 << args.deep_accounts_log2):
         # The same step on a DEEP state: 2^20 accounts instead of 4 * nTx. The proofs then reach their leaves at level ~21 instead
@@ -889,6 +988,11 @@ def main():
             out["single_batch_latency_ms"] = dict(single, note="one 2048-transaction batch alone on the device, enqueue + check, mean of 6; latency_flag = HZ_FLAG_LATENCY "
                                                               "(the context's concurrent chains on disjoint compute units)")
             out["batches_sweep"] = sweep
+        if export is not None:
+            for k in ("export_ms_per_batch", "value_export", "value_delivered_host", "wtns_write_s"):
+                if k in export:
+                    out[k] = export[k]
+            out["export"] = export
         if deep is not None:
             deep["ratio_to_value"] = round(deep["value"] / value, 4)
             out["value_deep_state"] = deep["value"]

@@ -47,6 +47,9 @@ static const uint32_t SRC_DERIVED = 0x80000000u;
 enum { COEF_PLUS1 = 0, COEF_MINUS1 = 1 };
 
 struct SecTab { SecMap sec[4]; uint32_t nsec; };
+// the sections that have lines (units per instance a multiple of four), ascending: lines >= first_line[i]; a section's first element
+// need not be line-aligned: element = 4 * line + rem
+struct LineTab { uint32_t first_line[4], upi[4], rem[4]; uint32_t nsec; };
 
 struct PosGroup {
     uint64_t n = 0;
@@ -62,7 +65,8 @@ struct DevPlan {
     uint64_t nvars = 0;
     // stored variables
     uint64_t n_quads = 0, n_s1 = 0, n_sx = 0;
-    DevBuf q_src, q_dst;          // u32[n_quads], uint4[n_quads]
+    DevBuf q_src, q_dst;          // u32[n_quads] physical line of instance 0 (in units of 4 elements), uint4[n_quads] the four variables
+    LineTab lt{};
     DevBuf s1_src, s1_dst;        // singles of sections with one unit per instance
     DevBuf sx_src, sx_dst;        // every other single
     // derived variables
@@ -78,6 +82,7 @@ struct DevPlan {
     DevBuf dval;                  // [instances exported together][D] elements
     uint64_t dval_inst = 0;
     DevBuf phys0, istride;        // hz_symmap_dev_index
+    DevBuf xbuf;                  // one exported vector on the device, the source of the host deliveries
     uint64_t bytes = 0;           // device bytes of the tables
 };
 void devplan_free(DevPlan* p) { delete p; }
@@ -105,28 +110,86 @@ struct ExpArgs {
 typedef __attribute__((address_space(1))) const hz_u32x4 g_cu4;
 typedef __attribute__((address_space(1))) hz_u32x4 g_u4;
 
-__global__ void __launch_bounds__(256) k_export_quads(const ExpArgs a, const uint32_t* __restrict__ src, const uint4* __restrict__ dst, uint64_t n) {
+// Eight lanes per line: a wavefront's load instruction reads eight whole 128-byte lines (16 bytes per lane, the pattern of a copy
+// kernel), its store instruction writes, for each of the four units of those lines, eight consecutive variables = 256 contiguous
+// bytes. (A first version gave each lane a line of its own: eight load instructions per wavefront all touching the same 64 lines,
+// 2.25 ms for the headline batch's transaction section against 1.x ms.) `line0` = the line's physical position for instance 0 in
+// units of four elements: no division on the way to the address.
+__device__ __forceinline__ void export_quads(const ExpArgs& a, const LineTab& lt, const uint32_t* __restrict__ line0, const uint32_t* __restrict__ dst, uint64_t n, uint32_t bx, uint32_t nbx) {
     const uint32_t inst = a.inst0 + blockIdx.y;
     g_u4* out = (g_u4*)(a.out + 2 * (uint64_t)blockIdx.y * a.out_stride);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4 d = dst[i];
-        g_cu4* p = (g_cu4*)(a.wit + 2 * v2p(a.st, src[i], inst));
-        const hz_u32x4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], x5 = p[5], x6 = p[6], x7 = p[7];
-        if (d.x != NONE32) { out[2 * (uint64_t)d.x] = x0; out[2 * (uint64_t)d.x + 1] = x1; }
-        if (d.y != NONE32) { out[2 * (uint64_t)d.y] = x2; out[2 * (uint64_t)d.y + 1] = x3; }
-        if (d.z != NONE32) { out[2 * (uint64_t)d.z] = x4; out[2 * (uint64_t)d.z + 1] = x5; }
-        if (d.w != NONE32) { out[2 * (uint64_t)d.w] = x6; out[2 * (uint64_t)d.w + 1] = x7; }
+    g_cu4* wit = (g_cu4*)a.wit;
+    const uint32_t lane = threadIdx.x & 63u, part = lane & 7u, sub = lane >> 3;
+    const uint64_t wave = ((uint64_t)bx * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)nbx * blockDim.x) >> 6;
+    for (uint64_t q0 = wave * 64; q0 < n; q0 += nwaves * 64) {
+        hz_u32x4 x[8];
+        uint32_t d[8];
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            const uint64_t q = q0 + (uint64_t)st * 8 + sub;
+            d[st] = NONE32;
+            if (q < n) {
+                const uint32_t l0 = line0[q];
+                uint32_t upi = lt.upi[0], rem = lt.rem[0];
+#pragma unroll
+                for (int i = 1; i < 4; i++)
+                    if ((uint32_t)i < lt.nsec && l0 >= lt.first_line[i]) { upi = lt.upi[i]; rem = lt.rem[i]; }
+                d[st] = dst[4 * q + (part >> 1)];
+                x[st] = wit[8 * (uint64_t)l0 + 2 * ((uint64_t)inst * upi + rem) + part];
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 8; st++)
+            if (d[st] != NONE32) out[2 * (uint64_t)d[st] + (part & 1u)] = x[st];
     }
 }
-__global__ void __launch_bounds__(256) k_export_singles(const ExpArgs a, const uint32_t* __restrict__ src, const uint32_t* __restrict__ dst, uint64_t n) {
+// two lanes per element
+template <bool UPI1>
+__device__ __forceinline__ void export_singles(const ExpArgs& a, const uint32_t* __restrict__ src, const uint32_t* __restrict__ dst, uint64_t n, uint32_t bx, uint32_t nbx) {
     const uint32_t inst = a.inst0 + blockIdx.y;
     g_u4* out = (g_u4*)(a.out + 2 * (uint64_t)blockIdx.y * a.out_stride);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        g_cu4* p = (g_cu4*)(a.wit + 2 * v2p(a.st, src[i], inst));
-        const hz_u32x4 x0 = p[0], x1 = p[1];
-        const uint64_t d = dst[i];
-        out[2 * d] = x0; out[2 * d + 1] = x1;
+    g_cu4* wit = (g_cu4*)a.wit;
+    const uint32_t half = threadIdx.x & 1u;
+    const uint64_t t0 = ((uint64_t)bx * blockDim.x + threadIdx.x) >> 1, nt = ((uint64_t)nbx * blockDim.x) >> 1;
+    for (uint64_t i0 = t0; i0 < n; i0 += 4 * nt) {
+        hz_u32x4 x[4];
+        uint32_t d[4];
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            const uint64_t i = i0 + (uint64_t)st * nt;
+            d[st] = NONE32;
+            if (i < n) {
+                d[st] = dst[i];
+                uint64_t p;
+                if (UPI1) {   // the section with one unit per instance (the last one of the layout that has it): no division
+                    const uint32_t v = src[i];
+                    uint64_t vbase = a.st.sec[0].vbase, base = a.st.sec[0].base;
+                    uint32_t nu = a.st.sec[0].n_units;
+#pragma unroll
+                    for (int k = 1; k < 4; k++)
+                        if ((uint32_t)k < a.st.nsec && (uint64_t)v >= a.st.sec[k].vbase) { vbase = a.st.sec[k].vbase; base = a.st.sec[k].base; nu = a.st.sec[k].n_units; }
+                    p = base + (uint64_t)(v - (uint32_t)vbase) * nu + inst;
+                } else p = v2p(a.st, src[i], inst);
+                x[st] = wit[2 * p + half];
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+            if (d[st] != NONE32) out[2 * (uint64_t)d[st] + half] = x[st];
     }
+}
+// ONE launch for every stored variable of an instance: the first bq blocks take the lines, the next b1 the elements of the sections
+// with one unit per instance (scattered 32-byte reads: latency, which the streaming blocks beside them hide), the last bx the rest
+struct StoredLists { const uint32_t* q_line0; const uint32_t* q_dst; uint64_t nq; const uint32_t* s1_src; const uint32_t* s1_dst; uint64_t n1; const uint32_t* sx_src; const uint32_t* sx_dst; uint64_t nx;
+                     uint32_t bq, b1, bx; };
+__global__ void __launch_bounds__(256) k_export_stored(const ExpArgs a, const LineTab lt, const StoredLists l) {
+    const uint32_t b = blockIdx.x;
+    if (b < l.bq) export_quads(a, lt, l.q_line0, l.q_dst, l.nq, b, l.bq);
+    else if (b < l.bq + l.b1) export_singles<true>(a, l.s1_src, l.s1_dst, l.n1, b - l.bq, l.b1);
+    else export_singles<false>(a, l.sx_src, l.sx_dst, l.nx, b - l.bq - l.b1, l.bx);
+}
+__global__ void __launch_bounds__(256) k_export_singles_only(const ExpArgs a, const uint32_t* __restrict__ src, const uint32_t* __restrict__ dst, uint64_t n) {
+    export_singles<false>(a, src, dst, n, blockIdx.x, gridDim.x);
 }
 // sections with ONE unit per instance, four instances per lane: instance inst0 + 4 * blockIdx.y + j of variable dst goes to
 // out + (4 * blockIdx.y + j) * out_stride; the four sources are one 128-byte line
@@ -313,6 +376,13 @@ static hz_status build_plan(const CtxGeom& g, const hz_symmap* m, DevPlan** out)
     P->device = g.device; P->per_instance = g.per_instance; P->total = g.total; P->n_inst = g.n_inst; P->nvars = m->index.size();
     P->st.nsec = g.nsec;
     for (uint32_t i = 0; i < g.nsec; i++) P->st.sec[i] = g.sec[i];
+    for (uint32_t i = 0; i < g.nsec; i++)
+        if (g.sec[i].upi % 4 == 0) {
+            LineTab& lt = P->lt;
+            lt.first_line[lt.nsec] = (uint32_t)(g.sec[i].base / 4); lt.upi[lt.nsec] = g.sec[i].upi; lt.rem[lt.nsec] = (uint32_t)(g.sec[i].base % 4);
+            lt.nsec++;
+        }
+    if (g.total / 4 >= NONE32) return set_err(HZ_ERR_ARG, "witness export: a physical buffer of %llu elements does not fit the 32-bit line numbers", (unsigned long long)g.total);
     const uint64_t nv = m->index.size(), D = m->derived.size();
     if (g.per_instance >= SRC_DERIVED || nv >= NONE32 || D >= SRC_DERIVED)
         return set_err(HZ_ERR_ARG, "witness export: %llu signals / %llu variables / %llu derived do not fit the 32-bit tables", (unsigned long long)g.per_instance, (unsigned long long)nv, (unsigned long long)D);
@@ -344,7 +414,8 @@ static hz_status build_plan(const CtxGeom& g, const hz_symmap* m, DevPlan** out)
             if (quad_done[(size_t)line]) continue;   // written with the line's first variable
             quad_done[(size_t)line] = 1;
             const uint64_t q0 = idx - (rel & 3);
-            q_src.push_back((uint32_t)q0);
+            const uint64_t p0 = s.base + ((q0 - s.vbase) / s.upi) * (uint64_t)s.n_units + (q0 - s.vbase) % s.upi;   // instance 0
+            q_src.push_back((uint32_t)((p0 - s.base % 4) / 4));
             q_dst.push_back(uint4{head[(size_t)q0], head[(size_t)q0 + 1], head[(size_t)q0 + 2], head[(size_t)q0 + 3]});
         } else if (s.upi == 1) { s1_src.push_back((uint32_t)idx); s1_dst.push_back((uint32_t)v);
         } else { sx_src.push_back((uint32_t)idx); sx_dst.push_back((uint32_t)v); }
@@ -569,19 +640,23 @@ static hz_status export_chunk(DevPlan* P, const CtxGeom& g, uint32_t inst0, uint
     ExpArgs a;
     memset(&a, 0, sizeof a);
     a.wit = (const hz_u32x4*)g.wit; a.out = (hz_u32x4*)d_out; a.out_stride = P->nvars; a.inst0 = inst0; a.st = P->st;
-    if (P->n_quads) {
-        hipLaunchKernelGGL(k_export_quads, dim3(grid_for(P->n_quads, 256), ninst), dim3(256), 0, s, a, (const uint32_t*)P->q_src.p, (const uint4*)P->q_dst.p, P->n_quads);
+    StoredLists l;
+    memset(&l, 0, sizeof l);
+    l.q_line0 = (const uint32_t*)P->q_src.p; l.q_dst = (const uint32_t*)P->q_dst.p; l.nq = P->n_quads;
+    l.sx_src = (const uint32_t*)P->sx_src.p; l.sx_dst = (const uint32_t*)P->sx_dst.p; l.nx = P->n_sx;
+    const bool x4 = P->n_s1 && ninst % 4 == 0;   // several instances together: the one-unit-per-instance sections four instances per lane
+    if (!x4) { l.s1_src = (const uint32_t*)P->s1_src.p; l.s1_dst = (const uint32_t*)P->s1_dst.p; l.n1 = P->n_s1; }
+    // blocks in proportion to the bytes each list moves, 2^16 in all at most
+    const uint64_t wq = (l.nq + 255) / 256, w1 = (l.n1 + 511) / 512, wx = (l.nx + 511) / 512, wsum = wq + w1 + wx;
+    if (wsum) {
+        const uint64_t cap = 1u << 16;
+        auto share = [&](uint64_t w) { return (uint32_t)(w == 0 ? 0 : wsum <= cap ? w : std::max<uint64_t>(1, w * cap / wsum)); };
+        l.bq = share(wq); l.b1 = share(w1); l.bx = share(wx);
+        hipLaunchKernelGGL(k_export_stored, dim3(l.bq + l.b1 + l.bx, ninst), dim3(256), 0, s, a, P->lt, l);
         HZ_HIP(hipGetLastError());
     }
-    if (P->n_s1) {
-        if (ninst % 4 == 0)
-            hipLaunchKernelGGL(k_export_singles_x4, dim3(grid_for(P->n_s1, 256), ninst / 4), dim3(256), 0, s, a, (const uint32_t*)P->s1_src.p, (const uint32_t*)P->s1_dst.p, P->n_s1);
-        else
-            hipLaunchKernelGGL(k_export_singles, dim3(grid_for(P->n_s1, 256), ninst), dim3(256), 0, s, a, (const uint32_t*)P->s1_src.p, (const uint32_t*)P->s1_dst.p, P->n_s1);
-        HZ_HIP(hipGetLastError());
-    }
-    if (P->n_sx) {
-        hipLaunchKernelGGL(k_export_singles, dim3(grid_for(P->n_sx, 256), ninst), dim3(256), 0, s, a, (const uint32_t*)P->sx_src.p, (const uint32_t*)P->sx_dst.p, P->n_sx);
+    if (x4) {
+        hipLaunchKernelGGL(k_export_singles_x4, dim3(grid_for(P->n_s1, 256), ninst / 4), dim3(256), 0, s, a, (const uint32_t*)P->s1_src.p, (const uint32_t*)P->s1_dst.p, P->n_s1);
         HZ_HIP(hipGetLastError());
     }
     if (P->n_dvars) {
@@ -671,7 +746,7 @@ struct PinnedRing {
     }
 };
 template <class Sink>
-static hz_status export_through_ring(hz_ctx* ctx, const hz_symmap* m, int32_t instance, uint64_t first, uint64_t count, Sink sink) {
+static hz_status export_through_ring(hz_ctx* ctx, const hz_symmap* m, int32_t instance, uint64_t first, uint64_t count, Sink sink, uint8_t* direct_out = nullptr) {
     CtxGeom g;
     DevPlan* P = nullptr;
     hz_status st = get_plan(ctx, m, g, &P);
@@ -679,10 +754,15 @@ static hz_status export_through_ring(hz_ctx* ctx, const hz_symmap* m, int32_t in
     if (instance < 0 || instance >= (int32_t)g.n_inst) return set_err(HZ_ERR_ARG, "witness export: bad instance %d", instance);
     if (first > P->nvars || count > P->nvars - first) return set_err(HZ_ERR_ARG, "witness export: range beyond the %llu variables", (unsigned long long)P->nvars);
     HZ_HIP(hipSetDevice(g.device));
-    DevBuf dout;
-    HZ_HIP(dout.alloc(std::max<uint64_t>(P->nvars, 1) * 32));
+    if (!P->xbuf.p) HZ_HIP(P->xbuf.alloc(std::max<uint64_t>(P->nvars, 1) * 32));
+    DevBuf& dout = P->xbuf;
     st = hz_witness_export_dev(ctx, m, instance, dout.p, g.s_main);
     if (st != HZ_OK) return st;
+    if (direct_out) {   // the caller's buffer is pinned: one copy at PCIe speed, no staging
+        HZ_HIP(hipMemcpyAsync(direct_out, (const uint8_t*)dout.p + first * 32, count * 32, hipMemcpyDeviceToHost, g.s_main));
+        HZ_HIP(hipStreamSynchronize(g.s_main));
+        return HZ_OK;
+    }
     PinnedRing ring;
     ring.bytes = (size_t)std::min<uint64_t>(std::max<uint64_t>(count, 1) * 32, 64ull << 20);
     for (int i = 0; i < 2; i++) { HZ_HIP(hipHostMalloc(&ring.b[i], ring.bytes, hipHostMallocDefault)); HZ_HIP(hipEventCreateWithFlags(&ring.ev[i], hipEventDisableTiming)); }
@@ -708,7 +788,10 @@ static hz_status export_through_ring(hz_ctx* ctx, const hz_symmap* m, int32_t in
 extern "C" hz_status hz_witness_export_host(hz_ctx* ctx, const hz_symmap* m, int32_t instance, uint64_t first_var, uint64_t count, uint8_t* out) {
     if (!out) return set_err(HZ_ERR_ARG, "hz_witness_export_host: null output buffer");
     uint8_t* p = out;
-    return export_through_ring(ctx, m, instance, first_var, count, [&](const uint8_t* b, uint64_t n) { memcpy(p, b, n * 32); p += n * 32; return true; });
+    hipPointerAttribute_t at;
+    bool pinned = hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();   // (an ordinary host pointer is an error to the query, not to us)
+    return export_through_ring(ctx, m, instance, first_var, count, [&](const uint8_t* b, uint64_t n) { memcpy(p, b, n * 32); p += n * 32; return true; }, pinned ? out : nullptr);
 }
 
 namespace hz {
