@@ -127,7 +127,7 @@ def poseidon_rates(L, torch):
             by = n * (32 * (t - 1) + 32 + (96 * nsbox if wit else 0))
             r = {"perm_per_s": round(n / ms * 1e3, 0), "GBs": round(by / ms / 1e6, 1), "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": by}
             # the integer-issue side: SQ_INSTS_VALU of this instantiation's launch of 2^20 permutations (committed PMC pass,
-            # tools/gpu_pmc_poseidon.sh) x the issue cost of the mix / (SIMDs x clock x this run's launch time)
+            # tools/gpu_suite.sh pmc-poseidon) x the issue cost of the mix / (SIMDs x clock x this run's launch time)
             insts = poseidon_valu("poseidon_batch_kernel<%d, %s>" % (t, "true" if wit else "false"))
             props = torch.cuda.get_device_properties(torch.cuda.current_device())
             fv = insts * VALU_CYCLES_PER_INST / (props.multi_processor_count * 4 * float(getattr(props, "clock_rate", 0) or 2400000) * 1e3 * ms * 1e-3) if insts else None
@@ -137,40 +137,54 @@ def poseidon_rates(L, torch):
                 fh = by / ms / 1e6 / HBM_PEAK_GBS
                 r["roofline"] = {"bound": "valu" if fv is not None and fv > fh else "hbm", "kernel": "poseidon_batch_kernel<%d, witness>" % t, "achieved": r["GBs"],
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fh, 5), "frac_hbm": round(fh, 5), "frac_valu": r.get("frac_valu"),
-                                 "traffic": measured_traffic("poseidon_t%d_witness" % t, None)}
+                                 "traffic": measured_traffic("poseidon_t%d_witness" % t, None)[0], "traffic_source": measured_traffic("poseidon_t%d_witness" % t, None)[1]}
             out["t%d_%s" % (t, mode)] = r
         del d_in, d_out, d_wit
     return out
 
 
+PROFILE_ROUNDS = ("r05", "r04")   # committed counter passes, newest first
+
+
+def _profile_json(suffix):
+    for r in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", "%s_%s" % (r, suffix))
+        try:
+            return json.load(open(path)), "profiles/%s_%s" % (r, suffix)
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
 def measured_traffic(kernel, bpl):
-    """HBM bytes of one launch of `kernel` (mean over its launches of the transaction grid) from the committed rocprofv3 PMC passes
-    (profiles/r04_hbm_counters.json, collected by tools/profile.sh on the same command line); None when that file does not cover
-    this configuration."""
+    """(HBM bytes of one launch of `kernel` (mean over its launches of the transaction grid), the file they come from): the committed
+    rocprofv3 PMC passes (profiles/rNN_hbm_counters.json, collected by tools/profile.sh on the same command line) -- a recorded
+    constant, not a measurement of this run; (None, None) when no file covers this configuration."""
+    d, src = _profile_json("hbm_counters.json")
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r04_hbm_counters.json")))
-        if bpl is not None and d.get("batches_per_launch") != bpl:
-            return None
+        if d is None or (bpl is not None and d.get("batches_per_launch") != bpl):
+            return None, None
         k = d["kernels"][kernel]
         if "fetch_bytes_mean" in k:   # per launch like `achieved`: mean over the kernel's launches of the transaction grid
-            return int(k["fetch_bytes_mean"] + k["write_bytes_mean"])
-        return int(k["fetch_bytes"] + k["write_bytes"])
-    except (OSError, KeyError, ValueError):
-        return None
+            return int(k["fetch_bytes_mean"] + k["write_bytes_mean"]), src
+        return int(k["fetch_bytes"] + k["write_bytes"]), src
+    except (KeyError, ValueError):
+        return None, None
 
 
 def measured_valu(kernel=None):
-    """VALU wave-instructions from the committed rocprofv3 SQ_INSTS_VALU pass of this command line (profiles/r04_valu_counters.json,
-    tools/gpu_pmc.sh): per step over every kernel, or per launch of `kernel`'s transaction grid. None when the file is missing."""
-    for name in ("r04_valu_counters.json",):
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if kernel is None:
-                return d["insts_valu_per_step"], d
-            return d["kernels"][kernel]["insts_valu_largest_grid_mean"], d
-        except (OSError, KeyError, ValueError):
-            continue
-    return None, None
+    """VALU wave-instructions from the committed rocprofv3 SQ_INSTS_VALU pass of this command line (profiles/rNN_valu_counters.json,
+    tools/gpu_suite.sh pmc): per step over every kernel, or per launch of `kernel`'s transaction grid. None when the file is missing."""
+    d, src = _profile_json("valu_counters.json")
+    try:
+        if d is None:
+            return None, None
+        d = dict(d, source_file=src)
+        if kernel is None:
+            return d["insts_valu_per_step"], d
+        return d["kernels"][kernel]["insts_valu_largest_grid_mean"], d
+    except (KeyError, ValueError):
+        return None, None
 
 
 # cycles one SIMD spends on one wave-instruction of this instruction mix when nothing stalls: 61 % v_mad_u64_u32 at 4.6-4.9, the 64-bit
@@ -179,11 +193,11 @@ VALU_CYCLES_PER_INST = 4.3
 
 
 def poseidon_valu(kernel):
-    """SQ_INSTS_VALU per launch of 2^20 permutations of one poseidon_batch_kernel instantiation (profiles/r04_poseidon_valu.json), or None"""
+    """SQ_INSTS_VALU per launch of 2^20 permutations of one poseidon_batch_kernel instantiation (profiles/rNN_poseidon_valu.json), or None"""
+    d, _ = _profile_json("poseidon_valu.json")
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_poseidon_valu.json")) as f:
-            return float(json.load(f)["kernels"][kernel]["insts_valu_per_launch"])
-    except (OSError, KeyError, ValueError):
+        return float(d["kernels"][kernel]["insts_valu_per_launch"])
+    except (KeyError, ValueError, TypeError):
         return None
 
 
@@ -344,10 +358,37 @@ def bench_sharded(args, L, D, packed, expected):
         sb.step(stream.cuda_stream)
     steps = max(4, args.steps)
     dt = D.timed(lambda: [sb.step(stream.cuda_stream) for _ in range(steps)])
+    # phases of one pass on this rank, HIP events on the pass's stream (gloo test hook: the collectives block on the host, their time
+    # shows as host time between the phases, not on the stream)
+    phases = {}
+    for _ in range(3):
+        marks = []
+
+        def mark(label):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            marks.append((label, e))
+        sb.step(stream.cuda_stream, mark)
+        torch.cuda.synchronize()
+        for (l0, e0), (l1, e1) in zip(marks, marks[1:]):
+            phases[l1] = phases.get(l1, 0.0) + e0.elapsed_time(e1) / 3
+    mine = {"rank": D.rank, "transactions": sb.count, "shard_ms": round(phases.get("shard", 0.0), 3), "all_gather_us": round(phases.get("all_gather", 0.0) * 1e3, 1),
+            "tail_ms": round(phases.get("tail", 0.0), 3), "broadcast_us": round(phases.get("broadcast", 0.0) * 1e3, 1), "expand_ms": round(phases.get("expand", 0.0), 3)}
+    per_rank = [mine]
+    if D.world > 1:
+        per_rank = [None] * D.world
+        D.dist.all_gather_object(per_rank, mine)
     res = None
     if D.rank == 0:
         abytes = algorithmic_bytes_per_tx(lv, F) * nTx
         res = {"value": round(nTx * steps / dt, 1), "unit": "tx-witnesses/s", "scaling": "strong", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+               "rccl_ranks": D.world if (D.backend == "nccl" and (D.world > 1 or D.force)) else 0,
+               "backend": D.backend if (D.world > 1 or D.force) else None,
+               "per_rank": per_rank,
+               "slowest_shard_ms": max(p["shard_ms"] for p in per_rank), "all_gather_us": max(p["all_gather_us"] for p in per_rank),
+               "broadcast_us": max(p["broadcast_us"] for p in per_rank),
+               "hardware_note": "RCCL between two GPUs over xGMI has not run on any box this code was built on (one-GPU boxes): unmeasured on hardware until "
+                                "the driver's 8-GPU run; rccl_ranks = 0 means the collectives of this line did not go through RCCL",
                "parallelism": "tx-shard%d" % D.world,
                "collective": "one all_gather of %d B%s per step (%s)" % (sb.slot * D.world, " + one broadcast of %d B (SHA-256 blocks split over the ranks)" % c.sha_state_bytes()
                                                                           if sb.split_tail else "", D.backend),
@@ -423,7 +464,7 @@ def bench_withdraw(args, L, D, launches=None, steps=None):
                "whole_launch": {"achieved_GBs": round(abytes / (ms_launch * 1e-3) / 1e9, 2), "frac": round(abytes / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                 "launch_ms": round(ms_launch, 3), "algorithmic_bytes_per_launch": int(abytes), "note": "k_withdraw_sha || k_withdraw, wall time"},
                "roofline": {"bound": "hbm", "kernel": "k_" + dk, "achieved": round(acc[dk][1] / (acc[dk][0] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(acc[dk][1] / (acc[dk][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": measured_traffic("k_" + dk, None),
+                            "frac": round(acc[dk][1] / (acc[dk][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": measured_traffic("k_" + dk, None)[0], "traffic_source": measured_traffic("k_" + dk, None)[1],
                             "launch_ms": round(acc[dk][0], 3), "algorithmic_bytes_per_launch": int(acc[dk][1])},
                "kernels_ms": {k: round(v[0], 3) for k, v in acc.items()},
                "kernels_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in acc.items() if v[0] > 0}}
@@ -520,6 +561,70 @@ def bench_export(args, L, D, ctxs, streams, run_enqueue, nTx, Bp):
                    "the ceiling is pcie_ceiling_tx_per_s. wtns_write_s: one batch as .wtns through the pinned ring into a memory-backed file"}
     del maps
     return res
+
+
+def bench_shard_standin(L, D, nTx, lv, m1, F, packed_ptr, pbytes, expected, world=8):
+    """A stand-in for BASELINE config 4 on ONE GPU: the batch cut into `world` contiguous transaction ranges exactly
+    as bench.py --gpus 8 --shard-tx cuts it (circuits_amd/multigpu.py), every range evaluated ALONE on this device -- what its own GPU
+    would see -- then rank 0's tail and every rank's share of the SHA-256 blocks, HIP events on the pass's stream. The two collectives
+    (328 KB all_gather, 73 KB broadcast) are not in the figure: RCCL over xGMI has not run on any box this code was built on."""
+    torch = D.torch
+    c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=D.local, flags=2)   # one batch per GPU: latency scheduling
+    stream = torch.cuda.Stream(device=D.local)
+    c.upload(0, packed_ptr, pbytes, stream.cuda_stream)
+    ranges = [L.shard_range(nTx, world, r) for r in range(world)]
+    rec = c.da_record_bytes()
+    slot = max(n for _, n in ranges) * rec
+    recv = torch.zeros(slot * world, dtype=torch.uint8, device="cuda")
+    sha = torch.zeros(c.sha_state_bytes(), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    reps = 3
+    shard_ms, expand_ms, tail_ms = [0.0] * world, [0.0] * world, 0.0
+    for rep in range(reps + 1):
+        for r in range(world - 1, -1, -1):   # rank 0 last: its context then holds its own shard's scratch for the tail
+            f, n = ranges[r]
+            c.set_shard(f, n, r == 0)
+
+            def shard(r=r):
+                c.enqueue(stream.cuda_stream)
+                c.da_export(recv.data_ptr() + r * slot, stream.cuda_stream)
+            t = timed(shard)
+            if rep:
+                shard_ms[r] += t / reps
+
+        def tail():
+            for r in range(1, world):
+                f, n = ranges[r]
+                c.da_import(f, n, recv.data_ptr() + r * slot, stream.cuda_stream)
+            c.enqueue_tail_chain(stream.cuda_stream)
+            c.sha_export(sha.data_ptr(), stream.cuda_stream)
+        t = timed(tail)
+        if rep:
+            tail_ms += t / reps
+        for r in range(world):
+            f, n = L.shard_range(c.sha_blocks(), world, r)
+            t = timed(lambda f=f, n=n: c.sha_expand(f, n, None, stream.cuda_stream))
+            if rep:
+                expand_ms[r] += t / reps
+        c.check()
+        assert c.get("main.hashGlobalInputs") == expected, "hashGlobalInputs mismatch (shard stand-in)"
+    total = max(shard_ms) + tail_ms + max(expand_ms)
+    del c
+    return {"world": world, "transactions_per_rank": [n for _, n in ranges], "shard_ms": [round(x, 3) for x in shard_ms], "slowest_shard_ms": round(max(shard_ms), 3),
+            "tail_ms_rank0": round(tail_ms, 3), "expand_ms": [round(x, 3) for x in expand_ms], "modelled_ms_per_batch": round(total, 3),
+            "modelled_tx_per_s": round(nTx / total * 1e3, 1),
+            "note": "config 4 as named (one batch over 8 GPUs), modelled on one GPU: slowest shard alone + rank 0's FeeTx / message / SHA-256 chain + slowest share of the "
+                    "block expansion; the all_gather and the broadcast (latency-sized) are NOT included -- RCCL between GPUs is unmeasured on hardware. A 256-transaction "
+                    "shard is 4 wavefronts per kernel: the dependent chains (33 level hashes, 148 ladder steps) set its time, so 8 GPUs do not make one batch 8 x faster"}
 
 
 def respawn(args):
@@ -797,6 +902,12 @@ def main():
         except Exception as e:   # noqa: BLE001 -- a secondary figure must never cost the main line
             export = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
+    standin = None
+    if world == 1 and not args.no_sweep:
+        try:
+            standin = bench_shard_standin(L, D, nTx, lv, m1, F, pin, pbytes, expected[0])
+        except Exception as e:   # noqa: BLE001
+            standin = {"error": "%s: %s" % (type(e).__name__, e)}
     deep = None
     if world == 1 and not args.no_deep_state and n_acc < (1 << args.deep_accounts_log2):
         # The same step on a DEEP state: 2^20 accounts instead of 4 * nTx. The proofs then reach their leaves at level ~21 instead
@@ -947,8 +1058,8 @@ def main():
                              "frac": round(step_insts * VALU_CYCLES_PER_INST / (n_simd * clock_hz * step_s), 5),
                              "measured_cycles_per_inst": round(n_simd * clock_hz * step_s / step_insts, 3),
                              "kernel": dk, "kernel_insts_per_launch": int(k_insts) if k_insts else None, "kernel_frac": round(frac_valu, 5) if frac_valu else None,
-                             "source": "SQ_INSTS_VALU of profiles/r04_valu_counters.json (%s), x %.1f cycles per wave-instruction of this mix (profiles/r03_instbench.txt), "
-                                       "/ (SIMDs x clock x the step time of THIS run)" % (vmeta.get("command", "?") if vmeta else "?", VALU_CYCLES_PER_INST)}
+                             "source": "SQ_INSTS_VALU of %s (%s), x %.1f cycles per wave-instruction of this mix (profiles/r03_instbench.txt), "
+                                       "/ (SIMDs x clock x the step time of THIS run)" % (vmeta.get("source_file", "?") if vmeta else "?", vmeta.get("command", "?") if vmeta else "?", VALU_CYCLES_PER_INST)}
         bound = "valu" if (frac_valu or 0) > frac_hbm else "hbm"
         out = {
             "metric": "rollup-main tx-witnesses/sec (nTx=%d, nLevels=%d)" % (nTx, lv),
@@ -967,7 +1078,8 @@ def main():
                                          if builder_stats else {"kind": "python (circuits_amd/builder.py), host hashing, process pool", "batches": len(all_seeds)})},
             "roofline": {"bound": bound, "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_hbm": round(frac_hbm, 5), "frac_valu": round(frac_valu, 5) if frac_valu else None,
-                         "traffic": measured_traffic(dk, Bp),
+                         "traffic": measured_traffic(dk, Bp)[0],
+                         "traffic_source": "%s (committed PMC pass of this command line, not measured by this run)" % measured_traffic(dk, Bp)[1] if measured_traffic(dk, Bp)[1] else None,
                          "launches_per_step": dlaunches, "launch_ms": round(dms / dlaunches, 3),
                          "algorithmic_bytes_per_launch": int(dbytes // dlaunches), "gpu_ms_per_step_all_launches": round(tot[dk], 3),
                          "note": "achieved / peak / frac price the kernel against the HBM roofline (the contract's figure); `bound` names the roofline with "
@@ -988,6 +1100,8 @@ def main():
             out["single_batch_latency_ms"] = dict(single, note="one 2048-transaction batch alone on the device, enqueue + check, mean of 6; latency_flag = HZ_FLAG_LATENCY "
                                                               "(the context's concurrent chains on disjoint compute units)")
             out["batches_sweep"] = sweep
+        if standin is not None:
+            out["shard_tx_standin"] = standin
         if export is not None:
             for k in ("export_ms_per_batch", "value_export", "value_delivered_host", "wtns_write_s"):
                 if k in export:

@@ -43,16 +43,21 @@ class ShardedBatch:
             self.sha = alloc(ctx.sha_state_bytes())
         ctx.set_shard(self.first, self.count, rank == 0)
 
-    def step(self, stream):
+    def step(self, stream, mark=None):
         """One sharded pass on HIP stream `stream` (a hipStream_t handle, required): export, collectives, imports and the tail
         are ordered by that stream, so `all_gather` / `broadcast` must enqueue on it too (bench.py: `with torch.cuda.stream(s)`),
-        or block until their buffers are complete."""
+        or block until their buffers are complete. `mark(label)` (optional) is called between the phases -- the caller records an
+        event on the stream there (bench.py: per-rank phase times of the sharded line)."""
+        mark = mark or (lambda label: None)
         if not stream:
             raise ValueError("ShardedBatch.step needs an explicit stream: the collective has to be ordered with the export/import kernels")
         c = self.ctx
+        mark("start")
         c.enqueue(stream)                       # this rank's transactions
         c.da_export(self.send.data_ptr(), stream)
+        mark("shard")
         self.all_gather(self.recv, self.send)   # collective 1: data-availability records
+        mark("all_gather")
         if self.rank == 0:
             for r in range(1, self.world):
                 f, n = self.ranges[r]
@@ -62,8 +67,11 @@ class ShardedBatch:
                 c.sha_export(self.sha.data_ptr(), stream)
             else:
                 c.enqueue_tail(stream)          # FeeTx + HashInputs, block witness included
+        mark("tail")
         if self.split_tail:
             self.broadcast(self.sha)            # collective 2: message blocks and chaining values from rank 0
+            mark("broadcast")
             f, n = self.blocks
             c.sha_expand(f, n, None if self.rank == 0 else self.sha.data_ptr(), stream)
+            mark("expand")
         c.check()

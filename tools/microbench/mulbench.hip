@@ -275,6 +275,102 @@ __global__ __launch_bounds__(64) void kbench_dot(uint32_t* x, int n) {
     for (int i = 0; i < 9; i++) x[tid * 18 + i] = a[0].v[i];
 }
 
+
+// V11 (round 5, the latency question of SURVEY 8a' "alternative lane mapping"): ONE product spread over the lanes of a quad -- lane q
+// (0..2) of the quad holds limbs 3q .. 3q+2 of each operand, lane 3 holds zeros (the "fourth block" that makes every shift uniform).
+// Block Montgomery in radix B = 2^87 (R = B^3 = 2^261, the same domain as fr.h): for j = 0..2
+//     every lane:  acc += A_q * B_j                 (B_j = lane j's three limbs, three DPP quad broadcasts; nine multiply-accumulates)
+//     lane 0:      M = -acc_low / p mod B           (three limbs, the interleaved reduction inside the low block)
+//     every lane:  acc += M * P_q                   (M from lane 0 by three DPP broadcasts; nine multiply-accumulates)
+//     every lane:  acc = acc >> 87 + (low block of lane q + 1)   (six DPP moves of raw 64-bit column sums; lane 0 adds its carry)
+// then two rounds of carry normalisation that ripple across the lanes. Same integer as fr_mul (the quotient m is unique).
+struct Q3 { uint32_t v[3]; };
+template <int CTRL>
+__device__ __forceinline__ uint32_t dppq(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false); }   // every lane of a quad has a source: `old` is never kept
+__device__ __forceinline__ uint64_t dppq64_next(uint64_t x) {   // from lane q + 1 of the quad (quad_perm [1,2,3,3]: the zero lane keeps reading itself and stays zero)
+    const uint32_t lo = dppq<0xF9>((uint32_t)x), hi = dppq<0xF9>((uint32_t)(x >> 32));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+template <int J>
+__device__ __forceinline__ void v11_step(uint64_t* c, const Q3& a, const Q3& b, const Q3& pq, uint64_t lane0_mask) {
+    const uint32_t b0 = dppq<J * 0x55>(b.v[0]), b1 = dppq<J * 0x55>(b.v[1]), b2 = dppq<J * 0x55>(b.v[2]);
+    c[0] += (uint64_t)a.v[0] * b0;
+    c[1] += (uint64_t)a.v[0] * b1 + (uint64_t)a.v[1] * b0;
+    c[2] += (uint64_t)a.v[0] * b2 + (uint64_t)a.v[1] * b1 + (uint64_t)a.v[2] * b0;
+    c[3] += (uint64_t)a.v[1] * b2 + (uint64_t)a.v[2] * b1;
+    c[4] += (uint64_t)a.v[2] * b2;
+    // the quotient block from the low block (meaningful in lane 0; the other lanes run the same instructions on their own columns)
+    uint64_t t0 = c[0];
+    const uint32_t m0 = ((uint32_t)t0 * INV29) & M29;
+    t0 += (uint64_t)m0 * p29(0);
+    uint64_t t1 = c[1] + (t0 >> 29) + (uint64_t)m0 * p29(1);
+    const uint32_t m1 = ((uint32_t)t1 * INV29) & M29;
+    t1 += (uint64_t)m1 * p29(0);
+    uint64_t t2 = c[2] + (t1 >> 29) + (uint64_t)m0 * p29(2) + (uint64_t)m1 * p29(1);
+    const uint32_t m2 = ((uint32_t)t2 * INV29) & M29;
+    t2 += (uint64_t)m2 * p29(0);
+    const uint64_t carry = (t2 >> 29) & lane0_mask;
+    const uint32_t M0 = dppq<0x00>(m0), M1 = dppq<0x00>(m1), M2 = dppq<0x00>(m2);
+    c[3] += (uint64_t)M1 * pq.v[2] + (uint64_t)M2 * pq.v[1];
+    c[4] += (uint64_t)M2 * pq.v[2];
+    // columns 0..2 of lanes 1.. go down one lane as they are; lane 0's have become its carry
+    const uint64_t l0 = c[0] + (uint64_t)M0 * pq.v[0];
+    const uint64_t l1 = c[1] + (uint64_t)M0 * pq.v[1] + (uint64_t)M1 * pq.v[0];
+    const uint64_t l2 = c[2] + (uint64_t)M0 * pq.v[2] + (uint64_t)M1 * pq.v[1] + (uint64_t)M2 * pq.v[0];
+    c[0] = c[3] + dppq64_next(l0) + carry;
+    c[1] = c[4] + dppq64_next(l1);
+    c[2] = dppq64_next(l2);
+    c[3] = 0; c[4] = 0;
+}
+__device__ __forceinline__ Q3 mul_v11(const Q3& a, const Q3& b, const Q3& pq, uint64_t lane0_mask) {
+    uint64_t c[5] = {0, 0, 0, 0, 0};
+    v11_step<0>(c, a, b, pq, lane0_mask);
+    v11_step<1>(c, a, b, pq, lane0_mask);
+    v11_step<2>(c, a, b, pq, lane0_mask);
+    // carries: inside the lane, then the lane's carry-out to lane q + 1 (quad_perm [3,0,1,2]: lane 0 receives lane 3's zero), twice
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        c[1] += c[0] >> 29; c[0] &= M29;
+        c[2] += c[1] >> 29; c[1] &= M29;
+        const uint64_t out = c[2] >> 29; c[2] &= M29;
+        const uint32_t lo = dppq<0x93>((uint32_t)out), hi = dppq<0x93>((uint32_t)(out >> 32));
+        c[0] += (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    Q3 r;
+    r.v[0] = (uint32_t)c[0]; r.v[1] = (uint32_t)c[1]; r.v[2] = (uint32_t)c[2];
+    return r;
+}
+// dependent chain a <- a * b on quads; the first launch also checks every product of the chain's first steps against fr_mul
+__global__ __launch_bounds__(64) void kbench11(uint32_t* x, int n, unsigned int* bad) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = threadIdx.x & 3, quad = tid >> 2;
+    // operands of the quad: nine limbs each, the same derivation as kbench<4> from x[quad * 18 ..]
+    uint32_t A[9], B[9];
+    for (int i = 0; i < 9; i++) { A[i] = x[quad * 18 + i] & M29; B[i] = x[quad * 18 + 9 + i] & M29; }
+    A[8] &= 0xffff; B[8] &= 0xffff;
+    Q3 a, b, pq;
+    for (int i = 0; i < 3; i++) {
+        a.v[i] = q < 3 ? A[3 * q + i] : 0u;
+        b.v[i] = q < 3 ? B[3 * q + i] : 0u;
+        pq.v[i] = q == 0 ? p29(i) : q == 1 ? p29(3 + i) : q == 2 ? p29(6 + i) : 0u;
+    }
+    const uint64_t lane0_mask = q == 0 ? ~0ull : 0ull;
+    if (bad) {   // verification: 64 dependent products, each compared with the one-lane product of the gathered operands
+        F29 fa, fb;
+        for (int i = 0; i < 9; i++) { fa.v[i] = A[i]; fb.v[i] = B[i]; }
+        for (int it = 0; it < 64; it++) {
+            a = mul_v11(a, b, pq, lane0_mask);
+            fa = mul_v4(fa, fb);
+            // normalise the reference the same way (mul_v4 leaves limb 8 with the top carry, limbs 0..7 below 2^29: already unique)
+            for (int i = 0; i < 3; i++)
+                if (q < 3 && a.v[i] != fa.v[3 * q + i]) atomicAdd(bad, 1u);
+        }
+        return;
+    }
+    for (int i = 0; i < n; i++) { a = mul_v11(a, b, pq, lane0_mask); b.v[0] ^= a.v[0] & 1; }
+    for (int i = 0; i < 3; i++) x[tid * 3 + i] = a.v[i];
+}
+
 template <int V>
 __global__ __launch_bounds__(64) void kbench(uint32_t* x, int n) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,7 +405,16 @@ int main() {
         hipMalloc(&d, h.size() * 4);
         uint64_t* dbg;
         hipMalloc(&dbg, 15 * 8);
-        for (int v : {4, 7, 8, 10, 9}) {
+        if (waves == 256 * 4) {   // V11 against the one-lane product, 64 dependent products per quad
+            unsigned int* bad; unsigned int hb = 0;
+            hipMalloc(&bad, 4); hipMemset(bad, 0, 4);
+            hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(kbench11, dim3(waves), dim3(64), 0, 0, d, 64, bad);
+            hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
+            printf("V11CHECK %u limb mismatches in %d quads x 64 products (0 expected)\n", hb, threads / 4);
+            hipFree(bad);
+        }
+        for (int v : {4, 11, 7, 8, 10, 9}) {
             hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
@@ -324,6 +429,7 @@ int main() {
                 if (v == 8) hipLaunchKernelGGL(kbench8<1>, dim3(waves), dim3(64), 0, 0, d, n, dbg);       // double-FMA limbs, one product
                 if (v == 9) hipLaunchKernelGGL(kbench8<3>, dim3(waves), dim3(64), 0, 0, d, n, (uint64_t*)nullptr);   // three products, one reduction
                 if (v == 10) hipLaunchKernelGGL(kbench_dot<3>, dim3(waves), dim3(64), 0, 0, d, n);          // fr_dot<3>, 9 x 29
+                if (v == 11) hipLaunchKernelGGL(kbench11, dim3(waves), dim3(64), 0, 0, d, n, (unsigned int*)nullptr);   // one product per QUAD of lanes
             };
             launch();
             hipDeviceSynchronize();
@@ -345,8 +451,9 @@ int main() {
             hipMemcpy(chk, d + 18 * 777, sizeof chk, hipMemcpyDeviceToHost);
             printf("[%08x %08x] ", chk[0], chk[8]);
             const int prods = (v == 9 || v == 10) ? 3 : 1;
-            printf("waves/SIMD=%d variant=%d: %.2f ms  %.1f ns per dependent step per wave  %.2f Gmul/s (%d product%s per reduction)\n", waves / 1024, v, ms, ms * 1e6 / n,
-                   (double)threads * n * prods / ms / 1e6, prods, prods > 1 ? "s" : "");
+            const double chains = v == 11 ? threads / 4.0 : threads;   // V11: a quad of lanes per chain
+            printf("waves/SIMD=%d variant=%d: %.2f ms  %.1f ns per dependent step per wave  %.2f Gmul/s (%d product%s per reduction%s)\n", waves / 1024, v, ms, ms * 1e6 / n,
+                   chains * n * prods / ms / 1e6, prods, prods > 1 ? "s" : "", v == 11 ? ", one product per quad of lanes" : "");
         }
         hipFree(d);
     }

@@ -10,9 +10,9 @@ cd $R
 grep '^{' $OUT/bench_default.log | tail -1 > $OUT/bench_line.json
 bash tools/profile.sh > $OUT/profile.log 2>&1
 cp gpurun_out/prof/kernel_stats.csv gpurun_out/prof/hbm_counters.csv gpurun_out/prof/hbm_counters.json $OUT/ 2>/dev/null
-bash tools/gpu_pmc.sh --no-e2e --no-deep-state --no-withdraw --no-poseidon --distinct-batches 4 > $OUT/pmc.log 2>&1
+bash tools/gpu_suite.sh pmc --no-e2e --no-deep-state --no-withdraw --no-poseidon --distinct-batches 4 > $OUT/pmc.log 2>&1
 cp gpurun_out/pmc/valu_summary.csv $OUT/valu_counters.csv 2>/dev/null; cp gpurun_out/pmc/valu_counters.json $OUT/valu_counters.json 2>/dev/null
-TL_OUT=round_tl bash tools/gpu_timeline.sh --no-withdraw --no-e2e --no-deep-state --no-sweep --distinct-batches 4 > $OUT/timeline.log 2>&1
+TL_OUT=round_tl bash tools/gpu_suite.sh timeline --no-withdraw --no-e2e --no-deep-state --no-sweep --distinct-batches 4 > $OUT/timeline.log 2>&1
 f=$(find gpurun_out/round_tl -name "*kernel_trace.csv" | head -1)
 if [ -n "$f" ]; then
   python - "$f" > $OUT/timeline_gantt.txt <<'PY'
