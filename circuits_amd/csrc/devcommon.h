@@ -124,7 +124,11 @@ __device__ __forceinline__ unsigned long long err_key(uint32_t inst, uint32_t un
     return ((unsigned long long)inst << 40) | ((unsigned long long)unit << 16) | cid;
 }
 
-__device__ __noinline__ void report_fail(ErrBuf* e, uint32_t inst, uint32_t unit, uint32_t cid, const Fr& lhs_m, const Fr& rhs_m) {
+// Out of line (the failing path is cold), in two parts so that nothing is passed by reference: a reference -- or a second 36-byte
+// struct, which the calling convention passes `byref` -- to a non-inlined function makes the caller keep the operand in scratch memory for
+// the whole kernel (round 4: six such slots in k_smt). report_slot claims the record, report_operand converts and stores ONE operand that
+// arrives in nine registers.
+__device__ __noinline__ ErrRec* report_slot(ErrBuf* e, uint32_t inst, uint32_t unit, uint32_t cid) {
     const unsigned long long key = err_key(inst, unit, cid);
     atomicMin(&e->minkey, key);
     const unsigned long long filter = e->filter;
@@ -132,20 +136,27 @@ __device__ __noinline__ void report_fail(ErrBuf* e, uint32_t inst, uint32_t unit
     if (filter == HZ_FILTER_PER_INST) {
         // the lane that reports an instance's lowest key takes that instance's slot; a lane that reports the same key several
         // times (a loop over the elements of one `===` array) keeps the first, as the shared list does
-        if (e->inst_min[inst] != key || atomicCAS(&e->inst_rec[inst].key, ~0ull, key) != ~0ull) return;
+        if (e->inst_min[inst] != key || atomicCAS(&e->inst_rec[inst].key, ~0ull, key) != ~0ull) return nullptr;
         dst = &e->inst_rec[inst];
     } else {
         atomicMin(&e->inst_min[inst], key);
-        if (filter != ~0ull && filter != key) return;
+        if (filter != ~0ull && filter != key) return nullptr;
         const unsigned int slot = atomicAdd(&e->count, 1u);
-        if (slot >= HZ_ERR_CAP) return;
+        if (slot >= HZ_ERR_CAP) return nullptr;
         dst = &e->rec[slot];
         dst->key = key;
     }
-    const Fc l = fr_to_canon(lhs_m), r = fr_to_canon(rhs_m);
-    for (int i = 0; i < 8; i++) {
-        dst->lhs[i] = l.v[i];
-        dst->rhs[i] = r.v[i];
+    return dst;
+}
+__device__ __noinline__ void report_operand(uint32_t* dst, const Fr v_m) {
+    const Fc c = fr_to_canon(v_m);
+    for (int i = 0; i < 8; i++) dst[i] = c.v[i];
+}
+__device__ __forceinline__ void report_fail(ErrBuf* e, uint32_t inst, uint32_t unit, uint32_t cid, const Fr& lhs_m, const Fr& rhs_m) {
+    ErrRec* dst = report_slot(e, inst, unit, cid);
+    if (dst) {
+        report_operand(dst->lhs, lhs_m);
+        report_operand(dst->rhs, rhs_m);
     }
 }
 

@@ -68,36 +68,69 @@ struct Scratch {
 };
 
 // ---- canonical-integer helpers ---------------------------------------------------------------------
-__device__ __forceinline__ uint32_t c_bit(const Fc& c, int i) { return (c.v[i >> 5] >> (i & 31)) & 1u; }
+// None of these indexes a register array with a run-time value: an array indexed that way lives in scratch memory (round 4 counted
+// 1 040 bytes per lane in k_smt, half of it the two keys whose bits the level loop reads). A word is picked by a chain of selects;
+// with a constant position (most call sites, after inlining) the chain folds away.
+__device__ __forceinline__ uint32_t c_word(const Fc& c, int w) {   // word w, 0 beyond the integer
+    uint32_t r = c.v[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) r = (w == j) ? c.v[j] : r;
+    return ((unsigned)w < 8u) ? r : 0u;
+}
+__device__ __forceinline__ uint32_t c_bit(const Fc& c, int i) { return (c_word(c, i >> 5) >> (i & 31)) & 1u; }
 // bits [from, from+n) of a canonical integer as u64 (n <= 64)
 __device__ __forceinline__ uint64_t c_bits64(const Fc& c, int from, int n) {
-    uint64_t r = 0;
-    for (int i = 0; i < n; i++) r |= (uint64_t)c_bit(c, from + i) << i;
-    return r;
+    const int w = from >> 5, sh = from & 31;
+    const uint64_t lo = (uint64_t)c_word(c, w) | ((uint64_t)c_word(c, w + 1) << 32);
+    uint64_t r = lo >> sh;
+    if (sh) r |= (uint64_t)c_word(c, w + 2) << (64 - sh);
+    return n >= 64 ? r : r & ((1ull << n) - 1ull);
 }
 // canonical integer with bits [from, from+n) of c moved to position 0 (n <= 256)
 __device__ __forceinline__ Fc c_extract(const Fc& c, int from, int n) {
-    Fc r = fc_zero();
-    for (int i = 0; i < n; i++) r.v[i >> 5] |= c_bit(c, from + i) << (i & 31);
+    const int w = from >> 5, sh = from & 31;
+    Fc r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t lo = c_word(c, w + j), hi = c_word(c, w + j + 1);
+        const uint32_t v = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+        const int left = n - 32 * j;   // bits of this word that belong to the field
+        r.v[j] = left >= 32 ? v : left <= 0 ? 0u : (v & ((1u << left) - 1u));
+    }
     return r;
 }
 // is the canonical integer < 2^n ?
 __device__ __forceinline__ bool c_fits(const Fc& c, int n) {
-    for (int i = n; i < 256; i++)
-        if (c_bit(c, i)) return false;
-    return true;
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int lo = n - 32 * j;     // bits of word j below 2^n
+        any |= lo >= 32 ? 0u : lo <= 0 ? c.v[j] : (c.v[j] >> lo);
+    }
+    return any == 0;
 }
 __device__ __forceinline__ Fc c_pow2(int k) {  // 2^k as a plain integer, k < 256
-    Fc r = fc_zero();
-    r.v[k >> 5] = 1u << (k & 31);
+    Fc r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = ((k >> 5) == j) ? (1u << (k & 31)) : 0u;
     return r;
 }
 // Montgomery 2^k for k < 253
 __device__ __forceinline__ Fr m_pow2(int k) { return fr_from_canon(c_pow2(k)); }
+// stores the bits [first, first + count) of `word` (count <= 32) as signals off + first .. : the inner loop of every bit decomposition
+__device__ __forceinline__ void put_word_bits_plain(const UnitIO& io, uint32_t off, uint32_t word, int count) {
+    for (int b = 0; b < count; b++) io.put_bit(off + b, (word >> b) & 1u);
+}
+// bits [0, n) of a canonical integer as signals off .. off + n, word by word (constant word indices)
+__device__ __forceinline__ void put_bits(const UnitIO& io, uint32_t off, const Fc& c, int n) {
+#define HZ_PB(j) { const int cnt = n - 32 * (j); if (cnt > 0) put_word_bits_plain(io, off + 32 * (j), c.v[j], cnt < 32 ? cnt : 32); }
+    HZ_PB(0) HZ_PB(1) HZ_PB(2) HZ_PB(3) HZ_PB(4) HZ_PB(5) HZ_PB(6) HZ_PB(7)
+#undef HZ_PB
+}
 
 // Num2Bits(n): stores out[0..n) from the canonical value; reports `sum === in` when it cannot hold
 __device__ __forceinline__ void num2bits_dev(const UnitIO& io, uint32_t off, const Fc& canon, int n, int cid) {
-    for (int i = 0; i < n; i++) io.put_bit(off + i, c_bit(canon, i));
+    put_bits(io, off, canon, n);
     if (n < 254 && !c_fits(canon, n)) {
         // lc1 = value mod 2^n
         const Fc lc = c_extract(canon, 0, n);
@@ -139,49 +172,50 @@ __device__ __forceinline__ Fr mux1_dev(const Fr& c0, const Fr& c1, const Fr& s) 
 // parts are small: each is  +-b_i, +-a_i, ... with a_i = 2^i, b_i = 2^128 - 2^i, so the sum fits
 // in 135 bits of a plain integer; evaluated with 192-bit integer arithmetic, no field products.
 __device__ __forceinline__ uint32_t comp_constant_dev(const UnitIO& io, const CompConstOff& off, const Fc& bits, const uint32_t* ct /*8 LE limbs*/) {
-    // sum accumulates in 5 x 32-bit limbs (160 bits)
-    uint32_t sum[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 127; i++) {
-        const uint32_t clsb = (ct[(2 * i) >> 5] >> ((2 * i) & 31)) & 1u, cmsb = (ct[(2 * i + 1) >> 5] >> ((2 * i + 1) & 31)) & 1u;
-        const uint32_t slsb = c_bit(bits, 2 * i), smsb = c_bit(bits, 2 * i + 1);
-        // a = 2^i, b = 2^128 - 2^i. part in {0, a, b}:
-        //  c=00: -b*m*l + b*m + b*l  -> b if (m|l) else 0
-        //  c=01: a*m*l - a*l + b*m - a*m + a -> m ? (l ? b : b... ) evaluate by cases below
-        //  c=10: b*m*l - a*m + a -> m ? (l ? b : 0) : a
-        //  c=11: -a*m*l + a -> (m&l) ? 0 : a
-        int sel;  // 0: zero, 1: a, 2: b
-        if (!cmsb && !clsb) sel = (smsb | slsb) ? 2 : 0;
-        else if (!cmsb && clsb) sel = smsb ? 2 : (slsb ? 0 : 1);   // m=1: l=1 -> a - a + b - a + a = b ; l=0 -> b - a + a = b. m=0: l=1 -> -a + a = 0 ; l=0 -> a
-        else if (cmsb && !clsb) sel = smsb ? (slsb ? 2 : 0) : 1;   // m=1,l=1: b - a + a = b ; m=1,l=0: -a + a = 0 ; m=0: a
-        else sel = (smsb & slsb) ? 0 : 1;
-        // store part
-        Fc part = fc_zero();
-        if (sel == 1) part.v[i >> 5] = 1u << (i & 31);
-        else if (sel == 2) {
-            // 2^128 - 2^i
-            Fc t = fc_zero();
-            t.v[4] = 1u;
-            // subtract 2^i
-            uint32_t sub[5] = {0, 0, 0, 0, 0};
-            sub[i >> 5] = 1u << (i & 31);
-            uint64_t br = 0;
-            for (int k = 0; k < 5; k++) {
-                const uint64_t d = (uint64_t)t.v[k] - sub[k] - br;
-                t.v[k] = (uint32_t)d;
-                br = (d >> 63) & 1;
-            }
-            part = t;
+    // sum accumulates in 5 x 32-bit limbs (160 bits); a = 2^i walks up as a 128-bit integer, b = 2^128 - 2^i is its negative mod 2^128.
+    // Pairs of bits are taken word by word (constant word indices), 16 pairs per word, 15 from the last one: no array is indexed at run time.
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    uint32_t a0 = 1, a1 = 0, a2 = 0, a3 = 0;
+    auto word = [&](uint32_t sw, uint32_t cw, const int w, const int pairs) {
+        for (int q = 0; q < pairs; q++) {
+            const int i = 16 * w + q;
+            const uint32_t clsb = cw & 1u, cmsb = (cw >> 1) & 1u, slsb = sw & 1u, smsb = (sw >> 1) & 1u;
+            cw >>= 2; sw >>= 2;
+            // part in {0, a, b}:
+            //  c=00: -b*m*l + b*m + b*l  -> b if (m|l) else 0
+            //  c=01: a*m*l - a*l + b*m - a*m + a -> m ? b : (l ? 0 : a)
+            //  c=10: b*m*l - a*m + a -> m ? (l ? b : 0) : a
+            //  c=11: -a*m*l + a -> (m&l) ? 0 : a
+            int sel;  // 0: zero, 1: a, 2: b
+            if (!cmsb && !clsb) sel = (smsb | slsb) ? 2 : 0;
+            else if (!cmsb && clsb) sel = smsb ? 2 : (slsb ? 0 : 1);
+            else if (cmsb && !clsb) sel = smsb ? (slsb ? 2 : 0) : 1;
+            else sel = (smsb & slsb) ? 0 : 1;
+            // b = 2^128 - a: the 128-bit negative of a (a > 0, so the fifth limb is 0)
+            const uint32_t n0 = 0u - a0, n1 = ~a1 + (a0 == 0), n2 = ~a2 + ((a0 | a1) == 0), n3 = ~a3 + ((a0 | a1 | a2) == 0);
+            Fc part = fc_zero();
+            part.v[0] = sel == 1 ? a0 : sel == 2 ? n0 : 0u;
+            part.v[1] = sel == 1 ? a1 : sel == 2 ? n1 : 0u;
+            part.v[2] = sel == 1 ? a2 : sel == 2 ? n2 : 0u;
+            part.v[3] = sel == 1 ? a3 : sel == 2 ? n3 : 0u;
+            io.put_c(off.parts + i, part);
+            uint64_t c = (uint64_t)s0 + part.v[0];
+            s0 = (uint32_t)c; c >>= 32;
+            c += (uint64_t)s1 + part.v[1]; s1 = (uint32_t)c; c >>= 32;
+            c += (uint64_t)s2 + part.v[2]; s2 = (uint32_t)c; c >>= 32;
+            c += (uint64_t)s3 + part.v[3]; s3 = (uint32_t)c; c >>= 32;
+            s4 += (uint32_t)c;
+            a3 = (a3 << 1) | (a2 >> 31); a2 = (a2 << 1) | (a1 >> 31); a1 = (a1 << 1) | (a0 >> 31); a0 <<= 1;
         }
-        io.put_c(off.parts + i, part);
-        uint64_t c = 0;
-        for (int k = 0; k < 5; k++) {
-            c += (uint64_t)sum[k] + part.v[k];
-            sum[k] = (uint32_t)c;
-            c >>= 32;
-        }
-    }
-    for (int i = 0; i < 135; i++) io.put_bit(off.bits + i, (sum[i >> 5] >> (i & 31)) & 1u);
-    return (sum[127 >> 5] >> (127 & 31)) & 1u;
+    };
+    word(bits.v[0], ct[0], 0, 16); word(bits.v[1], ct[1], 1, 16); word(bits.v[2], ct[2], 2, 16); word(bits.v[3], ct[3], 3, 16);
+    word(bits.v[4], ct[4], 4, 16); word(bits.v[5], ct[5], 5, 16); word(bits.v[6], ct[6], 6, 16); word(bits.v[7], ct[7], 7, 15);
+    put_word_bits_plain(io, off.bits, s0, 32);
+    put_word_bits_plain(io, off.bits + 32, s1, 32);
+    put_word_bits_plain(io, off.bits + 64, s2, 32);
+    put_word_bits_plain(io, off.bits + 96, s3, 32);
+    put_word_bits_plain(io, off.bits + 128, s4, 7);
+    return (s3 >> 31) & 1u;
 }
 
 __constant__ const uint32_t CT_MINUS1_D[8] = {0xf0000000u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
@@ -190,7 +224,7 @@ __constant__ const uint32_t CT_SUBORDER_M1_D[8] = {0x392126f0u, 0x677297dcu, 0x3
 
 // Num2Bits_strict: bits + AliasCheck
 __device__ __forceinline__ void num2bits_strict_dev(const UnitIO& io, const N2BStrictOff& off, const Fc& canon, int cid_alias) {
-    for (int i = 0; i < 254; i++) io.put_bit(off.bits + i, c_bit(canon, i));
+    put_bits(io, off.bits, canon, 254);
     const uint32_t o = comp_constant_dev(io, off.cc, canon, CT_MINUS1_D);
     if (o) report_fail(io.err, io.inst, io.err_unit, (uint32_t)cid_alias, fr_one(), fr_zero());
 }

@@ -127,6 +127,8 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
     const Fr fnc0 = sc.get(P.sc_fnc0), fnc1 = sc.get(P.sc_fnc1), isOld0 = sc.get(P.sc_isold0);
     const Fr enabled = fr_sub(fr_add(fnc0, fnc1), fr_mul(fnc0, fnc1));
     const Fc oldKey_c = fr_to_canon(sc.get(P.sc_oldkey)), newKey_c = fr_to_canon(sc.get(P.sc_newkey));
+    // the low 64 bits of the keys: the path bits of every level (n <= HZ_MAX_SMT_LEVELS < 64), read by shifts, never by indexing the key
+    const uint64_t keylo_old = (uint64_t)oldKey_c.v[0] | ((uint64_t)oldKey_c.v[1] << 32), keylo_new = (uint64_t)newKey_c.v[0] | ((uint64_t)newKey_c.v[1] << 32);
     const Fr h1old = sc.get(P.sc_leaf_old), h1new = sc.get(P.sc_leaf_new);
     // SMTLevIns: levIns[i] from the zero pattern of the siblings (both lanes need it)
     // isz[i] in {0,1}; done/levIns are 0/1 as well -> integer logic, exact for any input
@@ -164,17 +166,41 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
                 for (int k = 0; k < cnt; k++) { io.put_c(o.isz + 2 * (base + k), fc_zero()); io.put_bit(o.isz + 2 * (base + k) + 1, 1u); }
                 continue;
             }
-            Fr z[8], zi[8];
-            for (int k = 0; k < cnt; k++) { z[k] = io.in_m(P.siblings + base + k); zi[k] = z[k]; }
-            batch_inv<8>(zi, cnt);
-            for (int k = 0; k < cnt; k++) is_zero_dev(io, o.isz + 2 * (base + k), z[k], zi[k]);
+            // Montgomery's trick on the group without an array indexed at run time (such arrays live in scratch memory): the prefix
+            // products are pushed into a register array that ROTATES (constant indices only) and popped from the other end by the
+            // backward pass, which reads the siblings again (they are in the cache) rather than keeping eight of them beside the
+            // inversion's own state. One product body per loop: the loops stay rolled.
+            Fr pre[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) pre[q] = zero;
+            Fr acc = one;
+#pragma unroll 1
+            for (int k = 0; k < 8; k++) {
+                const Fr v = k < cnt ? io.in_m(P.siblings + base + (k < cnt ? k : 0)) : zero;
+#pragma unroll
+                for (int q = 0; q < 7; q++) pre[q] = pre[q + 1];
+                pre[7] = acc;
+                if (!fr_is_zero(v)) acc = fr_mul(acc, v);
+            }
+            Fr inv = fr_inv(acc);
+#pragma unroll 1
+            for (int k = 7; k >= 0; k--) {
+                if (k < cnt) {
+                    const Fr v = io.in_m(P.siblings + base + k);
+                    Fr vi = zero;
+                    if (!fr_is_zero(v)) { vi = fr_mul(inv, pre[7]); inv = fr_mul(inv, v); }
+                    is_zero_dev(io, o.isz + 2 * (base + k), v, vi);
+                }
+#pragma unroll
+                for (int q = 7; q > 0; q--) pre[q] = pre[q - 1];
+            }
         }
         // (isZero[n-1].out - 1) * enabled === 0
         if (!((zmask >> (n - 1)) & 1)) io.chk_zero(P.cid_levins, fr_neg(enabled));
         for (int k = 1; k <= n - 2; k++) io.put_bit(o.levIns + (k - 1), (uint32_t)((levmask >> k) & 1));
     } else {
         num2bits_strict_dev(io, o.n2bNew, newKey_c, P.cid_alias_new);
-        for (int k = 0; k < n; k++) io.put_bit(o.xors + k, c_bit(oldKey_c, k) ^ c_bit(newKey_c, k));
+        for (int k = 0; k < n; k++) io.put_bit(o.xors + k, (uint32_t)(((keylo_old ^ keylo_new) >> k) & 1));
     }
     // State machine (smtprocessorsm.circom). levIns is one-hot (integer logic above) and the xor bits
     // are integers, so every per-level state is one of a few field values selected by the level's
@@ -184,7 +210,6 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
     //   k == kl : aux1 = E, aux2 = E*fnc0, old0 = aux2*isOld0, upd = E - aux2, m = aux2 - old0 -> new1 or bot
     //   k >  kl : bot = m until kx, new1 = m at kx, 0 afterwards
     // fnc0 / fnc1 / isOld0 may be arbitrary field elements in a standalone RollupTx: field arithmetic.
-    const uint64_t keylo_old = (uint64_t)oldKey_c.v[0] | ((uint64_t)oldKey_c.v[1] << 32), keylo_new = (uint64_t)newKey_c.v[0] | ((uint64_t)newKey_c.v[1] << 32);
     const uint64_t xmask = (keylo_old ^ keylo_new) & ((1ull << n) - 1);   // n <= HZ_MAX_SMT_LEVELS < 64
     const int kl = __builtin_ctzll(levmask);
     const uint64_t xabove = xmask >> kl;
@@ -214,12 +239,12 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
         Fr p_na = fr_sub(one, enabled), p_new1 = zero, p_old0 = zero, p_upd = zero;
         Fr last_sum = zero;
         for (int k = 0; k < n; k++) {
-            const Fr aux1 = k == kl ? enabled : zero;
-            const Fr aux2 = k == kl ? A2 : zero;
-            const Fr t_old0 = k == kl ? O : zero;
-            const Fr t_upd = k == kl ? U : zero;
-            const Fr t_new1 = k == kx ? m : zero;
-            const Fr t_bot = (k >= kl && k < kx) ? m : zero;
+            const Fr aux1 = fr_select(k == kl, enabled, zero);   // (selects of values: a ?: on two lvalues selects an ADDRESS and sends both to scratch)
+            const Fr aux2 = fr_select(k == kl, A2, zero);
+            const Fr t_old0 = fr_select(k == kl, O, zero);
+            const Fr t_upd = fr_select(k == kl, U, zero);
+            const Fr t_new1 = fr_select(k == kx, m, zero);
+            const Fr t_bot = fr_select(k >= kl && k < kx, m, zero);
             const Fr t_na = fr_add(fr_add(fr_add(p_new1, p_old0), p_na), p_upd);
             const uint32_t b = o.sm + SM_N * k;
             if (thr_wave > 0 && (uint32_t)k > thr_wave) {
@@ -252,27 +277,28 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
             }
             continue;   // child stays zero
         }
-        const uint32_t sel = c_bit(newKey_c, k);
+        const uint32_t sel = (uint32_t)((keylo_new >> k) & 1);
         const Fr sib = io.in_m(P.siblings + k);
         Fr hin[2];
         Fr s_tb = zero, s_n1 = zero;
         if (!new_side) {
             // oldSwitcher(L = oldChild, R = sibling, sel); aux = (R-L)*sel
-            const Fr aux = sel ? fr_sub(sib, child) : zero;
+            const Fr aux = fr_select(sel != 0, fr_sub(sib, child), zero);
             io.put_m(lv + LV_OLDSW_AUX, aux);
-            hin[0] = sel ? sib : child;
-            hin[1] = sel ? child : sib;
+            hin[0] = fr_select(sel != 0, sib, child);
+            hin[1] = fr_select(sel != 0, child, sib);
         } else {
             // st_top + st_bot ; st_new1 ; st_old0 + st_upd ; st_top
-            s_tb = k < kl ? enabled : k < kx ? m : zero;
-            s_n1 = k == kx ? m : zero;
+            s_tb = fr_select(k < kl, enabled, fr_select(k < kx, m, zero));
+            s_n1 = fr_select(k == kx, m, zero);
             const Fr aux1 = fr_mul(child, s_tb);
             const Fr swL = fr_add(aux1, fr_mul(h1new, s_n1));
-            const Fr aux2 = k < kl ? fr_mul(sib, enabled) : zero;
+            Fr aux2 = zero;
+            if (k < kl) aux2 = fr_mul(sib, enabled);
             const Fr swR = fr_add(aux2, fr_mul(h1old, s_n1));
-            const Fr aux = sel ? fr_sub(swR, swL) : zero;
-            hin[0] = sel ? swR : swL;
-            hin[1] = sel ? swL : swR;
+            const Fr aux = fr_select(sel != 0, fr_sub(swR, swL), zero);
+            hin[0] = fr_select(sel != 0, swR, swL);
+            hin[1] = fr_select(sel != 0, swL, swR);
             io.put_m(lv + LV_NEWSW_AUX, aux); io.put_m(lv + LV_AUX1, aux1); io.put_m(lv + LV_AUX2, aux2);
             io.put_m(lv + LV_NEWSW_L, swL); io.put_m(lv + LV_NEWSW_R, swR);
         }
@@ -297,7 +323,7 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
         }
         if (!new_side) {
             // st_bot + st_new1 + st_upd ; st_top
-            const Fr s_a = k < kl ? zero : k == kl ? mU : k <= kx ? m : zero;
+            const Fr s_a = fr_select(k < kl, zero, fr_select(k == kl, mU, fr_select(k <= kx, m, zero)));
             const Fr aux0 = fr_mul(h1old, s_a);
             const Fr root = k < kl ? fr_add(aux0, fr_mul(h, enabled)) : aux0;
             io.put_m(lv + LV_AUX0, aux0); io.put_m(lv + LV_OLDROOT, root);

@@ -1,0 +1,41 @@
+"""Scratch memory on the kernels that carry the step: the build leaves the compiler's resource remarks per
+object (circuits_amd/csrc/Makefile); k_smt and k_hash4 -- 70 % of a step's instructions -- must not touch scratch at all (an array
+indexed at run time, a struct passed by reference to an out-of-line function, a ?: on two lvalues: each silently moves registers to
+memory), every timed kernel must stay within its recorded budget."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import resource_usage as RU   # noqa: E402
+
+# bytes of scratch per lane each timed kernel may use (the state when the budget was last lowered; lower it when a kernel improves)
+BUDGET = {"hz::k_smt": 0, "hz::k_hash4": 0, "hz::k_main_front": 7952, "hz::k_eddsa_pre": 2400, "hz::k_eddsa_seg<4>": 1664, "hz::k_eddsa_fix<8>": 3968,
+          "hz::k_rtx_back": 192, "hz::k_sha_expand": 272, "hz::k_sha_chain": 272, "hz::k_withdraw": 2048, "hz::k_withdraw_sha": 448,
+          "hz::poseidon_batch_kernel<3, true>": 0, "hz::poseidon_batch_kernel<5, true>": 0, "hzexp::k_export_stored": 0}
+
+
+def _rows():
+    files = [os.path.join(RU.BUILD, f) for f in os.listdir(RU.BUILD) if f.endswith(".ru.txt")] if os.path.isdir(RU.BUILD) else []
+    if not files:
+        pytest.skip("the library was not built in this tree (no build/*.ru.txt)")
+    return {r["name"]: r for r in RU.table(files)}
+
+
+def test_no_scratch_on_the_hash_chain_kernels():
+    rows = _rows()
+    for k in ("hz::k_smt", "hz::k_hash4"):
+        assert k in rows, sorted(rows)[:10]
+        assert rows[k]["scratch"] == 0, "%s uses %d bytes of scratch per lane" % (k, rows[k]["scratch"])
+        assert rows[k]["occupancy"] >= 2 and rows[k]["vgprs"] <= 256
+
+
+def test_timed_kernels_within_their_scratch_budget():
+    rows = _rows()
+    over = {k: (rows[k]["scratch"], b) for k, b in BUDGET.items() if k in rows and rows[k]["scratch"] > b}
+    missing = [k for k in BUDGET if k not in rows]
+    assert not missing, missing
+    assert not over, over
