@@ -525,7 +525,11 @@ uint64_t resolve_name(const hz_ctx* ctx, hz_symmap* m, const std::string& name_i
             m->derived.push_back(d);
             return m->memo[name] = DERIVED_FLAG | (m->derived.size() - 1);
         }
-        if (hz_symbol_lookup(ctx, (comp + ".out[0]").c_str(), &out)) {   // Num2Bits: in = sum 2^k out[k] over the stored bits
+        // Num2Bits: in = sum 2^k out[k] over the stored bits. Only when the layout stores the component's bits from bit 0 as ONE run of
+        // consecutive signals (a slice of a wider decomposition, or another template with an `in` and an `out[]`, must not be summed: the
+        // variable then stays unresolved for the .r1cs solver / the report; hz_symmap_check_r1cs is the backstop either way)
+        uint64_t out1 = 0;
+        if (hz_symbol_lookup(ctx, (comp + ".out[0]").c_str(), &out) && (!hz_symbol_lookup(ctx, (comp + ".out[1]").c_str(), &out1) || out1 > out)) {
             LinForm lf;
             lf.c0 = hzh::f_zero();
             F w = hzh::f_one();
@@ -866,6 +870,9 @@ void solve_linear(hz_symmap* m) {
         const size_t k = m->derived.size() - 1;
         is_const.resize(k + 1, 0); const_val.resize(k + 1);
         DerivedVar& d = m->derived[k];
+        // only what this solver defined: a plain wire may alias the variable to an entry of the .sym phase (a Poseidon or IsZero record,
+        // which own no linear forms), or to one that was folded already
+        if ((d.kind != DV_LINEAR && d.kind != DV_PRODUCT && d.kind != DV_QUOTIENT) || is_const[k] || (size_t)d.lin + (d.kind == DV_LINEAR ? 1u : 3u) != m->lins.size()) return;
         const uint32_t nf = d.kind == DV_LINEAR ? 1u : 3u;
         F v[3];
         for (uint32_t f = 0; f < nf; f++) {

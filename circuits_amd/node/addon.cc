@@ -742,6 +742,7 @@ struct StepWork {
     size_t each, stride;
     int32_t first, count;
     bool had_prev;
+    bool issued = false;    // the next step was enqueued (not when the previous one was rejected)
     hz_status st;
     hz_error err;
     std::string msg;
@@ -755,7 +756,11 @@ static void step_execute(napi_env, void* data) {
         w->st = api.witness_check(w->ctx, &w->err);
         if (w->st != HZ_OK && w->st != HZ_ERR_CONSTRAINT) { w->msg = api.last_error(); return; }
         w->checked = w->node->enq;   // one work item per circuit at a time (index.js): nobody else moves the counter
+        // a rejected step ends the pipeline here: the next enqueue would reset the failure record, and failures() -- every
+        // instance's first violated constraint -- is for exactly this moment. Nothing is enqueued, nothing staged.
+        if (w->st == HZ_ERR_CONSTRAINT) return;
     }
+    w->issued = true;
     hz_status e = api.witness_enqueue(w->ctx, nullptr);
     if (e == HZ_OK) w->node->enq++;
     w->staged_at = w->node->enq;
@@ -766,7 +771,8 @@ static void step_complete(napi_env env, napi_status, void* data) {
     StepWork* w = (StepWork*)data;
     napi_value result;
     release_held(env, w->node, w->checked);
-    if (w->keep) w->node->held.push_back({w->keep, w->staged_at});   // released when the step that consumes the copy has been checked
+    if (w->keep && w->issued) w->node->held.push_back({w->keep, w->staged_at});   // released when the step that consumes the copy has been checked
+    else if (w->keep) napi_delete_reference(env, w->keep);                          // nothing was staged from it
     if (w->st == HZ_OK) {
         napi_get_null(env, &result);
         napi_resolve_deferred(env, w->deferred, result);

@@ -219,13 +219,15 @@ class Circuit {
     }
     /** One iteration of a serving loop in one hop to the thread pool: check the previous step of this circuit (if one is in flight),
      *  enqueue the next, stage the inputs of the one after from `buf` (omit buf: nothing staged). Resolves when the enqueue has
-     *  been issued; rejects if the PREVIOUS step violated a constraint. Finish a loop with check(). */
+     *  been issued; rejects if the PREVIOUS step violated a constraint -- and then enqueues and stages NOTHING, so that failures()
+     *  still describes the rejected launch; call step() again to go on. Finish a loop with check(). */
     async step(buf, byteOffset, first, count, stride, sanityCheck) {
         const hadPrev = !!this._inFlight;
         const work = addon.step(this.handle, buf || null, byteOffset === undefined ? 0 : byteOffset, first === undefined ? 0 : first, buf ? (count === undefined ? 0 : count) : 0,
                                 stride === undefined || stride === 0 ? this.packedLayout().bytes : stride, hadPrev);   // bad arguments throw here: nothing enqueued
         this._inFlight = true;
         const fail = await work;
+        if (fail) this._inFlight = false;   // a rejected step is not followed: nothing was enqueued or staged, failures() can be asked now
         if (fail && wantsSanityCheck(sanityCheck)) throw constraintError(fail);
     }
     /** check() on the calling thread: blocks the event loop until the step is done (command-line tools, measurements) */

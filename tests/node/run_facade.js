@@ -146,8 +146,11 @@ async function main() {
         nb.fromBjjCompressed[1][5] = 2;
         circuit.packInput(nb, pin, 0);
         circuit.packInput(many[2].input, pin, 2 * lay.bytes);
-        await circuit.step(pin, 0, 0, many.length, lay.bytes, false);    // (the step in flight failed: not asserted here) stage instance 0 with the bad bit
-        await circuit.step(null, 0, 0, 0, 0, false);
+        await circuit.step(pin, 0, 0, many.length, lay.bytes, false);    // enqueues on the inputs of the case before (two bad batches), stages the bad bit
+        await circuit.step(null, 0, 0, 0, 0, false);                     // that step is rejected: nothing is enqueued behind it ...
+        const again = await circuit.failures();                          // ... so the per-instance report of the pipelined loop is still there
+        assert.deepStrictEqual(again.map((f) => f.instance), [0, 2]);
+        await circuit.step(null, 0, 0, 0, 0, false);                     // and the loop goes on: enqueues on the staged inputs
         await assert.rejects(circuit.check(true), (e) => /fromBjjCompressed boolean/.test(e.message) && e.constraint.instance === 0 && e.constraint.unit === 1 && /2 != 0/.test(e.message));
         nb.fromBjjCompressed[1][5] = 256;
         assert.throws(() => circuit.packInput(nb, pin, 0), RangeError);
