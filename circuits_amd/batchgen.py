@@ -46,7 +46,7 @@ def build_packed_batches(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, lay
         return pool.map(_one, tasks, chunksize=1)
 
 
-def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, lib, device, out_addr, base=None):
+def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, lib, device, out_addr, base=None, native_recipe=True):
     """one batch per seed, written to out_addr + i * layout[0] (pinned host memory): [(None, expected hashGlobalInputs, signed L2
     transactions)] plus the builder's counters. n_accounts must be a power of two >= 16 unless a shared `base` (DenseState) is given."""
     from circuits_amd import builder as B
@@ -56,12 +56,13 @@ def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accoun
     import time
     # state_s: the pre-populated state of each seed (DenseState, not part of building a batch); batch_s: everything from the first
     # add_tx to the packed inputs (Python transaction recipe + hzb_batch_build: walk, signing, hashing, packing)
-    res, stats = [], {"jobs": 0, "segments": 0, "device_ms": 0.0, "walk_s": 0.0, "eval_s": 0.0, "state_s": 0.0, "batch_s": 0.0}
+    res, stats = [], {"jobs": 0, "segments": 0, "device_ms": 0.0, "walk_s": 0.0, "eval_s": 0.0, "sign_s": 0.0, "state_s": 0.0, "batch_s": 0.0}
     for i, seed in enumerate(seeds):
         t0 = time.perf_counter()
         b = base if base is not None else B.DenseState.build(n_accounts.bit_length() - 1, seed=seed, hash_rows=hash_rows)
         t1 = time.perf_counter()
-        bb, _, hgi = NB.synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, tables, seed=seed, device=device, base=b, out=out_addr + i * layout[0])
+        bb, _, hgi = NB.synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, tables, seed=seed, device=device, base=b, out=out_addr + i * layout[0],
+                                               native_recipe=native_recipe)
         stats["state_s"] += t1 - t0
         stats["batch_s"] += time.perf_counter() - t1
         for k, v in bb.stats().items():

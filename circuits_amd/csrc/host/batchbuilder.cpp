@@ -497,7 +497,7 @@ struct hzb_batch {
     U256 new_state_root = u_zero(), new_exit_root = u_zero();
     uint64_t new_last_idx = 0;
     uint64_t jobs = 0, segments = 0;
-    double device_ms = 0.0, walk_s = 0.0, eval_s = 0.0;
+    double device_ms = 0.0, walk_s = 0.0, eval_s = 0.0, sign_s = 0.0;
     ~hzb_batch() { delete exit_tree; }
 };
 
@@ -623,6 +623,7 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
     struct PendingSig { size_t tx; U256 msg, r; Pt r8; const Signer* signer; Val hm; };
     std::vector<PendingSig> sigs;
     double msg_eval_s = 0.0;
+    const double t_sig0 = now_s();
     {
         Dag mdag;
         mdag.fn = dag.fn;
@@ -661,6 +662,7 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
             ps.hm = dag.poseidon(in, 5);   // evaluated with the batch's Merkle hashes
         }
     }
+    bb->sign_s = now_s() - t_sig0;   // messages (one Poseidon(7) each, evaluated), deterministic nonces, R8 = r * Base8 of all of them
     std::vector<int> sig_of((size_t)nTx, -1);
     for (size_t q = 0; q < sigs.size(); q++) sig_of[sigs[q].tx] = (int)q;
 
@@ -1069,6 +1071,146 @@ int hzb_batch_add_txs(hzb_batch* b, const hzb_tx* txs, uint64_t n) {
         if (int st = hzb_batch_add_tx(b, txs + i)) return st;   // the ones before it stay added, as with single calls
     return 0;
 }
+// ---- the synthetic benchmark batch, end to end in this library ----------------------------------------------------------------------------
+// The recipe of the reference's generator (tools/generate-input.js:61-109, tools/helpers/gen-inputs-utils.js:6-71): maxL1Tx
+// createAccountDeposits of a random key with a random float40 load amount, then signed L2 transfers of 20 % of the sender's balance
+// between random accounts of the pre-populated state (the first `exits` of them exits), userFee 176, one fee token and one fee
+// receiver. circuits_amd/native_builder.py states the same recipe in Python on Python's own generator; here it runs on a bit-exact
+// MT19937 + randrange, so both produce the same transactions and hence byte-identical circuit inputs (tests/test_native_builder.py).
+namespace {
+struct PyRandom {   // CPython's random.Random(seed) for a non-negative integer seed: init_by_array over its 32-bit words
+    uint32_t mt[624];
+    int idx = 624;
+    explicit PyRandom(uint64_t seed) {
+        uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        const int klen = key[1] ? 2 : 1;
+        mt[0] = 19650218u;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        int i = 1, j = 0;
+        for (int k = 624 > klen ? 624 : klen; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (++j >= klen) j = 0;
+        }
+        for (int k = 623; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; k++) {
+                const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+    U256 getrandbits(int k) {   // k <= 256: 32-bit words, least significant first, the last one shifted down
+        U256 r = u_zero();
+        for (int w = 0; k > 0; w++, k -= 32) {
+            uint32_t x = next();
+            if (k < 32) x >>= (32 - k);
+            r.w[w >> 1] |= (uint64_t)x << (32 * (w & 1));
+        }
+        return r;
+    }
+    static int bit_length(const U256& n) {
+        for (int i = 255; i >= 0; i--)
+            if (u_bit(n, (unsigned)i)) return i + 1;
+        return 0;
+    }
+    U256 randbelow(const U256& n) {   // random.randrange(n): rejection on getrandbits(n.bit_length())
+        const int k = bit_length(n);
+        U256 r = getrandbits(k);
+        while (u_cmp(r, n) >= 0) r = getrandbits(k);
+        return r;
+    }
+    uint64_t randbelow64(uint64_t n) { return randbelow(u_from64(n)).w[0]; }
+};
+U256 u_div_small(const U256& a, uint64_t d, uint64_t* rem = nullptr) {
+    U256 q;
+    unsigned __int128 r = 0;
+    for (int i = 3; i >= 0; i--) {
+        const unsigned __int128 cur = (r << 64) | a.w[i];
+        q.w[i] = (uint64_t)(cur / d);
+        r = cur % d;
+    }
+    if (rem) *rem = (uint64_t)r;
+    return q;
+}
+uint64_t floor_fix2float(const U256& v) {   // the largest float40 not above v (builder.py floor_fix2float)
+    if (u_is_zero(v)) return 0;
+    U256 m = v;
+    for (uint64_t e = 0; e < 32; e++) {
+        if (!(m.w[1] | m.w[2] | m.w[3]) && m.w[0] < (1ull << 35)) return m.w[0] + (e << 35);
+        m = u_div_small(m, 10);
+    }
+    return 0;
+}
+}  // namespace
+
+int hzb_batch_add_synthetic(hzb_batch* b, uint64_t seed, int32_t exits, int32_t n_keys, const uint8_t* l1_bjj_compressed, const uint8_t* l1_eth_addr,
+                            int32_t n_signers, const uint8_t* signer_keys) {
+    if (!b || !l1_bjj_compressed || !l1_eth_addr || !signer_keys || n_keys < 1 || n_signers < 1) return fail(HZB_ERR_ARG, "hzb_batch_add_synthetic: null argument");
+    hzb_db* db = b->db;
+    if (!db->base.present() || !b->txs.empty()) return fail(HZB_ERR_ARG, "hzb_batch_add_synthetic: needs an empty batch on a database with a pre-populated state (hzb_db_set_base)");
+    const Base& base = db->base;
+    PyRandom rng(seed);
+    const int n_tx = b->nTx, n_l1 = b->maxL1 < n_tx ? b->maxL1 : n_tx;
+    const U256 two96 = u_shl(u_from64(1), 96);
+    b->txs.reserve((size_t)n_tx);
+    for (int i = 0; i < n_l1; i++) {
+        Tx t;
+        memset(&t.c, 0, sizeof t.c);
+        const uint64_t q = rng.randbelow64((uint64_t)n_keys);
+        t.c.load_amount_f = floor_fix2float(rng.randbelow(two96));
+        t.c.on_chain = 1;
+        t.c.token_id = 1;
+        memcpy(t.c.from_bjj_compressed, l1_bjj_compressed + 32 * q, 32);
+        memcpy(t.c.from_eth_addr, l1_eth_addr + 32 * q, 32);
+        b->txs.push_back(t);
+    }
+    struct Acc { U256 bal; uint64_t nonce; };
+    std::unordered_map<uint64_t, Acc> tmp;
+    auto pick = [&]() { return base.first_idx + rng.randbelow64(base.N); };
+    auto account = [&](uint64_t idx) -> Acc {
+        auto it = tmp.find(idx);
+        if (it != tmp.end()) return it->second;
+        const Leaf l = db->leaf(idx);
+        return Acc{l.balance, l.nonce};
+    };
+    for (int t = 0; t < n_tx - n_l1; t++) {
+        const uint64_t frm = pick(), to = pick();
+        const Acc a = account(frm);
+        const uint64_t amount_f = floor_fix2float(u_div_small(u_mul(a.bal, u_from64(20)), 100));
+        const U256 amount = float40_to_fix(amount_f);
+        const bool is_exit = t < exits;
+        Tx x;
+        memset(&x.c, 0, sizeof x.c);
+        x.c.from_idx = frm; x.c.to_idx = is_exit ? 1 : to; x.c.amount_f = amount_f; x.c.nonce = a.nonce;
+        x.c.user_fee = 176; x.c.token_id = 1; x.c.flags = HZB_TX_HAS_NONCE | HZB_TX_HAS_SIGNER;
+        const uint64_t ki = base.key_idx[frm - base.first_idx];
+        if ((int64_t)ki >= n_signers) return fail(HZB_ERR_ARG, "hzb_batch_add_synthetic: account " + std::to_string(frm) + " belongs to key " + std::to_string(ki) + " of " + std::to_string(n_signers));
+        memcpy(x.c.signer_key, signer_keys + 32 * ki, 32);
+        b->txs.push_back(x);
+        const U256 nb = u_sub(u_sub(a.bal, amount), compute_fee(amount, 176));
+        tmp[frm] = Acc{nb, a.nonce + 1};
+        if (!is_exit && to != frm) {
+            const Acc r = account(to);
+            tmp[to] = Acc{u_add(r.bal, amount), r.nonce};
+        } else if (!is_exit) {
+            tmp[frm] = Acc{u_add(nb, amount), a.nonce + 1};
+        }
+    }
+    if (int st = hzb_batch_add_token(b, 1)) return st;
+    return hzb_batch_add_fee_idx(b, pick());
+}
+
 int hzb_batch_add_token(hzb_batch* b, uint32_t token_id) {
     if (!b) return fail(HZB_ERR_ARG, "hzb_batch_add_token: null batch");
     if ((int)b->fee_tokens.size() >= b->F) return fail(HZB_ERR_REJECTED, "fee plan full");
@@ -1134,6 +1276,7 @@ int hzb_batch_tx_flags(const hzb_batch* b, int32_t i, int32_t* is_amount_nullifi
     if (is_amount_nullified) *is_amount_nullified = b->nullified[(size_t)i];
     return HZB_OK;
 }
+double hzb_batch_sign_s(const hzb_batch* b) { return b ? b->sign_s : 0.0; }
 int hzb_batch_stats(const hzb_batch* b, uint64_t* jobs, uint64_t* segments, double* device_ms, double* walk_s, double* eval_s) {
     if (!b) return fail(HZB_ERR_ARG, "hzb_batch_stats: null batch");
     if (jobs) *jobs = b->jobs;

@@ -80,6 +80,7 @@ def host_lib():
         c.hzb_batch_destroy.argtypes = [ctypes.c_void_p]
         c.hzb_batch_add_tx.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         c.hzb_batch_add_txs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        c.hzb_batch_add_synthetic.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p]
         c.hzb_batch_add_token.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         c.hzb_batch_add_fee_idx.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         c.hzb_batch_build.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
@@ -325,11 +326,13 @@ class NativeBatchBuilder:
         jobs, segs = ctypes.c_uint64(), ctypes.c_uint64()
         dms, walk, ev = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         _check(self.c.hzb_batch_stats(self.h, ctypes.byref(jobs), ctypes.byref(segs), ctypes.byref(dms), ctypes.byref(walk), ctypes.byref(ev)))
-        return {"jobs": jobs.value, "segments": segs.value, "device_ms": dms.value, "walk_s": walk.value, "eval_s": ev.value}
+        f = self.c.hzb_batch_sign_s
+        f.restype, f.argtypes = ctypes.c_double, [ctypes.c_void_p]
+        return {"jobs": jobs.value, "segments": segs.value, "device_ms": dms.value, "walk_s": walk.value, "eval_s": ev.value, "sign_s": f(self.h)}
 
 
 def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, first_idx=256,
-                           base=None, out=None):
+                           base=None, out=None, native_recipe=False):
     """builder.synthetic_batch's recipe (reference tools/generate-input.js:61-109) on the native builder: the same seeded
     transactions, hence the same circuit inputs byte for byte. Pre-population goes through a DenseState (built here when `base` is None
     and n_accounts is a power of two >= 16, as synthetic_batch(dense=True) does). Returns (batch, packed, hashGlobalInputs)."""
@@ -346,6 +349,16 @@ def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455
     bkeys = base.keys()
     bb = db.build_batch(n_tx, n_levels, max_l1, max_fee)
     n_l1 = min(max_l1, n_tx)
+    if native_recipe:
+        # the whole recipe below inside libhz_host.so (hzb_batch_add_synthetic: CPython's generator restated bit for bit): no Python per
+        # transaction between the seed and the packed inputs
+        l1b = b"".join(a.bjj_compressed.to_bytes(32, "little") for a in keys)
+        l1e = b"".join(a.eth_addr.to_bytes(32, "little") for a in keys)
+        sk = b"".join(a.k.to_bytes(32, "little") for a in bkeys)
+        _check(bb.c.hzb_batch_add_synthetic(bb.h, ctypes.c_uint64(seed), exits, n_keys, l1b, l1e, len(bkeys), sk))
+        packed, hgi = bb.build(layout, out)
+        bb._db_keep = db
+        return bb, packed, hgi
     # the transactions as columns of one hzb_tx array (one hzb_batch_add_txs call); 32-byte fields as rows of bytes
     col = {k: [0] * n_tx for k in ("from_idx", "to_idx", "amount_f", "load_amount_f", "nonce", "user_fee", "on_chain", "flags")}
     wide = {k: [_ZERO32] * n_tx for k in ("from_eth_addr", "from_bjj_compressed", "signer_key")}

@@ -82,6 +82,13 @@ hzb_batch* hzb_batch_create(hzb_db* db, int32_t n_tx, int32_t n_levels, int32_t 
 void hzb_batch_destroy(hzb_batch* b);
 int hzb_batch_add_tx(hzb_batch* b, const hzb_tx* tx);
 int hzb_batch_add_txs(hzb_batch* b, const hzb_tx* txs, uint64_t n);   /* n calls of hzb_batch_add_tx; stops at the first refusal */
+/* The synthetic benchmark batch of the reference's generator (tools/generate-input.js:61-109) into an empty batch on a database with
+ * a pre-populated state: maxL1Tx deposits of random ones of the n_keys L1 keys, signed transfers of 20 % of the sender's balance
+ * (the first `exits` of them exits), userFee 176, fee token 1, one fee receiver -- the transactions circuits_amd/native_builder.py
+ * synthetic_batch_native makes from the same seed (CPython's random.Random(seed) restated bit for bit). signer_keys[k] = private
+ * scalar of the state's owner key k (hzb_db_set_base key_idx). */
+int hzb_batch_add_synthetic(hzb_batch* b, uint64_t seed, int32_t exits, int32_t n_keys, const uint8_t* l1_bjj_compressed, const uint8_t* l1_eth_addr,
+                            int32_t n_signers, const uint8_t* signer_keys);
 int hzb_batch_add_token(hzb_batch* b, uint32_t token_id);
 int hzb_batch_add_fee_idx(hzb_batch* b, uint64_t idx);
 /* Walks the batch, hashes it, and writes the circuit inputs in the packed bulk-upload format of hz_inputs_upload: signal i of the
@@ -96,6 +103,9 @@ int hzb_batch_exit_proof(hzb_batch* b, uint64_t idx, hzb_leaf* leaf, uint8_t* si
 int hzb_batch_tx_flags(const hzb_batch* b, int32_t i, int32_t* is_amount_nullified);
 /* jobs hashed, DAG segments, device milliseconds (0 on the host path), seconds spent in the walk and in the evaluator */
 int hzb_batch_stats(const hzb_batch* b, uint64_t* jobs, uint64_t* segments, double* device_ms, double* walk_s, double* eval_s);
+/* seconds of the build spent SIGNING the transactions that carry a signer key (messages, nonces, R8): a wallet's work in production,
+ * the synthetic generator's here; part of walk_s + eval_s */
+double hzb_batch_sign_s(const hzb_batch* b);
 
 #ifdef __cplusplus
 }

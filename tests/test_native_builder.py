@@ -178,6 +178,14 @@ def test_native_builder_on_a_dense_state(shadow):
     assert packed == pack_inputs(layout, bb.get_input()) and hgi == bb.get_hash_inputs()
     st = nb.stats()
     assert st["jobs"] > 200 and st["segments"] >= 8
+    # ... and so does the recipe INSIDE the library (hzb_batch_add_synthetic: CPython's random.Random restated bit for bit -- the float40
+    # load amounts draw 97 bits, the picks 6, the keys 4), for several seeds, shapes and exit counts
+    for seed, shape, k, exits in ((12, (20, 16, 6, 2), 6, 3), (0x48455A32, (64, 16, 16, 4), 7, 0), (5, (33, 12, 40, 3), 5, 9), (2**32 + 17, (16, 10, 4, 2), 4, 2)):
+        bs = B.DenseState.build(k, seed=seed & 0xFFFF, first_idx=256)
+        lay = make_layout(shape[0], shape[1], shape[3])
+        _, p_py, h_py = NB.synthetic_batch_native(*shape, lay, seed=seed, base=bs, exits=exits)
+        _, p_nat, h_nat = NB.synthetic_batch_native(*shape, lay, seed=seed, base=bs, exits=exits, native_recipe=True)
+        assert p_nat == p_py and h_nat == h_py, (seed, shape)
     # new accounts beyond the dense range share residues with base leaves: the tree pushes base leaves down
     base = B.DenseState.build(4, seed=13, first_idx=256)
     bb = B.synthetic_batch(40, 12, 30, 2, seed=14, base=base)

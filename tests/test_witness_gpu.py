@@ -276,6 +276,42 @@ def test_withdraw_config5_at_size(hz):
     assert e.value.instance == n - 3 and e.value.name == "withdraw.smtVerify.checkRoot" and (e.value.lhs, e.value.rhs) == (1, 0)
 
 
+def test_withdraw_config5_two_to_the_twenty(hz):
+    """BASELINE config 5 at its LITERAL count: 2^20 Withdraw(32) witnesses in 16 launches of 2^16 instances, every instance of a launch a
+    different leaf of an exit tree of 2^16 leaves (the line bench.py reports as `withdraw`), the assignment of leaves to instances
+    different in every launch. Per launch a seeded sample of 260 instances -- 4 160 over the run -- is compared WHOLE with the oracle's
+    witness of the same inputs, every instance's public hash with the builder's hashlib value, and no constraint fails
+    (reference src/withdraw.circom:21-176)."""
+    import random
+    from circuits_amd import builder as B
+    n, launches, per = 1 << 16, 16, 260
+    fx = B.ExitTreeFixture(1 << 16, device=0)
+    idxs = sorted(fx.exit_leaves)
+    assert len(idxs) == n
+    g = hz.ctx("withdraw", nLevels=32, n_instances=n)
+    wl = g.witness_len()
+    names = [nm for nm, _ in g.input_names()]
+    ins = [B.withdraw_input(fx, leaf, 32) for leaf in idxs]
+    o = OracleCtx("withdraw", nLevels=32, n_instances=per)
+    rng = random.Random(520)
+    hsig = g.lookup("main.hashGlobalInputs")
+    for launch in range(launches):
+        rot = (launch * 4099 * 40503) % n
+        order = [(k * 40503 + rot) % n for k in range(n)]   # a permutation (40503 is odd): instance k withdraws leaf order[k]
+        for name in names:
+            g.set_input(name, [ins[j][0][name] for j in order], instance=-1)
+        g.run()
+        got = g.read_raw_bytes(hsig * n, n)
+        assert [int.from_bytes(got[32 * k:32 * k + 32], "little") for k in range(n)] == [ins[j][1] for j in order], "launch %d" % launch
+        sample = sorted(rng.sample(range(n), per))
+        for j, k in enumerate(sample):
+            for name in names:
+                o.set_input(name, ins[order[k]][0][name], instance=j)
+        assert o.run() is None
+        for j, k in enumerate(sample):
+            assert g.read_bytes(0, wl, k) == o.read_bytes(0, wl, j), "launch %d, instance %d" % (launch, k)
+
+
 def test_constraint_failures_match_oracle(hz, batch):
     from circuits_amd import ConstraintError
     inp = dict(batch.get_input())
