@@ -192,6 +192,20 @@ def measured_valu(kernel=None):
 VALU_CYCLES_PER_INST = 4.3
 
 
+def deep_valu(launch_ms, torch, local):
+    """the integer-issue side of k_smt on the deep state: SQ_INSTS_VALU of its transaction launch from the committed counter pass taken with
+    --accounts 2^20 (profiles/rNN_valu_counters_deep.json) against THIS run's launch time"""
+    d, src = _profile_json("valu_counters_deep.json")
+    try:
+        insts = float(d["kernels"]["k_smt"]["insts_valu_largest_grid_mean"])
+    except (KeyError, TypeError, ValueError):
+        return {}
+    props = torch.cuda.get_device_properties(local)
+    clock_hz = float(getattr(props, "clock_rate", 0) or 2400000) * 1e3
+    return {"insts_valu_per_launch": int(insts), "frac_valu": round(insts * VALU_CYCLES_PER_INST / (props.multi_processor_count * 4 * clock_hz * launch_ms * 1e-3), 5),
+            "valu_source": src}
+
+
 def poseidon_valu(kernel):
     """SQ_INSTS_VALU per launch of 2^20 permutations of one poseidon_batch_kernel instantiation (profiles/rNN_poseidon_valu.json), or None"""
     d, _ = _profile_json("poseidon_valu.json")
@@ -963,8 +977,8 @@ def main():
         L.host_free(dpin)
         deep = {"state_accounts": 1 << kk, "value": round(nTx * Bp * dsteps / ddt, 1), "unit": "tx-witnesses/s", "steps": dsteps, "ms_per_step": round(ddt / dsteps * 1e3, 3),
                 "distinct_batches": n_deep, "kernels_ms": {k: round(v[0], 3) for k, v in dacc.items()},
-                "k_smt": {"launch_ms": round(dacc["smt"][0], 3), "achieved_GBs": round(dacc["smt"][1] / (dacc["smt"][0] * 1e-3) / 1e9, 2),
-                          "frac": round(dacc["smt"][1] / (dacc["smt"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                "k_smt": dict({"launch_ms": round(dacc["smt"][0], 3), "achieved_GBs": round(dacc["smt"][1] / (dacc["smt"][0] * 1e-3) / 1e9, 2),
+                               "frac": round(dacc["smt"][1] / (dacc["smt"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}, **deep_valu(dacc["smt"][0], torch, local)),
                 "state_build_s": round(t_base, 1), "batch_build_s": round(t_deep, 1),
                 "note": "same step, same shape; the pre-populated state (builder.DenseState, hashed on the device) is shared by the batches, "
                         "each of which has its own L1 keys, transactions and signatures"}

@@ -673,6 +673,7 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
     memset(&nop_tx.c, 0, sizeof(nop_tx.c));
     std::vector<uint64_t> aux_to_v((size_t)nTx, 0);
 
+    const double t_loop0 = now_s();
     for (int i = 0; i < nTx; i++) {
         Tx& tx = (size_t)i < ordered.size() ? ordered[(size_t)i] : nop_tx;
         const bool on = tx.c.on_chain != 0;
@@ -904,9 +905,12 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
     const double t_walk = now_s();
     // every hash of the batch: nLevels + 3 segments
     std::vector<U256> out;
+    const double t_f0 = now_s();
     st = db->flush(&exit_tree, &out);
     if (st) return st;
+    const double t_f1 = now_s();
     o.resolve(out);
+    const double t_f2 = now_s();
     for (const PendingSig& ps : sigs) {
         const U256 s = sign_s(ps.r, out[(size_t)ps.hm.job], ps.signer->k);
         o.put(S_s, (uint64_t)ps.tx, s);
@@ -947,6 +951,9 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
         while (u_cmp(h, u_p()) >= 0) h = u_sub(h, u_p());
         u_to_bytes(h, hash_global_inputs);
     }
+    if (getenv("HZB_TIMING"))
+        fprintf(stderr, "hzb build: pre-walk+sign %.2f ms, walk loop %.2f, flush %.2f (evaluator %.2f), resolve %.2f, tail (S, public hash) %.2f\n", (t_loop0 - t_start) * 1e3,
+                (t_walk - t_loop0) * 1e3, (t_f1 - t_f0) * 1e3, (dag.eval_s - eval0 - msg_eval_s) * 1e3, (t_f2 - t_f1) * 1e3, (now_s() - t_f2) * 1e3);
     bb->built = true;
     bb->jobs = dag.total_jobs - jobs0;
     bb->segments = dag.total_segments - segs0;

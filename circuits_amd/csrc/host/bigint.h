@@ -77,14 +77,43 @@ static inline U256 u_pow10(unsigned e) {
 // float40: 35-bit mantissa, 5-bit decimal exponent (reference src/lib/decode-float.circom:14-60)
 static inline U256 float40_to_fix(uint64_t f) { return u_mul(u_from64(f & ((1ull << 35) - 1)), u_pow10((unsigned)(f >> 35) & 31)); }
 
-// x (n64 words, little endian) mod m (m < 2^255): binary long division, a few microseconds for 512 bits
+// x (n64 <= 10 words, little endian) mod m (m != 0): Knuth's algorithm D on 64-bit digits (a bit-serial version of this took 10 us per
+// 512-bit operand: two of them per signature were a quarter of a batch's build)
 static inline U256 u_mod_wide(const uint64_t* x, int n64, const U256& m) {
-    U256 r = u_zero();
-    for (int i = 64 * n64 - 1; i >= 0; i--) {
-        r = u_shl(r, 1);
-        r.w[0] |= (x[i >> 6] >> (i & 63)) & 1;
-        if (u_cmp(r, m) >= 0) r = u_sub(r, m);
+    typedef unsigned __int128 u128w;
+    int n = 4;
+    while (n > 1 && m.w[n - 1] == 0) n--;
+    const int s = __builtin_clzll(m.w[n - 1]);
+    uint64_t v[4] = {0, 0, 0, 0}, u[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = n - 1; i >= 0; i--) v[i] = s ? ((m.w[i] << s) | (i ? (m.w[i - 1] >> (64 - s)) : 0)) : m.w[i];
+    u[n64] = s ? (x[n64 - 1] >> (64 - s)) : 0;
+    for (int i = n64 - 1; i >= 0; i--) u[i] = s ? ((x[i] << s) | (i ? (x[i - 1] >> (64 - s)) : 0)) : x[i];
+    for (int j = n64 - n; j >= 0; j--) {
+        u128w num = ((u128w)u[j + n] << 64) | u[j + n - 1];
+        u128w qhat = num / v[n - 1], rhat = num % v[n - 1];
+        while (qhat >> 64 || (n > 1 && qhat * v[n - 2] > ((rhat << 64) | u[j + n - 2]))) {
+            qhat--; rhat += v[n - 1];
+            if (rhat >> 64) break;
+        }
+        // u[j .. j+n] -= qhat * v
+        u128w borrow = 0, carry = 0;
+        for (int i = 0; i < n; i++) {
+            const u128w p = qhat * v[i] + carry;
+            carry = p >> 64;
+            const u128w d = (u128w)u[i + j] - (uint64_t)p - borrow;
+            u[i + j] = (uint64_t)d;
+            borrow = (d >> 64) & 1;
+        }
+        const u128w d = (u128w)u[j + n] - carry - borrow;
+        u[j + n] = (uint64_t)d;
+        if ((d >> 64) & 1) {   // qhat was one too large: add the divisor back
+            u128w c = 0;
+            for (int i = 0; i < n; i++) { c += (u128w)u[i + j] + v[i]; u[i + j] = (uint64_t)c; c >>= 64; }
+            u[j + n] += (uint64_t)c;
+        }
     }
+    U256 r = u_zero();
+    for (int i = 0; i < n; i++) r.w[i] = s ? ((u[i] >> s) | ((i + 1 < n ? u[i + 1] : 0) << (64 - s))) : u[i];   // the remainder, shifted back
     return r;
 }
 static inline void u_mul_wide(const U256& a, const U256& b, uint64_t* out8) {   // full 512-bit product

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-ARGS="--steps 4 --warmup 1 --cpu-sample 0 --no-e2e --no-deep-state --no-sweep --distinct-batches 4"
+ARGS="--steps 4 --warmup 1 --cpu-sample 0 --no-e2e --no-deep-state --no-sweep --no-export --distinct-batches 4"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o run -- python bench.py $ARGS --calibrate-copy > $OUT/bench_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o run -- python bench.py $ARGS --calibrate-copy > $OUT/bench_write.log 2>&1

@@ -3,6 +3,7 @@
 # FETCH_SIZE / WRITE_SIZE / VALU counter passes of the same command (separate --pmc passes), a kernel Gantt of the timed region, the
 # microbenchmarks behind DESIGN.md 3 and the overlap / power probes. Outputs under gpurun_out/round/.
 cd /tmp && export TMPDIR=/tmp
+export HZ_ROUND=5
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/round; rm -rf $OUT; mkdir -p $OUT
 cd $R
@@ -12,6 +13,10 @@ bash tools/profile.sh > $OUT/profile.log 2>&1
 cp gpurun_out/prof/kernel_stats.csv gpurun_out/prof/hbm_counters.csv gpurun_out/prof/hbm_counters.json $OUT/ 2>/dev/null
 bash tools/gpu_suite.sh pmc --no-e2e --no-deep-state --no-withdraw --no-poseidon --distinct-batches 4 > $OUT/pmc.log 2>&1
 cp gpurun_out/pmc/valu_summary.csv $OUT/valu_counters.csv 2>/dev/null; cp gpurun_out/pmc/valu_counters.json $OUT/valu_counters.json 2>/dev/null
+# the same pass on a DEEP state (2^20 accounts: every level of every proof hashes): deep_state.k_smt.frac_valu of the bench line
+PMC_TIMEOUT=400 bash tools/gpu_suite.sh pmc --no-e2e --no-deep-state --no-withdraw --no-poseidon --distinct-batches 4 --accounts 1048576 > $OUT/pmc_deep.log 2>&1
+cp gpurun_out/pmc/valu_counters.json $OUT/valu_counters_deep.json 2>/dev/null
+python tools/resource_usage.py > $OUT/resource_usage.txt 2>&1
 TL_OUT=round_tl bash tools/gpu_suite.sh timeline --no-withdraw --no-e2e --no-deep-state --no-sweep --distinct-batches 4 > $OUT/timeline.log 2>&1
 f=$(find gpurun_out/round_tl -name "*kernel_trace.csv" | head -1)
 if [ -n "$f" ]; then
