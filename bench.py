@@ -989,7 +989,7 @@ def main():
     # two contexts in flight, up to the headline's own point; (iii) what binds at each point.
     sweep, single = None, None
     if world == 1 and not args.no_sweep:
-        def small(bp, nctx, flags, steps):
+        def small(bp, nctx, flags, steps, kernels=None):
             cs = [L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=bp, flags=flags) for _ in range(nctx)]
             for k, cc in enumerate(cs):
                 for b in range(bp):
@@ -1013,11 +1013,23 @@ def main():
                         cs[k].check()
             go(nctx)
             t = D.timed(lambda: go(steps))
+            if kernels is not None:   # each kernel of this shape alone on the device: which chains set the latency
+                cs[0].set_profiling(True, exclusive=True)
+                for _ in range(2):
+                    cs[0].enqueue(streams[0].cuda_stream)
+                    cs[0].check()
+                    for name, ms, _by, _units in cs[0].profile():
+                        kernels[name] = round(kernels.get(name, 0.0) + ms / 2, 3)
+                cs[0].set_profiling(False)
             del cs
             return t / steps
         single = {}
+        single_kernels = {}
         for key, flags in (("default", 0), ("latency_flag", 2)):
-            single[key] = round(small(1, 1, flags, 6) * 1e3, 3)
+            single[key] = round(small(1, 1, flags, 6, single_kernels if flags == 2 else None) * 1e3, 3)
+        single["kernels_ms_latency_flag"] = single_kernels
+        single["critical_chains"] = ("front -> eddsa (signature prologue + 148-step ladder) -> eddsa_final, and front -> hash4 -> smt (33 dependent level "
+                                     "hashes) -> rtx_back -> hash_inputs: each kernel is a few dozen wavefronts, its time is the length of its dependent chain")
         sweep = []
         for bp in (1, 2, 4, 8, 16):
             if bp >= Bp or 2 * per_batch_bytes(bp) * bp > free_b - (6 << 30):

@@ -2,7 +2,7 @@
 // `./circuit input.json witness.json` the reference runs at tools/helpers/actions.js:132-146 (and of
 // `snarkjs wtns calculate` for the .wtns output). Plain C++ over the C ABI of include/hermez_witness.h.
 //
-//   hz_witness "RollupMain(2048,32,256,64)" input.json witness.wtns [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--check]]] [--map circuit.hzmap] [--device 0]
+//   hz_witness "RollupMain(2048,32,256,64)" input.json witness.wtns [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--no-check]]] [--map circuit.hzmap] [--device 0]
 //   hz_witness path/to/main.circom input.json witness.json
 //
 // The first argument is `Template(params)` or a .circom file whose `component main = Template(params);` line is
@@ -13,7 +13,7 @@
 // name-based checks, NOT for the reference's prover. With --circom-sym <the .sym of the circom compile> the .wtns is written
 // in the compiler's variable order (name join, hz_symmap_create); it fails listing the variables this layout does not store.
 // With --circom-r1cs <the .r1cs of the same compile> the variables no name resolves -- the wire-through signals of a compile without
-// constraint reduction -- are solved from the circuit's linear constraints (hz_symmap_create_r1cs), and --check evaluates every
+// constraint reduction -- are solved from the circuit's linear constraints (hz_symmap_create_r1cs), and (unless --no-check) every
 // constraint of the .r1cs on the witness before it is written (what `snarkjs wtns check` does; exit status 1 when one fails).
 // --map <file>: the resolved map is kept there -- read when the file exists (the .sym / .r1cs are then not needed), written after an
 // import otherwise: the import of a full-size circuit takes minutes, the map loads in seconds.
@@ -111,25 +111,29 @@ static hz_status set_json_unsupported() {
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s \"Template(params)\"|main.circom input.json witness.{wtns,json} [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--check]]] [--map circuit.hzmap] [--device N]\n", argv[0]);
+        fprintf(stderr, "usage: %s \"Template(params)\"|main.circom input.json witness.{wtns,json} [--sym out.sym] [--circom-sym circuit.sym [--circom-r1cs circuit.r1cs [--no-check]]] [--map circuit.hzmap] [--device N]\n", argv[0]);
         return 2;
     }
     const char* sym = nullptr;
     const char* circom_sym = nullptr;
     const char* circom_r1cs = nullptr;
     const char* map_path = nullptr;
-    bool check = false;
+    bool check = false, no_check = false;
     int device = 0;
     for (int i = 4; i < argc; i++) {
         if (!strcmp(argv[i], "--sym") && i + 1 < argc) sym = argv[++i];
         else if (!strcmp(argv[i], "--circom-sym") && i + 1 < argc) circom_sym = argv[++i];
         else if (!strcmp(argv[i], "--circom-r1cs") && i + 1 < argc) circom_r1cs = argv[++i];
         else if (!strcmp(argv[i], "--check")) check = true;
+        else if (!strcmp(argv[i], "--no-check")) no_check = true;
         else if (!strcmp(argv[i], "--map") && i + 1 < argc) map_path = argv[++i];
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     if ((circom_r1cs && !circom_sym) || (check && !circom_r1cs)) { fprintf(stderr, "--circom-r1cs goes with --circom-sym, --check with --circom-r1cs\n"); return 2; }
+    // an .r1cs is checked unless the caller opts out: an imported numbering has only ever been exercised on files this repository made
+    // itself (no circom compiler offline), and a wrongly served variable must not reach a prover
+    if (circom_r1cs && !no_check) check = true;
     std::string spec = argv[1];
     bool ok;
     if (spec.find('(') == std::string::npos) {
