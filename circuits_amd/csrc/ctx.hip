@@ -16,6 +16,10 @@
 using namespace hz;
 using namespace hzl;
 
+#ifndef HZ_SMT_BG_MIN
+#define HZ_SMT_BG_MIN 16384u   // units per launch from which the empty levels' constant blocks go through k_smt_bg
+#endif
+
 struct hz_ctx {
     // optional per-kernel timing (HIP events on the launch stream)
     bool profiling = false;
@@ -67,6 +71,10 @@ struct hz_ctx {
     hipEvent_t ev_sha[9] = {};   // HashInputs: chain group g done (0..7), expansion done (8)
     hipStream_t s_fix = nullptr;   // the fixed-base half of the signature check
     hipStream_t s_sha = nullptr;   // SHA-256 expansion groups behind the chain when HashInputs runs early on the fee stream
+    // the constant blocks of the structurally empty SMT levels, stored by k_smt_bg beside the chain kernel (throughput-sized launches)
+    hipStream_t s_bg = nullptr;
+    hipEvent_t ev_bg = nullptr;
+    DevBuf bg_rows;                // rows k_smt_bg wrote in the last enqueue (2 KB each): the bytes k_smt is NOT responsible for
     hipEvent_t ev_hash4 = nullptr, ev_tail = nullptr;
     ~hz_ctx() {
         if (s_ed) (void)hipStreamDestroy(s_ed);
@@ -75,6 +83,8 @@ struct hz_ctx {
         if (s_fix) (void)hipStreamDestroy(s_fix);
         if (s_copy) (void)hipStreamDestroy(s_copy);
         if (s_sha) (void)hipStreamDestroy(s_sha);
+        if (s_bg) (void)hipStreamDestroy(s_bg);
+        if (ev_bg) (void)hipEventDestroy(ev_bg);
         for (hipEvent_t e : {ev_hash4, ev_tail})
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_staged, ev_unpacked})
@@ -228,6 +238,12 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         if (e == hipSuccess) e = make_stream(&c->s_fee, ncu * 3 / 8, ncu / 2);       // fee-transaction chain
         if (e == hipSuccess) e = make_stream(&c->s_main, ncu / 2, ncu);              // front, hash-state, SMT chains, HashInputs
         if (e == hipSuccess && lo.p.tmpl == T_ROLLUP_MAIN && !c->partitioned) e = make_stream(&c->s_sha, 0, 0);
+        if (e == hipSuccess && !c->partitioned && lo.sec_tx >= 0) {   // k_smt_bg (throughput-sized launches of the transaction section)
+            e = hipStreamCreateWithFlags(&c->s_bg, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bg, hipEventDisableTiming);
+            if (e == hipSuccess) e = c->bg_rows.alloc(sizeof(unsigned long long));
+            if (e == hipSuccess) e = hipMemset(c->bg_rows.p, 0, sizeof(unsigned long long));
+        }
         for (hipEvent_t* ev : {&c->ev_hash4, &c->ev_tail})
             if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     }
@@ -723,8 +739,25 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         HZ_HIP(launch_hi_prep_body(make_hi(c, true), st));
         HZ_HIP(hipEventRecord(c->ev_tail, st));
     }
+    // EXPERIMENT, off unless HZ_SMT_BG_ON is set (round 5, profiles/r05_ksmt_bg_writer.txt: measured, no-go). The constant blocks of the
+    // structurally empty levels leave through k_smt_bg -- a small persistent store-only grid on a stream of its own, enqueued before the
+    // chain kernel and dependent on the front kernel only (function bits, keys) -- and k_smt stores nothing for those levels: k_smt alone
+    // 20.3 -> 16.1 ms, the writer alone 7.0 ms (5.2 TB/s), and the STEP 1.4-5 % SLOWER whatever the grid (128 .. 1024 wavefronts), the
+    // stream priority or the enqueue order: bytes stored beside an integer-bound kernel are not free on this device, inside its
+    // instruction stream (BgZero) they nearly are. Bit-exact either way (tests/test_witness_gpu.py runs a launch with it on).
+    const uint32_t smt_count = ucnt ? ucnt : n_units;
+    const bool bg_ext = c->s_bg && !c->sharded && smt_count >= HZ_SMT_BG_MIN && getenv("HZ_SMT_BG_ON");
+    if (bg_ext) {
+        sa.bg_external = 1;
+        hipStream_t sb = c->exclusive ? s : c->s_bg;
+        HZ_HIP(hipMemsetAsync(c->bg_rows.p, 0, sizeof(unsigned long long), sb));
+        if (!c->exclusive) HZ_HIP(hipStreamWaitEvent(sb, c->ev_front, 0));
+        { ProfScope ps(c, sb, "smt_bg", n_units); HZ_HIP(launch_smt_bg(sa, (unsigned long long*)c->bg_rows.p, sb)); }
+        if (!c->exclusive) HZ_HIP(hipEventRecord(c->ev_bg, sb));
+    }
     HZ_HIP(enqueue_smt_chain(c, sa, "smt", s));
     { ProfScope ps(c, s, "rtx_back", n_units); HZ_HIP(launch_rtx_back(ba, s)); }
+    if (bg_ext && !c->exclusive) HZ_HIP(hipStreamWaitEvent(s, c->ev_bg, 0));
     return HZ_OK;   // the caller joins the signature stream (ev_ed) after whatever else it launches on `s`
 }
 
@@ -1180,7 +1213,19 @@ extern "C" hz_status hz_profile_get(hz_ctx* c, int32_t i, const char** kernel, f
     HZ_HIP(hipEventElapsedTime(&p.ms, p.e0, p.e1));
     if (kernel) *kernel = p.name.c_str();
     if (ms) *ms = p.ms;
-    if (algorithmic_bytes) *algorithmic_bytes = p.bytes;
+    uint64_t bytes = p.bytes;
+    if (c->bg_rows.p && (p.name == "smt" || p.name == "smt_bg")) {
+        // the constant blocks k_smt_bg stored this step (2 KB rows: 64 units x 32 B) are its algorithmic bytes, not k_smt's
+        bool used = false;
+        for (size_t k = 0; k < c->prof_used; k++) used = used || c->prof[k].name == "smt_bg";
+        if (used) {
+            unsigned long long rows = 0;
+            HZ_HIP(hipMemcpy(&rows, c->bg_rows.p, sizeof rows, hipMemcpyDeviceToHost));
+            const uint64_t bg = (uint64_t)rows * 2048ull;
+            bytes = p.name == "smt_bg" ? bg : (bytes > bg ? bytes - bg : 0);
+        }
+    }
+    if (algorithmic_bytes) *algorithmic_bytes = bytes;
     if (units) *units = p.units;
     return HZ_OK;
 }

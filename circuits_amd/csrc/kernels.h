@@ -96,6 +96,7 @@ struct SmtArgs {
     uint32_t n_proc;
     uint32_t upi;
     uint32_t skip_mod;            // != 0: units u with u % skip_mod == skip_mod - 1 belong to another launch of the step (early tail)
+    uint32_t bg_external;         // != 0: the constant blocks of the structurally empty levels are k_smt_bg's this step, not k_smt's
     SmtProcDesc p[2];
 };
 
@@ -203,6 +204,7 @@ hipError_t launch_fr_sqrt(const void* d_a, void* d_out, size_t n, hipStream_t s)
 hipError_t launch_ay_sign_2_ax_main(const GadgetArgs& a, const EddsaOff& o, hipStream_t s);   // eddsa_kernels.hip (shares the curve code)
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s);
+hipError_t launch_smt_bg(const SmtArgs& a, unsigned long long* rows_written, hipStream_t s);
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
 hipError_t launch_da_mask(const RtxBackArgs& a, hipStream_t s);   // RollupMain phase H alone (amount bits of L1L2TxData times 1 - isAmountNullified), every unit
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s);         // AySign2Ax, message hash, variable-base ladder, R8 + h*8A

@@ -5,6 +5,7 @@
 //   k_smt    lane = (unit, chain)  one of the independent level-hash chains of the SMTProcessors
 #define HZ_FR_INLINE 1
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "tx_dev.h"
 #include "kernels.h"
 #include "smt_dev.h"
@@ -101,6 +102,65 @@ __device__ __forceinline__ uint32_t wave_max_u6(uint32_t v) {
     }
     return r;
 }
+// What the two kernels below must agree on, bit for bit: the shape of one SMTProcessor chain of one unit -- the zero pattern of its
+// siblings, the level SMTLevIns selects, where the keys part -- and from it the first level from which the chain is STRUCTURALLY empty.
+struct SmtShape {
+    uint64_t zmask;    // bit i = siblings[i] == 0
+    uint64_t levmask;  // levIns, one-hot
+    int kl, kx;        // the level with levIns = 1; the first level >= kl whose key bits differ (n: none)
+};
+__device__ __forceinline__ SmtShape smt_shape(const UnitIO& io, uint32_t siblings, int n, uint64_t keylo_old, uint64_t keylo_new) {
+    SmtShape sh;
+    // SMTLevIns: levIns[i] from the zero pattern of the siblings; isz[i] in {0,1}; done/levIns are 0/1 as well -> integer logic, exact for any input
+    uint64_t zmask = 0;
+    for (int k = 0; k < n; k++) {
+        const Fc s = io.in_c(siblings + k);
+        uint32_t any = 0;
+        for (int q = 0; q < 8; q++) any |= s.v[q];
+        if (!any) zmask |= 1ull << k;
+    }
+    uint64_t levmask = 0;
+    {
+        // levIns[n-1] = 1 - isz[n-2]; done[n-2] = levIns[n-1]; levIns[i] = (1-done[i])*(1-isz[i-1]); done[i-1] = levIns[i]+done[i]
+        uint32_t done = 0;
+        uint32_t li = 1u - (uint32_t)((zmask >> (n - 2)) & 1);
+        if (li) levmask |= 1ull << (n - 1);
+        done = li;
+        for (int k = n - 2; k > 0; k--) {
+            li = (1u - done) * (1u - (uint32_t)((zmask >> (k - 1)) & 1));
+            if (li) levmask |= 1ull << k;
+            done += li;
+        }
+        if (!done) levmask |= 1ull;
+    }
+    sh.zmask = zmask; sh.levmask = levmask;
+    const uint64_t xmask = (keylo_old ^ keylo_new) & ((1ull << n) - 1);   // n <= HZ_MAX_SMT_LEVELS < 64
+    sh.kl = __builtin_ctzll(levmask);
+    const uint64_t xabove = xmask >> sh.kl;
+    sh.kx = xabove ? sh.kl + __builtin_ctzll(xabove) : n;   // n: the keys agree on every level >= kl
+    return sh;
+}
+// Levels that are empty for STRUCTURAL reasons (child and sibling are zero whatever the hashes are): from the level returned on.
+// Old side: the child of level k is root(k+1) = h1old * s_a(k+1), zero from k = kx on (k = kl on when m = 0: update / nop / insert
+// into an empty slot); new side: both switcher inputs vanish above kx (from kl on when m = 0). The siblings above the highest
+// non-zero one are zero by inspection.
+__device__ __forceinline__ uint32_t smt_thr_lane(const SmtShape& sh, bool m_zero, bool new_side, int n) {
+    const uint64_t nz = ~sh.zmask & ((n < 64 ? (1ull << n) : 0ull) - 1ull);
+    const int hi_nz = nz ? 63 - __builtin_clzll(nz) : -1;
+    int thr_lane = m_zero ? sh.kl : (new_side ? sh.kx + 1 : sh.kx);
+    if (thr_lane < hi_nz + 1) thr_lane = hi_nz + 1;
+    if (thr_lane > n) thr_lane = n;
+    return (uint32_t)thr_lane;
+}
+// m = enabled * fnc0 * (1 - isOld0), the multiplier of the "insert below an existing leaf" states: zero for update / nop / insert into
+// an empty slot (the same field operations as k_smt's own m)
+__device__ __forceinline__ bool smt_m_is_zero(const Scratch& sc, const SmtProcDesc& P) {
+    const Fr fnc0 = sc.get(P.sc_fnc0), fnc1 = sc.get(P.sc_fnc1), isOld0 = sc.get(P.sc_isold0);
+    const Fr enabled = fr_sub(fr_add(fnc0, fnc1), fr_mul(fnc0, fnc1));
+    const Fr A2 = fr_mul(enabled, fnc0);
+    return fr_is_zero(fr_sub(A2, fr_mul(A2, isOld0)));
+}
+
 // Two wavefronts of this kernel per SIMD saturate the integer pipe (three, with the register budget that implies: no faster).
 // Two wavefronts per workgroup: the kernel alone does not care (20.7 ms either way), the STEP does -- with the signature ladders, the
 // fee chain and the SHA-256 tail of two contexts beside it, pairs of k_smt wavefronts placed together measured 35.7-35.9 ms per step
@@ -130,29 +190,8 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
     // the low 64 bits of the keys: the path bits of every level (n <= HZ_MAX_SMT_LEVELS < 64), read by shifts, never by indexing the key
     const uint64_t keylo_old = (uint64_t)oldKey_c.v[0] | ((uint64_t)oldKey_c.v[1] << 32), keylo_new = (uint64_t)newKey_c.v[0] | ((uint64_t)newKey_c.v[1] << 32);
     const Fr h1old = sc.get(P.sc_leaf_old), h1new = sc.get(P.sc_leaf_new);
-    // SMTLevIns: levIns[i] from the zero pattern of the siblings (both lanes need it)
-    // isz[i] in {0,1}; done/levIns are 0/1 as well -> integer logic, exact for any input
-    uint64_t zmask = 0;  // bit i = siblings[i] == 0
-    for (int k = 0; k < n; k++) {
-        const Fc s = io.in_c(P.siblings + k);
-        uint32_t any = 0;
-        for (int q = 0; q < 8; q++) any |= s.v[q];
-        if (!any) zmask |= 1ull << k;
-    }
-    uint64_t levmask = 0;
-    {
-        // levIns[n-1] = 1 - isz[n-2]; done[n-2] = levIns[n-1]; levIns[i] = (1-done[i])*(1-isz[i-1]); done[i-1] = levIns[i]+done[i]
-        uint32_t done = 0;
-        uint32_t li = 1u - (uint32_t)((zmask >> (n - 2)) & 1);
-        if (li) levmask |= 1ull << (n - 1);
-        done = li;
-        for (int k = n - 2; k > 0; k--) {
-            li = (1u - done) * (1u - (uint32_t)((zmask >> (k - 1)) & 1));
-            if (li) levmask |= 1ull << k;
-            done += li;
-        }
-        if (!done) levmask |= 1ull;
-    }
+    const SmtShape shape = smt_shape(io, P.siblings, n, keylo_old, keylo_new);
+    const uint64_t zmask = shape.zmask, levmask = shape.levmask;
     if (!new_side) {
         if (o.fnc != ~0u) { io.put_m(o.fnc, fnc0); io.put_m(o.fnc + 1, fnc1); }
         io.put_m(o.enabled, enabled);
@@ -210,31 +249,16 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
     //   k == kl : aux1 = E, aux2 = E*fnc0, old0 = aux2*isOld0, upd = E - aux2, m = aux2 - old0 -> new1 or bot
     //   k >  kl : bot = m until kx, new1 = m at kx, 0 afterwards
     // fnc0 / fnc1 / isOld0 may be arbitrary field elements in a standalone RollupTx: field arithmetic.
-    const uint64_t xmask = (keylo_old ^ keylo_new) & ((1ull << n) - 1);   // n <= HZ_MAX_SMT_LEVELS < 64
-    const int kl = __builtin_ctzll(levmask);
-    const uint64_t xabove = xmask >> kl;
-    const int kx = xabove ? kl + __builtin_ctzll(xabove) : n;   // n: the keys agree on every level >= kl
+    const int kl = shape.kl, kx = shape.kx;
     const Fr A2 = fr_mul(enabled, fnc0);
     const Fr O = fr_mul(A2, isOld0);
     const Fr U = fr_sub(enabled, A2);
     const Fr m = fr_sub(A2, O);
-    // Levels that are empty for STRUCTURAL reasons (child and sibling are zero whatever the hashes are): from the level thr_lane on.
-    // Old side: the child of level k is root(k+1) = h1old * s_a(k+1), zero from k = kx on (k = kl on when m = 0: update / nop / insert
-    // into an empty slot); new side: both switcher inputs vanish above kx (from kl on when m = 0). The siblings above the highest
-    // non-zero one are zero by inspection. thr_wave = the first level that is empty for every lane of the wavefront.
+    // thr_wave = the first level that is structurally empty (smt_thr_lane) for every lane of the wavefront.
     // ABOVE thr_wave (k > thr_wave) every per-level signal of every lane is zero as well -- the state-machine states (k > kl, and
     // k > kx or m = 0), the switcher auxiliaries and the roots (root(k) = h1 * s(k) with s(k) = 0): they are stored as zeros without
     // the products and conversions (`dead`, wave-uniform; 19 of 33 levels in a tree of 2^13 accounts).
-    uint32_t thr_wave = (uint32_t)n;
-    {
-        const bool m_zero = fr_is_zero(m);
-        const uint64_t nz = ~zmask & ((n < 64 ? (1ull << n) : 0ull) - 1ull);
-        const int hi_nz = nz ? 63 - __builtin_clzll(nz) : -1;
-        int thr_lane = m_zero ? kl : (new_side ? kx + 1 : kx);
-        if (thr_lane < hi_nz + 1) thr_lane = hi_nz + 1;
-        if (thr_lane > n) thr_lane = n;
-        thr_wave = wave_max_u6((uint32_t)thr_lane);
-    }
+    const uint32_t thr_wave = wave_max_u6(smt_thr_lane(shape, fr_is_zero(m), new_side, n));
     if (new_side) {
         Fr p_na = fr_sub(one, enabled), p_new1 = zero, p_old0 = zero, p_upd = zero;
         Fr last_sum = zero;
@@ -310,7 +334,7 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
         } else {
             // hashing level k (< thr_wave) also stores the blocks of empty levels thr + [k E / H, (k+1) E / H), E = n - thr, H = thr
             BgZero bg{a.base, a.n_units, i, o.levels + (new_side ? LV_NEWHASH : LV_OLDHASH), 0, 0, 0, 0};
-            if (thr_wave > 0) {
+            if (thr_wave > 0 && !a.bg_external) {   // (bg_external: k_smt_bg stores the empty levels' blocks beside this kernel)
                 const uint32_t E = (uint32_t)n - thr_wave;
                 bg.j = thr_wave + (uint32_t)k * E / thr_wave;
                 bg.j_end = thr_wave + ((uint32_t)k + 1) * E / thr_wave;
@@ -339,6 +363,61 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// EXPERIMENT (round 5, off by default: ctx.hip HZ_SMT_BG_ON; profiles/r05_ksmt_bg_writer.txt). The constant blocks of the structurally
+// empty levels written by a kernel of their own BESIDE k_smt instead of in the shadow of its hashing levels (BgZero): a small persistent
+// grid whose only work is stores -- a job = (64 consecutive units, chain); the wavefront derives the same thr_wave as k_smt's wavefront of
+// those units (smt_shape / smt_thr_lane: one statement of the rule for both) and streams the 243-signal block of every level from
+// thr_wave up; k_smt (bg_external) stores nothing for those levels. k_smt alone 20.3 -> 16.1 ms; the step 1.4-5 % slower.
+__global__ __launch_bounds__(64) void k_smt_bg(const SmtArgs a, unsigned long long* rows_written) {
+    const uint32_t count = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t n_blocks = (count + 63) / 64, n_jobs = n_blocks * 2 * a.n_proc;
+    const int n = (int)a.n_levels;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+        const uint32_t chain = job / n_blocks, blk = job - chain * n_blocks;
+        const uint32_t pi = chain >> 1;
+        const bool new_side = chain & 1;
+        const SmtProcDesc& P = a.p[pi];
+        const uint32_t li = blk * 64 + lane;
+        const uint32_t i = a.u0 + li * (a.ustride > 1 ? a.ustride : 1u);
+        const bool active = li < count && !(a.skip_mod && i % a.skip_mod == a.skip_mod - 1);
+        uint32_t thr_lane = 0;
+        if (active) {
+            const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+            const Scratch sc{a.scratch, a.n_units, i};
+            const Fc oldKey_c = fr_to_canon(sc.get(P.sc_oldkey)), newKey_c = fr_to_canon(sc.get(P.sc_newkey));
+            const uint64_t keylo_old = (uint64_t)oldKey_c.v[0] | ((uint64_t)oldKey_c.v[1] << 32), keylo_new = (uint64_t)newKey_c.v[0] | ((uint64_t)newKey_c.v[1] << 32);
+            const SmtShape shape = smt_shape(io, P.siblings, n, keylo_old, keylo_new);
+            thr_lane = smt_thr_lane(shape, smt_m_is_zero(sc, P), new_side, n);
+        }
+        const uint32_t thr_wave = wave_max_u6(thr_lane);
+        if (thr_wave == 0 || thr_wave >= (uint32_t)n) continue;   // (0: k_smt hashes every level of such a wavefront itself)
+        const uint32_t off0 = P.o.levels + (new_side ? LV_NEWHASH : LV_OLDHASH);
+        if (active) {
+            for (uint32_t j = thr_wave; j < (uint32_t)n; j++) {
+#pragma unroll 3
+                for (uint32_t sgn = 0; sgn < 243; sgn++) {
+                    Fc c;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[sgn][q];
+                    store_fr(a.base + ((size_t)(off0 + LV_SIZE * j + sgn) * a.n_units + i) * 32, c);
+                }
+            }
+        }
+        if (rows_written && lane == 0) atomicAdd(rows_written, (unsigned long long)((uint32_t)n - thr_wave) * 243ull);
+    }
+}
+hipError_t launch_smt_bg(const SmtArgs& a, unsigned long long* rows_written, hipStream_t s) {
+    const uint32_t count = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t n_jobs = ((count + 63) / 64) * 2 * a.n_proc;
+    // persistent and small: at most two wavefronts per CU, so that the chain kernels launched after it find their slots
+    static const uint32_t cap = getenv("HZ_SMT_BG_GRID") ? (uint32_t)atoi(getenv("HZ_SMT_BG_GRID")) : 512u;   // (experiments)
+    const uint32_t grid = n_jobs < cap ? n_jobs : cap;
+    if (!grid) return hipSuccess;
+    hipLaunchKernelGGL(k_smt_bg, dim3(grid), dim3(64), 0, s, a, rows_written);
+    return hipGetLastError();
+}
+
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
     const uint32_t nl = a.ucnt ? a.ucnt : a.n_units;
