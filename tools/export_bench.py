@@ -50,6 +50,23 @@ def main():
         ms = sorted(times)[len(times) // 2]
         print("export %-16s B=%d: %.3f ms per batch (min %.3f)  %.2f TB/s read+write   plan %.1f s  tables %.0f MB" % (
             name, nb, ms, min(times), 2 * wl * 32 / ms / 1e9, t_plan, tab / 1e6), flush=True)
+        if name == "component-major":   # several batches per call: the sections whose unit is the instance are read as whole lines
+            for cnt in (4, 8):
+                if cnt > nb:
+                    continue
+                big = torch.zeros(cnt * wl * 32, dtype=torch.uint8, device="cuda:0")
+                tt = []
+                for r in range(reps + 1):
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    ev0.record(s)
+                    L._check(L.c.hz_witness_export_range_dev(g.h, mp.h, (r * cnt) % (nb - cnt + 1) // 4 * 4, cnt, big.data_ptr(), s.cuda_stream))
+                    ev1.record(s)
+                    torch.cuda.synchronize()
+                    if r:
+                        tt.append(ev0.elapsed_time(ev1) / cnt)
+                print("export %-16s B=%d, %d batches per call: %.3f ms per batch  %.2f TB/s read+write" % (name, nb, cnt, sorted(tt)[len(tt) // 2], 2 * wl * 32 / sorted(tt)[len(tt) // 2] / 1e9), flush=True)
+                del big
         del mp
 
 
