@@ -1090,6 +1090,26 @@ static hz_status symmap_usable(const hz_symmap* m, const char* who);
 // then index / derived / linear forms. The constraint system is not kept: a loaded map serves the witness, hz_symmap_check_r1cs wants
 // the one made from the files.
 namespace {
+// FNV-1a over the file without its last `tail` bytes
+bool file_fnv1a(const char* path, uint64_t tail, uint64_t* out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const uint64_t size = (uint64_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (size < tail) { fclose(f); return false; }
+    uint64_t left = size - tail, h = 0xcbf29ce484222325ull;
+    std::vector<uint8_t> buf(1 << 20);
+    while (left) {
+        const size_t n = (size_t)std::min<uint64_t>(left, buf.size());
+        if (fread(buf.data(), 1, n, f) != n) { fclose(f); return false; }
+        for (size_t i = 0; i < n; i++) { h ^= buf[i]; h *= 0x100000001b3ull; }
+        left -= n;
+    }
+    fclose(f);
+    *out = h;
+    return true;
+}
 struct MapHdr { char magic[4]; uint32_t version; uint64_t witness_len, symbols, n_index, n_derived, n_lins, n_terms, n_solved, n_derived_vars; };
 }
 extern "C" hz_status hz_symmap_save(const hz_ctx* ctx, const hz_symmap* m, const char* path) {
@@ -1100,7 +1120,7 @@ extern "C" hz_status hz_symmap_save(const hz_ctx* ctx, const hz_symmap* m, const
     if (!f) return set_err(HZ_ERR_INPUT, "hz_symmap_save: cannot write %s", path);
     uint64_t n_terms = 0;
     for (const LinForm& lf : m->lins) n_terms += lf.terms.size();
-    MapHdr h{{'h', 'z', 's', 'm'}, 1, hz_witness_len(ctx), hz_symbol_count(ctx), m->index.size(), m->derived.size(), m->lins.size(), n_terms, m->n_solved, m->n_derived};
+    MapHdr h{{'h', 'z', 's', 'm'}, 2, hz_witness_len(ctx), hz_symbol_count(ctx), m->index.size(), m->derived.size(), m->lins.size(), n_terms, m->n_solved, m->n_derived};
     bool ok = fwrite(&h, sizeof h, 1, f) == 1;
     ok = ok && (m->index.empty() || fwrite(m->index.data(), 8, m->index.size(), f) == m->index.size());
     for (const DerivedVar& d : m->derived) {
@@ -1113,6 +1133,13 @@ extern "C" hz_status hz_symmap_save(const hz_ctx* ctx, const hz_symmap* m, const
         for (const auto& tm : lf.terms) ok = ok && fwrite(tm.first.v, 8, 4, f) == 4 && fwrite(&tm.second, 8, 1, f) == 1;
     }
     ok = (fclose(f) == 0) && ok;
+    if (ok) {   // version 2: FNV-1a (64 bit) of everything before it, as the last eight bytes -- a flipped bit in a value that passes every range check
+        uint64_t sum = 0;
+        ok = file_fnv1a(path, 0, &sum);
+        FILE* g = ok ? fopen(path, "ab") : nullptr;
+        ok = g && fwrite(&sum, 8, 1, g) == 1;
+        if (g) ok = (fclose(g) == 0) && ok;
+    }
     return ok ? HZ_OK : set_err(HZ_ERR_INPUT, "hz_symmap_save: short write to %s", path);
 }
 extern "C" hz_status hz_symmap_load(const hz_ctx* ctx, const char* path, hz_symmap** out) {
@@ -1122,7 +1149,12 @@ extern "C" hz_status hz_symmap_load(const hz_ctx* ctx, const char* path, hz_symm
     hz_symmap* m = nullptr;
     try {
         MapHdr h;
-        bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "hzsm", 4) && h.version == 1;
+        bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "hzsm", 4) && h.version == 2;
+        if (ok) {   // the trailing checksum first: nothing of a damaged file is followed
+            uint64_t want = 0, got = 0;
+            ok = fseek(f, -8, SEEK_END) == 0 && fread(&got, 8, 1, f) == 1 && file_fnv1a(path, 8, &want) && want == got;
+            fseek(f, (long)sizeof h, SEEK_SET);
+        }
         if (ok && (h.witness_len != hz_witness_len(ctx) || h.symbols != hz_symbol_count(ctx))) {
             fclose(f);
             return set_err(HZ_ERR_INPUT, "hz_symmap_load: %s was made for another template or shape (witness length %llu, this context %llu)", path,
