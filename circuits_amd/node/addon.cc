@@ -66,6 +66,10 @@ struct Api {
     decltype(&hz_symmap_nvars) symmap_nvars;
     decltype(&hz_symmap_unresolved) symmap_unresolved;
     decltype(&hz_witness_write_wtns_sym) witness_write_wtns_sym;
+    decltype(&hz_witness_export_host) witness_export_host;
+    decltype(&hz_symmap_upload) symmap_upload;
+    decltype(&hz_symmap_solved) symmap_solved;
+    decltype(&hz_symmap_derived) symmap_derived;
     decltype(&hz_poseidon_batch) poseidon_batch;
 } api;
 
@@ -87,7 +91,7 @@ static bool load_api(std::string& err) {
     SYM(inputs_packed_bytes) SYM(input_packed_width) SYM(input_packed_offset) SYM(host_alloc) SYM(host_free) SYM(inputs_upload) SYM(inputs_stage)
     SYM(inputs_stage_range) SYM(witness_enqueue) SYM(witness_check) SYM(witness_failures) SYM(witness_total) SYM(witness_read_raw) SYM(witness_dev_ptr)
     SYM(set_inputs_json) SYM(witness_write_json) SYM(witness_write_wtns) SYM(symbols_write_sym) SYM(symmap_create) SYM(symmap_create_r1cs) SYM(symmap_check_r1cs) SYM(symmap_destroy)
-    SYM(symmap_nvars) SYM(symmap_unresolved) SYM(witness_write_wtns_sym) SYM(poseidon_batch)
+    SYM(symmap_nvars) SYM(symmap_unresolved) SYM(witness_write_wtns_sym) SYM(witness_export_host) SYM(symmap_upload) SYM(symmap_solved) SYM(symmap_derived) SYM(poseidon_batch)
 #undef SYM
     return true;
 }
@@ -681,6 +685,140 @@ static napi_value WriteWtns(napi_env env, napi_callback_info info) {
     if (api.witness_write_wtns(c, inst, path.c_str()) != HZ_OK) return throw_hz(env, "hz_witness_write_wtns");
     return nullptr;
 }
+// ---- a circom .sym (+ .r1cs) imported ONCE and kept: the witness in the compiler's variable order -------------------------------------------
+// importSym(handle, symText, r1cs Buffer | null) -> map handle (an external; freed with the handle's finaliser or freeMap)
+// mapInfo(map) -> { nVars, unresolved, firstUnresolved, solved, derived }
+// exportWitness(handle, map, instance) -> Promise<ArrayBuffer of nVars x 32 bytes>: hz_witness_export_host on the libuv pool (one device pass
+//                                         + D2H; what the reference's calculateWitness returns, test/helpers/helpers.js:142,149, as bytes)
+// writeWtnsMap(handle, map, instance, file), checkMap(handle, map, instance) -> { bad, first }
+struct NodeMap { hz_symmap* m = nullptr; };
+static void map_finalize(napi_env, void* data, void*) {
+    NodeMap* nm = (NodeMap*)data;
+    if (nm->m) api.symmap_destroy(nm->m);
+    delete nm;
+}
+static NodeMap* get_map(napi_env env, napi_value v) {
+    void* p = nullptr;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((NodeMap*)p)->m) { napi_throw_error(env, nullptr, "bad or released symbol-map handle"); return nullptr; }
+    return (NodeMap*)p;
+}
+static napi_value ImportSym(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    size_t got = 0;
+    if (!get_args(env, info, 3, argv, &got)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    std::string sym;
+    if (!c || !get_str(env, argv[1], sym)) return nullptr;
+    bool is_buf = false;
+    void* rdata = nullptr; size_t rlen = 0;
+    if (got >= 3 && napi_is_buffer(env, argv[2], &is_buf) == napi_ok && is_buf) napi_get_buffer_info(env, argv[2], &rdata, &rlen);
+    hz_symmap* m = nullptr;
+    if (is_buf) {
+        if (api.symmap_create_r1cs(c, sym.c_str(), sym.size(), (const uint8_t*)rdata, rlen, &m) != HZ_OK) return throw_hz(env, "hz_symmap_create_r1cs");
+    } else if (api.symmap_create(c, sym.c_str(), sym.size(), &m) != HZ_OK) return throw_hz(env, "hz_symmap_create");
+    NodeMap* nm = new NodeMap();
+    nm->m = m;
+    napi_value ext;
+    if (napi_create_external(env, nm, map_finalize, nullptr, &ext) != napi_ok) { map_finalize(env, nm, nullptr); return nullptr; }
+    return ext;
+}
+static napi_value MapInfo(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    NodeMap* nm = get_map(env, argv[0]);
+    if (!nm) return nullptr;
+    uint64_t var = 0; const char* name = nullptr;
+    const uint64_t miss = api.symmap_unresolved(nm->m, 0, &var, &name);
+    napi_value o, v;
+    napi_create_object(env, &o);
+    napi_create_double(env, (double)api.symmap_nvars(nm->m), &v); napi_set_named_property(env, o, "nVars", v);
+    napi_create_double(env, (double)miss, &v); napi_set_named_property(env, o, "unresolved", v);
+    napi_create_double(env, (double)api.symmap_solved(nm->m), &v); napi_set_named_property(env, o, "solved", v);
+    napi_create_double(env, (double)api.symmap_derived(nm->m), &v); napi_set_named_property(env, o, "derived", v);
+    if (miss && name) { napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "firstUnresolved", v); }
+    return o;
+}
+static napi_value FreeMap(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    void* p = nullptr;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p && ((NodeMap*)p)->m) { api.symmap_destroy(((NodeMap*)p)->m); ((NodeMap*)p)->m = nullptr; }
+    return nullptr;
+}
+struct ExportWork {
+    napi_async_work work;
+    napi_deferred deferred;
+    hz_ctx* ctx; hz_symmap* map;
+    int32_t inst;
+    uint64_t nvars;
+    uint8_t* data;        // malloc'ed here, handed to the ArrayBuffer (freed by its finaliser)
+    hz_status st;
+    std::string msg;
+};
+static void export_execute(napi_env, void* data) {
+    ExportWork* w = (ExportWork*)data;
+    w->data = (uint8_t*)malloc((size_t)std::max<uint64_t>(w->nvars, 1) * 32);
+    if (!w->data) { w->st = HZ_ERR_ARG; w->msg = "out of memory for the exported witness"; return; }
+    w->st = api.witness_export_host(w->ctx, w->map, w->inst, 0, w->nvars, w->data);
+    if (w->st != HZ_OK) w->msg = api.last_error();
+}
+static void free_exported(napi_env, void* data, void*) { free(data); }
+static void export_complete(napi_env env, napi_status, void* data) {
+    ExportWork* w = (ExportWork*)data;
+    if (w->st == HZ_OK) {
+        napi_value ab;
+        if (napi_create_external_arraybuffer(env, w->data, (size_t)w->nvars * 32, free_exported, nullptr, &ab) == napi_ok) { w->data = nullptr; napi_resolve_deferred(env, w->deferred, ab); }
+        else { napi_value msg, e; napi_create_string_utf8(env, "cannot wrap the exported witness", NAPI_AUTO_LENGTH, &msg); napi_create_error(env, nullptr, msg, &e); napi_reject_deferred(env, w->deferred, e); }
+    } else {
+        napi_value msg, e;
+        napi_create_string_utf8(env, w->msg.c_str(), NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &e);
+        napi_reject_deferred(env, w->deferred, e);
+    }
+    free(w->data);
+    napi_delete_async_work(env, w->work);
+    delete w;
+}
+static napi_value ExportWitness(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    NodeMap* nm = get_map(env, argv[1]);
+    if (!c || !nm) return nullptr;
+    if (api.symmap_unresolved(nm->m, 0, nullptr, nullptr)) { napi_throw_error(env, nullptr, "the symbol map has unresolved variables (mapInfo)"); return nullptr; }
+    ExportWork* w = new ExportWork();
+    w->ctx = c; w->map = nm->m; w->inst = (int32_t)num(env, argv[2]); w->nvars = api.symmap_nvars(nm->m); w->data = nullptr; w->st = HZ_OK;
+    napi_value promise, name;
+    NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
+    NAPI_OK(napi_create_string_utf8(env, "hz_witness_export_host", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(napi_create_async_work(env, nullptr, name, export_execute, export_complete, w, &w->work));
+    NAPI_OK(napi_queue_async_work(env, w->work));
+    return promise;
+}
+static napi_value WriteWtnsMap(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    NodeMap* nm = get_map(env, argv[1]);
+    std::string path;
+    if (!c || !nm || !get_str(env, argv[3], path)) return nullptr;
+    if (api.witness_write_wtns_sym(c, nm->m, (int32_t)num(env, argv[2]), path.c_str()) != HZ_OK) return throw_hz(env, "hz_witness_write_wtns_sym");
+    return nullptr;
+}
+static napi_value CheckMap(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    NodeMap* nm = get_map(env, argv[1]);
+    if (!c || !nm) return nullptr;
+    uint64_t n_bad = 0, first = 0;
+    if (api.symmap_check_r1cs(c, nm->m, (int32_t)num(env, argv[2]), &n_bad, &first, 1) != HZ_OK) return throw_hz(env, "hz_symmap_check_r1cs");
+    napi_value o, v;
+    napi_create_object(env, &o);
+    napi_create_double(env, (double)n_bad, &v); napi_set_named_property(env, o, "bad", v);
+    napi_create_double(env, n_bad ? (double)first : -1.0, &v); napi_set_named_property(env, o, "first", v);
+    return o;
+}
 static napi_value WriteJson(napi_env env, napi_callback_info info) {
     napi_value argv[3];
     if (!get_args(env, info, 3, argv)) return nullptr;
@@ -825,7 +963,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"symbolCount", SymbolCount}, {"symbolGet", SymbolGet}, {"deviceCount", DeviceCount}, {"version", Version},
         {"packedLayout", PackedLayout}, {"hostAlloc", HostAlloc}, {"upload", Upload}, {"stageRange", StageRange}, {"enqueue", Enqueue},
         {"check", Check}, {"devPtr", DevPtr}, {"witnessTotal", WitnessTotal}, {"readRaw", ReadRaw}, {"setInputsJson", SetInputsJson},
-        {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}, {"step", Step}, {"checkSync", CheckSync}, {"failures", Failures}};
+        {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}, {"step", Step}, {"checkSync", CheckSync}, {"failures", Failures},
+        {"importSym", ImportSym}, {"mapInfo", MapInfo}, {"freeMap", FreeMap}, {"exportWitness", ExportWitness}, {"writeWtnsMap", WriteWtnsMap}, {"checkMap", CheckMap}};
     for (const auto& f : fns) {
         napi_value fn;
         napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn);

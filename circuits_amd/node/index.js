@@ -254,6 +254,31 @@ class Circuit {
         else if (symText) addon.writeWtns(this.handle, instance | 0, file, symText);
         else addon.writeWtns(this.handle, instance | 0, file);
     }
+    /** A circom .sym (and, for a compile without constraint reduction, its .r1cs as a Buffer) imported ONCE: the object that turns this
+     *  circuit's witnesses into the compiler's variable order -- what the reference's calculateWitness returns and its prove step reads
+     *  (test/helpers/helpers.js:142,149, tools/helpers/actions.js:132-170). Throws when a variable cannot be served. */
+    importSym(symText, r1cs) {
+        const map = addon.importSym(this.handle, symText, r1cs || null);
+        const info = addon.mapInfo(map);
+        if (info.unresolved) { addon.freeMap(map); throw new Error(`circom .sym: ${info.unresolved} variables are not stored by this layout (first: ${info.firstUnresolved})`); }
+        const circuit = this;
+        return {
+            nVars: info.nVars, solved: info.solved, derived: info.derived,
+            /** w[0 .. nVars) of one instance as bytes (32-byte little-endian elements): one device pass + one copy, off the event loop */
+            witnessBin(instance) { return addon.exportWitness(circuit.handle, map, instance | 0); },
+            /** the same as BigInt[] (tests; a full-size witness does not fit a JS array) */
+            async witness(instance) {
+                const u = new BigUint64Array(await addon.exportWitness(circuit.handle, map, instance | 0));
+                const w = new Array(u.length / 4);
+                for (let i = 0; i < w.length; i++) w[i] = u[4 * i] | (u[4 * i + 1] << 64n) | (u[4 * i + 2] << 128n) | (u[4 * i + 3] << 192n);
+                return w;
+            },
+            writeWtns(file, instance) { addon.writeWtnsMap(circuit.handle, map, instance | 0, file); },
+            /** every constraint of the .r1cs on the exported witness: { bad, first } (first = -1 when none) */
+            check(instance) { return addon.checkMap(circuit.handle, map, instance | 0); },
+            release() { addon.freeMap(map); },
+        };
+    }
     writeJson(file, instance) { addon.writeJson(this.handle, instance | 0, file); }
     writeSym(file) { addon.writeSym(this.handle, file); }
 

@@ -20,5 +20,27 @@ const { tester } = require(path.join(__dirname, "..", "..", "circuits_amd", "nod
         assert.throws(() => circuit.writeWtns(out + ".bad", 0, sym, fs.readFileSync(badFile), true), /constraints of the \.r1cs do not hold/);
         assert(!fs.existsSync(out + ".bad"));
     }
+    // the same compile imported ONCE and kept (circuit.importSym): w[] in the compiler's order in memory -- what the reference's
+    // calculateWitness hands its callers -- the .wtns from the kept map byte for byte the one above, the constraint check on the exported buffer
+    const map = circuit.importSym(sym, fs.readFileSync(r1csFile));
+    assert(map.nVars > 1000 && map.solved > 0 && map.derived > 0);
+    assert.deepStrictEqual(map.check(0), { bad: 0, first: -1 });
+    const w = await map.witness(0);
+    assert.strictEqual(w.length, map.nVars);
+    assert.strictEqual(w[0], 1n);
+    const bin = Buffer.from(await map.witnessBin(0));
+    const file = fs.readFileSync(out);
+    assert(file.slice(file.length - bin.length).equals(bin), "the .wtns data section is the exported vector");
+    map.writeWtns(out + ".map", 0);
+    assert(fs.readFileSync(out + ".map").equals(file));
+    assert.throws(() => circuit.importSym(sym), /not stored by this layout/);
+    if (badFile) {
+        const bad = circuit.importSym(sym, fs.readFileSync(badFile));
+        const r = bad.check(0);
+        assert(r.bad === 1 && r.first >= 0);
+        bad.release();
+        assert.throws(() => bad.check(0), /released symbol-map handle/);
+    }
+    map.release();
     console.log("wtns_r1cs: ok");
 })().catch((e) => { console.error(e); process.exit(1); });
