@@ -1140,7 +1140,8 @@ def main():
                        "distinct_batches": n_distinct, "state_accounts": n_acc, "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
                        "world_size": world, "backend": D.backend if world > 1 else None,
                        "witness_bytes_per_batch": witness_bytes, "step_latency_ms": round(single_ms, 3), "batch_build_s": round(t_build, 1),
-                       "batch_builder": ({"kind": "native (libhz_host.so hzb_batch_build) + hz_poseidon_dag", "batches": len(all_seeds),
+                       "batch_builder": ({"kind": "native (libhz_host.so hzb_batch_build_begin / _finish) + hz_poseidon_dag", "batches": len(all_seeds),
+                                          "pipelined": "the device evaluates batch i's Merkle hashes (a worker thread) while the host walks batch i + 1",
                                           "hashes": builder_stats["jobs"], "dag_segments": builder_stats["segments"], "device_ms": round(builder_stats["device_ms"], 1),
                                           "walk_and_sign_s": round(builder_stats["walk_s"], 2), "evaluator_s": round(builder_stats["eval_s"], 2),
                                           "state_s": round(builder_stats["state_s"], 2), "batch_s": round(builder_stats["batch_s"], 2),

@@ -46,7 +46,8 @@ def build_packed_batches(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, lay
         return pool.map(_one, tasks, chunksize=1)
 
 
-def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, lib, device, out_addr, base=None, native_recipe=True):
+def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accounts, layout, lib, device, out_addr, base=None, native_recipe=True,
+                                pipelined=True):
     """one batch per seed, written to out_addr + i * layout[0] (pinned host memory): [(None, expected hashGlobalInputs, signed L2
     transactions)] plus the builder's counters. n_accounts must be a power of two >= 16 unless a shared `base` (DenseState) is given."""
     from circuits_amd import builder as B
@@ -57,17 +58,35 @@ def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accoun
     # state_s: the pre-populated state of each seed (DenseState, not part of building a batch); batch_s: everything from the first
     # add_tx to the packed inputs (Python transaction recipe + hzb_batch_build: walk, signing, hashing, packing)
     res, stats = [], {"jobs": 0, "segments": 0, "device_ms": 0.0, "walk_s": 0.0, "eval_s": 0.0, "sign_s": 0.0, "state_s": 0.0, "batch_s": 0.0}
-    for i, seed in enumerate(seeds):
-        t0 = time.perf_counter()
-        b = base if base is not None else B.DenseState.build(n_accounts.bit_length() - 1, seed=seed, hash_rows=hash_rows)
-        t1 = time.perf_counter()
-        bb, _, hgi = NB.synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, tables, seed=seed, device=device, base=b, out=out_addr + i * layout[0],
-                                               native_recipe=native_recipe)
-        stats["state_s"] += t1 - t0
-        stats["batch_s"] += time.perf_counter() - t1
+
+    def finish(bb):
+        t = time.perf_counter()
+        _, hgi = bb.build_finish()
         for k, v in bb.stats().items():
             stats[k] += v
         res.append((None, hgi, n_tx - min(max_l1, n_tx)))
         bb.close()
         bb._db_keep.close()
+        stats["batch_s"] += time.perf_counter() - t
+
+    # two batches in flight (hzb_batch_build_begin / _finish): the device evaluates batch i's Merkle hashes while the host walks batch i + 1
+    live = None
+    for i, seed in enumerate(seeds):
+        t0 = time.perf_counter()
+        b = base if base is not None else B.DenseState.build(n_accounts.bit_length() - 1, seed=seed, hash_rows=hash_rows)
+        t1 = time.perf_counter()
+        bb = NB.synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, tables, seed=seed, device=device, base=b, out=out_addr + i * layout[0],
+                                       native_recipe=native_recipe, begin_only=pipelined)
+        stats["state_s"] += t1 - t0
+        stats["batch_s"] += time.perf_counter() - t1
+        if not pipelined:
+            bb = bb[0]
+        if live is not None:
+            finish(live)
+        live = bb
+        if not pipelined:
+            finish(live)
+            live = None
+    if live is not None:
+        finish(live)
     return res, stats

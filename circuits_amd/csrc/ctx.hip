@@ -74,6 +74,7 @@ struct hz_ctx {
     // the constant blocks of the structurally empty SMT levels, stored by k_smt_bg beside the chain kernel (throughput-sized launches)
     hipStream_t s_bg = nullptr;
     hipEvent_t ev_bg = nullptr;
+    DevBuf pos3;                   // poseidon_quad.h's constants (C, M R, M R^2): the latency form of k_smt
     DevBuf bg_rows;                // rows k_smt_bg wrote in the last enqueue (2 KB each): the bytes k_smt is NOT responsible for
     hipEvent_t ev_hash4 = nullptr, ev_tail = nullptr;
     ~hz_ctx() {
@@ -194,6 +195,9 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     if (e == hipSuccess) e = c->wit.alloc(lo.total * 32);
     if (e == hipSuccess) e = hipMemset(c->wit.p, 0, lo.total * 32);
     if (e == hipSuccess) e = c->err.alloc(sizeof(ErrBuf));
+    // the dense Poseidon constants of k_smt's latency form (small launches: launch_smt)
+    if (e == hipSuccess && !getenv("HZ_SMT_NO_LATENCY_FORM")) e = c->pos3.alloc(pos3_dense_bytes());
+    if (e == hipSuccess && c->pos3.p) e = upload_pos3_dense((Fr*)c->pos3.p);
     if (e == hipSuccess) e = c->inst_min.alloc((size_t)lo.n_inst * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->inst_min.p, 0xFF, c->inst_min.bytes);
     if (e == hipSuccess) e = hipMemset(c->err.p, 0, offsetof(ErrBuf, rec));
@@ -633,7 +637,15 @@ static Hash4Args make_hash4_rtx(uint8_t* base, Fr* sc, uint32_t n_units, const R
 }
 
 // the SMT chain kernel: one launch, one profile entry
-static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa, const char* name, hipStream_t s) {
+static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa0, const char* name, hipStream_t s) {
+    SmtArgs sa = sa0;
+    // The latency form (a quad of lanes per chain, 0.63 x the time of a dependent level hash for ~2.5 x its instructions) only where the
+    // whole STEP is a few dozen wavefronts per kernel: a small launch beside big ones (the fee chain of 32 batches: 2 048 lanes) competes
+    // for issue slots with them and cost the headline step 5 % (profiles/r05_smt_latency_form.txt).
+    uint32_t step_units = 0;
+    for (const auto& sec : c->lo.sections) step_units = std::max(step_units, (uint32_t)sec.n_units);
+    if (c->sharded) step_units = std::max(c->sh_count, 64u);
+    sa.pos3_dense = step_units <= HZ_SMT_LAT_MAX ? (const Fr*)c->pos3.p : nullptr;
     ProfScope ps(c, s, name, sa.n_units);
     return launch_smt(sa, s);
 }

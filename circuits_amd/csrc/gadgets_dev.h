@@ -20,6 +20,9 @@ struct UnitIO {
     // 1: the 32 lanes of this lane's aligned half-wavefront own 32 consecutive units and run in lockstep, so runs of bit signals may
     // be stored cooperatively (put_word_bits in sha_dev.h). Set by the kernels that guarantee it, wave-uniform.
     uint32_t coop32 = 0;
+    // 1: this lane repeats another lane's work (the non-leading lanes of a quad in the latency form of k_smt): it reports no failed
+    // constraint (its stores are the leader's, byte for byte)
+    uint32_t mute = 0;
 
     __device__ __forceinline__ uint8_t* addr(uint32_t sig) const { return base + ((size_t)sig * n_units + unit) * 32; }
     __device__ __forceinline__ uint8_t* addr_u(uint32_t sig, uint32_t u) const { return base + ((size_t)sig * n_units + u) * 32; }
@@ -38,10 +41,10 @@ struct UnitIO {
     __device__ __forceinline__ void put_bit(uint32_t sig, uint32_t b) const { put_u64(sig, b & 1u); }
     // `lhs === rhs` (Montgomery operands)
     __device__ __forceinline__ void chk(int cid, const Fr& lhs, const Fr& rhs) const {
-        if (!fr_eq(lhs, rhs)) report_fail(err, inst, err_unit, (uint32_t)cid, lhs, rhs);
+        if (!mute && !fr_eq(lhs, rhs)) report_fail(err, inst, err_unit, (uint32_t)cid, lhs, rhs);
     }
     __device__ __forceinline__ void chk_zero(int cid, const Fr& lhs) const {
-        if (!fr_is_zero(lhs)) report_fail(err, inst, err_unit, (uint32_t)cid, lhs, fr_zero());
+        if (!mute && !fr_is_zero(lhs)) report_fail(err, inst, err_unit, (uint32_t)cid, lhs, fr_zero());
     }
     __device__ __forceinline__ WitSboxSink sbox_sink(uint32_t sig0) const { return WitSboxSink{WitOut{base, n_units, unit}, sig0}; }
 };
@@ -131,7 +134,7 @@ __device__ __forceinline__ void put_bits(const UnitIO& io, uint32_t off, const F
 // Num2Bits(n): stores out[0..n) from the canonical value; reports `sum === in` when it cannot hold
 __device__ __forceinline__ void num2bits_dev(const UnitIO& io, uint32_t off, const Fc& canon, int n, int cid) {
     put_bits(io, off, canon, n);
-    if (n < 254 && !c_fits(canon, n)) {
+    if (n < 254 && !io.mute && !c_fits(canon, n)) {
         // lc1 = value mod 2^n
         const Fc lc = c_extract(canon, 0, n);
         report_fail(io.err, io.inst, io.err_unit, (uint32_t)cid, fr_from_canon(lc), fr_from_canon(canon));
@@ -226,7 +229,7 @@ __constant__ const uint32_t CT_SUBORDER_M1_D[8] = {0x392126f0u, 0x677297dcu, 0x3
 __device__ __forceinline__ void num2bits_strict_dev(const UnitIO& io, const N2BStrictOff& off, const Fc& canon, int cid_alias) {
     put_bits(io, off.bits, canon, 254);
     const uint32_t o = comp_constant_dev(io, off.cc, canon, CT_MINUS1_D);
-    if (o) report_fail(io.err, io.inst, io.err_unit, (uint32_t)cid_alias, fr_one(), fr_zero());
+    if (o && !io.mute) report_fail(io.err, io.inst, io.err_unit, (uint32_t)cid_alias, fr_one(), fr_zero());
 }
 
 // DecodeFloatBin (reference src/lib/decode-float.circom:12-44) on 40 bits given as u64

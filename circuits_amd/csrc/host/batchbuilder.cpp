@@ -13,6 +13,9 @@
 #include <stdint.h>
 #include <string.h>
 #include <chrono>
+#include <deque>
+#include <future>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -49,7 +52,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 // ---- values that may still be pending ---------------------------------------------------------------------------------------------
 struct Val {
-    int32_t job = -1;   // >= 0: the digest of that job of the current DAG
+    int64_t job = -1;   // >= 0: the digest of that job; job numbers run on over the flushes of a database
     U256 v = u_zero();
 };
 Val val_of(const U256& v) { Val r; r.v = v; return r; }
@@ -60,41 +63,49 @@ struct Job {
     int64_t in[6];   // >= 0: job number; < 0: -1 - (index of a constant)
 };
 
-// The pending hashes of one database: jobs, constants, and the places that wait for a digest
-struct Dag {
+// The jobs of one evaluation, detached from the database: what a worker thread evaluates while the next batch is walked
+// (hzb_batch_build_begin / _finish). Jobs [base, base + jobs.size()); an input below `base` is a digest of the flush before it.
+struct Flush {
     std::vector<Job> jobs;
     std::vector<U256> consts;
+    int64_t base = 0;
     hzb_dag_fn fn = nullptr;
     int32_t device = 0;
-    uint64_t total_jobs = 0, total_segments = 0;
+    std::shared_ptr<Flush> prev;   // the flush before this one while its digests may be inputs or outputs here; cut once this one is resolved
+    std::vector<U256> out;         // out[j - base] = digest of job j
+    int status = HZB_OK;
+    std::string err;
+    uint64_t segments = 0;
     double device_ms = 0.0, eval_s = 0.0;
+    std::shared_future<void> done;   // valid when a worker thread evaluates it
 
-    int64_t in_of(const Val& x) {
-        if (x.job >= 0) return x.job;
-        consts.push_back(x.v);
-        return -(int64_t)consts.size();
+    void wait() const { if (done.valid()) done.wait(); }
+    // the digest of job `id` (this flush's or the one before it), nullptr when neither holds it
+    const U256* find(int64_t id) const {
+        if (id >= base && id < base + (int64_t)out.size()) return &out[(size_t)(id - base)];
+        return prev ? prev->find(id) : nullptr;
     }
-    Val poseidon(const Val* xs, int n) {
-        Job j;
-        j.arity = (uint8_t)n;
-        j.wave = 0;
-        for (int k = 0; k < 6; k++) j.in[k] = -1;
-        for (int k = 0; k < n; k++) {
-            j.in[k] = in_of(xs[k]);
-            if (xs[k].job >= 0 && jobs[xs[k].job].wave >= j.wave) j.wave = jobs[xs[k].job].wave + 1;
-        }
-        jobs.push_back(j);
-        Val r;
-        r.job = (int32_t)jobs.size() - 1;
-        return r;
+    const U256& get(int64_t id) const {
+        const U256* v = find(id);
+        if (!v) throw Reject{"batch builder: a pending hash outlived the flush that computes it (job " + std::to_string(id) + ")"};
+        return *v;
     }
-    // evaluates every job; out[j] = digest of job j; forgets the jobs
-    int evaluate(std::vector<U256>& out) {
+    // evaluates every job: by hz_poseidon_dag on the device, segment by segment, or by the host Poseidon of this library
+    void run() {
         const size_t n = jobs.size();
         out.assign(n, u_zero());
-        if (!n) { consts.clear(); return HZB_OK; }
+        if (prev) {
+            prev->wait();
+            if (prev->status != HZB_OK) { status = prev->status; err = prev->err; return; }
+        }
+        if (!n) return;
         const double t0 = now_s();
         if (consts.empty()) consts.push_back(u_zero());
+        // digests of the flush before this one that are inputs here: constants by now
+        size_t n_ext = 0;
+        for (const Job& j : jobs)
+            for (int k = 0; k < j.arity; k++)
+                if (j.in[k] >= 0 && j.in[k] < base) n_ext++;
         // counting sort by (wave, arity)
         uint32_t max_wave = 0;
         for (const Job& j : jobs) if (j.wave > max_wave) max_wave = j.wave;
@@ -115,20 +126,31 @@ struct Dag {
                 seg_count.push_back(bucket[b + 1] - bucket[b]);
             }
         }
-        const size_t n_vals = n + consts.size();
-        if (n_vals >= (1ull << 32)) return fail(HZB_ERR_ARG, "batch builder: more than 2^32 values in one DAG");
+        const size_t n_vals = n + consts.size() + n_ext;
+        if (n_vals >= (1ull << 32)) { status = HZB_ERR_ARG; err = "batch builder: more than 2^32 values in one DAG"; return; }
         std::vector<uint8_t> vals(32 * n_vals, 0);
         for (size_t c = 0; c < consts.size(); c++) u_to_bytes(consts[c], &vals[32 * (n + c)]);
         std::vector<uint32_t> job_in(6 * n), job_out(n);
+        size_t ext = n + consts.size();
         for (size_t s = 0; s < n; s++) {
             const Job& j = jobs[order[s]];
             job_out[s] = order[s];
-            for (int k = 0; k < 6; k++) job_in[6 * s + k] = j.in[k] >= 0 ? (uint32_t)j.in[k] : (uint32_t)(n + (size_t)(-1 - j.in[k]));
+            for (int k = 0; k < 6; k++) {
+                const int64_t id = j.in[k];
+                if (id < 0) job_in[6 * s + k] = (uint32_t)(n + (size_t)(-1 - id));
+                else if (id >= base) job_in[6 * s + k] = (uint32_t)(id - base);
+                else {
+                    const U256* v = k < j.arity && prev ? prev->find(id) : nullptr;
+                    if (!v) { status = HZB_ERR_EVAL; err = "batch builder: a job reads a digest no flush holds (job " + std::to_string(id) + ")"; return; }
+                    u_to_bytes(*v, &vals[32 * ext]);
+                    job_in[6 * s + k] = (uint32_t)ext++;
+                }
+            }
         }
         if (fn) {
             double ms = 0.0;
             const int st = fn(device, vals.data(), n_vals, job_in.data(), job_out.data(), n, seg_t.data(), seg_first.data(), seg_count.data(), (uint32_t)seg_t.size(), &ms);
-            if (st != 0) return fail(HZB_ERR_EVAL, "batch builder: the DAG evaluator (hz_poseidon_dag) failed with status " + std::to_string(st));
+            if (st != 0) { status = HZB_ERR_EVAL; err = "batch builder: the DAG evaluator (hz_poseidon_dag) failed with status " + std::to_string(st); return; }
             device_ms += ms;
         } else {
             uint8_t buf[6 * 32];
@@ -139,11 +161,70 @@ struct Dag {
             }
         }
         for (size_t i = 0; i < n; i++) out[i] = u_from_bytes(&vals[32 * i]);
-        total_jobs += n;
-        total_segments += seg_t.size();
-        eval_s += now_s() - t0;
-        jobs.clear();
-        consts.clear();
+        segments = seg_t.size();
+        eval_s = now_s() - t0;
+        std::vector<Job>().swap(jobs);
+        std::vector<U256>().swap(consts);
+    }
+};
+
+// The pending hashes of one database: jobs, constants, and the places that wait for a digest
+struct Dag {
+    std::vector<Job> jobs;
+    std::vector<U256> consts;
+    int64_t base = 0;              // the number of jobs[0]
+    std::shared_ptr<Flush> last;   // the latest flush while its digests may still be referred to by number
+    hzb_dag_fn fn = nullptr;
+    int32_t device = 0;
+    uint64_t total_jobs = 0, total_segments = 0;
+    double device_ms = 0.0, eval_s = 0.0;
+
+    int64_t in_of(const Val& x) {
+        if (x.job >= 0) return x.job;
+        consts.push_back(x.v);
+        return -(int64_t)consts.size();
+    }
+    Val poseidon(const Val* xs, int n) {
+        Job j;
+        j.arity = (uint8_t)n;
+        j.wave = 0;
+        for (int k = 0; k < 6; k++) j.in[k] = -1;
+        for (int k = 0; k < n; k++) {
+            j.in[k] = in_of(xs[k]);
+            if (xs[k].job >= base && jobs[(size_t)(xs[k].job - base)].wave >= j.wave) j.wave = jobs[(size_t)(xs[k].job - base)].wave + 1;
+        }
+        jobs.push_back(j);
+        Val r;
+        r.job = base + (int64_t)jobs.size() - 1;
+        return r;
+    }
+    // the queued jobs as a flush of their own; the queue starts again, numbers running on
+    std::shared_ptr<Flush> detach() {
+        auto f = std::make_shared<Flush>();
+        f->jobs.swap(jobs);
+        f->consts.swap(consts);
+        f->base = base;
+        f->fn = fn;
+        f->device = device;
+        f->prev = last;
+        base += (int64_t)f->jobs.size();
+        last = f;
+        return f;
+    }
+    void account(const Flush& f) {
+        total_jobs += f.out.size();
+        total_segments += f.segments;
+        device_ms += f.device_ms;
+        eval_s += f.eval_s;
+    }
+    // evaluates every queued job here and now; out[j] = digest of the j-th of them
+    int evaluate(std::vector<U256>& out) {
+        std::shared_ptr<Flush> f = detach();
+        f->run();
+        f->prev.reset();
+        if (f->status != HZB_OK) return fail(f->status, f->err);
+        account(*f);
+        out = f->out;
         return HZB_OK;
     }
 };
@@ -332,18 +413,20 @@ struct Tree {
         root = up(key, lf, f.sib);
         return res;
     }
-    void resolve(const std::vector<U256>& out) {
-        for (size_t i = fresh_from; i < nodes.size(); i++) {
+    // the digests of flush f into the nodes [fresh_from, nodes_end) and values [fresh_vals_from, vals_end): what existed when f was detached
+    void resolve(const Flush& f, size_t nodes_end, size_t vals_end) {
+        for (size_t i = fresh_from; i < nodes_end; i++) {
             Val& h = nodes[i].h;
-            if (h.job >= 0) { h.v = out[(size_t)h.job]; h.job = -1; }
+            if (h.job >= 0) { h.v = f.get(h.job); h.job = -1; }
         }
-        for (size_t i = fresh_vals_from; i < leaf_vals.size(); i++) {
+        for (size_t i = fresh_vals_from; i < vals_end; i++) {
             Val& h = leaf_vals[i];
-            if (h.job >= 0) { h.v = out[(size_t)h.job]; h.job = -1; }
+            if (h.job >= 0) { h.v = f.get(h.job); h.job = -1; }
         }
-        fresh_from = nodes.size();
-        fresh_vals_from = leaf_vals.size();
+        if (nodes_end > fresh_from) fresh_from = nodes_end;
+        if (vals_end > fresh_vals_from) fresh_vals_from = vals_end;
     }
+    void resolve(const Flush& f) { resolve(f, nodes.size(), leaf_vals.size()); }
 };
 
 // ---- BabyJubjub fixed-base arithmetic and signing -----------------------------------------------------------------------------------
@@ -401,7 +484,7 @@ struct hzb_db {
     Tree* state = nullptr;
     std::unordered_map<uint64_t, Leaf> leaves;
     std::unordered_map<std::string, Signer> signers;   // by private scalar
-    ~hzb_db() { delete state; }
+    ~hzb_db();
 
     bool has_leaf(uint64_t idx) const { return leaves.count(idx) || base.has(idx); }
     Leaf leaf(uint64_t idx) const {
@@ -409,13 +492,20 @@ struct hzb_db {
         if (it != leaves.end()) return it->second;
         return base.state(idx);
     }
-    int flush(Tree* extra, std::vector<U256>* out_keep) {
-        std::vector<U256> out;
-        const int st = dag.evaluate(out);
-        if (st) return st;
-        state->resolve(out);
-        if (extra) extra->resolve(out);
-        if (out_keep) out_keep->swap(out);
+    // batches whose walk is done and whose hashes are on the way (hzb_batch_build_begin), oldest first. At most one stays outstanding
+    // while the next is walked: its nodes hold job numbers, the next walk's jobs take them as inputs.
+    std::deque<hzb_batch*> outstanding;
+    int drain();   // finishes every outstanding batch
+    // the hashes queued outside a batch (direct state construction), here and now
+    int flush() {
+        if (int st = drain()) return st;
+        if (dag.jobs.empty()) return HZB_OK;
+        std::shared_ptr<Flush> f = dag.detach();
+        f->run();
+        if (f->status != HZB_OK) return fail(f->status, f->err);
+        dag.account(*f);
+        state->resolve(*f);
+        f->prev.reset();
         return HZB_OK;
     }
     const Signer& signer(const U256& k) {
@@ -483,33 +573,15 @@ U256 compute_fee(const U256& amount, unsigned sel) {
 
 }  // namespace
 
-struct hzb_batch {
-    hzb_db* db;
-    int32_t nTx, L, maxL1, F;
-    std::vector<Tx> txs;
-    std::vector<uint32_t> fee_tokens;
-    std::vector<uint64_t> fee_idxs;
-    uint32_t current_num_batch;
-    bool built = false;
-    Tree* exit_tree = nullptr;
-    std::unordered_map<uint64_t, Leaf> exit_leaves;
-    std::vector<uint8_t> nullified;
-    U256 new_state_root = u_zero(), new_exit_root = u_zero();
-    uint64_t new_last_idx = 0;
-    uint64_t jobs = 0, segments = 0;
-    double device_ms = 0.0, walk_s = 0.0, eval_s = 0.0, sign_s = 0.0;
-    ~hzb_batch() { delete exit_tree; }
-};
-
 namespace {
 
 // where the packed buffer waits for values
 struct Out {
-    uint8_t* packed;
-    uint64_t packed_bytes;
+    uint8_t* packed = nullptr;
+    uint64_t packed_bytes = 0;
     int64_t off[S_COUNT];
     uint32_t width[S_COUNT];
-    struct Fix { uint64_t at; int32_t job; };
+    struct Fix { uint64_t at; int64_t job; };
     std::vector<Fix> fixes;
 
     void put(Sig s, uint64_t index, const U256& v) {
@@ -525,6 +597,20 @@ struct Out {
         }
     }
     void put64(Sig s, uint64_t index, uint64_t v) { put(s, index, u_from64(v)); }
+    // bits [0, count) of v, one element each, from `index` on
+    void put_bits(Sig s, uint64_t index, const U256& v, unsigned count) {
+        if (off[s] < 0) return;
+        if (width[s] == 1) {
+            const uint64_t at = (uint64_t)off[s] + index;
+            if (at + count > packed_bytes) throw Reject{std::string("packed buffer too small for ") + SIG_NAMES[s]};
+            for (unsigned k = 0; k < count; k++) packed[at + k] = (uint8_t)((v.w[k >> 6] >> (k & 63)) & 1);
+        } else {
+            const uint64_t at = (uint64_t)off[s] + 32 * index;
+            if (at + 32ull * count > packed_bytes) throw Reject{std::string("packed buffer too small for ") + SIG_NAMES[s]};
+            memset(packed + at, 0, 32ull * count);
+            for (unsigned k = 0; k < count; k++) packed[at + 32ull * k] = (uint8_t)((v.w[k >> 6] >> (k & 63)) & 1);
+        }
+    }
     void put(Sig s, uint64_t index, const Val& v) {
         if (off[s] < 0) return;
         if (v.job < 0) { put(s, index, v.v); return; }
@@ -533,11 +619,52 @@ struct Out {
         if (at + 32 > packed_bytes) throw Reject{std::string("packed buffer too small for ") + SIG_NAMES[s]};
         fixes.push_back(Fix{at, v.job});
     }
-    void resolve(const std::vector<U256>& out) {
-        for (const Fix& f : fixes) u_to_bytes(out[(size_t)f.job], packed + f.at);
-        fixes.clear();
+    void resolve(const Flush& f) {
+        for (const Fix& x : fixes) u_to_bytes(f.get(x.job), packed + x.at);
+        std::vector<Fix>().swap(fixes);
     }
 };
+
+struct PendingSig { size_t tx; U256 msg, r; Pt r8; const Signer* signer; Val hm; };
+
+// what the walk of a batch leaves for its second half (build_finish): the places and values that wait for the digests
+struct BuildRun {
+    Out o;
+    uint8_t* hash_global_inputs = nullptr;
+    std::shared_ptr<Flush> fl;
+    std::vector<PendingSig> sigs;
+    std::vector<Tx> ordered;
+    std::vector<uint64_t> aux_to_v, idxs;
+    uint64_t old_last_idx = 0;
+    Val old_state_root, new_state_root, new_exit_root;
+    size_t state_nodes_end = 0, state_vals_end = 0;
+    uint64_t msg_jobs = 0, msg_segments = 0;
+    double msg_device_ms = 0.0, msg_eval_s = 0.0;
+    double t_start = 0.0, t_loop0 = 0.0, t_walk = 0.0;
+};
+
+}  // namespace
+
+struct hzb_batch {
+    hzb_db* db;
+    int32_t nTx, L, maxL1, F;
+    std::vector<Tx> txs;
+    std::vector<uint32_t> fee_tokens;
+    std::vector<uint64_t> fee_idxs;
+    uint32_t current_num_batch;
+    bool built = false;
+    std::unique_ptr<BuildRun> run;   // between hzb_batch_build_begin and _finish
+    Tree* exit_tree = nullptr;
+    std::unordered_map<uint64_t, Leaf> exit_leaves;
+    std::vector<uint8_t> nullified;
+    U256 new_state_root = u_zero(), new_exit_root = u_zero();
+    uint64_t new_last_idx = 0;
+    uint64_t jobs = 0, segments = 0;
+    double device_ms = 0.0, walk_s = 0.0, eval_s = 0.0, sign_s = 0.0;
+    ~hzb_batch() { delete exit_tree; }
+};
+
+namespace {
 
 void put_leaf(Out& o, const Sig* six, uint64_t i, const Leaf& l) {
     o.put64(six[0], i, l.token); o.put64(six[1], i, l.nonce); o.put64(six[2], i, l.sign);
@@ -551,25 +678,33 @@ void put_siblings(Out& o, Sig s, uint64_t i, int L, const Tree& tree, const std:
     }
 }
 
-int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
+int build_finish(hzb_batch* bb);
+
+// First half of a build: the walk. Every transaction's state changes, the packed inputs that are known, the hash jobs queued; at the
+// end the jobs leave as one flush -- evaluated here (threaded = false) or by a worker thread while the caller walks the next batch.
+int build_begin(hzb_batch* bb, bool threaded) {
     hzb_db* db = bb->db;
     Dag& dag = db->dag;
+    BuildRun& run = *bb->run;
+    Out& o = run.o;
     const int L = bb->L, F = bb->F, nTx = bb->nTx;
     const double t_start = now_s();
-    const double eval0 = dag.eval_s, dms0 = dag.device_ms;
-    const uint64_t jobs0 = dag.total_jobs, segs0 = dag.total_segments;
+    run.t_start = t_start;
     const U256 ETH_ANY = u_sub(u_shl(u_from64(1), 160), u_from64(1));
 
     int n_l1 = 0;
     for (const Tx& t : bb->txs) n_l1 += t.c.on_chain ? 1 : 0;
     if (n_l1 > bb->maxL1) throw Reject{"too many L1 txs"};
-    int st = db->flush(nullptr, nullptr);   // hashes queued outside a batch (direct state construction)
+    int st = dag.jobs.empty() ? HZB_OK : db->flush();   // hashes queued outside a batch (direct state construction)
     if (st) return st;
+    // one batch may be on its way while this one is walked; an older one is finished first (its digests would be out of reach)
+    while (db->outstanding.size() > 1)
+        if ((st = build_finish(db->outstanding.front())) != HZB_OK) return st;
 
     o.put64(S_oldLastIdx, 0, db->last_idx);
-    const U256 old_state_root = db->state->root_hash().v;
-    const uint64_t old_last_idx = db->last_idx;
-    o.put(S_oldStateRoot, 0, old_state_root);
+    run.old_state_root = db->state->root_hash();
+    run.old_last_idx = db->last_idx;
+    o.put(S_oldStateRoot, 0, run.old_state_root);
     o.put64(S_globalChainID, 0, db->chain_id);
     o.put64(S_currentNumBatch, 0, bb->current_num_batch);
     std::vector<uint32_t> plan(bb->fee_tokens);
@@ -584,7 +719,8 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
     bb->nullified.assign((size_t)nTx, 0);
 
     // L1 transactions first, each group in arrival order
-    std::vector<Tx> ordered;
+    std::vector<Tx>& ordered = run.ordered;
+    ordered.clear();
     for (const Tx& t : bb->txs) if (t.c.on_chain) ordered.push_back(t);
     for (const Tx& t : bb->txs) if (!t.c.on_chain) ordered.push_back(t);
     // Nonces are assigned in a pre-pass: the rq fields of atomic transactions hold the neighbour's nonce
@@ -620,9 +756,8 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
     }
     // The messages of the transactions this builder signs: one Poseidon(7) each, independent of the state -- evaluated first because
     // the deterministic nonce of a signature depends on its message
-    struct PendingSig { size_t tx; U256 msg, r; Pt r8; const Signer* signer; Val hm; };
-    std::vector<PendingSig> sigs;
-    double msg_eval_s = 0.0;
+    std::vector<PendingSig>& sigs = run.sigs;
+    sigs.clear();
     const double t_sig0 = now_s();
     {
         Dag mdag;
@@ -646,7 +781,7 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
         st = mdag.evaluate(msgs);
         if (st) return st;
         dag.total_jobs += mdag.total_jobs; dag.total_segments += mdag.total_segments; dag.device_ms += mdag.device_ms; dag.eval_s += mdag.eval_s;
-        msg_eval_s = mdag.eval_s;
+        run.msg_jobs = mdag.total_jobs; run.msg_segments = mdag.total_segments; run.msg_device_ms = mdag.device_ms; run.msg_eval_s = mdag.eval_s;
         // R8 = r * Base8 of every signature at once: the additions on a few host threads, one inversion for all (hostlib.cpp)
         std::vector<uint8_t> rk(32 * sigs.size()), rx(32 * sigs.size()), ry(32 * sigs.size());
         for (size_t q = 0; q < sigs.size(); q++) {
@@ -671,9 +806,10 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
     static const Sig LEAF3[6] = {S_tokenID3, S_nonce3, S_sign3, S_balance3, S_ay3, S_ethAddr3};
     Tx nop_tx;
     memset(&nop_tx.c, 0, sizeof(nop_tx.c));
-    std::vector<uint64_t> aux_to_v((size_t)nTx, 0);
+    std::vector<uint64_t>& aux_to_v = run.aux_to_v;
+    aux_to_v.assign((size_t)nTx, 0);
 
-    const double t_loop0 = now_s();
+    run.t_loop0 = now_s();
     for (int i = 0; i < nTx; i++) {
         Tx& tx = (size_t)i < ordered.size() ? ordered[(size_t)i] : nop_tx;
         const bool on = tx.c.on_chain != 0;
@@ -861,7 +997,7 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
         o.put(S_rqToEthAddr, u, tx.rq_eth); o.put(S_rqToBjjAy, u, tx.rq_ay);
         o.put(S_s, u, sig_s); o.put(S_r8x, u, sig_r8x); o.put(S_r8y, u, sig_r8y);
         o.put64(S_loadAmountF, u, tx.c.load_amount_f); o.put(S_fromEthAddr, u, from_eth);
-        for (unsigned k = 0; k < 256; k++) o.put64(S_fromBjjCompressed, u * 256 + k, u_bit(bjj, k));
+        o.put_bits(S_fromBjjCompressed, u * 256, bjj, 256);
         put_leaf(o, LEAF1, u, st1);
         put_leaf(o, LEAF2, u, st2);
         put_siblings(o, S_siblings1, u, L, *db->state, sib1);
@@ -881,7 +1017,8 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
     // fee transactions (src/fee-tx.circom, src/rollup-main.circom:393-431)
     o.put(S_imInitStateRootFee, 0, db->state->root_hash());
     for (int j = 0; j < F; j++) o.put(S_imFinalAccFee, (uint64_t)j, acc_fee[(size_t)j]);
-    std::vector<uint64_t> idxs(bb->fee_idxs);
+    std::vector<uint64_t>& idxs = run.idxs;
+    idxs = bb->fee_idxs;
     idxs.resize((size_t)F, 0);
     for (int j = 0; j < F; j++) {
         o.put64(S_feeIdxs, (uint64_t)j, idxs[(size_t)j]);
@@ -902,23 +1039,62 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
         put_siblings(o, S_siblings3, (uint64_t)j, L, *db->state, sib3);
         if (j < F - 1) o.put(S_imStateRootFee, (uint64_t)j, db->state->root_hash());
     }
-    const double t_walk = now_s();
-    // every hash of the batch: nLevels + 3 segments
-    std::vector<U256> out;
-    const double t_f0 = now_s();
-    st = db->flush(&exit_tree, &out);
-    if (st) return st;
-    const double t_f1 = now_s();
-    o.resolve(out);
-    const double t_f2 = now_s();
-    for (const PendingSig& ps : sigs) {
-        const U256 s = sign_s(ps.r, out[(size_t)ps.hm.job], ps.signer->k);
-        o.put(S_s, (uint64_t)ps.tx, s);
-    }
-    bb->new_state_root = db->state->root_hash().v;
-    bb->new_exit_root = exit_tree.root_hash().v;
+    run.t_walk = now_s();
+    // the state moves on from here: what this batch leaves behind is named now, valued when its hashes are in
+    run.new_state_root = db->state->root_hash();
+    run.new_exit_root = exit_tree.root_hash();
     bb->new_last_idx = db->last_idx;
     db->num_batch = bb->current_num_batch;
+    run.state_nodes_end = db->state->nodes.size();
+    run.state_vals_end = db->state->leaf_vals.size();
+    // every hash of the batch: nLevels + 3 segments
+    run.fl = dag.detach();
+    db->outstanding.push_back(bb);
+    if (threaded) {
+        std::shared_ptr<Flush> f = run.fl;
+        f->done = std::async(std::launch::async, [f] { f->run(); }).share();
+    } else {
+        run.fl->run();
+    }
+    return HZB_OK;
+}
+
+// Second half: the digests into the trees and the packed inputs, the S of the signatures, the roots, the public hash.
+int build_finish(hzb_batch* bb) {
+    hzb_db* db = bb->db;
+    Dag& dag = db->dag;
+    // in order: the trees are resolved flush by flush
+    while (!db->outstanding.empty() && db->outstanding.front() != bb)
+        if (int st = build_finish(db->outstanding.front())) return st;
+    BuildRun& run = *bb->run;
+    Out& o = run.o;
+    Flush& fl = *run.fl;
+    const int L = bb->L, F = bb->F, nTx = bb->nTx;
+    const std::vector<Tx>& ordered = run.ordered;
+    const std::vector<uint64_t>& aux_to_v = run.aux_to_v;
+    const std::vector<uint64_t>& idxs = run.idxs;
+    Tx nop_tx;
+    memset(&nop_tx.c, 0, sizeof(nop_tx.c));
+    const double t_f0 = now_s();
+    fl.wait();
+    db->outstanding.pop_front();
+    if (fl.status != HZB_OK) return fail(fl.status, fl.err);
+    dag.account(fl);
+    const double t_f1 = now_s();
+    db->state->resolve(fl, run.state_nodes_end, run.state_vals_end);
+    bb->exit_tree->resolve(fl);
+    o.resolve(fl);
+    const double t_f2 = now_s();
+    for (const PendingSig& ps : run.sigs) {
+        const U256 s = sign_s(ps.r, fl.get(ps.hm.job), ps.signer->k);
+        o.put(S_s, (uint64_t)ps.tx, s);
+    }
+    auto value = [&](const Val& v) { return v.job >= 0 ? fl.get(v.job) : v.v; };
+    const U256 old_state_root = value(run.old_state_root);
+    const uint64_t old_last_idx = run.old_last_idx;
+    bb->new_state_root = value(run.new_state_root);
+    bb->new_exit_root = value(run.new_exit_root);
+    uint8_t* hash_global_inputs = run.hash_global_inputs;
 
     // the public hash (src/hash-inputs.circom:117-184)
     if (hash_global_inputs) {
@@ -952,18 +1128,39 @@ int build(hzb_batch* bb, Out& o, uint8_t* hash_global_inputs) {
         u_to_bytes(h, hash_global_inputs);
     }
     if (getenv("HZB_TIMING"))
-        fprintf(stderr, "hzb build: pre-walk+sign %.2f ms, walk loop %.2f, flush %.2f (evaluator %.2f), resolve %.2f, tail (S, public hash) %.2f\n", (t_loop0 - t_start) * 1e3,
-                (t_walk - t_loop0) * 1e3, (t_f1 - t_f0) * 1e3, (dag.eval_s - eval0 - msg_eval_s) * 1e3, (t_f2 - t_f1) * 1e3, (now_s() - t_f2) * 1e3);
+        fprintf(stderr, "hzb build: pre-walk+sign %.2f ms, walk loop %.2f, wait for the flush %.2f (evaluator %.2f), resolve %.2f, tail (S, public hash) %.2f\n",
+                (run.t_loop0 - run.t_start) * 1e3, (run.t_walk - run.t_loop0) * 1e3, (t_f1 - t_f0) * 1e3, fl.eval_s * 1e3, (t_f2 - t_f1) * 1e3, (now_s() - t_f2) * 1e3);
     bb->built = true;
-    bb->jobs = dag.total_jobs - jobs0;
-    bb->segments = dag.total_segments - segs0;
-    bb->device_ms = dag.device_ms - dms0;
-    bb->eval_s = dag.eval_s - eval0;
-    bb->walk_s = (t_walk - t_start) - msg_eval_s;   // the walk proper: bookkeeping, nonces and R8 of the signatures
+    bb->jobs = fl.out.size() + run.msg_jobs;
+    bb->segments = fl.segments + run.msg_segments;
+    bb->device_ms = fl.device_ms + run.msg_device_ms;
+    bb->eval_s = fl.eval_s + run.msg_eval_s;
+    bb->walk_s = (run.t_walk - run.t_start) - run.msg_eval_s;   // the walk proper: bookkeeping, nonces and R8 of the signatures
+    fl.prev.reset();   // nothing of the flush before it is needed through this one any more
+    if (dag.last.get() == &fl && db->outstanding.empty()) dag.last.reset();   // every node is a value again: no number refers to it
+    bb->run.reset();
     return HZB_OK;
 }
 
 }  // namespace
+
+int hzb_db::drain() {
+    while (!outstanding.empty()) {
+        hzb_batch* b = outstanding.front();
+        try {
+            if (int st = build_finish(b)) { poisoned = true; return st; }
+        } catch (const Reject& r) {
+            poisoned = true;
+            return fail(HZB_ERR_REJECTED, r.msg);
+        }
+    }
+    return HZB_OK;
+}
+hzb_db::~hzb_db() {
+    for (hzb_batch* b : outstanding)   // their worker threads read flushes the batches own: let them end
+        if (b->run && b->run->fl) b->run->fl->wait();
+    delete state;
+}
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -975,6 +1172,7 @@ static const char* const POISONED = "the database was left half-updated by a bat
 hzb_db* hzb_db_clone(const hzb_db* src) {
     if (!src) { fail(HZB_ERR_ARG, "hzb_db_clone: null database"); return nullptr; }
     if (src->poisoned) { fail(HZB_ERR_REJECTED, POISONED); return nullptr; }
+    if (const_cast<hzb_db*>(src)->drain() != HZB_OK) return nullptr;   // a batch on its way: the copy starts from values, not from job numbers
     hzb_db* db = new hzb_db();
     db->chain_id = src->chain_id; db->last_idx = src->last_idx; db->num_batch = src->num_batch;
     db->dag = src->dag;
@@ -1046,7 +1244,7 @@ int hzb_db_get_account(hzb_db* db, uint64_t idx, hzb_leaf* out) {
 int hzb_db_state_root(hzb_db* db, uint8_t* out) {
     if (!db || !out) return fail(HZB_ERR_ARG, "hzb_db_state_root: null argument");
     if (db->poisoned) return fail(HZB_ERR_REJECTED, POISONED);
-    const int st = db->flush(nullptr, nullptr);
+    const int st = db->flush();
     if (st) return st;
     u_to_bytes(db->state->root_hash().v, out);
     return HZB_OK;
@@ -1062,7 +1260,22 @@ hzb_batch* hzb_batch_create(hzb_db* db, int32_t n_tx, int32_t n_levels, int32_t 
     b->current_num_batch = db->num_batch + 1;
     return b;
 }
-void hzb_batch_destroy(hzb_batch* b) { delete b; }
+void hzb_batch_destroy(hzb_batch* b) {
+    if (!b) return;
+    if (b->run && b->run->fl) {   // begun, never finished: the state's nodes must not keep job numbers nobody resolves
+        bool queued = false;
+        for (hzb_batch* q : b->db->outstanding) queued = queued || q == b;
+        if (queued) {
+            try {
+                if (build_finish(b) != HZB_OK) b->db->poisoned = true;
+            } catch (const Reject&) { b->db->poisoned = true; }
+            for (auto it = b->db->outstanding.begin(); it != b->db->outstanding.end(); ++it)
+                if (*it == b) { b->db->outstanding.erase(it); break; }
+        }
+        if (b->run && b->run->fl) b->run->fl->wait();
+    }
+    delete b;
+}
 int hzb_batch_add_tx(hzb_batch* b, const hzb_tx* tx) {
     if (!b || !tx) return fail(HZB_ERR_ARG, "hzb_batch_add_tx: null argument");
     if ((int)b->txs.size() >= b->nTx) return fail(HZB_ERR_REJECTED, "batch full");
@@ -1230,25 +1443,45 @@ int hzb_batch_add_fee_idx(hzb_batch* b, uint64_t idx) {
     b->fee_idxs.push_back(idx);
     return HZB_OK;
 }
-int hzb_batch_build(hzb_batch* b, int32_t n_signals, const char* const* names, const uint64_t* offsets, const uint32_t* widths, uint8_t* packed, uint64_t packed_bytes,
-                    uint8_t* hash_global_inputs) {
-    if (!b || !names || !offsets || !widths || !packed || n_signals < 0) return fail(HZB_ERR_ARG, "hzb_batch_build: null argument");
-    if (b->built) return fail(HZB_ERR_ARG, "hzb_batch_build: the batch has been built");
+static int batch_build_begin(hzb_batch* b, int32_t n_signals, const char* const* names, const uint64_t* offsets, const uint32_t* widths, uint8_t* packed,
+                             uint64_t packed_bytes, uint8_t* hash_global_inputs, bool threaded, const char* who) {
+    if (!b || !names || !offsets || !widths || !packed || n_signals < 0) return fail(HZB_ERR_ARG, std::string(who) + ": null argument");
+    if (b->built || b->run) return fail(HZB_ERR_ARG, std::string(who) + ": the batch has been built");
     if (b->db->poisoned) return fail(HZB_ERR_REJECTED, POISONED);
-    Out o;
+    b->run.reset(new BuildRun());
+    Out& o = b->run->o;
     o.packed = packed;
     o.packed_bytes = packed_bytes;
+    b->run->hash_global_inputs = hash_global_inputs;
     for (int s = 0; s < S_COUNT; s++) { o.off[s] = -1; o.width[s] = 32; }
     for (int i = 0; i < n_signals; i++) {
         int s = 0;
         while (s < S_COUNT && strcmp(SIG_NAMES[s], names[i]) != 0) s++;
-        if (s == S_COUNT) return fail(HZB_ERR_ARG, std::string("hzb_batch_build: the batch builder does not produce the input signal ") + names[i]);
-        if (widths[i] != 32 && widths[i] != 1) return fail(HZB_ERR_ARG, std::string("hzb_batch_build: element width of ") + names[i] + " must be 32 or 1");
+        if (s == S_COUNT) { b->run.reset(); return fail(HZB_ERR_ARG, std::string(who) + ": the batch builder does not produce the input signal " + names[i]); }
+        if (widths[i] != 32 && widths[i] != 1) { b->run.reset(); return fail(HZB_ERR_ARG, std::string(who) + ": element width of " + names[i] + " must be 32 or 1"); }
         o.off[s] = (int64_t)offsets[i];
         o.width[s] = widths[i];
     }
     try {
-        const int st = build(b, o, hash_global_inputs);
+        const int st = build_begin(b, threaded);
+        if (st != HZB_OK) { b->db->poisoned = true; b->run.reset(); }
+        return st;
+    } catch (const Reject& r) {
+        b->db->poisoned = true;
+        b->run.reset();
+        return fail(HZB_ERR_REJECTED, r.msg);
+    } catch (const std::bad_alloc&) {
+        b->db->poisoned = true;
+        b->run.reset();
+        return fail(HZB_ERR_ARG, std::string(who) + ": out of memory");
+    }
+}
+static int batch_build_finish(hzb_batch* b, const char* who) {
+    if (!b) return fail(HZB_ERR_ARG, std::string(who) + ": null batch");
+    if (b->built) return HZB_OK;
+    if (!b->run || !b->run->fl) return fail(HZB_ERR_ARG, std::string(who) + ": the batch's build has not begun");
+    try {
+        const int st = build_finish(b);
         if (st != HZB_OK) b->db->poisoned = true;   // the evaluator failed after the walk had updated the state
         return st;
     } catch (const Reject& r) {
@@ -1256,9 +1489,19 @@ int hzb_batch_build(hzb_batch* b, int32_t n_signals, const char* const* names, c
         return fail(HZB_ERR_REJECTED, r.msg);
     } catch (const std::bad_alloc&) {
         b->db->poisoned = true;
-        return fail(HZB_ERR_ARG, "hzb_batch_build: out of memory");
+        return fail(HZB_ERR_ARG, std::string(who) + ": out of memory");
     }
 }
+int hzb_batch_build(hzb_batch* b, int32_t n_signals, const char* const* names, const uint64_t* offsets, const uint32_t* widths, uint8_t* packed, uint64_t packed_bytes,
+                    uint8_t* hash_global_inputs) {
+    if (int st = batch_build_begin(b, n_signals, names, offsets, widths, packed, packed_bytes, hash_global_inputs, false, "hzb_batch_build")) return st;
+    return batch_build_finish(b, "hzb_batch_build");
+}
+int hzb_batch_build_begin(hzb_batch* b, int32_t n_signals, const char* const* names, const uint64_t* offsets, const uint32_t* widths, uint8_t* packed, uint64_t packed_bytes,
+                          uint8_t* hash_global_inputs) {
+    return batch_build_begin(b, n_signals, names, offsets, widths, packed, packed_bytes, hash_global_inputs, true, "hzb_batch_build_begin");
+}
+int hzb_batch_build_finish(hzb_batch* b) { return batch_build_finish(b, "hzb_batch_build_finish"); }
 int hzb_batch_roots(const hzb_batch* b, uint8_t* new_state_root, uint8_t* new_exit_root, uint64_t* new_last_idx) {
     if (!b || !b->built) return fail(HZB_ERR_ARG, "hzb_batch_roots: the batch has not been built");
     if (new_state_root) u_to_bytes(b->new_state_root, new_state_root);

@@ -97,6 +97,7 @@ struct SmtArgs {
     uint32_t upi;
     uint32_t skip_mod;            // != 0: units u with u % skip_mod == skip_mod - 1 belong to another launch of the step (early tail)
     uint32_t bg_external;         // != 0: the constant blocks of the structurally empty levels are k_smt_bg's this step, not k_smt's
+    const Fr* pos3_dense;         // the dense constants of poseidon_quad.h (C[195], M1[9], M2[9]); NULL: no latency form for this launch
     SmtProcDesc p[2];
 };
 
@@ -203,7 +204,12 @@ hipError_t launch_gadget(int tmpl, const GadgetArgs& a, hipStream_t s);
 hipError_t launch_fr_sqrt(const void* d_a, void* d_out, size_t n, hipStream_t s);   // eddsa_kernels.hip (hz_fr_ops HZ_FR_SQRT)
 hipError_t launch_ay_sign_2_ax_main(const GadgetArgs& a, const EddsaOff& o, hipStream_t s);   // eddsa_kernels.hip (shares the curve code)
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
+#ifndef HZ_SMT_LAT_MAX
+#define HZ_SMT_LAT_MAX 4096u   // units per launch up to which k_smt runs in its latency form (a quad of lanes per chain)
+#endif
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s);
+size_t pos3_dense_bytes();
+hipError_t upload_pos3_dense(Fr* dst);   // synchronous; dst holds pos3_dense_bytes()
 hipError_t launch_smt_bg(const SmtArgs& a, unsigned long long* rows_written, hipStream_t s);
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
 hipError_t launch_da_mask(const RtxBackArgs& a, hipStream_t s);   // RollupMain phase H alone (amount bits of L1L2TxData times 1 - isAmountNullified), every unit

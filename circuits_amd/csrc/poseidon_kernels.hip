@@ -166,10 +166,17 @@ extern "C" hz_status hz_poseidon_dag(int32_t device, uint8_t* vals, uint64_t n_v
     // then every Merkle hash): buffers that only grow, a stream and two events of its own per device -- a first version allocated,
     // freed and synchronised the whole device on every call (a third of the evaluator's 6.4 ms per 2048-transaction batch).
     struct Resident { DevBuf vals, in, out; hipStream_t s = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; std::mutex mu; };
-    static Resident resident[16];
+    // Two sets per device: a batch builder's worker thread evaluates one batch's Merkle hashes while the thread that walks the next
+    // batch evaluates its signatures' messages (hzb_batch_build_begin) -- neither waits for the other's whole evaluation.
+    static Resident resident[16][2];
     if (device < 0 || device >= 16) return set_err(HZ_ERR_ARG, "hz_poseidon_dag: device %d", device);
-    Resident& R = resident[device];
-    std::lock_guard<std::mutex> lock(R.mu);
+    std::unique_lock<std::mutex> lock(resident[device][0].mu, std::try_to_lock);
+    int slot = 0;
+    if (!lock.owns_lock()) {
+        lock = std::unique_lock<std::mutex>(resident[device][1].mu);
+        slot = 1;
+    }
+    Resident& R = resident[device][slot];
     if (!R.s) {
         HZ_HIP(hipStreamCreateWithFlags(&R.s, hipStreamNonBlocking));
         HZ_HIP(hipEventCreate(&R.e0));

@@ -57,5 +57,14 @@ __device__ __forceinline__ Fr poseidon3_zero_level(const UnitIO& io, uint32_t si
     return h;
 }
 
+// the same block from the four lanes of a quad, a quarter each (the latency form of k_smt: every lane of the quad holds the same unit)
+__device__ __forceinline__ void poseidon3_zero_level_quad(const UnitIO& io, uint32_t sig0, uint32_t lane_in_quad) {
+    for (uint32_t s = lane_in_quad; s < 243; s += 4) {
+        Fc c;
+#pragma unroll
+        for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[s][q];
+        store_fr(io.addr(sig0 + s), c);
+    }
+}
 
 }  // namespace hz

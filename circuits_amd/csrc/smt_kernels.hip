@@ -8,7 +8,9 @@
 #include <stdlib.h>
 #include "tx_dev.h"
 #include "kernels.h"
+#include <vector>
 #include "smt_dev.h"
+#include "poseidon_quad.h"
 
 namespace hz {
 
@@ -169,9 +171,15 @@ __device__ __forceinline__ bool smt_m_is_zero(const Scratch& sc, const SmtProcDe
 #ifndef HZ_SMT_BLOCK
 #define HZ_SMT_BLOCK 128
 #endif
-__global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_smt(const SmtArgs a) {
+// LAT (round 5): the latency form for small launches -- a QUAD of lanes per (unit, chain). All four lanes walk the chain's logic with the
+// same values (the three that are not the leader store the same bytes to the same places and report nothing); the level hash itself is
+// poseidon3_quad (poseidon_quad.h): the state over the lanes of the quad, 0.63 x the time of a dependent hash. The constant blocks of
+// empty levels are stored where the chain passes them, a quarter per lane (no BgZero: a launch this small is nowhere near the store roofline).
+template <bool LAT>
+__global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : 2))) void k_smt(const SmtArgs a) {
     const Fr* K3 = poseidon_consts_w<3>();
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t li = LAT ? tidx >> 2 : tidx, qj = LAT ? (threadIdx.x & 3u) : 0u;
     if (li >= (a.ucnt ? a.ucnt : a.n_units)) return;
     const uint32_t i = a.u0 + li * (a.ustride > 1 ? a.ustride : 1u);
     // the units another launch of this step evaluates (the last transaction of every batch: the early HashInputs chain, ctx.hip)
@@ -181,7 +189,8 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
     const SmtProcDesc& P = a.p[pi];
     const SmtProcOff& o = P.o;
     const int n = (int)a.n_levels;
-    const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+    UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+    io.mute = qj != 0;
     const Scratch sc{a.scratch, a.n_units, i};
     const Fr one = fr_one(), zero = fr_zero();
     const Fr fnc0 = sc.get(P.sc_fnc0), fnc1 = sc.get(P.sc_fnc1), isOld0 = sc.get(P.sc_isold0);
@@ -291,8 +300,9 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
     for (int k = n - 1; k >= 0; k--) {
         const uint32_t lv = o.levels + LV_SIZE * k;
         if (thr_wave > 0 && (uint32_t)k > thr_wave) {
-            // dead level: nothing but zeros beside its (constant) hash block, which a hashing level stores
+            // dead level: nothing but zeros beside its (constant) hash block, which a hashing level stores (the latency form: here)
             const Fc z0 = fc_zero();
+            if (LAT) poseidon3_zero_level_quad(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH), qj);
             if (!new_side) {
                 io.put_c(lv + LV_OLDSW_AUX, z0); io.put_c(lv + LV_AUX0, z0); io.put_c(lv + LV_OLDROOT, z0);
             } else {
@@ -329,12 +339,23 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(2)
         Fr h;
         if (thr_wave > 0 && (uint32_t)k >= thr_wave) {
             // structurally empty for the whole wavefront: its block is stored by one of the hashing levels (below), only the digest here
+            if (LAT) poseidon3_zero_level_quad(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH), qj);
 #pragma unroll
             for (int q = 0; q < 9; q++) h.v[q] = HZ_POSEIDON3_ZERO_HASH[q];
+        } else if (LAT) {
+            const uint32_t hs = lv + (new_side ? LV_NEWHASH : LV_OLDHASH);
+            if (__all(fr_is_zero(hin[0]) && fr_is_zero(hin[1]))) {
+                poseidon3_zero_level_quad(io, hs, qj);
+#pragma unroll
+                for (int q = 0; q < 9; q++) h.v[q] = HZ_POSEIDON3_ZERO_HASH[q];
+            } else {
+                const Pos3Dense KD{a.pos3_dense, a.pos3_dense + 195, a.pos3_dense + 204};
+                h = poseidon3_quad(hin[0], hin[1], KD, WitOut{a.base, a.n_units, i}, hs, qj);
+            }
         } else {
             // hashing level k (< thr_wave) also stores the blocks of empty levels thr + [k E / H, (k+1) E / H), E = n - thr, H = thr
             BgZero bg{a.base, a.n_units, i, o.levels + (new_side ? LV_NEWHASH : LV_OLDHASH), 0, 0, 0, 0};
-            if (thr_wave > 0 && !a.bg_external) {   // (bg_external: k_smt_bg stores the empty levels' blocks beside this kernel)
+            if (thr_wave > 0 && !a.bg_external && !LAT) {   // (bg_external: k_smt_bg stores the empty levels' blocks beside this kernel)
                 const uint32_t E = (uint32_t)n - thr_wave;
                 bg.j = thr_wave + (uint32_t)k * E / thr_wave;
                 bg.j_end = thr_wave + ((uint32_t)k + 1) * E / thr_wave;
@@ -429,11 +450,40 @@ hipError_t launch_hash4(const Hash4Args& a, hipStream_t s) {
 // One launch for the whole chain (round 1 launched it in chunks of 11 levels so that workgroup slots turned over during its store
 // phase; with the empty-level blocks stored in the shadow of the hashing levels one launch is as good for the step and better for
 // the kernel itself: no per-chunk prologue, no tail of a chunk waiting for its slowest wavefront).
+namespace pos3host {
+#include "gen/poseidon_consts_host.inc"
+}
+size_t pos3_dense_bytes() { return (size_t)HZ_POS3_DENSE_FRS * sizeof(Fr); }
+hipError_t upload_pos3_dense(Fr* dst) {
+    static const std::vector<Fr> tab = [] {
+        auto mont = [](const uint64_t* w) {
+            Fc c;
+            for (int i = 0; i < 4; i++) { c.v[2 * i] = (uint32_t)w[i]; c.v[2 * i + 1] = (uint32_t)(w[i] >> 32); }
+            return fr_from_canon(c);
+        };
+        Fr r2;
+        for (int i = 0; i < 9; i++) r2.v[i] = fr_r2(i);
+        std::vector<Fr> t(HZ_POS3_DENSE_FRS);
+        for (int i = 0; i < 195; i++) t[i] = mont(pos3host::HZ_POSEIDON_HC_T3[i]);
+        for (int i = 0; i < 9; i++) {
+            t[195 + i] = mont(pos3host::HZ_POSEIDON_HM_T3[i]);   // M R
+            t[204 + i] = fr_mul(t[195 + i], r2);                 // M R * R^2 / R = M R^2: times a canonical a, over R: (M a) R
+        }
+        return t;
+    }();
+    return hipMemcpy(dst, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice);
+}
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s) {
     const uint32_t nl = a.ucnt ? a.ucnt : a.n_units;
+    if (a.pos3_dense && nl <= HZ_SMT_LAT_MAX) {   // the latency form: a quad of lanes per (unit, chain)
+        dim3 g(((size_t)nl * 4 + HZ_SMT_BLOCK - 1) / HZ_SMT_BLOCK);
+        g.y = 2 * a.n_proc;
+        hipLaunchKernelGGL(k_smt<true>, g, dim3(HZ_SMT_BLOCK), 0, s, a);
+        return hipGetLastError();
+    }
     dim3 g((nl + HZ_SMT_BLOCK - 1) / HZ_SMT_BLOCK);
     g.y = 2 * a.n_proc;
-    hipLaunchKernelGGL(k_smt, g, dim3(HZ_SMT_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_smt<false>, g, dim3(HZ_SMT_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

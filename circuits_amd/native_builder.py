@@ -84,6 +84,8 @@ def host_lib():
         c.hzb_batch_add_token.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         c.hzb_batch_add_fee_idx.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         c.hzb_batch_build.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        c.hzb_batch_build_begin.argtypes = c.hzb_batch_build.argtypes
+        c.hzb_batch_build_finish.argtypes = [ctypes.c_void_p]
         c.hzb_batch_roots.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 3
         c.hzb_batch_exit_proof.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         c.hzb_batch_tx_flags.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
@@ -302,6 +304,25 @@ class NativeBatchBuilder:
         self.hash_global_inputs = _int(hgi)
         return (buf.raw if buf is not None else out), self.hash_global_inputs
 
+    def build_begin(self, layout, out=None):
+        """first half of build() (hzb_batch_build_begin): the walk; the batch's Merkle hashes are evaluated by a worker thread while the
+        caller goes on -- typically to the next batch, on this database or another. build_finish() completes it."""
+        n, names, offs, widths, total = layout if len(layout) == 5 else layout_tables(layout)
+        self._buf = None
+        if out is None:
+            self._buf = ctypes.create_string_buffer(total)
+            out = ctypes.addressof(self._buf)
+        else:
+            ctypes.memset(out, 0, total)
+        self._out, self._hgi = out, (ctypes.c_uint8 * 32)()
+        _check(self.c.hzb_batch_build_begin(self.h, n, names, offs, widths, out, total, self._hgi))
+
+    def build_finish(self):
+        """-> (packed, hashGlobalInputs) as build()"""
+        _check(self.c.hzb_batch_build_finish(self.h))
+        self.hash_global_inputs = _int(self._hgi)
+        return (self._buf.raw if self._buf is not None else self._out), self.hash_global_inputs
+
     def get_hash_inputs(self):
         return self.hash_global_inputs
 
@@ -332,7 +353,7 @@ class NativeBatchBuilder:
 
 
 def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, first_idx=256,
-                           base=None, out=None, native_recipe=False):
+                           base=None, out=None, native_recipe=False, begin_only=False):
     """builder.synthetic_batch's recipe (reference tools/generate-input.js:61-109) on the native builder: the same seeded
     transactions, hence the same circuit inputs byte for byte. Pre-population goes through a DenseState (built here when `base` is None
     and n_accounts is a power of two >= 16, as synthetic_batch(dense=True) does). Returns (batch, packed, hashGlobalInputs)."""
@@ -356,8 +377,11 @@ def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455
         l1e = b"".join(a.eth_addr.to_bytes(32, "little") for a in keys)
         sk = b"".join(a.k.to_bytes(32, "little") for a in bkeys)
         _check(bb.c.hzb_batch_add_synthetic(bb.h, ctypes.c_uint64(seed), exits, n_keys, l1b, l1e, len(bkeys), sk))
-        packed, hgi = bb.build(layout, out)
         bb._db_keep = db
+        if begin_only:   # the caller finishes it (build_finish) after it has begun the next batch
+            bb.build_begin(layout, out)
+            return bb
+        packed, hgi = bb.build(layout, out)
         return bb, packed, hgi
     # the transactions as columns of one hzb_tx array (one hzb_batch_add_txs call); 32-byte fields as rows of bytes
     col = {k: [0] * n_tx for k in ("from_idx", "to_idx", "amount_f", "load_amount_f", "nonce", "user_fee", "on_chain", "flags")}
@@ -405,6 +429,9 @@ def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455
     bb.add_txs(arr)
     bb.add_token(1)
     bb.add_fee_idx(pick())
-    packed, hgi = bb.build(layout, out)
     bb._db_keep = db
+    if begin_only:
+        bb.build_begin(layout, out)
+        return bb
+    packed, hgi = bb.build(layout, out)
     return bb, packed, hgi

@@ -97,6 +97,17 @@ int hzb_batch_add_fee_idx(hzb_batch* b, uint64_t idx);
  * builder does not know is an error. hash_global_inputs receives the value the circuit's public output must take. */
 int hzb_batch_build(hzb_batch* b, int32_t n_signals, const char* const* names, const uint64_t* offsets, const uint32_t* widths, uint8_t* packed, uint64_t packed_bytes,
                     uint8_t* hash_global_inputs);
+/* The same in two halves, for a caller that builds batch after batch: _begin walks the batch (state changes, every packed input that
+ * is no hash, the hash jobs) and hands the jobs to a worker thread; _finish waits for the digests and completes the packed inputs, the
+ * signatures' S, the roots and hash_global_inputs. Between the two the caller may create, fill and _begin the NEXT batch -- on the
+ * same database (the state the next batch sees is complete: Merkle nodes whose hash is on its way are named by job number, and the
+ * next batch's jobs take those numbers as inputs) or on another one -- so the device evaluates batch N's Merkle hashes while the host
+ * walks batch N + 1. `packed` and `hash_global_inputs` must stay valid until _finish returns. One batch per database may be on its
+ * way while another is walked; _begin finishes an older one first, every other call on the database or on an unfinished batch finishes
+ * what is outstanding (hzb_db_state_root, hzb_db_clone, hzb_batch_destroy ...). The packed bytes are those of hzb_batch_build. */
+int hzb_batch_build_begin(hzb_batch* b, int32_t n_signals, const char* const* names, const uint64_t* offsets, const uint32_t* widths, uint8_t* packed,
+                          uint64_t packed_bytes, uint8_t* hash_global_inputs);
+int hzb_batch_build_finish(hzb_batch* b);
 /* after build: roots, counters, and the exit leaves for Withdraw (reference test/withdraw.test.js:39-157) */
 int hzb_batch_roots(const hzb_batch* b, uint8_t* new_state_root, uint8_t* new_exit_root, uint64_t* new_last_idx);
 int hzb_batch_exit_proof(hzb_batch* b, uint64_t idx, hzb_leaf* leaf, uint8_t* siblings /* [n_levels + 1][32] */, int32_t* n_siblings);

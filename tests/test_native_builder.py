@@ -380,3 +380,106 @@ def test_hip_native_builder_with_the_device_evaluator(hz):
         w.run()
         done += 1
     assert 1 <= done <= 4
+
+
+def _chain_batches(db, base, n_batches, shape, layout, pipelined, rng_seed=91):
+    """consecutive batches on ONE database: deposits that create accounts, signed transfers between accounts of the dense state and the
+    accounts earlier batches created, exits; pipelined: batch k + 1 is walked before batch k is finished"""
+    import random
+    nTx, L, maxL1, F = shape
+    rng = random.Random(rng_seed)
+    keys = [B.Account(5000 + i) for i in range(4)]
+    bkeys = base.keys()
+    owner = lambda idx: bkeys[int(base.key_idx[idx - base.first_idx])]   # noqa: E731
+    made, out, live = [], [], []
+    for k in range(n_batches):
+        bb = db.build_batch(nTx, L, maxL1, F)
+        bb.add_token(1)
+        bb.add_fee_idx(base.first_idx + 1)
+        for q in range(2):
+            a = keys[(k + q) % 4]
+            bb.add_tx({"fromIdx": 0, "loadAmountF": B.fix2float(1000 * (k + 1)), "tokenID": 1, "fromBjjCompressed": a.bjj_compressed, "fromEthAddr": a.eth_addr,
+                       "toIdx": 0, "onChain": True})
+        for q in range(nTx - 4):
+            frm = base.first_idx + rng.randrange(base.N)
+            to = base.first_idx + rng.randrange(base.N)
+            tx = {"fromIdx": frm, "toIdx": B.EXIT_IDX if q == 0 else to, "amount": 3 + q, "tokenID": 1, "userFee": 126, "signer": owner(frm)}
+            bb.add_tx(tx)
+        if pipelined:
+            bb.build_begin(layout)
+            live.append(bb)
+            if len(live) > 1:
+                done = live.pop(0)
+                out.append(done.build_finish() + (done.roots(),))
+        else:
+            out.append(bb.build(layout) + (bb.roots(),))
+        made.append(bb)
+    for bb in live:
+        out.append(bb.build_finish() + (bb.roots(),))
+    return out, made
+
+
+def test_pipelined_builds_on_one_database_give_the_bytes_of_one_build_after_the_other():
+    """hzb_batch_build_begin / _finish: batch k + 1 is walked while batch k's hashes are evaluated by a worker thread -- Merkle nodes named
+    by job number across the two flushes. Five consecutive batches on one database, against the same five built one after the other:
+    packed inputs, hashGlobalInputs, roots, the state root afterwards and an exit proof of every batch."""
+    shape = (12, 16, 4, 2)
+    layout = make_layout(shape[0], shape[1], shape[3])
+    base = B.DenseState.build(5, seed=21, first_idx=256)
+    db_a, db_b = NB.NativeRollupDB(base=base), NB.NativeRollupDB(base=base)
+    seq, made_a = _chain_batches(db_a, base, 5, shape, layout, pipelined=False)
+    pip, made_b = _chain_batches(db_b, base, 5, shape, layout, pipelined=True)
+    assert len(seq) == len(pip) == 5
+    for k, (a, b) in enumerate(zip(seq, pip)):
+        assert a[1] == b[1] and a[2] == b[2], "batch %d: public hash / roots" % k
+        assert a[0] == b[0], "batch %d: packed inputs" % k
+    assert len({a[1] for a in seq}) == 5 and seq[0][2][0] != seq[1][2][0]
+    assert db_a.state_root == db_b.state_root == seq[-1][2][0]
+    for ba, bp in zip(made_a, made_b):
+        frm = None
+        for idx in range(base.first_idx, base.first_idx + base.N):
+            try:
+                pa = ba.exit_proof(idx)
+            except NB.BuilderError:
+                continue
+            frm = idx
+            assert pa == bp.exit_proof(idx)
+            break
+        assert frm is not None
+    # calls that need values finish what is outstanding: a clone taken while a batch is on its way, a batch destroyed unfinished
+    bb = db_b.build_batch(*shape)
+    bb.add_token(1)
+    bb.add_tx({"fromIdx": 0, "loadAmountF": B.fix2float(77), "tokenID": 1, "fromBjjCompressed": B.Account(1).bjj_compressed, "fromEthAddr": B.Account(1).eth_addr,
+               "toIdx": 0, "onChain": True})
+    bb.build_begin(layout)
+    cl = db_b.clone()
+    packed, hgi = bb.build_finish()
+    assert cl.state_root == bb.roots()[0] == db_b.state_root
+    bc = db_a.build_batch(*shape)
+    bc.add_token(1)
+    bc.add_tx({"fromIdx": 0, "loadAmountF": B.fix2float(77), "tokenID": 1, "fromBjjCompressed": B.Account(1).bjj_compressed, "fromEthAddr": B.Account(1).eth_addr,
+               "toIdx": 0, "onChain": True})
+    assert bc.build(layout) == (packed, hgi)
+    bd = db_a.build_batch(*shape)
+    bd.add_token(1)
+    bd.build_begin(layout)
+    bd.close()   # unfinished
+    be = db_b.build_batch(*shape)
+    be.add_token(1)
+    be.build(layout)
+    assert db_a.state_root == db_b.state_root
+
+
+@pytest.mark.gpu
+def test_hip_pipelined_builds_on_one_database_through_the_device_evaluator(hz):
+    """the same chain of batches with hz_poseidon_dag as the evaluator (two resident sets per device: the worker thread's Merkle hashes of
+    batch k beside the walking thread's message hashes of batch k + 1) against the host Poseidon, one build after the other"""
+    shape = (48, 16, 4, 2)
+    layout = make_layout(shape[0], shape[1], shape[3])
+    base = B.DenseState.build(6, seed=23, first_idx=256)
+    db_a, db_b = NB.NativeRollupDB(base=base), NB.NativeRollupDB(base=base, device=0)
+    seq, _ = _chain_batches(db_a, base, 6, shape, layout, pipelined=False)
+    pip, made = _chain_batches(db_b, base, 6, shape, layout, pipelined=True)
+    assert [a[:2] for a in seq] == [b[:2] for b in pip] and [a[2] for a in seq] == [b[2] for b in pip]
+    assert all(m.stats()["device_ms"] > 0 for m in made)
+    assert db_a.state_root == db_b.state_root
