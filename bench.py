@@ -725,8 +725,9 @@ def main():
     ap.add_argument("--withdraw-per-launch", type=int, default=1 << 16)
     ap.add_argument("--withdraw-leaves", type=int, default=1 << 16, help="leaves of the exit tree the withdrawals are drawn from (SURVEY 8d: 2^16)")
     ap.add_argument("--latency-scheduling", action="store_true",
-                    help="with --inflight 1: HZ_FLAG_LATENCY contexts (concurrent kernel chains on disjoint compute units); for the "
-                         "single-batch latency figure: --batches-per-launch 1 --inflight 1 --latency-scheduling")
+                    help="HZ_FLAG_LATENCY contexts (their concurrent kernel chains on CU-masked streams of their own): the latency regime, "
+                         "one to four batches per launch; single-batch latency: --batches-per-launch 1 --inflight 1 --latency-scheduling, "
+                         "its throughput: --batches-per-launch 1 --inflight 4 --latency-scheduling")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon-BN254/sec secondary metric")
     ap.add_argument("--no-withdraw", action="store_true", help="skip the config-5 (withdraw) secondary line")
@@ -848,7 +849,7 @@ def main():
     ctxs, streams = [], []
     for k in range(inflight):
         c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=Bp,
-                  flags=2 if (args.latency_scheduling and inflight == 1) else 0)
+                  flags=2 if args.latency_scheduling else 0)
         ctxs.append(c)
         streams.append(torch.cuda.Stream(device=local))
     if os.environ.get("HZ_BENCH_OWN_STREAMS") == "1":   # experiment: the contexts' own streams (what a host without torch passes: NULL)
@@ -1032,6 +1033,21 @@ def main():
     # two contexts in flight, up to the headline's own point; (iii) what binds at each point.
     sweep, single = None, None
     if world == 1 and not args.no_sweep:
+        def flagged_point(bp, nctx):
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", "12", "--warmup", "3", "--batches-per-launch", str(bp), "--inflight", str(nctx),
+                   "--distinct-batches", "4", "--cpu-sample", "0", "--no-withdraw", "--no-e2e", "--no-poseidon", "--no-export", "--no-node", "--no-deep-state",
+                   "--no-sweep", "--no-shard", "--no-verify", "--latency-scheduling"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
+                if r.returncode != 0 or not ln:
+                    return {"contexts": nctx, "error": "child exited with %d: %s" % (r.returncode, (r.stderr or "").strip().splitlines()[-1][:200] if r.stderr else "")}
+                d = json.loads(ln[-1])
+                return {"contexts": nctx, "ms_per_step": d["ms_per_step"], "tx_per_s": d["value"], "process": "child (bench.py --batches-per-launch %d --inflight %d --latency-scheduling)" % (bp, nctx)}
+            except Exception as e:   # noqa: BLE001 -- a secondary figure must never cost the main line
+                return {"contexts": nctx, "error": "%s: %s" % (type(e).__name__, e)}
+
+
         def small(bp, nctx, flags, steps, kernels=None):
             cs = [L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=bp, flags=flags) for _ in range(nctx)]
             for k, cc in enumerate(cs):
@@ -1079,6 +1095,15 @@ def main():
                 continue
             ms = small(bp, 2, 0, 8) * 1e3
             sweep.append({"batches_per_launch": bp, "contexts": 2, "ms_per_step": round(ms, 3), "tx_per_s": round(nTx * bp / ms * 1e3, 1)})
+            if bp <= 4 and 4 * per_batch_bytes(bp) * bp <= free_b - (6 << 30):
+                # the latency regime's own schedule: HZ_FLAG_LATENCY contexts (their chains on CU-masked streams, each owning a hardware
+                # queue), two and four of them in flight -- plain contexts do not overlap there (their streams share hardware queues).
+                # Each point in a process of its own: many such queues in a process that has made other contexts before can abort in
+                # the runtime (csrc/ctx.hip "the other half of the same hazard"), and the main line must not depend on that.
+                # (four in flight reach 560 k / 859 k / 1 118 k tx/s at 1 / 2 / 4 batches in a process that has the device to itself --
+                # tools/experiments/latency_inflight.sh, profiles/r05_latency_regime.txt -- but sixteen CU-masked queues beside this
+                # process's own exceed the hardware queues of the device and the scheduler then time-slices them: not run here)
+                sweep[-1]["latency_flag_x2"] = flagged_point(bp, 2)
         sweep.append({"batches_per_launch": Bp, "contexts": inflight, "ms_per_step": round(dt / args.steps * 1e3, 3), "tx_per_s": round(nTx * Bp * args.steps / dt, 1)})
         for i, pt in enumerate(sweep):
             # doubling the batches of a launch: a step that barely gets longer is waiting on dependent chains (latency); one that

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "hostutil.h"
@@ -75,9 +76,15 @@ struct hz_ctx {
     hipStream_t s_bg = nullptr;
     hipEvent_t ev_bg = nullptr;
     DevBuf pos3;                   // poseidon_quad.h's constants (C, M R, M R^2): the latency form of k_smt
+    bool smt_lat = false;          // this context's chain launches take the latency form (hz_ctx_create)
     DevBuf bg_rows;                // rows k_smt_bg wrote in the last enqueue (2 KB each): the bytes k_smt is NOT responsible for
     hipEvent_t ev_hash4 = nullptr, ev_tail = nullptr;
+    void release_masked();
     ~hz_ctx() {
+        if (partitioned) {   // CU-masked streams go back to the process's pool (masked_stream_pool below)
+            release_masked();
+            s_ed = s_fee = s_main = s_fix = nullptr;
+        }
         if (s_ed) (void)hipStreamDestroy(s_ed);
         if (s_fee) (void)hipStreamDestroy(s_fee);
         if (s_main) (void)hipStreamDestroy(s_main);
@@ -160,6 +167,37 @@ struct ProfScope {
 };
 
 
+// Every CU-masked stream owns a hardware queue, and the runtime does not hand a destroyed one's queue back soon enough: a process that
+// creates and destroys HZ_FLAG_LATENCY contexts in a loop (a benchmark's sweep, a test suite) ran out of queues after a few dozen
+// (HSA_STATUS_ERROR_OUT_OF_RESOURCES, the process aborts). The four streams of a partitioned context are therefore never destroyed:
+// a context that ends puts them into this pool (per device and role: the mask is a function of both), the next one takes them from it.
+// A stream in the pool is idle: the context synchronised with its work before it let go.
+// The other half of the same hazard is NOT cured here: with ROCr's asynchronous scratch reclaim (the default of ROCm 7), a process that
+// has made plain contexts and then keeps four HZ_FLAG_LATENCY contexts of the headline shape in flight -- sixteen hardware queues whose
+// kernels use scratch (k_main_front 7.7 KB per lane) -- can abort in a queue callback (HSA_STATUS_ERROR_OUT_OF_RESOURCES with 247 GB of
+// HBM free; tools/experiments/masked_stream_churn.py reproduces it in seconds). HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0 cures it
+// (tools/experiments/scratch_env_probe.sh: the only one of six runtime knobs that does) and costs 10-50 % of every step (the headline
+// 36.2 -> 39.9 ms, 16 batches x 2 contexts 20.9 -> 45.9 ms): not a default. A fresh process with up to four such contexts has not
+// failed; bench.py runs those sweep points in child processes. The cure proper is kernels without scratch.
+namespace {
+struct MaskedPool {
+    std::mutex mu;
+    std::vector<hipStream_t> idle[16][4];
+};
+MaskedPool& masked_pool() { static MaskedPool* p = new MaskedPool(); return *p; }   // (never destroyed: streams outlive static teardown order)
+}  // namespace
+void hz_ctx::release_masked() {
+    if (device < 0 || device >= 16) return;
+    hipStream_t st[4] = {s_ed, s_fix, s_fee, s_main};
+    MaskedPool& P = masked_pool();
+    for (int k = 0; k < 4; k++) {
+        if (!st[k]) continue;
+        (void)hipStreamSynchronize(st[k]);
+        std::lock_guard<std::mutex> g(P.mu);
+        P.idle[device][k].push_back(st[k]);
+    }
+}
+
 static uint8_t* sec_ptr(hz_ctx* c, int sec) { return (uint8_t*)c->wit.p + c->lo.sections[sec].base * 32; }
 
 static uint32_t block_units(const Layout&, const Section& s, const Block& b) {
@@ -195,9 +233,22 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     if (e == hipSuccess) e = c->wit.alloc(lo.total * 32);
     if (e == hipSuccess) e = hipMemset(c->wit.p, 0, lo.total * 32);
     if (e == hipSuccess) e = c->err.alloc(sizeof(ErrBuf));
-    // the dense Poseidon constants of k_smt's latency form (small launches: launch_smt)
-    if (e == hipSuccess && !getenv("HZ_SMT_NO_LATENCY_FORM")) e = c->pos3.alloc(pos3_dense_bytes());
-    if (e == hipSuccess && c->pos3.p) e = upload_pos3_dense((Fr*)c->pos3.p);
+    {
+        // k_smt's latency form (a quad of lanes per chain: 0.63 x the time of a dependent level hash for ~2.5 x its instructions, one
+        // wavefront per SIMD) -- where the chain IS the step and the step is small: the standalone SMTProcessor and FeeTx mains of at
+        // most HZ_SMT_LAT_MAX units. Not RollupTx / RollupMain: their single batch is bound by the signature chain (9.5 ms against
+        // 8.0-8.3 for the state-tree chain with this form, 9.5 without), and with several contexts in flight its 512 wavefronts at one
+        // per SIMD hold a whole CU partition -- four HZ_FLAG_LATENCY contexts of one batch each: 432 k tx/s with it, 560 k without; a
+        // small launch beside big ones (the fee chain of a 32-batch step) cost the headline 5 % (profiles/r05_smt_latency_form.txt).
+        // HZ_SMT_LATENCY_FORM=1 forces it for every context whose step is small enough (tests, experiments), =0 forbids it.
+        uint32_t step_units = 0;
+        for (const auto& sec : lo.sections) step_units = std::max(step_units, (uint32_t)sec.n_units);
+        const char* force = getenv("HZ_SMT_LATENCY_FORM");
+        const bool chain_is_step = lo.p.tmpl == T_SMT_PROCESSOR || lo.p.tmpl == T_FEE_TX;
+        c->smt_lat = step_units <= HZ_SMT_LAT_MAX && (force ? force[0] == '1' : chain_is_step);
+        if (e == hipSuccess && c->smt_lat) e = c->pos3.alloc(pos3_dense_bytes());
+        if (e == hipSuccess && c->pos3.p) e = upload_pos3_dense((Fr*)c->pos3.p);
+    }
     if (e == hipSuccess) e = c->inst_min.alloc((size_t)lo.n_inst * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->inst_min.p, 0xFF, c->inst_min.bytes);
     if (e == hipSuccess) e = hipMemset(c->err.p, 0, offsetof(ErrBuf, rec));
@@ -232,6 +283,16 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
             if (!c->partitioned) {
                 if (st == &c->s_ed && prio_greatest != prio_least) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest);
                 return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+            }
+            if (c->device >= 0 && c->device < 16) {   // an idle one of the same role, if the process has made one before
+                const int role = st == &c->s_ed ? 0 : st == &c->s_fix ? 1 : st == &c->s_fee ? 2 : 3;
+                MaskedPool& P = masked_pool();
+                std::lock_guard<std::mutex> g(P.mu);
+                if (!P.idle[c->device][role].empty()) {
+                    *st = P.idle[c->device][role].back();
+                    P.idle[c->device][role].pop_back();
+                    return hipSuccess;
+                }
             }
             std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
             for (int b = lo_cu; b < hi_cu; b++) mask[b >> 5] |= 1u << (b & 31);
@@ -639,13 +700,7 @@ static Hash4Args make_hash4_rtx(uint8_t* base, Fr* sc, uint32_t n_units, const R
 // the SMT chain kernel: one launch, one profile entry
 static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa0, const char* name, hipStream_t s) {
     SmtArgs sa = sa0;
-    // The latency form (a quad of lanes per chain, 0.63 x the time of a dependent level hash for ~2.5 x its instructions) only where the
-    // whole STEP is a few dozen wavefronts per kernel: a small launch beside big ones (the fee chain of 32 batches: 2 048 lanes) competes
-    // for issue slots with them and cost the headline step 5 % (profiles/r05_smt_latency_form.txt).
-    uint32_t step_units = 0;
-    for (const auto& sec : c->lo.sections) step_units = std::max(step_units, (uint32_t)sec.n_units);
-    if (c->sharded) step_units = std::max(c->sh_count, 64u);
-    sa.pos3_dense = step_units <= HZ_SMT_LAT_MAX ? (const Fr*)c->pos3.p : nullptr;
+    sa.pos3_dense = c->smt_lat ? (const Fr*)c->pos3.p : nullptr;
     ProfScope ps(c, s, name, sa.n_units);
     return launch_smt(sa, s);
 }

@@ -706,6 +706,40 @@ def test_latency_scheduling_flag_bit_exact(hz):
     _compare(g, o)
 
 
+def test_both_forms_of_the_smt_chain_kernel_write_the_same_witness(hz, monkeypatch):
+    """k_smt<true> (the latency form: a quad of lanes per chain, poseidon_quad.h) is the default of the standalone SMTProcessor / FeeTx
+    mains only; HZ_SMT_LATENCY_FORM forces it on (1) or off (0) for any small context. RollupMain (transaction chains, fee chain, the
+    early last-transaction launch) with both: the same physical buffer, the oracle's; a failing chain constraint reported once."""
+    from circuits_amd import builder as B
+    from circuits_amd import ConstraintError
+    shape = (64, 16, 8, 4)
+    bb = B.synthetic_batch(*shape, n_accounts=32, exits=3, seed=78)
+    o = OracleCtx("rollup-main", *shape)
+    o.set_inputs(bb.get_input())
+    assert o.run() is None
+    raws, fails = [], []
+    for form in ("1", "0"):
+        monkeypatch.setenv("HZ_SMT_LATENCY_FORM", form)
+        g = hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3])
+        g.set_inputs(bb.get_input())
+        g.run()
+        _compare(g, o)
+        raws.append(g.read_raw_bytes(0, g.total()))
+        # a sibling of a processor that is not the tree's: the root check fails for that transaction, in either form, once
+        bad = dict(bb.get_input())
+        sib = [list(r) for r in bad["siblings1"]]
+        i_l2 = next(i for i in range(shape[0]) if not bad["onChain"][i] and bad["fromIdx"][i])
+        sib[i_l2][0] = (sib[i_l2][0] + 1) % P
+        bad["siblings1"] = sib
+        g.set_inputs(bad)
+        with pytest.raises(ConstraintError) as e:
+            g.run()
+        fails.append((e.value.instance, e.value.unit, e.value.name, e.value.lhs, e.value.rhs, g.failures()))
+        del g
+    assert raws[0] == raws[1] and fails[0] == fails[1] and fails[0][0] == 0
+    monkeypatch.delenv("HZ_SMT_LATENCY_FORM")
+
+
 def test_fee_tx_and_hash_inputs_mains_bit_exact(hz):
     from scenarios import fee_tx_cases, hash_inputs_case
     cases = fee_tx_cases(16)
