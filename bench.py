@@ -1096,8 +1096,9 @@ def main():
             ms = small(bp, 2, 0, 8) * 1e3
             sweep.append({"batches_per_launch": bp, "contexts": 2, "ms_per_step": round(ms, 3), "tx_per_s": round(nTx * bp / ms * 1e3, 1)})
             if bp <= 4 and 4 * per_batch_bytes(bp) * bp <= free_b - (6 << 30):
-                # the latency regime's own schedule: HZ_FLAG_LATENCY contexts (their chains on CU-masked streams, each owning a hardware
-                # queue), two and four of them in flight -- plain contexts do not overlap there (their streams share hardware queues).
+                # the latency regime's own schedule: HZ_FLAG_LATENCY contexts (every concurrent chain on its own share of the compute
+                # units), two of them in flight -- plain contexts do not overlap there (their kernels evict each other's code from the
+                # instruction caches of the CUs they share: profiles/r05_latency_regime.txt).
                 # Each point in a process of its own: many such queues in a process that has made other contexts before can abort in
                 # the runtime (csrc/ctx.hip "the other half of the same hazard"), and the main line must not depend on that.
                 # (four in flight reach 560 k / 859 k / 1 118 k tx/s at 1 / 2 / 4 batches in a process that has the device to itself --

@@ -281,6 +281,13 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         auto make_stream = [&](hipStream_t* st, int lo_cu, int hi_cu) {
             if (!c->partitioned) {
+                static const char* dq = getenv("HZ_DEDICATED_QUEUES");   // experiment: a hardware queue per stream (a CU mask of every CU), no partition
+                if (dq && dq[0] == '1' && hipGetDeviceProperties(&prop, c->device) == hipSuccess) {
+                    if (dq[1] == 'e' && st != &c->s_ed) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);   // "1e": the ladder stream only
+                    std::vector<uint32_t> all((prop.multiProcessorCount + 31) / 32, 0u);
+                    for (int b = 0; b < prop.multiProcessorCount; b++) all[b >> 5] |= 1u << (b & 31);
+                    return hipExtStreamCreateWithCUMask(st, (uint32_t)all.size(), all.data());
+                }
                 if (st == &c->s_ed && prio_greatest != prio_least) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest);
                 return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
             }
