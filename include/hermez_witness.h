@@ -92,10 +92,12 @@ typedef struct {
     int32_t n_instances;
     int32_t flags;       /* 0, or one of HZ_FLAG_* */
 } hz_params;
-/* HZ_FLAG_LATENCY: a RollupMain context that serves one request at a time (one to ~16 batches, nothing else on the device) puts
- * its concurrent kernel chains -- front/hash/SMT/HashInputs, the two signature kernels, the fee chain -- on disjoint sets of compute
- * units through CU-masked streams: single-batch latency 36.5 -> 25 ms. Default (0 or HZ_FLAG_THROUGHPUT): any kernel on any CU,
- * the right choice when a second context is in flight. */
+/* HZ_FLAG_LATENCY: a RollupMain context of one to four batches puts its concurrent kernel chains -- front/hash/SMT/HashInputs, the
+ * two signature kernels, the fee chain -- on disjoint sets of compute units through CU-masked streams: one 2048-transaction batch
+ * alone 13.4 -> 9.8 ms. Up to four such contexts in flight overlap (every context uses the same four masks): one batch each, 380 k
+ * tx-witnesses/s with two, 560 k with four; plain contexts do not overlap in that regime (257 k). From eight batches per launch on,
+ * the default (0 or HZ_FLAG_THROUGHPUT: any kernel on any CU) is faster. Every such context holds four hardware queues: keep to four
+ * of them per device, across processes (profiles/r05_latency_regime.txt). */
 #define HZ_FLAG_THROUGHPUT 1
 #define HZ_FLAG_LATENCY 2
 

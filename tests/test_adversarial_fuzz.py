@@ -68,11 +68,11 @@ def _fuzz(hz, template, shape, gen, n_total, chunk, ctx_kw):
 @pytest.mark.gpu
 @pytest.mark.parametrize("template,shape,n_total,chunk", [
     ("smt-processor", (0, 33, 0, 0), 10240, 10240),
-    ("smt-processor", (0, 33, 0, 0), 4096, 2048),    # launches small enough for the latency form of the chain kernel (kernels.h HZ_SMT_LAT_MAX)
+    ("smt-processor", (0, 33, 0, 0), 4096, 2048),    # contexts small enough for the latency form of the chain kernel (ctx.hip hz_ctx_create: its default here)
     ("smt-verifier", (0, 33, 0, 0), 10240, 10240),
     ("withdraw", (0, 32, 0, 0), 10240, 2048),
-    ("rollup-tx", (0, 32, 0, 64), 10240, 2048),      # (the latency form)
-    ("rollup-tx", (0, 32, 0, 64), 6144, 6144),       # (the throughput form)
+    ("rollup-tx", (0, 32, 0, 64), 10240, 2048),
+    ("rollup-tx", (0, 32, 0, 64), 6144, 6144),
 ])
 def test_hip_adversarial_fuzz(hz, template, shape, n_total, chunk):
     L, F = shape[1], shape[3]
