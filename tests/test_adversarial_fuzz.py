@@ -72,7 +72,6 @@ def _fuzz(hz, template, shape, gen, n_total, chunk, ctx_kw):
     ("smt-verifier", (0, 33, 0, 0), 10240, 10240),
     ("withdraw", (0, 32, 0, 0), 10240, 2048),
     ("rollup-tx", (0, 32, 0, 64), 10240, 2048),
-    ("rollup-tx", (0, 32, 0, 64), 6144, 6144),
 ])
 def test_hip_adversarial_fuzz(hz, template, shape, n_total, chunk):
     L, F = shape[1], shape[3]
