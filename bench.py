@@ -1083,10 +1083,11 @@ def main():
             del cs
             return t / steps
         single = {}
-        single_kernels = {}
-        for key, flags in (("default", 0), ("latency_flag", 2)):
-            single[key] = round(small(1, 1, flags, 6, single_kernels if flags == 2 else None) * 1e3, 3)
-        single["kernels_ms_latency_flag"] = single_kernels
+        for key, flags in (("default", 0), ("latency_flag", 2), ("latency_solo_flags", 6)):   # 6 = HZ_FLAG_LATENCY | HZ_FLAG_SOLO
+            kern_ms = {} if flags else None
+            single[key] = round(small(1, 1, flags, 6, kern_ms) * 1e3, 3)
+            if flags:
+                single["kernels_ms_" + key] = kern_ms
         single["critical_chains"] = ("front -> eddsa (signature prologue + 148-step ladder) -> eddsa_final, and front -> hash4 -> smt (33 dependent level "
                                      "hashes) -> rtx_back -> hash_inputs: each kernel is a few dozen wavefronts, its time is the length of its dependent chain")
         sweep = []
@@ -1209,7 +1210,8 @@ def main():
             out["roofline_valu"] = roofline_valu
         if single is not None:
             out["single_batch_latency_ms"] = dict(single, note="one 2048-transaction batch alone on the device, enqueue + check, mean of 6; latency_flag = HZ_FLAG_LATENCY "
-                                                              "(the context's concurrent chains on disjoint compute units)")
+                                                              "(the context's concurrent chains on disjoint compute units); latency_solo_flags = with HZ_FLAG_SOLO as well (the SMT chain "
+                                                              "kernel in its latency form: right only when no other context is in flight)")
             out["batches_sweep"] = sweep
         if standin is not None:
             out["shard_tx_standin"] = standin

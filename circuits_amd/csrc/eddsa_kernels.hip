@@ -826,6 +826,10 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     ed_prologue(K, io, sc, a.ed, K6, sg, &on_curve);
     sc.set(SC_ED_H, fr_from_canon(sg.h_c)); sc.set(SC_ED_ZP, sg.zp);
     sc.set(SC_ED_P0X, sg.p0.x); sc.set(SC_ED_P0Y, sg.p0.y);
+    if (a.chain_in_ladder) {   // small launches: the second segment's lane walks the doubling chain itself (k_eddsa_ladder)
+        sc.set(SC_ED_DBLX, on_curve ? K.one : fr_zero());
+        return;
+    }
     // 8A of an on-curve A is on the curve; when it is the identity the circuit substitutes Base8 (zp = 1): regular either way
     const PtA d147 = ed_dbl_chain(K, sg.p0, 147, on_curve);
     sc.set(SC_ED_DBLX, d147.x); sc.set(SC_ED_DBLY, d147.y);
@@ -862,7 +866,16 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
             // the doubling between the segments and the second segment's base point (escalarmulany.circom: doublers / m2e)
             const EdCtx c = K.with(io[g]);
             PtA d147;
-            d147.x = sc.get(SC_ED_DBLX); d147.y = sc.get(SC_ED_DBLY);
+            if (a.chain_in_ladder) {
+                // The 147 doublings between the segments' base points feed THIS lane only, and its segment is 42 steps shorter than
+                // the first one's: walked here (0.6 ms of one wavefront) they are off the launch's critical path, which is the first
+                // segment's lane, instead of in front of both (k_eddsa_pre). SC_ED_DBLX carries the prologue's on-curve flag.
+                PtA p0;
+                p0.x = sc.get(SC_ED_P0X); p0.y = sc.get(SC_ED_P0Y);
+                d147 = ed_dbl_chain(K, p0, 147, !fr_is_zero(sc.get(SC_ED_DBLX)));
+            } else {
+                d147.x = sc.get(SC_ED_DBLX); d147.y = sc.get(SC_ED_DBLY);
+            }
             const MDbl dd = mont_dbl_dev(c, d147);
             c.io.put_m(o.dblr, dd.x1_2); c.io.put_m(o.dblr + 1, dd.lamda); c.io.put_m(o.dblr + 2, dd.out.x); c.io.put_m(o.dblr + 3, dd.out.y);
             p[g] = m2e_dev(c, dd.out);
@@ -1031,7 +1044,9 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa_final(const EddsaArgs a) {
 // wavefronts, each G times as long (latency). Few units (a single batch or a handful): the device is far from full and
 // latency is what counts; many units per launch: the integer pipe is the limit.
 template <int G>
-static hipError_t launch_eddsa_split(const EddsaArgs& a, uint32_t n, hipStream_t s) {
+static hipError_t launch_eddsa_split(const EddsaArgs& a0, uint32_t n, hipStream_t s) {
+    EddsaArgs a = a0;
+    a.chain_in_ladder = 1;
     hipLaunchKernelGGL(k_eddsa_pre, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
     const uint32_t nl = (n + G - 1) / G;
     hipLaunchKernelGGL(k_eddsa_ladder<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK, 2), dim3(HZ_BLOCK), 0, s, a);

@@ -127,6 +127,7 @@ struct EddsaArgs {
     uint32_t n_units, upi;
     EddsaOff ed;
     uint32_t* side;      // seg_any_proj's parked numerators (eddsa_side_bytes(n)); nullptr: the inversion-per-step ladder
+    uint32_t chain_in_ladder;   // set by launch_eddsa for small launches: the doubling chain between the segments is the second segment lane's
 };
 size_t eddsa_side_bytes(uint32_t n_signatures);   // 0 when a launch of that size does not use the buffer
 

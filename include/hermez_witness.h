@@ -100,6 +100,11 @@ typedef struct {
  * of them per device, across processes (profiles/r05_latency_regime.txt). */
 #define HZ_FLAG_THROUGHPUT 1
 #define HZ_FLAG_LATENCY 2
+/* HZ_FLAG_SOLO (with HZ_FLAG_LATENCY, contexts of at most two batches): nothing else runs on the device while this context's step
+ * does -- no second context in flight. Its SMT chain kernel then takes the latency form (a quad of lanes per chain, the level hash
+ * spread over the quad: 0.67 x the chain's time for 2.5 x its instructions and a whole CU partition's wavefront slots -- which is why
+ * it is wrong beside other contexts: one batch x 4 contexts 432 k tx/s with it, 560 k without). */
+#define HZ_FLAG_SOLO 4
 
 typedef struct {
     int32_t instance;      /* which instance failed */
