@@ -728,6 +728,7 @@ def main():
                     help="HZ_FLAG_LATENCY contexts (their concurrent kernel chains on CU-masked streams of their own): the latency regime, "
                          "one to four batches per launch; single-batch latency: --batches-per-launch 1 --inflight 1 --latency-scheduling, "
                          "its throughput: --batches-per-launch 1 --inflight 4 --latency-scheduling")
+    ap.add_argument("--solo", action="store_true", help="with --latency-scheduling --inflight 1: HZ_FLAG_SOLO as well (nothing else on the device: the SMT chain kernel in its latency form)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon-BN254/sec secondary metric")
     ap.add_argument("--no-withdraw", action="store_true", help="skip the config-5 (withdraw) secondary line")
@@ -849,7 +850,7 @@ def main():
     ctxs, streams = [], []
     for k in range(inflight):
         c = L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=Bp,
-                  flags=2 if args.latency_scheduling else 0)
+                  flags=(6 if (args.solo and inflight == 1) else 2) if args.latency_scheduling else 0)
         ctxs.append(c)
         streams.append(torch.cuda.Stream(device=local))
     if os.environ.get("HZ_BENCH_OWN_STREAMS") == "1":   # experiment: the contexts' own streams (what a host without torch passes: NULL)
