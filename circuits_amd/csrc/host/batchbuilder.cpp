@@ -191,12 +191,21 @@ struct Dag {
         for (int k = 0; k < 6; k++) j.in[k] = -1;
         for (int k = 0; k < n; k++) {
             j.in[k] = in_of(xs[k]);
-            if (xs[k].job >= base && jobs[(size_t)(xs[k].job - base)].wave >= j.wave) j.wave = jobs[(size_t)(xs[k].job - base)].wave + 1;
+            if (xs[k].job >= base) {
+                const uint32_t w = jobs[(size_t)(xs[k].job - base)].wave;
+                if (w >= j.wave) j.wave = w + 1;
+            }
         }
         jobs.push_back(j);
         Val r;
         r.job = base + (int64_t)jobs.size() - 1;
         return r;
+    }
+    // room for a batch of `n_tx` transactions on trees of depth `levels` (two paths per transaction): no regrowth while it is walked
+    void reserve_for(size_t n_tx, size_t levels) {
+        const size_t n = n_tx * (2 * (levels + 2) + 8);
+        if (jobs.capacity() < jobs.size() + n) jobs.reserve(jobs.size() + n);
+        if (consts.capacity() < consts.size() + 2 * n) consts.reserve(consts.size() + 2 * n);
     }
     // the queued jobs as a flush of their own; the queue starts again, numbers running on
     std::shared_ptr<Flush> detach() {
@@ -341,6 +350,7 @@ struct Tree {
     }
     Found find(uint64_t key) const {
         Found f;
+        f.sib.reserve(48);
         int64_t node = root;
         int lvl = 0;
         for (;;) {
@@ -373,7 +383,7 @@ struct Tree {
         for (int i = (int)sib.size() - 1; i >= 0; i--) {
             const int64_t l = ((key >> i) & 1) ? sib[(size_t)i] : rt, r = ((key >> i) & 1) ? rt : sib[(size_t)i];
             const Val in[2] = {hash_of(l), hash_of(r)};
-            nodes.push_back(TNode{false, l, r, dag->poseidon(in, 2)});
+            nodes.emplace_back(TNode{false, l, r, dag->poseidon(in, 2)});
             rt = (int64_t)nodes.size() - 1;
         }
         return rt;
@@ -385,7 +395,7 @@ struct Tree {
         res.is_old0 = f.is_old0;
         res.old_key = f.is_old0 ? key : f.leaf_key;
         res.old_value = f.leaf_value;
-        std::vector<int64_t> full = f.sib;
+        std::vector<int64_t> full = std::move(f.sib);
         if (!f.is_old0) {
             size_t i = full.size();
             while (((f.leaf_key >> i) & 1) == ((key >> i) & 1)) {
@@ -399,7 +409,7 @@ struct Tree {
         root = up(key, lf, full);
         if (!f.is_old0) full.pop_back();
         while (!full.empty() && full.back() == 0) full.pop_back();
-        res.sib = full;
+        res.sib = std::move(full);
         return res;
     }
     SmtResult update(uint64_t key, const Val& value) {
@@ -408,9 +418,9 @@ struct Tree {
         SmtResult res;
         res.old_key = key;
         res.old_value = f.leaf_value;
-        res.sib = f.sib;
         const int64_t lf = new_leaf(key, value);
         root = up(key, lf, f.sib);
+        res.sib = std::move(f.sib);
         return res;
     }
     // the digests of flush f into the nodes [fresh_from, nodes_end) and values [fresh_vals_from, vals_end): what existed when f was detached
@@ -597,6 +607,17 @@ struct Out {
         }
     }
     void put64(Sig s, uint64_t index, uint64_t v) { put(s, index, u_from64(v)); }
+    // `count` consecutive 32-byte elements, already packed
+    void put_row(Sig s, uint64_t index, const uint8_t* bytes32, uint64_t count) {
+        if (off[s] < 0) return;
+        if (width[s] != 32) {
+            for (uint64_t k = 0; k < count; k++) put(s, index + k, u_from_bytes(bytes32 + 32 * k));
+            return;
+        }
+        const uint64_t at = (uint64_t)off[s] + 32 * index;
+        if (at + 32 * count > packed_bytes) throw Reject{std::string("packed buffer too small for ") + SIG_NAMES[s]};
+        memcpy(packed + at, bytes32, 32 * count);
+    }
     // bits [0, count) of v, one element each, from `index` on
     void put_bits(Sig s, uint64_t index, const U256& v, unsigned count) {
         if (off[s] < 0) return;
@@ -810,6 +831,12 @@ int build_begin(hzb_batch* bb, bool threaded) {
     aux_to_v.assign((size_t)nTx, 0);
 
     run.t_loop0 = now_s();
+    dag.reserve_for((size_t)nTx, (size_t)L);
+    db->state->nodes.reserve(db->state->nodes.size() + (size_t)nTx * 2 * ((size_t)L + 2));
+    db->state->leaf_vals.reserve(db->state->leaf_vals.size() + (size_t)nTx * 2);
+    o.fixes.reserve((size_t)nTx * 2 * ((size_t)L + 4));
+    // imAccFeeOut[i][*] = the accumulated fees after transaction i: F values of which at most one changed -- kept as packed bytes
+    std::vector<uint8_t> acc_row((size_t)F * 32, 0);
     for (int i = 0; i < nTx; i++) {
         Tx& tx = (size_t)i < ordered.size() ? ordered[(size_t)i] : nop_tx;
         const bool on = tx.c.on_chain != 0;
@@ -924,7 +951,7 @@ int build_begin(hzb_batch* bb, bool threaded) {
             sib1 = res.sib;
             if (!on)
                 for (int j = 0; j < F; j++)
-                    if (plan[(size_t)j] == token) { acc_fee[(size_t)j] = u_add(acc_fee[(size_t)j], fee); break; }
+                    if (plan[(size_t)j] == token) { acc_fee[(size_t)j] = u_add(acc_fee[(size_t)j], fee); u_to_bytes(acc_fee[(size_t)j], &acc_row[32 * (size_t)j]); break; }
             // ---- processor 2: NOP unless the transaction carries an amount (nullified or not)
             if (has_amount) {
                 if (is_exit) {
@@ -1010,7 +1037,7 @@ int build_begin(hzb_batch* bb, bool threaded) {
         if (i < nTx - 1) {
             o.put64(S_imOnChain, u, on ? 1 : 0); o.put64(S_imOutIdx, u, db->last_idx);
             o.put(S_imStateRoot, u, db->state->root_hash()); o.put(S_imExitRoot, u, exit_tree.root_hash());
-            for (int j = 0; j < F; j++) o.put(S_imAccFeeOut, u * (uint64_t)F + (uint64_t)j, acc_fee[(size_t)j]);
+            o.put_row(S_imAccFeeOut, u * (uint64_t)F, acc_row.data(), (uint64_t)F);
         }
         if ((size_t)i < ordered.size()) ordered[(size_t)i] = tx;
     }
