@@ -180,9 +180,13 @@ struct ProfScope {
 // 36.2 -> 39.9 ms, 16 batches x 2 contexts 20.9 -> 45.9 ms): not a default. A fresh process with up to four such contexts has not
 // failed; bench.py runs those sweep points in child processes. The cure proper is kernels without scratch.
 namespace {
+#ifndef HZ_MAX_PARTITIONED
+#define HZ_MAX_PARTITIONED 2
+#endif
 struct MaskedPool {
     std::mutex mu;
     std::vector<hipStream_t> idle[16][4];
+    int alive[16] = {};   // partitioned contexts per device
 };
 MaskedPool& masked_pool() { static MaskedPool* p = new MaskedPool(); return *p; }   // (never destroyed: streams outlive static teardown order)
 }  // namespace
@@ -190,6 +194,10 @@ void hz_ctx::release_masked() {
     if (device < 0 || device >= 16) return;
     hipStream_t st[4] = {s_ed, s_fix, s_fee, s_main};
     MaskedPool& P = masked_pool();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        if (P.alive[device] > 0) P.alive[device]--;
+    }
     for (int k = 0; k < 4; k++) {
         if (!st[k]) continue;
         (void)hipStreamSynchronize(st[k]);
@@ -275,6 +283,18 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         (void)units;
         const bool want = (p->flags & HZ_FLAG_LATENCY) != 0 || getenv("HZ_FORCE_LATENCY_SCHEDULING") != nullptr;
         c->partitioned = lo.p.tmpl == T_ROLLUP_MAIN && want && hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 64;
+        // At most TWO partitioned contexts alive per device and process by default (HZ_MAX_PARTITIONED=<n> raises it): each holds four
+        // hardware queues, and with four of them in flight (sixteen queues) a process that had made plain contexts before aborted in the
+        // runtime every time it was tried (above; tests/test_witness_gpu.py first ran six at once: the same abort) -- two never did. A
+        // process that has the device to itself and creates nothing else reached 560 k tx/s with four (one batch each, 390 k with two).
+        // A context over the limit gets plain streams: the same witness, the default schedule.
+        if (c->partitioned && c->device >= 0 && c->device < 16) {
+            static const int cap = getenv("HZ_MAX_PARTITIONED") ? atoi(getenv("HZ_MAX_PARTITIONED")) : HZ_MAX_PARTITIONED;
+            MaskedPool& P = masked_pool();
+            std::lock_guard<std::mutex> g(P.mu);
+            if (P.alive[c->device] >= cap) c->partitioned = false;
+            else P.alive[c->device]++;
+        }
         const int ncu = c->partitioned ? prop.multiProcessorCount : 0;
         // The variable-base ladder is the longest dependent chain of a step and runs on few wavefronts: its stream gets the highest
         // priority, so its workgroups are dispatched ahead of the wide kernels' (a 32-batch step alone: 56.8 -> 47.9 ms; two contexts

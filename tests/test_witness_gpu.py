@@ -704,6 +704,15 @@ def test_latency_scheduling_flag_bit_exact(hz):
     g.enqueue(s.cuda_stream)
     g.check()
     _compare(g, o)
+    # more such contexts alive than the library partitions per device (two by default: include/hermez_witness.h; the third gets the
+    # default schedule), with and without HZ_FLAG_SOLO (4): the same witness from each. One at a time: several scratch-using contexts IN
+    # FLIGHT in a process that has run big launches before is what the ROCm 7 runtime aborts on (profiles/r05_latency_regime.txt 4).
+    more = [hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3], flags=2 | (4 if k % 2 else 0)) for k in range(2)]
+    for c in more:
+        c.set_inputs(bb.get_input())
+        c.enqueue(s.cuda_stream)
+        c.check()
+        _compare(c, o)
 
 
 def test_both_forms_of_the_smt_chain_kernel_write_the_same_witness(hz, monkeypatch):

@@ -5,6 +5,8 @@ python tools/experiments/masked_stream_churn.py [rounds] [big: 0 | 1]"""
 import os
 import sys
 
+os.environ.setdefault("HZ_MAX_PARTITIONED", "4")   # the library's default of two per device is what this script shows the reason for
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
+export HZ_MAX_PARTITIONED=4   # (the library partitions two contexts per device by default)
 export HZ_FORCE_LATENCY_SCHEDULING=1
 B="python bench.py --cpu-sample 0 --no-withdraw --no-e2e --no-poseidon --no-export --no-node --no-deep-state --no-sweep --no-shard --no-verify --distinct-batches 4"
 for cfg in "1 1" "1 2" "1 4" "2 2" "2 4"; do
