@@ -51,10 +51,13 @@ struct FeeSrcRtx {
 // The 256 fromBjjCompressed input rows (8 KB per transaction) are read by lane 1 only: it packs them into the key (its own job),
 // checks them boolean (RollupMain phase A) and stores DecodeTx's L1TxFullData rows bit * onChain as copies -- round 2 read them three
 // times and paid three field conversions per bit (1.1 GB of the kernel's 4.6 GB of reads, a quarter of lane 0's instructions).
+#ifndef HZ_FRONT_WAVES
+#define HZ_FRONT_WAVES 2
+#endif
 #ifndef HZ_FRONT_BLOCK
 #define HZ_FRONT_BLOCK HZ_BLOCK
 #endif
-__global__ __launch_bounds__(HZ_FRONT_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_main_front(const MainFrontArgs a) {
+__global__ __launch_bounds__(HZ_FRONT_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_FRONT_WAVES))) void k_main_front(const MainFrontArgs a) {
     const Fr* K7 = poseidon_consts_w<7>();
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_units = a.B * a.nTx;
