@@ -127,6 +127,7 @@ static const char* block_owner(const Layout& lo, int sec, const Block& b) {
     if (has(".sigVerifier.eqCheck")) return "eddsa_final";
     if (has(".getAx.") || has(".sigVerifier.")) return "eddsa";
     if (has(".s3.out") || has(".s4.out") || has(".s5.out") || n == "main.hasherInputs.L1L2TxsData") return "rtx_back";
+    if (!fee && lo.p.tmpl == T_ROLLUP_MAIN && has(".feeAccumulator.")) return "fee_acc";   // (standalone RollupTx: part of its front kernel)
     return fee ? "fee_front" : "front";
 }
 static uint64_t owner_bytes(const hz_ctx* c, const char* owner) {
@@ -744,7 +745,7 @@ static HashInputsArgs make_hi(hz_ctx* c, bool is_main);
 // the last one out: `skip_mod`, so no signal is written twice and a failing constraint of that transaction is recorded once).
 // The 3.6 ms of one-wavefront chain latency and the expansion leave the end of the step.
 static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bool is_main, uint32_t sib1, uint32_t sib2, hipStream_t s, bool early_tail = false,
-                                  bool early_prep = false) {
+                                  bool early_prep = false, const MainFrontArgs* feeacc = nullptr) {
     const Layout& lo = c->lo;
     Fr* sc = (Fr*)c->sc_tx.p;
     ErrBuf* err = (ErrBuf*)c->err.p;
@@ -769,6 +770,10 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         hipStream_t sfix = c->exclusive ? c->s_ed : c->s_fix;
         HZ_HIP(hipStreamWaitEvent(sfix, c->ev_front, 0));
         { ProfScope ps(c, sfix, "eddsa_fix", n_units); HZ_HIP(launch_eddsa_fix(ea, sfix)); }
+        // RollupMain's fee accumulators (k_main_feeacc) need the front step only and feed nothing downstream: they follow the fixed-base
+        // half on its stream -- 10 + 1.5 ms against the 16.6 ms of the ladder beside it (one batch: 4.5 + 0.6 against 6.8) -- and are
+        // joined with it (ev_fix -> the signature stream -> the launch stream)
+        if (feeacc) { ProfScope ps(c, sfix, "fee_acc", n_units); HZ_HIP(launch_main_feeacc(*feeacc, sfix)); }
         HZ_HIP(hipEventRecord(c->ev_fix, sfix));
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_front, 0));
         { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed)); }
@@ -999,7 +1004,7 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             HZ_HIP(hipEventRecord(c->ev_front, s));
             const bool early = tail_now && !c->partitioned;   // CU-partitioned contexts keep the tail on the main stream
             const bool early_prep = tail_now && c->partitioned;
-            st = enqueue_rtx_tail(c, fa.tx_base, lo.sections[lo.sec_tx].n_units, true, lo.mi.siblings1, lo.mi.siblings2, s, early, early_prep);
+            st = enqueue_rtx_tail(c, fa.tx_base, lo.sections[lo.sec_tx].n_units, true, lo.mi.siblings1, lo.mi.siblings2, s, early, early_prep, &fa);
             if (st != HZ_OK) return st;
             if (early) {
                 HZ_HIP(hipStreamWaitEvent(s, c->ev_tail, 0));

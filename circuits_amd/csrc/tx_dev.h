@@ -27,6 +27,7 @@ enum ScratchField {
     SC_ED_H, SC_ED_ZP, SC_ED_P0X, SC_ED_P0Y, SC_ED_DBLX, SC_ED_DBLY, SC_ED_S0X, SC_ED_S0Y, SC_ED_S1X, SC_ED_S1Y,
     SC_ED_Q1X, SC_ED_Q1Y,   // k_eddsa_seg: the second segment's start point (DBL* keeps 2^147 * 8A: a lane's padding slot repeats a unit)
     SC_ISAMTNULL,
+    SC_FEE2CHARGE, SC_FA_TOKEN,   // RollupMain: the front kernel's hand-off to k_main_feeacc (the FeeAccumulator as a kernel of its own)
     // written by the hash step
     SC_LEAF_P1OLD, SC_LEAF_P1NEW, SC_LEAF_P2OLD, SC_LEAF_P2NEW,
     // written by the smt step: levels[0].oldRoot / newRoot per processor
@@ -374,6 +375,34 @@ __device__ __forceinline__ Fr compute_fee_tail_dev(const UnitIO& io, const Compu
     return fr_from_canon(feeOut_c);
 }
 
+// FeeAccumulator (src/fee-accumulator.circom; RollupTx phase H, src/rollup-tx.circom): batched inverses of tokenID - feePlanTokenID[i]
+template <class FEE>
+__device__ __forceinline__ void fee_accumulator_dev(const UnitIO& io, const RtxOff& o, int Fn, const FEE& feeSrc, const Fr& fee2Charge, const Fr& tokenID) {
+    {
+        bool sel_in = false;
+        for (int base = 0; base < Fn; base += 16) {
+            const int n = (Fn - base) < 16 ? (Fn - base) : 16;
+            Fr dz[16], dzi[16];
+            for (int i = 0; i < n; i++) { dz[i] = fr_sub(feeSrc.plan(base + i), tokenID); dzi[i] = dz[i]; }
+            batch_inv<16>(dzi, n);
+            for (int i = 0; i < n; i++) {
+                const uint32_t b = o.feeAcc + FA_N * (base + i);
+                // IsEqual's output and the running "already selected" flag are bits whatever the inputs are: the chain
+                // selOut = 1 - (1 - eq)(1 - selIn), s = eq (1 - selIn), out = fee2Charge * s + accIn is logic plus one selection
+                const bool eq = fr_is_zero(dz[i]);
+                (void)is_zero_dev(io, b + FA_ISZ_INV, dz[i], dzi[i]);
+                const bool ms = eq && !sel_in;
+                const bool sel_out = eq || sel_in;
+                const Fr accIn = feeSrc.acc(base + i);
+                const Fr out = ms ? fr_add(fee2Charge, accIn) : accIn;   // (accIn + fee - accIn)*s + accIn
+                io.put_bit(b + FA_SELOUT, sel_out ? 1u : 0u); io.put_bit(b + FA_MUX_S, ms ? 1u : 0u); io.put_m(b + FA_MUX_OUT, out);
+                feeSrc.out(io, base + i, out);
+                sel_in = sel_out;
+            }
+        }
+    }
+}
+
 struct FrontOut {
     Fr isAmountNullified;
 };
@@ -383,7 +412,7 @@ struct FrontOut {
 // accFeeIn / feePlanTokens are read through the pointers (Montgomery conversion on load).
 // `l1full` != ~0u (k_main_front): this lane also stores DecodeTx's L1TxFullData rows of the fromBjjCompressed bits (signal offset of
 // L1TxFullData in the section) and makes RollupMain's boolean check of them (`bjj_bool_cid`), from the one read of those inputs.
-template <class IN, class FEE>
+template <class IN, class FEE, bool FEEACC = true>
 __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const Scratch& sc, const RtxOff& o, const IN& in, const RtxExt& x,
                                                        int Fn, const FEE& feeSrc, bool own_sig = true, uint32_t l1full = ~0u, int bjj_bool_cid = -1) {
     const Fr one = fr_one(), zero = fr_zero();
@@ -596,30 +625,10 @@ __device__ __forceinline__ FrontOut rollup_tx_front_dev(const UnitIO& io, const 
     const Fr isAmountNullified = fr_sub(one, fr_mul(fr_sub(one, nullifyAmount), underflowOk));
     io.put_m(bo.isAmountNullified, isAmountNullified);
     const Fr isP2Nop = fr_sub(one, ez);
-    // ---- H: FeeAccumulator (batched inverses of tokenID - feePlanTokenID[i])
-    {
-        bool sel_in = false;
-        for (int base = 0; base < Fn; base += 16) {
-            const int n = (Fn - base) < 16 ? (Fn - base) : 16;
-            Fr dz[16], dzi[16];
-            for (int i = 0; i < n; i++) { dz[i] = fr_sub(feeSrc.plan(base + i), x.tokenID); dzi[i] = dz[i]; }
-            batch_inv<16>(dzi, n);
-            for (int i = 0; i < n; i++) {
-                const uint32_t b = o.feeAcc + FA_N * (base + i);
-                // IsEqual's output and the running "already selected" flag are bits whatever the inputs are: the chain
-                // selOut = 1 - (1 - eq)(1 - selIn), s = eq (1 - selIn), out = fee2Charge * s + accIn is logic plus one selection
-                const bool eq = fr_is_zero(dz[i]);
-                (void)is_zero_dev(io, b + FA_ISZ_INV, dz[i], dzi[i]);
-                const bool ms = eq && !sel_in;
-                const bool sel_out = eq || sel_in;
-                const Fr accIn = feeSrc.acc(base + i);
-                const Fr out = ms ? fr_add(fee2Charge, accIn) : accIn;   // (accIn + fee - accIn)*s + accIn
-                io.put_bit(b + FA_SELOUT, sel_out ? 1u : 0u); io.put_bit(b + FA_MUX_S, ms ? 1u : 0u); io.put_m(b + FA_MUX_OUT, out);
-                feeSrc.out(io, base + i, out);
-                sel_in = sel_out;
-            }
-        }
-    }
+    // ---- H: FeeAccumulator -- here (standalone RollupTx) or as a kernel of its own beside the chains this kernel feeds (RollupMain):
+    // it is half of this function's arithmetic (64 IsZero with four inversions, 128 input conversions) and feeds none of them
+    if constexpr (FEEACC) fee_accumulator_dev(io, o, Fn, feeSrc, fee2Charge, x.tokenID);
+    else { sc.set(SC_FEE2CHARGE, fee2Charge); sc.set(SC_FA_TOKEN, x.tokenID); }
     // ---- hand-off to the hash / smt / eddsa / back steps
     const Fr p32 = m_pow2(32), p72 = m_pow2(72);
     auto e0 = [&](const Fr& tok, const Fr& non, const Fr& sg) { return fr_add(fr_add(tok, fr_mul(non, p32)), fr_mul(sg, p72)); };

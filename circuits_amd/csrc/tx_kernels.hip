@@ -110,7 +110,22 @@ __global__ __launch_bounds__(HZ_FRONT_BLOCK) __attribute__((amdgpu_waves_per_eu(
         x.pastAy[j] = ok ? io.in_m_u(m.toBjjAy, u - j - 1) : fr_zero();
     }
     const FeeSrcMain fs{&io, a.fee_base, a.B * a.F, b * a.F, a.fi.feePlanTokens, a.fi.imFinalAccFee, m.imAccFeeOut, a.nTx, i};
-    rollup_tx_front_dev(io, sc, a.rtx, m, x, (int)a.F, fs, false, a.dec.l1full, C_MAIN_BJJ_BOOL);
+    rollup_tx_front_dev<MainTxInOff, FeeSrcMain, false>(io, sc, a.rtx, m, x, (int)a.F, fs, false, a.dec.l1full, C_MAIN_BJJ_BOOL);
+}
+
+// RollupTx's FeeAccumulator for RollupMain, lane = transaction: needs the fee the transaction pays and its token (scratch, from the
+// front kernel), the fee plan and the accumulated fees before it (inputs); feeds only its own signals and RollupMain's im* checks.
+// A kernel of its own on the fixed-base signature stream: half of what k_main_front used to do, off the two chains that kernel heads.
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_main_feeacc(const MainFrontArgs a) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_units = a.B * a.nTx;
+    if (li >= (a.ucnt ? a.ucnt : n_units)) return;
+    const uint32_t u = a.u0 + li;
+    const uint32_t b = u / a.nTx, i = u % a.nTx;
+    const UnitIO io{a.tx_base, n_units, u, b, i, a.err};
+    const Scratch sc{a.scratch, n_units, u};
+    const FeeSrcMain fs{&io, a.fee_base, a.B * a.F, b * a.F, a.fi.feePlanTokens, a.fi.imFinalAccFee, a.mi.imAccFeeOut, a.nTx, i};
+    fee_accumulator_dev(io, a.rtx, (int)a.F, fs, sc.get(SC_FEE2CHARGE), sc.get(SC_FA_TOKEN));
 }
 
 
@@ -202,6 +217,11 @@ hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
     dim3 g((nl + HZ_FRONT_BLOCK - 1) / HZ_FRONT_BLOCK);
     g.y = 2;   // DecodeTx lane, RollupTx-front lane
     hipLaunchKernelGGL(k_main_front, g, dim3(HZ_FRONT_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_main_feeacc(const MainFrontArgs& a, hipStream_t s) {
+    const uint32_t nl = a.ucnt ? a.ucnt : a.B * a.nTx;
+    hipLaunchKernelGGL(k_main_feeacc, grid1(nl), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
