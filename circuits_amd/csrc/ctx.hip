@@ -754,6 +754,12 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     ea.base = base; ea.scratch = sc; ea.err = err; ea.n_units = n_units; ea.upi = lo.sections[lo.sec_tx].upi; ea.ed = lo.rtx.ed;
     const uint32_t u0 = is_main ? c->sh_first : 0, ucnt = is_main ? c->sh_count : 0;
     ea.u0 = u0; ea.ucnt = ucnt;
+    ea.in_onChain = ~0u;
+    if (is_main && !getenv("HZ_ED_NO_PRE_SPLIT")) {
+        const auto& mi = lo.mi;
+        ea.in_onChain = mi.onChain; ea.in_newAccount = mi.newAccount; ea.in_auxFromIdx = mi.auxFromIdx; ea.in_sign1 = mi.sign1; ea.in_ay1 = mi.ay1;
+        ea.in_txCompressedData = mi.txCompressedData; ea.in_fromBjjCompressed = mi.fromBjjCompressed;
+    }
     {
         // the split form (launches of <= HZ_ED_SPLIT_MAX signatures) parks its numerators in a side buffer: 84.7 KB per signature,
         // allocated by the first launch that takes that form and sized for it (a shard: its own range, not the section)
@@ -775,8 +781,10 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         // joined with it (ev_fix -> the signature stream -> the launch stream)
         if (feeacc) { ProfScope ps(c, sfix, "fee_acc", n_units); HZ_HIP(launch_main_feeacc(*feeacc, sfix)); }
         HZ_HIP(hipEventRecord(c->ev_fix, sfix));
-        HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_front, 0));
-        { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed)); }
+        // the signature stream waits for the front step INSIDE launch_eddsa: a RollupMain launch small enough for the split form starts
+        // the point half of its prologue before that (k_eddsa_pre_a reads inputs only; ev_reset: the error buffer, the inputs' scatter)
+        HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_reset, 0));
+        { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed, c->ev_front)); }
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_fix, 0));
         { ProfScope ps(c, c->s_ed, "eddsa_final", n_units); HZ_HIP(launch_eddsa_final(ea, c->s_ed)); }
         HZ_HIP(hipEventRecord(c->ev_ed, c->s_ed));
@@ -1010,6 +1018,8 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
                 HZ_HIP(hipStreamWaitEvent(s, c->ev_tail, 0));
             } else if (tail_now) {
                 // HashInputs needs the roots and the data-availability bits, not the signatures: it runs beside the ladders
+                // (partitioned contexts: chain and expansion on this stream, one launch each -- the expansion piped over the fee stream
+                // in eight groups, as the throughput schedule does, costs a single batch 1.25 ms: 9.1 against 7.86 ms)
                 HZ_HIP(hipStreamWaitEvent(s, c->ev_fee, 0));
                 if (early_prep) HZ_HIP(hipStreamWaitEvent(s, c->ev_tail, 0));
                 { ProfScope ps(c, s, "hash_inputs", (uint64_t)lo.hi.sha.nblocks); HZ_HIP(launch_hash_inputs(make_hi(c, true), s, c->partitioned ? nullptr : c->s_fee, c->ev_sha, 9, early_prep)); }

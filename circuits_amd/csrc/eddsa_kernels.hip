@@ -666,21 +666,15 @@ __device__ __forceinline__ Fr ay_sign_2_ax_dev(const EdCtx& c, const UnitIO& io,
     return x;
 }
 
-__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out, bool* on_curve) {
+// the prologue without the message hash: AySign2Ax, 8A, the zero checks and the point the ladder starts from; returns Ax
+__device__ __forceinline__ Fr ed_prologue_point(const EdK& K, const UnitIO& io, const EddsaOff& o, const Fr& enabled, const Fr& signSig, const Fr& aySig, const Fr& Ay,
+                                                EdSig& out, bool* on_curve) {
     const EdCtx c = K.with(io);
-    const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
-    const Fr R8x = sc.get(SC_ED_R8X), R8y = sc.get(SC_ED_R8Y), M = sc.get(SC_SIGL2HASH);
     const Fr x = ay_sign_2_ax_dev(c, io, o, aySig, signSig);
-    // ---- EdDSAPoseidonVerifier (the S decomposition and range check belong to k_eddsa_fix)
-    Fr hin[5] = {R8x, R8y, x, Ay, M};
-    WitSboxSink s6 = io.sbox_sink(o.hash);
-    const Fr h = poseidon_hash<6>(hin, K6, s6);
-    out.h_c = fr_to_canon(h);
-    num2bits_strict_dev(io, o.h2bits, out.h_c, C_RTX_SIG_H_ALIAS);
     PtA A;
     A.x = x; A.y = Ay;
     {
-        const Fr x2 = fr_sqr(x), y2 = fr_sqr(Ay);   // is the point the ladder starts from on the curve? (k_eddsa_pre's fast doubling chain)
+        const Fr x2 = fr_sqr(x), y2 = fr_sqr(Ay);   // is the point the ladder starts from on the curve? (the fast doubling chain)
         *on_curve = fr_eq(fr_add(fr_mul(c.a, x2), y2), fr_add(c.one, fr_mul(fr_mul(c.d, x2), y2)));
     }
     const PtA d1 = baby_add_dev(c, o.dbl1, A, A);
@@ -698,7 +692,21 @@ __device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const S
     out.p0.y = zpb ? ld_const(HZ_BJJ_BASE8_Y) : d3.y;
     io.put_m(o.seg0p, out.p0.x); io.put_m(o.seg0p + 1, out.p0.y);
     out.enabled = enabled;
+    return x;
+}
+// the message hash of EdDSAPoseidonVerifier (the S decomposition and range check belong to k_eddsa_fix) and its bits
+__device__ __forceinline__ void ed_prologue_hash(const UnitIO& io, const EddsaOff& o, const Fr* K6, const Fr& R8x, const Fr& R8y, const Fr& x, const Fr& Ay, const Fr& M, EdSig& out) {
+    Fr hin[5] = {R8x, R8y, x, Ay, M};
+    WitSboxSink s6 = io.sbox_sink(o.hash);
+    const Fr h = poseidon_hash<6>(hin, K6, s6);
+    out.h_c = fr_to_canon(h);
+    num2bits_strict_dev(io, o.h2bits, out.h_c, C_RTX_SIG_H_ALIAS);
     out.R8.x = R8x; out.R8.y = R8y;
+}
+__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out, bool* on_curve) {
+    const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
+    const Fr x = ed_prologue_point(K, io, o, enabled, signSig, aySig, Ay, out, on_curve);
+    ed_prologue_hash(io, o, K6, sc.get(SC_ED_R8X), sc.get(SC_ED_R8Y), x, Ay, sc.get(SC_SIGL2HASH), out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -833,6 +841,74 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     // 8A of an on-curve A is on the curve; when it is the identity the circuit substitutes Base8 (zp = 1): regular either way
     const PtA d147 = ed_dbl_chain(K, sg.p0, 147, on_curve);
     sc.set(SC_ED_DBLX, d147.x); sc.set(SC_ED_DBLY, d147.y);
+}
+
+// RollupMain, small launches: the prologue as two kernels (EddsaArgs.in_*). The signature's point half needs four values of the front
+// step -- verifySignEnabled and the sender's sign / ay behind the new-account multiplexers -- and they are a handful of products of
+// INPUTS (src/rollup-tx-states.circom:99-130, src/rollup-tx.circom:318-335: finalFromIdx = Mux1(fromIdx, auxFromIdx, onChain * newAccount),
+// verifySignEnabled = (1 - onChain) * (1 - IsZero(finalFromIdx)), s1Sign / s1Ay = Mux1(sign1 / ay1, the key's, isP1Insert)): recomputed
+// here (values only, the front kernel stores the signals) this kernel starts WITH the front kernel instead of after it, and the
+// chain front -> prologue -> ladder of a single batch loses a millisecond. The key's bits are read only when isP1Insert is not zero
+// (a product with zero is zero whatever the other operand).
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_pre_a(const EddsaArgs a) {
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n) return;
+    const uint32_t i = a.u0 + li;
+    EdK K;
+    K.one = fr_one();
+    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+    const Scratch sc{a.scratch, a.n_units, i};
+    const Fr one = K.one;
+    const Fr onChain = io.in_m(a.in_onChain), newAccount = io.in_m(a.in_newAccount);
+    const Fr fromIdx = fr_from_u64(c_bits64(io.in_c(a.in_txCompressedData), 48, 48));
+    const Fr sel = fr_mul(onChain, newAccount);   // selFromIdx.s = isP1Insert
+    const Fr finalFromIdx = mux1_dev(fromIdx, io.in_m(a.in_auxFromIdx), sel);
+    const Fr enabled = fr_is_zero(finalFromIdx) ? fr_zero() : fr_sub(one, onChain);   // (1 - onChain) * (1 - isZero)
+    Fr bjjAy = fr_zero(), bjjSign = fr_zero();
+    if (!fr_is_zero(sel)) {
+        // BitsCompressed2AySign as the front kernel evaluates it (tx_dev.h rollup_tx_front_dev, phase E): bits 0..253, bit 255
+        Fc packed = fc_zero();
+        bool all_bool = true;
+        for (int k = 0; k < 254; k++) {
+            const Fc b = io.in_c(a.in_fromBjjCompressed + k);
+            bool is1 = b.v[0] == 1u, is0 = b.v[0] == 0u;
+            for (int q = 1; q < 8; q++) { is1 = is1 && b.v[q] == 0u; is0 = is0 && b.v[q] == 0u; }
+            if (!(is0 || is1)) all_bool = false;
+            if (is1) packed.v[k >> 5] |= 1u << (k & 31);
+        }
+        if (all_bool) {
+            fc_cond_sub_p(packed.v);
+            bjjAy = fr_from_canon(packed);
+        } else {
+            Fr acc = fr_zero();
+            for (int k = 253; k >= 0; k--) acc = fr_add(fr_dbl(acc), io.in_m(a.in_fromBjjCompressed + k));
+            bjjAy = acc;
+        }
+        bjjSign = io.in_m(a.in_fromBjjCompressed + 255);
+    }
+    const Fr s1Sign = mux1_dev(io.in_m(a.in_sign1), bjjSign, sel), s1Ay = mux1_dev(io.in_m(a.in_ay1), bjjAy, sel);
+    EdSig sg;
+    bool on_curve = false;
+    const Fr x = ed_prologue_point(K, io, a.ed, enabled, fr_mul(s1Sign, enabled), fr_mul(s1Ay, enabled), s1Ay, sg, &on_curve);
+    sc.set(SC_ED_ZP, sg.zp);
+    sc.set(SC_ED_P0X, sg.p0.x); sc.set(SC_ED_P0Y, sg.p0.y);
+    sc.set(SC_ED_DBLX, on_curve ? K.one : fr_zero());   // (chain_in_ladder: the second segment's lane walks the doubling chain)
+    sc.set(SC_ED_DBLY, x);                              // Ax for k_eddsa_pre_b (the slot is free in this form)
+}
+// lane = signature: the message hash (needs the front step: R8, Ay, the message) and its bits
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_pre_b(const EddsaArgs a) {
+    const Fr* K6 = poseidon_consts_w<6>();
+    const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n) return;
+    const uint32_t i = a.u0 + li;
+    const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+    const Scratch sc{a.scratch, a.n_units, i};
+    EdSig sg;
+    ed_prologue_hash(io, a.ed, K6, sc.get(SC_ED_R8X), sc.get(SC_ED_R8Y), sc.get(SC_ED_DBLY), sc.get(SC_ED_AY), sc.get(SC_SIGL2HASH), sg);
+    sc.set(SC_ED_H, fr_from_canon(sg.h_c));
 }
 
 // lane = (segment, G signatures in lockstep). Lane li of a segment evaluates the signatures of units li, li + nl, li + 2 nl, ...
@@ -1044,10 +1120,18 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa_final(const EddsaArgs a) {
 // wavefronts, each G times as long (latency). Few units (a single batch or a handful): the device is far from full and
 // latency is what counts; many units per launch: the integer pipe is the limit.
 template <int G>
-static hipError_t launch_eddsa_split(const EddsaArgs& a0, uint32_t n, hipStream_t s) {
+static hipError_t launch_eddsa_split(const EddsaArgs& a0, uint32_t n, hipStream_t s, hipEvent_t front_done) {
     EddsaArgs a = a0;
     a.chain_in_ladder = 1;
-    hipLaunchKernelGGL(k_eddsa_pre, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
+    if (a.in_onChain != ~0u && front_done) {   // RollupMain: the point half of the prologue beside the front kernel, the hash half after it
+        hipLaunchKernelGGL(k_eddsa_pre_a, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
+        const hipError_t e = hipStreamWaitEvent(s, front_done, 0);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_eddsa_pre_b, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
+    } else {
+        if (front_done) { const hipError_t e = hipStreamWaitEvent(s, front_done, 0); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(k_eddsa_pre, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
+    }
     const uint32_t nl = (n + G - 1) / G;
     hipLaunchKernelGGL(k_eddsa_ladder<G>, dim3((nl + HZ_BLOCK - 1) / HZ_BLOCK, 2), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
@@ -1079,11 +1163,12 @@ static hipError_t launch_eddsa_fix_g(const EddsaArgs& a, uint32_t n, hipStream_t
 size_t eddsa_side_bytes(uint32_t n) {
     return n <= HZ_ED_SPLIT_MAX ? (size_t)2 * n * 147 * SD_FIELDS * 9 * sizeof(uint32_t) : 0;
 }
-hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s) {
+hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s, hipEvent_t front_done) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     // a launch the device does not fill is latency bound: the two segments of every signature as independent lanes (148 / 106
     // dependent steps instead of 254), one signature per lane
-    if (n <= HZ_ED_SPLIT_MAX) return launch_eddsa_split<1>(a, n, s);
+    if (n <= HZ_ED_SPLIT_MAX) return launch_eddsa_split<1>(a, n, s, front_done);
+    if (front_done) { const hipError_t e = hipStreamWaitEvent(s, front_done, 0); if (e != hipSuccess) return e; }
     return launch_eddsa_seg<HZ_ED_G>(a, n, s);
 }
 hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {

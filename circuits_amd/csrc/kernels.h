@@ -128,6 +128,10 @@ struct EddsaArgs {
     EddsaOff ed;
     uint32_t* side;      // seg_any_proj's parked numerators (eddsa_side_bytes(n)); nullptr: the inversion-per-step ladder
     uint32_t chain_in_ladder;   // set by launch_eddsa for small launches: the doubling chain between the segments is the second segment lane's
+    // RollupMain, small launches (set by ctx.hip; in_onChain == ~0u: off): the prologue in two kernels. k_eddsa_pre_a -- AySign2Ax, 8A,
+    // the zero checks -- takes what it needs of the front step straight from the INPUTS (five signals and, for a new account, the key
+    // bits) and so runs beside the front kernel instead of behind it; k_eddsa_pre_b -- the message hash and its bits -- follows both.
+    uint32_t in_onChain, in_newAccount, in_auxFromIdx, in_sign1, in_ay1, in_txCompressedData, in_fromBjjCompressed;
 };
 size_t eddsa_side_bytes(uint32_t n_signatures);   // 0 when a launch of that size does not use the buffer
 
@@ -215,7 +219,7 @@ hipError_t upload_pos3_dense(Fr* dst);   // synchronous; dst holds pos3_dense_by
 hipError_t launch_smt_bg(const SmtArgs& a, unsigned long long* rows_written, hipStream_t s);
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
 hipError_t launch_da_mask(const RtxBackArgs& a, hipStream_t s);   // RollupMain phase H alone (amount bits of L1L2TxData times 1 - isAmountNullified), every unit
-hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s);         // AySign2Ax, message hash, variable-base ladder, R8 + h*8A
+hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s, hipEvent_t front_done = nullptr);   // front_done: waited for where the front step's scratch is first read (NULL: the caller has ordered the stream already)         // AySign2Ax, message hash, variable-base ladder, R8 + h*8A
 hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s);     // S bits / range, S*B8 (independent of the above)
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s);   // the equality of the two sides
 hipError_t launch_fee_front(const FeeFrontArgs& a, hipStream_t s);
