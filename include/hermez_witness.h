@@ -94,7 +94,7 @@ typedef struct {
 } hz_params;
 /* HZ_FLAG_LATENCY: a RollupMain context of one to four batches puts its concurrent kernel chains -- front/hash/SMT/HashInputs, the
  * two signature kernels, the fee chain -- on disjoint sets of compute units through CU-masked streams: one 2048-transaction batch
- * alone 13.4 -> 9.8 ms. Up to four such contexts in flight overlap (every context uses the same four masks): one batch each, 380 k
+ * alone 14.6 -> 9.4 ms (7.9 with HZ_FLAG_SOLO). Up to four such contexts in flight overlap (every context uses the same four masks): one batch each, 380 k
  * tx-witnesses/s with two, 560 k with four; plain contexts do not overlap in that regime (257 k). From eight batches per launch on,
  * the default (0 or HZ_FLAG_THROUGHPUT: any kernel on any CU) is faster. Every such context holds four hardware queues, and the ROCm 7 runtime has
  * aborted processes that kept four of them in flight after having made plain contexts (profiles/r05_latency_regime.txt): within one
