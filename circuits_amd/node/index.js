@@ -99,7 +99,9 @@ function wantsSanityCheck(arg) {
 
 class Circuit {
     /** opts.nInstances: independent instances of the main component evaluated by one run (default 1 = the reference's shape);
-     *  opts.flags: 2 = HZ_FLAG_LATENCY (one request at a time); opts.device: HIP device ordinal */
+     *  opts.flags: 2 = HZ_FLAG_LATENCY (one to four batches per circuit: its kernel chains on compute units of their own; two such circuits
+     *  in flight overlap, plain ones do not), 6 = with HZ_FLAG_SOLO (nothing else runs on the device: 7.9 ms for one 2048-transaction
+     *  batch; include/hermez_witness.h); opts.device: HIP device ordinal */
     constructor(main, opts) {
         this.main = main;
         this.opts = opts || {};
