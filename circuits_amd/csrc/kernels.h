@@ -211,7 +211,8 @@ hipError_t launch_fr_sqrt(const void* d_a, void* d_out, size_t n, hipStream_t s)
 hipError_t launch_ay_sign_2_ax_main(const GadgetArgs& a, const EddsaOff& o, hipStream_t s);   // eddsa_kernels.hip (shares the curve code)
 hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
 #ifndef HZ_SMT_LAT_MAX
-#define HZ_SMT_LAT_MAX 4096u   // units per launch up to which k_smt runs in its latency form (a quad of lanes per chain)
+#define HZ_SMT_LAT_MAX 2048u   // units up to which k_smt may run in its latency form (a quad of lanes per chain): one wavefront per SIMD of half the
+                               // device holds 2048 units x 4 chains x 4 lanes; two batches alone: 11.7 ms with it, 9.7 without (one: 7.9 / 9.4)
 #endif
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s);
 size_t pos3_dense_bytes();

@@ -102,7 +102,7 @@ typedef struct {
  * HZ_MAX_PARTITIONED=4 in the environment lifts that for a process that creates nothing else on the device. */
 #define HZ_FLAG_THROUGHPUT 1
 #define HZ_FLAG_LATENCY 2
-/* HZ_FLAG_SOLO (with HZ_FLAG_LATENCY, contexts of at most two batches): nothing else runs on the device while this context's step
+/* HZ_FLAG_SOLO (with HZ_FLAG_LATENCY, contexts of ONE batch: no effect on larger ones): nothing else runs on the device while this context's step
  * does -- no second context in flight. Its SMT chain kernel then takes the latency form (a quad of lanes per chain, the level hash
  * spread over the quad: 0.67 x the chain's time for 2.5 x its instructions and a whole CU partition's wavefront slots -- which is why
  * it is wrong beside other contexts: one batch x 4 contexts 432 k tx/s with it, 560 k without). */
