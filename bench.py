@@ -684,6 +684,85 @@ def bench_shard_standin(L, D, nTx, lv, m1, F, packed_ptr, pbytes, expected, worl
                     "shard is 4 wavefronts per kernel: the dependent chains (33 level hashes, 148 ladder steps) set its time, so 8 GPUs do not make one batch 8 x faster"}
 
 
+class Rotation:
+    """The measured loop. The packed inputs of `n` distinct batches lie TWICE in a row in a source buffer (pinned host memory for the
+    upload-inclusive figures, HBM for `value`: "inputs resident when the timed region starts"), so that any window of consecutive
+    batches modulo n is contiguous. Context k's instance b holds batch (k * bp + b + r) mod n in round r, and EVERY step is a new round:
+    right after a step's enqueue the next round's window is staged (hz_inputs_stage_range: one copy beside the step's kernels), the next
+    enqueue scatters it into the witness layout first. No instance sees the same batch in two consecutive steps, so nothing that a step
+    finds in the persistent witness buffer from the step before (csrc/ctx.hip "constant marks") is its own batch's."""
+
+    def __init__(self, ctxs, streams, bp, n, pbytes, expected, host_src, dev_src=None):
+        self.cs, self.st, self.bp, self.n, self.pb, self.exp = ctxs, streams, bp, n, pbytes, expected
+        self.host, self.dev = host_src, dev_src
+        self.cur = [0] * len(ctxs)   # the round whose inputs context k's last enqueue consumed (or that were uploaded)
+        self.nxt = [0] * len(ctxs)   # the round staged for its next enqueue (== cur: nothing staged)
+
+    def slot(self, k, b, r=None):
+        return (k * self.bp + b + (self.cur[k] if r is None else r)) % self.n
+
+    def load(self):   # round 0 through hz_inputs_upload (copy + scatter)
+        for k, c in enumerate(self.cs):
+            for b in range(self.bp):
+                c.upload(b, self.host + self.slot(k, b, 0) * self.pb, self.pb, self.st[k].cuda_stream)
+            self.cur[k] = self.nxt[k] = 0
+
+    def stage(self, k, src):
+        r = self.nxt[k] + 1
+        b = 0
+        while b < self.bp:   # one call when bp <= n
+            run = min(self.bp - b, self.n)
+            self.cs[k].stage_range(b, run, src + self.slot(k, b, r) * self.pb, self.pb)
+            b += run
+        self.nxt[k] = r
+
+    def enqueue(self, k):
+        self.cs[k].enqueue(self.st[k].cuda_stream)
+        self.cur[k] = self.nxt[k]
+
+    def step(self, k, src):
+        self.enqueue(k)
+        if src:
+            self.stage(k, src)
+
+    def go(self, n, src):
+        """n steps round-robin over the contexts in flight; src: where the next round's inputs come from (None: no rotation, every
+        step re-evaluates the inputs it already holds -- experiments only)"""
+        pend = [False] * len(self.cs)
+        for i in range(n):
+            k = i % len(self.cs)
+            if pend[k]:
+                self.cs[k].check()
+            self.step(k, src)
+            pend[k] = True
+        for k in range(len(self.cs)):
+            if pend[k]:
+                self.cs[k].check()
+
+    def drain(self):   # consume what is still staged
+        for k in range(len(self.cs)):
+            if self.nxt[k] != self.cur[k]:
+                self.enqueue(k)
+                self.cs[k].check()
+
+    def verify(self, what, instances=None):
+        for k, c in enumerate(self.cs):
+            for b in (range(self.bp) if instances is None else instances):
+                assert c.get("main.hashGlobalInputs", b) == self.exp[self.slot(k, b)], "hashGlobalInputs mismatch (%s, context %d, batch %d, round %d)" % (what, k, b, self.cur[k])
+
+
+def doubled_sources(L, torch, src_ptr, n, pbytes):
+    """(pinned, device tensor): the n packed batches at src_ptr twice in a row, in pinned host memory and in HBM"""
+    pin2 = L.host_alloc(2 * n * pbytes)
+    ctypes.memmove(pin2, src_ptr, n * pbytes)
+    ctypes.memmove(pin2 + n * pbytes, src_ptr, n * pbytes)
+    host_view = torch.frombuffer((ctypes.c_char * (2 * n * pbytes)).from_address(pin2), dtype=torch.uint8)
+    dev = torch.empty(2 * n * pbytes, dtype=torch.uint8, device="cuda")
+    dev.copy_(host_view)
+    torch.cuda.synchronize()
+    return pin2, dev
+
+
 def respawn(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks (one process per GPU) and hand over."""
     s = socket.socket()
@@ -730,6 +809,8 @@ def main():
                          "its throughput: --batches-per-launch 1 --inflight 4 --latency-scheduling")
     ap.add_argument("--solo", action="store_true", help="with --latency-scheduling --inflight 1: HZ_FLAG_SOLO as well (nothing else on the device: the SMT chain kernel in its latency form)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-rotate", action="store_true", help="experiments: every step re-evaluates the inputs its instances already hold (rounds 1-5's `value` loop) "
+                                                              "instead of a new batch per instance and step")
     ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon-BN254/sec secondary metric")
     ap.add_argument("--no-withdraw", action="store_true", help="skip the config-5 (withdraw) secondary line")
     ap.add_argument("--no-e2e", action="store_true", help="skip the upload-inclusive run (value_e2e)")
@@ -858,51 +939,23 @@ def main():
             cuda_stream = None
         streams = [_Null() for _ in streams]
 
-    def slot(k, b):   # which batch lives in instance b of context k
-        return (k * Bp + b) % n_distinct
-
-    def upload(k):
-        for b in range(Bp):
-            ctxs[k].upload(b, pin + slot(k, b) * pbytes, pbytes, streams[k].cuda_stream)
-
-    for k in range(inflight):
-        upload(k)   # inputs resident in HBM before the timed region
+    pin2, dsrc_t = doubled_sources(L, torch, pin, n_distinct, pbytes)
+    dsrc = None if args.no_rotate else dsrc_t.data_ptr()
+    R = Rotation(ctxs, streams, Bp, n_distinct, pbytes, expected, pin2, dsrc)
+    R.load()   # inputs resident in HBM before the timed region (round 0 in the witness layout, every batch in packed form)
     # one checked pass per context: parity of every batch's public output with the builder's independently computed value
     ctxs[0].set_profiling(True)
     for k in range(inflight):
-        ctxs[k].enqueue(streams[k].cuda_stream)
+        R.enqueue(k)
         ctxs[k].check()
-        if not args.no_verify:
-            for b in range(Bp):
-                assert ctxs[k].get("main.hashGlobalInputs", b) == expected[slot(k, b)], "hashGlobalInputs mismatch (context %d, batch %d)" % (k, b)
+    if not args.no_verify:
+        R.verify("first pass")
+    full_bytes = {name: by for name, _ms, by, _u in ctxs[0].profile()}   # a fresh buffer holds nothing: every signal was stored
     ctxs[0].set_profiling(False)
 
-    def stage(k):   # the inputs of context k's NEXT step: the PCIe copies run beside the kernels of the step just enqueued
-        b = 0
-        while b < Bp:   # runs of batches that are contiguous in the pinned buffer go as one hz_inputs_stage_range (one copy)
-            e = b + 1
-            while e < Bp and slot(k, e) == slot(k, e - 1) + 1:
-                e += 1
-            ctxs[k].stage_range(b, e - b, pin + slot(k, b) * pbytes, pbytes)
-            b = e
-
-    phase_ms = float(os.environ.get("HZ_BENCH_OFFSET_MS", "0"))   # experiment: start the contexts this far apart
-
-    def run_steps(n, with_upload=False):
-        pending = [False] * inflight
-        for i in range(n):
-            k = i % inflight
-            if pending[k]:
-                ctxs[k].check()
-            elif phase_ms and k:
-                time.sleep(phase_ms * 1e-3)
-            ctxs[k].enqueue(streams[k].cuda_stream)   # with_upload: first scatters the inputs staged for this step
-            if with_upload:
-                stage(k)
-            pending[k] = True
-        for k in range(inflight):
-            if pending[k]:
-                ctxs[k].check()
+    def upload(k):
+        for b in range(Bp):
+            ctxs[k].upload(b, pin2 + R.slot(k, b) * pbytes, pbytes, streams[k].cuda_stream)
 
     if args.calibrate_copy:
         a = torch.zeros(1 << 28, dtype=torch.int32, device="cuda")
@@ -910,22 +963,35 @@ def main():
         b.copy_(a)
         torch.cuda.synchronize()
         del a, b
-    run_steps(args.warmup)
-    dt = D.timed(lambda: run_steps(args.steps))
+    # `value`: every step = scatter of the round's packed inputs (HBM -> witness layout) + witness kernels + check, then the next
+    # round's window staged from the packed copies in HBM. The first enqueue of the warm-up consumes nothing new; from then on every
+    # step of every context evaluates batches its instances did not hold the step before.
+    for k in range(inflight):
+        if dsrc:
+            R.stage(k, dsrc)
+    R.go(max(args.warmup, inflight if dsrc else 0), dsrc)
+    dt = D.timed(lambda: R.go(args.steps, dsrc))
+    R.drain()
+    if not args.no_verify:
+        R.verify("after the timed region", instances=(0, Bp // 2, Bp - 1))
     dt_e2e = None
     if not args.no_e2e:
         for k in range(inflight):
-            stage(k)
-        run_steps(max(inflight, args.warmup), True)   # every timed step below consumes inputs staged during the step before it
-        dt_e2e = D.timed(lambda: run_steps(args.steps, True))
-        run_steps(inflight, False)   # drain the last staged inputs
+            R.stage(k, pin2)
+        R.go(max(inflight, args.warmup), pin2)   # every timed step below consumes inputs staged during the step before it
+        dt_e2e = D.timed(lambda: R.go(args.steps, pin2))
+        R.drain()
+        if not args.no_verify:
+            R.verify("after the upload-inclusive region", instances=(0, Bp - 1))
 
     # latency of one step alone on the device (wall clock around enqueue + check; `batches_per_launch` batches)
     lat = []
     for _ in range(3):
+        if dsrc:
+            R.stage(0, dsrc)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        ctxs[0].enqueue(streams[0].cuda_stream)
+        R.enqueue(0)
         ctxs[0].check()
         lat.append((time.perf_counter() - t1) * 1e3)
     single_ms = min(lat)
@@ -934,12 +1000,16 @@ def main():
     ctxs[0].set_profiling(True, exclusive=True)  # each kernel alone on the device: durations for the per-kernel roofline
     acc = {}
     reps = 3
-    for _ in range(reps):
-        ctxs[0].enqueue(streams[0].cuda_stream)
+    for _ in range(reps):   # (each repetition a new round as well: the chain kernel's time and bytes are those of a step that meets new batches)
+        if dsrc:
+            R.stage(0, dsrc)
+            torch.cuda.synchronize()
+        R.enqueue(0)
         ctxs[0].check()
         for name, ms, by, units in ctxs[0].profile():
-            a = acc.setdefault(name, [0.0, by, units, 0])
-            a[0] += ms / reps      # a kernel launched in several pieces (the SMT chain: chunks of levels) adds up over its launches
+            a = acc.setdefault(name, [0.0, 0.0, units, 0])
+            a[0] += ms / reps      # a kernel launched in several pieces adds up over its launches
+            a[1] += by / reps      # algorithmic bytes of THIS launch (k_smt: without what the constant marks let it leave in place)
             a[3] += 1.0 / reps
     ctxs[0].set_profiling(False)
     # upload path alone: one instance's packed inputs, host -> device -> witness layout (HIP events on the stream)
@@ -957,7 +1027,7 @@ def main():
     export = None
     if world == 1 and not args.no_export:
         try:
-            export = bench_export(args, L, D, ctxs, streams, lambda k: ctxs[k].enqueue(streams[k].cuda_stream), nTx, Bp)
+            export = bench_export(args, L, D, ctxs, streams, lambda k: R.step(k, dsrc), nTx, Bp)
         except Exception as e:   # noqa: BLE001 -- a secondary figure must never cost the main line
             export = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
@@ -999,27 +1069,38 @@ def main():
         t_deep = time.time() - t_deep
         dexp = [b[1] for b in dbatches]
         del dbatches
+        dpin2, ddev_t = doubled_sources(L, torch, dpin, n_deep, pbytes)
+        L.host_free(dpin)
+        ddev = None if args.no_rotate else ddev_t.data_ptr()
+        RD = Rotation(ctxs, streams, Bp, n_deep, pbytes, dexp, dpin2, ddev)
+        RD.load()
         for k in range(inflight):
-            for b in range(Bp):
-                ctxs[k].upload(b, dpin + ((k * Bp + b) % n_deep) * pbytes, pbytes, streams[k].cuda_stream)
-        for k in range(inflight):
-            ctxs[k].enqueue(streams[k].cuda_stream)
+            RD.enqueue(k)
             ctxs[k].check()
-            for b in range(Bp):
-                assert ctxs[k].get("main.hashGlobalInputs", b) == dexp[(k * Bp + b) % n_deep], "hashGlobalInputs mismatch (deep state, context %d, batch %d)" % (k, b)
+        RD.verify("deep state")
         dsteps = max(4, args.steps // 2)
-        run_steps(max(1, args.warmup))
-        ddt = D.timed(lambda: run_steps(dsteps))
+        for k in range(inflight):
+            if ddev:
+                RD.stage(k, ddev)
+        RD.go(max(1, args.warmup, inflight), ddev)
+        ddt = D.timed(lambda: RD.go(dsteps, ddev))
+        RD.drain()
+        RD.verify("deep state, after the timed region", instances=(0, Bp - 1))
         ctxs[0].set_profiling(True, exclusive=True)
         dacc = {}
         for _ in range(2):
-            ctxs[0].enqueue(streams[0].cuda_stream)
+            if ddev:
+                RD.stage(0, ddev)
+                torch.cuda.synchronize()
+            RD.enqueue(0)
             ctxs[0].check()
             for name, ms, by, units in ctxs[0].profile():
-                a = dacc.setdefault(name, [0.0, by])
+                a = dacc.setdefault(name, [0.0, 0.0])
                 a[0] += ms / 2
+                a[1] += by / 2
         ctxs[0].set_profiling(False)
-        L.host_free(dpin)
+        del ddev_t
+        L.host_free(dpin2)
         deep = {"state_accounts": 1 << kk, "value": round(nTx * Bp * dsteps / ddt, 1), "unit": "tx-witnesses/s", "steps": dsteps, "ms_per_step": round(ddt / dsteps * 1e3, 3),
                 "distinct_batches": n_deep, "kernels_ms": {k: round(v[0], 3) for k, v in dacc.items()},
                 "k_smt": dict({"launch_ms": round(dacc["smt"][0], 3), "achieved_GBs": round(dacc["smt"][1] / (dacc["smt"][0] * 1e-3) / 1e9, 2),
@@ -1051,32 +1132,26 @@ def main():
 
         def small(bp, nctx, flags, steps, kernels=None):
             cs = [L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=bp, flags=flags) for _ in range(nctx)]
+            RS = Rotation(cs, [streams[k % len(streams)] for k in range(nctx)], bp, n_distinct, pbytes, expected, pin2, dsrc)
+            RS.load()
             for k, cc in enumerate(cs):
-                for b in range(bp):
-                    cc.upload(b, pin + ((k * bp + b) % n_distinct) * pbytes, pbytes, streams[k % len(streams)].cuda_stream)
-            for k, cc in enumerate(cs):
-                cc.enqueue(streams[k % len(streams)].cuda_stream)
+                RS.enqueue(k)
                 cc.check()
-                if not args.no_verify:
-                    assert cc.get("main.hashGlobalInputs", bp - 1) == expected[(k * bp + bp - 1) % n_distinct], "hashGlobalInputs mismatch (sweep, %d x %d)" % (bp, nctx)
-
-            def go(n):
-                pend = [False] * nctx
-                for i in range(n):
-                    k = i % nctx
-                    if pend[k]:
-                        cs[k].check()
-                    cs[k].enqueue(streams[k % len(streams)].cuda_stream)
-                    pend[k] = True
-                for k in range(nctx):
-                    if pend[k]:
-                        cs[k].check()
-            go(nctx)
-            t = D.timed(lambda: go(steps))
+            if not args.no_verify:
+                RS.verify("sweep, %d x %d" % (bp, nctx), instances=(bp - 1,))
+            for k in range(nctx):
+                if dsrc:
+                    RS.stage(k, dsrc)
+            RS.go(nctx, dsrc)
+            t = D.timed(lambda: RS.go(steps, dsrc))
+            RS.drain()
             if kernels is not None:   # each kernel of this shape alone on the device: which chains set the latency
                 cs[0].set_profiling(True, exclusive=True)
                 for _ in range(2):
-                    cs[0].enqueue(streams[0].cuda_stream)
+                    if dsrc:
+                        RS.stage(0, dsrc)
+                        torch.cuda.synchronize()
+                    RS.enqueue(0)
                     cs[0].check()
                     for name, ms, _by, _units in cs[0].profile():
                         kernels[name] = round(kernels.get(name, 0.0) + ms / 2, 3)
@@ -1118,6 +1193,8 @@ def main():
             else:
                 pt["binds"] = "valu"
     L.host_free(pin)
+    del dsrc_t
+    L.host_free(pin2)
     torch.cuda.empty_cache()
 
     out = None
@@ -1134,8 +1211,7 @@ def main():
         # dominant kernel for an HBM roofline = the kernel that writes most of the witness (k_smt: three quarters of a step's
         # bytes, and the only one besides the front / hash kernels that fills the device). k_eddsa's launches last longer
         # but run on few wavefronts, latency bound, underneath the others: their figures are in kernels_ms / kernels_GBs.
-        # (k_smt_bg, the pure-store kernel that writes the empty levels' constant blocks beside k_smt, has its own entry below)
-        dk = max((k for k in tot if k != "smt_bg"), key=lambda k: byt[k])
+        dk = max(tot, key=lambda k: byt[k])
         dname = max((n for n in acc if kern.get(n, n) == dk), key=lambda n: acc[n][0])
         dms, dbytes, dunits, dlaunches = acc[dname]
         dlaunches = max(1, int(round(dlaunches)))
@@ -1165,7 +1241,11 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": "rollup-main nTx=%d nLevels=%d maxL1Tx=%d maxFeeTx=%d" % (nTx, lv, m1, F), "batches_per_launch": Bp, "contexts_in_flight": inflight,
-                       "distinct_batches": n_distinct, "state_accounts": n_acc, "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
+                       "distinct_batches": n_distinct,
+                       "rotation": ("none (--no-rotate): every step re-evaluates the inputs its instances hold" if args.no_rotate else
+                                    "every step a new round: instance b of context k holds batch (k * %d + b + round) mod %d; the round's packed inputs (resident in HBM) are "
+                                    "scattered into the witness layout inside the timed region; hashGlobalInputs of the last round checked after it" % (Bp, n_distinct)),
+                       "constant_marks": os.environ.get("HZ_NO_ZMARK") is None, "state_accounts": n_acc, "l1_txs": nTx - n_l2, "l2_signed_txs": n_l2, "parallelism": "batch-dp%d" % world,
                        "world_size": world, "backend": D.backend if world > 1 else None,
                        "witness_bytes_per_batch": witness_bytes, "step_latency_ms": round(single_ms, 3), "batch_build_s": round(t_build, 1),
                        "batch_builder": ({"kind": "native (libhz_host.so hzb_batch_build_begin / _finish) + hz_poseidon_dag", "batches": len(all_seeds),
@@ -1189,24 +1269,23 @@ def main():
                          "traffic_source": "%s (committed PMC pass of this command line, not measured by this run)" % measured_traffic(dk, Bp)[1] if measured_traffic(dk, Bp)[1] else None,
                          "launches_per_step": dlaunches, "launch_ms": round(dms / dlaunches, 3),
                          "algorithmic_bytes_per_launch": int(dbytes // dlaunches), "gpu_ms_per_step_all_launches": round(tot[dk], 3),
+                         "bytes_per_launch_into_a_fresh_buffer": int(full_bytes.get(dname, 0)),
+                         "left_in_place_frac": round(1.0 - dbytes / dlaunches / full_bytes[dname], 4) if full_bytes.get(dname) else None,
                          "note": "achieved / peak / frac price the kernel against the HBM roofline (the contract's figure); `bound` names the roofline with "
                                  "the larger measured fraction: frac_valu = its VALU wave-instructions x issue cycles / (SIMDs x clock x its duration). "
                                  "algorithmic bytes = 32 B x the witness signals this launch is responsible for; duration = HIP events on its stream with the "
                                  "kernel alone on the device; traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes. "
-                                 "Levels of an SMT proof below the leaf (the hash of an empty subtree) are stored from a constant block and are "
-                                 "HBM-store bound; the levels that hash data are integer-VALU issue bound (DESIGN.md 4)"},
+                                 "Constant marks (DESIGN.md 4): the witness buffer is persistent, and the levels of an SMT proof above its leaf get the same "
+                                 "constant S-box block whatever the batch -- k_smt keeps, per chain and unit, the level from which the buffer already holds it "
+                                 "and stores an empty level only below that mark. algorithmic_bytes_per_launch counts what the launch DID store (the kernel "
+                                 "counts what it left in place: left_in_place_frac of bytes_per_launch_into_a_fresh_buffer), measured on steps that meet new "
+                                 "batches (config.rotation). What is left is integer-VALU issue bound: frac_valu is the binding fraction"},
             "whole_pass": {"algorithmic_bytes_per_tx": algorithmic_bytes_per_tx(lv, F),
                            "achieved_GBs": round(algorithmic_bytes_per_tx(lv, F) * value / world / 1e9, 2),
                            "frac": round(algorithmic_bytes_per_tx(lv, F) * value / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernels_ms": {k: round(v[0], 3) for k, v in acc.items()},
             "kernels_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in acc.items() if v[0] > 0},
         }
-        if "smt_bg" in acc and acc["smt_bg"][0] > 0:
-            b_ms, b_by = acc["smt_bg"][0], acc["smt_bg"][1]
-            out["roofline_smt_bg"] = {"bound": "hbm", "kernel": "k_smt_bg", "achieved": round(b_by / (b_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(b_by / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "launch_ms": round(b_ms, 3), "algorithmic_bytes_per_launch": int(b_by),
-                                      "note": "the constant S-box blocks of the structurally empty SMT levels (counted by the kernel: rows of 64 units x 32 B), stored by a small "
-                                              "persistent grid beside k_smt in the timed step; duration = the kernel alone on the device; k_smt's algorithmic bytes exclude them"}
         if roofline_valu is not None:
             out["roofline_valu"] = roofline_valu
         if single is not None:

@@ -17,10 +17,6 @@
 using namespace hz;
 using namespace hzl;
 
-#ifndef HZ_SMT_BG_MIN
-#define HZ_SMT_BG_MIN 16384u   // units per launch from which the empty levels' constant blocks go through k_smt_bg
-#endif
-
 struct hz_ctx {
     // optional per-kernel timing (HIP events on the launch stream)
     bool profiling = false;
@@ -72,12 +68,19 @@ struct hz_ctx {
     hipEvent_t ev_sha[9] = {};   // HashInputs: chain group g done (0..7), expansion done (8)
     hipStream_t s_fix = nullptr;   // the fixed-base half of the signature check
     hipStream_t s_sha = nullptr;   // SHA-256 expansion groups behind the chain when HashInputs runs early on the fee stream
-    // the constant blocks of the structurally empty SMT levels, stored by k_smt_bg beside the chain kernel (throughput-sized launches)
-    hipStream_t s_bg = nullptr;
-    hipEvent_t ev_bg = nullptr;
+    // Constant marks. The witness buffer is persistent: what the previous step left in it is still there when the next one starts,
+    // and more than a third of what a step of the headline shape used to store does not depend on its inputs -- the S-box block of
+    // Poseidon(0, 0) in the hash slots of every SMT level above a proof's leaf (HZ_POSEIDON3_ZERO_WIT, 243 signals per level and
+    // chain: 36.7 of 100 GB per step), zeros in the switcher / state-machine signals of those levels. k_smt keeps two bytes per
+    // (chain, unit) -- from which level up the buffer holds that content -- stores an empty level only below the mark and leaves
+    // the mark of what the buffer holds after the step (smt_kernels.hip). Nothing but k_smt writes those slots; the marks are cleared
+    // (0xFF: "nothing held") at creation and by hz_clear_inputs. HZ_NO_ZMARK=1: no marks, every level stored every step.
+    DevBuf zm_tx, zm_fee;
+    DevBuf zm_skip;                // profiling: elements not stored by [0] the transaction launch, [1] the fee launch, [2] the early-tail launch
+    bool zm_reset = false;         // hz_clear_inputs: the next enqueue clears the marks first
+    hz::ExportScratch exp_scratch; // export.hip's per-context buffers (ctx_internal.h)
     DevBuf pos3;                   // poseidon_quad.h's constants (C, M R, M R^2): the latency form of k_smt
     bool smt_lat = false;          // this context's chain launches take the latency form (hz_ctx_create)
-    DevBuf bg_rows;                // rows k_smt_bg wrote in the last enqueue (2 KB each): the bytes k_smt is NOT responsible for
     hipEvent_t ev_hash4 = nullptr, ev_tail = nullptr;
     void release_masked();
     ~hz_ctx() {
@@ -91,8 +94,6 @@ struct hz_ctx {
         if (s_fix) (void)hipStreamDestroy(s_fix);
         if (s_copy) (void)hipStreamDestroy(s_copy);
         if (s_sha) (void)hipStreamDestroy(s_sha);
-        if (s_bg) (void)hipStreamDestroy(s_bg);
-        if (ev_bg) (void)hipEventDestroy(ev_bg);
         for (hipEvent_t e : {ev_hash4, ev_tail})
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_staged, ev_unpacked})
@@ -266,6 +267,14 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
     if (e == hipSuccess) e = hipMemcpy((uint8_t*)c->err.p + offsetof(ErrBuf, inst_min), &c->inst_min.p, sizeof(void*), hipMemcpyHostToDevice);
     if (e == hipSuccess && lo.sec_tx >= 0) e = c->sc_tx.alloc((size_t)SC_COUNT * lo.sections[lo.sec_tx].n_units * sizeof(Fr));
     if (e == hipSuccess && lo.sec_fee >= 0) e = c->sc_fee.alloc((size_t)SC_COUNT * lo.sections[lo.sec_fee].n_units * sizeof(Fr));
+    if (!getenv("HZ_NO_ZMARK")) {   // constant marks: two bytes per (chain, unit) of every section k_smt walks
+        if (e == hipSuccess && lo.sec_tx >= 0) e = c->zm_tx.alloc((size_t)4 * lo.sections[lo.sec_tx].n_units * sizeof(uint16_t));
+        if (e == hipSuccess && lo.sec_fee >= 0) e = c->zm_fee.alloc((size_t)2 * lo.sections[lo.sec_fee].n_units * sizeof(uint16_t));
+        if (e == hipSuccess && c->zm_tx.p) e = hipMemset(c->zm_tx.p, 0xFF, c->zm_tx.bytes);
+        if (e == hipSuccess && c->zm_fee.p) e = hipMemset(c->zm_fee.p, 0xFF, c->zm_fee.bytes);
+        if (e == hipSuccess) e = c->zm_skip.alloc(3 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(c->zm_skip.p, 0, c->zm_skip.bytes);
+    }
     if (e == hipSuccess && lo.sec_hi >= 0) {
         e = c->msg.alloc((size_t)lo.hi.sha.nblocks * 64 * lo.n_inst);
         if (e == hipSuccess) e = c->chain.alloc((size_t)(lo.hi.sha.nblocks + 1) * 32 * lo.n_inst);
@@ -333,12 +342,6 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         if (e == hipSuccess) e = make_stream(&c->s_fee, ncu * 3 / 8, ncu / 2);       // fee-transaction chain
         if (e == hipSuccess) e = make_stream(&c->s_main, ncu / 2, ncu);              // front, hash-state, SMT chains, HashInputs
         if (e == hipSuccess && lo.p.tmpl == T_ROLLUP_MAIN && !c->partitioned) e = make_stream(&c->s_sha, 0, 0);
-        if (e == hipSuccess && !c->partitioned && lo.sec_tx >= 0) {   // k_smt_bg (throughput-sized launches of the transaction section)
-            e = hipStreamCreateWithFlags(&c->s_bg, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bg, hipEventDisableTiming);
-            if (e == hipSuccess) e = c->bg_rows.alloc(sizeof(unsigned long long));
-            if (e == hipSuccess) e = hipMemset(c->bg_rows.p, 0, sizeof(unsigned long long));
-        }
         for (hipEvent_t* ev : {&c->ev_hash4, &c->ev_tail})
             if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     }
@@ -373,9 +376,9 @@ extern "C" uint64_t hz_witness_len(const hz_ctx* c) { return c ? c->lo.per_insta
 // batches fit the 288 GB of a device). The same arithmetic as hz_ctx_create and the lazy allocations below.
 static uint64_t layout_device_bytes(const Layout& lo) {
     uint64_t n = lo.total * 32 + sizeof(ErrBuf) + (uint64_t)lo.n_inst * (sizeof(unsigned long long) + sizeof(ErrRec));
-    if (lo.sec_tx >= 0) n += (uint64_t)SC_COUNT * lo.sections[lo.sec_tx].n_units * sizeof(Fr);
+    if (lo.sec_tx >= 0) n += (uint64_t)(SC_COUNT * sizeof(Fr) + 4 * sizeof(uint16_t)) * lo.sections[lo.sec_tx].n_units;
     if (lo.p.tmpl == T_ROLLUP_MAIN || lo.p.tmpl == T_ROLLUP_TX) n += eddsa_side_bytes(lo.sections[lo.sec_tx].n_units);
-    if (lo.sec_fee >= 0) n += (uint64_t)SC_COUNT * lo.sections[lo.sec_fee].n_units * sizeof(Fr);
+    if (lo.sec_fee >= 0) n += (uint64_t)(SC_COUNT * sizeof(Fr) + 2 * sizeof(uint16_t)) * lo.sections[lo.sec_fee].n_units;
     if (lo.sec_hi >= 0) n += ((uint64_t)lo.hi.sha.nblocks * 64 + ((uint64_t)lo.hi.sha.nblocks + 1) * 32) * lo.n_inst;
     uint64_t packed = 0;   // the staging slots of the bulk-upload path (hz_inputs_upload / hz_inputs_stage), one per instance
     for (const InputDesc& d : lo.inputs) packed = ((packed + 31) & ~31ull) + (uint64_t)d.inner * d.outer * d.ebytes;
@@ -401,7 +404,9 @@ extern "C" const char* hz_input_name(const hz_ctx* c, int32_t i, uint64_t* flat_
     return d.name.c_str();
 }
 extern "C" void hz_clear_inputs(hz_ctx* c) {
-    if (c) std::fill(c->input_set.begin(), c->input_set.end(), 0);
+    if (!c) return;
+    std::fill(c->input_set.begin(), c->input_set.end(), 0);
+    c->zm_reset = true;   // a caller that starts over gets a step that stores everything
 }
 extern "C" const char* hz_constraint_name(int32_t id) { return constraint_name(id); }
 
@@ -624,7 +629,7 @@ extern "C" hz_status hz_inputs_upload(hz_ctx* c, int32_t instance, const void* p
     if (st != HZ_OK) return st;
     hipStream_t s = stream ? (hipStream_t)stream : c->s_main;
     if (c->ev_unpacked) HZ_HIP(hipStreamWaitEvent(s, c->ev_unpacked, 0));   // a staged copy of this slot may still be waiting for its unpack
-    HZ_HIP(hipMemcpyAsync(slot, packed, bytes, hipMemcpyHostToDevice, s));
+    HZ_HIP(hipMemcpyAsync(slot, packed, bytes, hipMemcpyDefault, s));   // (`packed` may be device memory: inputs kept resident in packed form)
     st = launch_unpack(c, (uint32_t)instance, s);
     if (st != HZ_OK) return st;
     HZ_HIP(hipEventRecord(c->ev_inputs, s));
@@ -650,7 +655,7 @@ extern "C" hz_status hz_inputs_stage(hz_ctx* c, int32_t instance, const void* pa
         return set_err(HZ_ERR_ARG, "hz_inputs_stage: all stage calls between two enqueues of a context must use the same stream");
     c->stage_stream = s;
     HZ_HIP(hipStreamWaitEvent(s, c->ev_unpacked, 0));   // the slot's previous content has been scattered
-    HZ_HIP(hipMemcpyAsync(slot, packed, bytes, hipMemcpyHostToDevice, s));
+    HZ_HIP(hipMemcpyAsync(slot, packed, bytes, hipMemcpyDefault, s));   // (`packed` may be device memory: inputs kept resident in packed form)
     HZ_HIP(hipEventRecord(c->ev_staged, s));   // all stage calls between two enqueues use one stream: the last record covers them
     c->staged[instance] = 1;
     c->any_staged = true;
@@ -680,7 +685,7 @@ extern "C" hz_status hz_inputs_stage_range(hz_ctx* c, int32_t first, int32_t cou
     st = hz_inputs_stage(c, first, packed, bytes_each, stream);   // creates the copy stream and events on first use; instance `first`
     if (st != HZ_OK || count == 1) return st;
     hipStream_t s = stream ? (hipStream_t)stream : c->s_copy;
-    HZ_HIP(hipMemcpyAsync(slot + bytes_each, (const uint8_t*)packed + bytes_each, (size_t)(count - 1) * bytes_each, hipMemcpyHostToDevice, s));
+    HZ_HIP(hipMemcpyAsync(slot + bytes_each, (const uint8_t*)packed + bytes_each, (size_t)(count - 1) * bytes_each, hipMemcpyDefault, s));
     HZ_HIP(hipEventRecord(c->ev_staged, s));
     for (int32_t j = 1; j < count; j++) c->staged[first + j] = 1;
     return HZ_OK;
@@ -731,6 +736,9 @@ static Hash4Args make_hash4_rtx(uint8_t* base, Fr* sc, uint32_t n_units, const R
 static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa0, const char* name, hipStream_t s) {
     SmtArgs sa = sa0;
     sa.pos3_dense = c->smt_lat ? (const Fr*)c->pos3.p : nullptr;
+    const bool fee = sa.scratch == (Fr*)c->sc_fee.p;
+    sa.zmark = (uint16_t*)(fee ? c->zm_fee.p : c->zm_tx.p);
+    sa.skipped = (c->profiling && c->zm_skip.p) ? (unsigned long long*)c->zm_skip.p + (fee ? 1 : 0) : nullptr;
     ProfScope ps(c, s, name, sa.n_units);
     return launch_smt(sa, s);
 }
@@ -822,6 +830,8 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         SmtArgs sl = sa;
         sl.u0 = (uint32_t)lo.p.nTx - 1; sl.ucnt = lo.n_inst; sl.ustride = (uint32_t)lo.p.nTx;
         sl.p[0].sc_root_old = SC_EROOT_P1OLD; sl.p[0].sc_root_new = SC_EROOT_P1NEW; sl.p[1].sc_root_old = SC_EROOT_P2OLD; sl.p[1].sc_root_new = SC_EROOT_P2NEW;
+        sl.zmark = (uint16_t*)c->zm_tx.p;   // (marks are per unit: these units are nobody else's this step)
+        sl.skipped = (c->profiling && c->zm_skip.p) ? (unsigned long long*)c->zm_skip.p + 2 : nullptr;
         HZ_HIP(launch_smt(sl, st));
         RtxBackArgs bl = ba;
         bl.u0 = sl.u0; bl.ucnt = sl.ucnt; bl.ustride = sl.ustride;
@@ -848,25 +858,8 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         HZ_HIP(launch_hi_prep_body(make_hi(c, true), st));
         HZ_HIP(hipEventRecord(c->ev_tail, st));
     }
-    // EXPERIMENT, off unless HZ_SMT_BG_ON is set (round 5, profiles/r05_ksmt_bg_writer.txt: measured, no-go). The constant blocks of the
-    // structurally empty levels leave through k_smt_bg -- a small persistent store-only grid on a stream of its own, enqueued before the
-    // chain kernel and dependent on the front kernel only (function bits, keys) -- and k_smt stores nothing for those levels: k_smt alone
-    // 20.3 -> 16.1 ms, the writer alone 7.0 ms (5.2 TB/s), and the STEP 1.4-5 % SLOWER whatever the grid (128 .. 1024 wavefronts), the
-    // stream priority or the enqueue order: bytes stored beside an integer-bound kernel are not free on this device, inside its
-    // instruction stream (BgZero) they nearly are. Bit-exact either way (tests/test_witness_gpu.py runs a launch with it on).
-    const uint32_t smt_count = ucnt ? ucnt : n_units;
-    const bool bg_ext = c->s_bg && !c->sharded && smt_count >= HZ_SMT_BG_MIN && getenv("HZ_SMT_BG_ON");
-    if (bg_ext) {
-        sa.bg_external = 1;
-        hipStream_t sb = c->exclusive ? s : c->s_bg;
-        HZ_HIP(hipMemsetAsync(c->bg_rows.p, 0, sizeof(unsigned long long), sb));
-        if (!c->exclusive) HZ_HIP(hipStreamWaitEvent(sb, c->ev_front, 0));
-        { ProfScope ps(c, sb, "smt_bg", n_units); HZ_HIP(launch_smt_bg(sa, (unsigned long long*)c->bg_rows.p, sb)); }
-        if (!c->exclusive) HZ_HIP(hipEventRecord(c->ev_bg, sb));
-    }
     HZ_HIP(enqueue_smt_chain(c, sa, "smt", s));
     { ProfScope ps(c, s, "rtx_back", n_units); HZ_HIP(launch_rtx_back(ba, s)); }
-    if (bg_ext && !c->exclusive) HZ_HIP(hipStreamWaitEvent(s, c->ev_bg, 0));
     return HZ_OK;   // the caller joins the signature stream (ev_ed) after whatever else it launches on `s`
 }
 
@@ -988,6 +981,12 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
         ~StreamAlias() { c->s_ed = ed; c->s_fee = fee; }
     } alias(c, s);
     { const hz_status st = reset_err(c, s, filter); if (st != HZ_OK) return st; }
+    if (c->zm_reset) {   // (before ev_reset: every side stream waits for it before its first kernel)
+        if (c->zm_tx.p) HZ_HIP(hipMemsetAsync(c->zm_tx.p, 0xFF, c->zm_tx.bytes, s));
+        if (c->zm_fee.p) HZ_HIP(hipMemsetAsync(c->zm_fee.p, 0xFF, c->zm_fee.bytes, s));
+        c->zm_reset = false;
+    }
+    if (c->profiling && c->zm_skip.p) HZ_HIP(hipMemsetAsync(c->zm_skip.p, 0, c->zm_skip.bytes, s));
     HZ_HIP(hipEventRecord(c->ev_reset, s));
     ErrBuf* err = (ErrBuf*)c->err.p;
     c->prof_used = 0;
@@ -1325,16 +1324,12 @@ extern "C" hz_status hz_profile_get(hz_ctx* c, int32_t i, const char** kernel, f
     if (kernel) *kernel = p.name.c_str();
     if (ms) *ms = p.ms;
     uint64_t bytes = p.bytes;
-    if (c->bg_rows.p && (p.name == "smt" || p.name == "smt_bg")) {
-        // the constant blocks k_smt_bg stored this step (2 KB rows: 64 units x 32 B) are its algorithmic bytes, not k_smt's
-        bool used = false;
-        for (size_t k = 0; k < c->prof_used; k++) used = used || c->prof[k].name == "smt_bg";
-        if (used) {
-            unsigned long long rows = 0;
-            HZ_HIP(hipMemcpy(&rows, c->bg_rows.p, sizeof rows, hipMemcpyDeviceToHost));
-            const uint64_t bg = (uint64_t)rows * 2048ull;
-            bytes = p.name == "smt_bg" ? bg : (bytes > bg ? bytes - bg : 0);
-        }
+    if (c->zm_skip.p && (p.name == "smt" || p.name == "fee_smt")) {
+        // what the launch left in place because the buffer held it already (constant marks) is not among the bytes it is responsible for
+        unsigned long long sk[3] = {0, 0, 0};
+        HZ_HIP(hipMemcpy(sk, c->zm_skip.p, sizeof sk, hipMemcpyDeviceToHost));
+        const uint64_t left = (uint64_t)sk[p.name == "smt" ? 0 : 1] * 32ull;
+        bytes = bytes > left ? bytes - left : 0;
     }
     if (algorithmic_bytes) *algorithmic_bytes = bytes;
     if (units) *units = p.units;
@@ -1347,6 +1342,7 @@ extern "C" hz_status hz_witness_run(hz_ctx* c, hz_error* err) {
     return hz_witness_check(c, err);
 }
 
+hz::ExportScratch* hz::ctx_export_scratch(hz_ctx* c) { return &c->exp_scratch; }
 void hz::ctx_geometry(const hz_ctx* c, CtxGeom& g) {
     const Layout& lo = c->lo;
     g.nsec = (uint32_t)std::min<size_t>(lo.sections.size(), 4);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/hermez_witness.h"
+#include "hostutil.h"
 
 namespace hz {
 // section of the witness: virtual element v of instance i (v - vbase = sig * upi + unit) lives at physical element
@@ -18,4 +19,12 @@ struct CtxGeom {
     const void* wit = nullptr;
 };
 void ctx_geometry(const hz_ctx* c, CtxGeom& g);
+// The export's scratch belongs to the CONTEXT, not to the map: two contexts that export through one map (each on its own stream) must
+// not share the derived-value buffer or the staging vector of the host deliveries (a map's device plan holds tables only).
+struct ExportScratch {
+    DevBuf dval;              // derived values of the instances exported together: [instances][D] elements
+    uint64_t dval_elems = 0;
+    DevBuf xbuf;              // one exported vector, the source of a host delivery (released after deliveries above 64 MB)
+};
+ExportScratch* ctx_export_scratch(hz_ctx* c);
 }  // namespace hz

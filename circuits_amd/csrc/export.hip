@@ -79,10 +79,7 @@ struct DevPlan {
     DevBuf lvl_k;
     PosGroup pg[6];
     DevBuf pl_slot, pl_k;
-    DevBuf dval;                  // [instances exported together][D] elements
-    uint64_t dval_inst = 0;
     DevBuf phys0, istride;        // hz_symmap_dev_index
-    DevBuf xbuf;                  // one exported vector on the device, the source of the host deliveries
     uint64_t bytes = 0;           // device bytes of the tables
 };
 void devplan_free(DevPlan* p) { delete p; }
@@ -564,18 +561,20 @@ static hz_status get_plan(hz_ctx* ctx, const hz_symmap* m, CtxGeom& g, DevPlan**
                        (unsigned long long)m->unresolved[0], m->first_label[0].c_str());
     ctx_geometry(ctx, g);
     std::lock_guard<std::mutex> lk(m->dev_mu);
-    DevPlan* P = m->dev;
-    bool same = P && P->device == g.device && P->per_instance == g.per_instance && P->total == g.total && P->n_inst == g.n_inst && P->st.nsec == g.nsec && P->nvars == m->index.size();
-    for (uint32_t i = 0; same && i < g.nsec; i++) same = !memcmp(&P->st.sec[i], &g.sec[i], sizeof(SecMap));
-    if (!same) {
-        if (P) { devplan_free(P); m->dev = nullptr; }
+    DevPlan* P = nullptr;
+    for (DevPlan* Q : m->devs) {
+        bool same = Q->device == g.device && Q->per_instance == g.per_instance && Q->total == g.total && Q->n_inst == g.n_inst && Q->st.nsec == g.nsec && Q->nvars == m->index.size();
+        for (uint32_t i = 0; same && i < g.nsec; i++) same = !memcmp(&Q->st.sec[i], &g.sec[i], sizeof(SecMap));
+        if (same) { P = Q; break; }
+    }
+    if (!P) {
         try {
             const hz_status st = build_plan(g, m, &P);
             if (st != HZ_OK) return st;
         } catch (const std::bad_alloc&) {
             return set_err(HZ_ERR_INPUT, "witness export: out of host memory while building the device plan");
         }
-        m->dev = P;
+        m->devs.push_back(P);
     }
     *plan = P;
     return HZ_OK;
@@ -584,18 +583,18 @@ static hz_status get_plan(hz_ctx* ctx, const hz_symmap* m, CtxGeom& g, DevPlan**
 static unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)std::min<uint64_t>((n + block - 1) / block, 1u << 16); }
 
 // derived values of `ninst` instances from inst0 on into P->dval
-static hz_status derive(DevPlan* P, const CtxGeom& g, uint32_t inst0, uint32_t ninst, hipStream_t s) {
+static hz_status derive(DevPlan* P, ExportScratch* X, const CtxGeom& g, uint32_t inst0, uint32_t ninst, hipStream_t s) {
     if (P->D == 0 || P->n_dvars == 0) return HZ_OK;
-    if (P->dval_inst < ninst) {
-        HZ_HIP(P->dval.alloc((size_t)ninst * P->D * 32));
-        P->dval_inst = ninst;
+    if (X->dval_elems < (uint64_t)ninst * P->D) {   // (hipFree waits for the device: nothing in flight reads the old one)
+        HZ_HIP(X->dval.alloc((size_t)ninst * P->D * 32));
+        X->dval_elems = (uint64_t)ninst * P->D;
     }
     for (int t = 2; t <= 7; t++) {
         const PosGroup& G = P->pg[t - 2];
         if (!G.n) continue;
         PosArgs a;
         memset(&a, 0, sizeof a);
-        a.wit = (const hz_u32x4*)g.wit; a.dval = (hz_u32x4*)P->dval.p; a.D = P->D; a.n = G.n; a.inst0 = inst0; a.st = P->st;
+        a.wit = (const hz_u32x4*)g.wit; a.dval = (hz_u32x4*)X->dval.p; a.D = P->D; a.n = G.n; a.inst0 = inst0; a.st = P->st;
         a.first = (const uint32_t*)G.first.p; a.loff = (const uint32_t*)G.loff.p; a.pl_slot = (const uint16_t*)P->pl_slot.p; a.pl_k = (const uint32_t*)P->pl_k.p;
         a.C = (const Fr*)G.C.p; a.M = (const Fr*)G.M.p;
         const dim3 grid((unsigned)((G.n + 63) / 64), ninst), block(64);
@@ -611,7 +610,7 @@ static hz_status derive(DevPlan* P, const CtxGeom& g, uint32_t inst0, uint32_t n
     }
     DrvArgs a;
     memset(&a, 0, sizeof a);
-    a.wit = (const hz_u32x4*)g.wit; a.dval = (hz_u32x4*)P->dval.p; a.D = P->D; a.inst0 = inst0; a.st = P->st;
+    a.wit = (const hz_u32x4*)g.wit; a.dval = (hz_u32x4*)X->dval.p; a.D = P->D; a.inst0 = inst0; a.st = P->st;
     a.kind = (const uint8_t*)P->kind.p; a.arg = (const uint32_t*)P->arg.p;
     a.form_off = (const uint32_t*)P->form_off.p; a.form_c0 = (const uint32_t*)P->form_c0.p; a.term_coef = (const uint32_t*)P->term_coef.p; a.term_src = (const uint32_t*)P->term_src.p;
     a.pool = (const Fr*)P->pool.p; a.lvl_k = (const uint32_t*)P->lvl_k.p;
@@ -636,7 +635,7 @@ extern "C" hz_status hz_symmap_upload(hz_ctx* ctx, const hz_symmap* m, uint64_t*
 
 namespace hzexp {
 // instances [inst0, inst0 + ninst) into out[j][var], j = 0..ninst-1; ninst <= 32768
-static hz_status export_chunk(DevPlan* P, const CtxGeom& g, uint32_t inst0, uint32_t ninst, void* d_out, hipStream_t s) {
+static hz_status export_chunk(DevPlan* P, ExportScratch* X, const CtxGeom& g, uint32_t inst0, uint32_t ninst, void* d_out, hipStream_t s) {
     ExpArgs a;
     memset(&a, 0, sizeof a);
     a.wit = (const hz_u32x4*)g.wit; a.out = (hz_u32x4*)d_out; a.out_stride = P->nvars; a.inst0 = inst0; a.st = P->st;
@@ -660,9 +659,9 @@ static hz_status export_chunk(DevPlan* P, const CtxGeom& g, uint32_t inst0, uint
         HZ_HIP(hipGetLastError());
     }
     if (P->n_dvars) {
-        const hz_status sd = derive(P, g, inst0, ninst, s);
+        const hz_status sd = derive(P, X, g, inst0, ninst, s);
         if (sd != HZ_OK) return sd;
-        hipLaunchKernelGGL(k_export_dvars, dim3(grid_for(P->n_dvars, 256), ninst), dim3(256), 0, s, (const hz_u32x4*)P->dval.p, P->D, (hz_u32x4*)d_out, P->nvars, (const uint32_t*)P->dv_v.p,
+        hipLaunchKernelGGL(k_export_dvars, dim3(grid_for(P->n_dvars, 256), ninst), dim3(256), 0, s, (const hz_u32x4*)X->dval.p, P->D, (hz_u32x4*)d_out, P->nvars, (const uint32_t*)P->dv_v.p,
                            (const uint32_t*)P->dv_k.p, P->n_dvars);
         HZ_HIP(hipGetLastError());
     }
@@ -682,7 +681,7 @@ extern "C" hz_status hz_witness_export_range_dev(hz_ctx* ctx, const hz_symmap* m
     const uint32_t CH = 32768;   // (grid.y is 16 bits; the derived-value buffer is sized for one chunk)
     for (uint32_t done = 0; done < (uint32_t)count; done += CH) {
         const uint32_t n = std::min<uint32_t>(CH, (uint32_t)count - done);
-        const hz_status sc = export_chunk(P, g, (uint32_t)first_instance + done, n, (uint8_t*)d_out + (uint64_t)done * P->nvars * 32, s);
+        const hz_status sc = export_chunk(P, ctx_export_scratch(ctx), g, (uint32_t)first_instance + done, n, (uint8_t*)d_out + (uint64_t)done * P->nvars * 32, s);
         if (sc != HZ_OK) return sc;
     }
     return HZ_OK;
@@ -728,9 +727,10 @@ extern "C" hz_status hz_witness_derive_dev(hz_ctx* ctx, const hz_symmap* m, int3
     if (instance < -1 || instance >= (int32_t)g.n_inst) return set_err(HZ_ERR_ARG, "hz_witness_derive_dev: bad instance %d", instance);
     HZ_HIP(hipSetDevice(g.device));
     if (instance < 0 && g.n_inst > 32768) return set_err(HZ_ERR_ARG, "hz_witness_derive_dev: at most 32768 instances at once");
-    const hz_status sd = derive(P, g, instance < 0 ? 0 : (uint32_t)instance, instance < 0 ? g.n_inst : 1, stream ? (hipStream_t)stream : g.s_main);
+    ExportScratch* X = ctx_export_scratch(ctx);
+    const hz_status sd = derive(P, X, g, instance < 0 ? 0 : (uint32_t)instance, instance < 0 ? g.n_inst : 1, stream ? (hipStream_t)stream : g.s_main);
     if (sd != HZ_OK) return sd;
-    if (d_derived) *d_derived = P->dval.p;
+    if (d_derived) *d_derived = X->dval.p;
     return HZ_OK;
 }
 
@@ -754,8 +754,13 @@ static hz_status export_through_ring(hz_ctx* ctx, const hz_symmap* m, int32_t in
     if (instance < 0 || instance >= (int32_t)g.n_inst) return set_err(HZ_ERR_ARG, "witness export: bad instance %d", instance);
     if (first > P->nvars || count > P->nvars - first) return set_err(HZ_ERR_ARG, "witness export: range beyond the %llu variables", (unsigned long long)P->nvars);
     HZ_HIP(hipSetDevice(g.device));
-    if (!P->xbuf.p) HZ_HIP(P->xbuf.alloc(std::max<uint64_t>(P->nvars, 1) * 32));
-    DevBuf& dout = P->xbuf;
+    ExportScratch* X = ctx_export_scratch(ctx);
+    if (X->xbuf.bytes < std::max<uint64_t>(P->nvars, 1) * 32) HZ_HIP(X->xbuf.alloc(std::max<uint64_t>(P->nvars, 1) * 32));
+    DevBuf& dout = X->xbuf;
+    struct Release {   // a whole-witness staging vector (3.86 GB at the headline shape) does not stay behind a host delivery
+        DevBuf& b;
+        ~Release() { if (b.bytes > (64ull << 20)) b.release(); }
+    } release_after{dout};
     st = hz_witness_export_dev(ctx, m, instance, dout.p, g.s_main);
     if (st != HZ_OK) return st;
     if (direct_out) {   // the caller's buffer is pinned: one copy at PCIe speed, no staging

@@ -1149,7 +1149,12 @@ extern "C" hz_status hz_symmap_load(const hz_ctx* ctx, const char* path, hz_symm
     hz_symmap* m = nullptr;
     try {
         MapHdr h;
-        bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "hzsm", 4) && h.version == 2;
+        bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "hzsm", 4);
+        if (ok && h.version != 2) {
+            fclose(f);
+            return set_err(HZ_ERR_INPUT, "hz_symmap_load: %s is a version-%u map (this library reads version 2: files carry a checksum since): import the .sym / .r1cs again "
+                                         "and save the map (hz_witness --map)", path, h.version);
+        }
         if (ok) {   // the trailing checksum first: nothing of a damaged file is followed
             uint64_t want = 0, got = 0;
             ok = fseek(f, -8, SEEK_END) == 0 && fread(&got, 8, 1, f) == 1 && file_fnv1a(path, 8, &want) && want == got;
@@ -1240,10 +1245,14 @@ static hz_status symmap_usable(const hz_symmap* m, const char* who) {
     return HZ_OK;
 }
 extern "C" hz_status hz_witness_read_sym(hz_ctx* ctx, const hz_symmap* m, int32_t instance, uint64_t first, uint64_t count, uint8_t* out) {
-    const hz_status st = symmap_usable(m, "hz_witness_read_sym");
-    if (st != HZ_OK) return st;
+    if (!m) return set_err(HZ_ERR_ARG, "hz_witness_read_sym: null symbol map");
     if (first > m->index.size() || count > m->index.size() - first) return set_err(HZ_ERR_ARG, "hz_witness_read_sym: range beyond the %zu variables", m->index.size());
-    if (count > SMALL_READ) return hz_witness_export_host(ctx, m, instance, first, count, out);   // the device pass (export.hip)
+    // only the variables ASKED FOR have to be served: a map with an unresolved variable elsewhere still answers (on the host path)
+    for (size_t k = 0; k < m->unresolved.size(); k++)
+        if (m->unresolved[k] >= first && m->unresolved[k] - first < count)
+            return set_err(HZ_ERR_INPUT, "hz_witness_read_sym: variable %llu (%s) of the range is not stored by this layout (%zu of %zu variables of the .sym are not)",
+                           (unsigned long long)m->unresolved[k], m->first_label[k].c_str(), m->unresolved.size(), m->index.size());
+    if (count > SMALL_READ && m->unresolved.empty()) return hz_witness_export_host(ctx, m, instance, first, count, out);   // the device pass (export.hip)
     return symmap_values(ctx, m, instance, m->index.data() + first, count, out);
 }
 extern "C" uint64_t hz_symmap_derived(const hz_symmap* m) { return m ? m->n_derived : 0; }

@@ -10,6 +10,7 @@
 // whole batch is bounded by the tree depth: the jobs are sorted into (wave, width) segments and evaluated segment by segment -- by
 // hz_poseidon_dag on the device (one launch per tree level for ALL transactions) or by the host Poseidon of this library.
 // Caller-side code: it prepares circuit INPUTS, never a witness, and shares nothing with oracle/.
+#include <atomic>
 #include <stdint.h>
 #include <string.h>
 #include <chrono>
@@ -65,7 +66,14 @@ struct Job {
 
 // The jobs of one evaluation, detached from the database: what a worker thread evaluates while the next batch is walked
 // (hzb_batch_build_begin / _finish). Jobs [base, base + jobs.size()); an input below `base` is a digest of the flush before it.
+static std::atomic<long> g_live_flushes{0};   // hzb_live_flushes(): the tests' proof that a pipelined build frees what it made
 struct Flush {
+    Flush() { g_live_flushes++; }
+    Flush(const Flush&) = delete;
+    Flush& operator=(const Flush&) = delete;
+    // `done` refers to the worker's shared state and the worker refers to this object by plain pointer (NOT by shared_ptr: the future inside the
+    // object it keeps alive was a cycle that never died -- a few MB per pipelined batch); whoever drops the last reference waits here.
+    ~Flush() { wait(); g_live_flushes--; }
     std::vector<Job> jobs;
     std::vector<U256> consts;
     int64_t base = 0;
@@ -1078,7 +1086,7 @@ int build_begin(hzb_batch* bb, bool threaded) {
     run.fl = dag.detach();
     db->outstanding.push_back(bb);
     if (threaded) {
-        std::shared_ptr<Flush> f = run.fl;
+        Flush* f = run.fl.get();   // kept alive by run.fl (and by the next flush's `prev`) until somebody has waited for it: ~Flush
         f->done = std::async(std::launch::async, [f] { f->run(); }).share();
     } else {
         run.fl->run();
@@ -1554,6 +1562,7 @@ int hzb_batch_tx_flags(const hzb_batch* b, int32_t i, int32_t* is_amount_nullifi
     return HZB_OK;
 }
 double hzb_batch_sign_s(const hzb_batch* b) { return b ? b->sign_s : 0.0; }
+long hzb_live_flushes(void) { return g_live_flushes.load(); }
 int hzb_batch_stats(const hzb_batch* b, uint64_t* jobs, uint64_t* segments, double* device_ms, double* walk_s, double* eval_s) {
     if (!b) return fail(HZB_ERR_ARG, "hzb_batch_stats: null batch");
     if (jobs) *jobs = b->jobs;

@@ -96,7 +96,12 @@ struct SmtArgs {
     uint32_t n_proc;
     uint32_t upi;
     uint32_t skip_mod;            // != 0: units u with u % skip_mod == skip_mod - 1 belong to another launch of the step (early tail)
-    uint32_t bg_external;         // != 0: the constant blocks of the structurally empty levels are k_smt_bg's this step, not k_smt's
+    // Constant marks (ctx.hip "constant marks"): two bytes per (chain, unit) that say from which level up the persistent witness buffer
+    // ALREADY holds what an empty level gets -- low byte: the constant S-box block of the level hash (HZ_POSEIDON3_ZERO_WIT), high byte: zeros
+    // in the per-level switcher / state-machine signals. k_smt stores such a level only below the mark and leaves the new mark behind.
+    // NULL: every level is stored (HZ_NO_ZMARK, experiments).
+    uint16_t* zmark;              // [2 * n_proc][n_units]
+    unsigned long long* skipped;  // profiling: elements (32 B each) this launch did NOT store because of the marks; NULL: not counted
     const Fr* pos3_dense;         // the dense constants of poseidon_quad.h (C[195], M1[9], M2[9]); NULL: no latency form for this launch
     SmtProcDesc p[2];
 };
@@ -217,7 +222,6 @@ hipError_t launch_hash4(const Hash4Args& a, hipStream_t s);
 hipError_t launch_smt(const SmtArgs& a, hipStream_t s);
 size_t pos3_dense_bytes();
 hipError_t upload_pos3_dense(Fr* dst);   // synchronous; dst holds pos3_dense_bytes()
-hipError_t launch_smt_bg(const SmtArgs& a, unsigned long long* rows_written, hipStream_t s);
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
 hipError_t launch_da_mask(const RtxBackArgs& a, hipStream_t s);   // RollupMain phase H alone (amount bits of L1L2TxData times 1 - isAmountNullified), every unit
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s, hipEvent_t front_done = nullptr);   // front_done: waited for where the front step's scratch is first read (NULL: the caller has ordered the stream already)         // AySign2Ax, message hash, variable-base ladder, R8 + h*8A

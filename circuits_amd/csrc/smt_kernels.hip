@@ -104,8 +104,8 @@ __device__ __forceinline__ uint32_t wave_max_u6(uint32_t v) {
     }
     return r;
 }
-// What the two kernels below must agree on, bit for bit: the shape of one SMTProcessor chain of one unit -- the zero pattern of its
-// siblings, the level SMTLevIns selects, where the keys part -- and from it the first level from which the chain is STRUCTURALLY empty.
+// The shape of one SMTProcessor chain of one unit -- the zero pattern of its siblings, the level SMTLevIns selects, where the keys
+// part -- and from it the first level from which the chain is STRUCTURALLY empty.
 struct SmtShape {
     uint64_t zmask;    // bit i = siblings[i] == 0
     uint64_t levmask;  // levIns, one-hot
@@ -154,15 +154,6 @@ __device__ __forceinline__ uint32_t smt_thr_lane(const SmtShape& sh, bool m_zero
     if (thr_lane > n) thr_lane = n;
     return (uint32_t)thr_lane;
 }
-// m = enabled * fnc0 * (1 - isOld0), the multiplier of the "insert below an existing leaf" states: zero for update / nop / insert into
-// an empty slot (the same field operations as k_smt's own m)
-__device__ __forceinline__ bool smt_m_is_zero(const Scratch& sc, const SmtProcDesc& P) {
-    const Fr fnc0 = sc.get(P.sc_fnc0), fnc1 = sc.get(P.sc_fnc1), isOld0 = sc.get(P.sc_isold0);
-    const Fr enabled = fr_sub(fr_add(fnc0, fnc1), fr_mul(fnc0, fnc1));
-    const Fr A2 = fr_mul(enabled, fnc0);
-    return fr_is_zero(fr_sub(A2, fr_mul(A2, isOld0)));
-}
-
 // Two wavefronts of this kernel per SIMD saturate the integer pipe (three, with the register budget that implies: no faster).
 // Two wavefronts per workgroup: the kernel alone does not care (20.7 ms either way), the STEP does -- with the signature ladders, the
 // fee chain and the SHA-256 tail of two contexts beside it, pairs of k_smt wavefronts placed together measured 35.7-35.9 ms per step
@@ -268,6 +259,19 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(LA
     // k > kx or m = 0), the switcher auxiliaries and the roots (root(k) = h1 * s(k) with s(k) = 0): they are stored as zeros without
     // the products and conversions (`dead`, wave-uniform; 19 of 33 levels in a tree of 2^13 accounts).
     const uint32_t thr_wave = wave_max_u6(smt_thr_lane(shape, fr_is_zero(m), new_side, n));
+    // Constant marks (SmtArgs::zmark): the witness buffer outlives the step, and what an empty level gets does not depend on the inputs --
+    // the 243-signal block of Poseidon(0, 0) in its hash slots (from level markH up this unit's chain holds it already), zeros in the
+    // switcher / state-machine signals of a dead level (from markD up). Such a level is stored only BELOW the wavefront's mark (the
+    // maximum over its lanes: every lane holds the constant from there on); the lane leaves the marks of what the buffer holds now.
+    uint32_t mkH = (uint32_t)n, mkD = (uint32_t)n;
+    if (a.zmark) {
+        const uint32_t v = *(const __attribute__((address_space(1))) uint16_t*)(a.zmark + (size_t)chain * a.n_units + i);
+        mkH = (v & 0xffu) < (uint32_t)n ? (v & 0xffu) : (uint32_t)n;
+        mkD = (v >> 8) < (uint32_t)n ? (v >> 8) : (uint32_t)n;
+    }
+    const uint32_t markH = wave_max_u6(mkH), markD = wave_max_u6(mkD);
+    uint32_t newH = thr_wave > 0 ? thr_wave : (uint32_t)n;   // lowered below by hashing levels whose inputs vanish on every lane
+    uint32_t n_skipped = 0;                                   // signals of this lane left as they were (wave-uniform)
     if (new_side) {
         Fr p_na = fr_sub(one, enabled), p_new1 = zero, p_old0 = zero, p_upd = zero;
         Fr last_sum = zero;
@@ -281,8 +285,10 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(LA
             const Fr t_na = fr_add(fr_add(fr_add(p_new1, p_old0), p_na), p_upd);
             const uint32_t b = o.sm + SM_N * k;
             if (thr_wave > 0 && (uint32_t)k > thr_wave) {
-                const Fc z0 = fc_zero();
-                io.put_c(b + SM_AUX1, z0); io.put_c(b + SM_AUX2, z0); io.put_c(b + SM_OLD0, z0); io.put_c(b + SM_NEW1, z0); io.put_c(b + SM_BOT, z0);
+                if ((uint32_t)k < markD) {
+                    const Fc z0 = fc_zero();
+                    io.put_c(b + SM_AUX1, z0); io.put_c(b + SM_AUX2, z0); io.put_c(b + SM_OLD0, z0); io.put_c(b + SM_NEW1, z0); io.put_c(b + SM_BOT, z0);
+                } else n_skipped += 5;
             } else {
                 io.put_m(b + SM_AUX1, aux1); io.put_m(b + SM_AUX2, aux2); io.put_m(b + SM_OLD0, t_old0); io.put_m(b + SM_NEW1, t_new1);
                 io.put_m(b + SM_BOT, t_bot);
@@ -302,8 +308,11 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(LA
         if (thr_wave > 0 && (uint32_t)k > thr_wave) {
             // dead level: nothing but zeros beside its (constant) hash block, which a hashing level stores (the latency form: here)
             const Fc z0 = fc_zero();
-            if (LAT) poseidon3_zero_level_quad(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH), qj);
-            if (!new_side) {
+            if ((uint32_t)k >= markH) n_skipped += 243;
+            else if (LAT) poseidon3_zero_level_quad(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH), qj);
+            if ((uint32_t)k >= markD) {
+                n_skipped += new_side ? 7 : 3;
+            } else if (!new_side) {
                 io.put_c(lv + LV_OLDSW_AUX, z0); io.put_c(lv + LV_AUX0, z0); io.put_c(lv + LV_OLDROOT, z0);
             } else {
                 io.put_c(lv + LV_NEWSW_AUX, z0); io.put_c(lv + LV_AUX1, z0); io.put_c(lv + LV_AUX2, z0);
@@ -339,13 +348,16 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(LA
         Fr h;
         if (thr_wave > 0 && (uint32_t)k >= thr_wave) {
             // structurally empty for the whole wavefront: its block is stored by one of the hashing levels (below), only the digest here
-            if (LAT) poseidon3_zero_level_quad(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH), qj);
+            if ((uint32_t)k >= markH) n_skipped += 243;   // (== thr_wave: the dead levels above counted themselves)
+            else if (LAT) poseidon3_zero_level_quad(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH), qj);
 #pragma unroll
             for (int q = 0; q < 9; q++) h.v[q] = HZ_POSEIDON3_ZERO_HASH[q];
         } else if (LAT) {
             const uint32_t hs = lv + (new_side ? LV_NEWHASH : LV_OLDHASH);
             if (__all(fr_is_zero(hin[0]) && fr_is_zero(hin[1]))) {
-                poseidon3_zero_level_quad(io, hs, qj);
+                if ((uint32_t)k >= markH) n_skipped += 243;
+                else poseidon3_zero_level_quad(io, hs, qj);
+                if (newH == (uint32_t)k + 1) newH = (uint32_t)k;
 #pragma unroll
                 for (int q = 0; q < 9; q++) h.v[q] = HZ_POSEIDON3_ZERO_HASH[q];
             } else {
@@ -353,17 +365,24 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(LA
                 h = poseidon3_quad(hin[0], hin[1], KD, WitOut{a.base, a.n_units, i}, hs, qj);
             }
         } else {
-            // hashing level k (< thr_wave) also stores the blocks of empty levels thr + [k E / H, (k+1) E / H), E = n - thr, H = thr
+            // hashing level k (< thr_wave) also stores the blocks of the empty levels that do not hold theirs yet:
+            // thr + [k E / H, (k+1) E / H), E = min(markH, n) - thr (often 0: the previous step left them), H = thr
             BgZero bg{a.base, a.n_units, i, o.levels + (new_side ? LV_NEWHASH : LV_OLDHASH), 0, 0, 0, 0};
-            if (thr_wave > 0 && !a.bg_external && !LAT) {   // (bg_external: k_smt_bg stores the empty levels' blocks beside this kernel)
-                const uint32_t E = (uint32_t)n - thr_wave;
+            if (thr_wave > 0 && markH > thr_wave && !LAT) {
+                const uint32_t E = markH - thr_wave;
                 bg.j = thr_wave + (uint32_t)k * E / thr_wave;
                 bg.j_end = thr_wave + ((uint32_t)k + 1) * E / thr_wave;
                 bg.per = ((bg.j_end - bg.j) * 243 + 80) / 81;
             }
             SmtSboxSink sk{io.sbox_sink(lv + (new_side ? LV_NEWHASH : LV_OLDHASH)), &bg};
-            if (__all(fr_is_zero(hin[0]) && fr_is_zero(hin[1]))) h = poseidon3_zero_level(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
-            else h = poseidon_hash<3>(hin, K3, sk);
+            if (__all(fr_is_zero(hin[0]) && fr_is_zero(hin[1]))) {
+                if ((uint32_t)k >= markH) {
+                    n_skipped += 243;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) h.v[q] = HZ_POSEIDON3_ZERO_HASH[q];
+                } else h = poseidon3_zero_level(io, lv + (new_side ? LV_NEWHASH : LV_OLDHASH));
+                if (newH == (uint32_t)k + 1) newH = (uint32_t)k;
+            } else h = poseidon_hash<3>(hin, K3, sk);
             bg.flush();
         }
         if (!new_side) {
@@ -381,62 +400,15 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(LA
         }
     }
     sc.set(root_slot, child);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 5, off by default: ctx.hip HZ_SMT_BG_ON; profiles/r05_ksmt_bg_writer.txt). The constant blocks of the structurally
-// empty levels written by a kernel of their own BESIDE k_smt instead of in the shadow of its hashing levels (BgZero): a small persistent
-// grid whose only work is stores -- a job = (64 consecutive units, chain); the wavefront derives the same thr_wave as k_smt's wavefront of
-// those units (smt_shape / smt_thr_lane: one statement of the rule for both) and streams the 243-signal block of every level from
-// thr_wave up; k_smt (bg_external) stores nothing for those levels. k_smt alone 20.3 -> 16.1 ms; the step 1.4-5 % slower.
-__global__ __launch_bounds__(64) void k_smt_bg(const SmtArgs a, unsigned long long* rows_written) {
-    const uint32_t count = a.ucnt ? a.ucnt : a.n_units;
-    const uint32_t n_blocks = (count + 63) / 64, n_jobs = n_blocks * 2 * a.n_proc;
-    const int n = (int)a.n_levels;
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
-        const uint32_t chain = job / n_blocks, blk = job - chain * n_blocks;
-        const uint32_t pi = chain >> 1;
-        const bool new_side = chain & 1;
-        const SmtProcDesc& P = a.p[pi];
-        const uint32_t li = blk * 64 + lane;
-        const uint32_t i = a.u0 + li * (a.ustride > 1 ? a.ustride : 1u);
-        const bool active = li < count && !(a.skip_mod && i % a.skip_mod == a.skip_mod - 1);
-        uint32_t thr_lane = 0;
-        if (active) {
-            const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
-            const Scratch sc{a.scratch, a.n_units, i};
-            const Fc oldKey_c = fr_to_canon(sc.get(P.sc_oldkey)), newKey_c = fr_to_canon(sc.get(P.sc_newkey));
-            const uint64_t keylo_old = (uint64_t)oldKey_c.v[0] | ((uint64_t)oldKey_c.v[1] << 32), keylo_new = (uint64_t)newKey_c.v[0] | ((uint64_t)newKey_c.v[1] << 32);
-            const SmtShape shape = smt_shape(io, P.siblings, n, keylo_old, keylo_new);
-            thr_lane = smt_thr_lane(shape, smt_m_is_zero(sc, P), new_side, n);
-        }
-        const uint32_t thr_wave = wave_max_u6(thr_lane);
-        if (thr_wave == 0 || thr_wave >= (uint32_t)n) continue;   // (0: k_smt hashes every level of such a wavefront itself)
-        const uint32_t off0 = P.o.levels + (new_side ? LV_NEWHASH : LV_OLDHASH);
-        if (active) {
-            for (uint32_t j = thr_wave; j < (uint32_t)n; j++) {
-#pragma unroll 3
-                for (uint32_t sgn = 0; sgn < 243; sgn++) {
-                    Fc c;
-#pragma unroll
-                    for (int q = 0; q < 8; q++) c.v[q] = HZ_POSEIDON3_ZERO_WIT[sgn][q];
-                    store_fr(a.base + ((size_t)(off0 + LV_SIZE * j + sgn) * a.n_units + i) * 32, c);
-                }
-            }
-        }
-        if (rows_written && lane == 0) atomicAdd(rows_written, (unsigned long long)((uint32_t)n - thr_wave) * 243ull);
+    if (a.zmark && qj == 0) {
+        const uint32_t newD = thr_wave > 0 ? (thr_wave + 1 < (uint32_t)n ? thr_wave + 1 : (uint32_t)n) : (uint32_t)n;
+        *(__attribute__((address_space(1))) uint16_t*)(a.zmark + (size_t)chain * a.n_units + i) = (uint16_t)(newH | (newD << 8));
     }
-}
-hipError_t launch_smt_bg(const SmtArgs& a, unsigned long long* rows_written, hipStream_t s) {
-    const uint32_t count = a.ucnt ? a.ucnt : a.n_units;
-    const uint32_t n_jobs = ((count + 63) / 64) * 2 * a.n_proc;
-    // persistent and small: at most two wavefronts per CU, so that the chain kernels launched after it find their slots
-    static const uint32_t cap = getenv("HZ_SMT_BG_GRID") ? (uint32_t)atoi(getenv("HZ_SMT_BG_GRID")) : 512u;   // (experiments)
-    const uint32_t grid = n_jobs < cap ? n_jobs : cap;
-    if (!grid) return hipSuccess;
-    hipLaunchKernelGGL(k_smt_bg, dim3(grid), dim3(64), 0, s, a, rows_written);
-    return hipGetLastError();
+    if (a.skipped) {   // (profiling only) n_skipped is wave-uniform: one atomic per wavefront
+        const unsigned long long lead = __ballot(qj == 0);
+        if (n_skipped && lead && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)lead) - 1))
+            atomicAdd(a.skipped, (unsigned long long)n_skipped * (unsigned long long)__popcll(lead));
+    }
 }
 
 static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK); }

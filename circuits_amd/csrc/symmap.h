@@ -42,10 +42,11 @@ struct hz_symmap {
         std::vector<uint32_t> wire, coef;
         std::vector<hzh::F> pool;
     } r1cs;
-    // device-resident form of the map (export.hip): built by the first hz_witness_export_dev / hz_symmap_upload for a context's layout
-    // and device, kept until the map is destroyed
-    mutable hzexp::DevPlan* dev = nullptr;
+    // device-resident form of the map (export.hip): tables only, one plan per (device, geometry) a context has asked for -- built by the
+    // first hz_witness_export_dev / hz_symmap_upload of such a context and kept until the map is destroyed (never freed or rebuilt under
+    // another context's feet); what an export writes besides its output lives in the context (ctx_internal.h ExportScratch)
+    mutable std::vector<hzexp::DevPlan*> devs;
     mutable std::mutex dev_mu;
-    ~hz_symmap() { if (dev) hzexp::devplan_free(dev); }
+    ~hz_symmap() { for (hzexp::DevPlan* d : devs) hzexp::devplan_free(d); }
 };
 

@@ -302,7 +302,8 @@ class NativeBatchBuilder:
         hgi = (ctypes.c_uint8 * 32)()
         _check(self.c.hzb_batch_build(self.h, n, names, offs, widths, out, total, hgi))
         self.hash_global_inputs = _int(hgi)
-        return (buf.raw if buf is not None else out), self.hash_global_inputs
+        self._built = ((buf.raw if buf is not None else out), self.hash_global_inputs)   # build_finish() after build(): the same pair
+        return self._built
 
     def build_begin(self, layout, out=None):
         """first half of build() (hzb_batch_build_begin): the walk; the batch's Merkle hashes are evaluated by a worker thread while the
@@ -319,6 +320,8 @@ class NativeBatchBuilder:
 
     def build_finish(self):
         """-> (packed, hashGlobalInputs) as build()"""
+        if getattr(self, "_built", None) is not None:
+            return self._built
         _check(self.c.hzb_batch_build_finish(self.h))
         self.hash_global_inputs = _int(self._hgi)
         return (self._buf.raw if self._buf is not None else self._out), self.hash_global_inputs

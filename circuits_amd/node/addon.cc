@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -105,6 +106,22 @@ static napi_value throw_hz(napi_env env, const char* what) {
 // (stageRange / step / upload) is issued on a stream and consumed by the NEXT enqueue; its source ArrayBuffer must outlive the DMA,
 // whatever the JS side does with it. Enqueues are numbered; a buffer staged after enqueue e is referenced until the check of
 // enqueue e + 1 has completed (that enqueue waited for the copy on the device).
+// "A context is used by one thread at a time" (hermez_witness.h): every work item that drives a context from the libuv pool (run, check,
+// failures, step, export) holds the context's mutex, so two pending promises of one circuit never interleave inside the library
+// (Promise.all([m.witnessBin(0), m.witnessBin(1)]) once shared a staging buffer between two pool threads).
+static std::mutex g_ctx_mu_reg;
+static std::vector<std::pair<hz_ctx*, std::mutex*>> g_ctx_mu;
+static std::mutex& ctx_mu(hz_ctx* c) {
+    std::lock_guard<std::mutex> g(g_ctx_mu_reg);
+    for (auto& e : g_ctx_mu) if (e.first == c) return *e.second;
+    g_ctx_mu.push_back({c, new std::mutex()});
+    return *g_ctx_mu.back().second;
+}
+static void ctx_mu_forget(hz_ctx* c) {
+    std::lock_guard<std::mutex> g(g_ctx_mu_reg);
+    for (size_t i = 0; i < g_ctx_mu.size(); i++)
+        if (g_ctx_mu[i].first == c) { delete g_ctx_mu[i].second; g_ctx_mu.erase(g_ctx_mu.begin() + (long)i); return; }
+}
 struct NodeCtx {
     hz_ctx* c = nullptr;
     uint64_t enq = 0;                                    // enqueues issued so far
@@ -135,6 +152,7 @@ static void hold(napi_env env, NodeCtx* n, napi_value buf) {
 static void finalize_ctx(napi_env env, void* data, void*) {
     NodeCtx* n = (NodeCtx*)data;
     if (!n) return;
+    if (n->c) ctx_mu_forget(n->c);
     if (n->c && api.ctx_destroy) api.ctx_destroy(n->c);   // synchronises the device: nothing reads the held buffers after this
     for (auto& h : n->held) napi_delete_reference(env, h.first);
     delete n;
@@ -213,6 +231,7 @@ static napi_value failure_record(napi_env env, const hz_error& err) {
 }
 static void run_execute(napi_env, void* data) {
     RunWork* w = (RunWork*)data;
+    std::lock_guard<std::mutex> one_at_a_time(ctx_mu(w->ctx));
     memset(&w->err, 0, sizeof w->err);
     w->st = api.witness_run(w->ctx, &w->err);
     if (w->st != HZ_OK) w->msg = api.last_error();
@@ -501,6 +520,7 @@ static napi_value Enqueue(napi_env env, napi_callback_info info) {
 // check(handle) -> Promise<null | failure record> (same shape as run): waits for the step on the libuv pool
 static void check_execute(napi_env, void* data) {
     RunWork* w = (RunWork*)data;
+    std::lock_guard<std::mutex> one_at_a_time(ctx_mu(w->ctx));
     memset(&w->err, 0, sizeof w->err);
     w->st = api.witness_check(w->ctx, &w->err);
     if (w->st != HZ_OK) w->msg = api.last_error();
@@ -547,6 +567,7 @@ struct FailWork {
 };
 static void fail_execute(napi_env, void* data) {
     FailWork* w = (FailWork*)data;
+    std::lock_guard<std::mutex> one_at_a_time(ctx_mu(w->ctx));
     size_t n = 0;
     w->st = api.witness_failures(w->ctx, nullptr, 0, &n);
     if (w->st == HZ_OK && n) {
@@ -691,15 +712,19 @@ static napi_value WriteWtns(napi_env env, napi_callback_info info) {
 // exportWitness(handle, map, instance) -> Promise<ArrayBuffer of nVars x 32 bytes>: hz_witness_export_host on the libuv pool (one device pass
 //                                         + D2H; what the reference's calculateWitness returns, test/helpers/helpers.js:142,149, as bytes)
 // writeWtnsMap(handle, map, instance, file), checkMap(handle, map, instance) -> { bad, first }
-struct NodeMap { hz_symmap* m = nullptr; };
-static void map_finalize(napi_env, void* data, void*) {
+struct NodeMap {
+    hz_symmap* m = nullptr;
+    int in_flight = 0;          // export work items queued or running (JS thread only): freeMap waits for them
+    bool free_pending = false;
+};
+static void map_finalize(napi_env, void* data, void*) {   // (a pending work item holds a reference to the external: never runs under one)
     NodeMap* nm = (NodeMap*)data;
     if (nm->m) api.symmap_destroy(nm->m);
     delete nm;
 }
 static NodeMap* get_map(napi_env env, napi_value v) {
     void* p = nullptr;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((NodeMap*)p)->m) { napi_throw_error(env, nullptr, "bad or released symbol-map handle"); return nullptr; }
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((NodeMap*)p)->m || ((NodeMap*)p)->free_pending) { napi_throw_error(env, nullptr, "bad or released symbol-map handle"); return nullptr; }
     return (NodeMap*)p;
 }
 static napi_value ImportSym(napi_env env, napi_callback_info info) {
@@ -742,13 +767,19 @@ static napi_value FreeMap(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return nullptr;
     void* p = nullptr;
-    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p && ((NodeMap*)p)->m) { api.symmap_destroy(((NodeMap*)p)->m); ((NodeMap*)p)->m = nullptr; }
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p && ((NodeMap*)p)->m) {
+        NodeMap* nm = (NodeMap*)p;
+        if (nm->in_flight > 0) nm->free_pending = true;   // an export is reading it on the pool: freed by the completion of the last one
+        else { api.symmap_destroy(nm->m); nm->m = nullptr; }
+    }
     return nullptr;
 }
 struct ExportWork {
     napi_async_work work;
     napi_deferred deferred;
     hz_ctx* ctx; hz_symmap* map;
+    NodeCtx* node; NodeMap* nmap;
+    napi_ref keep_ctx, keep_map;   // the circuit and map externals: neither is finalised while the work item is pending
     int32_t inst;
     uint64_t nvars;
     uint8_t* data;        // malloc'ed here, handed to the ArrayBuffer (freed by its finaliser)
@@ -759,6 +790,7 @@ static void export_execute(napi_env, void* data) {
     ExportWork* w = (ExportWork*)data;
     w->data = (uint8_t*)malloc((size_t)std::max<uint64_t>(w->nvars, 1) * 32);
     if (!w->data) { w->st = HZ_ERR_ARG; w->msg = "out of memory for the exported witness"; return; }
+    std::lock_guard<std::mutex> one_at_a_time(ctx_mu(w->ctx));   // the export stages through the context's buffers on its main stream
     w->st = api.witness_export_host(w->ctx, w->map, w->inst, 0, w->nvars, w->data);
     if (w->st != HZ_OK) w->msg = api.last_error();
 }
@@ -776,18 +808,25 @@ static void export_complete(napi_env env, napi_status, void* data) {
         napi_reject_deferred(env, w->deferred, e);
     }
     free(w->data);
+    if (--w->nmap->in_flight == 0 && w->nmap->free_pending && w->nmap->m) { api.symmap_destroy(w->nmap->m); w->nmap->m = nullptr; w->nmap->free_pending = false; }
+    if (w->keep_ctx) napi_delete_reference(env, w->keep_ctx);
+    if (w->keep_map) napi_delete_reference(env, w->keep_map);
     napi_delete_async_work(env, w->work);
     delete w;
 }
 static napi_value ExportWitness(napi_env env, napi_callback_info info) {
     napi_value argv[3];
     if (!get_args(env, info, 3, argv)) return nullptr;
-    hz_ctx* c = get_ctx(env, argv[0]);
+    NodeCtx* node = get_node(env, argv[0]);
+    hz_ctx* c = node ? node->c : nullptr;
     NodeMap* nm = get_map(env, argv[1]);
     if (!c || !nm) return nullptr;
     if (api.symmap_unresolved(nm->m, 0, nullptr, nullptr)) { napi_throw_error(env, nullptr, "the symbol map has unresolved variables (mapInfo)"); return nullptr; }
     ExportWork* w = new ExportWork();
-    w->ctx = c; w->map = nm->m; w->inst = (int32_t)num(env, argv[2]); w->nvars = api.symmap_nvars(nm->m); w->data = nullptr; w->st = HZ_OK;
+    w->ctx = c; w->map = nm->m; w->node = node; w->nmap = nm; w->keep_ctx = w->keep_map = nullptr;
+    napi_create_reference(env, argv[0], 1, &w->keep_ctx);
+    napi_create_reference(env, argv[1], 1, &w->keep_map);
+    nm->in_flight++; w->inst = (int32_t)num(env, argv[2]); w->nvars = api.symmap_nvars(nm->m); w->data = nullptr; w->st = HZ_OK;
     napi_value promise, name;
     NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
     NAPI_OK(napi_create_string_utf8(env, "hz_witness_export_host", NAPI_AUTO_LENGTH, &name));
@@ -802,6 +841,7 @@ static napi_value WriteWtnsMap(napi_env env, napi_callback_info info) {
     NodeMap* nm = get_map(env, argv[1]);
     std::string path;
     if (!c || !nm || !get_str(env, argv[3], path)) return nullptr;
+    std::lock_guard<std::mutex> one_at_a_time(ctx_mu(c));   // (an export of this circuit may be pending on the pool)
     if (api.witness_write_wtns_sym(c, nm->m, (int32_t)num(env, argv[2]), path.c_str()) != HZ_OK) return throw_hz(env, "hz_witness_write_wtns_sym");
     return nullptr;
 }
@@ -812,6 +852,7 @@ static napi_value CheckMap(napi_env env, napi_callback_info info) {
     NodeMap* nm = get_map(env, argv[1]);
     if (!c || !nm) return nullptr;
     uint64_t n_bad = 0, first = 0;
+    std::lock_guard<std::mutex> one_at_a_time(ctx_mu(c));
     if (api.symmap_check_r1cs(c, nm->m, (int32_t)num(env, argv[2]), &n_bad, &first, 1) != HZ_OK) return throw_hz(env, "hz_symmap_check_r1cs");
     napi_value o, v;
     napi_create_object(env, &o);
@@ -887,6 +928,7 @@ struct StepWork {
 };
 static void step_execute(napi_env, void* data) {
     StepWork* w = (StepWork*)data;
+    std::lock_guard<std::mutex> one_at_a_time(ctx_mu(w->ctx));
     memset(&w->err, 0, sizeof w->err);
     w->st = HZ_OK;
     w->checked = 0;

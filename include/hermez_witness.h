@@ -152,6 +152,8 @@ hz_status hz_set_input_dev(hz_ctx* ctx, int32_t instance, const char* name, cons
 /* Replicate all input signals of instance `src` onto instance `dst`, device to device, on `stream`.
  * (No reference counterpart: snarkjs computes one witness per call; this fills a multi-instance context.) */
 hz_status hz_copy_instance_inputs(hz_ctx* ctx, int32_t src, int32_t dst, void* stream);
+/* Forget which inputs were set (the next enqueue wants every one again) and whatever the library remembers of the buffer's content:
+ * the step after it stores every signal, including the constants an earlier step left in place (DESIGN.md "constant marks"). */
 void hz_clear_inputs(hz_ctx* ctx);
 /* Bulk input path (the marshalling half of calculateWitness(input), reference test/helpers/helpers.js:147-149, for a process that
  * feeds batch after batch): ONE packed buffer per instance instead of one call per signal. Layout: every input signal in
@@ -159,7 +161,9 @@ void hz_clear_inputs(hz_ctx* ctx);
  * hz_set_input takes -- of hz_input_packed_width(i) bytes each: 32, or 1 for bit-valued signals (fromBjjCompressed).
  * hz_inputs_upload copies the buffer to the device asynchronously on `stream` (truly so from hz_host_alloc'ed pinned memory, which
  * the caller must keep unchanged until the stream reaches the copy) and one kernel scatters it into the witness layout and
- * range-checks the 32-byte elements; an element >= r is reported by the next hz_witness_check as HZ_ERR_INPUT. */
+ * range-checks the 32-byte elements; an element >= r is reported by the next hz_witness_check as HZ_ERR_INPUT.
+ * `packed` may also be DEVICE memory (hz_inputs_upload / _stage / _stage_range alike): a host that keeps the packed inputs of its
+ * batches resident in HBM hands each step's over with a device-to-device copy (bench.py's `value` loop). */
 uint64_t hz_inputs_packed_bytes(const hz_ctx* ctx);
 int32_t hz_input_packed_width(const hz_ctx* ctx, int32_t i);
 uint64_t hz_input_packed_offset(const hz_ctx* ctx, int32_t i);

@@ -117,6 +117,8 @@ int hzb_batch_stats(const hzb_batch* b, uint64_t* jobs, uint64_t* segments, doub
 /* seconds of the build spent SIGNING the transactions that carry a signer key (messages, nonces, R8): a wallet's work in production,
  * the synthetic generator's here; part of walk_s + eval_s */
 double hzb_batch_sign_s(const hzb_batch* b);
+/* self test: hash flushes (the unit of a build's deferred Merkle hashing) alive in this process; 0 once every database and batch is destroyed */
+long hzb_live_flushes(void);
 
 #ifdef __cplusplus
 }

@@ -16,20 +16,25 @@ async function main() {
     const size = fs.statSync(file).size;
     const nDistinct = Math.floor(size / each);
     if (nDistinct < 1) throw new Error("packed file too small");
-    // pinned copy of the packed batches, laid out so that every context's B batches are contiguous (one copy per stageRange)
-    const pin = ctxs[0].hostAlloc(each * B * inflight);
+    // pinned copy of the packed batches, TWICE in a row: any window of B consecutive batches modulo nDistinct is contiguous (one copy per
+    // stageRange). As in bench.py's Rotation, context k's instance b holds batch (k * B + b + r) mod nDistinct in round r and every step
+    // is a new round: no instance evaluates the batch it held the step before.
+    const nWin = Math.max(nDistinct, B);   // (fewer distinct batches than B: the window repeats them)
+    const pin = ctxs[0].hostAlloc(each * 2 * nWin);
     const u8 = new Uint8Array(pin);
     const fd = fs.openSync(file, "r");
-    for (let k = 0; k < inflight; k++) for (let b = 0; b < B; b++) fs.readSync(fd, u8, (k * B + b) * each, each, ((k * B + b) % nDistinct) * each);
+    for (let j = 0; j < 2 * nWin; j++) fs.readSync(fd, u8, j * each, each, (j % nDistinct) * each);
     fs.closeSync(fd);
-    const stage = (k) => ctxs[k].stageRange(0, B, pin, k * B * each, each);
+    const round = new Array(inflight).fill(0);   // the round staged for context k's next enqueue
+    const winOff = (k, r) => (((k * B + r) % nWin) * each);
+    const stage = (k) => ctxs[k].stageRange(0, B, pin, winOff(k, round[k]), each);
     // first pass: inputs in, one checked step per context, public outputs against the builder's values
     for (let k = 0; k < inflight; k++) { stage(k); ctxs[k].enqueue(); await ctxs[k].check(true); }
     if (expected) {
         for (let k = 0; k < inflight; k++) {
             const rd = ctxs[k].reader();
             for (const b of [0, B - 1]) {
-                const want = expected[(k * B + b) % nDistinct];
+                const want = expected[((k * B + b) % nWin) % nDistinct];
                 if (rd.get(b, "main.hashGlobalInputs").toString() !== want) throw new Error(`hashGlobalInputs mismatch (context ${k}, batch ${b})`);
             }
         }
@@ -43,7 +48,7 @@ async function main() {
             const k = i % inflight;
             if (pending[k]) ctxs[k].checkSync(true);
             ctxs[k].enqueue();
-            if (withStage) stage(k);
+            if (withStage) { round[k]++; stage(k); }
             pending[k] = true;
         }
         for (let k = 0; k < inflight; k++) if (pending[k]) ctxs[k].checkSync(true);
@@ -55,7 +60,7 @@ async function main() {
         for (let k = 0; k < inflight; k++) {
             const mine = Math.floor(n / inflight) + (k < n % inflight ? 1 : 0);
             chains.push((async () => {
-                for (let i = 0; i < mine; i++) await ctxs[k].step(pin, k * B * each, 0, B, each, true);
+                for (let i = 0; i < mine; i++) { round[k]++; await ctxs[k].step(pin, winOff(k, round[k]), 0, B, each, true); }
                 if (mine) await ctxs[k].check(true);
             })());
         }
@@ -67,7 +72,16 @@ async function main() {
     await run(steps);
     const dt = Number(process.hrtime.bigint() - t0) / 1e9;
     for (let k = 0; k < inflight; k++) { ctxs[k].enqueue(); await ctxs[k].check(true); }   // drain the last staged inputs
+    if (expected) {   // the rotation really happened: the last round's batches are what the instances hold
+        for (let k = 0; k < inflight; k++) {
+            const rd = ctxs[k].reader();
+            for (const b of [0, B - 1]) {
+                const want = expected[((k * B + b + round[k]) % nWin) % nDistinct];
+                if (rd.get(b, "main.hashGlobalInputs").toString() !== want) throw new Error(`hashGlobalInputs mismatch after the timed region (context ${k}, batch ${b}, round ${round[k]})`);
+            }
+        }
+    }
     console.log(JSON.stringify({ value_node: nTx * B * steps / dt, ms_per_step: dt / steps * 1e3, steps, batches_per_launch: B, contexts_in_flight: inflight,
-        distinct_batches: Math.min(nDistinct, B * inflight), mode, host: "node " + process.version + " over N-API (circuits_amd/node)", uploads: "inside the timed region (stageRange per step)" }));
+        distinct_batches: Math.min(nDistinct, B * inflight), mode, host: "node " + process.version + " over N-API (circuits_amd/node)", uploads: "inside the timed region (stageRange per step)", rotation: "a new batch per instance and step" }));
 }
 main().catch((e) => { console.error(e); process.exit(1); });

@@ -41,6 +41,12 @@ const { tester } = require(path.join(__dirname, "..", "..", "circuits_amd", "nod
         bad.release();
         assert.throws(() => bad.check(0), /released symbol-map handle/);
     }
+    // several exports of one circuit pending at once (the export stages through per-context buffers on the context's stream: the work
+    // items must not interleave) and release() while they are pending (deferred to the last completion; the handle is dead at once)
+    const many = [map.witnessBin(0), map.witnessBin(0), map.witnessBin(0)];
     map.release();
+    assert.throws(() => map.witnessBin(0), /released symbol-map handle/);
+    assert.throws(() => map.check(0), /released symbol-map handle/);
+    for (const ab of await Promise.all(many)) assert(Buffer.from(ab).equals(bin), "concurrent exports of one circuit return the same vector");
     console.log("wtns_r1cs: ok");
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -468,6 +468,38 @@ def test_pipelined_builds_on_one_database_give_the_bytes_of_one_build_after_the_
     be.add_token(1)
     be.build(layout)
     assert db_a.state_root == db_b.state_root
+    # nothing a pipelined build made outlives its owners (a worker that held its flush by shared_ptr from inside the flush once did)
+    import gc
+    for x in made_a + made_b + [bb, bc, bd, be]:
+        x.close()
+    for d in (cl, db_a, db_b):
+        d.close()
+    del made_a, made_b, bb, bc, bd, be, cl, db_a, db_b
+    gc.collect()
+    NB.host_lib().hzb_live_flushes.restype = ctypes.c_long
+    assert NB.host_lib().hzb_live_flushes() == 0
+
+
+def test_batchgen_native_sequential_path_matches_the_pipelined_one():
+    """circuits_amd/batchgen.py build_packed_batches_native(pipelined=False) -- build() then the same bookkeeping as the pipelined path"""
+    from circuits_amd import batchgen
+    shape = (12, 16, 4, 2)
+    layout = make_layout(shape[0], shape[1], shape[3])
+
+    class HostLib:   # the evaluator of the dense state: host Poseidon
+        @staticmethod
+        def poseidon_batch_bytes(t, n, data, device=0):
+            out = ctypes.create_string_buffer(32 * n)
+            assert NB.host_lib().hzb_poseidon_many(t - 1, n, data, out) == 0
+            return out.raw
+    outs = []
+    for pipelined in (True, False):
+        buf = ctypes.create_string_buffer(layout[0] * 3)
+        res, stats = batchgen.build_packed_batches_native([5, 6, 7], shape[0], shape[1], shape[2], shape[3], 32, layout, HostLib, None, ctypes.addressof(buf),
+                                                          pipelined=pipelined)
+        outs.append((buf.raw, [r[1] for r in res]))
+        assert stats["jobs"] > 0
+    assert outs[0] == outs[1] and len(set(outs[0][1])) == 3
 
 
 @pytest.mark.gpu

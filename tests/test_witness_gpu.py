@@ -312,33 +312,6 @@ def test_withdraw_config5_two_to_the_twenty(hz):
             assert g.read_bytes(0, wl, k) == o.read_bytes(0, wl, j), "launch %d, instance %d" % (launch, k)
 
 
-def test_throughput_launch_with_the_external_block_writer(hz, monkeypatch):
-    """The round-5 experiment kept behind HZ_SMT_BG_ON (profiles/r05_ksmt_bg_writer.txt): the constant blocks of the structurally empty
-    SMT levels stored by k_smt_bg beside k_smt instead of by k_smt itself. Slower as a step, but it must be the same witness: 16 451
-    RollupTx(16, 4) instances (ragged last wavefront), whole physical buffer against the oracle."""
-    from circuits_amd import builder as B
-    monkeypatch.setenv("HZ_SMT_BG_ON", "1")
-    bb = B.synthetic_batch(12, 16, 4, 4, n_accounts=6, exits=2, seed=21)
-    singles = [bb.get_single_tx_input(i)[0] for i in range(12)]
-    n = 16451
-    g = hz.ctx("rollup-tx", nLevels=16, maxFeeTx=4, n_instances=n)
-    o = OracleCtx("rollup-tx", nLevels=16, maxFeeTx=4, n_instances=len(singles))
-    for k, inp in enumerate(singles):
-        g.set_inputs(inp, instance=k)
-        o.set_inputs(inp, instance=k)
-    for k in range(len(singles), n):
-        g.copy_instance_inputs(k % len(singles), k)
-    g.set_profiling(True)
-    g.run()
-    assert "smt_bg" in [p[0] for p in g.profile()]          # the writer really ran
-    g.set_profiling(False)
-    assert o.run() is None
-    wl = g.witness_len()
-    ref = [o.read_bytes(0, wl, j) for j in range(len(singles))]
-    for k in list(range(0, n, 97)) + [n - 1, n - 2, n - 64, n - 65]:
-        assert g.read_bytes(0, wl, k) == ref[k % len(singles)], k
-
-
 def test_constraint_failures_match_oracle(hz, batch):
     from circuits_amd import ConstraintError
     inp = dict(batch.get_input())
