@@ -143,7 +143,7 @@ def poseidon_rates(L, torch):
     return out
 
 
-PROFILE_ROUNDS = ("r05", "r04")   # committed counter passes, newest first
+PROFILE_ROUNDS = ("r06", "r05", "r04")   # committed counter passes, newest first
 
 
 def _profile_json(suffix):
@@ -170,6 +170,19 @@ def measured_traffic(kernel, bpl):
         return int(k["fetch_bytes"] + k["write_bytes"]), src
     except (KeyError, ValueError):
         return None, None
+
+
+def stall_attribution(kernel):
+    """Where the wavefronts of `kernel` spend their cycles: the committed SQ_WAVE_CYCLES / SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY /
+    SQ_WAIT_ANY pass of this command line (profiles/rNN_stall_counters.json, tools/pmc_diag.sh) -- a recorded constant like `traffic`."""
+    d, src = _profile_json("stall_counters.json")
+    try:
+        k = d["kernels"][kernel]
+        return {"active": k["active"], "issue_stall": k["issue_stall"], "waitcnt": k["waitcnt"], "source": src,
+                "note": "fractions of the kernel's wave cycles: an instruction executing / ready but the pipe taken (two wavefronts per SIMD: by the "
+                        "other one) / parked on s_waitcnt; a committed counter pass, not measured by this run"}
+    except (KeyError, TypeError):
+        return None
 
 
 def measured_valu(kernel=None):
@@ -1266,6 +1279,7 @@ def main():
             "roofline": {"bound": bound, "kernel": dk, "launch": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_hbm": round(frac_hbm, 5), "frac_valu": round(frac_valu, 5) if frac_valu else None,
                          "traffic": measured_traffic(dk, Bp)[0],
+                         "stall": stall_attribution(dk),
                          "traffic_source": "%s (committed PMC pass of this command line, not measured by this run)" % measured_traffic(dk, Bp)[1] if measured_traffic(dk, Bp)[1] else None,
                          "launches_per_step": dlaunches, "launch_ms": round(dms / dlaunches, 3),
                          "algorithmic_bytes_per_launch": int(dbytes // dlaunches), "gpu_ms_per_step_all_launches": round(tot[dk], 3),

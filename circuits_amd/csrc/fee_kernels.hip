@@ -401,14 +401,7 @@ __global__ __launch_bounds__(HZ_WD_BLOCK) void k_withdraw(const WithdrawArgs a) 
     num2bits_strict_dev(io, v.n2bOld, fc_zero(), C_WD_N2B_OLD);
     num2bits_strict_dev(io, v.n2bNew, idx_c, C_WD_ALIAS_NEW);
     // SMTLevIns
-    uint64_t zmask = 0;
-    for (int base = 0; base < n; base += 16) {
-        const int cnt = (n - base) < 16 ? (n - base) : 16;
-        Fr z[16], zi[16];
-        for (int k = 0; k < cnt; k++) { z[k] = io.in_m(o.siblingsState + base + k); zi[k] = z[k]; if (fr_is_zero(z[k])) zmask |= 1ull << (base + k); }
-        batch_inv<16>(zi, cnt);
-        for (int k = 0; k < cnt; k++) is_zero_dev(io, v.isz + 2 * (base + k), z[k], zi[k]);
-    }
+    const uint64_t zmask = is_zero_run_dev<8>(io, n, [&](int k) { return io.in_m(o.siblingsState + k); }, [&](int k) { return v.isz + 2 * k; });
     if (!((zmask >> (n - 1)) & 1)) io.chk_zero(C_WD_LEVINS, fr_neg(one));
     uint64_t levmask = 0;
     {

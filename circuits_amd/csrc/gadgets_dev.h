@@ -167,6 +167,51 @@ __device__ __forceinline__ void batch_inv(Fr (&x)[N], int n) {
     }
 }
 
+// A RUN of n IsZero gadgets (slot k: input load(k); store(k, in, inv) writes its signals -- is_zero_dev at one or several offsets) with
+// batched inverses and no private memory. batch_inv above keeps its operands and prefix products in arrays indexed by a loop counter; a
+// loop this size does not unroll, so those arrays live in scratch memory (three of 576 bytes per lane in k_withdraw and the
+// FeeAccumulator, 1.5 KB in the RollupTx front until round 6). Here the prefix products of W slots are pushed into a register window
+// that ROTATES (constant indices only) and popped by the backward pass, which evaluates its operand again (`load` is a cached input load
+// and a conversion) instead of keeping it. One inversion per W slots. Returns the mask of the zero inputs (slots below 64).
+template <int W, class LOAD, class STORE>
+__device__ __forceinline__ uint64_t is_zero_run_store_dev(int n, LOAD load, STORE store) {
+    const Fr one = fr_one(), zero = fr_zero();
+    uint64_t zmask = 0;
+    for (int base = 0; base < n; base += W) {
+        const int cnt = (n - base) < W ? (n - base) : W;
+        Fr pre[W];
+#pragma unroll
+        for (int q = 0; q < W; q++) pre[q] = zero;
+        Fr acc = one;
+#pragma unroll 1
+        for (int k = 0; k < W; k++) {
+            const Fr v = k < cnt ? load(base + (k < cnt ? k : 0)) : zero;
+#pragma unroll
+            for (int q = 0; q < W - 1; q++) pre[q] = pre[q + 1];
+            pre[W - 1] = acc;
+            if (!fr_is_zero(v)) acc = fr_mul(acc, v);
+        }
+        Fr inv = fr_inv(acc);
+#pragma unroll 1
+        for (int k = W - 1; k >= 0; k--) {
+            if (k < cnt) {
+                const Fr v = load(base + k);
+                Fr vi = zero;
+                if (!fr_is_zero(v)) { vi = fr_mul(inv, pre[W - 1]); inv = fr_mul(inv, v); }
+                else if (base + k < 64) zmask |= 1ull << (base + k);
+                store(base + k, v, vi);
+            }
+#pragma unroll
+            for (int q = W - 1; q > 0; q--) pre[q] = pre[q - 1];
+        }
+    }
+    return zmask;
+}
+template <int W, class LOAD, class OFF>
+__device__ __forceinline__ uint64_t is_zero_run_dev(const UnitIO& io, int n, LOAD load, OFF off) {
+    return is_zero_run_store_dev<W>(n, load, [&](int k, const Fr& v, const Fr& vi) { (void)is_zero_dev(io, off(k), v, vi); });
+}
+
 __device__ __forceinline__ Fr mux1_dev(const Fr& c0, const Fr& c1, const Fr& s) { return fr_add(fr_mul(fr_sub(c1, c0), s), c0); }
 
 // CompConstant(ct) over 254 bits given as canonical integer `bits` (bit i = in[i]); `nbits_valid`

@@ -787,6 +787,12 @@ int build_begin(hzb_batch* bb, bool threaded) {
     // the deterministic nonce of a signature depends on its message
     std::vector<PendingSig>& sigs = run.sigs;
     sigs.clear();
+    std::vector<uint8_t> rk, rx, ry;
+    struct Joined {   // (a Reject thrown by the walk must not leave the worker writing into vectors that are being unwound)
+        std::future<void> f;
+        ~Joined() { if (f.valid()) f.wait(); }
+        Joined& operator=(std::future<void>&& g) { f = std::move(g); return *this; }
+    } r8_done;
     const double t_sig0 = now_s();
     {
         Dag mdag;
@@ -811,22 +817,22 @@ int build_begin(hzb_batch* bb, bool threaded) {
         if (st) return st;
         dag.total_jobs += mdag.total_jobs; dag.total_segments += mdag.total_segments; dag.device_ms += mdag.device_ms; dag.eval_s += mdag.eval_s;
         run.msg_jobs = mdag.total_jobs; run.msg_segments = mdag.total_segments; run.msg_device_ms = mdag.device_ms; run.msg_eval_s = mdag.eval_s;
-        // R8 = r * Base8 of every signature at once: the additions on a few host threads, one inversion for all (hostlib.cpp)
-        std::vector<uint8_t> rk(32 * sigs.size()), rx(32 * sigs.size()), ry(32 * sigs.size());
+        // R8 = r * Base8 of every signature at once (hostlib.cpp: the additions on the host's threads, one inversion for all) -- BESIDE the
+        // walk below, which needs none of it: the points go into the packed inputs and into the hm = Poseidon(R8, A, msg) jobs after the
+        // walk (those digests are only read by build_finish, for S)
+        rk.resize(32 * sigs.size()); rx.resize(32 * sigs.size()); ry.resize(32 * sigs.size());
         for (size_t q = 0; q < sigs.size(); q++) {
             sigs[q].msg = msgs[q];
             sigs[q].r = sign_nonce(sigs[q].signer->k, sigs[q].msg);
             u_to_bytes(sigs[q].r, &rk[32 * q]);
         }
-        hzb_bjj_mul_base8_many(sigs.size(), rk.data(), rx.data(), ry.data(), 0);
-        for (size_t q = 0; q < sigs.size(); q++) {
-            PendingSig& ps = sigs[q];
-            ps.r8 = Pt{u_from_bytes(&rx[32 * q]), u_from_bytes(&ry[32 * q])};
-            const Val in[5] = {val_of(ps.r8.x), val_of(ps.r8.y), val_of(ps.signer->a.x), val_of(ps.signer->a.y), val_of(ps.msg)};
-            ps.hm = dag.poseidon(in, 5);   // evaluated with the batch's Merkle hashes
+        if (!sigs.empty()) {
+            const size_t n_sig = sigs.size();
+            uint8_t *pk = rk.data(), *px = rx.data(), *py = ry.data();
+            r8_done = std::async(std::launch::async, [n_sig, pk, px, py] { hzb_bjj_mul_base8_many(n_sig, pk, px, py, 0); });
         }
     }
-    bb->sign_s = now_s() - t_sig0;   // messages (one Poseidon(7) each, evaluated), deterministic nonces, R8 = r * Base8 of all of them
+    bb->sign_s = now_s() - t_sig0;   // what the walk waits for: messages (one Poseidon(7) each, evaluated) and deterministic nonces; + the wait for R8 below
     std::vector<int> sig_of((size_t)nTx, -1);
     for (size_t q = 0; q < sigs.size(); q++) sig_of[sigs[q].tx] = (int)q;
 
@@ -1005,8 +1011,7 @@ int build_begin(hzb_batch* bb, bool threaded) {
                 if (sig_of[(size_t)i] < 0) {
                     if (tx.c.flags & HZB_TX_HAS_SIG) { sig_r8x = u_from_bytes(tx.c.r8x); sig_r8y = u_from_bytes(tx.c.r8y); sig_s = u_from_bytes(tx.c.s); }
                 } else {
-                    sig_r8x = sigs[(size_t)sig_of[(size_t)i]].r8.x;
-                    sig_r8y = sigs[(size_t)sig_of[(size_t)i]].r8.y;   // s follows the evaluation
+                    // R8 follows the walk (it is being computed beside it), s the evaluation
                 }
             }
         }
@@ -1073,6 +1078,18 @@ int build_begin(hzb_batch* bb, bool threaded) {
         put_leaf(o, LEAF3, (uint64_t)j, st3);
         put_siblings(o, S_siblings3, (uint64_t)j, L, *db->state, sib3);
         if (j < F - 1) o.put(S_imStateRootFee, (uint64_t)j, db->state->root_hash());
+    }
+    {
+        const double t_r8 = now_s();
+        if (r8_done.f.valid()) r8_done.f.get();
+        for (size_t q = 0; q < sigs.size(); q++) {
+            PendingSig& ps = sigs[q];
+            ps.r8 = Pt{u_from_bytes(&rx[32 * q]), u_from_bytes(&ry[32 * q])};
+            o.put(S_r8x, (uint64_t)ps.tx, ps.r8.x); o.put(S_r8y, (uint64_t)ps.tx, ps.r8.y);
+            const Val in[5] = {val_of(ps.r8.x), val_of(ps.r8.y), val_of(ps.signer->a.x), val_of(ps.signer->a.y), val_of(ps.msg)};
+            ps.hm = dag.poseidon(in, 5);   // evaluated with the batch's Merkle hashes
+        }
+        bb->sign_s += now_s() - t_r8;
     }
     run.t_walk = now_s();
     // the state moves on from here: what this batch leaves behind is named now, valued when its hashes are in

@@ -8,6 +8,7 @@
 // (Ark, S-box, Mix per round, circomlib 0.5.2 poseidon.circom) on the plain parameters of gen/poseidon_consts_host.inc. The
 // device-form routines stay reachable for the self tests (hzb_fr_inv, hzb_poseidon_dev9: same digests).
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -186,13 +187,28 @@ extern "C" int hzb_bjj_mul_base8(const uint8_t* k, uint8_t* ox, uint8_t* oy) {
     hpt_to_affine(base8_mul_proj(k), ox, oy);
     return 0;
 }
+// CPUs this process may really use: the cgroup's quota where there is one (the GPU boxes show 256 logical CPUs and grant 16), the
+// affinity mask otherwise
+static unsigned host_cpus(unsigned cap) {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        unsigned long long period = 0;
+        if (fscanf(f, "%31s %llu", q, &period) == 2 && period && strcmp(q, "max")) {
+            const unsigned long long quota = strtoull(q, nullptr, 10);
+            if (quota) n = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(n, (quota + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return std::min(cap, n);
+}
 // count scalars (32 bytes each, little endian) -> count affine points: the additions spread over `threads` host threads (0: as many
-// as the host offers, at most 8; a signature batch is a few thousand independent scalars), ONE inversion for all of them
+// as the host grants, at most 32; a signature batch is a few thousand independent scalars), ONE inversion for all of them
 extern "C" int hzb_bjj_mul_base8_many(uint64_t count, const uint8_t* k, uint8_t* ox, uint8_t* oy, int32_t threads) {
     if (!count) return 0;
     base8_table();
     std::vector<HPt> pts((size_t)count);
-    unsigned nt = threads > 0 ? (unsigned)threads : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned nt = threads > 0 ? (unsigned)threads : host_cpus(32u);
     if (const char* e = getenv("HZB_THREADS")) nt = (unsigned)std::max(1, atoi(e));
     nt = (unsigned)std::min<uint64_t>(nt, (count + 63) / 64);
     auto work = [&](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) pts[(size_t)i] = base8_mul_proj(k + 32 * i); };

@@ -1,6 +1,6 @@
 // Kernels of the per-transaction path (SURVEY 8a' K2-K4 and the back/top step):
-//   k_main_front  lane = (tx, half) RollupMain phase A/C checks + DecodeTx | RollupTx front
-//   k_rtx_front   lane = instance   standalone RollupTx front
+//   k_main_front  lane = (tx, role) RollupMain phase A/C checks + DecodeTx | RollupTx front: states | mux | balance
+//   k_rtx_front   lane = (instance, role) standalone RollupTx front
 //   k_dec_main    lane = instance   standalone DecodeTx
 //   k_hash4       lane = (tx, j)    HashState j in {old1, old2, new1, new2} + its SMTHash1
 //   k_smt         lane = (tx, c)    one of the four independent level-hash chains of the two
@@ -45,12 +45,26 @@ struct FeeSrcRtx {
 };
 
 
-// Two lanes per transaction (blockIdx.y): 0 = RollupMain's boolean checks, DecodeTx and the im* checks on its outputs; 1 = the
-// RollupTx front logic, which takes the few DecodeTx outputs it consumes straight from the input bits (decode_fields_dev). The halves
-// share no signal; a single batch has 32 wavefronts per half and the kernel is the head of both of its critical paths.
-// The 256 fromBjjCompressed input rows (8 KB per transaction) are read by lane 1 only: it packs them into the key (its own job),
-// checks them boolean (RollupMain phase A) and stores DecodeTx's L1TxFullData rows bit * onChain as copies -- round 2 read them three
-// times and paid three field conversions per bit (1.1 GB of the kernel's 4.6 GB of reads, a quarter of lane 0's instructions).
+// the neighbours' fields of RqTxVerifier (rtx_states_lane_dev): RollupMain wires them from the transactions around (src/rollup-main.circom:269-379)
+struct NbMain {
+    const UnitIO* io;
+    uint32_t off[3];       // txCompressedDataV2, toEthAddr, toBjjAy
+    uint32_t u, i, nTx;
+    __device__ __forceinline__ Fr fut(int m, int j) const { return i + j + 1 < nTx ? io->in_m_u(off[m], u + j + 1) : fr_zero(); }
+    __device__ __forceinline__ Fr past(int m, int j) const { return (int)i - j - 1 >= 0 ? io->in_m_u(off[m], u - j - 1) : fr_zero(); }
+};
+struct NbRtx {             // standalone RollupTx: they are inputs
+    const UnitIO* io;
+    uint32_t f[3], p[3];
+    __device__ __forceinline__ Fr fut(int m, int j) const { return io->in_m(f[m] + j); }
+    __device__ __forceinline__ Fr past(int m, int j) const { return io->in_m(p[m] + j); }
+};
+
+// Four lanes per transaction (blockIdx.y): 0 = RollupMain's boolean checks, DecodeTx and the im* checks on its outputs; 1..3 = the three
+// lanes of the RollupTx front (tx_dev.h: states, mux, balance), which take the few DecodeTx outputs they consume straight from the input
+// bits (decode_fields_dev). The lanes share no signal; a single batch has 32 wavefronts per lane and the kernel is the head of both of
+// its critical paths. The 256 fromBjjCompressed input rows (8 KB per transaction) are read by the mux lane only: it packs them into the
+// key (its own job), checks them boolean (RollupMain phase A) and stores DecodeTx's L1TxFullData rows bit * onChain as copies.
 #ifndef HZ_FRONT_WAVES
 #define HZ_FRONT_WAVES 2
 #endif
@@ -75,7 +89,7 @@ __global__ __launch_bounds__(HZ_FRONT_BLOCK) __attribute__((amdgpu_waves_per_eu(
         if (i + 1 < a.nTx) bool_chk(C_MAIN_IMONCHAIN_BOOL, io.in_m(m.imOnChain));
         bool_chk(C_MAIN_ONCHAIN_BOOL, io.in_m(m.onChain));
         bool_chk(C_MAIN_NEWACCOUNT_BOOL, io.in_m(m.newAccount));
-        // (the boolean check of the 256 fromBjjCompressed bits and their L1TxFullData rows: the other lane, which reads them anyway)
+        // (the boolean check of the 256 fromBjjCompressed bits and their L1TxFullData rows: the mux lane, which reads them anyway)
         bool_chk(C_MAIN_ISOLD0_1_BOOL, io.in_m(m.isOld0_1));
         bool_chk(C_MAIN_ISOLD0_2_BOOL, io.in_m(m.isOld0_2));
         // B
@@ -95,22 +109,17 @@ __global__ __launch_bounds__(HZ_FRONT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // D: wiring (:269-379)
     RtxExt x;
     decode_fields_dev(io, m, x);
-    x.oldStateRoot = i == 0 ? glob(a.g.oldStateRoot) : io.in_m_u(m.imStateRoot, u - 1);
-    x.oldExitRoot = i == 0 ? fr_zero() : io.in_m_u(m.imExitRoot, u - 1);
-    for (int j = 0; j < 3; j++) {
-        const bool ok = i + j + 1 < a.nTx;
-        x.futV2[j] = ok ? io.in_m_u(m.txCompressedDataV2, u + j + 1) : fr_zero();
-        x.futEth[j] = ok ? io.in_m_u(m.toEthAddr, u + j + 1) : fr_zero();
-        x.futAy[j] = ok ? io.in_m_u(m.toBjjAy, u + j + 1) : fr_zero();
+    if (blockIdx.y == 1) {
+        x.oldStateRoot = i == 0 ? glob(a.g.oldStateRoot) : io.in_m_u(m.imStateRoot, u - 1);
+        x.oldExitRoot = i == 0 ? fr_zero() : io.in_m_u(m.imExitRoot, u - 1);
+        const NbMain nb{&io, {m.txCompressedDataV2, m.toEthAddr, m.toBjjAy}, u, i, a.nTx};
+        rtx_states_lane_dev(io, sc, a.rtx, m, x, nb, false);
+    } else if (blockIdx.y == 2) {
+        rtx_mux_lane_dev(io, sc, a.rtx, m, x, a.dec.l1full, C_MAIN_BJJ_BOOL);
+    } else {
+        const FeeSrcMain fs{&io, a.fee_base, a.B * a.F, b * a.F, a.fi.feePlanTokens, a.fi.imFinalAccFee, m.imAccFeeOut, a.nTx, i};
+        (void)rtx_balance_lane_dev<MainTxInOff, FeeSrcMain, false>(io, sc, a.rtx, m, x, (int)a.F, fs);
     }
-    for (int j = 0; j < 4; j++) {
-        const bool ok = (int)i - j - 1 >= 0;
-        x.pastV2[j] = ok ? io.in_m_u(m.txCompressedDataV2, u - j - 1) : fr_zero();
-        x.pastEth[j] = ok ? io.in_m_u(m.toEthAddr, u - j - 1) : fr_zero();
-        x.pastAy[j] = ok ? io.in_m_u(m.toBjjAy, u - j - 1) : fr_zero();
-    }
-    const FeeSrcMain fs{&io, a.fee_base, a.B * a.F, b * a.F, a.fi.feePlanTokens, a.fi.imFinalAccFee, m.imAccFeeOut, a.nTx, i};
-    rollup_tx_front_dev<MainTxInOff, FeeSrcMain, false>(io, sc, a.rtx, m, x, (int)a.F, fs, false, a.dec.l1full, C_MAIN_BJJ_BOOL);
 }
 
 // RollupTx's FeeAccumulator for RollupMain, lane = transaction: needs the fee the transaction pays and its token (scratch, from the
@@ -135,16 +144,21 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
     const Scratch sc{a.scratch, a.N, i};
     const RtxInOff& r = a.in;
-    io.put_u64(0, 1);  // main.one
     RtxExt x;
     x.fromIdx = io.in_m(r.fromIdx); x.toIdx = io.in_m(r.toIdx); x.toBjjSign = io.in_m(r.toBjjSign); x.amount = io.in_m(r.amount);
     x.tokenID = io.in_m(r.tokenID); x.nonce = io.in_m(r.nonce); x.userFee = io.in_m(r.userFee); x.sigL2Hash = io.in_m(r.sigL2Hash);
     x.oldStateRoot = io.in_m(r.oldStateRoot); x.oldExitRoot = io.in_m(r.oldExitRoot);
-    for (int j = 0; j < 3; j++) { x.futV2[j] = io.in_m(r.futureV2 + j); x.futEth[j] = io.in_m(r.futureToEthAddr + j); x.futAy[j] = io.in_m(r.futureToBjjAy + j); }
-    for (int j = 0; j < 4; j++) { x.pastV2[j] = io.in_m(r.pastV2 + j); x.pastEth[j] = io.in_m(r.pastToEthAddr + j); x.pastAy[j] = io.in_m(r.pastToBjjAy + j); }
-    const FeeSrcRtx fs{&io, r.feePlanTokens, r.accFeeIn, a.rtx.o_accFeeOut};
-    const FrontOut fo = rollup_tx_front_dev(io, sc, a.rtx, r, x, (int)a.F, fs);
-    io.put_m(r.o_isAmountNullified, fo.isAmountNullified);
+    if (blockIdx.y == 0) {   // the same three lanes as k_main_front's (tx_dev.h)
+        io.put_u64(0, 1);  // main.one
+        const NbRtx nb{&io, {r.futureV2, r.futureToEthAddr, r.futureToBjjAy}, {r.pastV2, r.pastToEthAddr, r.pastToBjjAy}};
+        rtx_states_lane_dev(io, sc, a.rtx, r, x, nb, true);
+    } else if (blockIdx.y == 1) {
+        rtx_mux_lane_dev(io, sc, a.rtx, r, x, ~0u, -1);
+    } else {
+        const FeeSrcRtx fs{&io, r.feePlanTokens, r.accFeeIn, a.rtx.o_accFeeOut};
+        const FrontOut fo = rtx_balance_lane_dev<RtxInOff, FeeSrcRtx, true>(io, sc, a.rtx, r, x, (int)a.F, fs);
+        io.put_m(r.o_isAmountNullified, fo.isAmountNullified);
+    }
 }
 
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_dec_main(const DecMainArgs a) {
@@ -215,7 +229,7 @@ static inline dim3 grid1(uint32_t n) { return dim3((n + HZ_BLOCK - 1) / HZ_BLOCK
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
     const uint32_t nl = a.ucnt ? a.ucnt : a.B * a.nTx;
     dim3 g((nl + HZ_FRONT_BLOCK - 1) / HZ_FRONT_BLOCK);
-    g.y = 2;   // DecodeTx lane, RollupTx-front lane
+    g.y = 4;   // DecodeTx lane, the three RollupTx-front lanes
     hipLaunchKernelGGL(k_main_front, g, dim3(HZ_FRONT_BLOCK), 0, s, a);
     return hipGetLastError();
 }
@@ -225,7 +239,9 @@ hipError_t launch_main_feeacc(const MainFrontArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_rtx_front, grid1(a.N), dim3(HZ_BLOCK), 0, s, a);
+    dim3 g = grid1(a.N);
+    g.y = 3;   // states, mux, balance
+    hipLaunchKernelGGL(k_rtx_front, g, dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s) {

@@ -782,24 +782,24 @@ struct ExportWork {
     napi_ref keep_ctx, keep_map;   // the circuit and map externals: neither is finalised while the work item is pending
     int32_t inst;
     uint64_t nvars;
-    uint8_t* data;        // malloc'ed here, handed to the ArrayBuffer (freed by its finaliser)
+    uint8_t* data;        // the backing store of the ArrayBuffer the promise resolves with: created on the JS thread, referenced (keep_ab)
+                          // until the work item completes, written by the pool thread (no external buffer: node 12 asserts in
+                          // ArrayBufferReference::Finalize when an environment ends with one alive)
+    napi_ref keep_ab;
     hz_status st;
     std::string msg;
 };
 static void export_execute(napi_env, void* data) {
     ExportWork* w = (ExportWork*)data;
-    w->data = (uint8_t*)malloc((size_t)std::max<uint64_t>(w->nvars, 1) * 32);
-    if (!w->data) { w->st = HZ_ERR_ARG; w->msg = "out of memory for the exported witness"; return; }
     std::lock_guard<std::mutex> one_at_a_time(ctx_mu(w->ctx));   // the export stages through the context's buffers on its main stream
     w->st = api.witness_export_host(w->ctx, w->map, w->inst, 0, w->nvars, w->data);
     if (w->st != HZ_OK) w->msg = api.last_error();
 }
-static void free_exported(napi_env, void* data, void*) { free(data); }
 static void export_complete(napi_env env, napi_status, void* data) {
     ExportWork* w = (ExportWork*)data;
     if (w->st == HZ_OK) {
         napi_value ab;
-        if (napi_create_external_arraybuffer(env, w->data, (size_t)w->nvars * 32, free_exported, nullptr, &ab) == napi_ok) { w->data = nullptr; napi_resolve_deferred(env, w->deferred, ab); }
+        if (napi_get_reference_value(env, w->keep_ab, &ab) == napi_ok && ab) napi_resolve_deferred(env, w->deferred, ab);
         else { napi_value msg, e; napi_create_string_utf8(env, "cannot wrap the exported witness", NAPI_AUTO_LENGTH, &msg); napi_create_error(env, nullptr, msg, &e); napi_reject_deferred(env, w->deferred, e); }
     } else {
         napi_value msg, e;
@@ -807,7 +807,7 @@ static void export_complete(napi_env env, napi_status, void* data) {
         napi_create_error(env, nullptr, msg, &e);
         napi_reject_deferred(env, w->deferred, e);
     }
-    free(w->data);
+    if (w->keep_ab) napi_delete_reference(env, w->keep_ab);
     if (--w->nmap->in_flight == 0 && w->nmap->free_pending && w->nmap->m) { api.symmap_destroy(w->nmap->m); w->nmap->m = nullptr; w->nmap->free_pending = false; }
     if (w->keep_ctx) napi_delete_reference(env, w->keep_ctx);
     if (w->keep_map) napi_delete_reference(env, w->keep_map);
@@ -826,7 +826,20 @@ static napi_value ExportWitness(napi_env env, napi_callback_info info) {
     w->ctx = c; w->map = nm->m; w->node = node; w->nmap = nm; w->keep_ctx = w->keep_map = nullptr;
     napi_create_reference(env, argv[0], 1, &w->keep_ctx);
     napi_create_reference(env, argv[1], 1, &w->keep_map);
-    nm->in_flight++; w->inst = (int32_t)num(env, argv[2]); w->nvars = api.symmap_nvars(nm->m); w->data = nullptr; w->st = HZ_OK;
+    nm->in_flight++; w->inst = (int32_t)num(env, argv[2]); w->nvars = api.symmap_nvars(nm->m); w->data = nullptr; w->keep_ab = nullptr; w->st = HZ_OK;
+    {
+        napi_value ab;
+        void* store = nullptr;
+        if (napi_create_arraybuffer(env, (size_t)std::max<uint64_t>(w->nvars, 1) * 32, &store, &ab) != napi_ok || !store || napi_create_reference(env, ab, 1, &w->keep_ab) != napi_ok) {
+            nm->in_flight--;
+            if (w->keep_ctx) napi_delete_reference(env, w->keep_ctx);
+            if (w->keep_map) napi_delete_reference(env, w->keep_map);
+            delete w;
+            napi_throw_error(env, nullptr, "out of memory for the exported witness");
+            return nullptr;
+        }
+        w->data = (uint8_t*)store;
+    }
     napi_value promise, name;
     NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
     NAPI_OK(napi_create_string_utf8(env, "hz_witness_export_host", NAPI_AUTO_LENGTH, &name));

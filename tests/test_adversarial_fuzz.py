@@ -70,8 +70,10 @@ def _fuzz(hz, template, shape, gen, n_total, chunk, ctx_kw):
     ("smt-processor", (0, 33, 0, 0), 10240, 10240),
     ("smt-processor", (0, 33, 0, 0), 4096, 2048),    # contexts small enough for the latency form of the chain kernel (ctx.hip hz_ctx_create: its default here)
     ("smt-verifier", (0, 33, 0, 0), 10240, 10240),
-    ("withdraw", (0, 32, 0, 0), 10240, 2048),
-    ("rollup-tx", (0, 32, 0, 64), 10240, 2048),
+    # (two chunks through ONE context each: the second step meets the first one's buffer -- constant marks, persistent scratch;
+    #  10 240 instances of these two took a minute of a ten-minute suite for the same two kernel forms)
+    ("withdraw", (0, 32, 0, 0), 4096, 2048),
+    ("rollup-tx", (0, 32, 0, 64), 4096, 2048),
 ])
 def test_hip_adversarial_fuzz(hz, template, shape, n_total, chunk):
     L, F = shape[1], shape[3]
@@ -91,6 +93,6 @@ def test_hip_adversarial_fuzz_rollup_main(hz):
     """whole batches with garbage anywhere (transactions, fee slots, intermediate signals, key bits that are not bits): the front
     kernel's copied L1TxFullData rows, the early last-transaction chains, the fee chain and HashInputs on rejected batches"""
     shape = (4, 16, 2, 2)
-    rejected, cids = _fuzz(hz, "rollup-main", shape, lambda n, s: FZ.rollup_main_cases(n, shape, 11000 + s), 1536, 512,
+    rejected, cids = _fuzz(hz, "rollup-main", shape, lambda n, s: FZ.rollup_main_cases(n, shape, 11000 + s), 1024, 512,
                            dict(nTx=4, nLevels=16, maxL1Tx=2, maxFeeTx=2))
-    assert 700 < rejected < 1536 and len(cids) >= 6
+    assert 450 < rejected < 1024 and len(cids) >= 6

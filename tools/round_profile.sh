@@ -3,7 +3,7 @@
 # FETCH_SIZE / WRITE_SIZE / VALU counter passes of the same command (separate --pmc passes), a kernel Gantt of the timed region, the
 # microbenchmarks behind DESIGN.md 3 and the overlap / power probes. Outputs under gpurun_out/round/.
 cd /tmp && export TMPDIR=/tmp
-export HZ_ROUND=5
+export HZ_ROUND=6
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/round; rm -rf $OUT; mkdir -p $OUT
 cd $R
