@@ -62,6 +62,7 @@ EXPORTS = [
     "hz_witness_total", "hz_witness_read_raw", "hz_ctx_set_profiling", "hz_profile_count", "hz_profile_get",
     "hz_ctx_set_shard", "hz_da_record_bytes", "hz_da_export", "hz_da_import", "hz_witness_enqueue_tail",
     "hz_witness_enqueue_tail_chain", "hz_sha_blocks", "hz_sha_state_bytes", "hz_sha_export", "hz_sha_expand",
+    "hz_comm_create", "hz_comm_destroy", "hz_comm_rank", "hz_comm_world", "hz_shard_step", "hz_ctx_ntx",
     "hz_symmap_create", "hz_symmap_create_r1cs", "hz_symmap_solved", "hz_symmap_check_r1cs", "hz_symmap_save", "hz_symmap_load", "hz_symmap_destroy", "hz_symmap_nvars", "hz_symmap_unresolved", "hz_symmap_derived", "hz_witness_read_sym", "hz_witness_write_wtns_sym", "hz_witness_gather",
     "hz_symmap_from_index", "hz_component_major_index", "hz_symmap_upload", "hz_witness_export_dev", "hz_witness_export_range_dev", "hz_witness_export_host", "hz_symmap_dev_index", "hz_witness_derive_dev",
     "hz_symbol_count", "hz_symbol_get", "hz_symbol_lookup", "hz_constraint_name", "hz_poseidon_batch",
@@ -167,6 +168,13 @@ class Lib:
             getattr(c, f).restype = u64
         c.hz_sha_export.argtypes = [vp, vp, vp]
         c.hz_sha_expand.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
+        c.hz_comm_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p, ctypes.POINTER(vp)]
+        c.hz_comm_destroy.argtypes = [vp]
+        c.hz_comm_destroy.restype = None
+        c.hz_comm_rank.argtypes = [vp]
+        c.hz_comm_world.argtypes = [vp]
+        c.hz_shard_step.argtypes = [vp, vp, vp]
+        c.hz_ctx_ntx.argtypes = [vp]
         c.hz_ctx_set_profiling.argtypes = [vp, ctypes.c_int32]
         c.hz_profile_count.argtypes = [vp]
         c.hz_profile_get.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(u64), ctypes.POINTER(u64)]
@@ -245,6 +253,26 @@ class Lib:
         f, c = ctypes.c_int32(), ctypes.c_int32()
         self.c.hz_shard_range(n_tx, world, rank, ctypes.byref(f), ctypes.byref(c))
         return f.value, c.value
+
+
+class Comm:
+    """hz_comm: one per rank. transport "rccl" (librccl.so loaded by the library with dlopen) or "socket" (host-staged over the rendezvous)"""
+
+    def __init__(self, L, transport, rank, world, path=None, device=0):
+        self.L = L
+        self.h = ctypes.c_void_p()
+        L._check(L.c.hz_comm_create({"rccl": 1, "socket": 2}[transport], device, rank, world, path.encode() if path else None, ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.c.hz_comm_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def pack_inputs(layout, inputs):
@@ -443,6 +471,10 @@ class Ctx:
 
     def sha_expand(self, first, count, d_buf=None, stream=None):
         self.L._check(self.L.c.hz_sha_expand(self.h, first, count, d_buf, stream))
+
+    def shard_step(self, comm, stream):
+        """hz_shard_step: one sharded pass on `stream` (a hipStream_t handle) through the communicator `comm` (Comm); then check()"""
+        self.L._check(self.L.c.hz_shard_step(self.h, comm.h, stream))
 
     def set_profiling(self, on=True, exclusive=False):
         self.L._check(self.L.c.hz_ctx_set_profiling(self.h, (2 if exclusive else 1) if on else 0))

@@ -124,6 +124,7 @@ static const char* block_owner(const Layout& lo, int sec, const Block& b) {
     if (has(".topSwitcher.") || has(".checkOldInput.") || has(".areKeyEquals.") || has(".keysOk.") || (has(".processor") && n.size() > 8 && n.compare(n.size() - 8, 8, ".newRoot") == 0))
         return fee ? "fee_back" : "rtx_back";
     if (has(".processor")) return fee ? "fee_smt" : "smt";
+    if (!fee && lo.p.tmpl == T_ROLLUP_MAIN && has(".hashSig.")) return "sig_hash";
     if (has(".sigVerifier.mulFix.") || has(".sigVerifier.snum2bits") || has(".sigVerifier.compConstant")) return "eddsa_fix";
     if (has(".sigVerifier.eqCheck")) return "eddsa_final";
     if (has(".getAx.") || has(".sigVerifier.")) return "eddsa";
@@ -372,6 +373,7 @@ extern "C" void hz_ctx_destroy(hz_ctx* c) {
     delete c;
 }
 extern "C" uint64_t hz_witness_len(const hz_ctx* c) { return c ? c->lo.per_instance : 0; }
+extern "C" int32_t hz_ctx_ntx(const hz_ctx* c) { return (c && c->lo.p.tmpl == T_ROLLUP_MAIN) ? (int32_t)c->lo.p.nTx : 0; }
 // Device memory a context of this layout holds once every buffer that is allocated on first use exists (capacity planning: how many
 // batches fit the 288 GB of a device). The same arithmetic as hz_ctx_create and the lazy allocations below.
 static uint64_t layout_device_bytes(const Layout& lo) {
@@ -792,6 +794,8 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         // the signature stream waits for the front step INSIDE launch_eddsa: a RollupMain launch small enough for the split form starts
         // the point half of its prologue before that (k_eddsa_pre_a reads inputs only; ev_reset: the error buffer, the inputs' scatter)
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_reset, 0));
+        // RollupMain: DecodeTx's sigL2Hash (inputs only; read by the prologue below and by nothing else) heads the signature stream
+        if (feeacc) { ProfScope ps(c, c->s_ed, "sig_hash", n_units); HZ_HIP(launch_main_sighash(*feeacc, c->s_ed)); }
         { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed, c->ev_front)); }
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_fix, 0));
         { ProfScope ps(c, c->s_ed, "eddsa_final", n_units); HZ_HIP(launch_eddsa_final(ea, c->s_ed)); }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
     if (t == 0) {
         Fc oldLastIdx, newLastIdx, oldStateRoot, newStateRoot, newExitRoot, chainID, batch;
         if (a.is_main) {
-            auto glob = [&](uint32_t sig) { return load_fr(a.glob_base + ((size_t)sig * B + bt) * 32); };
+            auto glob = [&](uint32_t sig) __attribute__((always_inline)) { return load_fr(a.glob_base + ((size_t)sig * B + bt) * 32); };
             oldLastIdx = glob(a.g.oldLastIdx); oldStateRoot = glob(a.g.oldStateRoot); chainID = glob(a.g.globalChainID); batch = glob(a.g.currentNumBatch);
             newLastIdx = fr_to_canon(a.tx_scratch[(size_t)SC_OUTIDX * txU + tx0 + (nTx - 1)]);
             newStateRoot = fr_to_canon(a.fee_scratch[(size_t)SC_ROOT_P2NEW * feeU + fee0 + (Fn - 1)]);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
             newStateRoot = hio.in_c(o.i_newStateRoot); newExitRoot = hio.in_c(o.i_newExitRoot); chainID = hio.in_c(o.i_globalChainID);
             batch = hio.in_c(o.i_currentNumBatch);
         }
-        auto idx48 = [&](uint32_t off, const Fc& v) {
+        auto idx48 = [&](uint32_t off, const Fc& v) __attribute__((always_inline)) {
             num2bits_dev(hio, off, v, 48, C_HI_N2B);
             uint32_t pad = 0;
             for (uint32_t i = L; i < 48; i++) pad += c_bit(v, i);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_hi_prep(const HashInputsArgs a) {
     if (u < nTx) {
         const uint64_t pos = offL2 + (uint64_t)u * (2 * L + 48);
         if (a.is_main) {
-            auto txs = [&](uint32_t sig) { return load_fr(a.tx_base + ((size_t)sig * txU + tx0 + u) * 32).v[0] & 1u; };
+            auto txs = [&](uint32_t sig) __attribute__((always_inline)) { return load_fr(a.tx_base + ((size_t)sig * txU + tx0 + u) * 32).v[0] & 1u; };
             for (uint32_t k = 0; k < L; k++) msg_set_bit(msgw, pos + (L - 1 - k), txs(a.dec.n2bData + 48 + k));
             for (uint32_t k = 0; k < L; k++) msg_set_bit(msgw, pos + (2 * L - 1 - k), txs(a.dec.n2bFinalToIdx + k));
             for (uint32_t k = 0; k < 40; k++) msg_set_bit(msgw, pos + 2 * L + k, txs(a.rtx_main_l1l2amt + k));
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_sha_chain(const HashInputsArgs a) {
     if (wave == 0) __builtin_amdgcn_s_setprio(3);
     // prefetch: item q = (batch l, uint4 w of the chunk's 8 x 4): the 512 bytes of a batch's chunk are contiguous in the message
     uint4 pre[8];
-    auto fetch = [&](int c0) {
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t q = tid + 256u * r, l = q >> 5, w = q & 31;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_sha_chain(const HashInputsArgs a) {
             pre[r] = (l < nbt && b < blk1) ? msg4[((size_t)(bt0 + l) * nb + b) * 4 + (w & 3)] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    auto stash = [&](int which) {
+    auto stash = [&](int which) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t q = tid + 256u * r, l = q >> 5, w = q & 31;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_sha_chain_w(const HashInputsArgs a) {
     const int blk0 = (int)a.blk0, blk1 = (int)a.blk1;
     const uint32_t* msgw = reinterpret_cast<const uint32_t*>(a.msg);
     if (wave == 0) __builtin_amdgcn_s_setprio(3);
-    auto expand = [&](int c0, int which) {
+    auto expand = [&](int c0, int which) __attribute__((always_inline)) {
         if (wave == 0) return;
         for (uint32_t q = tid - 64; q < nbt * HZ_SHA_CHUNK; q += 192) {
             const uint32_t l = q / HZ_SHA_CHUNK, j = q % HZ_SHA_CHUNK;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(HZ_WD_BLOCK) void k_withdraw(const WithdrawArgs a) 
     num2bits_strict_dev(io, v.n2bOld, fc_zero(), C_WD_N2B_OLD);
     num2bits_strict_dev(io, v.n2bNew, idx_c, C_WD_ALIAS_NEW);
     // SMTLevIns
-    const uint64_t zmask = is_zero_run_dev<8>(io, n, [&](int k) { return io.in_m(o.siblingsState + k); }, [&](int k) { return v.isz + 2 * k; });
+    const uint64_t zmask = is_zero_run_dev<8>(io, n, [&](int k) __attribute__((always_inline)) { return io.in_m(o.siblingsState + k); }, [&](int k) __attribute__((always_inline)) { return v.isz + 2 * k; });
     if (!((zmask >> (n - 1)) & 1)) io.chk_zero(C_WD_LEVINS, fr_neg(one));
     uint64_t levmask = 0;
     {
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(HZ_WDSHA_BLOCK) void k_withdraw_sha(const WithdrawA
     }
     uint32_t msg[32];
     for (int k = 0; k < 32; k++) msg[k] = 0;
-    auto put_be = [&](int pos, const Fc& c, int nb) {
+    auto put_be = [&](int pos, const Fc& c, int nb) __attribute__((always_inline)) {
         for (int k = 0; k < nb; k++)
             if (c_bit(c, nb - 1 - k)) msg[(pos + k) >> 5] |= 1u << (31 - ((pos + k) & 31));
     };
@@ -520,8 +520,8 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_da_export(const DaArgs a) {
     if (li >= a.ucnt) return;
     const uint32_t u = a.u0 + li;
     uint8_t* r = a.buf + (size_t)li * HZ_DA_RECORD_BYTES;
-    auto bit = [&](uint32_t sig) { return load_fr(a.tx_base + ((size_t)sig * a.nTx + u) * 32).v[0] & 1u; };
-    auto pack = [&](uint32_t sig0, uint32_t n, uint8_t* dst, uint32_t nbytes) {
+    auto bit = [&](uint32_t sig) __attribute__((always_inline)) { return load_fr(a.tx_base + ((size_t)sig * a.nTx + u) * 32).v[0] & 1u; };
+    auto pack = [&](uint32_t sig0, uint32_t n, uint8_t* dst, uint32_t nbytes) __attribute__((always_inline)) {
         for (uint32_t b = 0; b < nbytes; b++) {
             uint32_t v = 0;
             for (uint32_t k = 0; k < 8 && 8 * b + k < n; k++) v |= bit(sig0 + 8 * b + k) << k;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_da_import(const DaArgs a) {
     const uint32_t u = a.u0 + li;
     const uint8_t* r = a.buf + (size_t)li * HZ_DA_RECORD_BYTES;
     const UnitIO io{a.tx_base, a.nTx, u, 0, u, nullptr};
-    auto unpack = [&](uint32_t sig0, uint32_t n, const uint8_t* src) {
+    auto unpack = [&](uint32_t sig0, uint32_t n, const uint8_t* src) __attribute__((always_inline)) {
         for (uint32_t k = 0; k < n; k++) io.put_bit(sig0 + k, (src[k >> 3] >> (k & 7)) & 1u);
     };
     unpack(a.l1full, L1FULL_BITS, r);

@@ -112,6 +112,15 @@ __device__ __forceinline__ bool c_fits(const Fc& c, int n) {
     }
     return any == 0;
 }
+// c |= v << pos for a value of at most 64 bits (pos + 64 may run past the top word: those bits are dropped). `pos` is a constant at
+// every call site, so the three word indices are constants after inlining: no run-time indexed register array (those live in scratch).
+__device__ __forceinline__ void c_or_bits64(Fc& c, const int pos, uint64_t v) {
+    const int w = pos >> 5, sh = pos & 31;
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const uint32_t p0 = lo << sh, p1 = sh ? ((lo >> (32 - sh)) | (hi << sh)) : hi, p2 = sh ? (hi >> (32 - sh)) : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) c.v[j] |= (j == w) ? p0 : (j == w + 1) ? p1 : (j == w + 2) ? p2 : 0u;
+}
 __device__ __forceinline__ Fc c_pow2(int k) {  // 2^k as a plain integer, k < 256
     Fc r;
 #pragma unroll
@@ -209,7 +218,7 @@ __device__ __forceinline__ uint64_t is_zero_run_store_dev(int n, LOAD load, STOR
 }
 template <int W, class LOAD, class OFF>
 __device__ __forceinline__ uint64_t is_zero_run_dev(const UnitIO& io, int n, LOAD load, OFF off) {
-    return is_zero_run_store_dev<W>(n, load, [&](int k, const Fr& v, const Fr& vi) { (void)is_zero_dev(io, off(k), v, vi); });
+    return is_zero_run_store_dev<W>(n, load, [&](int k, const Fr& v, const Fr& vi) __attribute__((always_inline)) { (void)is_zero_dev(io, off(k), v, vi); });
 }
 
 __device__ __forceinline__ Fr mux1_dev(const Fr& c0, const Fr& c1, const Fr& s) { return fr_add(fr_mul(fr_sub(c1, c0), s), c0); }
@@ -224,7 +233,7 @@ __device__ __forceinline__ uint32_t comp_constant_dev(const UnitIO& io, const Co
     // Pairs of bits are taken word by word (constant word indices), 16 pairs per word, 15 from the last one: no array is indexed at run time.
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
     uint32_t a0 = 1, a1 = 0, a2 = 0, a3 = 0;
-    auto word = [&](uint32_t sw, uint32_t cw, const int w, const int pairs) {
+    auto word = [&](uint32_t sw, uint32_t cw, const int w, const int pairs) __attribute__((always_inline)) {
         for (int q = 0; q < pairs; q++) {
             const int i = 16 * w + q;
             const uint32_t clsb = cw & 1u, cmsb = (cw >> 1) & 1u, slsb = sw & 1u, smsb = (sw >> 1) & 1u;

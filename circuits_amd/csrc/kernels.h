@@ -208,6 +208,7 @@ hipError_t launch_smtver_main(const SmtMainArgs& a, hipStream_t s);
 
 hipError_t launch_withdraw_sha(const WithdrawArgs& a, hipStream_t s);
 hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s);
+hipError_t launch_main_sighash(const MainFrontArgs& a, hipStream_t s);  // DecodeTx's sigL2Hash from the inputs alone (SC_SIGL2HASH for the signature prologue)
 hipError_t launch_main_feeacc(const MainFrontArgs& a, hipStream_t s);   // RollupTx's FeeAccumulator, after the front kernel (reads its scratch hand-off)
 hipError_t launch_rtx_front(const RtxFrontArgs& a, hipStream_t s);
 hipError_t launch_dec_main(const DecMainArgs& a, hipStream_t s);

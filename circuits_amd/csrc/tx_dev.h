@@ -38,9 +38,8 @@ enum ScratchField {
     SC_COUNT
 };
 
-struct DecResult {
-    Fr fromIdx, toIdx, toBjjSign, amount, tokenID, nonce, userFee, sigL2Hash, outIdx, v2;
-};
+__device__ __forceinline__ Fr fr_iszero_bit(const Fr& v) { return fr_from_bit(fr_is_zero(v) ? 1u : 0u); }   // an IsZero's OUTPUT (its `inv` needs the inversion)
+
 
 // L1TxFullData[160 + 255 - i] = fromBjjCompressed[i] * onChain (src/decode-tx.circom:300-303). The bit is an input signal (checked
 // boolean by RollupMain phase A): for 0 and 1 the product is 0 or onChain itself -- a copy, whatever onChain is; anything else takes
@@ -54,142 +53,170 @@ __device__ __forceinline__ void l1full_bjj_bit_dev(const UnitIO& io, uint32_t l1
     else io.put_m(sig, fr_mul(fr_from_canon(b), onChain));
 }
 
-// DecodeTx. `IN` provides the signal offsets of the inputs inside the lane's section (MainTxInOff
-// or DecInOff share the member names used here). K7 = Poseidon t=7 constant block.
-// `with_bjj` = false: the 256 fromBjjCompressed rows of L1TxFullData are somebody else's (k_main_front: the RollupTx-front lane reads
-// those bits anyway -- l1full_bjj_bit_dev -- so that 8 KB of input per transaction are read once instead of three times).
+// DecodeTx's sigL2Hash (src/decode-tx.circom:249-283) from the inputs alone: Poseidon(txCompressedData, toEthAddr[0..159] | amountF << 160 |
+// maxNumBatch << 200, toBjjAy, rqTxCompressedDataV2, rqToEthAddr, rqToBjjAy) -- e1 from the same bits the Num2Bits of the template decompose
 template <class IN>
-__device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOff& o, const IN& in, int L, const Fr& previousOnChain,
-                                                   const Fr& inIdx, const Fr& globalChainID, const Fr& currentNumBatch, const Fr* K7,
-                                                   bool with_bjj = true) {
+__device__ __forceinline__ Fr decode_sig_hash_dev(const UnitIO& io, const DecOff& o, const IN& in, const Fr* K7) {
+    Fc e1 = c_extract(io.in_c(in.toEthAddr), 0, 160);
+    c_or_bits64(e1, 160, c_bits64(io.in_c(in.amountF), 0, 40));
+    c_or_bits64(e1, 200, c_bits64(io.in_c(in.maxNumBatch), 0, 32));
+    Fr hin[6];
+    hin[0] = io.in_m(in.txCompressedData); hin[1] = fr_from_canon(e1); hin[2] = io.in_m(in.toBjjAy); hin[3] = io.in_m(in.rqTxCompressedDataV2);
+    hin[4] = io.in_m(in.rqToEthAddr); hin[5] = io.in_m(in.rqToBjjAy);
+    WitSboxSink sink = io.sbox_sink(o.hashSig);
+    return poseidon_hash<7>(hin, K7, sink);
+}
+
+// DecodeTx (src/decode-tx.circom:44-369). `IN` provides the signal offsets of the inputs inside the lane's section (MainTxInOff or DecInOff
+// share the member names used here); `EXT` the four values that come from outside the transaction -- previousOnChain(), inIdx(),
+// globalChainID(), currentNumBatch() -- LOADED WHERE THEY ARE USED; K7 = Poseidon t = 7 constant block.
+// OUT: the template's output signals are stored (the standalone main). with_bjj = false: the 256 fromBjjCompressed rows of L1TxFullData are
+// somebody else's (k_main_front: the mux lane reads those bits anyway). with_hash = false: sigL2Hash is k_main_sighash's.
+// Written so that little lives long (rounds 1-5: 2 KB of spills per lane): the fields of txCompressedData are kept as 64-bit integers
+// and converted where a field element is needed, every bit decomposition is stored next to the load of its input, a value that is
+// only needed for a late check is loaded at the check.
+struct DecResult {
+    Fr v2, outIdx, sigL2Hash;
+};
+template <bool OUT, class IN, class EXT>
+__device__ __forceinline__ DecResult decode_tx_dev(const UnitIO& io, const DecOff& o, const IN& in, int L, const EXT& ext, const Fr* K7,
+                                                   bool with_bjj = true, bool with_hash = true) {
     DecResult r;
     const Fr one = fr_one();
-    const Fr onChain = io.in_m(in.onChain), newAccount = io.in_m(in.newAccount);
+    const Fr onChain = io.in_m(in.onChain);
     const Fr notOn = fr_sub(one, onChain);
     const Fc notOn_c = fr_to_canon(notOn), on_c = fr_to_canon(onChain);
-    const Fc d = io.in_c(in.txCompressedData);
-    num2bits_dev(io, o.n2bData, d, 225, C_DEC_N2B_DATA);
-    const uint64_t constSig = c_bits64(d, 0, 32), chainID = c_bits64(d, 32, 16), fromIdx = c_bits64(d, 48, 48), toIdx = c_bits64(d, 96, 48);
-    const uint64_t tokenID = c_bits64(d, 144, 32), nonce = c_bits64(d, 176, 40), userFee = c_bits64(d, 216, 8);
-    const uint32_t toBjjSign = c_bit(d, 224);
+    auto gate_rows = [&](uint32_t sig0, int step, uint64_t field, int n, const Fc& g) __attribute__((always_inline)) {   // rows sig0, sig0 + step, ..: bit i of field times the gate
+#pragma unroll 1
+        for (int i = 0; i < n; i++) io.put_c((uint32_t)((int)sig0 + step * i), ((field >> i) & 1ull) ? g : fc_zero());
+    };
+    // ---- txCompressedData: bits, fields, padding
+    uint64_t constSig, chainID, fromIdx, toIdx, tokenID, nonce, userFee;
+    uint32_t toBjjSign;
     {
-        uint32_t pf = 0, pt = 0;
-        for (int i = L; i < 48; i++) { pf += c_bit(d, 48 + i); pt += c_bit(d, 96 + i); }
+        const Fc d = io.in_c(in.txCompressedData);
+        num2bits_dev(io, o.n2bData, d, 225, C_DEC_N2B_DATA);
+        constSig = c_bits64(d, 0, 32); chainID = c_bits64(d, 32, 16); fromIdx = c_bits64(d, 48, 48); toIdx = c_bits64(d, 96, 48);
+        tokenID = c_bits64(d, 144, 32); nonce = c_bits64(d, 176, 40); userFee = c_bits64(d, 216, 8);
+        toBjjSign = c_bit(d, 224);
+        const uint64_t hi_mask = L < 48 ? ~((1ull << L) - 1ull) & ((1ull << 48) - 1ull) : 0ull;   // the index bits above nLevels must be 0
+        const uint32_t pf = (uint32_t)__popcll(fromIdx & hi_mask), pt = (uint32_t)__popcll(toIdx & hi_mask);
         if (pf) report_fail(io.err, io.inst, io.err_unit, C_DEC_PAD_FROM, fr_from_u64(pf), fr_zero());
         if (pt) report_fail(io.err, io.inst, io.err_unit, C_DEC_PAD_TO, fr_from_u64(pt), fr_zero());
     }
-    r.fromIdx = fr_from_u64(fromIdx); r.toIdx = fr_from_u64(toIdx); r.tokenID = fr_from_u64(tokenID); r.nonce = fr_from_u64(nonce);
-    r.userFee = fr_from_u64(userFee); r.toBjjSign = fr_from_bit(toBjjSign);
-    const Fc am = io.in_c(in.amountF);
-    num2bits_dev(io, o.n2bAmount, am, 40, C_DEC_N2B_AMOUNT);
-    const uint64_t amountF = c_bits64(am, 0, 40);
-    r.amount = decode_float_dev(io, o.dfAmount, amountF);
-    // txCompressedDataV2 (:174-212): every field bit times (1-onChain)
+    // ---- amountF
+    uint64_t amountF;
     {
-        Fc v2bits = fc_zero();  // plain integer of the 216 gated bits
-        int k = 0;
-        auto put = [&](uint32_t bit) {
-            io.put_c(o.v2in + k, bit ? notOn_c : fc_zero());
-            v2bits.v[k >> 5] |= bit << (k & 31);
-            k++;
-        };
-        for (int i = 0; i < 48; i++) put(c_bit(d, 48 + i));
-        for (int i = 0; i < 48; i++) put(c_bit(d, 96 + i));
-        for (int i = 0; i < 40; i++) put(c_bit(am, i));
-        for (int i = 0; i < 32; i++) put(c_bit(d, 144 + i));
-        for (int i = 0; i < 40; i++) put(c_bit(d, 176 + i));
-        for (int i = 0; i < 8; i++) put(c_bit(d, 216 + i));
+        const Fc am = io.in_c(in.amountF);
+        num2bits_dev(io, o.n2bAmount, am, 40, C_DEC_N2B_AMOUNT);
+        amountF = c_bits64(am, 0, 40);
+        const Fr amount = decode_float_dev(io, o.dfAmount, amountF);
+        if constexpr (OUT) io.put_m(o.o_amount, amount);
+    }
+    // ---- the other bit decompositions, each next to its load; L1TxFullData's rows (:285-324, every bit times onChain) with them
+    uint64_t loadAmountF;
+    {
+        const Fc te = io.in_c(in.toEthAddr);
+        num2bits_dev(io, o.n2bToEthAddr, te, 160, C_DEC_N2B_TOETHADDR);
+    }
+    {
+        const Fc fe = io.in_c(in.fromEthAddr);
+        num2bits_dev(io, o.n2bFromEthAddr, fe, 160, C_DEC_N2B_FROMETHADDR);
+        gate_rows(o.l1full + 159, -1, c_bits64(fe, 0, 64), 64, on_c);
+        gate_rows(o.l1full + 159 - 64, -1, c_bits64(fe, 64, 64), 64, on_c);
+        gate_rows(o.l1full + 159 - 128, -1, c_bits64(fe, 128, 32), 32, on_c);
+    }
+    {
+        const Fc la = io.in_c(in.loadAmountF);
+        num2bits_dev(io, o.n2bLoadAmountF, la, 40, C_DEC_N2B_LOADAMOUNTF);
+        loadAmountF = c_bits64(la, 0, 40);
+    }
+    if (with_bjj) {
+#pragma unroll 1
+        for (int i = 0; i < 256; i++) l1full_bjj_bit_dev(io, o.l1full, i, io.in_c(in.fromBjjCompressed + i), onChain, on_c);
+    }
+    gate_rows(o.l1full + 160 + 256 + 48 - 1, -1, fromIdx, 48, on_c);
+    gate_rows(o.l1full + 160 + 256 + 48 + 40 - 1, -1, loadAmountF, 40, on_c);
+    gate_rows(o.l1full + 160 + 256 + 48 + 40 + 40 - 1, -1, amountF, 40, on_c);
+    gate_rows(o.l1full + 160 + 256 + 48 + 40 + 40 + 32 - 1, -1, tokenID, 32, on_c);
+    gate_rows(o.l1full + 160 + 256 + 48 + 40 + 40 + 32 + 48 - 1, -1, toIdx, 48, on_c);
+    // ---- txCompressedDataV2 (:174-212): every field bit times (1 - onChain)
+    gate_rows(o.v2in + 0, 1, fromIdx, 48, notOn_c); gate_rows(o.v2in + 48, 1, toIdx, 48, notOn_c); gate_rows(o.v2in + 96, 1, amountF, 40, notOn_c);
+    gate_rows(o.v2in + 136, 1, tokenID, 32, notOn_c); gate_rows(o.v2in + 168, 1, nonce, 40, notOn_c); gate_rows(o.v2in + 208, 1, userFee, 8, notOn_c);
+    gate_rows(o.l1l2Fee + 7, -1, userFee, 8, notOn_c);
+    {
+        // the plain integer of the 216 gated bits, field by field (constant positions: no word of it is indexed at run time)
+        Fc v2bits = fc_zero();
+        c_or_bits64(v2bits, 0, fromIdx); c_or_bits64(v2bits, 48, toIdx); c_or_bits64(v2bits, 96, amountF);
+        c_or_bits64(v2bits, 136, tokenID); c_or_bits64(v2bits, 168, nonce); c_or_bits64(v2bits, 208, userFee);
         Fr v2 = fr_mul(fr_from_canon(v2bits), notOn);
         if (toBjjSign) v2 = fr_add(v2, m_pow2(216));
         r.v2 = v2;
+        if constexpr (OUT) io.put_m(o.o_v2, v2);
     }
-    // batched inverses of the six IsZero inputs of this template
-    const Fr auxFromIdx = io.in_m(in.auxFromIdx), auxToIdx = io.in_m(in.auxToIdx);
-    const Fc maxNumBatch_c = io.in_c(in.maxNumBatch);
-    const Fr maxNumBatch = fr_from_canon(maxNumBatch_c);
-    const Fr onNew = fr_mul(onChain, newAccount);
-    r.outIdx = fr_add(inIdx, onNew);
-    Fr z[6];
-    z[0] = r.toIdx; z[1] = r.fromIdx; z[2] = fr_sub(r.outIdx, auxFromIdx); z[3] = fr_sub(fr_from_u64(chainID), globalChainID);
-    z[4] = fr_sub(fr_from_u64(3322668559ull), fr_from_u64(constSig)); z[5] = maxNumBatch;
-    Fr zi[6];
-    for (int i = 0; i < 6; i++) zi[i] = z[i];
-    batch_inv<6>(zi, 6);
-    // L1L2TxData (:214-247)
-    const Fr tz = is_zero_dev(io, o.toIdxIsZero, z[0], zi[0]);
-    const Fr sel_s = fr_mul(notOn, tz);
-    const Fr finalTo = mux1_dev(r.toIdx, auxToIdx, sel_s);
-    io.put_m(o.selToIdx_s, sel_s);
-    const Fc finalTo_c = fr_to_canon(finalTo);
-    io.put_c(o.selToIdx_out, finalTo_c);
-    num2bits_dev(io, o.n2bFinalToIdx, finalTo_c, L, C_DEC_N2B_FINALTOIDX);
-    for (int i = 0; i < 8; i++) io.put_c(o.l1l2Fee + (7 - i), c_bit(d, 216 + i) ? notOn_c : fc_zero());
-    // sigL2Hash (:249-283)
-    const Fc te = io.in_c(in.toEthAddr);
-    num2bits_dev(io, o.n2bToEthAddr, te, 160, C_DEC_N2B_TOETHADDR);
-    num2bits_dev(io, o.n2bMaxNumBatch, maxNumBatch_c, 32, C_DEC_N2B_MAXNUMBATCH);
+    // ---- L1L2TxData (:214-247)
     {
-        // e1 = toEthAddr[0..159] | amountF << 160 | maxNumBatch << 200 (from the bit decompositions)
-        Fc e1 = c_extract(te, 0, 160);
-        for (int i = 0; i < 40; i++) e1.v[(160 + i) >> 5] |= c_bit(am, i) << ((160 + i) & 31);
-        for (int i = 0; i < 32; i++) e1.v[(200 + i) >> 5] |= c_bit(maxNumBatch_c, i) << ((200 + i) & 31);
-        Fr hin[6];
-        hin[0] = fr_from_canon(d); hin[1] = fr_from_canon(e1); hin[2] = io.in_m(in.toBjjAy); hin[3] = io.in_m(in.rqTxCompressedDataV2);
-        hin[4] = io.in_m(in.rqToEthAddr); hin[5] = io.in_m(in.rqToBjjAy);
-        WitSboxSink sink = io.sbox_sink(o.hashSig);
-        r.sigL2Hash = poseidon_hash<7>(hin, K7, sink);
-    }
-    // L1TxFullData (:285-324): every bit times onChain
-    const Fc fe = io.in_c(in.fromEthAddr), la = io.in_c(in.loadAmountF);
-    num2bits_dev(io, o.n2bFromEthAddr, fe, 160, C_DEC_N2B_FROMETHADDR);
-    num2bits_dev(io, o.n2bLoadAmountF, la, 40, C_DEC_N2B_LOADAMOUNTF);
-    {
-        auto put = [&](int pos, uint32_t bit) { io.put_c(o.l1full + pos, bit ? on_c : fc_zero()); };
-        for (int i = 0; i < 160; i++) put(160 - 1 - i, c_bit(fe, i));
-        if (with_bjj) {
-            for (int i = 0; i < 256; i++) l1full_bjj_bit_dev(io, o.l1full, i, io.in_c(in.fromBjjCompressed + i), onChain, on_c);
+        const Fr sel_s = fr_select(toIdx == 0, notOn, fr_zero());   // (1 - onChain) * toIdxIsZero.out
+        const Fr finalTo = mux1_dev(fr_from_u64(toIdx), io.in_m(in.auxToIdx), sel_s);
+        io.put_m(o.selToIdx_s, sel_s);
+        const Fc finalTo_c = fr_to_canon(finalTo);
+        io.put_c(o.selToIdx_out, finalTo_c);
+        num2bits_dev(io, o.n2bFinalToIdx, finalTo_c, L, C_DEC_N2B_FINALTOIDX);
+        if constexpr (OUT) {
+            for (int i = 0; i < L; i++) io.put_bit(o.o_l1l2 + (L - 1 - i), (uint32_t)((fromIdx >> i) & 1ull));
+            for (int i = 0; i < L; i++) io.put_bit(o.o_l1l2 + (2 * L - 1 - i), c_bit(finalTo_c, i));
+            for (int i = 0; i < 40; i++) io.put_bit(o.o_l1l2 + (2 * L + 40 - 1 - i), (uint32_t)((amountF >> i) & 1ull));
+            gate_rows(o.o_l1l2 + 2 * L + 48 - 1, -1, userFee, 8, notOn_c);
         }
-        for (int i = 0; i < 48; i++) put(160 + 256 + 48 - 1 - i, c_bit(d, 48 + i));
-        for (int i = 0; i < 40; i++) put(160 + 256 + 48 + 40 - 1 - i, c_bit(la, i));
-        for (int i = 0; i < 40; i++) put(160 + 256 + 48 + 40 + 40 - 1 - i, c_bit(am, i));
-        for (int i = 0; i < 32; i++) put(160 + 256 + 48 + 40 + 40 + 32 - 1 - i, c_bit(d, 144 + i));
-        for (int i = 0; i < 48; i++) put(160 + 256 + 48 + 40 + 40 + 32 + 48 - 1 - i, c_bit(d, 96 + i));
     }
-    // checks (:326-368)
-    const Fr fz = is_zero_dev(io, o.fromIdxIsZero, z[1], zi[1]);
-    io.chk(C_DEC_NEWACCOUNT, fr_mul(onChain, fz), newAccount);
-    io.put_m(o.outIdx, r.outIdx);
-    io.put_m(o.idxChecker_en, onNew);
+    // ---- maxNumBatch: bits, LessThan(32)(currentNumBatch, maxNumBatch + 1) = Num2Bits(33)(in0 + 2^32 - in1), the check (:352-368)
     {
-        const Fr e = is_zero_dev(io, o.idxChecker, z[2], zi[2]);
-        io.chk_zero(C_DEC_IDXCHECKER, fr_mul(fr_sub(one, e), onNew));
-    }
-    io.chk_zero(C_DEC_L1_BEFORE_L2, fr_mul(fr_sub(one, previousOnChain), onChain));
-    {
-        const Fr e = is_zero_dev(io, o.chainIDChecker, z[3], zi[3]);
-        io.chk_zero(C_DEC_CHAINID, fr_mul(fr_sub(one, e), notOn));
-    }
-    {
-        const Fr e = is_zero_dev(io, o.constSigChecker, z[4], zi[4]);
-        io.chk_zero(C_DEC_CONSTSIG, fr_mul(fr_sub(one, e), notOn));
-    }
-    const Fr mz = is_zero_dev(io, o.maxNumBatchIsZero, z[5], zi[5]);
-    {
-        // LessThan(32)(currentNumBatch, maxNumBatch + 1): Num2Bits(33)(in0 + 2^32 - in1)
-        const Fr v = fr_sub(fr_add(currentNumBatch, m_pow2(32)), fr_add(maxNumBatch, one));
+        const Fc maxNumBatch_c = io.in_c(in.maxNumBatch);
+        num2bits_dev(io, o.n2bMaxNumBatch, maxNumBatch_c, 32, C_DEC_N2B_MAXNUMBATCH);
+        const Fr maxNumBatch = fr_from_canon(maxNumBatch_c);
+        const Fr v = fr_sub(fr_add(ext.currentNumBatch(), m_pow2(32)), fr_add(maxNumBatch, one));
         const Fc vc = fr_to_canon(v);
         num2bits_dev(io, o.maxNumBatchLt, vc, 33, C_DEC_N2B_MAXNUMBATCH_LT);
         const Fr ok = fr_from_bit(1u - c_bit(vc, 32));
-        io.chk_zero(C_DEC_MAXNUMBATCH, fr_mul(fr_sub(one, ok), fr_sub(one, mz)));
+        io.chk_zero(C_DEC_MAXNUMBATCH, fr_mul(fr_sub(one, ok), fr_sub(one, fr_iszero_bit(maxNumBatch))));
     }
-    if (o.o_fromIdx != ~0u) {
-        io.put_m(o.o_fromIdx, r.fromIdx); io.put_m(o.o_toIdx, r.toIdx); io.put_m(o.o_tokenID, r.tokenID); io.put_m(o.o_nonce, r.nonce);
-        io.put_m(o.o_userFee, r.userFee); io.put_bit(o.o_toBjjSign, toBjjSign); io.put_m(o.o_amount, r.amount);
-        io.put_m(o.o_sigL2Hash, r.sigL2Hash); io.put_m(o.o_v2, r.v2);
-        for (int i = 0; i < L; i++) io.put_bit(o.o_l1l2 + (L - 1 - i), c_bit(d, 48 + i));
-        for (int i = 0; i < L; i++) io.put_bit(o.o_l1l2 + (2 * L - 1 - i), c_bit(finalTo_c, i));
-        for (int i = 0; i < 40; i++) io.put_bit(o.o_l1l2 + (2 * L + 40 - 1 - i), c_bit(am, i));
-        for (int i = 0; i < 8; i++) io.put_c(o.o_l1l2 + (2 * L + 48 - 1 - i), c_bit(d, 216 + i) ? notOn_c : fc_zero());
+    // ---- the other checks (:326-351), each with the loads it needs
+    const Fr newAccount = io.in_m(in.newAccount);
+    const Fr onNew = fr_mul(onChain, newAccount);
+    r.outIdx = fr_add(ext.inIdx(), onNew);
+    io.chk(C_DEC_NEWACCOUNT, fr_select(fromIdx == 0, onChain, fr_zero()), newAccount);   // onChain * fromIdxIsZero.out
+    io.put_m(o.outIdx, r.outIdx);
+    io.put_m(o.idxChecker_en, onNew);
+    io.chk_zero(C_DEC_IDXCHECKER, fr_mul(fr_sub(one, fr_iszero_bit(fr_sub(r.outIdx, io.in_m(in.auxFromIdx)))), onNew));
+    io.chk_zero(C_DEC_L1_BEFORE_L2, fr_mul(fr_sub(one, ext.previousOnChain()), onChain));
+    io.chk_zero(C_DEC_CHAINID, fr_mul(fr_sub(one, fr_iszero_bit(fr_sub(fr_from_u64(chainID), ext.globalChainID()))), notOn));
+    io.chk_zero(C_DEC_CONSTSIG, fr_select(constSig == 3322668559ull, fr_zero(), notOn));
+    // ---- the six IsZero of this template (inv, out): one inversion, the prefix products in a rotating register window
+    {
+        const Fr outIdx = r.outIdx;
+        auto operand = [&](int k) __attribute__((always_inline)) -> Fr {
+            switch (k) {
+                case 0: return fr_from_u64(toIdx);
+                case 1: return fr_from_u64(fromIdx);
+                case 2: return fr_sub(outIdx, io.in_m(in.auxFromIdx));
+                case 3: return fr_sub(fr_from_u64(chainID), ext.globalChainID());
+                case 4: return fr_sub(fr_from_u64(3322668559ull), fr_from_u64(constSig));
+                default: return io.in_m(in.maxNumBatch);
+            }
+        };
+        auto store = [&](int k, const Fr& v, const Fr& vi) __attribute__((always_inline)) {
+            const IsZOff off = k == 0 ? o.toIdxIsZero : k == 1 ? o.fromIdxIsZero : k == 2 ? o.idxChecker : k == 3 ? o.chainIDChecker : k == 4 ? o.constSigChecker : o.maxNumBatchIsZero;
+            (void)is_zero_dev(io, off, v, vi);
+        };
+        (void)is_zero_run_store_dev<6>(6, operand, store);
+    }
+    // ---- sigL2Hash (:249-283) (with_hash = false: k_main_sighash has it -- a permutation of width 7 keeps 63 registers of state and as many
+    // of temporaries)
+    r.sigL2Hash = with_hash ? decode_sig_hash_dev(io, o, in, K7) : fr_zero();
+    if constexpr (OUT) {
+        io.put_m(o.o_fromIdx, fr_from_u64(fromIdx)); io.put_m(o.o_toIdx, fr_from_u64(toIdx)); io.put_m(o.o_tokenID, fr_from_u64(tokenID));
+        io.put_m(o.o_nonce, fr_from_u64(nonce)); io.put_m(o.o_userFee, fr_from_u64(userFee)); io.put_bit(o.o_toBjjSign, toBjjSign);
+        io.put_m(o.o_sigL2Hash, r.sigL2Hash);
     }
     return r;
 }
@@ -287,8 +314,8 @@ __device__ __forceinline__ Fr mux4_bits_dev(const UnitIO& io, uint32_t b, const 
     const Fr zero = fr_zero(), one = fr_one();
     // out = (a3210 + ... + a30 + a3) * s3 + (a210 + ... + a0 + c0); a term = its coefficient times the product of the selectors
     // BELOW bit 3 (a3210 = coef * s2 s1 s0, a32 = coef * s2, ...), so the low three bits decide it
-    auto term = [&](int mask) { return ((sel & (mask & 7)) == (uint32_t)(mask & 7)) ? mux4_coef(c, mask) : zero; };
-    auto prod = [&](int mask) { return ((sel & mask) == (uint32_t)mask) ? one : zero; };
+    auto term = [&](int mask) __attribute__((always_inline)) { return ((sel & (mask & 7)) == (uint32_t)(mask & 7)) ? mux4_coef(c, mask) : zero; };
+    auto prod = [&](int mask) __attribute__((always_inline)) { return ((sel & mask) == (uint32_t)mask) ? one : zero; };
     const Fr h3210 = term(15), h321 = term(14), h320 = term(13), h310 = term(11), h32 = term(12), h31 = term(10), h30 = term(9);
     const Fr a210 = term(7), a21 = term(6), a20 = term(5), a10 = term(3), a2 = term(4), a1 = term(2), a0 = term(1);
     const Fr a3 = mux4_coef(c, 8);
@@ -322,7 +349,7 @@ __device__ __forceinline__ Fr fr_from_i128(hz_i128 x) {   // |x| < 2^127
 // coef(mask) of the table block m as an integer
 __device__ __forceinline__ hz_i128 fee_coef_int(int m, int mask) {
     hz_i128 acc = 0;
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 16; k++) {
         if ((k & ~mask) != 0) continue;
         const hz_i128 e = (hz_i128)HZ_FEE_TABLE[16 * m + k];
@@ -331,32 +358,48 @@ __device__ __forceinline__ hz_i128 fee_coef_int(int m, int mask) {
     return acc;
 }
 // coef(mask) over inputs given by a loader (Montgomery values)
+// (a ROLLED loop: unrolled, the sixteen inputs are common subexpressions of the fifteen coefficients and the compiler keeps all of them
+//  -- 144 registers -- alive across the whole multiplexer)
 template <class LOAD>
 __device__ __forceinline__ Fr mux4_coef_ld(LOAD c, int mask) {
     Fr acc = fr_zero();
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 16; k++) {
         if ((k & ~mask) != 0) continue;
-        acc = (__popc(mask ^ k) & 1) ? fr_sub(acc, c(k)) : fr_add(acc, c(k));
+        const Fr v = c(k);
+        acc = (__popc(mask ^ k) & 1) ? fr_sub(acc, v) : fr_add(acc, v);
     }
     return acc;
 }
-// MultiMux4(1) with signal inputs from a loader: the body of mux4_var_dev (same signals, same values)
-template <class LOAD>
-__device__ __forceinline__ Fr mux4_var_ld_dev(const UnitIO& io, uint32_t b, LOAD c, const Fr& t0, const Fr& t1, const Fr& t2, const Fr& t3) {
-    const Fr t10 = fr_mul(t1, t0), t20 = fr_mul(t2, t0), t21 = fr_mul(t2, t1), t210 = fr_mul(t21, t0);
-    io.put_m(b + MX4_S10, t10); io.put_m(b + MX4_S20, t20); io.put_m(b + MX4_S21, t21); io.put_m(b + MX4_S210, t210);
+// ... and for inputs that are 64-bit integers (the fee table): the coefficient as a signed integer, one conversion
+template <class LOAD64>
+__device__ __forceinline__ Fr mux4_coef_int(LOAD64 c, int mask) {
+    hz_i128 acc = 0;
+#pragma unroll 1
+    for (int k = 0; k < 16; k++) {
+        if ((k & ~mask) != 0) continue;
+        const hz_i128 e = (hz_i128)c(k);
+        acc = (__popc(mask ^ k) & 1) ? acc - e : acc + e;
+    }
+    return fr_from_i128(acc);
+}
+// MultiMux4(1) with signal inputs from a loader: the body of mux4_var_dev (same signals, same values). `tprod(m)` = the product of the
+// selectors in the three-bit mask m (1: t0, 2: t1, 3: t1 t0, 4: t2, .. 7: t2 t1 t0), `t3` the fourth selector -- recomputed per term: this
+// is the path of inputs no batch builder produces, and four products held across fifteen terms are 36 registers of a kernel's budget.
+template <class LOAD, class TPROD>
+__device__ __forceinline__ Fr mux4_var_ld_dev(const UnitIO& io, uint32_t b, LOAD c, TPROD tprod, const Fr& t3) {
+    io.put_m(b + MX4_S10, tprod(3)); io.put_m(b + MX4_S20, tprod(5)); io.put_m(b + MX4_S21, tprod(6)); io.put_m(b + MX4_S210, tprod(7));
     Fr hi = fr_zero(), lo = fr_zero();
-    auto term = [&](int mask, const Fr& sel, uint32_t sig, bool high) {   // one product term, stored and added to its half
-        const Fr a = fr_mul(mux4_coef_ld(c, mask), sel);
+    auto term = [&](int mask, uint32_t sig, bool high) __attribute__((always_inline)) {   // one product term, stored and added to its half
+        const Fr a = fr_mul(mux4_coef_ld(c, mask), tprod(mask & 7));
         io.put_m(b + sig, a);
         if (high) hi = fr_add(hi, a); else lo = fr_add(lo, a);
     };
-    term(15, t210, MX4V_A3210, true); term(14, t21, MX4V_A321, true); term(13, t20, MX4V_A320, true); term(11, t10, MX4V_A310, true);
-    term(12, t2, MX4V_A32, true); term(10, t1, MX4V_A31, true); term(9, t0, MX4V_A30, true);
+    term(15, MX4V_A3210, true); term(14, MX4V_A321, true); term(13, MX4V_A320, true); term(11, MX4V_A310, true);
+    term(12, MX4V_A32, true); term(10, MX4V_A31, true); term(9, MX4V_A30, true);
     hi = fr_add(hi, mux4_coef_ld(c, 8));   // a3: no product, not stored
-    term(7, t210, MX4V_A210, false); term(6, t21, MX4V_A21, false); term(5, t20, MX4V_A20, false); term(3, t10, MX4V_A10, false);
-    term(4, t2, MX4V_A2, false); term(2, t1, MX4V_A1, false); term(1, t0, MX4V_A0, false);
+    term(7, MX4V_A210, false); term(6, MX4V_A21, false); term(5, MX4V_A20, false); term(3, MX4V_A10, false);
+    term(4, MX4V_A2, false); term(2, MX4V_A1, false); term(1, MX4V_A0, false);
     lo = fr_add(lo, c(0));
     const Fr out = fr_add(fr_mul(hi, t3), lo);
     io.put_m(b + MX4V_OUT, out);
@@ -364,22 +407,22 @@ __device__ __forceinline__ Fr mux4_var_ld_dev(const UnitIO& io, uint32_t b, LOAD
 }
 // ... and with selectors that are bits (s_i = b_i * a with a = 1): a product of selectors is 1 exactly when all its bits are set, so every
 // term is either its coefficient or 0 -- additions only. Same signals, same values. `sel` = the four selector bits.
-template <class LOAD>
-__device__ __forceinline__ Fr mux4_bits_ld_dev(const UnitIO& io, uint32_t b, LOAD c, uint32_t sel) {
+template <class COEF, class LOAD>
+__device__ __forceinline__ Fr mux4_bits_ld_dev(const UnitIO& io, uint32_t b, COEF coef, LOAD c, uint32_t sel) {
     const Fr zero = fr_zero(), one = fr_one();
-    auto prod = [&](int mask) { return ((sel & mask) == (uint32_t)mask) ? one : zero; };
+    auto prod = [&](int mask) __attribute__((always_inline)) { return ((sel & mask) == (uint32_t)mask) ? one : zero; };
     io.put_m(b + MX4_S10, prod(3)); io.put_m(b + MX4_S20, prod(5)); io.put_m(b + MX4_S21, prod(6)); io.put_m(b + MX4_S210, prod(7));
     Fr hi = zero, lo = zero;
     // a term = its coefficient times the product of the selectors BELOW bit 3 (a3210 = coef * s2 s1 s0, a32 = coef * s2, ...)
-    auto term = [&](int mask, uint32_t sig, bool high) {
+    auto term = [&](int mask, uint32_t sig, bool high) __attribute__((always_inline)) {
         const bool on = (sel & (uint32_t)(mask & 7)) == (uint32_t)(mask & 7);
-        const Fr a = fr_select(on, mux4_coef_ld(c, mask), zero);
+        const Fr a = fr_select(on, coef(mask), zero);
         io.put_m(b + sig, a);
         if (high) hi = fr_add(hi, a); else lo = fr_add(lo, a);
     };
     term(15, MX4V_A3210, true); term(14, MX4V_A321, true); term(13, MX4V_A320, true); term(11, MX4V_A310, true);
     term(12, MX4V_A32, true); term(10, MX4V_A31, true); term(9, MX4V_A30, true);
-    hi = fr_add(hi, mux4_coef_ld(c, 8));
+    hi = fr_add(hi, coef(8));
     term(7, MX4V_A210, false); term(6, MX4V_A21, false); term(5, MX4V_A20, false); term(3, MX4V_A10, false);
     term(4, MX4V_A2, false); term(2, MX4V_A1, false); term(1, MX4V_A0, false);
     lo = fr_add(lo, c(0));
@@ -388,16 +431,18 @@ __device__ __forceinline__ Fr mux4_bits_ld_dev(const UnitIO& io, uint32_t b, LOA
     return out;
 }
 
-__device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFeeOff& o, const Fc& feeSel_c, const Fr& amount, const Fr& applyFee) {
+// `amount()` is evaluated where the tail multiplies by it (a loader: nothing of the caller's is kept alive across the multiplexers)
+template <class AMT>
+__device__ __forceinline__ Fr compute_fee_ld_dev(const UnitIO& io, const ComputeFeeOff& o, const Fc& feeSel_c, AMT amount, const Fr& applyFee) {
     const Fr one = fr_one(), zero = fr_zero();
     io.put_m(o.applyFee, applyFee);
     num2bits_dev(io, o.n2bFeeSel, feeSel_c, 8, C_RTX_FEE_N2B_SEL);
     const uint32_t selbyte = (uint32_t)c_bits64(feeSel_c, 0, 8);
-    const Fc applyFee_c = fr_to_canon(applyFee);
-#pragma unroll
-    for (int i = 0; i < 8; i++) io.put_c(o.muxS + i, ((selbyte >> i) & 1u) ? applyFee_c : fc_zero());
-    // the first level's outputs, read back where the second level needs them
-    auto lvl1 = [&](int m) { return io.in_m(o.mux1 + MX4C_N * m + MX4_OUT_C); };
+    {
+        const Fc applyFee_c = fr_to_canon(applyFee);
+#pragma unroll 1
+        for (int i = 0; i < 8; i++) io.put_c(o.muxS + i, ((selbyte >> i) & 1u) ? applyFee_c : fc_zero());
+    }
     // applyFee is 0 or 1 in every witness RollupTx produces ((1 - onChain) * (1 - nop)); as a main component it is an input and
     // may be anything. When it is a bit on every lane of the wavefront the selectors are bits and the 16 + 1 multiplexers need no
     // field product at all: the selected table entry IS the first level's output.
@@ -405,39 +450,55 @@ __device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFee
     if (__all(ap1 || fr_is_zero(applyFee))) {
         const uint32_t selbits = ap1 ? selbyte : 0u;
         const uint32_t lo4 = selbits & 15u;
-        const Fr s10 = ((lo4 & 3u) == 3u) ? one : zero, s20 = ((lo4 & 5u) == 5u) ? one : zero, s21 = ((lo4 & 6u) == 6u) ? one : zero,
-                 s210 = ((lo4 & 7u) == 7u) ? one : zero;
 #pragma unroll 1
         for (int m = 0; m < 16; m++) {
             const uint32_t b = o.mux1 + MX4C_N * m;
-            io.put_m(b + MX4_S10, s10); io.put_m(b + MX4_S20, s20); io.put_m(b + MX4_S21, s21); io.put_m(b + MX4_S210, s210);
+            io.put_bit(b + MX4_S10, (lo4 & 3u) == 3u); io.put_bit(b + MX4_S20, (lo4 & 5u) == 5u); io.put_bit(b + MX4_S21, (lo4 & 6u) == 6u); io.put_bit(b + MX4_S210, (lo4 & 7u) == 7u);
             io.put_m(b + MX4_OUT_C, fr_from_u64(HZ_FEE_TABLE[16 * m + lo4]));   // Mux4 with constant inputs and bit selectors: the selected entry
         }
-        const Fr factor = mux4_bits_ld_dev(io, o.mux2, lvl1, selbits >> 4);
-        return compute_fee_tail_dev(io, o, feeSel_c, amount, factor);
+        // the second level's inputs ARE table entries here: its coefficients are integer sums (no field element is loaded back)
+        auto tab = [&](int k) __attribute__((always_inline)) { return HZ_FEE_TABLE[16 * k + lo4]; };
+        const Fr factor = mux4_bits_ld_dev(io, o.mux2, [&](int mask) __attribute__((always_inline)) { return mux4_coef_int(tab, mask); },
+                                           [&](int k) __attribute__((always_inline)) { return fr_from_u64(tab(k)); }, selbits >> 4);
+        return compute_fee_tail_dev(io, o, feeSel_c, amount(), factor);
     }
-    const Fr s0 = fr_select((selbyte & 1u) != 0, applyFee, zero), s1 = fr_select((selbyte & 2u) != 0, applyFee, zero),
-             s2 = fr_select((selbyte & 4u) != 0, applyFee, zero), s3 = fr_select((selbyte & 8u) != 0, applyFee, zero);
-    const Fr s10 = fr_mul(s1, s0), s20 = fr_mul(s2, s0), s21 = fr_mul(s2, s1), s210 = fr_mul(s21, s0);
+    // The general path (selectors that are field elements): every selector and selector product is recomputed where it is used --
+    // slower, and nothing but applyFee stays alive across the seventeen multiplexers.
+    auto sel = [&](int bit) __attribute__((always_inline)) { return fr_select(((selbyte >> bit) & 1u) != 0, applyFee, zero); };
+    auto sprod = [&](int m3, int base) __attribute__((always_inline)) -> Fr {   // product of the selectors base + {the bits of m3}, m3 = 1..7
+        switch (m3) {
+            case 1: return sel(base);
+            case 2: return sel(base + 1);
+            case 3: return fr_mul(sel(base + 1), sel(base));
+            case 4: return sel(base + 2);
+            case 5: return fr_mul(sel(base + 2), sel(base));
+            case 6: return fr_mul(sel(base + 2), sel(base + 1));
+            default: return fr_mul(fr_mul(sel(base + 2), sel(base + 1)), sel(base));
+        }
+    };
 #pragma unroll 1
     for (int m = 0; m < 16; m++) {
         // out = (sum over masks with bit 3) * s3 + (sum over masks without): constant inputs, the a-terms are linear in the selector
         // products and are not stored
         Fr hi = fr_from_i128(fee_coef_int(m, 8)), lo = fr_from_i128(fee_coef_int(m, 0));
-        auto both = [&](int mask, const Fr& sp) {
+#pragma unroll 1
+        for (int mask = 1; mask < 8; mask++) {
+            const Fr sp = sprod(mask, 0);
             lo = fr_add(lo, fr_mul(fr_from_i128(fee_coef_int(m, mask)), sp));
             hi = fr_add(hi, fr_mul(fr_from_i128(fee_coef_int(m, mask | 8)), sp));
-        };
-        both(1, s0); both(2, s1); both(3, s10); both(4, s2); both(5, s20); both(6, s21); both(7, s210);
+        }
         const uint32_t b = o.mux1 + MX4C_N * m;
-        io.put_m(b + MX4_S10, s10); io.put_m(b + MX4_S20, s20); io.put_m(b + MX4_S21, s21); io.put_m(b + MX4_S210, s210);
-        io.put_m(b + MX4_OUT_C, fr_add(fr_mul(hi, s3), lo));
+        io.put_m(b + MX4_S10, sprod(3, 0)); io.put_m(b + MX4_S20, sprod(5, 0)); io.put_m(b + MX4_S21, sprod(6, 0)); io.put_m(b + MX4_S210, sprod(7, 0));
+        io.put_m(b + MX4_OUT_C, fr_add(fr_mul(hi, sel(3)), lo));
     }
-    // second level: selectors s[4..7], signal inputs: every product term is stored
-    const Fr t0 = fr_select((selbyte & 16u) != 0, applyFee, zero), t1 = fr_select((selbyte & 32u) != 0, applyFee, zero),
-             t2 = fr_select((selbyte & 64u) != 0, applyFee, zero), t3 = fr_select((selbyte & 128u) != 0, applyFee, zero);
-    const Fr factor = mux4_var_ld_dev(io, o.mux2, lvl1, t0, t1, t2, t3);
-    return compute_fee_tail_dev(io, o, feeSel_c, amount, factor);
+    // second level: selectors s[4..7], signal inputs (the first level's outputs, read back from the witness buffer -- same lane, same
+    // address): every product term is stored
+    auto lvl1 = [&](int m) __attribute__((always_inline)) { return io.in_m(o.mux1 + MX4C_N * m + MX4_OUT_C); };
+    const Fr factor = mux4_var_ld_dev(io, o.mux2, lvl1, [&](int m3) __attribute__((always_inline)) { return sprod(m3, 4); }, sel(7));
+    return compute_fee_tail_dev(io, o, feeSel_c, amount(), factor);
+}
+__device__ __forceinline__ Fr compute_fee_dev(const UnitIO& io, const ComputeFeeOff& o, const Fc& feeSel_c, const Fr& amount, const Fr& applyFee) {
+    return compute_fee_ld_dev(io, o, feeSel_c, [&]() __attribute__((always_inline)) { return amount; }, applyFee);
 }
 __device__ __forceinline__ Fr compute_fee_tail_dev(const UnitIO& io, const ComputeFeeOff& o, const Fc& feeSel_c, const Fr& amount, const Fr& factor) {
     const Fr notShifted = fr_mul(factor, amount);
@@ -445,6 +506,7 @@ __device__ __forceinline__ Fr compute_fee_tail_dev(const UnitIO& io, const Compu
     io.put_c(o.feeOutNotShifted, ns_c);
     const uint32_t shiftOff = c_bit(feeSel_c, 6) & c_bit(feeSel_c, 7);
     io.put_bit(o.applyShift, 1u - shiftOff);
+#pragma unroll 1
     for (int i = 0; i < 253; i++) io.put_bit(o.bits + i, c_bit(ns_c, i));
     if (!c_fits(ns_c, 253)) report_fail(io.err, io.inst, io.err_unit, C_RTX_FEE_BITS, fr_from_canon(c_extract(ns_c, 0, 253)), notShifted);
     uint32_t ovS = 0, ovN = 0;
@@ -466,7 +528,7 @@ __device__ __forceinline__ Fr compute_fee_tail_dev(const UnitIO& io, const Compu
 #endif
 template <class FEE>
 __device__ __forceinline__ void fee_accumulator_dev(const UnitIO& io, const RtxOff& o, int Fn, const FEE& feeSrc, const Fr& fee2Charge, const Fr& tokenID) {
-    (void)is_zero_run_dev<HZ_FA_WINDOW>(io, Fn, [&](int i) { return fr_sub(feeSrc.plan(i), tokenID); }, [&](int i) { return o.feeAcc + FA_N * i + FA_ISZ_INV; });
+    (void)is_zero_run_dev<HZ_FA_WINDOW>(io, Fn, [&](int i) __attribute__((always_inline)) { return fr_sub(feeSrc.plan(i), tokenID); }, [&](int i) __attribute__((always_inline)) { return o.feeAcc + FA_N * i + FA_ISZ_INV; });
     // IsEqual's output and the running "already selected" flag are bits whatever the inputs are: the chain
     // selOut = 1 - (1 - eq)(1 - selIn), s = eq (1 - selIn), out = fee2Charge * s + accIn is logic plus one selection
     bool sel_in = false;
@@ -503,15 +565,13 @@ struct FrontOut {
 // compiler drops the rest): some thirty products per lane against the thousand of a ComputeFee, no lane waits for another, no signal
 // is written twice, every constraint is checked by exactly one lane.
 struct RtxStates {
-    Fr onChain, newAccount, notOn, newExit;
+    Fr onChain, newAccount, notOn;
     Fr loadAmount, isLoadAmount, isAmount;
-    Fr isP1Insert, finalFromIdx, tz, selectAuxToIdx, finalToIdx, isAny, ffz, isFinalFromIdx;
-    Fr P1_fnc0, P1_fnc1, m1_s10, m1_a10, m1_a1, m1_a0, key1;
-    Fr isExit, effAmt1, isP2Insert, P2_fnc0, P2_fnc1, m2_s10, m2_a10, m2_a0, key2;
-    Fr verifySignEnabled, tmpE, tmpB, checkToEthAddr, checkToBjj, onNotCreate, shouldEth, eqEth, nullEth, eqT1, nullT1, sc20, sc21, eqT2, nullT2;
-    Fr nullifyLoadAmount, applyT1Amt, na0, nullifyAmount;
+    Fr isP1Insert, finalFromIdx, finalToIdx, isFinalFromIdx;
+    bool ffz, eqEth, eqT1, eqT2;          // IsZero outputs are bits whatever the inputs are: kept as bits (a field element is nine registers)
+    Fr key1, effAmt1, isP2Insert, key2;
+    Fr verifySignEnabled, checkToEthAddr, checkToBjj, nullifyLoadAmount, nullifyAmount;
 };
-__device__ __forceinline__ Fr fr_iszero_bit(const Fr& v) { return fr_from_bit(fr_is_zero(v) ? 1u : 0u); }
 // DecodeFloatBin's value without its signals (decode_float_dev stores them)
 __device__ __forceinline__ Fr decode_float_val(uint64_t f40) {
     Fr pe = fr_from_u64(((f40 >> 35) & 1) ? 10 : 1), p10 = fr_from_u64(10);
@@ -521,59 +581,104 @@ __device__ __forceinline__ Fr decode_float_val(uint64_t f40) {
     }
     return fr_mul(fr_from_u64(f40 & ((1ull << 35) - 1)), pe);
 }
-template <class IN>
-__device__ __forceinline__ RtxStates rtx_states_dev(const UnitIO& io, const IN& in, const RtxExt& x) {
+// STORE (the states lane): every signal of RollupTxStates is stored, every hand-off field written, WHERE it is computed -- a value that
+// is only kept for a store at the end of the function is nine registers held across everything in between (the witness pointer serves
+// loads and stores alike: the compiler does not move one across the other).
+template <bool STORE, class IN>
+__device__ __forceinline__ RtxStates rtx_states_dev(const UnitIO& io, const Scratch& sc, const StatesOff& so, const IN& in, const RtxExt& x) {
     RtxStates f;
-    const Fr one = fr_one();
-    f.onChain = io.in_m(in.onChain); f.newAccount = io.in_m(in.newAccount); f.newExit = io.in_m(in.newExit);
+    const Fr one = fr_one(), zero = fr_zero();
+    auto put = [&](uint32_t sig, const Fr& v) __attribute__((always_inline)) { if constexpr (STORE) io.put_m(sig, v); };
+    auto hand = [&](uint32_t field, const Fr& v) __attribute__((always_inline)) { if constexpr (STORE) sc.set(field, v); };
+    auto bit = [&](bool b) __attribute__((always_inline)) { return fr_from_bit(b ? 1u : 0u); };
+    f.onChain = io.in_m(in.onChain); f.newAccount = io.in_m(in.newAccount);
     f.notOn = fr_sub(one, f.onChain);
     f.loadAmount = decode_float_val(c_bits64(io.in_c(in.loadAmountF), 0, 40));
-    f.isLoadAmount = fr_sub(one, fr_iszero_bit(f.loadAmount));
-    f.isAmount = fr_sub(one, fr_iszero_bit(x.amount));
+    f.isLoadAmount = bit(!fr_is_zero(f.loadAmount));
+    f.isAmount = bit(!fr_is_zero(x.amount));
+    if constexpr (STORE) {
+        io.chk_zero(C_RTX_ST_L2_LOADAMOUNT, fr_mul(f.notOn, f.isLoadAmount));
+        io.chk_zero(C_RTX_ST_L2_NEWACCOUNT, fr_mul(f.notOn, f.newAccount));
+    }
     f.isP1Insert = fr_mul(f.onChain, f.newAccount);                                        // selFromIdx.s
     f.finalFromIdx = mux1_dev(x.fromIdx, io.in_m(in.auxFromIdx), f.isP1Insert);
-    f.tz = fr_iszero_bit(x.toIdx);
-    f.selectAuxToIdx = fr_mul(f.notOn, f.tz);
-    f.finalToIdx = mux1_dev(x.toIdx, io.in_m(in.auxToIdx), f.selectAuxToIdx);
-    const Fr toEthAddr = io.in_m(in.toEthAddr);
-    f.isAny = fr_iszero_bit(fr_sub(toEthAddr, fr_sub(m_pow2(160), one)));
-    f.ffz = fr_iszero_bit(f.finalFromIdx);
-    f.isFinalFromIdx = fr_sub(one, f.ffz);
-    f.P1_fnc0 = fr_mul(f.isP1Insert, f.isFinalFromIdx); f.P1_fnc1 = fr_mul(fr_sub(one, f.isP1Insert), f.isFinalFromIdx);
-    // Mux2 c = [0,f,f,f], s = [P1_fnc0, P1_fnc1]
-    f.m1_s10 = fr_mul(f.P1_fnc1, f.P1_fnc0);
-    f.m1_a10 = fr_mul(fr_neg(f.finalFromIdx), f.m1_s10); f.m1_a1 = fr_mul(f.finalFromIdx, f.P1_fnc1); f.m1_a0 = fr_mul(f.finalFromIdx, f.P1_fnc0);
-    f.key1 = fr_add(fr_add(f.m1_a10, f.m1_a1), f.m1_a0);
-    f.isExit = fr_iszero_bit(fr_sub(f.finalToIdx, one));
-    f.effAmt1 = fr_mul(x.amount, fr_sub(one, f.ffz));                                      // amount * (1 - nop)
-    f.isP2Insert = fr_mul(f.isExit, f.newExit);
-    f.P2_fnc0 = fr_mul(f.isP2Insert, f.isFinalFromIdx); f.P2_fnc1 = fr_mul(fr_sub(one, f.isP2Insert), f.isFinalFromIdx);
-    // Mux2 c = [0, finalToIdx, 0, finalFromIdx], s = [isAmount, isExit]
-    f.m2_s10 = fr_mul(f.isExit, f.isAmount);
-    f.m2_a10 = fr_mul(fr_sub(f.finalFromIdx, f.finalToIdx), f.m2_s10); f.m2_a0 = fr_mul(f.finalToIdx, f.isAmount);
-    f.key2 = fr_add(f.m2_a10, f.m2_a0);
+    put(so.selFromIdx_s, f.isP1Insert); put(so.selFromIdx_out, f.finalFromIdx); put(so.isP1Insert, f.isP1Insert);
+    hand(SC_ISP1INSERT, f.isP1Insert);
+    const bool tz = fr_is_zero(x.toIdx);
+    const Fr selectAuxToIdx = fr_mul(f.notOn, bit(tz));
+    f.finalToIdx = mux1_dev(x.toIdx, io.in_m(in.auxToIdx), selectAuxToIdx);
+    put(so.selectAuxToIdx, selectAuxToIdx); put(so.selToIdx_out, f.finalToIdx);
+    f.ffz = fr_is_zero(f.finalFromIdx);
+    f.isFinalFromIdx = bit(!f.ffz);
+    const Fr notNop = f.isFinalFromIdx;                                                    // 1 - nop, nop = finalFromIdxIsZero.out
+    {
+        const Fr P1_fnc0 = fr_mul(f.isP1Insert, f.isFinalFromIdx), P1_fnc1 = fr_mul(fr_sub(one, f.isP1Insert), f.isFinalFromIdx);
+        put(so.P1_fnc0, P1_fnc0); put(so.P1_fnc1, P1_fnc1);
+        hand(SC_P1_FNC0, P1_fnc0); hand(SC_P1_FNC1, P1_fnc1);
+        // Mux2 c = [0,f,f,f], s = [P1_fnc0, P1_fnc1]
+        const Fr s10 = fr_mul(P1_fnc1, P1_fnc0);
+        const Fr a10 = fr_mul(fr_neg(f.finalFromIdx), s10), a1 = fr_mul(f.finalFromIdx, P1_fnc1), a0 = fr_mul(f.finalFromIdx, P1_fnc0);
+        put(so.mux1 + M2_S10, s10); put(so.mux1 + M2_A10, a10); put(so.mux1 + M2_A1, a1); put(so.mux1 + M2_A0, a0);
+        f.key1 = fr_add(fr_add(a10, a1), a0);
+        hand(SC_KEY_1, f.key1);
+    }
+    const bool isExit_b = fr_is_zero(fr_sub(f.finalToIdx, one));
+    const Fr isExit = bit(isExit_b);
+    hand(SC_ISEXIT, isExit);
+    f.effAmt1 = fr_mul(x.amount, notNop);                                                  // amount * (1 - nop)
+    f.isP2Insert = fr_mul(isExit, io.in_m(in.newExit));
+    put(so.isP2Insert, f.isP2Insert);
+    hand(SC_ISP2INSERT, f.isP2Insert);
+    {
+        const Fr P2_fnc0 = fr_mul(f.isP2Insert, f.isFinalFromIdx), P2_fnc1 = fr_mul(fr_sub(one, f.isP2Insert), f.isFinalFromIdx);
+        put(so.P2_fnc0, P2_fnc0); put(so.P2_fnc1, P2_fnc1);
+        if constexpr (STORE) {   // the processor sees a NOP when nothing is transferred: isP2Nop = 1 - IsZero(effectiveAmount)
+            const bool moves = !fr_is_zero(f.effAmt1);
+            sc.set(SC_P2_FNC0, fr_select(moves, P2_fnc0, zero)); sc.set(SC_P2_FNC1, fr_select(moves, P2_fnc1, zero));
+        }
+        // Mux2 c = [0, finalToIdx, 0, finalFromIdx], s = [isAmount, isExit]
+        const Fr s10 = fr_mul(isExit, f.isAmount);
+        const Fr a10 = fr_mul(fr_sub(f.finalFromIdx, f.finalToIdx), s10), a0 = fr_mul(f.finalToIdx, f.isAmount);
+        put(so.mux2 + M2_S10, s10); put(so.mux2 + M2_A10, a10); put(so.mux2 + M2_A1, zero); put(so.mux2 + M2_A0, a0);
+        f.key2 = fr_add(a10, a0);
+        hand(SC_KEY_2, f.key2);
+    }
     f.verifySignEnabled = fr_mul(f.notOn, f.isFinalFromIdx);
-    f.tmpE = fr_mul(fr_sub(one, f.isAny), f.selectAuxToIdx); f.tmpB = fr_mul(f.isAny, f.selectAuxToIdx);
-    f.checkToEthAddr = fr_mul(f.tmpE, fr_sub(one, f.ffz)); f.checkToBjj = fr_mul(f.tmpB, fr_sub(one, f.ffz));
-    f.onNotCreate = fr_mul(fr_sub(one, f.newAccount), f.onChain);
-    f.shouldEth = fr_mul(f.onNotCreate, f.isAmount);
-    f.eqEth = fr_iszero_bit(fr_sub(io.in_m(in.ethAddr1), io.in_m(in.fromEthAddr)));
-    f.nullEth = fr_mul(f.shouldEth, fr_sub(one, f.eqEth));
-    f.eqT1 = fr_iszero_bit(fr_sub(io.in_m(in.tokenID1), x.tokenID));
-    f.nullT1 = fr_mul(f.onNotCreate, fr_sub(one, f.eqT1));
-    f.sc20 = fr_mul(f.onChain, f.isAmount); f.sc21 = fr_mul(f.sc20, fr_sub(one, f.isP2Insert));
-    f.eqT2 = fr_iszero_bit(fr_sub(io.in_m(in.tokenID2), x.tokenID));
-    f.nullT2 = fr_mul(f.sc21, fr_sub(one, f.eqT2));
-    f.nullifyLoadAmount = fr_mul(f.nullT1, f.isLoadAmount);
-    f.applyT1Amt = fr_mul(f.nullT1, f.isAmount);
-    f.na0 = fr_sub(one, fr_mul(fr_sub(one, f.nullEth), fr_sub(one, f.nullT2)));
-    f.nullifyAmount = fr_sub(one, fr_mul(fr_sub(one, f.na0), fr_sub(one, f.applyT1Amt)));
+    put(so.verifySignEnabled, f.verifySignEnabled);
+    hand(SC_ED_ENABLED, f.verifySignEnabled);
+    {
+        const Fr isAny = bit(fr_is_zero(fr_sub(io.in_m(in.toEthAddr), fr_sub(m_pow2(160), one))));
+        const Fr tmpE = fr_mul(fr_sub(one, isAny), selectAuxToIdx), tmpB = fr_mul(isAny, selectAuxToIdx);
+        f.checkToEthAddr = fr_mul(tmpE, notNop); f.checkToBjj = fr_mul(tmpB, notNop);
+        put(so.tmpCheckToEthAddr, tmpE); put(so.tmpCheckToBjj, tmpB); put(so.checkToEthAddr, f.checkToEthAddr); put(so.checkToBjj, f.checkToBjj);
+    }
+    const Fr onNotCreate = fr_mul(fr_sub(one, f.newAccount), f.onChain);
+    const Fr shouldEth = fr_mul(onNotCreate, f.isAmount);
+    put(so.onChainNotCreateAccount, onNotCreate); put(so.shouldCheckEthAddr, shouldEth);
+    f.eqEth = fr_is_zero(fr_sub(io.in_m(in.ethAddr1), io.in_m(in.fromEthAddr)));
+    const Fr nullEth = fr_mul(shouldEth, bit(!f.eqEth));
+    put(so.applyNullifierEthAddr, nullEth);
+    f.eqT1 = fr_is_zero(fr_sub(io.in_m(in.tokenID1), x.tokenID));
+    const Fr nullT1 = fr_mul(onNotCreate, bit(!f.eqT1));
+    put(so.applyNullifierTokenID1, nullT1);
+    const Fr sc20 = fr_mul(f.onChain, f.isAmount), sc21 = fr_mul(sc20, fr_sub(one, f.isP2Insert));
+    put(so.shouldCheckTokenID2_0, sc20); put(so.shouldCheckTokenID2_1, sc21);
+    f.eqT2 = fr_is_zero(fr_sub(io.in_m(in.tokenID2), x.tokenID));
+    const Fr nullT2 = fr_mul(sc21, bit(!f.eqT2));
+    put(so.applyNullifierTokenID2, nullT2);
+    f.nullifyLoadAmount = fr_mul(nullT1, f.isLoadAmount);
+    const Fr applyT1Amt = fr_mul(nullT1, f.isAmount);
+    put(so.nullifyLoadAmount, f.nullifyLoadAmount); put(so.applyCheckTokenID1ToAmount, applyT1Amt);
+    const Fr na0 = fr_sub(one, fr_mul(fr_sub(one, nullEth), fr_sub(one, nullT2)));
+    f.nullifyAmount = fr_sub(one, fr_mul(fr_sub(one, na0), fr_sub(one, applyT1Amt)));
+    put(so.nullifyAmount_0, na0); put(so.nullifyAmount, f.nullifyAmount);
     return f;
 }
 
 // ---- states lane. `NB` gives the neighbours' fields of RqTxVerifier: fut(m, j), past(m, j), m = 0 txCompressedDataV2, 1 toEthAddr, 2 toBjjAy
-template <class IN, class NB>
-__device__ __forceinline__ void rtx_states_lane_dev(const UnitIO& io, const Scratch& sc, const RtxOff& o, const IN& in, const RtxExt& x, const NB& nb, bool own_sig) {
+// `xs()` evaluates the transaction's decoded fields and old roots (RtxExt) where they are needed (rtx_balance_lane_dev does the same)
+template <class IN, class NB, class XS>
+__device__ __forceinline__ void rtx_states_lane_dev(const UnitIO& io, const Scratch& sc, const RtxOff& o, const IN& in, XS xs, const NB& nb, bool own_sig) {
     const Fr one = fr_one(), zero = fr_zero();
     const StatesOff& so = o.st;
     {   // ---- A: decode loadAmountF (its signals), RollupTxStates
@@ -581,28 +686,11 @@ __device__ __forceinline__ void rtx_states_lane_dev(const UnitIO& io, const Scra
         num2bits_dev(io, o.n2bLoadAmountF, la_c, 40, C_RTX_N2B_LOADAMOUNTF);
         (void)decode_float_dev(io, o.dfLoadAmount, c_bits64(la_c, 0, 40));
     }
-    const RtxStates f = rtx_states_dev(io, in, x);
-    io.put_m(so.selFromIdx_s, f.isP1Insert); io.put_m(so.selFromIdx_out, f.finalFromIdx);
-    io.put_m(so.selectAuxToIdx, f.selectAuxToIdx); io.put_m(so.selToIdx_out, f.finalToIdx);
-    io.chk_zero(C_RTX_ST_L2_LOADAMOUNT, fr_mul(f.notOn, f.isLoadAmount));
-    io.chk_zero(C_RTX_ST_L2_NEWACCOUNT, fr_mul(f.notOn, f.newAccount));
-    io.put_m(so.isP1Insert, f.isP1Insert); io.put_m(so.P1_fnc0, f.P1_fnc0); io.put_m(so.P1_fnc1, f.P1_fnc1);
-    io.put_m(so.mux1 + M2_S10, f.m1_s10); io.put_m(so.mux1 + M2_A10, f.m1_a10); io.put_m(so.mux1 + M2_A1, f.m1_a1); io.put_m(so.mux1 + M2_A0, f.m1_a0);
-    io.put_m(so.isP2Insert, f.isP2Insert); io.put_m(so.P2_fnc0, f.P2_fnc0); io.put_m(so.P2_fnc1, f.P2_fnc1);
-    io.put_m(so.mux2 + M2_S10, f.m2_s10); io.put_m(so.mux2 + M2_A10, f.m2_a10); io.put_m(so.mux2 + M2_A1, zero); io.put_m(so.mux2 + M2_A0, f.m2_a0);
-    io.put_m(so.verifySignEnabled, f.verifySignEnabled);
-    io.put_m(so.tmpCheckToEthAddr, f.tmpE); io.put_m(so.tmpCheckToBjj, f.tmpB); io.put_m(so.checkToEthAddr, f.checkToEthAddr); io.put_m(so.checkToBjj, f.checkToBjj);
-    io.put_m(so.onChainNotCreateAccount, f.onNotCreate); io.put_m(so.shouldCheckEthAddr, f.shouldEth);
-    io.put_m(so.applyNullifierEthAddr, f.nullEth); io.put_m(so.applyNullifierTokenID1, f.nullT1);
-    io.put_m(so.shouldCheckTokenID2_0, f.sc20); io.put_m(so.shouldCheckTokenID2_1, f.sc21);
-    io.put_m(so.applyNullifierTokenID2, f.nullT2);
-    io.put_m(so.nullifyLoadAmount, f.nullifyLoadAmount); io.put_m(so.applyCheckTokenID1ToAmount, f.applyT1Amt);
-    io.put_m(so.nullifyAmount_0, f.na0); io.put_m(so.nullifyAmount, f.nullifyAmount);
     {   // ---- B: RqTxVerifier
         const Fc rq_c = io.in_c(in.rqOffset);
         num2bits_dev(io, o.rq_n2b, rq_c, 3, C_RTX_RQ_N2B);
         const Fr s[3] = {fr_from_bit(c_bit(rq_c, 0)), fr_from_bit(c_bit(rq_c, 1)), fr_from_bit(c_bit(rq_c, 2))};
-        auto one_mux = [&](const int m, uint32_t rq_sig, int cid) {
+        auto one_mux = [&](const int m, uint32_t rq_sig, int cid) __attribute__((always_inline)) {
             const Fr c[8] = {zero, nb.fut(m, 0), nb.fut(m, 1), nb.fut(m, 2), nb.past(m, 3), nb.past(m, 2), nb.past(m, 1), nb.past(m, 0)};
             io.chk(cid, mux3_dev(io, o.rq_mux[m], c, s), io.in_m(rq_sig));
         };
@@ -610,47 +698,55 @@ __device__ __forceinline__ void rtx_states_lane_dev(const UnitIO& io, const Scra
         one_mux(1, in.rqToEthAddr, C_RTX_RQ_ETHADDR);
         one_mux(2, in.rqToBjjAy, C_RTX_RQ_BJJAY);
     }
+    const RtxStates f = rtx_states_dev<true>(io, sc, so, in, xs());   // RollupTxStates: signals, checks, hand-off of keys and functions
     // ---- C: ForceEqualIfEnabled x8 ((1 - isz.out) * enabled === 0): the outputs are the comparisons above, the IsZero signals follow
-    const Fr eqNonce = fr_iszero_bit(fr_sub(io.in_m(in.nonce1), x.nonce));
+    const Fr eqNonce = fr_iszero_bit(fr_sub(io.in_m(in.nonce1), xs().nonce));
     const Fr eqToEth = fr_iszero_bit(fr_sub(io.in_m(in.ethAddr2), io.in_m(in.toEthAddr)));
     const Fr eqToAy = fr_iszero_bit(fr_sub(io.in_m(in.toBjjAy), io.in_m(in.ay2)));
-    const Fr eqToSign = fr_iszero_bit(fr_sub(x.toBjjSign, io.in_m(in.sign2)));
-    auto force = [&](const Fr& e, const Fr& enabled, int cid) { io.chk_zero(cid, fr_mul(fr_sub(one, e), enabled)); };
+    const Fr eqToSign = fr_iszero_bit(fr_sub(xs().toBjjSign, io.in_m(in.sign2)));
+    auto force = [&](const Fr& e, const Fr& enabled, int cid) __attribute__((always_inline)) { io.chk_zero(cid, fr_mul(fr_sub(one, e), enabled)); };
     force(eqNonce, f.notOn, C_RTX_NONCE);
     const Fr en_toEth = fr_sub(one, fr_mul(fr_sub(one, f.checkToEthAddr), fr_sub(one, f.checkToBjj)));
     io.put_m(o.checkToEthAddr_en, en_toEth);
     force(eqToEth, en_toEth, C_RTX_TOETHADDR);
     force(eqToAy, f.checkToBjj, C_RTX_TOBJJAY);
     force(eqToSign, f.checkToBjj, C_RTX_TOBJJSIGN);
-    force(f.eqT1, f.notOn, C_RTX_TOKENID1);
+    force(fr_from_bit(f.eqT1 ? 1u : 0u), f.notOn, C_RTX_TOKENID1);
     const Fr en_t2 = fr_mul(f.notOn, fr_sub(one, f.isP2Insert));
     io.put_m(o.checkTokenID2_en, en_t2);
-    force(f.eqT2, en_t2, C_RTX_TOKENID2);
-    force(f.eqT1, f.isP1Insert, C_RTX_TOKENID1_L1);
-    force(f.eqEth, f.isP1Insert, C_RTX_FROMETHADDR);
-    // ---- every IsZero of the front (states, phase C, BalanceUpdater's effectiveAmount): (inv, out) signals, two inversions for 14 slots
+    force(fr_from_bit(f.eqT2 ? 1u : 0u), en_t2, C_RTX_TOKENID2);
+    force(fr_from_bit(f.eqT1 ? 1u : 0u), f.isP1Insert, C_RTX_TOKENID1_L1);
+    force(fr_from_bit(f.eqEth ? 1u : 0u), f.isP1Insert, C_RTX_FROMETHADDR);
+    // ---- hand-off to the hash / smt / eddsa / back steps: what is not RollupTxStates' (those fields are written where they are computed)
+    sc.set(SC_OLDVALUE1, io.in_m(in.oldValue1)); sc.set(SC_OLDVALUE2, io.in_m(in.oldValue2));
+    sc.set(SC_ISOLD0_1, io.in_m(in.isOld0_1)); sc.set(SC_ISOLD0_2, io.in_m(in.isOld0_2));
+    sc.set(SC_OLDSTATEROOT, xs().oldStateRoot); sc.set(SC_OLDEXITROOT, xs().oldExitRoot);
+    sc.set(SC_ED_S, io.in_m(in.s)); sc.set(SC_ED_R8X, io.in_m(in.r8x)); sc.set(SC_ED_R8Y, io.in_m(in.r8y));
+    if (own_sig) sc.set(SC_SIGL2HASH, xs().sigL2Hash);   // else: k_main_sighash stores it
+    // ---- every IsZero of the front (states, phase C, BalanceUpdater's effectiveAmount): (inv, out) signals, two inversions for 14 slots.
+    // Last: an inversion is the lane's peak of register use, and by now nothing but the run's own operands is alive.
     {
         const Fr finalFromIdx = f.finalFromIdx, finalToIdx = f.finalToIdx, loadAmount = f.loadAmount, effAmt1 = f.effAmt1;
-        auto operand = [&](int k) -> Fr {
+        auto operand = [&](int k) __attribute__((always_inline)) -> Fr {
             switch (k) {
-                case 0: return x.toIdx;
+                case 0: return xs().toIdx;
                 case 1: return fr_sub(io.in_m(in.toEthAddr), fr_sub(m_pow2(160), one));
                 case 2: return finalFromIdx;
                 case 3: return loadAmount;
-                case 4: return x.amount;
+                case 4: return xs().amount;
                 case 5: return fr_sub(io.in_m(in.ethAddr1), io.in_m(in.fromEthAddr));
-                case 6: return fr_sub(io.in_m(in.tokenID1), x.tokenID);
-                case 7: return fr_sub(io.in_m(in.tokenID2), x.tokenID);
-                case 8: return fr_sub(io.in_m(in.nonce1), x.nonce);
+                case 6: return fr_sub(io.in_m(in.tokenID1), xs().tokenID);
+                case 7: return fr_sub(io.in_m(in.tokenID2), xs().tokenID);
+                case 8: return fr_sub(io.in_m(in.nonce1), xs().nonce);
                 case 9: return fr_sub(io.in_m(in.ethAddr2), io.in_m(in.toEthAddr));
                 case 10: return fr_sub(io.in_m(in.toBjjAy), io.in_m(in.ay2));
-                case 11: return fr_sub(x.toBjjSign, io.in_m(in.sign2));
+                case 11: return fr_sub(xs().toBjjSign, io.in_m(in.sign2));
                 case 12: return fr_sub(finalToIdx, one);
                 default: return effAmt1;
             }
         };
-        auto store = [&](int k, const Fr& v, const Fr& vi) {
-            auto put = [&](IsZOff off) { (void)is_zero_dev(io, off, v, vi); };
+        auto store = [&](int k, const Fr& v, const Fr& vi) __attribute__((always_inline)) {
+            auto put = [&](IsZOff off) __attribute__((always_inline)) { (void)is_zero_dev(io, off, v, vi); };
             switch (k) {
                 case 0: put(so.toIdxIsZero); break;
                 case 1: put(so.isToEthAddrAny); break;
@@ -670,18 +766,6 @@ __device__ __forceinline__ void rtx_states_lane_dev(const UnitIO& io, const Scra
         };
         (void)is_zero_run_store_dev<7>(14, operand, store);
     }
-    // ---- hand-off to the hash / smt / eddsa / back steps (this lane's share)
-    const Fr isP2Nop = fr_sub(one, fr_iszero_bit(f.effAmt1));
-    sc.set(SC_ISP1INSERT, f.isP1Insert); sc.set(SC_ISP2INSERT, f.isP2Insert);
-    sc.set(SC_OLDVALUE1, io.in_m(in.oldValue1)); sc.set(SC_OLDVALUE2, io.in_m(in.oldValue2));
-    sc.set(SC_KEY_1, f.key1); sc.set(SC_KEY_2, f.key2);
-    sc.set(SC_P1_FNC0, f.P1_fnc0); sc.set(SC_P1_FNC1, f.P1_fnc1);
-    sc.set(SC_P2_FNC0, fr_mul(f.P2_fnc0, isP2Nop)); sc.set(SC_P2_FNC1, fr_mul(f.P2_fnc1, isP2Nop));
-    sc.set(SC_ISOLD0_1, io.in_m(in.isOld0_1)); sc.set(SC_ISOLD0_2, io.in_m(in.isOld0_2));
-    sc.set(SC_ISEXIT, f.isExit); sc.set(SC_OLDSTATEROOT, x.oldStateRoot); sc.set(SC_OLDEXITROOT, x.oldExitRoot);
-    sc.set(SC_ED_ENABLED, f.verifySignEnabled);
-    sc.set(SC_ED_S, io.in_m(in.s)); sc.set(SC_ED_R8X, io.in_m(in.r8x)); sc.set(SC_ED_R8Y, io.in_m(in.r8y));
-    if (own_sig) sc.set(SC_SIGL2HASH, x.sigL2Hash);   // else: the DecodeTx lane stores it
 }
 
 // ---- mux lane. `l1full` != ~0u (k_main_front): this lane also stores DecodeTx's L1TxFullData rows of the fromBjjCompressed bits (signal
@@ -734,54 +818,66 @@ __device__ __forceinline__ void rtx_mux_lane_dev(const UnitIO& io, const Scratch
         bjjAy = acc;
         bjjSign = io.in_m(in.fromBjjCompressed + 255);
     }
-    const RtxStates f = rtx_states_dev(io, in, x);
-    const Fr tokenID1 = io.in_m(in.tokenID1), tokenID2 = io.in_m(in.tokenID2), nonce1 = io.in_m(in.nonce1), nonce2 = io.in_m(in.nonce2);
-    const Fr sign1 = io.in_m(in.sign1), sign2 = io.in_m(in.sign2), ay1 = io.in_m(in.ay1), ay2 = io.in_m(in.ay2);
-    const Fr ethAddr1 = io.in_m(in.ethAddr1), ethAddr2 = io.in_m(in.ethAddr2);
     const Fr p32 = m_pow2(32), p72 = m_pow2(72);
-    auto e0 = [&](const Fr& tok, const Fr& non, const Fr& sg) { return fr_add(fr_add(tok, fr_mul(non, p32)), fr_mul(sg, p72)); };
+    auto e0 = [&](const Fr& tok, const Fr& non, const Fr& sg) __attribute__((always_inline)) { return fr_add(fr_add(tok, fr_mul(non, p32)), fr_mul(sg, p72)); };
+    // hand-off of the OLD states' hash inputs first (nothing of them stays alive), then the multiplexers one account field at a time
+    sc.set(SC_HS_IN + 0, e0(io.in_m(in.tokenID1), io.in_m(in.nonce1), io.in_m(in.sign1))); sc.set(SC_HS_IN + 1, io.in_m(in.balance1));
+    sc.set(SC_HS_IN + 2, io.in_m(in.ay1)); sc.set(SC_HS_IN + 3, io.in_m(in.ethAddr1));
+    sc.set(SC_HS_IN + 4, e0(io.in_m(in.tokenID2), io.in_m(in.nonce2), io.in_m(in.sign2))); sc.set(SC_HS_IN + 5, io.in_m(in.balance2));
+    sc.set(SC_HS_IN + 6, io.in_m(in.ay2)); sc.set(SC_HS_IN + 7, io.in_m(in.ethAddr2));
+    const RtxStates f = rtx_states_dev<false>(io, sc, o.st, in, x);
+    const Fr isP1 = f.isP1Insert, isP2 = f.isP2Insert, notOn = f.notOn, vse = f.verifySignEnabled;
     // the 16 Mux1 (s1OldValue / s2OldValue need the old hashes: hash step), each stored where it is computed
-    const Fr s1Balance = mux1_dev(io.in_m(in.balance1), zero, f.isP1Insert);
-    const Fr s1Sign = mux1_dev(sign1, bjjSign, f.isP1Insert);
-    const Fr s1Ay = mux1_dev(ay1, bjjAy, f.isP1Insert);
-    const Fr s1Nonce = mux1_dev(nonce1, zero, f.isP1Insert);
-    const Fr s1EthAddr = mux1_dev(ethAddr1, io.in_m(in.fromEthAddr), f.isP1Insert);
-    const Fr s1TokenID = mux1_dev(tokenID1, x.tokenID, f.isP1Insert);
-    const Fr s1OldKey = mux1_dev(f.key1, io.in_m(in.oldKey1), f.isP1Insert);
-    io.put_m(o.mux16 + MX_S1BALANCE, s1Balance); io.put_m(o.mux16 + MX_S1SIGN, s1Sign); io.put_m(o.mux16 + MX_S1AY, s1Ay); io.put_m(o.mux16 + MX_S1NONCE, s1Nonce);
-    io.put_m(o.mux16 + MX_S1ETHADDR, s1EthAddr); io.put_m(o.mux16 + MX_S1TOKENID, s1TokenID); io.put_m(o.mux16 + MX_S1OLDKEY, s1OldKey);
-    const Fr s2Balance = mux1_dev(io.in_m(in.balance2), zero, f.isP2Insert);
-    const Fr s2Sign = mux1_dev(sign2, s1Sign, f.isP2Insert);
-    const Fr s2Ay = mux1_dev(ay2, s1Ay, f.isP2Insert);
-    const Fr s2Nonce = mux1_dev(nonce2, zero, f.isP2Insert);
-    const Fr s2EthAddr = mux1_dev(ethAddr2, s1EthAddr, f.isP2Insert);
-    const Fr s2TokenID = mux1_dev(tokenID2, s1TokenID, f.isP2Insert);
-    const Fr s2OldKey = mux1_dev(f.key2, io.in_m(in.oldKey2), f.isP2Insert);
-    io.put_m(o.mux16 + MX_S2BALANCE, s2Balance); io.put_m(o.mux16 + MX_S2SIGN, s2Sign); io.put_m(o.mux16 + MX_S2AY, s2Ay); io.put_m(o.mux16 + MX_S2NONCE, s2Nonce);
-    io.put_m(o.mux16 + MX_S2ETHADDR, s2EthAddr); io.put_m(o.mux16 + MX_S2TOKENID, s2TokenID); io.put_m(o.mux16 + MX_S2OLDKEY, s2OldKey);
-    // ---- F (inputs only): signSignature / aySignature
-    const Fr signSig = fr_mul(s1Sign, f.verifySignEnabled), aySig = fr_mul(s1Ay, f.verifySignEnabled);
-    io.put_m(o.ed.signSignature, signSig); io.put_m(o.ed.aySignature, aySig);
-    // ---- hand-off: the hash-state inputs but the two new balances (balance lane), the old keys, the signature's key
-    sc.set(SC_HS_IN + 0, e0(tokenID1, nonce1, sign1)); sc.set(SC_HS_IN + 1, io.in_m(in.balance1)); sc.set(SC_HS_IN + 2, ay1); sc.set(SC_HS_IN + 3, ethAddr1);
-    sc.set(SC_HS_IN + 4, e0(tokenID2, nonce2, sign2)); sc.set(SC_HS_IN + 5, io.in_m(in.balance2)); sc.set(SC_HS_IN + 6, ay2); sc.set(SC_HS_IN + 7, ethAddr2);
-    sc.set(SC_HS_IN + 8, e0(s1TokenID, fr_add(s1Nonce, f.notOn), s1Sign));
-    sc.set(SC_HS_IN + 10, s1Ay); sc.set(SC_HS_IN + 11, s1EthAddr);
+    io.put_m(o.mux16 + MX_S1BALANCE, mux1_dev(io.in_m(in.balance1), zero, isP1));
+    io.put_m(o.mux16 + MX_S2BALANCE, mux1_dev(io.in_m(in.balance2), zero, isP2));
+    {
+        const Fr s1OldKey = mux1_dev(f.key1, io.in_m(in.oldKey1), isP1), s2OldKey = mux1_dev(f.key2, io.in_m(in.oldKey2), isP2);
+        io.put_m(o.mux16 + MX_S1OLDKEY, s1OldKey); io.put_m(o.mux16 + MX_S2OLDKEY, s2OldKey);
+        sc.set(SC_KEY_S1OLD, s1OldKey); sc.set(SC_KEY_S2OLD, s2OldKey);
+    }
+    {
+        const Fr s1EthAddr = mux1_dev(io.in_m(in.ethAddr1), io.in_m(in.fromEthAddr), isP1), s2EthAddr = mux1_dev(io.in_m(in.ethAddr2), s1EthAddr, isP2);
+        io.put_m(o.mux16 + MX_S1ETHADDR, s1EthAddr); io.put_m(o.mux16 + MX_S2ETHADDR, s2EthAddr);
+        sc.set(SC_HS_IN + 11, s1EthAddr); sc.set(SC_HS_IN + 15, s2EthAddr);
+    }
+    const Fr s1Ay = mux1_dev(io.in_m(in.ay1), bjjAy, isP1);
+    {
+        const Fr s2Ay = mux1_dev(io.in_m(in.ay2), s1Ay, isP2);
+        io.put_m(o.mux16 + MX_S1AY, s1Ay); io.put_m(o.mux16 + MX_S2AY, s2Ay);
+        sc.set(SC_HS_IN + 10, s1Ay); sc.set(SC_HS_IN + 14, s2Ay); sc.set(SC_ED_AY, s1Ay);
+    }
+    const Fr s1Sign = mux1_dev(io.in_m(in.sign1), bjjSign, isP1), s2Sign = mux1_dev(io.in_m(in.sign2), s1Sign, isP2);
+    io.put_m(o.mux16 + MX_S1SIGN, s1Sign); io.put_m(o.mux16 + MX_S2SIGN, s2Sign);
+    {   // ---- F (inputs only): signSignature / aySignature
+        const Fr signSig = fr_mul(s1Sign, vse), aySig = fr_mul(s1Ay, vse);
+        io.put_m(o.ed.signSignature, signSig); io.put_m(o.ed.aySignature, aySig);
+        sc.set(SC_ED_SIGN, signSig); sc.set(SC_ED_AYSIG, aySig);
+    }
+    const Fr s1TokenID = mux1_dev(io.in_m(in.tokenID1), x.tokenID, isP1), s2TokenID = mux1_dev(io.in_m(in.tokenID2), s1TokenID, isP2);
+    io.put_m(o.mux16 + MX_S1TOKENID, s1TokenID); io.put_m(o.mux16 + MX_S2TOKENID, s2TokenID);
+    const Fr s1Nonce = mux1_dev(io.in_m(in.nonce1), zero, isP1), s2Nonce = mux1_dev(io.in_m(in.nonce2), zero, isP2);
+    io.put_m(o.mux16 + MX_S1NONCE, s1Nonce); io.put_m(o.mux16 + MX_S2NONCE, s2Nonce);
+    // the new states' e0 (tokenID + nonce * 2^32 + sign * 2^72); the two new balances are the balance lane's
+    sc.set(SC_HS_IN + 8, e0(s1TokenID, fr_add(s1Nonce, notOn), s1Sign));
     sc.set(SC_HS_IN + 12, e0(s2TokenID, s2Nonce, s2Sign));
-    sc.set(SC_HS_IN + 14, s2Ay); sc.set(SC_HS_IN + 15, s2EthAddr);
-    sc.set(SC_KEY_S1OLD, s1OldKey); sc.set(SC_KEY_S2OLD, s2OldKey);
-    sc.set(SC_ED_SIGN, signSig); sc.set(SC_ED_AYSIG, aySig); sc.set(SC_ED_AY, s1Ay);
 }
 
 // ---- balance lane: G (BalanceUpdater) and H -- the FeeAccumulator here (standalone RollupTx) or as a kernel of its own beside the chains the
 // front kernel feeds (RollupMain: it is half of a transaction's front arithmetic and feeds none of them)
-template <class IN, class FEE, bool FEEACC>
-__device__ __forceinline__ FrontOut rtx_balance_lane_dev(const UnitIO& io, const Scratch& sc, const RtxOff& o, const IN& in, const RtxExt& x, int Fn, const FEE& feeSrc) {
+// `xs()` evaluates the transaction's decoded fields (RtxExt): called where they are needed instead of held across ComputeFee
+template <class IN, class FEE, bool FEEACC, class XS>
+__device__ __forceinline__ FrontOut rtx_balance_lane_dev(const UnitIO& io, const Scratch& sc, const RtxOff& o, const IN& in, XS xs, int Fn, const FEE& feeSrc) {
     const Fr one = fr_one(), zero = fr_zero();
-    const RtxStates f = rtx_states_dev(io, in, x);
     const BalUpdOff& bo = o.bu;
-    const Fc userFee_c = fr_to_canon(x.userFee);
-    const Fr fee2Charge = compute_fee_dev(io, bo.fee, userFee_c, x.amount, fr_mul(f.notOn, fr_sub(one, f.ffz)));
+    Fr fee2Charge;
+    {   // ComputeFee needs applyFee = (1 - onChain) * (1 - nop) of the states and nothing else: evaluated for it alone, so that none of the
+        // balance arithmetic's operands is alive across the 17 multiplexers
+        const RtxExt x0 = xs();
+        const RtxStates f0 = rtx_states_dev<false>(io, sc, o.st, in, x0);
+        fee2Charge = compute_fee_ld_dev(io, bo.fee, fr_to_canon(x0.userFee), [&]() __attribute__((always_inline)) { return xs().amount; }, fr_mul(f0.notOn, f0.isFinalFromIdx));
+    }
+    const RtxExt x = xs();
+    const RtxStates f = rtx_states_dev<false>(io, sc, o.st, in, x);
     const Fr el1 = fr_mul(f.loadAmount, f.onChain), el2 = fr_mul(el1, fr_sub(one, f.nullifyLoadAmount));
     const Fr ea2 = fr_mul(f.effAmt1, fr_sub(one, f.nullifyAmount));
     io.put_m(bo.effLoad1, el1); io.put_m(bo.effLoad2, el2); io.put_m(bo.effAmt1, f.effAmt1); io.put_m(bo.effAmt2, ea2);

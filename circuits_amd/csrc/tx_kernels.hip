@@ -45,6 +45,27 @@ struct FeeSrcRtx {
 };
 
 
+// what DecodeTx takes from outside its transaction (decode_tx_dev's EXT): RollupMain wires it from the transaction before / the batch's
+// globals (src/rollup-main.circom:221-256), the standalone main has inputs
+struct DecExtMain {
+    const UnitIO* io;
+    const uint8_t* glob_base;
+    uint32_t B, b, i, u, imOnChain, imOutIdx, g_oldLastIdx, g_chainID, g_numBatch;
+    __device__ __forceinline__ Fr glob(uint32_t sig) const { return fr_from_canon(load_fr(glob_base + ((size_t)sig * B + b) * 32)); }
+    __device__ __forceinline__ Fr previousOnChain() const { return i == 0 ? fr_one() : io->in_m_u(imOnChain, u - 1); }
+    __device__ __forceinline__ Fr inIdx() const { return i == 0 ? glob(g_oldLastIdx) : io->in_m_u(imOutIdx, u - 1); }
+    __device__ __forceinline__ Fr globalChainID() const { return glob(g_chainID); }
+    __device__ __forceinline__ Fr currentNumBatch() const { return glob(g_numBatch); }
+};
+struct DecExtIn {
+    const UnitIO* io;
+    uint32_t s_prev, s_inIdx, s_chainID, s_numBatch;
+    __device__ __forceinline__ Fr previousOnChain() const { return io->in_m(s_prev); }
+    __device__ __forceinline__ Fr inIdx() const { return io->in_m(s_inIdx); }
+    __device__ __forceinline__ Fr globalChainID() const { return io->in_m(s_chainID); }
+    __device__ __forceinline__ Fr currentNumBatch() const { return io->in_m(s_numBatch); }
+};
+
 // the neighbours' fields of RqTxVerifier (rtx_states_lane_dev): RollupMain wires them from the transactions around (src/rollup-main.circom:269-379)
 struct NbMain {
     const UnitIO* io;
@@ -68,6 +89,9 @@ struct NbRtx {             // standalone RollupTx: they are inputs
 #ifndef HZ_FRONT_WAVES
 #define HZ_FRONT_WAVES 2
 #endif
+#ifndef HZ_SIGHASH_WAVES
+#define HZ_SIGHASH_WAVES 2
+#endif
 #ifndef HZ_FRONT_BLOCK
 #define HZ_FRONT_BLOCK HZ_BLOCK
 #endif
@@ -81,11 +105,11 @@ __global__ __launch_bounds__(HZ_FRONT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     const UnitIO io{a.tx_base, n_units, u, b, i, a.err};
     const Scratch sc{a.scratch, n_units, u};
     const MainTxInOff& m = a.mi;
-    auto glob = [&](uint32_t sig) { return fr_from_canon(load_fr(a.glob_base + ((size_t)sig * a.B + b) * 32)); };
+    auto glob = [&](uint32_t sig) __attribute__((always_inline)) { return fr_from_canon(load_fr(a.glob_base + ((size_t)sig * a.B + b) * 32)); };
     const Fr one = fr_one();
     if (blockIdx.y == 0) {
         // A (src/rollup-main.circom:207-219)
-        auto bool_chk = [&](int cid, const Fr& v) { io.chk_zero(cid, fr_mul(v, fr_sub(v, one))); };
+        auto bool_chk = [&](int cid, const Fr& v) __attribute__((always_inline)) { io.chk_zero(cid, fr_mul(v, fr_sub(v, one))); };
         if (i + 1 < a.nTx) bool_chk(C_MAIN_IMONCHAIN_BOOL, io.in_m(m.imOnChain));
         bool_chk(C_MAIN_ONCHAIN_BOOL, io.in_m(m.onChain));
         bool_chk(C_MAIN_NEWACCOUNT_BOOL, io.in_m(m.newAccount));
@@ -93,33 +117,50 @@ __global__ __launch_bounds__(HZ_FRONT_BLOCK) __attribute__((amdgpu_waves_per_eu(
         bool_chk(C_MAIN_ISOLD0_1_BOOL, io.in_m(m.isOld0_1));
         bool_chk(C_MAIN_ISOLD0_2_BOOL, io.in_m(m.isOld0_2));
         // B
-        const Fr previousOnChain = i == 0 ? one : io.in_m_u(m.imOnChain, u - 1);
-        const Fr inIdx = i == 0 ? glob(a.g.oldLastIdx) : io.in_m_u(m.imOutIdx, u - 1);
-        const DecResult d = decode_tx_dev(io, a.dec, m, (int)a.L, previousOnChain, inIdx, glob(a.g.globalChainID), glob(a.g.currentNumBatch), K7, false);
+        const DecExtMain ext{&io, a.glob_base, a.B, b, i, u, m.imOnChain, m.imOutIdx, a.g.oldLastIdx, a.g.globalChainID, a.g.currentNumBatch};
+        const DecResult d = decode_tx_dev<false>(io, a.dec, m, (int)a.L, ext, K7, false, false);
         // C (:258-265)
         io.chk(C_MAIN_IM_V2, d.v2, io.in_m(m.txCompressedDataV2));
         if (i + 1 < a.nTx) {
             io.chk(C_MAIN_IM_ONCHAIN, io.in_m(m.onChain), io.in_m(m.imOnChain));
             io.chk(C_MAIN_IM_OUTIDX, d.outIdx, io.in_m(m.imOutIdx));
         }
-        sc.set(SC_OUTIDX, d.outIdx);
-        sc.set(SC_SIGL2HASH, d.sigL2Hash);
+        sc.set(SC_OUTIDX, d.outIdx);   // (sigL2Hash: k_main_sighash)
         return;
     }
     // D: wiring (:269-379)
     RtxExt x;
     decode_fields_dev(io, m, x);
     if (blockIdx.y == 1) {
-        x.oldStateRoot = i == 0 ? glob(a.g.oldStateRoot) : io.in_m_u(m.imStateRoot, u - 1);
-        x.oldExitRoot = i == 0 ? fr_zero() : io.in_m_u(m.imExitRoot, u - 1);
         const NbMain nb{&io, {m.txCompressedDataV2, m.toEthAddr, m.toBjjAy}, u, i, a.nTx};
-        rtx_states_lane_dev(io, sc, a.rtx, m, x, nb, false);
+        auto xs = [&]() __attribute__((always_inline)) {
+            RtxExt y;
+            decode_fields_dev(io, m, y);
+            y.oldStateRoot = i == 0 ? glob(a.g.oldStateRoot) : io.in_m_u(m.imStateRoot, u - 1);
+            y.oldExitRoot = i == 0 ? fr_zero() : io.in_m_u(m.imExitRoot, u - 1);
+            return y;
+        };
+        rtx_states_lane_dev(io, sc, a.rtx, m, xs, nb, false);
     } else if (blockIdx.y == 2) {
         rtx_mux_lane_dev(io, sc, a.rtx, m, x, a.dec.l1full, C_MAIN_BJJ_BOOL);
     } else {
         const FeeSrcMain fs{&io, a.fee_base, a.B * a.F, b * a.F, a.fi.feePlanTokens, a.fi.imFinalAccFee, m.imAccFeeOut, a.nTx, i};
-        (void)rtx_balance_lane_dev<MainTxInOff, FeeSrcMain, false>(io, sc, a.rtx, m, x, (int)a.F, fs);
+        (void)rtx_balance_lane_dev<MainTxInOff, FeeSrcMain, false>(io, sc, a.rtx, m, [&]() __attribute__((always_inline)) { RtxExt y; decode_fields_dev(io, m, y); return y; }, (int)a.F, fs);
     }
+}
+
+// DecodeTx's sigL2Hash for RollupMain, lane = transaction: one Poseidon of width 7 over six INPUTS (decode_sig_hash_dev) -- nothing of the
+// front step feeds it and only the signature prologue reads it, so it runs at the head of the signature stream, beside the front kernel
+// instead of inside its DecodeTx lane (where its 63 registers of state sat on top of everything DecodeTx keeps alive).
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_SIGHASH_WAVES))) void k_main_sighash(const MainFrontArgs a) {
+    const Fr* K7 = poseidon_consts_w<7>();
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_units = a.B * a.nTx;
+    if (li >= (a.ucnt ? a.ucnt : n_units)) return;
+    const uint32_t u = a.u0 + li;
+    const UnitIO io{a.tx_base, n_units, u, u / a.nTx, u % a.nTx, a.err};
+    const Scratch sc{a.scratch, n_units, u};
+    sc.set(SC_SIGL2HASH, decode_sig_hash_dev(io, a.dec, a.mi, K7));
 }
 
 // RollupTx's FeeAccumulator for RollupMain, lane = transaction: needs the fee the transaction pays and its token (scratch, from the
@@ -151,12 +192,12 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
     if (blockIdx.y == 0) {   // the same three lanes as k_main_front's (tx_dev.h)
         io.put_u64(0, 1);  // main.one
         const NbRtx nb{&io, {r.futureV2, r.futureToEthAddr, r.futureToBjjAy}, {r.pastV2, r.pastToEthAddr, r.pastToBjjAy}};
-        rtx_states_lane_dev(io, sc, a.rtx, r, x, nb, true);
+        rtx_states_lane_dev(io, sc, a.rtx, r, [&]() __attribute__((always_inline)) { return x; }, nb, true);
     } else if (blockIdx.y == 1) {
         rtx_mux_lane_dev(io, sc, a.rtx, r, x, ~0u, -1);
     } else {
         const FeeSrcRtx fs{&io, r.feePlanTokens, r.accFeeIn, a.rtx.o_accFeeOut};
-        const FrontOut fo = rtx_balance_lane_dev<RtxInOff, FeeSrcRtx, true>(io, sc, a.rtx, r, x, (int)a.F, fs);
+        const FrontOut fo = rtx_balance_lane_dev<RtxInOff, FeeSrcRtx, true>(io, sc, a.rtx, r, [&]() __attribute__((always_inline)) { return x; }, (int)a.F, fs);
         io.put_m(r.o_isAmountNullified, fo.isAmountNullified);
     }
 }
@@ -167,8 +208,8 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) v
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
     io.put_u64(0, 1);
-    decode_tx_dev(io, a.dec, a.in, (int)a.L, io.in_m(a.in.previousOnChain), io.in_m(a.in.inIdx), io.in_m(a.in.globalChainID),
-                  io.in_m(a.in.currentNumBatch), K7);
+    const DecExtIn ext{&io, a.in.previousOnChain, a.in.inIdx, a.in.globalChainID, a.in.currentNumBatch};
+    (void)decode_tx_dev<true>(io, a.dec, a.in, (int)a.L, ext, K7);
 }
 
 __global__ __launch_bounds__(HZ_BLOCK) void k_rtx_back(const RtxBackArgs a) {
@@ -231,6 +272,11 @@ hipError_t launch_main_front(const MainFrontArgs& a, hipStream_t s) {
     dim3 g((nl + HZ_FRONT_BLOCK - 1) / HZ_FRONT_BLOCK);
     g.y = 4;   // DecodeTx lane, the three RollupTx-front lanes
     hipLaunchKernelGGL(k_main_front, g, dim3(HZ_FRONT_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_main_sighash(const MainFrontArgs& a, hipStream_t s) {
+    const uint32_t nl = a.ucnt ? a.ucnt : a.B * a.nTx;
+    hipLaunchKernelGGL(k_main_sighash, grid1(nl), dim3(HZ_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_main_feeacc(const MainFrontArgs& a, hipStream_t s) {

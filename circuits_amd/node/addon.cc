@@ -72,6 +72,12 @@ struct Api {
     decltype(&hz_symmap_solved) symmap_solved;
     decltype(&hz_symmap_derived) symmap_derived;
     decltype(&hz_poseidon_batch) poseidon_batch;
+    // one batch over the GPUs of a node (hz_shard_step: the collectives live in the library)
+    decltype(&hz_comm_create) comm_create;
+    decltype(&hz_comm_destroy) comm_destroy;
+    decltype(&hz_shard_step) shard_step;
+    decltype(&hz_ctx_set_shard) ctx_set_shard;
+    decltype(&hz_shard_range) shard_range;
 } api;
 
 static bool load_api(std::string& err) {
@@ -93,6 +99,7 @@ static bool load_api(std::string& err) {
     SYM(inputs_stage_range) SYM(witness_enqueue) SYM(witness_check) SYM(witness_failures) SYM(witness_total) SYM(witness_read_raw) SYM(witness_dev_ptr)
     SYM(set_inputs_json) SYM(witness_write_json) SYM(witness_write_wtns) SYM(symbols_write_sym) SYM(symmap_create) SYM(symmap_create_r1cs) SYM(symmap_check_r1cs) SYM(symmap_destroy)
     SYM(symmap_nvars) SYM(symmap_unresolved) SYM(witness_write_wtns_sym) SYM(witness_export_host) SYM(symmap_upload) SYM(symmap_solved) SYM(symmap_derived) SYM(poseidon_batch)
+    SYM(comm_create) SYM(comm_destroy) SYM(shard_step) SYM(ctx_set_shard) SYM(shard_range)
 #undef SYM
     return true;
 }
@@ -1011,6 +1018,110 @@ static napi_value Step(napi_env env, napi_callback_info info) {
     return promise;
 }
 
+// ---- one batch over the GPUs of a node: one Node process per GPU, each with a RollupMain circuit of ONE instance -------------------------
+// commCreate(transport: "rccl" | "socket", rank, world, rendezvousPath, device = 0) -> comm handle   (hz_comm_create: blocks until every rank has joined)
+// shardStep(handle, comm) -> Promise<null | failure record>: hz_shard_step on the context's own stream + hz_witness_check, on the libuv pool
+// setShard(handle, first, count, tail)   hz_ctx_set_shard for a host that drives the pieces itself (count < 0: back to the whole batch)
+// shardRange(nTx, world, rank) -> [first, count]
+struct NodeComm { hz_comm* c = nullptr; };
+static void comm_finalize(napi_env, void* data, void*) {
+    NodeComm* nc = (NodeComm*)data;
+    if (nc->c) api.comm_destroy(nc->c);
+    delete nc;
+}
+static napi_value CommCreate(napi_env env, napi_callback_info info) {
+    std::string err;
+    if (!load_api(err)) { napi_throw_error(env, nullptr, err.c_str()); return nullptr; }
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    std::string transport, path;
+    if (argc < 4 || !get_str(env, argv[0], transport) || !get_str(env, argv[3], path)) { napi_throw_error(env, nullptr, "commCreate(transport, rank, world, path, device)"); return nullptr; }
+    const int32_t kind = transport == "rccl" ? HZ_COMM_RCCL : transport == "socket" ? HZ_COMM_SOCKET : 0;
+    int32_t rank = 0, world = 1, device = 0;
+    napi_get_value_int32(env, argv[1], &rank); napi_get_value_int32(env, argv[2], &world);
+    if (argc >= 5) napi_get_value_int32(env, argv[4], &device);
+    NodeComm* nc = new NodeComm();
+    if (api.comm_create(kind, device, rank, world, path.empty() ? nullptr : path.c_str(), &nc->c) != HZ_OK) { delete nc; return throw_hz(env, "hz_comm_create"); }
+    napi_value ext;
+    if (napi_create_external(env, nc, comm_finalize, nullptr, &ext) != napi_ok) { comm_finalize(env, nc, nullptr); return nullptr; }
+    return ext;
+}
+struct ShardWork {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref keep_ctx, keep_comm;
+    hz_ctx* ctx; hz_comm* comm;
+    hz_status st;
+    hz_error err;
+    std::string msg;
+};
+static void shard_execute(napi_env, void* data) {
+    ShardWork* w = (ShardWork*)data;
+    std::lock_guard<std::mutex> one_at_a_time(ctx_mu(w->ctx));
+    memset(&w->err, 0, sizeof w->err);
+    w->st = api.shard_step(w->ctx, w->comm, nullptr);
+    if (w->st == HZ_OK) w->st = api.witness_check(w->ctx, &w->err);
+    if (w->st != HZ_OK) w->msg = api.last_error();
+}
+static void shard_complete(napi_env env, napi_status, void* data) {
+    ShardWork* w = (ShardWork*)data;
+    napi_value result;
+    if (w->st == HZ_OK) { napi_get_null(env, &result); napi_resolve_deferred(env, w->deferred, result); }
+    else if (w->st == HZ_ERR_CONSTRAINT) napi_resolve_deferred(env, w->deferred, failure_record(env, w->err));
+    else {
+        napi_value msg, e;
+        napi_create_string_utf8(env, w->msg.c_str(), NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &e);
+        napi_reject_deferred(env, w->deferred, e);
+    }
+    if (w->keep_ctx) napi_delete_reference(env, w->keep_ctx);
+    if (w->keep_comm) napi_delete_reference(env, w->keep_comm);
+    napi_delete_async_work(env, w->work);
+    delete w;
+}
+static napi_value ShardStep(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    void* p = nullptr;
+    if (!c || napi_get_value_external(env, argv[1], &p) != napi_ok || !p || !((NodeComm*)p)->c) { napi_throw_error(env, nullptr, "shardStep(circuit handle, comm)"); return nullptr; }
+    ShardWork* w = new ShardWork();
+    w->ctx = c; w->comm = ((NodeComm*)p)->c; w->st = HZ_OK; w->keep_ctx = w->keep_comm = nullptr;
+    napi_create_reference(env, argv[0], 1, &w->keep_ctx);
+    napi_create_reference(env, argv[1], 1, &w->keep_comm);
+    napi_value promise, name;
+    NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
+    NAPI_OK(napi_create_string_utf8(env, "hz_shard_step", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(napi_create_async_work(env, nullptr, name, shard_execute, shard_complete, w, &w->work));
+    NAPI_OK(napi_queue_async_work(env, w->work));
+    return promise;
+}
+static napi_value SetShard(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return nullptr;
+    hz_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    int32_t first = 0, count = -1, tail = 1;
+    napi_get_value_int32(env, argv[1], &first); napi_get_value_int32(env, argv[2], &count); napi_get_value_int32(env, argv[3], &tail);
+    if (api.ctx_set_shard(c, first, count, tail) != HZ_OK) return throw_hz(env, "hz_ctx_set_shard");
+    return nullptr;
+}
+static napi_value ShardRange(napi_env env, napi_callback_info info) {
+    std::string err;
+    if (!load_api(err)) { napi_throw_error(env, nullptr, err.c_str()); return nullptr; }
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    int32_t nTx = 0, world = 1, rank = 0, first = 0, count = 0;
+    napi_get_value_int32(env, argv[0], &nTx); napi_get_value_int32(env, argv[1], &world); napi_get_value_int32(env, argv[2], &rank);
+    api.shard_range(nTx, world, rank, &first, &count);
+    napi_value arr, v;
+    napi_create_array_with_length(env, 2, &arr);
+    napi_create_int32(env, first, &v); napi_set_element(env, arr, 0, v);
+    napi_create_int32(env, count, &v); napi_set_element(env, arr, 1, v);
+    return arr;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
     const struct { const char* name; napi_callback fn; } fns[] = {
         {"create", Create}, {"setInput", SetInput}, {"clearInputs", ClearInputs}, {"run", Run}, {"witnessLen", WitnessLen},
@@ -1019,7 +1130,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"packedLayout", PackedLayout}, {"hostAlloc", HostAlloc}, {"upload", Upload}, {"stageRange", StageRange}, {"enqueue", Enqueue},
         {"check", Check}, {"devPtr", DevPtr}, {"witnessTotal", WitnessTotal}, {"readRaw", ReadRaw}, {"setInputsJson", SetInputsJson},
         {"writeWtns", WriteWtns}, {"writeJson", WriteJson}, {"writeSym", WriteSym}, {"poseidonBatch", PoseidonBatch}, {"step", Step}, {"checkSync", CheckSync}, {"failures", Failures},
-        {"importSym", ImportSym}, {"mapInfo", MapInfo}, {"freeMap", FreeMap}, {"exportWitness", ExportWitness}, {"writeWtnsMap", WriteWtnsMap}, {"checkMap", CheckMap}};
+        {"importSym", ImportSym}, {"mapInfo", MapInfo}, {"freeMap", FreeMap}, {"exportWitness", ExportWitness}, {"writeWtnsMap", WriteWtnsMap}, {"checkMap", CheckMap},
+        {"commCreate", CommCreate}, {"shardStep", ShardStep}, {"setShard", SetShard}, {"shardRange", ShardRange}};
     for (const auto& f : fns) {
         napi_value fn;
         napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn);

@@ -244,6 +244,28 @@ class Circuit {
     async failures() {
         return (await addon.failures(this.handle)).map((f) => Object.assign({ message: constraintError(f).message }, f));
     }
+    // ---- one batch over the GPUs of a node: one Node process per GPU, each with a RollupMain circuit of one instance --------------------
+    // (the reference's counterpart: the `-n` thread-per-component mode of its compiled witness calculator, tools/helpers/actions.js:39-45)
+    /** Joins the communicator of this rank (hz_comm_create; blocks until every rank has): transport "rccl" (RCCL over xGMI, loaded by the
+     *  library with dlopen) or "socket" (the two small collectives staged through host memory over the rendezvous: no RCCL needed);
+     *  `path`: a Unix socket name every rank can reach -- rank 0 listens, the others connect. */
+    joinComm(transport, rank, world, path) { this._comm = addon.commCreate(transport, rank | 0, world | 0, path || "", this.opts.device | 0); return this._comm; }
+    /** Every rank sets the SAME inputs (the whole batch) and calls this: the rank's transaction range, the all_gather of the
+     *  data-availability records, rank 0's FeeTx / message / SHA-256 chain, the broadcast, the rank's share of the block witness, and the
+     *  check of this rank's constraints. The witness stays sharded: getSignal / readRaw serve what this rank computed. */
+    shardStep(input, sanityCheck) {
+        return this._serial(async () => {
+            if (!this._comm) throw new Error("shardStep: joinComm(transport, rank, world, path) first");
+            if (input) { addon.clearInputs(this.handle); this._setInputs(0, input); }
+            const fail = await addon.shardStep(this.handle, this._comm);
+            if (fail && wantsSanityCheck(sanityCheck)) throw constraintError(fail);
+        });
+    }
+    /** for a host that drives the pieces itself: this circuit evaluates transactions [first, first + count) only (count < 0: all again) */
+    setShard(first, count, tail) { addon.setShard(this.handle, first | 0, count | 0, tail ? 1 : 0); }
+    static shardRange(nTx, world, rank) { return addon.shardRange(nTx | 0, world | 0, rank | 0); }
+    /** one signal of instance 0 by name, straight from the device (a sharded circuit holds only its own part of the witness) */
+    readSignal(name) { return unpackFr(addon.read(this.handle, 0, this._index(name), 1), 0); }
     devPtr() { return addon.devPtr(this.handle); }
     witnessTotal() { return addon.witnessTotal(this.handle); }
     readRaw(first, count) { return addon.readRaw(this.handle, first, count); }

@@ -355,6 +355,27 @@ uint64_t hz_sha_state_bytes(const hz_ctx* ctx);
 hz_status hz_sha_export(hz_ctx* ctx, void* d_buf, void* stream);
 hz_status hz_sha_expand(hz_ctx* ctx, int32_t first, int32_t count, const void* d_buf, void* stream);
 
+/* The whole sharded pass inside the library, for a host in any language (the N-API addon binds it: circuit.shardStep). Counterpart of
+ * the `-n` thread-per-component mode of the reference's compiled witness calculator (tools/helpers/actions.js:39-45).
+ *   hz_comm_create   one per rank. transport HZ_COMM_RCCL: librccl.so is loaded with dlopen (no link-time dependency; HZ_RCCL_LIB names
+ *                    another file), rank 0's ncclGetUniqueId travels over the rendezvous, ncclCommInitRank on `device`; the collectives
+ *                    are ncclAllGather / ncclBroadcast on the pass's stream (xGMI). HZ_COMM_SOCKET: the two collectives staged through
+ *                    host memory over the rendezvous itself (47-330 KB + 73 KB per pass: latency-sized) -- for boxes without RCCL and for
+ *                    tests. rendezvous_path: a Unix socket name every rank of the node can reach (rank 0 listens on it, the others
+ *                    connect, HZ_COMM_TIMEOUT_S seconds of patience, default 120); may be NULL when world == 1.
+ *   hz_shard_step    one pass on `stream` (NULL: the context's own): this rank's transactions, all_gather of the data-availability records, rank 0's
+ *                    imports + FeeTx + message + SHA-256 chain, broadcast of the block states, this rank's share of the block
+ *                    witness. The first call shards the context (hz_ctx_set_shard with hz_shard_range(nTx, world, rank)) and
+ *                    allocates the exchange buffers; every rank calls hz_witness_check afterwards. A communicator serves one context. */
+typedef struct hz_comm hz_comm;
+enum { HZ_COMM_RCCL = 1, HZ_COMM_SOCKET = 2 };
+hz_status hz_comm_create(int32_t transport, int32_t device, int32_t rank, int32_t world, const char* rendezvous_path, hz_comm** out);
+void hz_comm_destroy(hz_comm* comm);
+int32_t hz_comm_rank(const hz_comm* comm);
+int32_t hz_comm_world(const hz_comm* comm);
+hz_status hz_shard_step(hz_ctx* ctx, hz_comm* comm, void* stream);
+int32_t hz_ctx_ntx(const hz_ctx* ctx);   /* transactions per batch of a RollupMain context (0 otherwise) */
+
 #ifdef __cplusplus
 }
 #endif

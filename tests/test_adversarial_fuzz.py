@@ -67,7 +67,7 @@ def _fuzz(hz, template, shape, gen, n_total, chunk, ctx_kw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("template,shape,n_total,chunk", [
-    ("smt-processor", (0, 33, 0, 0), 10240, 10240),
+    ("smt-processor", (0, 33, 0, 0), 6144, 6144),
     ("smt-processor", (0, 33, 0, 0), 4096, 2048),    # contexts small enough for the latency form of the chain kernel (ctx.hip hz_ctx_create: its default here)
     ("smt-verifier", (0, 33, 0, 0), 10240, 10240),
     # (two chunks through ONE context each: the second step meets the first one's buffer -- constant marks, persistent scratch;

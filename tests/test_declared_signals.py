@@ -339,15 +339,34 @@ def test_hip_complete_rollup_main(hz):
     o.set_inputs(inp)
     assert o.run() is None
     vals = o.read(0, o.witness_len())
-    known = {}
-    for n in DF.all_names(m):
-        try:
-            known[n] = vals[o.lookup(n)]
-        except KeyError:
-            pass
-    val, unknown = DF.solve_with_hashes(m, known, lambda xs: B.host().poseidon(xs))
-    assert not unknown
     order = DF.all_names(m)
+    # every variable as it follows from the oracle's witness: solved at build time for exactly these inputs (__graft_entry__.
+    # solve_complete_system: 45 s of Python that does not need the GPU), checked here against the oracle's stored signals; solved here
+    # when the shipped values belong to other inputs
+    val = None
+    cache = path.replace(".json.gz", ".val.json.gz")
+    if full and os.path.exists(cache):
+        import gzip
+        import hashlib
+        import json
+        c = json.loads(gzip.open(cache).read())
+        if c["input_digest"] == hashlib.sha256(json.dumps(inp, sort_keys=True, default=str).encode()).hexdigest() and c["n"] == len(order):
+            val = {n: int(v, 16) for n, v in zip(order, c["vals"])}
+            for n in order[::7]:
+                try:
+                    assert val[n] == vals[o.lookup(n)], n
+                except KeyError:
+                    pass
+    if val is None:
+        known = {}
+        for n in order:
+            try:
+                known[n] = vals[o.lookup(n)]
+            except KeyError:
+                pass
+        val, unknown = DF.solve_with_hashes(m, known, lambda xs: B.host().poseidon(xs))
+        assert not unknown
+    order = list(order)
     random.Random(0xC0).shuffle(order)
     sym, r1cs, names = DF.sym_and_r1cs(m, order)
     mp = g.import_sym(sym, r1cs)

@@ -196,7 +196,7 @@ def _constraint_checked_names(stored):
     return checks
 
 
-CASES = [("hash-state", {}, None), ("rollup-tx", dict(nLevels=8, maxFeeTx=16), "rtx"), ("rollup-main", dict(nTx=8, nLevels=16, maxL1Tx=3, maxFeeTx=4), "main"),
+CASES = [("hash-state", {}, None), ("rollup-tx", dict(nLevels=8, maxFeeTx=16), "rtx"), ("rollup-main", dict(nTx=4, nLevels=16, maxL1Tx=2, maxFeeTx=2), "main"),
          ("fee-tx", dict(nLevels=16), "fee"), ("decode-tx", dict(nLevels=16), "dec")]
 
 
@@ -209,8 +209,8 @@ def _inputs(kind):
     if kind == "rtx":
         _, bbs = scenarios.config2_batch()
         return bbs[1].get_single_tx_input(1)[0]   # the signed L2 transfer
-    if kind == "main":
-        return B.synthetic_batch(8, 16, 3, 4, n_accounts=6, exits=2).get_input()
+    if kind == "main":   # (the shape of CASES: four transactions carry every kind of line a larger batch repeats)
+        return B.synthetic_batch(4, 16, 2, 2, n_accounts=6, exits=1).get_input()
     if kind == "fee":
         return scenarios.fee_tx_cases(16)[1][0]
     bb = B.synthetic_batch(8, 16, 3, 4, n_accounts=6, exits=2)

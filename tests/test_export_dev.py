@@ -204,7 +204,7 @@ def test_headline_shape_exported_in_variable_order(hz, config4):
         t0 = time.time()
         tab = mp.upload()
         t_plan = time.time() - t0
-        for inst in (0, 1):
+        for inst in ((0, 1) if name == "component-major" else (1,)):   # (both instances in the order a compile resembles, the second in the permutation)
             out.zero_()
             torch.cuda.synchronize()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -66,3 +66,17 @@ def test_node_facade_writes_the_wtns_of_an_unreduced_compile(tmp_path):
     assert r.returncode == 0 and "wtns_r1cs: ok" in r.stdout, r.stdout + r.stderr
     got = _parse_wtns(files["out.wtns"])
     assert got[0] == 1 and got[1:] == [val[n] for n in names]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["socket", "rccl"])
+def test_node_sharded_batch_with_the_collectives_in_the_library(transport):
+    """tests/node/shard_two.js: one RollupMain batch over two Node processes, hz_shard_step's all_gather and broadcast staged over a Unix
+    socket (two ranks on this one GPU) -- and the same pass through RCCL loaded with dlopen, one rank (RCCL refuses two ranks on one
+    device; the calls on the pass's stream are the ones eight ranks make). Reference: tools/helpers/actions.js:39-45."""
+    if shutil.which("node") is None:
+        pytest.skip("node is not installed")
+    r = subprocess.run(["node", os.path.join(ROOT, "tests", "node", "shard_two.js"), FX, transport], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rank 0: ok" in r.stdout, r.stdout + r.stderr
+    if transport == "socket":
+        assert "rank 1: ok" in r.stdout

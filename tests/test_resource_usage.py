@@ -13,8 +13,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import resource_usage as RU   # noqa: E402
 
 # bytes of scratch per lane each timed kernel may use (the state when the budget was last lowered; lower it when a kernel improves)
-BUDGET = {"hz::k_smt<false>": 0, "hz::k_smt<true>": 0, "hz::k_hash4": 0, "hz::k_main_front": 7952, "hz::k_eddsa_pre": 2400, "hz::k_eddsa_seg<4>": 1664, "hz::k_eddsa_fix<8>": 3968,
-          "hz::k_rtx_back": 192, "hz::k_sha_expand": 272, "hz::k_sha_chain": 272, "hz::k_withdraw": 2048, "hz::k_withdraw_sha": 448,
+BUDGET = {"hz::k_smt<false>": 0, "hz::k_smt<true>": 0, "hz::k_hash4": 0, "hz::k_main_feeacc": 0,
+          "hz::k_main_front": 480,      # (7 776 until round 6: three lanes per transaction, loaders instead of held values; tx_dev.h)
+          "hz::k_main_sighash": 256,    # one Poseidon of width 7 at two wavefronts per SIMD
+          "hz::k_withdraw": 336,        # (2 016: the IsZero run in a rotating register window)
+          "hz::k_eddsa_pre": 2400, "hz::k_eddsa_seg<4>": 1664, "hz::k_eddsa_fix<8>": 3968,
+          "hz::k_rtx_back": 192, "hz::k_sha_expand": 272, "hz::k_sha_chain": 272, "hz::k_withdraw_sha": 448,
           "hz::poseidon_batch_kernel<3, true>": 0, "hz::poseidon_batch_kernel<5, true>": 0, "hzexp::k_export_stored": 0}
 
 

@@ -16,7 +16,7 @@ what=${1:-suite}; shift
 fields='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d.get("value_deep_state"), d.get("value_e2e"), d.get("value_node"), d.get("export_ms_per_batch"), d.get("value_export"), d["roofline"]["frac"], d["roofline"].get("frac_valu"), d["kernels_ms"])'
 case $what in
 suite)
-  ( time timeout 2300 python -m pytest tests -m gpu -x -q --durations=5 ) 2>&1 | tail -14
+  ( time timeout 2300 python -m pytest tests -m gpu -x -q --durations=10 ) 2>&1 | tail -14
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 ;;
 iter)
   K="$1"; shift
