@@ -1121,7 +1121,10 @@ def main():
                 "state_build_s": round(t_base, 1), "batch_build_s": round(t_deep, 1),
                 "note": "same step, same shape; the pre-populated state (builder.DenseState, hashed on the device) is shared by the batches, "
                         "each of which has its own L1 keys, transactions and signatures"}
-    del ctxs, c
+    R.cs = RD = None   # (the rotation objects hold the contexts: they must go before the sweep allocates its own)
+    del ctxs, c, R
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     # SURVEY 8(d) "occupancy caveat": a single 2048-transaction batch is 32 wavefronts per per-transaction kernel on a 1024-SIMD device.
     # (i) the latency of ONE batch alone, with and without HZ_FLAG_LATENCY (CU-masked chains); (ii) throughput against batches per launch,
@@ -1169,7 +1172,8 @@ def main():
                     for name, ms, _by, _units in cs[0].profile():
                         kernels[name] = round(kernels.get(name, 0.0) + ms / 2, 3)
                 cs[0].set_profiling(False)
-            del cs
+            RS.cs = None
+            del cs, RS
             return t / steps
         single = {}
         for key, flags in (("default", 0), ("latency_flag", 2), ("latency_solo_flags", 6)):   # 6 = HZ_FLAG_LATENCY | HZ_FLAG_SOLO
@@ -1195,6 +1199,8 @@ def main():
                 # tools/experiments/latency_inflight.sh, profiles/r05_latency_regime.txt -- but sixteen CU-masked queues beside this
                 # process's own exceed the hardware queues of the device and the scheduler then time-slices them: not run here)
                 sweep[-1]["latency_flag_x2"] = flagged_point(bp, 2)
+                if bp <= 2:   # four in flight: the library's cap on partitioned contexts since round 6 (csrc/ctx.hip HZ_MAX_PARTITIONED)
+                    sweep[-1]["latency_flag_x4"] = flagged_point(bp, 4)
         sweep.append({"batches_per_launch": Bp, "contexts": inflight, "ms_per_step": round(dt / args.steps * 1e3, 3), "tx_per_s": round(nTx * Bp * args.steps / dt, 1)})
         for i, pt in enumerate(sweep):
             # doubling the batches of a launch: a step that barely gets longer is waiting on dependent chains (latency); one that

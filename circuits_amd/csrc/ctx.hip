@@ -3,6 +3,7 @@
 // include/hermez_witness.h (the calls that replace circom's tester()/calculateWitness()/assertOut(),
 // reference test/helpers/helpers.js:139-155).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -79,9 +80,10 @@ struct hz_ctx {
     DevBuf zm_skip;                // profiling: elements not stored by [0] the transaction launch, [1] the fee launch, [2] the early-tail launch
     bool zm_reset = false;         // hz_clear_inputs: the next enqueue clears the marks first
     hz::ExportScratch exp_scratch; // export.hip's per-context buffers (ctx_internal.h)
+    DevBuf smt_trace;              // experiments: HZ_SMT_TRACE=<file> -- per-wavefront start / end / placement of the transaction k_smt launch
     DevBuf pos3;                   // poseidon_quad.h's constants (C, M R, M R^2): the latency form of k_smt
     bool smt_lat = false;          // this context's chain launches take the latency form (hz_ctx_create)
-    hipEvent_t ev_hash4 = nullptr, ev_tail = nullptr;
+    hipEvent_t ev_hash4 = nullptr, ev_tail = nullptr, ev_sighash = nullptr;
     void release_masked();
     ~hz_ctx() {
         if (partitioned) {   // CU-masked streams go back to the process's pool (masked_stream_pool below)
@@ -94,7 +96,7 @@ struct hz_ctx {
         if (s_fix) (void)hipStreamDestroy(s_fix);
         if (s_copy) (void)hipStreamDestroy(s_copy);
         if (s_sha) (void)hipStreamDestroy(s_sha);
-        for (hipEvent_t e : {ev_hash4, ev_tail})
+        for (hipEvent_t e : {ev_hash4, ev_tail, ev_sighash})
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_staged, ev_unpacked})
             if (e) (void)hipEventDestroy(e);
@@ -184,7 +186,7 @@ struct ProfScope {
 // failed; bench.py runs those sweep points in child processes. The cure proper is kernels without scratch.
 namespace {
 #ifndef HZ_MAX_PARTITIONED
-#define HZ_MAX_PARTITIONED 2
+#define HZ_MAX_PARTITIONED 4   // (2 until round 6: with k_main_front at 7.7 KB of scratch per lane four flagged contexts in flight aborted in the runtime)
 #endif
 struct MaskedPool {
     std::mutex mu;
@@ -294,10 +296,12 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         (void)units;
         const bool want = (p->flags & HZ_FLAG_LATENCY) != 0 || getenv("HZ_FORCE_LATENCY_SCHEDULING") != nullptr;
         c->partitioned = lo.p.tmpl == T_ROLLUP_MAIN && want && hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 64;
-        // At most TWO partitioned contexts alive per device and process by default (HZ_MAX_PARTITIONED=<n> raises it): each holds four
-        // hardware queues, and with four of them in flight (sixteen queues) a process that had made plain contexts before aborted in the
-        // runtime every time it was tried (above; tests/test_witness_gpu.py first ran six at once: the same abort) -- two never did. A
-        // process that has the device to itself and creates nothing else reached 560 k tx/s with four (one batch each, 390 k with two).
+        // At most FOUR partitioned contexts alive per device and process by default (HZ_MAX_PARTITIONED=<n> changes it): each holds four
+        // hardware queues, and the scratch memory of a queue is sized by the hungriest kernel it has run. Round 5 capped this at two: with
+        // k_main_front at 7.7 KB of scratch per lane, four flagged contexts in flight (sixteen queues) aborted in the runtime in a process
+        // that had made plain contexts before. Round 6 took that kernel to 480 bytes (the largest of a flagged context's kernels is now
+        // k_eddsa_ladder<1> at 2.8 KB) and the reproducer (tools/experiments/masked_stream_churn.py 3 1: plain, 2, 4, 3 flagged contexts
+        // of the headline shape, three rounds) runs clean; tests/test_witness_gpu.py keeps it as a test, in a process of its own.
         // A context over the limit gets plain streams: the same witness, the default schedule.
         if (c->partitioned && c->device >= 0 && c->device < 16) {
             static const int cap = getenv("HZ_MAX_PARTITIONED") ? atoi(getenv("HZ_MAX_PARTITIONED")) : HZ_MAX_PARTITIONED;
@@ -343,7 +347,7 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         if (e == hipSuccess) e = make_stream(&c->s_fee, ncu * 3 / 8, ncu / 2);       // fee-transaction chain
         if (e == hipSuccess) e = make_stream(&c->s_main, ncu / 2, ncu);              // front, hash-state, SMT chains, HashInputs
         if (e == hipSuccess && lo.p.tmpl == T_ROLLUP_MAIN && !c->partitioned) e = make_stream(&c->s_sha, 0, 0);
-        for (hipEvent_t* ev : {&c->ev_hash4, &c->ev_tail})
+        for (hipEvent_t* ev : {&c->ev_hash4, &c->ev_tail, &c->ev_sighash})
             if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     }
     for (hipEvent_t* ev : {&c->ev_reset, &c->ev_front, &c->ev_ed, &c->ev_fee, &c->ev_fix, &c->ev_user_in, &c->ev_user_out, &c->ev_inputs})
@@ -370,6 +374,13 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
 extern "C" void hz_ctx_destroy(hz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->smt_trace.p && getenv("HZ_SMT_TRACE")) {   // the LAST transaction launch's trace, appended to the file (one record per context)
+        (void)hipDeviceSynchronize();
+        std::vector<uint8_t> h(c->smt_trace.bytes);
+        if (hipMemcpy(h.data(), c->smt_trace.p, h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen(getenv("HZ_SMT_TRACE"), "ab")) { const uint64_t n = h.size(); fwrite(&n, 8, 1, f); fwrite(h.data(), 1, h.size(), f); fclose(f); }
+        }
+    }
     delete c;
 }
 extern "C" uint64_t hz_witness_len(const hz_ctx* c) { return c ? c->lo.per_instance : 0; }
@@ -741,6 +752,13 @@ static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa0, const char* n
     const bool fee = sa.scratch == (Fr*)c->sc_fee.p;
     sa.zmark = (uint16_t*)(fee ? c->zm_fee.p : c->zm_tx.p);
     sa.skipped = (c->profiling && c->zm_skip.p) ? (unsigned long long*)c->zm_skip.p + (fee ? 1 : 0) : nullptr;
+    if (!fee && getenv("HZ_SMT_TRACE")) {   // tools/experiments/smt_trace.py
+        const uint32_t nl = sa.ucnt ? sa.ucnt : sa.n_units;
+        const size_t waves = (size_t)((nl + 127) / 128) * 2 * 2 * sa.n_proc;
+        if (c->smt_trace.bytes < waves * 32) { if (c->smt_trace.alloc(waves * 32) != hipSuccess) return hipErrorOutOfMemory; }
+        (void)hipMemsetAsync(c->smt_trace.p, 0, waves * 32, s);
+        sa.trace = (unsigned long long*)c->smt_trace.p;
+    }
     ProfScope ps(c, s, name, sa.n_units);
     return launch_smt(sa, s);
 }
@@ -794,9 +812,9 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
         // the signature stream waits for the front step INSIDE launch_eddsa: a RollupMain launch small enough for the split form starts
         // the point half of its prologue before that (k_eddsa_pre_a reads inputs only; ev_reset: the error buffer, the inputs' scatter)
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_reset, 0));
-        // RollupMain: DecodeTx's sigL2Hash (inputs only; read by the prologue below and by nothing else) heads the signature stream
-        if (feeacc) { ProfScope ps(c, c->s_ed, "sig_hash", n_units); HZ_HIP(launch_main_sighash(*feeacc, c->s_ed)); }
-        { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed, c->ev_front)); }
+        // (RollupMain: DecodeTx's sigL2Hash comes from k_main_sighash at the head of the fee stream -- ev_sighash; the hash half of the
+        // prologue waits for it, the point half and the ladder's head do not)
+        { ProfScope ps(c, c->s_ed, "eddsa", n_units); HZ_HIP(launch_eddsa(ea, c->s_ed, c->ev_front, feeacc ? c->ev_sighash : nullptr)); }
         HZ_HIP(hipStreamWaitEvent(c->s_ed, c->ev_fix, 0));
         { ProfScope ps(c, c->s_ed, "eddsa_final", n_units); HZ_HIP(launch_eddsa_final(ea, c->s_ed)); }
         HZ_HIP(hipEventRecord(c->ev_ed, c->s_ed));
@@ -1004,8 +1022,13 @@ static hz_status enqueue_impl(hz_ctx* c, void* stream, unsigned long long filter
             hz_status st = HZ_OK;
             const bool tail_now = !c->sharded;   // sharded contexts run the tail separately (hz_witness_enqueue_tail)
             if (c->sharded && c->sh_count == 0) break;   // an empty shard (more ranks than transactions): nothing to evaluate
+            fa.u0 = c->sh_first; fa.ucnt = c->sh_count;
+            // DecodeTx's sigL2Hash (k_main_sighash: one Poseidon of width 7 over INPUTS; read by the signature prologue's hash half only)
+            // heads the fee stream -- beside the front kernel and the prologue's point half, in front of a chain that has time to spare
+            HZ_HIP(hipStreamWaitEvent(c->s_fee, c->ev_reset, 0));
+            { ProfScope ps(c, c->s_fee, "sig_hash", (uint64_t)fa.nTx * fa.B); HZ_HIP(launch_main_sighash(fa, c->s_fee)); }
+            HZ_HIP(hipEventRecord(c->ev_sighash, c->s_fee));
             if (tail_now) {
-                HZ_HIP(hipStreamWaitEvent(c->s_fee, c->ev_reset, 0));
                 st = enqueue_fee(c, fa.fee_base, lo.sections[lo.sec_fee].n_units, true, c->s_fee);   // independent of the transactions
                 if (st != HZ_OK) return st;
                 HZ_HIP(hipEventRecord(c->ev_fee, c->s_fee));

@@ -1120,16 +1120,18 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa_final(const EddsaArgs a) {
 // wavefronts, each G times as long (latency). Few units (a single batch or a handful): the device is far from full and
 // latency is what counts; many units per launch: the integer pipe is the limit.
 template <int G>
-static hipError_t launch_eddsa_split(const EddsaArgs& a0, uint32_t n, hipStream_t s, hipEvent_t front_done) {
+static hipError_t launch_eddsa_split(const EddsaArgs& a0, uint32_t n, hipStream_t s, hipEvent_t front_done, hipEvent_t hash_done) {
     EddsaArgs a = a0;
     a.chain_in_ladder = 1;
     if (a.in_onChain != ~0u && front_done) {   // RollupMain: the point half of the prologue beside the front kernel, the hash half after it
         hipLaunchKernelGGL(k_eddsa_pre_a, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
-        const hipError_t e = hipStreamWaitEvent(s, front_done, 0);
+        hipError_t e = hipStreamWaitEvent(s, front_done, 0);
+        if (e == hipSuccess && hash_done) e = hipStreamWaitEvent(s, hash_done, 0);   // sigL2Hash (k_main_sighash, on another stream)
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_eddsa_pre_b, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
     } else {
         if (front_done) { const hipError_t e = hipStreamWaitEvent(s, front_done, 0); if (e != hipSuccess) return e; }
+        if (hash_done) { const hipError_t e = hipStreamWaitEvent(s, hash_done, 0); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(k_eddsa_pre, dim3((n + HZ_BLOCK - 1) / HZ_BLOCK), dim3(HZ_BLOCK), 0, s, a);
     }
     const uint32_t nl = (n + G - 1) / G;
@@ -1163,12 +1165,13 @@ static hipError_t launch_eddsa_fix_g(const EddsaArgs& a, uint32_t n, hipStream_t
 size_t eddsa_side_bytes(uint32_t n) {
     return n <= HZ_ED_SPLIT_MAX ? (size_t)2 * n * 147 * SD_FIELDS * 9 * sizeof(uint32_t) : 0;
 }
-hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s, hipEvent_t front_done) {
+hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s, hipEvent_t front_done, hipEvent_t hash_done) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     // a launch the device does not fill is latency bound: the two segments of every signature as independent lanes (148 / 106
     // dependent steps instead of 254), one signature per lane
-    if (n <= HZ_ED_SPLIT_MAX) return launch_eddsa_split<1>(a, n, s, front_done);
+    if (n <= HZ_ED_SPLIT_MAX) return launch_eddsa_split<1>(a, n, s, front_done, hash_done);
     if (front_done) { const hipError_t e = hipStreamWaitEvent(s, front_done, 0); if (e != hipSuccess) return e; }
+    if (hash_done) { const hipError_t e = hipStreamWaitEvent(s, hash_done, 0); if (e != hipSuccess) return e; }
     return launch_eddsa_seg<HZ_ED_G>(a, n, s);
 }
 hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {

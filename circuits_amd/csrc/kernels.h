@@ -102,6 +102,11 @@ struct SmtArgs {
     // NULL: every level is stored (HZ_NO_ZMARK, experiments).
     uint16_t* zmark;              // [2 * n_proc][n_units]
     unsigned long long* skipped;  // profiling: elements (32 B each) this launch did NOT store because of the marks; NULL: not counted
+    uint32_t chain_order;         // blockIdx.y -> chain, four bits each (0: the identity). Workgroups are dispatched in blockIdx order and a
+                                  // launch of the headline size is exactly two rounds of the device's wavefront slots: which chains
+                                  // share the first round decides how long the last one runs alone (smt_kernels.hip launch_smt)
+    unsigned long long* trace;    // experiments (HZ_SMT_TRACE): four words per wavefront of the transaction launch -- start, end (100 MHz
+                                  // wall clock), HW_ID | XCC_ID << 32, blockIdx.x | blockIdx.y << 24 | wave << 28; NULL: off
     const Fr* pos3_dense;         // the dense constants of poseidon_quad.h (C[195], M1[9], M2[9]); NULL: no latency form for this launch
     SmtProcDesc p[2];
 };
@@ -225,7 +230,7 @@ size_t pos3_dense_bytes();
 hipError_t upload_pos3_dense(Fr* dst);   // synchronous; dst holds pos3_dense_bytes()
 hipError_t launch_rtx_back(const RtxBackArgs& a, hipStream_t s);
 hipError_t launch_da_mask(const RtxBackArgs& a, hipStream_t s);   // RollupMain phase H alone (amount bits of L1L2TxData times 1 - isAmountNullified), every unit
-hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s, hipEvent_t front_done = nullptr);   // front_done: waited for where the front step's scratch is first read (NULL: the caller has ordered the stream already)         // AySign2Ax, message hash, variable-base ladder, R8 + h*8A
+hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s, hipEvent_t front_done = nullptr, hipEvent_t hash_done = nullptr);   // hash_done: SC_SIGL2HASH is written (RollupMain: k_main_sighash on the fee stream)   // front_done: waited for where the front step's scratch is first read (NULL: the caller has ordered the stream already)         // AySign2Ax, message hash, variable-base ladder, R8 + h*8A
 hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s);     // S bits / range, S*B8 (independent of the above)
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s);   // the equality of the two sides
 hipError_t launch_fee_front(const FeeFrontArgs& a, hipStream_t s);

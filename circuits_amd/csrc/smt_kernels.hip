@@ -6,6 +6,7 @@
 #define HZ_FR_INLINE 1
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include "tx_dev.h"
 #include "kernels.h"
 #include <vector>
@@ -175,8 +176,9 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(LA
     const uint32_t i = a.u0 + li * (a.ustride > 1 ? a.ustride : 1u);
     // the units another launch of this step evaluates (the last transaction of every batch: the early HashInputs chain, ctx.hip)
     if (a.skip_mod && i % a.skip_mod == a.skip_mod - 1) return;
-    const uint32_t chain = blockIdx.y, pi = chain >> 1;
+    const uint32_t chain = a.chain_order ? ((a.chain_order >> (4u * blockIdx.y)) & 15u) : blockIdx.y, pi = chain >> 1;
     const bool new_side = chain & 1;
+    const unsigned long long t_start = a.trace ? wall_clock64() : 0ull;
     const SmtProcDesc& P = a.p[pi];
     const SmtProcOff& o = P.o;
     const int n = (int)a.n_levels;
@@ -404,6 +406,13 @@ __global__ __launch_bounds__(HZ_SMT_BLOCK) __attribute__((amdgpu_waves_per_eu(LA
         const uint32_t newD = thr_wave > 0 ? (thr_wave + 1 < (uint32_t)n ? thr_wave + 1 : (uint32_t)n) : (uint32_t)n;
         *(__attribute__((address_space(1))) uint16_t*)(a.zmark + (size_t)chain * a.n_units + i) = (uint16_t)(newH | (newD << 8));
     }
+    if (a.trace && (threadIdx.x & 63u) == 0) {
+        const uint32_t w = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        unsigned long long* t = a.trace + 4ull * w;
+        t[0] = t_start; t[1] = wall_clock64();
+        t[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        t[3] = blockIdx.x | (chain << 24) | ((threadIdx.x >> 6) << 28) | ((unsigned long long)thr_wave << 32);
+    }
     if (a.skipped) {   // (profiling only) n_skipped is wave-uniform: one atomic per wavefront
         const unsigned long long lead = __ballot(qj == 0);
         if (n_skipped && lead && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)lead) - 1))
@@ -455,6 +464,8 @@ hipError_t launch_smt(const SmtArgs& a, hipStream_t s) {
     }
     dim3 g((nl + HZ_SMT_BLOCK - 1) / HZ_SMT_BLOCK);
     g.y = 2 * a.n_proc;
+    // (Which chains share the first of a headline launch's two rounds of wavefront slots -- SmtArgs::chain_order -- was measured with the
+    //  per-wavefront trace, profiles/r06_smt_wave_trace.txt: five orders, the kernel alone 16.34-16.50 ms in every one. Identity.)
     hipLaunchKernelGGL(k_smt<false>, g, dim3(HZ_SMT_BLOCK), 0, s, a);
     return hipGetLastError();
 }

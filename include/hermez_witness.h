@@ -96,10 +96,11 @@ typedef struct {
  * two signature kernels, the fee chain -- on disjoint sets of compute units through CU-masked streams: one 2048-transaction batch
  * alone 14.6 -> 9.4 ms (7.9 with HZ_FLAG_SOLO). Up to four such contexts in flight overlap (every context uses the same four masks): one batch each, 380 k
  * tx-witnesses/s with two, 560 k with four; plain contexts do not overlap in that regime (257 k). From eight batches per launch on,
- * the default (0 or HZ_FLAG_THROUGHPUT: any kernel on any CU) is faster. Every such context holds four hardware queues, and the ROCm 7 runtime has
- * aborted processes that kept four of them in flight after having made plain contexts (profiles/r05_latency_regime.txt): within one
- * process only two per device get the partition by default, further ones silently get the default schedule (same witness);
- * HZ_MAX_PARTITIONED=4 in the environment lifts that for a process that creates nothing else on the device. */
+ * the default (0 or HZ_FLAG_THROUGHPUT: any kernel on any CU) is faster. Every such context holds four hardware queues whose scratch
+ * memory the runtime sizes by their hungriest kernel: within one process FOUR contexts per device get the partition by default
+ * (HZ_MAX_PARTITIONED=<n> in the environment changes it; two until round 6, when a front kernel with 7.7 KB of scratch per lane made
+ * four of them abort in the ROCm 7 runtime: profiles/r05_latency_regime.txt), further ones silently get the default schedule
+ * (same witness). */
 #define HZ_FLAG_THROUGHPUT 1
 #define HZ_FLAG_LATENCY 2
 /* HZ_FLAG_SOLO (with HZ_FLAG_LATENCY, contexts of ONE batch: no effect on larger ones): nothing else runs on the device while this context's step

@@ -702,15 +702,31 @@ def test_latency_scheduling_flag_bit_exact(hz):
     g.enqueue(s.cuda_stream)
     g.check()
     _compare(g, o)
-    # more such contexts alive than the library partitions per device (two by default: include/hermez_witness.h; the third gets the
-    # default schedule), with and without HZ_FLAG_SOLO (4): the same witness from each. One at a time: several scratch-using contexts IN
-    # FLIGHT in a process that has run big launches before is what the ROCm 7 runtime aborts on (profiles/r05_latency_regime.txt 4).
-    more = [hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3], flags=2 | (4 if k % 2 else 0)) for k in range(2)]
+    # more such contexts alive (the library partitions four per device by default: include/hermez_witness.h; one over the cap gets the
+    # default schedule), with and without HZ_FLAG_SOLO (4): the same witness from each, one at a time (four IN FLIGHT at the headline
+    # shape: test_four_flagged_contexts_in_flight_after_plain_ones, in a process of its own)
+    more = [hz.ctx("rollup-main", nTx=shape[0], nLevels=shape[1], maxL1Tx=shape[2], maxFeeTx=shape[3], flags=2 | (4 if k % 2 else 0)) for k in range(4)]
     for c in more:
         c.set_inputs(bb.get_input())
         c.enqueue(s.cuda_stream)
         c.check()
         _compare(c, o)
+
+
+def test_four_flagged_contexts_in_flight_after_plain_ones():
+    """The sequence that aborted the process in round 5 (HSA_STATUS_ERROR_OUT_OF_RESOURCES in a queue callback: sixteen CU-masked queues
+    whose kernels took 7.7 KB of scratch per lane): plain contexts of the headline shape, then two, FOUR and three HZ_FLAG_LATENCY
+    contexts in flight, every public hash checked -- tools/experiments/masked_stream_churn.py, in a process of its own (an abort of
+    the runtime must cost this test, not the suite). The library's default cap is four such contexts since k_main_front needs 480 B."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("HZ_MAX_PARTITIONED", None)   # the library's own default
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "masked_stream_churn.py"), "1", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-600:] + r.stderr[-1200:]
+    assert "4 contexts with flags 2 ran" in r.stdout
 
 
 def test_both_forms_of_the_smt_chain_kernel_write_the_same_witness(hz, monkeypatch):

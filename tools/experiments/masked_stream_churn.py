@@ -5,7 +5,7 @@ python tools/experiments/masked_stream_churn.py [rounds] [big: 0 | 1]"""
 import os
 import sys
 
-os.environ.setdefault("HZ_MAX_PARTITIONED", "4")   # the library's default of two per device is what this script shows the reason for
+# (round 5 set HZ_MAX_PARTITIONED=4 here against the library's default of two; the default is four since round 6)
 
 import torch
 
