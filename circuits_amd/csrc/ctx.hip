@@ -656,14 +656,18 @@ extern "C" hz_status hz_inputs_stage(hz_ctx* c, int32_t instance, const void* pa
     uint8_t* slot = nullptr;
     const hz_status st = upload_common(c, "hz_inputs_stage", instance, packed, bytes, &slot);
     if (st != HZ_OK) return st;
-    if (!c->s_copy) {
-        HZ_HIP(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+    if (!c->ev_staged) {
+        // the copy stream. A partitioned context (HZ_FLAG_LATENCY) stages on its MAIN stream instead: it already holds four hardware
+        // queues, four such contexts hold sixteen -- all the runtime is given (GPU_MAX_HW_QUEUES) -- and a fifth queue each made the
+        // scheduler time-slice them (four contexts in flight: 94 ms per one-batch step instead of ~4). Its copies are small and
+        // follow the step they were issued behind.
+        if (!c->partitioned) HZ_HIP(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
         HZ_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
         HZ_HIP(hipEventCreateWithFlags(&c->ev_unpacked, hipEventDisableTiming));
-        HZ_HIP(hipEventRecord(c->ev_unpacked, c->s_copy));
+        HZ_HIP(hipEventRecord(c->ev_unpacked, c->partitioned ? c->s_main : c->s_copy));
         c->staged.assign(c->lo.n_inst, 0);
     }
-    hipStream_t s = stream ? (hipStream_t)stream : c->s_copy;
+    hipStream_t s = stream ? (hipStream_t)stream : (c->partitioned ? c->s_main : c->s_copy);
     if (c->any_staged && c->stage_stream != s)   // ev_staged is one event: a second stream's copies would not be covered by it
         return set_err(HZ_ERR_ARG, "hz_inputs_stage: all stage calls between two enqueues of a context must use the same stream");
     c->stage_stream = s;
@@ -697,7 +701,7 @@ extern "C" hz_status hz_inputs_stage_range(hz_ctx* c, int32_t first, int32_t cou
     }
     st = hz_inputs_stage(c, first, packed, bytes_each, stream);   // creates the copy stream and events on first use; instance `first`
     if (st != HZ_OK || count == 1) return st;
-    hipStream_t s = stream ? (hipStream_t)stream : c->s_copy;
+    hipStream_t s = stream ? (hipStream_t)stream : (c->partitioned ? c->s_main : c->s_copy);
     HZ_HIP(hipMemcpyAsync(slot + bytes_each, (const uint8_t*)packed + bytes_each, (size_t)(count - 1) * bytes_each, hipMemcpyDefault, s));
     HZ_HIP(hipEventRecord(c->ev_staged, s));
     for (int32_t j = 1; j < count; j++) c->staged[first + j] = 1;

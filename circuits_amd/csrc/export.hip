@@ -26,6 +26,7 @@
 // Nothing here computes a witness signal the kernels of the step did not already pin down: derived values are the linear (or
 // constant-factor) consequences the unreduced R1CS states, evaluated in the same field arithmetic as everything else (fr.h).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
@@ -580,7 +581,13 @@ static hz_status get_plan(hz_ctx* ctx, const hz_symmap* m, CtxGeom& g, DevPlan**
     return HZ_OK;
 }
 
-static unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)std::min<uint64_t>((n + block - 1) / block, 1u << 16); }
+// HZ_EXPORT_BLOCKS: workgroups per launch (experiments: a copy that runs BESIDE a step should not take every wavefront slot of the
+// device; the kernels loop over their lists whatever the grid)
+static uint64_t block_cap() {
+    static const uint64_t cap = getenv("HZ_EXPORT_BLOCKS") ? (uint64_t)std::max(1, atoi(getenv("HZ_EXPORT_BLOCKS"))) : (1u << 16);
+    return cap;
+}
+static unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)std::min<uint64_t>((n + block - 1) / block, block_cap()); }
 
 // derived values of `ninst` instances from inst0 on into P->dval
 static hz_status derive(DevPlan* P, ExportScratch* X, const CtxGeom& g, uint32_t inst0, uint32_t ninst, hipStream_t s) {
@@ -648,7 +655,7 @@ static hz_status export_chunk(DevPlan* P, ExportScratch* X, const CtxGeom& g, ui
     // blocks in proportion to the bytes each list moves, 2^16 in all at most
     const uint64_t wq = (l.nq + 255) / 256, w1 = (l.n1 + 511) / 512, wx = (l.nx + 511) / 512, wsum = wq + w1 + wx;
     if (wsum) {
-        const uint64_t cap = 1u << 16;
+        const uint64_t cap = std::max<uint64_t>(3, block_cap() == (1u << 16) ? block_cap() : block_cap() / std::max<uint32_t>(1, ninst));
         auto share = [&](uint64_t w) { return (uint32_t)(w == 0 ? 0 : wsum <= cap ? w : std::max<uint64_t>(1, w * cap / wsum)); };
         l.bq = share(wq); l.b1 = share(w1); l.bx = share(wx);
         hipLaunchKernelGGL(k_export_stored, dim3(l.bq + l.b1 + l.bx, ninst), dim3(256), 0, s, a, P->lt, l);
