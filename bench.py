@@ -165,6 +165,8 @@ def measured_traffic(kernel, bpl):
         if d is None or (bpl is not None and d.get("batches_per_launch") != bpl):
             return None, None
         k = d["kernels"][kernel]
+        if "write_bytes_median" in k:   # the steady-state launch (the first ones into a fresh buffer store what the constant marks later leave)
+            return int(k["fetch_bytes_median"] + k["write_bytes_median"]), src
         if "fetch_bytes_mean" in k:   # per launch like `achieved`: mean over the kernel's launches of the transaction grid
             return int(k["fetch_bytes_mean"] + k["write_bytes_mean"]), src
         return int(k["fetch_bytes"] + k["write_bytes"]), src
@@ -302,6 +304,21 @@ def node_host_line(args, packed_file, exp_file, Bp, inflight):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def flagged_point(bp, nctx):
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "12", "--warmup", "3", "--batches-per-launch", str(bp), "--inflight", str(nctx),
+           "--distinct-batches", "4", "--cpu-sample", "0", "--no-withdraw", "--no-e2e", "--no-poseidon", "--no-export", "--no-node", "--no-deep-state",
+           "--no-sweep", "--no-shard", "--no-verify", "--latency-scheduling"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        if r.returncode != 0 or not ln:
+            return {"contexts": nctx, "error": "child exited with %d: %s" % (r.returncode, (r.stderr or "").strip().splitlines()[-1][:200] if r.stderr else "")}
+        d = json.loads(ln[-1])
+        return {"contexts": nctx, "ms_per_step": d["ms_per_step"], "tx_per_s": d["value"], "process": "child (bench.py --batches-per-launch %d --inflight %d --latency-scheduling)" % (bp, nctx)}
+    except Exception as e:   # noqa: BLE001 -- a secondary figure must never cost the main line
+        return {"contexts": nctx, "error": "%s: %s" % (type(e).__name__, e)}
+
+
 def with_node_host(args):
     """`value_node` needs a process of its own, and needs this one to stay off the GPU: measured (round 3), a Node host started as a
     child of a Python process that still holds its HIP runtime -- idle, contexts freed, but its dozen hardware queues alive -- runs
@@ -328,6 +345,11 @@ def with_node_host(args):
                 if out.get("value_e2e"):
                     node_line["ratio_to_value_e2e"] = round(node_line["value_node"] / out["value_e2e"], 4)
             out["node_host"] = node_line
+        if out.get("batches_sweep") and not args.no_sweep:
+            # four HZ_FLAG_LATENCY contexts in flight, one / two batches each: a process of its own with the device to itself
+            for pt in out["batches_sweep"]:
+                if pt.get("batches_per_launch") in (1, 2) and "latency_flag_x2" in pt:
+                    pt["latency_flag_x4"] = flagged_point(pt["batches_per_launch"], 4)
         print(json.dumps(out))
     finally:
         shutil.rmtree(keep_dir, ignore_errors=True)
@@ -1131,21 +1153,6 @@ def main():
     # two contexts in flight, up to the headline's own point; (iii) what binds at each point.
     sweep, single = None, None
     if world == 1 and not args.no_sweep:
-        def flagged_point(bp, nctx):
-            cmd = [sys.executable, os.path.abspath(__file__), "--steps", "12", "--warmup", "3", "--batches-per-launch", str(bp), "--inflight", str(nctx),
-                   "--distinct-batches", "4", "--cpu-sample", "0", "--no-withdraw", "--no-e2e", "--no-poseidon", "--no-export", "--no-node", "--no-deep-state",
-                   "--no-sweep", "--no-shard", "--no-verify", "--latency-scheduling"]
-            try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
-                ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
-                if r.returncode != 0 or not ln:
-                    return {"contexts": nctx, "error": "child exited with %d: %s" % (r.returncode, (r.stderr or "").strip().splitlines()[-1][:200] if r.stderr else "")}
-                d = json.loads(ln[-1])
-                return {"contexts": nctx, "ms_per_step": d["ms_per_step"], "tx_per_s": d["value"], "process": "child (bench.py --batches-per-launch %d --inflight %d --latency-scheduling)" % (bp, nctx)}
-            except Exception as e:   # noqa: BLE001 -- a secondary figure must never cost the main line
-                return {"contexts": nctx, "error": "%s: %s" % (type(e).__name__, e)}
-
-
         def small(bp, nctx, flags, steps, kernels=None):
             cs = [L.ctx("rollup-main", nTx=nTx, nLevels=lv, maxL1Tx=m1, maxFeeTx=F, device=local, n_instances=bp, flags=flags) for _ in range(nctx)]
             RS = Rotation(cs, [streams[k % len(streams)] for k in range(nctx)], bp, n_distinct, pbytes, expected, pin2, dsrc)
@@ -1199,8 +1206,9 @@ def main():
                 # tools/experiments/latency_inflight.sh, profiles/r05_latency_regime.txt -- but sixteen CU-masked queues beside this
                 # process's own exceed the hardware queues of the device and the scheduler then time-slices them: not run here)
                 sweep[-1]["latency_flag_x2"] = flagged_point(bp, 2)
-                if bp <= 2:   # four in flight: the library's cap on partitioned contexts since round 6 (csrc/ctx.hip HZ_MAX_PARTITIONED)
-                    sweep[-1]["latency_flag_x4"] = flagged_point(bp, 4)
+                # (four in flight -- the library's cap on partitioned contexts since round 6 -- are sixteen CU-masked queues: beside THIS
+                #  process's own queues the scheduler time-slices them (25 k tx/s instead of 560 k), so those points are measured by the
+                #  outer process after this worker has exited: with_node_host)
         sweep.append({"batches_per_launch": Bp, "contexts": inflight, "ms_per_step": round(dt / args.steps * 1e3, 3), "tx_per_s": round(nTx * Bp * args.steps / dt, 1)})
         for i, pt in enumerate(sweep):
             # doubling the batches of a launch: a step that barely gets longer is waiting on dependent chains (latency); one that
@@ -1322,6 +1330,20 @@ def main():
             out["export"] = export
         if deep is not None:
             deep["ratio_to_value"] = round(deep["value"] / value, 4)
+        # what a hashing level costs: the two committed SQ_INSTS_VALU passes differ by the levels between the two states' leaves
+        try:
+            i_deep, i_base = float(deep["k_smt"]["insts_valu_per_launch"]), float(k_insts)
+            waves = nTx * Bp * 4 / 64.0                                   # wavefronts of the transaction launch (four chains per transaction)
+            lv_base, lv_deep = (n_acc - 1).bit_length(), deep["state_accounts"].bit_length() - 1
+            per_level = (i_deep - i_base) / (waves * (lv_deep - lv_base))
+            deep["k_smt"].update({"insts_per_hashing_level_and_wave": int(per_level), "hashing_levels": [lv_base, lv_deep],
+                                  "insts_per_wave": [int(i_base / waves), int(i_deep / waves)],
+                                  "not_level_hashes_frac": [round(1 - per_level * (lv_base + 0.9) * waves / i_base, 4), round(1 - per_level * (lv_deep + 0.9) * waves / i_deep, 4)],
+                                  "note": "per chain-wavefront: (instructions on the deep state - on the recipe's state) / (levels between their leaves); a proof "
+                                          "reaches its leaf about 0.9 levels below log2(accounts); not_level_hashes_frac = the share of a launch's instructions that is "
+                                          "NOT level hashing (key bits, SMTLevIns inversions, state machine, conversions, stores of the dead levels)"})
+        except (KeyError, TypeError, ZeroDivisionError):
+            pass
             out["value_deep_state"] = deep["value"]
             out["deep_state"] = deep
         if dt_e2e is not None:

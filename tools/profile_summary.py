@@ -104,7 +104,11 @@ if fetch or write:
                 key = "poseidon_t%s_%s" % (targ[0], "witness" if targ[1] in ("true", "1") else "digest")
             kernels[key] = {"fetch_bytes": max(fv) * 1024 * f_corr, "write_bytes": max(wv) * 1024 * w_corr,
                                                                  "fetch_bytes_mean": sum(fg) / len(fg) * 1024 * f_corr, "write_bytes_mean": sum(wg) / len(wg) * 1024 * w_corr,
-                                                                 "largest_grid_dispatches": max(len(fg), len(wg))}
+                                                                 "largest_grid_dispatches": max(len(fg), len(wg)),
+                                                                 # the first launches into a fresh buffer store everything; the rest what the
+                                                                 # constant marks leave: the MEDIAN is the steady-state launch
+                                                                 "fetch_bytes_median": sorted(fg)[len(fg) // 2] * 1024 * f_corr if fg else 0.0,
+                                                                 "write_bytes_median": sorted(wg)[len(wg) // 2] * 1024 * w_corr if wg else 0.0}
     bpl = 32
     for tok in cmd.split():
         pass
