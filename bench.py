@@ -1330,20 +1330,20 @@ def main():
             out["export"] = export
         if deep is not None:
             deep["ratio_to_value"] = round(deep["value"] / value, 4)
-        # what a hashing level costs: the two committed SQ_INSTS_VALU passes differ by the levels between the two states' leaves
-        try:
-            i_deep, i_base = float(deep["k_smt"]["insts_valu_per_launch"]), float(k_insts)
-            waves = nTx * Bp * 4 / 64.0                                   # wavefronts of the transaction launch (four chains per transaction)
-            lv_base, lv_deep = (n_acc - 1).bit_length(), deep["state_accounts"].bit_length() - 1
-            per_level = (i_deep - i_base) / (waves * (lv_deep - lv_base))
-            deep["k_smt"].update({"insts_per_hashing_level_and_wave": int(per_level), "hashing_levels": [lv_base, lv_deep],
-                                  "insts_per_wave": [int(i_base / waves), int(i_deep / waves)],
-                                  "not_level_hashes_frac": [round(1 - per_level * (lv_base + 0.9) * waves / i_base, 4), round(1 - per_level * (lv_deep + 0.9) * waves / i_deep, 4)],
-                                  "note": "per chain-wavefront: (instructions on the deep state - on the recipe's state) / (levels between their leaves); a proof "
-                                          "reaches its leaf about 0.9 levels below log2(accounts); not_level_hashes_frac = the share of a launch's instructions that is "
-                                          "NOT level hashing (key bits, SMTLevIns inversions, state machine, conversions, stores of the dead levels)"})
-        except (KeyError, TypeError, ZeroDivisionError):
-            pass
+            # what a hashing level costs: the two committed SQ_INSTS_VALU passes differ by the levels between the two states' leaves
+            try:
+                i_deep, i_base = float(deep["k_smt"]["insts_valu_per_launch"]), float(k_insts)
+                waves = nTx * Bp * 4 / 64.0                                   # wavefronts of the transaction launch (four chains per transaction)
+                lv_base, lv_deep = (n_acc - 1).bit_length(), deep["state_accounts"].bit_length() - 1
+                per_level = (i_deep - i_base) / (waves * (lv_deep - lv_base))
+                deep["k_smt"].update({"insts_per_hashing_level_and_wave": int(per_level), "hashing_levels": [lv_base, lv_deep],
+                                      "insts_per_wave": [int(i_base / waves), int(i_deep / waves)],
+                                      "not_level_hashes_frac": [round(1 - per_level * (lv_base + 0.9) * waves / i_base, 4), round(1 - per_level * (lv_deep + 0.9) * waves / i_deep, 4)],
+                                      "note": "per chain-wavefront: (instructions on the deep state - on the recipe's state) / (levels between their leaves); a proof "
+                                              "reaches its leaf about 0.9 levels below log2(accounts); not_level_hashes_frac = the share of a launch's instructions that is "
+                                              "NOT level hashing (key bits, SMTLevIns inversions, state machine, conversions, stores of the dead levels)"})
+            except (KeyError, TypeError, ZeroDivisionError):
+                pass
             out["value_deep_state"] = deep["value"]
             out["deep_state"] = deep
         if dt_e2e is not None:
