@@ -105,16 +105,15 @@ def _compare_replicated(g, o, n_gpu, n_dist, which, rows_per_chunk=256):
                 r0 + r, k, which[k], int.from_bytes(a[r, k].tobytes(), "little"), int.from_bytes(b[r, k].tobytes(), "little")))
 
 
-@pytest.mark.parametrize("L,F,N", [(32, 64, 16384 + 67)])   # (a (16, 4) case ran here too: same kernels, same forms, 19 s of a ten-minute suite)
+@pytest.mark.parametrize("L,F,N", [(16, 4, 16384 + 67)])   # (32, 64) ran here too: same kernels and forms, 29 s of a ten-minute suite; that shape
+# runs the throughput forms whole in test_headline_launch_whole_buffer
 def test_throughput_signature_kernels_bit_exact(hz, L, F, N):
     """Launches of more than 16 384 transactions take the THROUGHPUT form of the signature check -- k_eddsa_pre + k_eddsa_seg<4> (lane =
     segment x four signatures in lockstep, their state parked in LDS between turns, one shared inversion per ladder step) and
     k_eddsa_fix<8> -- which is what bench.py measures; every other GPU test stays below that size and runs the split form. 16 451
     RollupTx instances (not a multiple of four or eight: lanes with a padding slot that repeats their first unit), drawn from 40
     different transactions (L1
-    creates, signed L2 transfers, exits) that the oracle evaluates once each; the whole physical buffer is compared: up to 23.6 GB
-    at the benchmark's own (nLevels, maxFeeTx) = (32, 64), where k_smt's 33-level chains and their empty-level blocks run at this unit
-    count too. reference src/rollup-tx.circom:445-482,537-570, circomlib eddsaposeidon.circom."""
+    creates, signed L2 transfers, exits) that the oracle evaluates once each; the whole physical buffer is compared. reference src/rollup-tx.circom:445-482,537-570, circomlib eddsaposeidon.circom."""
     from circuits_amd import builder as B
     bb = B.synthetic_batch(40, L, 6, F, n_accounts=12, exits=3, seed=4242)
     D = bb.nTx
@@ -252,7 +251,7 @@ def test_withdraw_config5_at_size(hz):
     host_fx = B.ExitTreeFixture(64)   # the device-hashed tree construction agrees with host hashing
     dev_fx = B.ExitTreeFixture(64, device=0)
     assert host_fx.exit_tree.root == dev_fx.exit_tree.root
-    n = 2090   # (32 full wavefronts and a ragged one; 4 160 until round 6 -- the 2^20 test below compares 2 080 more instances whole)
+    n = 2090   # (32 full wavefronts and a ragged one; 4 160 until round 6 -- the 2^20 test below compares 1 040 more instances whole)
     idxs = sorted(fx.exit_leaves)
     g = hz.ctx("withdraw", nLevels=32, n_instances=n)
     o = OracleCtx("withdraw", nLevels=32, n_instances=n)
@@ -280,11 +279,11 @@ def test_withdraw_config5_two_to_the_twenty(hz):
     """BASELINE config 5 at its LITERAL count: 2^20 Withdraw(32) witnesses in 16 launches of 2^16 instances, every instance of a launch a
     different leaf of an exit tree of 2^16 leaves (the line bench.py reports as `withdraw`), the assignment of leaves to instances
     different in every launch. Every instance's public hash is compared with the builder's hashlib value in every launch and no
-    constraint fails; in every second launch a seeded sample of 260 instances -- 2 080 over the run -- is compared WHOLE with the
+    constraint fails; in every second launch a seeded sample of 130 instances -- 1 040 over the run -- is compared WHOLE with the
     oracle's witness of the same inputs (reference src/withdraw.circom:21-176)."""
     import random
     from circuits_amd import builder as B
-    n, launches, per = 1 << 16, 16, 260
+    n, launches, per = 1 << 16, 16, 130
     fx = B.ExitTreeFixture(1 << 16, device=0)
     idxs = sorted(fx.exit_leaves)
     assert len(idxs) == n
