@@ -1280,6 +1280,7 @@ def main():
                                           "hashes": builder_stats["jobs"], "dag_segments": builder_stats["segments"], "device_ms": round(builder_stats["device_ms"], 1),
                                           "walk_and_sign_s": round(builder_stats["walk_s"], 2), "evaluator_s": round(builder_stats["eval_s"], 2),
                                           "state_s": round(builder_stats["state_s"], 2), "batch_s": round(builder_stats["batch_s"], 2),
+                                          "phases_ms_per_batch": {k: round(1e3 * v / max(1, len(all_seeds)), 2) for k, v in builder_stats.get("phases_s", {}).items()},
                                           "recipe": "native (hzb_batch_add_synthetic: the reference generator's recipe inside libhz_host.so)",
                                           "ms_per_batch": round(1e3 * builder_stats["batch_s"] / max(1, len(all_seeds)), 1),
                                           "sign_ms_per_batch": round(1e3 * builder_stats["sign_s"] / max(1, len(all_seeds)), 1),

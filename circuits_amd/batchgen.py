@@ -59,15 +59,21 @@ def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accoun
     # add_tx to the packed inputs (Python transaction recipe + hzb_batch_build: walk, signing, hashing, packing)
     res, stats = [], {"jobs": 0, "segments": 0, "device_ms": 0.0, "walk_s": 0.0, "eval_s": 0.0, "sign_s": 0.0, "state_s": 0.0, "batch_s": 0.0}
 
+    phases = stats["phases_s"] = {}
+
     def finish(bb):
         t = time.perf_counter()
         _, hgi = bb.build_finish()
+        t1 = time.perf_counter()
         for k, v in bb.stats().items():
             stats[k] += v
         res.append((None, hgi, n_tx - min(max_l1, n_tx)))
         bb.close()
         bb._db_keep.close()
-        stats["batch_s"] += time.perf_counter() - t
+        t2 = time.perf_counter()
+        phases["build_finish"] = phases.get("build_finish", 0.0) + t1 - t
+        phases["close"] = phases.get("close", 0.0) + t2 - t1
+        stats["batch_s"] += t2 - t
 
     # two batches in flight (hzb_batch_build_begin / _finish): the device evaluates batch i's Merkle hashes while the host walks batch i + 1
     live = None
@@ -76,7 +82,7 @@ def build_packed_batches_native(seeds, n_tx, n_levels, max_l1, max_fee, n_accoun
         b = base if base is not None else B.DenseState.build(n_accounts.bit_length() - 1, seed=seed, hash_rows=hash_rows)
         t1 = time.perf_counter()
         bb = NB.synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, tables, seed=seed, device=device, base=b, out=out_addr + i * layout[0],
-                                       native_recipe=native_recipe, begin_only=pipelined)
+                                       native_recipe=native_recipe, begin_only=pipelined, phases=phases)
         stats["state_s"] += t1 - t0
         stats["batch_s"] += time.perf_counter() - t1
         if not pipelined:

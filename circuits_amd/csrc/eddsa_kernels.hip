@@ -28,6 +28,23 @@ namespace hz {
 #undef HZ_CONST_ARR
 
 struct PtA { Fr x, y; };
+// The helpers below (point conversions, BabyAdd, the segment heads and tails, the prologue) were separate functions until round 6: a
+// call passes its structs BY REFERENCE (more than 16 dwords of aggregates never travel in registers), so every caller kept the curve
+// constants, the witness cursor, the kernel's argument block and each point in private memory -- 1.6 KB per lane in k_eddsa_seg<4>, none
+// of it inside the ladder loop. Inlined, those objects are registers.
+#ifndef HZ_ED_CALL
+#define HZ_ED_CALL __forceinline__
+#endif
+// two inverses with one inversion, zeros stay zero: batch_inv<2> without its arrays (a loop over two field products does not unroll)
+__device__ __forceinline__ void inv_pair(Fr& a, Fr& b) {
+    const bool za = fr_is_zero(a), zb = fr_is_zero(b);
+    const Fr one = fr_one();
+    const Fr a1 = fr_select(za, one, a), b1 = fr_select(zb, one, b);   // (limb selects: `c ? x : y` on two structs selects an ADDRESS)
+    const Fr inv = fr_inv(fr_mul(a1, b1));
+    const Fr ia = fr_mul(inv, b1), ib = fr_mul(inv, a1);
+    a = fr_select(za, a, ia);
+    b = fr_select(zb, b, ib);
+}
 
 __device__ __forceinline__ Fr ld_const(const uint32_t* p) {
     Fr r;
@@ -91,16 +108,28 @@ struct EdK {
     Fr a, d, A, one;
     __device__ __forceinline__ EdCtx with(const UnitIO& io) const { return EdCtx{io, a, d, A, one}; }
 };
+// 168700, 168696, 168698 in Montgomery form as literals (c * 2^261 mod p): a constant the compiler can re-materialise costs no register
+// across the ladder and no spill slot; fr_from_u64 computed them with a product per kernel and kept 27 registers alive
+__device__ __forceinline__ EdK ed_k() {
+    constexpr uint32_t ka[9] = {0x1e4c3bf6u, 0x1632a3c4u, 0x0f025983u, 0x1533bdfbu, 0x1e960fcfu, 0x1e77617fu, 0x136b897du, 0x18c1d173u, 0x0002d053u};
+    constexpr uint32_t kd[9] = {0x1e4c3e9cu, 0x19b5d231u, 0x170a87f5u, 0x0793a2bdu, 0x1f019767u, 0x0f24dfc7u, 0x0d641be0u, 0x00ceff39u, 0x002c7818u};
+    constexpr uint32_t kA[9] = {0x0e4c3d49u, 0x17f43afbu, 0x130670bcu, 0x0e63b05cu, 0x1ecbd39bu, 0x06ce20a3u, 0x1067d2afu, 0x1cc86856u, 0x0017a435u};
+    EdK K;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { K.a.v[i] = ka[i]; K.d.v[i] = kd[i]; K.A.v[i] = kA[i]; }
+    K.one = fr_one();
+    return K;
+}
 
 // BabyAdd: stores beta,gamma,delta,tau,xout,yout; checks the two division constraints
-__device__ __noinline__ PtA baby_add_dev(const EdCtx& c, BabyAddOff off, const PtA& p, const PtA& q) {
+__device__ HZ_ED_CALL PtA baby_add_dev(const EdCtx& c, BabyAddOff off, const PtA& p, const PtA& q) {
     const Fr beta = fr_mul(p.x, q.y), gamma = fr_mul(p.y, q.x);
     const Fr delta = fr_mul(fr_sub(p.y, fr_mul(c.a, p.x)), fr_add(q.x, q.y));
     const Fr tau = fr_mul(beta, gamma);
     const Fr dt = fr_mul(c.d, tau);
     Fr den[2] = {fr_add(c.one, dt), fr_sub(c.one, dt)};
     Fr inv[2] = {den[0], den[1]};
-    batch_inv<2>(inv, 2);
+    inv_pair(inv[0], inv[1]);
     const Fr numx = fr_add(beta, gamma), numy = fr_sub(fr_add(delta, fr_mul(c.a, beta)), gamma);
     PtA r;
     r.x = fr_mul(numx, inv[0]);
@@ -112,7 +141,7 @@ __device__ __noinline__ PtA baby_add_dev(const EdCtx& c, BabyAddOff off, const P
     return r;
 }
 struct MDbl { Fr x1_2, lamda; PtA out; };
-__device__ __noinline__ MDbl mont_dbl_dev(const EdCtx& c, const PtA& p) {
+__device__ HZ_ED_CALL MDbl mont_dbl_dev(const EdCtx& c, const PtA& p) {
     MDbl r;
     r.x1_2 = fr_sqr(p.x);
     const Fr num = fr_add(fr_add(fr_add(fr_dbl(r.x1_2), r.x1_2), fr_mul(fr_dbl(c.A), p.x)), c.one);
@@ -123,10 +152,10 @@ __device__ __noinline__ MDbl mont_dbl_dev(const EdCtx& c, const PtA& p) {
     r.out.y = fr_sub(fr_mul(r.lamda, fr_sub(p.x, r.out.x)), p.y);
     return r;
 }
-__device__ __noinline__ PtA e2m_dev(const EdCtx& c, const PtA& p) {
+__device__ HZ_ED_CALL PtA e2m_dev(const EdCtx& c, const PtA& p) {
     Fr den[2] = {fr_sub(c.one, p.y), p.x};
     Fr inv[2] = {den[0], den[1]};
-    batch_inv<2>(inv, 2);
+    inv_pair(inv[0], inv[1]);
     PtA o;
     o.x = fr_mul(fr_add(c.one, p.y), inv[0]);
     o.y = fr_mul(o.x, inv[1]);
@@ -134,10 +163,10 @@ __device__ __noinline__ PtA e2m_dev(const EdCtx& c, const PtA& p) {
     if (fr_is_zero(den[1])) c.io.chk(C_RTX_SIG_EC, fr_zero(), o.x);
     return o;
 }
-__device__ __noinline__ PtA m2e_dev(const EdCtx& c, const PtA& p) {
+__device__ HZ_ED_CALL PtA m2e_dev(const EdCtx& c, const PtA& p) {
     Fr den[2] = {p.y, fr_add(p.x, c.one)};
     Fr inv[2] = {den[0], den[1]};
-    batch_inv<2>(inv, 2);
+    inv_pair(inv[0], inv[1]);
     PtA o;
     o.x = fr_mul(p.x, inv[0]);
     o.y = fr_mul(fr_sub(p.x, c.one), inv[1]);
@@ -177,7 +206,7 @@ __device__ __forceinline__ Fr fr_limbs_u64(uint64_t x) {   // small integer in s
     return r;
 }
 template <int G>
-__device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl) {
+__device__ HZ_ED_CALL void seg_any_lock(const EdK& K, const UnitIO* io, const SegAnyOff& o, const Fc* e, int e0, int n, PtA* p, PtA* dbl) {
     Fr dx0[G], dx1[G], dy0[G];   // doubler output D_{i+1}: x in scales 0 and 1, y in scale 0
     PtA addIn[G];                // the accumulator, scale 0, canonical
     Fr nx1_2[G], d_num[G];       // scale 0
@@ -217,7 +246,8 @@ __device__ __noinline__ void seg_any_lock(const EdK& K, const UnitIO* io, const 
             if (fr_is_zero(a_den)) zmask |= 1u << (2 * g);
             if (more && fr_is_zero(dd)) zmask |= 1u << (2 * g + 1);
         }
-        batch_inv<2 * G>(inv, 2 * G);   // scale-0 divisors in, scale-2 inverses out
+        if constexpr (G == 1) inv_pair(inv[0], inv[1]);   // scale-0 divisors in, scale-2 inverses out
+        else batch_inv<2 * G>(inv, 2 * G);
 #pragma unroll 1
         for (int g = 0; g < G; g++) {
             const UnitIO& w = io[g];
@@ -317,7 +347,7 @@ __device__ __forceinline__ void ls_hput(const LaneLds& L, int h0, int g, const F
 
 // start of a segment for signature g: e2m, doubler_0 (as the head of seg_any_lock)
 template <int G>
-__device__ __noinline__ void seg_lds_init(const EdK& K, const UnitIO& io, const SegAnyOff& o, const PtA& p, const LaneLds& L, int g) {
+__device__ HZ_ED_CALL void seg_lds_init(const EdK& K, const UnitIO& io, const SegAnyOff& o, const PtA& p, const LaneLds& L, int g) {
     constexpr int LS_PER_G = ls_per_g<G>();
     const EdCtx c = K.with(io);
     const PtA m = e2m_dev(c, p);
@@ -423,7 +453,7 @@ __device__ __forceinline__ void seg_lds_steps(const EdK& K, const MkIo& mk_io, c
 // end of a segment for signature g (the tail of seg_any_lock): p = the segment's start point (Edwards); returns its output and
 // the last doubler output (Montgomery form)
 template <int G>
-__device__ __noinline__ PtA seg_lds_fin(const EdK& K, const UnitIO& io, const SegAnyOff& o, uint32_t bit0, const PtA& p, const LaneLds& L, int g, PtA* dbl) {
+__device__ HZ_ED_CALL PtA seg_lds_fin(const EdK& K, const UnitIO& io, const SegAnyOff& o, uint32_t bit0, const PtA& p, const LaneLds& L, int g, PtA* dbl) {
     const EdCtx c = K.with(io);
     const int s0 = g * ls_per_g<G>();
     dbl->x = L.get(s0 + LS_DX1);
@@ -475,7 +505,7 @@ struct SideBuf {
 };
 
 
-__device__ __noinline__ void seg_any_proj(const EdK& K, const UnitIO& io, const SegAnyOff& o, const Fc& e, int e0, int n, PtA* p, PtA* dbl, const SideBuf& sd) {
+__device__ HZ_ED_CALL void seg_any_proj(const EdK& K, const UnitIO& io, const SegAnyOff& o, const Fc& e, int e0, int n, PtA* p, PtA* dbl, const SideBuf& sd) {
     const EdCtx c = K.with(io);
     const int steps = n - 1;
     const PtA m = e2m_dev(c, *p);
@@ -582,7 +612,7 @@ __device__ __forceinline__ uint32_t fix_window_bits(const Fc& e, int e0, int nbi
     return k;
 }
 template <int G>
-__device__ __noinline__ void seg_fix_lock(const EdK& K, const UnitIO* io, const SegFixOff& o, const Fc* e, int e0, int nbits, int win0, int seg, PtA* out) {
+__device__ HZ_ED_CALL void seg_fix_lock(const EdK& K, const UnitIO* io, const SegFixOff& o, const Fc* e, int e0, int nbits, int win0, int seg, PtA* out) {
     // the chain in scale 0 (see seg_any_lock): window points from the plain table, one reduction per window (lamda) instead of five
     PtA acc[G];
     const Fr A0 = fr_limbs_u64(168698);
@@ -683,7 +713,7 @@ __device__ __forceinline__ Fr ed_prologue_point(const EdK& K, const UnitIO& io, 
     // isZero.in <== dbl3.x (the input x of the third doubling) ; zeropoint.in <== dbl3.xout
     Fr z[2] = {d2.x, d3.x};
     Fr zi[2] = {z[0], z[1]};
-    batch_inv<2>(zi, 2);
+    inv_pair(zi[0], zi[1]);
     const Fr az = is_zero_dev(io, o.isZero, z[0], zi[0]);
     io.chk_zero(C_RTX_SIG_A_NONZERO, fr_mul(az, enabled));
     out.zp = is_zero_dev(io, o.zeropoint, z[1], zi[1]);
@@ -703,7 +733,7 @@ __device__ __forceinline__ void ed_prologue_hash(const UnitIO& io, const EddsaOf
     num2bits_strict_dev(io, o.h2bits, out.h_c, C_RTX_SIG_H_ALIAS);
     out.R8.x = R8x; out.R8.y = R8y;
 }
-__device__ __noinline__ void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out, bool* on_curve) {
+__device__ HZ_ED_CALL void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out, bool* on_curve) {
     const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
     const Fr x = ed_prologue_point(K, io, o, enabled, signSig, aySig, Ay, out, on_curve);
     ed_prologue_hash(io, o, K6, sc.get(SC_ED_R8X), sc.get(SC_ED_R8Y), x, Ay, sc.get(SC_SIGL2HASH), out);
@@ -734,9 +764,9 @@ __device__ __forceinline__ PtP ed_dbl_proj(const EdK& K, const PtP& p) {
 }
 // the circuit's own chain: e2m, then `count` Montgomery doublings with the 0-divisor convention (no signals, no checks: the
 // segment lanes store and check every one of these steps again)
-__device__ __noinline__ PtA ed_dbl_chain_affine(const EdK& K, const PtA& p0, int count) {
+__device__ HZ_ED_CALL PtA ed_dbl_chain_affine(const EdK& K, const PtA& p0, int count) {
     Fr den[2] = {fr_sub(K.one, p0.y), p0.x};
-    batch_inv<2>(den, 2);
+    inv_pair(den[0], den[1]);
     PtA m;
     m.x = fr_mul(fr_add(K.one, p0.y), den[0]);
     m.y = fr_mul(m.x, den[1]);
@@ -767,9 +797,9 @@ __device__ __noinline__ PtA ed_dbl_chain_affine(const EdK& K, const PtA& p0, int
 // is a rational map: carried as (X : Y : Z) with x = X/Z, y = Y/Z it needs no inversion either (4S + 12M per step). A zero divisor
 // anywhere (the circuit's quotient is then 0 by convention, not a rational value) makes Z = 0 for good: then, and only then, the
 // affine chain is walked (its y = 0 case is a linear recurrence).
-__device__ __noinline__ PtA ed_dbl_chain_generic(const EdK& K, const PtA& p0, int count) {
+__device__ HZ_ED_CALL PtA ed_dbl_chain_generic(const EdK& K, const PtA& p0, int count) {
     Fr den[2] = {fr_sub(K.one, p0.y), p0.x};
-    batch_inv<2>(den, 2);
+    inv_pair(den[0], den[1]);
     PtA m;
     m.x = fr_mul(fr_add(K.one, p0.y), den[0]);
     m.y = fr_mul(m.x, den[1]);
@@ -806,7 +836,7 @@ __device__ __forceinline__ PtA ed_dbl_chain(const EdK& K, const PtA& p0, int cou
     // Edwards (X/Z, Y/Z) -> Montgomery u = (Z + Y) / (Z - Y), v = u * Z / X
     Fr den[2] = {fr_sub(q.Z, q.Y), q.X};
     Fr inv[2] = {den[0], den[1]};
-    batch_inv<2>(inv, 2);
+    inv_pair(inv[0], inv[1]);
     PtA m;
     m.x = fr_mul(fr_add(q.Z, q.Y), inv[0]);
     m.y = fr_mul(fr_mul(m.x, q.Z), inv[1]);
@@ -824,9 +854,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
     const uint32_t i = a.u0 + li;
-    EdK K;
-    K.one = fr_one();
-    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EdK K = ed_k();
     const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
     const Scratch sc{a.scratch, a.n_units, i};
     EdSig sg;
@@ -855,9 +883,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
     const uint32_t i = a.u0 + li;
-    EdK K;
-    K.one = fr_one();
-    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EdK K = ed_k();
     const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
     const Scratch sc{a.scratch, a.n_units, i};
     const Fr one = K.one;
@@ -914,6 +940,14 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
 // lane = (segment, G signatures in lockstep). Lane li of a segment evaluates the signatures of units li, li + nl, li + 2 nl, ...
 // (nl lanes): consecutive lanes keep writing consecutive units. A slot past the end repeats the lane's first unit (same values to
 // the same addresses).
+// field by field: `c ? a : b` on two structs selects an address, and the kernel's argument block would follow it into private memory
+__device__ __forceinline__ SegAnyOff seg_off_select(bool first, const SegAnyOff& a, const SegAnyOff& b) {
+    SegAnyOff r;
+    r.e2m = first ? a.e2m : b.e2m; r.bits = first ? a.bits : b.bits; r.m2e = first ? a.m2e : b.m2e;
+    r.eadder = first ? a.eadder : b.eadder;
+    r.lastSel = first ? a.lastSel : b.lastSel; r.nbits = first ? a.nbits : b.nbits;
+    return r;
+}
 template <int G>
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_ladder(const EddsaArgs a) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
@@ -921,9 +955,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= nl) return;
     const uint32_t seg = blockIdx.y;
-    EdK K;
-    K.one = fr_one();
-    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EdK K = ed_k();
     const EddsaOff& o = a.ed;
     UnitIO io[G];
     Fc h_c[G];
@@ -958,12 +990,15 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
             c.io.put_m(o.m2e0, p[g].x); c.io.put_m(o.m2e0 + 1, p[g].y);
         }
     }
+    // ONE call site per form (the bodies are inlined: two segments times two forms were four copies of the ladder in this kernel)
+    const SegAnyOff so = seg_off_select(seg == 0, o.seg[0], o.seg[1]);
+    const int e0 = seg == 0 ? 0 : 148, nb = seg == 0 ? 148 : 106;
     if (G == 1 && a.side) {
         const SideBuf sd{a.side, 2 * nl, seg * nl + li};
-        if (seg == 0) seg_any_proj(K, io[0], o.seg[0], h_c[0], 0, 148, p, dbl, sd);
-        else seg_any_proj(K, io[0], o.seg[1], h_c[0], 148, 106, p, dbl, sd);
-    } else if (seg == 0) seg_any_lock<G>(K, io, o.seg[0], h_c, 0, 148, p, dbl);
-    else seg_any_lock<G>(K, io, o.seg[1], h_c, 148, 106, p, dbl);
+        seg_any_proj(K, io[0], so, h_c[0], e0, nb, p, dbl, sd);
+    } else {
+        seg_any_lock<G>(K, io, so, h_c, e0, nb, p, dbl);
+    }
 #pragma unroll 1
     for (int g = 0; g < G; g++) {
         const Scratch sc{a.scratch, a.n_units, io[g].unit};
@@ -990,9 +1025,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     if (li >= nl) return;
     const uint32_t seg = blockIdx.y;
     const LaneLds L{(lds_u32*)(st + threadIdx.x)};
-    EdK K;
-    K.one = fr_one();
-    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EdK K = ed_k();
     const EddsaOff& o = a.ed;
     typedef __attribute__((address_space(1))) uint8_t gl_u8;
     uint8_t* const wbase = (uint8_t*)(gl_u8*)a.base;
@@ -1049,9 +1082,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     const uint32_t nl = (n + G - 1) / G;
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= nl) return;
-    EdK K;
-    K.one = fr_one();
-    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EdK K = ed_k();
     const EddsaOff& o = a.ed;
     UnitIO io[G];
     Fc S253[G];
@@ -1092,9 +1123,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa_final(const EddsaArgs a) {
     PtA right;
     {
         // mulAny.out = segment 0 + segment 1, the zero-point substitution undone, R8 + h*8A (eddsaposeidon.circom)
-        EdK K;
-        K.one = one;
-        K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+        const EdK K = ed_k();
         const EdCtx c = K.with(io);
         PtA s0, s1, R8;
         s0.x = sc.get(SC_ED_S0X); s0.y = sc.get(SC_ED_S0Y); s1.x = sc.get(SC_ED_S1X); s1.y = sc.get(SC_ED_S1Y);
@@ -1109,7 +1138,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_eddsa_final(const EddsaArgs a) {
     }
     Fr d2[2] = {fr_sub(right.x, sc.get(SC_ED_LEFTX)), fr_sub(right.y, sc.get(SC_ED_LEFTY))};
     Fr di[2] = {d2[0], d2[1]};
-    batch_inv<2>(di, 2);
+    inv_pair(di[0], di[1]);
     const Fr ex = is_zero_dev(io, o.eqCheckX, d2[0], di[0]);
     io.chk_zero(C_RTX_SIG_EQX, fr_mul(fr_sub(one, ex), enabled));
     const Fr ey = is_zero_dev(io, o.eqCheckY, d2[1], di[1]);
@@ -1208,9 +1237,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_ay_sign_2_ax_main(const GadgetArgs
     if (i >= a.N) return;
     const UnitIO io{a.base, a.N, i, i, 0, a.err};
     io.put_u64(0, 1);
-    EdK K;
-    K.one = fr_one();
-    K.a = fr_from_u64(168700); K.d = fr_from_u64(168696); K.A = fr_from_u64(168698);
+    const EdK K = ed_k();
     io.put_m(a.io.out[0], ay_sign_2_ax_dev(K.with(io), io, o, io.in_m(a.io.in[0]), io.in_m(a.io.in[1])));
 }
 hipError_t launch_ay_sign_2_ax_main(const GadgetArgs& a, const EddsaOff& o, hipStream_t s) {

@@ -356,7 +356,7 @@ class NativeBatchBuilder:
 
 
 def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455A31, n_accounts=None, n_keys=8, exits=0, device=None, first_idx=256,
-                           base=None, out=None, native_recipe=False, begin_only=False):
+                           base=None, out=None, native_recipe=False, begin_only=False, phases=None):
     """builder.synthetic_batch's recipe (reference tools/generate-input.js:61-109) on the native builder: the same seeded
     transactions, hence the same circuit inputs byte for byte. Pre-population goes through a DenseState (built here when `base` is None
     and n_accounts is a power of two >= 16, as synthetic_batch(dense=True) does). Returns (batch, packed, hashGlobalInputs)."""
@@ -368,9 +368,19 @@ def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455
             raise ValueError("synthetic_batch_native: n_accounts must be a power of two >= 16 (DenseState)")
         base = B.DenseState.build(n_accounts.bit_length() - 1, seed=seed, first_idx=first_idx, n_keys=n_keys)
     import numpy as np
+    import time
+    tick = [time.perf_counter()]
+
+    def phase(name):   # where the time of a build goes besides the walk (bench.py: config.batch_builder.phases_ms)
+        t = time.perf_counter()
+        if phases is not None:
+            phases[name] = phases.get(name, 0.0) + t - tick[0]
+        tick[0] = t
     db = NativeRollupDB(chain_id=1, device=device, base=base)
+    phase("database")
     keys = [B.Account(seed * 1000 + i) for i in range(n_keys)]
     bkeys = base.keys()
+    phase("l1_keys")
     bb = db.build_batch(n_tx, n_levels, max_l1, max_fee)
     n_l1 = min(max_l1, n_tx)
     if native_recipe:
@@ -380,9 +390,11 @@ def synthetic_batch_native(n_tx, n_levels, max_l1, max_fee, layout, seed=0x48455
         l1e = b"".join(a.eth_addr.to_bytes(32, "little") for a in keys)
         sk = b"".join(a.k.to_bytes(32, "little") for a in bkeys)
         _check(bb.c.hzb_batch_add_synthetic(bb.h, ctypes.c_uint64(seed), exits, n_keys, l1b, l1e, len(bkeys), sk))
+        phase("recipe")
         bb._db_keep = db
         if begin_only:   # the caller finishes it (build_finish) after it has begun the next batch
             bb.build_begin(layout, out)
+            phase("build_begin")
             return bb
         packed, hgi = bb.build(layout, out)
         return bb, packed, hgi

@@ -6,7 +6,7 @@ name=$1; shift
 mkdir -p ../../variants /tmp/var_all_$name
 pids=""
 for src in *.hip; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-pass-failed -Wno-unused-function "$@" -c $src -o /tmp/var_all_$name/${src%.hip}.o 2>/tmp/var_all_$name/${src%.hip}.log &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-pass-failed -mllvm -pragma-unroll-threshold=1000000 -Wno-unused-function "$@" -c $src -o /tmp/var_all_$name/${src%.hip}.o 2>/tmp/var_all_$name/${src%.hip}.log &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done
