@@ -794,10 +794,12 @@ static hz_status enqueue_rtx_tail(hz_ctx* c, uint8_t* base, uint32_t n_units, bo
     }
     {
         // the split form (launches of <= HZ_ED_SPLIT_MAX signatures) parks its numerators in a side buffer: 84.7 KB per signature,
-        // allocated by the first launch that takes that form and sized for it (a shard: its own range, not the section)
+        // allocated by the first launch that takes that form and sized for it (a shard: its own range, not the section); the throughput
+        // form keeps the lane state of the fixed-base kernel there (1.7 KB per eight signatures)
         const size_t need = eddsa_side_bytes(ucnt ? ucnt : n_units);
         if (need > c->ed_side.bytes || (need && !c->ed_side.p)) {
             HZ_HIP(hipStreamSynchronize(c->s_ed));
+            HZ_HIP(hipStreamSynchronize(c->exclusive ? c->s_ed : c->s_fix));
             HZ_HIP(c->ed_side.alloc(need));
         }
     }

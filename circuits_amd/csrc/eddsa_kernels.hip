@@ -35,17 +35,6 @@ struct PtA { Fr x, y; };
 #ifndef HZ_ED_CALL
 #define HZ_ED_CALL __forceinline__
 #endif
-// two inverses with one inversion, zeros stay zero: batch_inv<2> without its arrays (a loop over two field products does not unroll)
-__device__ __forceinline__ void inv_pair(Fr& a, Fr& b) {
-    const bool za = fr_is_zero(a), zb = fr_is_zero(b);
-    const Fr one = fr_one();
-    const Fr a1 = fr_select(za, one, a), b1 = fr_select(zb, one, b);   // (limb selects: `c ? x : y` on two structs selects an ADDRESS)
-    const Fr inv = fr_inv(fr_mul(a1, b1));
-    const Fr ia = fr_mul(inv, b1), ib = fr_mul(inv, a1);
-    a = fr_select(za, a, ia);
-    b = fr_select(zb, b, ib);
-}
-
 __device__ __forceinline__ Fr ld_const(const uint32_t* p) {
     Fr r;
     for (int i = 0; i < 9; i++) r.v[i] = p[i];
@@ -668,6 +657,110 @@ __device__ HZ_ED_CALL void seg_fix_lock(const EdK& K, const UnitIO* io, const Se
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The fixed-base half with G > 1 signatures per lane in lockstep (throughput launches, k_eddsa_fix<8>): what a signature carries from
+// one turn to the next -- its accumulator, the prefix product of the window's shared inversion, its scalar bits, the first segment's
+// output -- is 25 field elements for eight signatures and cannot live in registers. seg_fix_lock keeps it in arrays indexed by g,
+// which the compiler puts in PRIVATE memory (2.6 KB per lane, the largest scratch frame of the step until round 6); the LDS is taken
+// (two ladder wavefronts of 70 KB per CU). Here the same state sits in a GLOBAL buffer of the context (EddsaArgs::side, unused by the
+// throughput ladder), slot s limb l of lane L at p[(s * 9 + l) * stride + L]: the same coalesced traffic, addressed explicitly, and no
+// scratch reservation on the queue. Values and their order of evaluation are seg_fix_lock's.
+struct LaneMem {
+    uint32_t* p;       // buffer + lane
+    uint32_t stride;   // lanes of the launch, rounded up to a wavefront
+    __device__ __forceinline__ Fr get(int slot) const {
+        Fr r;
+#pragma unroll
+        for (int l = 0; l < 9; l++) r.v[l] = p[(size_t)(slot * 9 + l) * stride];
+        return r;
+    }
+    __device__ __forceinline__ void put(int slot, const Fr& v) const {
+#pragma unroll
+        for (int l = 0; l < 9; l++) p[(size_t)(slot * 9 + l) * stride] = v.v[l];
+    }
+    __device__ __forceinline__ uint32_t getw(int word) const { return p[(size_t)word * stride]; }
+    __device__ __forceinline__ void putw(int word, uint32_t v) const { p[(size_t)word * stride] = v; }
+};
+template <int G> struct FixMem {   // slots, in field elements: accumulator (x, y) per signature, prefix products, first-segment outputs, scalar bits
+    static constexpr int ACC = 0, PRE = 2 * G, Q = 3 * G, BITS = 5 * G, SLOTS = 5 * G + (8 * G + 8) / 9;
+};
+// window i of signature g's scalar: bits e0 + 3 i .. + 2 (those at or above nbits read as zero), from the words parked at FixMem::BITS
+template <int G>
+__device__ __forceinline__ uint32_t lm_window_bits(const LaneMem& M, int g, int e0, int nbits, int i) {
+    const int pos = e0 + 3 * i, w = pos >> 5, sh = pos & 31;
+    const int w0 = FixMem<G>::BITS * 9 + g * 8;
+    uint64_t v = M.getw(w0 + w);
+    if (sh > 29 && w + 1 < 8) v |= (uint64_t)M.getw(w0 + w + 1) << 32;
+    uint32_t k = (uint32_t)(v >> sh) & 7u;
+    const int left = nbits - 3 * i;   // bits of this window that belong to the segment
+    if (left < 3) k &= (1u << (left > 0 ? left : 0)) - 1u;
+    return k;
+}
+template <int G, class MkIo, class Sink>
+__device__ __forceinline__ void seg_fix_mem(const EdK& K, const MkIo& mk_io, const SegFixOff& o, const LaneMem& M, int e0, int nbits, int win0, int seg, const Sink& sink) {
+    using FM = FixMem<G>;
+    const Fr A0 = fr_limbs_u64(168698);
+    {
+        const Fr x0 = ld_const(HZ_BJJ_FIX_DBLLAST0[2 * seg]), y0 = ld_const(HZ_BJJ_FIX_DBLLAST0[2 * seg + 1]);
+#pragma unroll 1
+        for (int g = 0; g < G; g++) { M.put(FM::ACC + 2 * g, x0); M.put(FM::ACC + 2 * g + 1, y0); }
+    }
+#pragma unroll 1
+    for (int i = 0; i < (int)o.nwin; i++) {
+        const uint32_t wb = o.windows + WIN_N * i;
+        // one inversion for the G divisors of the window (batch_inv's two passes): forward = prefix products, parked; backward = each
+        // signature's inverse peeled off and used at once, its divisor evaluated again (a table load and a subtraction)
+        Fr prod = fr_one();
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const uint32_t k = lm_window_bits<G>(M, g, e0, nbits, i);
+            const Fr d = fr_sub(ld_const(HZ_BJJ_FIX_WIN0[((win0 + i) * 8 + k) * 2]), M.get(FM::ACC + 2 * g));
+            M.put(FM::PRE + g, prod);
+            if (!fr_is_zero(d)) prod = fr_mul(prod, d);
+        }
+        Fr inv = fr_inv(prod);   // scale-0 divisors in, scale-2 inverses out
+#pragma unroll 1
+        for (int g = G - 1; g >= 0; g--) {
+            const UnitIO w = mk_io(g);
+            const uint32_t k = lm_window_bits<G>(M, g, e0, nbits, i);
+            PtA mo;
+            mo.x = ld_const(HZ_BJJ_FIX_WIN0[((win0 + i) * 8 + k) * 2]);
+            mo.y = ld_const(HZ_BJJ_FIX_WIN0[((win0 + i) * 8 + k) * 2 + 1]);
+            const Fr ax = M.get(FM::ACC + 2 * g), ay = M.get(FM::ACC + 2 * g + 1);
+            const Fr d = fr_sub(mo.x, ax);
+            const bool dz = fr_is_zero(d);
+            Fr inv_g = fr_zero();
+            if (!dz) {
+                inv_g = fr_mul(inv, M.get(FM::PRE + g));
+                inv = fr_mul(inv, d);
+            }
+            w.put_bit(wb + WIN_S10, (k & 1) & ((k >> 1) & 1));
+            w.put_c(wb + WIN_MUX0, fr_pack_canon(mo.x)); w.put_c(wb + WIN_MUX1, fr_pack_canon(mo.y));
+            const Fr num = fr_sub_lazy(mo.y, ay);   // a multiplicand only (fr.h "lazily reduced sums")
+            const Fr l1 = fr_mul(num, inv_g);
+            const Fr l0 = fr_canon_limbs(l1);
+            if (dz) w.chk(C_RTX_SIG_EC, fr_zero(), fr_scale_up(num));
+            const Fr nx = ed_put0(w, wb + WIN_ADD_OUT0, fr_sub3(fr_mul(l0, l1), A0, ax, mo.x));
+            const Fr ny = fr_sub(fr_mul(l1, fr_sub_lazy(ax, nx)), ay);
+            w.put_c(wb + WIN_ADD_LAMDA, fr_pack_canon(l0));
+            M.put(FM::ACC + 2 * g, nx); M.put(FM::ACC + 2 * g + 1, ed_put0(w, wb + WIN_ADD_OUT1, ny));
+        }
+    }
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        const UnitIO io = mk_io(g);
+        const EdCtx c = K.with(io);
+        PtA acc;
+        acc.x = fr_scale_up(M.get(FM::ACC + 2 * g)); acc.y = fr_scale_up(M.get(FM::ACC + 2 * g + 1));
+        const PtA me = m2e_dev(c, acc);
+        c.io.put_m(o.m2e, me.x); c.io.put_m(o.m2e + 1, me.y);
+        PtA cn;
+        cn.x = ld_const(HZ_BJJ_FIX_CNEG[2 * seg]);
+        cn.y = ld_const(HZ_BJJ_FIX_CNEG[2 * seg + 1]);
+        sink(g, c, baby_add_dev(c, o.cAdd, me, cn));
+    }
+}
+
 // Everything before the scalar multiplications of one signature: AySign2Ax, the S range check,
 // the message hash and its bits, 8*A and the zero-point substitution.
 struct EdSig {
@@ -847,6 +940,16 @@ __device__ __forceinline__ PtA ed_dbl_chain(const EdK& K, const PtA& p0, int cou
 #ifndef HZ_ED_WAVES
 #define HZ_ED_WAVES 2
 #endif
+#ifndef HZ_ED_FIX_G
+#define HZ_ED_FIX_G 8   // signatures per lane of the fixed-base half in throughput launches
+#endif
+// the kernels of the SPLIT form (launches of at most HZ_ED_SPLIT_MAX signatures: a few dozen wavefronts, one long dependent chain each).
+// At ONE wavefront per SIMD (512 registers: what would spill goes to the accumulation registers) they use no private memory at all and
+// one batch's ladder takes 5.70 instead of 5.84 ms -- but two flagged contexts in flight lose 3 % (403 k against 415-419 k tx/s,
+// profiles/r06_eddsa_inline_ab.txt): the default stays two, -DHZ_ED_WAVES_LAT=1 is the scratch-free build.
+#ifndef HZ_ED_WAVES_LAT
+#define HZ_ED_WAVES_LAT 2
+#endif
 // lane = signature: everything before the scalar multiplication, and the start of its second segment
 __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_pre(const EddsaArgs a) {
     const Fr* K6 = poseidon_consts_w<6>();
@@ -878,7 +981,7 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
 // here (values only, the front kernel stores the signals) this kernel starts WITH the front kernel instead of after it, and the
 // chain front -> prologue -> ladder of a single batch loses a millisecond. The key's bits are read only when isP1Insert is not zero
 // (a product with zero is zero whatever the other operand).
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_pre_a(const EddsaArgs a) {
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES_LAT))) void k_eddsa_pre_a(const EddsaArgs a) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
@@ -949,7 +1052,7 @@ __device__ __forceinline__ SegAnyOff seg_off_select(bool first, const SegAnyOff&
     return r;
 }
 template <int G>
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_ladder(const EddsaArgs a) {
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES_LAT))) void k_eddsa_ladder(const EddsaArgs a) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t nl = (n + G - 1) / G;
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1077,13 +1180,46 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
 // nothing but S, so it runs beside the variable-base ladder in its own kernel with its own signatures-per-lane (85 inversions
 // per lane: more signatures share each of them than in the 254-step ladder kernel).
 template <int G>
-__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_WAVES))) void k_eddsa_fix(const EddsaArgs a) {
+__global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(G == 1 ? HZ_ED_WAVES_LAT : HZ_ED_WAVES))) void k_eddsa_fix(const EddsaArgs a) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
     const uint32_t nl = (n + G - 1) / G;
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= nl) return;
     const EdK K = ed_k();
     const EddsaOff& o = a.ed;
+    if constexpr (G > 1) {
+        // several signatures per lane: their state in the context's lane buffer (seg_fix_mem above), nothing indexed by g in this kernel
+        using FM = FixMem<G>;
+        const LaneMem M{a.side + li, (nl + 63u) & ~63u};
+        auto mk_io = [&](int g) __attribute__((always_inline)) {
+            uint32_t ui = li + (uint32_t)g * nl;
+            if (ui >= n) ui = li;   // a padding slot repeats the lane's first signature
+            const uint32_t i = a.u0 + ui;
+            return UnitIO{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
+        };
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const UnitIO io = mk_io(g);
+            const Scratch sc{a.scratch, a.n_units, io.unit};
+            const Fc S_c = fr_to_canon(sc.get(SC_ED_S));
+            num2bits_dev(io, o.snum2bits, S_c, 253, C_RTX_SIG_N2B_S);
+            const Fc S253 = c_extract(S_c, 0, 253);
+            if (comp_constant_dev(io, o.sCmp, S253, CT_SUBORDER_M1_D)) io.chk_zero(C_RTX_SIG_S_RANGE, sc.get(SC_ED_ENABLED));
+#pragma unroll
+            for (int q = 0; q < 8; q++) M.putw(FM::BITS * 9 + g * 8 + q, S253.v[q]);
+        }
+        seg_fix_mem<G>(K, mk_io, o.fseg[0], M, 0, 246, 0, 0, [&](int g, const EdCtx&, const PtA& q) __attribute__((always_inline)) {
+            M.put(FM::Q + 2 * g, q.x); M.put(FM::Q + 2 * g + 1, q.y);
+        });
+        seg_fix_mem<G>(K, mk_io, o.fseg[1], M, 246, 7, 82, 1, [&](int g, const EdCtx& c, const PtA& r) __attribute__((always_inline)) {
+            PtA q;
+            q.x = M.get(FM::Q + 2 * g); q.y = M.get(FM::Q + 2 * g + 1);
+            const PtA left = baby_add_dev(c, o.fadders0, q, r);
+            const Scratch sc{a.scratch, a.n_units, c.io.unit};
+            sc.set(SC_ED_LEFTX, left.x); sc.set(SC_ED_LEFTY, left.y);
+        });
+        return;
+    }
     UnitIO io[G];
     Fc S253[G];
     PtA q[G], r[G];
@@ -1192,7 +1328,10 @@ static hipError_t launch_eddsa_fix_g(const EddsaArgs& a, uint32_t n, hipStream_t
     return hipGetLastError();
 }
 size_t eddsa_side_bytes(uint32_t n) {
-    return n <= HZ_ED_SPLIT_MAX ? (size_t)2 * n * 147 * SD_FIELDS * 9 * sizeof(uint32_t) : 0;
+    if (n <= HZ_ED_SPLIT_MAX) return (size_t)2 * n * 147 * SD_FIELDS * 9 * sizeof(uint32_t);   // seg_any_proj's numerators
+    // the throughput form: the lane state of k_eddsa_fix<HZ_ED_FIX_G> (1.7 KB per lane of eight signatures)
+    const size_t lanes = (((size_t)n + HZ_ED_FIX_G - 1) / HZ_ED_FIX_G + 63) & ~(size_t)63;
+    return lanes * FixMem<HZ_ED_FIX_G>::SLOTS * 9 * sizeof(uint32_t);
 }
 hipError_t launch_eddsa(const EddsaArgs& a, hipStream_t s, hipEvent_t front_done, hipEvent_t hash_done) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;
@@ -1209,7 +1348,7 @@ hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {
     // Eight signatures per lane: 85 windows x (8 turns + one shared inversion) is still a shorter chain than the variable-base ladder
     // beside it (11.0 ms alone against 17.4), and an eighth of an inversion per window instead of a quarter is 0.2 G fewer
     // wave-instructions per 65 536 signatures (four per lane: 7.5 ms alone, step +0.3..0.6 ms; profiles/r03_eddsa_seg_ab.txt).
-    return launch_eddsa_fix_g<8>(a, n, s);
+    return launch_eddsa_fix_g<HZ_ED_FIX_G>(a, n, s);
 }
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s) {
     const uint32_t n = a.ucnt ? a.ucnt : a.n_units;

@@ -1,5 +1,8 @@
 // FeeTx (reference src/fee-tx.circom:26-112), HashState as main (src/lib/hash-state.circom:18-40),
 // HashInputs (src/hash-inputs.circom:23-185) and Withdraw (src/withdraw.circom:21-176).
+// (the field routines inlined here too since round 6: an out-of-line fr_mul takes its operands by reference, 36 bytes of private memory
+// each -- 270-340 B per lane in k_fee_front / k_fee_back / k_withdraw; the kernels are latency / store bound either way)
+#define HZ_FR_INLINE
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "sha_dev.h"
@@ -23,7 +26,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_fee_front(const FeeFrontArgs a) {
     const Fr feeIdx = io.in_m(a.in_feeIdx), feePlanToken = io.in_m(a.in_feePlanToken), tokenID = io.in_m(a.in_tokenID);
     Fr z[2] = {feeIdx, fr_sub(tokenID, feePlanToken)};   // tokenIDChecker: in[0] = feePlanToken, in[1] = tokenID
     Fr zi[2] = {z[0], z[1]};
-    batch_inv<2>(zi, 2);
+    inv_pair(zi[0], zi[1]);
     const Fr fz = is_zero_dev(io, a.fee.feeIdxIsZero, z[0], zi[0]);
     const Fr e = is_zero_dev(io, a.fee.tokenIDChecker, z[1], zi[1]);
     io.chk_zero(C_FEE_TOKENID, fr_mul(fr_sub(one, e), fr_sub(one, fz)));
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(HZ_WD_BLOCK) void k_withdraw(const WithdrawArgs a) 
         // areKeyEquals(oldKey = 0, key); keysOk = MultiAND(4)(fnc=0, 1-isOld0=1, keq, enabled=1)
         Fr z[2] = {idx, fr_sub(rootExit, child)};   // checkRoot: in[0] = levels[0].root, in[1] = root
         Fr zi[2] = {z[0], z[1]};
-        batch_inv<2>(zi, 2);
+        inv_pair(zi[0], zi[1]);
         const Fr keq = is_zero_dev(io, v.keyEq, z[0], zi[0]);
         io.put_u64(v.and_a, 0); io.put_m(v.and_b, keq); io.put_u64(v.and_c, 0);
         const Fr e = is_zero_dev(io, v.checkRoot, z[1], zi[1]);

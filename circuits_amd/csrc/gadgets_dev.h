@@ -176,6 +176,18 @@ __device__ __forceinline__ void batch_inv(Fr (&x)[N], int n) {
     }
 }
 
+// two inverses with one inversion, zeros stay zero: batch_inv<2> without its arrays (a loop over two field products does not unroll, so
+// `pre[]` and the operands would sit in private memory)
+__device__ __forceinline__ void inv_pair(Fr& a, Fr& b) {
+    const bool za = fr_is_zero(a), zb = fr_is_zero(b);
+    const Fr one = fr_one();
+    const Fr a1 = fr_select(za, one, a), b1 = fr_select(zb, one, b);   // (limb selects: `c ? x : y` on two structs selects an ADDRESS)
+    const Fr inv = fr_inv(fr_mul(a1, b1));
+    const Fr ia = fr_mul(inv, b1), ib = fr_mul(inv, a1);
+    a = fr_select(za, a, ia);
+    b = fr_select(zb, b, ib);
+}
+
 // A RUN of n IsZero gadgets (slot k: input load(k); store(k, in, inv) writes its signals -- is_zero_dev at one or several offsets) with
 // batched inverses and no private memory. batch_inv above keeps its operands and prefix products in arrays indexed by a loop counter; a
 // loop this size does not unroll, so those arrays live in scratch memory (three of 576 bytes per lane in k_withdraw and the

@@ -20,15 +20,19 @@ __constant__ const uint32_t SHA_H0[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int r) { return (x >> r) | (x << (32 - r)); }
 
 // plain compression (chaining value only)
+// (both loops unrolled: a schedule array indexed by a loop counter lives in private memory, 256 bytes per lane)
 __device__ __forceinline__ void sha256_compress(uint32_t* hv, const uint32_t* w16) {
     uint32_t w[64];
+#pragma unroll
     for (int t = 0; t < 16; t++) w[t] = w16[t];
+#pragma unroll
     for (int t = 16; t < 64; t++) {
         const uint32_t s0 = rotr32(w[t - 15], 7) ^ rotr32(w[t - 15], 18) ^ (w[t - 15] >> 3);
         const uint32_t s1 = rotr32(w[t - 2], 17) ^ rotr32(w[t - 2], 19) ^ (w[t - 2] >> 10);
         w[t] = s1 + w[t - 7] + s0 + w[t - 16];
     }
     uint32_t a = hv[0], b = hv[1], c = hv[2], d = hv[3], e = hv[4], f = hv[5], g = hv[6], h = hv[7];
+#pragma unroll
     for (int t = 0; t < 64; t++) {
         const uint32_t t1 = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[t] + w[t];
         const uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
@@ -78,20 +82,15 @@ __device__ __forceinline__ uint32_t xor3_dev(const UnitIO& io, uint32_t off, uin
     return o;
 }
 
-// compression with the full bit-level witness written at signal offset `base`
+// compression with the full bit-level witness written at signal offset `base`.
+// The message schedule is a WINDOW of sixteen words that moves with the round -- r[0] = w[t] in round t, the step that makes w[t + 16]
+// follows the round and the window shifts by one (fifteen register moves beside ~360 stored signals) -- instead of an array w[64] indexed
+// by the loop counter, which is 256 bytes of private memory per lane. Same signals at the same offsets; only the order in which a lane
+// issues its stores changes (schedule step t + 16 after round t).
 __device__ void sha256_block_witness(const UnitIO& io, uint32_t base, uint32_t* hv, const uint32_t* w16) {
-    uint32_t w[64];
-    for (int t = 0; t < 16; t++) w[t] = w16[t];
-#pragma unroll 1
-    for (int t = 16; t < 64; t++) {
-        const uint32_t o = base + (uint32_t)(t - 16) * SHA_SCHED_W;
-        const uint32_t x15 = w[t - 15], x2 = w[t - 2];
-        const uint32_t s0 = xor3_dev(io, o, rotr32(x15, 7), rotr32(x15, 18), x15 >> 3);
-        const uint32_t s1 = xor3_dev(io, o + 64, rotr32(x2, 17), rotr32(x2, 19), x2 >> 10);
-        const uint64_t sum = (uint64_t)s1 + w[t - 7] + s0 + w[t - 16];
-        put_word_bits(io, o + 128, sum, 34);
-        w[t] = (uint32_t)sum;
-    }
+    uint32_t r[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) r[t] = w16[t];
     uint32_t a = hv[0], b = hv[1], c = hv[2], d = hv[3], e = hv[4], f = hv[5], g = hv[6], h = hv[7];
     const uint32_t rbase = base + 48 * SHA_SCHED_W;
 #pragma unroll 1
@@ -100,7 +99,7 @@ __device__ void sha256_block_witness(const UnitIO& io, uint32_t base, uint32_t* 
         const uint32_t S1 = xor3_dev(io, o, rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
         const uint32_t ch = (e & f) ^ (~e & g);
         put_word_bits(io, o + 64, ch, 32);
-        const uint64_t t1 = (uint64_t)h + S1 + ch + SHA_K[t] + w[t];
+        const uint64_t t1 = (uint64_t)h + S1 + ch + SHA_K[t] + r[0];
         put_word_bits(io, o + 96, t1, 35);
         const uint32_t S0 = xor3_dev(io, o + 131, rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
         const uint32_t mid = b & c, maj = (a & b) ^ (a & c) ^ (b & c);
@@ -112,9 +111,23 @@ __device__ void sha256_block_witness(const UnitIO& io, uint32_t base, uint32_t* 
         put_word_bits(io, o + 292, se, 33);
         put_word_bits(io, o + 325, sa, 33);
         h = g; g = f; f = e; e = (uint32_t)se; d = c; c = b; b = a; a = (uint32_t)sa;
+        uint32_t nw = 0;
+        if (t < 48) {   // schedule step t + 16: w[t + 16] from w[t + 1], w[t + 14], w[t + 9], w[t]
+            const uint32_t so = base + (uint32_t)t * SHA_SCHED_W;
+            const uint32_t x15 = r[1], x2 = r[14];
+            const uint32_t s0 = xor3_dev(io, so, rotr32(x15, 7), rotr32(x15, 18), x15 >> 3);
+            const uint32_t s1 = xor3_dev(io, so + 64, rotr32(x2, 17), rotr32(x2, 19), x2 >> 10);
+            const uint64_t sum = (uint64_t)s1 + r[9] + s0 + r[0];
+            put_word_bits(io, so + 128, sum, 34);
+            nw = (uint32_t)sum;
+        }
+#pragma unroll
+        for (int i = 0; i < 15; i++) r[i] = r[i + 1];
+        r[15] = nw;
     }
     const uint32_t fbase = rbase + 64 * SHA_ROUND_W;
     const uint32_t st[8] = {a, b, c, d, e, f, g, h};
+#pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint64_t s = (uint64_t)hv[i] + st[i];
         put_word_bits(io, fbase + 33 * i, s, 33);
@@ -126,33 +139,19 @@ __device__ void sha256_block_witness(const UnitIO& io, uint32_t base, uint32_t* 
 // the final additions); what precedes its slice is recomputed without stores (at most 48 + 64 cheap steps against ~3 600 stored
 // signals per lane at nparts = 8). A block is then nparts independent store streams instead of one 29 k-signal stream.
 __device__ void sha256_block_witness_part(const UnitIO& io, uint32_t base, const uint32_t* hv, const uint32_t* w16, uint32_t part, uint32_t nparts) {
-    uint32_t w[64];
-    for (int t = 0; t < 16; t++) w[t] = w16[t];
+    uint32_t r[16];   // the schedule window of sha256_block_witness
+#pragma unroll
+    for (int t = 0; t < 16; t++) r[t] = w16[t];
     const int s_lo = 16 + (int)(48u * part / nparts), s_hi = 16 + (int)(48u * (part + 1) / nparts);
     const int r_lo = (int)(64u * part / nparts), r_hi = (int)(64u * (part + 1) / nparts);
-#pragma unroll 1
-    for (int t = 16; t < 64; t++) {
-        const uint32_t x15 = w[t - 15], x2 = w[t - 2];
-        if (t >= s_lo && t < s_hi) {
-            const uint32_t o = base + (uint32_t)(t - 16) * SHA_SCHED_W;
-            const uint32_t s0 = xor3_dev(io, o, rotr32(x15, 7), rotr32(x15, 18), x15 >> 3);
-            const uint32_t s1 = xor3_dev(io, o + 64, rotr32(x2, 17), rotr32(x2, 19), x2 >> 10);
-            const uint64_t sum = (uint64_t)s1 + w[t - 7] + s0 + w[t - 16];
-            put_word_bits(io, o + 128, sum, 34);
-            w[t] = (uint32_t)sum;
-        } else {
-            const uint32_t s0 = rotr32(x15, 7) ^ rotr32(x15, 18) ^ (x15 >> 3);
-            const uint32_t s1 = rotr32(x2, 17) ^ rotr32(x2, 19) ^ (x2 >> 10);
-            w[t] = s1 + w[t - 7] + s0 + w[t - 16];
-        }
-    }
     uint32_t a = hv[0], b = hv[1], c = hv[2], d = hv[3], e = hv[4], f = hv[5], g = hv[6], h = hv[7];
     const uint32_t rbase = base + 48 * SHA_SCHED_W;
+    // (the slice's last schedule step, s_hi - 1, is made in iteration s_hi - 17 < r_hi: 48 (part + 1) / nparts <= 64 (part + 1) / nparts)
 #pragma unroll 1
     for (int t = 0; t < r_hi; t++) {
         const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
         const uint32_t ch = (e & f) ^ (~e & g);
-        const uint64_t t1 = (uint64_t)h + S1 + ch + SHA_K[t] + w[t];
+        const uint64_t t1 = (uint64_t)h + S1 + ch + SHA_K[t] + r[0];
         const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
         const uint32_t mid = b & c, maj = (a & b) ^ (a & c) ^ (b & c);
         const uint64_t t2 = (uint64_t)S0 + maj;
@@ -170,10 +169,31 @@ __device__ void sha256_block_witness_part(const UnitIO& io, uint32_t base, const
             put_word_bits(io, o + 325, sa, 33);
         }
         h = g; g = f; f = e; e = (uint32_t)se; d = c; c = b; b = a; a = (uint32_t)sa;
+        uint32_t nw = 0;
+        const int ts = t + 16;   // the schedule step that follows round t
+        if (ts < 64) {
+            const uint32_t x15 = r[1], x2 = r[14];
+            if (ts >= s_lo && ts < s_hi) {
+                const uint32_t so = base + (uint32_t)t * SHA_SCHED_W;
+                const uint32_t s0 = xor3_dev(io, so, rotr32(x15, 7), rotr32(x15, 18), x15 >> 3);
+                const uint32_t s1 = xor3_dev(io, so + 64, rotr32(x2, 17), rotr32(x2, 19), x2 >> 10);
+                const uint64_t sum = (uint64_t)s1 + r[9] + s0 + r[0];
+                put_word_bits(io, so + 128, sum, 34);
+                nw = (uint32_t)sum;
+            } else {
+                const uint32_t s0 = rotr32(x15, 7) ^ rotr32(x15, 18) ^ (x15 >> 3);
+                const uint32_t s1 = rotr32(x2, 17) ^ rotr32(x2, 19) ^ (x2 >> 10);
+                nw = s1 + r[9] + s0 + r[0];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 15; i++) r[i] = r[i + 1];
+        r[15] = nw;
     }
     if (part + 1 == nparts) {
         const uint32_t fbase = rbase + 64 * SHA_ROUND_W;
         const uint32_t st[8] = {a, b, c, d, e, f, g, h};
+#pragma unroll
         for (int i = 0; i < 8; i++) put_word_bits(io, fbase + 33 * i, (uint64_t)hv[i] + st[i], 33);
     }
 }

@@ -21,7 +21,7 @@ __device__ __forceinline__ Fr smt_top_dev(const UnitIO& io, const Scratch& sc, c
     z[0] = fr_sub(outL, oldRoot);                               // checkOldInput: in[0] = oldRoot, in[1] = topSwitcher.outL
     z[1] = fr_sub(sc.get(P.sc_newkey), sc.get(P.sc_oldkey));    // areKeyEquals: in[0] = oldKey, in[1] = newKey
     zi[0] = z[0]; zi[1] = z[1];
-    batch_inv<2>(zi, 2);
+    inv_pair(zi[0], zi[1]);
     const Fr e = is_zero_dev(io, o.checkOld, z[0], zi[0]);
     io.chk_zero(cid_oldroot, fr_mul(fr_sub(one, e), enabled));
     const Fr newRoot = fr_add(fr_mul(enabled, fr_sub(outR, oldRoot)), oldRoot);

@@ -4,6 +4,7 @@
 // iden3's go-merkletree, circomlib's Go twin) reach the same level-hash kernels the rollup circuits use:
 //   SMTProcessor main = k_smtproc_front (leaf hashes, scratch) -> k_smt (the chain kernel of smt_kernels.hip, unchanged) -> k_smtproc_back
 //   SMTVerifier main  = k_smtver_main, the general form of the verifier k_withdraw specialises (enabled = 1, fnc = 0, oldKey = 0)
+#define HZ_FR_INLINE   // (an out-of-line product takes its operands through private memory: fee_kernels.hip)
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "smt_dev.h"
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(HZ_BLOCK) void k_smtver_main(const SmtMainArgs a) {
     {
         Fr z[2] = {fr_sub(key, oldKey), fr_sub(root, child)};   // areKeyEquals: in[0] = oldKey, in[1] = key; checkRoot: in[0] = levels[0].root, in[1] = root
         Fr zi[2] = {z[0], z[1]};
-        batch_inv<2>(zi, 2);
+        inv_pair(zi[0], zi[1]);
         const Fr keq = is_zero_dev(io, v.keyEq, z[0], zi[0]);
         // keysOk = MultiAND(4)(fnc, 1 - isOld0, keq, enabled)
         const Fr aa = fr_mul(fnc, fr_sub(one, isOld0)), ab = fr_mul(keq, enabled), ac = fr_mul(aa, ab);

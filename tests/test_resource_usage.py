@@ -14,16 +14,20 @@ import resource_usage as RU   # noqa: E402
 
 # bytes of scratch per lane each timed kernel may use (the state when the budget was last lowered; lower it when a kernel improves)
 BUDGET = {"hz::k_smt<false>": 0, "hz::k_smt<true>": 0, "hz::k_hash4": 0, "hz::k_main_feeacc": 0,
-          "hz::k_main_front": 480,      # (7 776 until round 6: three lanes per transaction, loaders instead of held values; tx_dev.h)
+          "hz::k_main_front": 480,      # (7 776 until round 6: three lanes per transaction, loaders instead of held values; tx_dev.h) -- spills
           "hz::k_main_sighash": 0,      # (256: a `#pragma unroll` dropped silently past 16 384 instructions kept the width-7 Poseidon state in
                                         # private memory -- -pragma-unroll-threshold in the Makefile)
-          "hz::k_withdraw": 336,        # (2 016: the IsZero run in a rotating register window)
+          "hz::k_rtx_back": 0, "hz::k_fee_front": 0, "hz::k_fee_back": 0, "hz::k_hi_prep": 80,   # (160 / 272 / 304 / 128: field routines inlined,
+                                        # pair inversions without arrays)
+          "hz::k_sha_expand": 0, "hz::k_sha_chain": 0, "hz::k_sha_chain_w": 0,   # (272: the message schedule as a moving window of 16 words)
+          "hz::k_withdraw": 112, "hz::k_withdraw_sha": 48,   # (2 016 -> 336 -> 112; 320 -> 48)
           # the signature kernels (round 6: helpers inlined -- a call passes structs by reference, i.e. through private memory --, the
-          # curve constants as literals, pair inversions without arrays; 1 904 / 976 / 224 / 2 784 / 1 616 / 1 600 / 3 920 / 784 before)
+          # curve constants as literals, pair inversions without arrays, the lane state of the fixed-base kernel in a buffer of the
+          # context; 1 904 / 976 / 224 / 2 784 / 1 616 / 1 600 / 3 920 / 784 before). The split-form kernels are scratch-free at
+          # -DHZ_ED_WAVES_LAT=1 (eddsa_kernels.hip says why that is not the default).
           "hz::k_eddsa_pre": 336, "hz::k_eddsa_pre_a": 304, "hz::k_eddsa_pre_b": 0, "hz::k_eddsa_ladder<1>": 800, "hz::k_eddsa_seg<4>": 0,
-          "hz::k_eddsa_fix<1>": 64, "hz::k_eddsa_fix<8>": 2608, "hz::k_eddsa_final": 0,
+          "hz::k_eddsa_fix<1>": 64, "hz::k_eddsa_fix<8>": 0, "hz::k_eddsa_final": 0,
           "hz::k_dec_main": 240, "hz::poseidon_dag_kernel<6>": 0, "hz::poseidon_dag_kernel<7>": 0,
-          "hz::k_rtx_back": 192, "hz::k_sha_expand": 272, "hz::k_sha_chain": 272, "hz::k_withdraw_sha": 448,
           "hz::poseidon_batch_kernel<3, true>": 0, "hz::poseidon_batch_kernel<5, true>": 0, "hzexp::k_export_stored": 0}
 
 
