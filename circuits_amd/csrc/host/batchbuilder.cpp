@@ -788,14 +788,16 @@ int build_begin(hzb_batch* bb, bool threaded) {
     std::vector<PendingSig>& sigs = run.sigs;
     sigs.clear();
     std::vector<uint8_t> rk, rx, ry;
+    const double t_sig0 = now_s();
+    // (declared before r8_done: the worker below reads and writes these, and r8_done -- destroyed first -- joins it)
+    Dag mdag;
+    int sig_st = HZB_OK;
     struct Joined {   // (a Reject thrown by the walk must not leave the worker writing into vectors that are being unwound)
         std::future<void> f;
         ~Joined() { if (f.valid()) f.wait(); }
         Joined& operator=(std::future<void>&& g) { f = std::move(g); return *this; }
     } r8_done;
-    const double t_sig0 = now_s();
     {
-        Dag mdag;
         mdag.fn = dag.fn;
         mdag.device = dag.device;
         for (size_t i = 0; i < ordered.size() && i < (size_t)nTx; i++) {
@@ -812,27 +814,32 @@ int build_begin(hzb_batch* bb, bool threaded) {
             ps.signer = &db->signer(u_from_bytes(t.c.signer_key));
             sigs.push_back(ps);
         }
-        std::vector<U256> msgs;
-        st = mdag.evaluate(msgs);
-        if (st) return st;
-        dag.total_jobs += mdag.total_jobs; dag.total_segments += mdag.total_segments; dag.device_ms += mdag.device_ms; dag.eval_s += mdag.eval_s;
-        run.msg_jobs = mdag.total_jobs; run.msg_segments = mdag.total_segments; run.msg_device_ms = mdag.device_ms; run.msg_eval_s = mdag.eval_s;
-        // R8 = r * Base8 of every signature at once (hostlib.cpp: the additions on the host's threads, one inversion for all) -- BESIDE the
-        // walk below, which needs none of it: the points go into the packed inputs and into the hm = Poseidon(R8, A, msg) jobs after the
-        // walk (those digests are only read by build_finish, for S)
+        // The walk below needs NONE of this -- not the messages, not the nonces, not R8 (the points go into the packed inputs and into
+        // the hm = Poseidon(R8, A, msg) jobs after the walk; those digests are only read by build_finish, for S): the evaluation of the
+        // messages on the device, the deterministic nonces and R8 = r * Base8 of every signature at once (hostlib.cpp: the additions on
+        // the host's threads, one inversion for all) run on a worker BESIDE the walk. Round 5 had only R8 there and the walk waited 1.9 ms
+        // per batch for the messages' round trip.
         rk.resize(32 * sigs.size()); rx.resize(32 * sigs.size()); ry.resize(32 * sigs.size());
-        for (size_t q = 0; q < sigs.size(); q++) {
-            sigs[q].msg = msgs[q];
-            sigs[q].r = sign_nonce(sigs[q].signer->k, sigs[q].msg);
-            u_to_bytes(sigs[q].r, &rk[32 * q]);
-        }
         if (!sigs.empty()) {
-            const size_t n_sig = sigs.size();
             uint8_t *pk = rk.data(), *px = rx.data(), *py = ry.data();
-            r8_done = std::async(std::launch::async, [n_sig, pk, px, py] { hzb_bjj_mul_base8_many(n_sig, pk, px, py, 0); });
+            std::vector<PendingSig>* psigs = &sigs;
+            Dag* pm = &mdag;
+            int* pst = &sig_st;
+            r8_done = std::async(std::launch::async, [psigs, pm, pst, pk, px, py] {
+                std::vector<U256> msgs;
+                *pst = pm->evaluate(msgs);
+                if (*pst) return;
+                std::vector<PendingSig>& sg = *psigs;
+                for (size_t q = 0; q < sg.size(); q++) {
+                    sg[q].msg = msgs[q];
+                    sg[q].r = sign_nonce(sg[q].signer->k, sg[q].msg);
+                    u_to_bytes(sg[q].r, &pk[32 * q]);
+                }
+                hzb_bjj_mul_base8_many(sg.size(), pk, px, py, 0);
+            });
         }
     }
-    bb->sign_s = now_s() - t_sig0;   // what the walk waits for: messages (one Poseidon(7) each, evaluated) and deterministic nonces; + the wait for R8 below
+    bb->sign_s = now_s() - t_sig0;   // what the walk waits for: naming the message jobs; + the wait for the worker (messages, nonces, R8) below
     std::vector<int> sig_of((size_t)nTx, -1);
     for (size_t q = 0; q < sigs.size(); q++) sig_of[sigs[q].tx] = (int)q;
 
@@ -1082,6 +1089,9 @@ int build_begin(hzb_batch* bb, bool threaded) {
     {
         const double t_r8 = now_s();
         if (r8_done.f.valid()) r8_done.f.get();
+        if (sig_st) return sig_st;
+        dag.total_jobs += mdag.total_jobs; dag.total_segments += mdag.total_segments; dag.device_ms += mdag.device_ms; dag.eval_s += mdag.eval_s;
+        run.msg_jobs = mdag.total_jobs; run.msg_segments = mdag.total_segments; run.msg_device_ms = mdag.device_ms; run.msg_eval_s = mdag.eval_s;
         for (size_t q = 0; q < sigs.size(); q++) {
             PendingSig& ps = sigs[q];
             ps.r8 = Pt{u_from_bytes(&rx[32 * q]), u_from_bytes(&ry[32 * q])};

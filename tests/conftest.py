@@ -37,13 +37,24 @@ def hz():
 @pytest.fixture(scope="session")
 def config4():
     """BASELINE config 4's batch -- RollupMain(2048, 32, 256, 64), the benchmark's own synthetic recipe -- with the oracle's complete
-    witness, computed once for the GPU tests that compare against it (33 s of one core, 3.9 GB)."""
+    witness, computed once for the GPU tests that compare against it (33 s of one core, 3.9 GB); and a SECOND batch on a state of other
+    depth ("batch2" / "input2" / "oracle2": test_headline_launch_whole_buffer), whose oracle runs beside the first one's on another core."""
+    import threading
     from circuits_amd import builder as B
     from oracle_binding import OracleCtx
     shape = (2048, 32, 256, 64)
-    bb = B.synthetic_batch(*shape, n_accounts=2048, exits=32, seed=0x48455A31)
-    inp = bb.get_input()
-    o = OracleCtx("rollup-main", *shape)
-    o.set_inputs(inp)
-    assert o.run() is None
-    return {"shape": shape, "batch": bb, "input": inp, "oracle": o}
+    out = {"shape": shape}
+
+    def one(suffix, n_accounts, exits, seed):
+        bb = B.synthetic_batch(*shape, n_accounts=n_accounts, exits=exits, seed=seed)
+        inp = bb.get_input()
+        o = OracleCtx("rollup-main", *shape)
+        o.set_inputs(inp)
+        out["error" + suffix] = o.run()   # (the library call releases the interpreter lock: the two runs overlap)
+        out["batch" + suffix], out["input" + suffix], out["oracle" + suffix] = bb, inp, o
+    t = threading.Thread(target=one, args=("2", 4096, 7, 0x48455A32))
+    t.start()
+    one("", 2048, 32, 0x48455A31)
+    t.join()
+    assert out["error"] is None and out["error2"] is None
+    return out

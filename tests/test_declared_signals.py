@@ -382,7 +382,7 @@ def test_hip_complete_rollup_main(hz):
     import fuzz_common as FZ
     from circuits_amd import ConstraintError
     stat = {True: 0, False: 0}
-    for case in FZ.rollup_main_cases(160, shape, 4242):
+    for case in FZ.rollup_main_cases(96, shape, 4242):   # (160 until the suite had to fit ten minutes: 0.2 s each)
         g.set_inputs(case)
         try:
             g.run()
@@ -392,7 +392,7 @@ def test_hip_complete_rollup_main(hz):
         n_bad, first = mp.check_r1cs(cap=4)
         assert rejected == (n_bad > 0), (rejected, n_bad, first)
         stat[rejected] += 1
-    assert stat[True] >= 40 and stat[False] >= 10, stat
+    assert stat[True] >= 24 and stat[False] >= 6, stat
 
 
 @pytest.mark.gpu
