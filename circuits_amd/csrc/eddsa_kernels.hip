@@ -826,11 +826,6 @@ __device__ __forceinline__ void ed_prologue_hash(const UnitIO& io, const EddsaOf
     num2bits_strict_dev(io, o.h2bits, out.h_c, C_RTX_SIG_H_ALIAS);
     out.R8.x = R8x; out.R8.y = R8y;
 }
-__device__ HZ_ED_CALL void ed_prologue(const EdK& K, const UnitIO& io, const Scratch& sc, const EddsaOff& o, const Fr* K6, EdSig& out, bool* on_curve) {
-    const Fr enabled = sc.get(SC_ED_ENABLED), signSig = sc.get(SC_ED_SIGN), aySig = sc.get(SC_ED_AYSIG), Ay = sc.get(SC_ED_AY);
-    const Fr x = ed_prologue_point(K, io, o, enabled, signSig, aySig, Ay, out, on_curve);
-    ed_prologue_hash(io, o, K6, sc.get(SC_ED_R8X), sc.get(SC_ED_R8Y), x, Ay, sc.get(SC_SIGL2HASH), out);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // h * 8A = the two SegmentMulAny of circomlib's EscalarMulAny(254): bits 0..147 from 8A, bits 148..253 from 2^148 * 8A. The second
@@ -960,17 +955,31 @@ __global__ __launch_bounds__(HZ_BLOCK) __attribute__((amdgpu_waves_per_eu(HZ_ED_
     const EdK K = ed_k();
     const UnitIO io{a.base, a.n_units, i, i / a.upi, i % a.upi, a.err};
     const Scratch sc{a.scratch, a.n_units, i};
-    EdSig sg;
+    // Three phases that hand over through the inter-kernel scratch instead of through registers (what one phase leaves for the kernels
+    // behind it is stored when it is known, what the next phase needs is loaded where it is used): the point half, the message hash --
+    // only Ax crosses from the first into the second --, the doubling chain from the stored 8A. Held in one EdSig across the width-6
+    // Poseidon, the prologue's outputs were 62 registers of live values and 1.9 KB of private memory (round 5).
     bool on_curve = false;
-    ed_prologue(K, io, sc, a.ed, K6, sg, &on_curve);
-    sc.set(SC_ED_H, fr_from_canon(sg.h_c)); sc.set(SC_ED_ZP, sg.zp);
-    sc.set(SC_ED_P0X, sg.p0.x); sc.set(SC_ED_P0Y, sg.p0.y);
+    Fr x;
+    {
+        EdSig sg;
+        x = ed_prologue_point(K, io, a.ed, sc.get(SC_ED_ENABLED), sc.get(SC_ED_SIGN), sc.get(SC_ED_AYSIG), sc.get(SC_ED_AY), sg, &on_curve);
+        sc.set(SC_ED_ZP, sg.zp);
+        sc.set(SC_ED_P0X, sg.p0.x); sc.set(SC_ED_P0Y, sg.p0.y);
+    }
+    {
+        EdSig sg;
+        ed_prologue_hash(io, a.ed, K6, sc.get(SC_ED_R8X), sc.get(SC_ED_R8Y), x, sc.get(SC_ED_AY), sc.get(SC_SIGL2HASH), sg);
+        sc.set(SC_ED_H, fr_from_canon(sg.h_c));
+    }
     if (a.chain_in_ladder) {   // small launches: the second segment's lane walks the doubling chain itself (k_eddsa_ladder)
         sc.set(SC_ED_DBLX, on_curve ? K.one : fr_zero());
         return;
     }
     // 8A of an on-curve A is on the curve; when it is the identity the circuit substitutes Base8 (zp = 1): regular either way
-    const PtA d147 = ed_dbl_chain(K, sg.p0, 147, on_curve);
+    PtA p0;
+    p0.x = sc.get(SC_ED_P0X); p0.y = sc.get(SC_ED_P0Y);
+    const PtA d147 = ed_dbl_chain(K, p0, 147, on_curve);
     sc.set(SC_ED_DBLX, d147.x); sc.set(SC_ED_DBLY, d147.y);
 }
 

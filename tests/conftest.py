@@ -45,16 +45,20 @@ def config4():
     shape = (2048, 32, 256, 64)
     out = {"shape": shape}
 
-    def one(suffix, n_accounts, exits, seed):
+    # the batches one after the other (the Python builder shares its hashing state between instances: not for two threads), the two oracle
+    # runs beside each other (the library call releases the interpreter lock; the oracle keeps no state between contexts)
+    for suffix, n_accounts, exits, seed in (("", 2048, 32, 0x48455A31), ("2", 4096, 7, 0x48455A32)):
         bb = B.synthetic_batch(*shape, n_accounts=n_accounts, exits=exits, seed=seed)
         inp = bb.get_input()
         o = OracleCtx("rollup-main", *shape)
         o.set_inputs(inp)
-        out["error" + suffix] = o.run()   # (the library call releases the interpreter lock: the two runs overlap)
         out["batch" + suffix], out["input" + suffix], out["oracle" + suffix] = bb, inp, o
-    t = threading.Thread(target=one, args=("2", 4096, 7, 0x48455A32))
+
+    def run(suffix):
+        out["error" + suffix] = out["oracle" + suffix].run()
+    t = threading.Thread(target=run, args=("2",))
     t.start()
-    one("", 2048, 32, 0x48455A31)
+    run("")
     t.join()
     assert out["error"] is None and out["error2"] is None
     return out

@@ -25,7 +25,7 @@ BUDGET = {"hz::k_smt<false>": 0, "hz::k_smt<true>": 0, "hz::k_hash4": 0, "hz::k_
           # curve constants as literals, pair inversions without arrays, the lane state of the fixed-base kernel in a buffer of the
           # context; 1 904 / 976 / 224 / 2 784 / 1 616 / 1 600 / 3 920 / 784 before). The split-form kernels are scratch-free at
           # -DHZ_ED_WAVES_LAT=1 (eddsa_kernels.hip says why that is not the default).
-          "hz::k_eddsa_pre": 336, "hz::k_eddsa_pre_a": 304, "hz::k_eddsa_pre_b": 0, "hz::k_eddsa_ladder<1>": 800, "hz::k_eddsa_seg<4>": 0,
+          "hz::k_eddsa_pre": 256, "hz::k_eddsa_pre_a": 304, "hz::k_eddsa_pre_b": 0, "hz::k_eddsa_ladder<1>": 800, "hz::k_eddsa_seg<4>": 0,
           "hz::k_eddsa_fix<1>": 64, "hz::k_eddsa_fix<8>": 0, "hz::k_eddsa_final": 0,
           "hz::k_dec_main": 240, "hz::poseidon_dag_kernel<6>": 0, "hz::poseidon_dag_kernel<7>": 0,
           "hz::poseidon_batch_kernel<3, true>": 0, "hz::poseidon_batch_kernel<5, true>": 0, "hzexp::k_export_stored": 0}
