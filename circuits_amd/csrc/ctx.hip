@@ -83,6 +83,7 @@ struct hz_ctx {
     DevBuf smt_trace;              // experiments: HZ_SMT_TRACE=<file> -- per-wavefront start / end / placement of the transaction k_smt launch
     DevBuf pos3;                   // poseidon_quad.h's constants (C, M R, M R^2): the latency form of k_smt
     bool smt_lat = false;          // this context's chain launches take the latency form (hz_ctx_create)
+    bool smt_lat_few = false;      // ... while at most two partitioned contexts are alive on the device (HZ_FLAG_LATENCY, one batch)
     hipEvent_t ev_hash4 = nullptr, ev_tail = nullptr, ev_sighash = nullptr;
     void release_masked();
     ~hz_ctx() {
@@ -261,7 +262,12 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         // doubling chain left the signature prologue the state-tree chain is the longer one of a single batch (9.6 against 8.2 ms)
         const bool chain_is_step = lo.p.tmpl == T_SMT_PROCESSOR || lo.p.tmpl == T_FEE_TX || (p->flags & HZ_FLAG_SOLO) != 0;
         c->smt_lat = step_units <= HZ_SMT_LAT_MAX && (force ? force[0] == '1' : chain_is_step);
-        if (e == hipSuccess && c->smt_lat) e = c->pos3.alloc(pos3_dense_bytes());
+        // ... and HZ_FLAG_LATENCY contexts of one batch WHILE AT MOST TWO of them are alive on the device (decided per launch,
+        // enqueue_smt_chain): one alone 8.7 -> 7.7 ms, two in flight 427-436 k -> 448 k tx/s, four in flight 640 k -> 540 k
+        // (profiles/r06_flagged_latency_form.txt) -- the form's 512 wavefronts at one per SIMD fill the main stream's partition once,
+        // two contexts' launches rarely coincide, four contexts' do.
+        c->smt_lat_few = !c->smt_lat && !force && step_units <= HZ_SMT_LAT_MAX && lo.p.tmpl == T_ROLLUP_MAIN && (p->flags & HZ_FLAG_LATENCY) != 0;
+        if (e == hipSuccess && (c->smt_lat || c->smt_lat_few)) e = c->pos3.alloc(pos3_dense_bytes());
         if (e == hipSuccess && c->pos3.p) e = upload_pos3_dense((Fr*)c->pos3.p);
     }
     if (e == hipSuccess) e = c->inst_min.alloc((size_t)lo.n_inst * sizeof(unsigned long long));
@@ -752,7 +758,13 @@ static Hash4Args make_hash4_rtx(uint8_t* base, Fr* sc, uint32_t n_units, const R
 // the SMT chain kernel: one launch, one profile entry
 static hipError_t enqueue_smt_chain(hz_ctx* c, const SmtArgs& sa0, const char* name, hipStream_t s) {
     SmtArgs sa = sa0;
-    sa.pos3_dense = c->smt_lat ? (const Fr*)c->pos3.p : nullptr;
+    bool lat = c->smt_lat;
+    if (!lat && c->smt_lat_few && c->partitioned && c->device >= 0 && c->device < 16) {
+        MaskedPool& P = masked_pool();
+        std::lock_guard<std::mutex> g(P.mu);
+        lat = P.alive[c->device] <= 2;
+    }
+    sa.pos3_dense = lat ? (const Fr*)c->pos3.p : nullptr;
     const bool fee = sa.scratch == (Fr*)c->sc_fee.p;
     sa.zmark = (uint16_t*)(fee ? c->zm_fee.p : c->zm_tx.p);
     sa.skipped = (c->profiling && c->zm_skip.p) ? (unsigned long long*)c->zm_skip.p + (fee ? 1 : 0) : nullptr;

@@ -94,8 +94,10 @@ typedef struct {
 } hz_params;
 /* HZ_FLAG_LATENCY: a RollupMain context of one to four batches puts its concurrent kernel chains -- front/hash/SMT/HashInputs, the
  * two signature kernels, the fee chain -- on disjoint sets of compute units through CU-masked streams: one 2048-transaction batch
- * alone 14.6 -> 9.4 ms (7.9 with HZ_FLAG_SOLO). Up to four such contexts in flight overlap (every context uses the same four masks): one batch each, 380 k
- * tx-witnesses/s with two, 560 k with four; plain contexts do not overlap in that regime (257 k). From eight batches per launch on,
+ * alone 14.4 -> 7.7 ms (7.3 with HZ_FLAG_SOLO). Up to four such contexts in flight overlap (every context uses the same four masks): one batch each, 450 k
+ * tx-witnesses/s with two, 640 k with four; plain contexts do not overlap in that regime (250 k). While at most TWO such contexts of one
+ * batch are alive on the device their SMT chain kernel takes the latency form HZ_FLAG_SOLO describes (decided per launch; with four
+ * in flight it would cost 15 %: profiles/r06_flagged_latency_form.txt). From eight batches per launch on,
  * the default (0 or HZ_FLAG_THROUGHPUT: any kernel on any CU) is faster. Every such context holds four hardware queues whose scratch
  * memory the runtime sizes by their hungriest kernel: within one process FOUR contexts per device get the partition by default
  * (HZ_MAX_PARTITIONED=<n> in the environment changes it; two until round 6, when a front kernel with 7.7 KB of scratch per lane made
@@ -106,7 +108,8 @@ typedef struct {
 /* HZ_FLAG_SOLO (with HZ_FLAG_LATENCY, contexts of ONE batch: no effect on larger ones): nothing else runs on the device while this context's step
  * does -- no second context in flight. Its SMT chain kernel then takes the latency form (a quad of lanes per chain, the level hash
  * spread over the quad: 0.67 x the chain's time for 2.5 x its instructions and a whole CU partition's wavefront slots -- which is why
- * it is wrong beside other contexts: one batch x 4 contexts 432 k tx/s with it, 560 k without). */
+ * it is wrong beside MANY other contexts: one batch x 4 contexts 540 k tx/s with it, 640 k without; a HZ_FLAG_LATENCY context takes it by
+ * itself while at most two are alive; HZ_FLAG_SOLO keeps it whatever else exists). */
 #define HZ_FLAG_SOLO 4
 
 typedef struct {
