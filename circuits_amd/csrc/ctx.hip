@@ -266,7 +266,8 @@ extern "C" hz_status hz_ctx_create(const hz_params* p, hz_ctx** out) {
         // enqueue_smt_chain): one alone 8.7 -> 7.7 ms, two in flight 427-436 k -> 448 k tx/s, four in flight 640 k -> 540 k
         // (profiles/r06_flagged_latency_form.txt) -- the form's 512 wavefronts at one per SIMD fill the main stream's partition once,
         // two contexts' launches rarely coincide, four contexts' do.
-        c->smt_lat_few = !c->smt_lat && !force && step_units <= HZ_SMT_LAT_MAX && lo.p.tmpl == T_ROLLUP_MAIN && (p->flags & HZ_FLAG_LATENCY) != 0;
+        c->smt_lat_few = !c->smt_lat && !force && step_units <= HZ_SMT_LAT_MAX && lo.p.tmpl == T_ROLLUP_MAIN &&
+                         ((p->flags & HZ_FLAG_LATENCY) != 0 || getenv("HZ_FORCE_LATENCY_SCHEDULING") != nullptr);   // (the same condition as `want` below)
         if (e == hipSuccess && (c->smt_lat || c->smt_lat_few)) e = c->pos3.alloc(pos3_dense_bytes());
         if (e == hipSuccess && c->pos3.p) e = upload_pos3_dense((Fr*)c->pos3.p);
     }
