@@ -1357,6 +1357,7 @@ hipError_t launch_eddsa_fix(const EddsaArgs& a, hipStream_t s) {
     // Eight signatures per lane: 85 windows x (8 turns + one shared inversion) is still a shorter chain than the variable-base ladder
     // beside it (11.0 ms alone against 17.4), and an eighth of an inversion per window instead of a quarter is 0.2 G fewer
     // wave-instructions per 65 536 signatures (four per lane: 7.5 ms alone, step +0.3..0.6 ms; profiles/r03_eddsa_seg_ab.txt).
+    if (!a.side) return hipErrorInvalidValue;   // the lane state lives in the context's side buffer (eddsa_side_bytes)
     return launch_eddsa_fix_g<HZ_ED_FIX_G>(a, n, s);
 }
 hipError_t launch_eddsa_final(const EddsaArgs& a, hipStream_t s) {
