@@ -162,3 +162,25 @@ def test_smt_processor_main_shuffled_garbage(hz, n):
             pass
         parts = FZ.run_oracle_threads("smt-processor", (0, 33, 0, 0), cur)
         FZ.compare_instanced(g, parts, n)
+
+
+def test_flagged_context_switches_the_chain_kernel_form_with_the_marks_in_place(hz, batches):
+    """A HZ_FLAG_LATENCY context of one batch takes k_smt's latency form while at most two such contexts are alive on the device and the plain
+    form otherwise (csrc/ctx.hip enqueue_smt_chain: decided per launch). The marks are per unit and chain, a wavefront of the latency form
+    holds 16 units and one of the plain form 64: steps of ONE context under alternating forms -- neighbours created and destroyed in between
+    -- must leave the whole buffer equal to the oracle's after every step (states of different depth: the marks move both ways)."""
+    mk = lambda: hz.ctx("rollup-main", nTx=SHAPE[0], nLevels=SHAPE[1], maxL1Tx=SHAPE[2], maxFeeTx=SHAPE[3], flags=2)   # noqa: E731
+    g = mk()
+    others = []
+    for step, (k, n_others) in enumerate(((0, 0), (1, 2), (0, 0), (2, 3), (1, 1), (0, 2), (0, 0))):
+        while len(others) > n_others:
+            others.pop().close()
+        while len(others) < n_others:
+            others.append(mk())
+        inp, o, h = batches[k]
+        g.set_inputs(inp)
+        g.run()
+        assert g.get("main.hashGlobalInputs") == h
+        _same(g, o, "step %d (batch %d, %d other flagged contexts alive)" % (step, k, n_others))
+    for c in others:
+        c.close()
